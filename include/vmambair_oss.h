@@ -1,0 +1,117 @@
+/*
+ * vmambair_oss.h -- C ABI of the MI355X (gfx950) Omni-Selective-Scan core.
+ *
+ * This is the drop-in boundary for the one native module the reference's archs import:
+ *     import selective_scan_cuda_core          (reference: SRGAN/VmambaIR/archs/MambaSISR6_arch.py:22,
+ *                                               Deraining/basicsr/models/archs/mamber32_arch.py:18,
+ *                                               RealSR/VmambaIR/archs/MambaRealSR11_arch.py:24,32)
+ * whose two entry points are pybind11 functions
+ *     fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows) -> [out, x]
+ *     bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows)
+ *            -> [du, ddelta, dA, dB, dC, dD, ddelta_bias]
+ * (reference: Mamba/kernels/selective_scan/csrc/selective_scan/cus/selective_scan.cpp:157-164,
+ *  241-250,351-354).  Behind those, the reference fills a parameter struct of sizes, element
+ * strides and raw pointers (selective_scan.h:26-90, SSMParamsBase / SSMParamsBwd) and launches
+ * one kernel per I/O dtype on a caller-supplied stream
+ * (cus/selective_scan_core_fwd.cu:6-8, cus/selective_scan_core_bwd.cu:6-8).
+ *
+ * The functions below are what a binding for that module links against: plain pointers, sizes,
+ * element strides and a HIP stream -- no torch types.  The binding layer (ours:
+ * vmambair_amd/_capi.py + selective_scan_cuda_core.py; a maintainer's: INTEGRATION.md) does the
+ * shape/dtype checks and allocates outputs exactly as cus/selective_scan.cpp:165-220,256-327.
+ *
+ * All device pointers must live on the device that is current when the call is made.  Calls are
+ * asynchronous on `stream`, never synchronise the host, and are re-entrant.
+ * Return value: 0 on success, a negative OSS_ERR_* for a rejected argument, or a positive
+ * hipError_t if the launch failed.
+ */
+#ifndef VMAMBAIR_OSS_H
+#define VMAMBAIR_OSS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSS_OK 0
+#define OSS_ERR_NULL (-1)        /* a required pointer is NULL                               */
+#define OSS_ERR_SHAPE (-2)       /* batch/dim/seqlen/dstate/n_groups invalid (dim % groups)   */
+#define OSS_ERR_DSTATE (-3)      /* dstate > OSS_MAX_DSTATE (reference: selective_scan.cpp:191) */
+#define OSS_ERR_WORKSPACE (-4)   /* workspace missing or too small                           */
+
+#define OSS_MAX_DSTATE 256
+
+/* I/O element type of u, delta, B, C, out, dout, du, ddelta (the reference's input_t);
+ * A, D, delta_bias, x and every weight gradient are always float (weight_t). */
+typedef enum { OSS_F32 = 0, OSS_F16 = 1, OSS_BF16 = 2 } oss_dtype;
+
+/* Opaque stream handle: a hipStream_t (NULL = the default stream). */
+typedef void *oss_stream_t;
+
+/* Mirrors SSMParamsBase (selective_scan.h:26-66).  Strides are in ELEMENTS; the last (time)
+ * dimension of u, delta, B, C, out must be contiguous (selective_scan.cpp:183-199). */
+typedef struct {
+    int batch, dim, seqlen, dstate, n_groups;
+    int delta_softplus;
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    int64_t A_d_stride;                                  /* A is (dim, dstate), dstate stride 1 */
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
+    const void *u, *delta;  /* (batch, dim, seqlen) io dtype                                   */
+    const float *A;         /* (dim, dstate)                                                   */
+    const void *B, *C;      /* (batch, n_groups, dstate, seqlen) io dtype                      */
+    const float *D;         /* (dim) or NULL                                                   */
+    const float *delta_bias;/* (dim) or NULL                                                   */
+    void *out;              /* (batch, dim, seqlen) io dtype                                   */
+    float *x;               /* (batch, dim, oss_scan_num_chunks(seqlen), 2*dstate) contiguous  */
+} oss_scan_fwd_params;
+
+/* Mirrors SSMParamsBwd (selective_scan.h:68-90). */
+typedef struct {
+    oss_scan_fwd_params f;  /* f.out unused; f.x = the tensor fwd returned (required when
+                               oss_scan_num_chunks(seqlen) > 1, selective_scan.cpp:310)          */
+    int64_t dout_batch_stride, dout_d_stride;
+    int64_t du_batch_stride, du_d_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride;
+    const void *dout;       /* (batch, dim, seqlen) io dtype                                   */
+    void *du, *ddelta;      /* (batch, dim, seqlen) io dtype                                   */
+    float *dA;              /* (dim, dstate) contiguous, overwritten                           */
+    void *dB, *dC;          /* (batch, n_groups, dstate, seqlen) CONTIGUOUS, io dtype,
+                               overwritten (the cast of selective_scan.cpp:347 is fused)        */
+    float *dD;              /* (dim) or NULL, overwritten                                      */
+    float *ddelta_bias;     /* (dim) or NULL, overwritten                                      */
+    void *workspace;        /* oss_scan_bwd_workspace_bytes() bytes of scratch, no init needed */
+    size_t workspace_bytes;
+} oss_scan_bwd_params;
+
+/* Time steps between two saved states in `x` (the reference's is 2048,
+ * selective_scan.cpp:217; `x` is opaque to every caller, only our bwd reads it). */
+int oss_scan_chunk(void);
+int oss_scan_num_chunks(int seqlen);
+
+/* Replaces selective_scan_fwd_cuda<1, input_t, float> (cus/selective_scan_fwd_kernel.cuh:174-207). */
+int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream);
+
+/* Replaces selective_scan_bwd_cuda<1, input_t, float> (cus/selective_scan_bwd_kernel.cuh:275-310)
+ * plus the zero-fills and casts around it (cus/selective_scan.cpp:319-327,347). */
+size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups);
+int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream);
+
+/* Kernel-variant override for tuning / A-B benches: -1 = heuristic (default). */
+void oss_scan_set_variant(int fwd_variant, int bwd_variant);
+int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
+
+/* HBM copy-kernel (float4 read+write) used by bench.py to measure the achievable bandwidth in
+ * the same run as the scan kernels; copies n_bytes (multiple of 16) from src to dst. */
+int oss_hbm_copy(const void *src, void *dst, size_t n_bytes, oss_stream_t stream);
+
+const char *oss_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMAMBAIR_OSS_H */

@@ -1,0 +1,88 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/vmambair_oss.h declares,
+and the ctypes structures have the layout the header gives them.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+import vmambair_amd
+from vmambair_amd import _build, _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vmambair_oss.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(oss_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_is_built_and_loads():
+    assert os.path.exists(_build.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _capi.load()
+    assert lib.oss_version().startswith(b"vmambair_oss")
+    assert lib.oss_scan_chunk() == 256
+    assert lib.oss_scan_num_chunks(1) == 1 and lib.oss_scan_num_chunks(256) == 1
+    assert lib.oss_scan_num_chunks(257) == 2 and lib.oss_scan_num_chunks(4096) == 16
+
+
+def test_every_declared_symbol_is_exported():
+    declared = _declared_functions()
+    assert declared == sorted(_capi.SYMBOLS)
+    lib = ctypes.CDLL(_build.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_struct_layout_matches_header():
+    """Compile a tiny C probe against the header and compare sizeof/offsetof with ctypes."""
+    probe = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "vmambair_oss.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(oss_scan_fwd_params), offsetof(oss_scan_fwd_params, u_batch_stride),
+         offsetof(oss_scan_fwd_params, u), offsetof(oss_scan_fwd_params, x), sizeof(oss_scan_bwd_params),
+         offsetof(oss_scan_bwd_params, dout_batch_stride), offsetof(oss_scan_bwd_params, dout),
+         offsetof(oss_scan_bwd_params, workspace_bytes));
+  return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "probe.c")
+        open(c, "w").write(probe)
+        exe = os.path.join(td, "probe")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    F, B = _capi.ScanFwdParams, _capi.ScanBwdParams
+    want = [ctypes.sizeof(F), F.u_batch_stride.offset, F.u.offset, F.x.offset, ctypes.sizeof(B),
+            B.dout_batch_stride.offset, B.dout.offset, B.workspace_bytes.offset]
+    assert got == want
+
+
+def test_workspace_query_is_pure():
+    lib = _capi.load()
+    n = lib.oss_scan_bwd_workspace_bytes(2, 8, 100, 16, 4)
+    tiles = (2 + 3) // 4  # 2 rows per group, 4 rows per workgroup in the smallest variant
+    assert n == 4 * (2 * 4 * tiles * 2 * 16 * 100 + 2 * 8 * 18)
+    assert lib.oss_scan_bwd_workspace_bytes(2, 7, 100, 16, 4) == 0  # dim % n_groups != 0
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    """The product has no CPU path: the op only has a GPU kernel (cf. TORCH_CHECK(u.is_cuda()),
+    cus/selective_scan.cpp:174)."""
+    u = torch.zeros(1, 4, 8)
+    with pytest.raises(RuntimeError, match="CUDA/HIP tensor"):
+        vmambair_amd.selective_scan_fwd(u, u, torch.zeros(4, 2), torch.zeros(1, 1, 2, 8), torch.zeros(1, 1, 2, 8),
+                                        None, None, True, 1)
+    with pytest.raises(RuntimeError):
+        vmambair_amd.selective_scan_fwd(u.double(), u.double(), torch.zeros(4, 2), torch.zeros(1, 1, 2, 8),
+                                        torch.zeros(1, 1, 2, 8), None, None, True, 1)
+
+
+def test_drop_in_module_surface():
+    import selective_scan_cuda_core as m
+    assert callable(m.fwd) and callable(m.bwd)

@@ -1,0 +1,97 @@
+"""ctypes binding of include/vmambair_oss.h (the C ABI of the HIP library).
+
+The structures mirror ``oss_scan_fwd_params`` / ``oss_scan_bwd_params`` field for field.  The
+library is loaded on first use; a missing library is a hard error (no fallback path exists).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+OSS_F32, OSS_F16, OSS_BF16 = 0, 1, 2
+
+ERRORS = {
+    -1: "OSS_ERR_NULL: a required pointer is NULL",
+    -2: "OSS_ERR_SHAPE: invalid batch/dim/seqlen/dstate/n_groups",
+    -3: "OSS_ERR_DSTATE: selective_scan only supports state dimension <= 256",
+    -4: "OSS_ERR_WORKSPACE: workspace missing or too small",
+}
+
+
+class ScanFwdParams(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int), ("dim", C.c_int), ("seqlen", C.c_int), ("dstate", C.c_int), ("n_groups", C.c_int),
+        ("delta_softplus", C.c_int),
+        ("u_batch_stride", C.c_int64), ("u_d_stride", C.c_int64),
+        ("delta_batch_stride", C.c_int64), ("delta_d_stride", C.c_int64),
+        ("out_batch_stride", C.c_int64), ("out_d_stride", C.c_int64),
+        ("A_d_stride", C.c_int64),
+        ("B_batch_stride", C.c_int64), ("B_group_stride", C.c_int64), ("B_dstate_stride", C.c_int64),
+        ("C_batch_stride", C.c_int64), ("C_group_stride", C.c_int64), ("C_dstate_stride", C.c_int64),
+        ("u", C.c_void_p), ("delta", C.c_void_p), ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("D", C.c_void_p), ("delta_bias", C.c_void_p), ("out", C.c_void_p), ("x", C.c_void_p),
+    ]
+
+
+class ScanBwdParams(C.Structure):
+    _fields_ = [
+        ("f", ScanFwdParams),
+        ("dout_batch_stride", C.c_int64), ("dout_d_stride", C.c_int64),
+        ("du_batch_stride", C.c_int64), ("du_d_stride", C.c_int64),
+        ("ddelta_batch_stride", C.c_int64), ("ddelta_d_stride", C.c_int64),
+        ("dout", C.c_void_p), ("du", C.c_void_p), ("ddelta", C.c_void_p), ("dA", C.c_void_p),
+        ("dB", C.c_void_p), ("dC", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+#: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bwd_workspace_bytes",
+           "oss_scan_bwd", "oss_scan_set_variant", "oss_scan_last_variant", "oss_hbm_copy", "oss_version"]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """dlopen the in-tree library; raise loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = C.CDLL(path)
+    lib.oss_scan_chunk.restype = C.c_int
+    lib.oss_scan_num_chunks.restype = C.c_int
+    lib.oss_scan_num_chunks.argtypes = [C.c_int]
+    lib.oss_scan_fwd.restype = C.c_int
+    lib.oss_scan_fwd.argtypes = [C.POINTER(ScanFwdParams), C.c_int, C.c_void_p]
+    lib.oss_scan_bwd_workspace_bytes.restype = C.c_size_t
+    lib.oss_scan_bwd_workspace_bytes.argtypes = [C.c_int] * 5
+    lib.oss_scan_bwd.restype = C.c_int
+    lib.oss_scan_bwd.argtypes = [C.POINTER(ScanBwdParams), C.c_int, C.c_void_p]
+    lib.oss_scan_set_variant.restype = None
+    lib.oss_scan_set_variant.argtypes = [C.c_int, C.c_int]
+    lib.oss_scan_last_variant.restype = C.c_int
+    lib.oss_scan_last_variant.argtypes = [C.c_int]
+    lib.oss_hbm_copy.restype = C.c_int
+    lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.oss_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {ERRORS.get(rc, rc)}")
+    raise RuntimeError(f"{what}: HIP error {rc}")

@@ -1,0 +1,150 @@
+"""UNets that stack the OSS block -- host-side mirror of the reference's registered archs, needed
+here only because the headline metric (images/s of a ×4 SR training step) is quoted on the whole
+net.  Module / parameter names equal the reference's so its checkpoints load unchanged.
+
+Reference: ``MambaSISR6`` SRGAN/VmambaIR/archs/MambaSISR6_arch.py:520-643 (+ ``Upsampler`` /
+``default_conv`` of archs/common.py:8-9,45-60), ``Mamber32`` Deraining/basicsr/models/archs/
+mamber32_arch.py:519-649, ``MambaRealSR11`` RealSR/VmambaIR/archs/MambaRealSR11_arch.py:878-975.
+All three are the same Restormer-shaped 4-level encoder/decoder; they differ in the OSS block
+variant and in the tail.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .oss_block import MamberBlock
+
+
+def _conv3(cin: int, cout: int, bias: bool) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
+
+
+class OverlapPatchEmbed(nn.Module):
+    def __init__(self, in_c: int = 3, embed_dim: int = 48, bias: bool = False):
+        super().__init__()
+        self.proj = _conv3(in_c, embed_dim, bias)
+
+    def forward(self, x):
+        return self.proj(x)
+
+
+class Downsample(nn.Module):
+    def __init__(self, n_feat: int):
+        super().__init__()
+        self.body = nn.Sequential(_conv3(n_feat, n_feat // 2, False), nn.PixelUnshuffle(2))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, n_feat: int):
+        super().__init__()
+        self.body = nn.Sequential(_conv3(n_feat, n_feat * 2, False), nn.PixelShuffle(2))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _x4_tail(n_feat: int, out_channels: int) -> nn.Sequential:
+    """conv(n -> 4n) + PixelShuffle(2), twice, then conv(n -> out), all 3x3 with bias
+    (archs/common.py:45-60; MambaSISR6_arch.py:598-602)."""
+    up = nn.Sequential(_conv3(n_feat, 4 * n_feat, True), nn.PixelShuffle(2),
+                       _conv3(n_feat, 4 * n_feat, True), nn.PixelShuffle(2))
+    return nn.Sequential(up, _conv3(n_feat, out_channels, True))
+
+
+class _OSSUNet(nn.Module):
+    variant = "srgan"
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=(6, 2, 2, 1), num_refinement_blocks=6,
+                 heads=(1, 2, 4, 8), ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias"):
+        super().__init__()
+
+        def stage(width, count, head):
+            return nn.Sequential(*[MamberBlock(dim=width, num_heads=head, ffn_expansion_factor=ffn_expansion_factor,
+                                               bias=bias, LayerNorm_type=LayerNorm_type, variant=self.variant)
+                                   for _ in range(count)])
+
+        d1, d2, d3, d4 = dim, dim * 2, dim * 4, dim * 8
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+        self.encoder_level1 = stage(d1, num_blocks[0], heads[0])
+        self.down1_2 = Downsample(d1)
+        self.encoder_level2 = stage(d2, num_blocks[1], heads[1])
+        self.down2_3 = Downsample(d2)
+        self.encoder_level3 = stage(d3, num_blocks[2], heads[2])
+        self.down3_4 = Downsample(d3)
+        self.latent = stage(d4, num_blocks[3], heads[3])
+        self.up4_3 = Upsample(d4)
+        self.reduce_chan_level3 = nn.Conv2d(d4, d3, kernel_size=1, bias=bias)
+        self.decoder_level3 = stage(d3, num_blocks[2], heads[2])
+        self.up3_2 = Upsample(d3)
+        self.reduce_chan_level2 = nn.Conv2d(d3, d2, kernel_size=1, bias=bias)
+        self.decoder_level2 = stage(d2, num_blocks[1], heads[1])
+        self.up2_1 = Upsample(d2)  # level 1 of the decoder keeps 2*dim channels (no 1x1 reduce)
+        self.decoder_level1 = stage(d2, num_blocks[0], heads[0])
+        self.refinement = stage(d2, num_refinement_blocks, heads[0])
+
+    def body(self, inp_img: torch.Tensor) -> torch.Tensor:
+        e1 = self.encoder_level1(self.patch_embed(inp_img))
+        e2 = self.encoder_level2(self.down1_2(e1))
+        e3 = self.encoder_level3(self.down2_3(e2))
+        lat = self.latent(self.down3_4(e3))
+        d3 = self.decoder_level3(self.reduce_chan_level3(torch.cat([self.up4_3(lat), e3], 1)))
+        d2 = self.decoder_level2(self.reduce_chan_level2(torch.cat([self.up3_2(d3), e2], 1)))
+        d1 = self.decoder_level1(torch.cat([self.up2_1(d2), e1], 1))
+        return self.refinement(d1)
+
+
+class MambaSISR6(_OSSUNet):
+    """×scale SR net of the SRGAN tree (YAML ``network_g.type: MambaSISR6``,
+    SRGAN/options/MambaSISR15_x4.yml:55-65)."""
+    variant = "srgan"
+
+    def __init__(self, inp_channels=3, out_channels=3, scale=4, dim=48, num_blocks=(6, 2, 2, 1),
+                 num_refinement_blocks=6, heads=(1, 2, 4, 8), ffn_expansion_factor=2.66, bias=False,
+                 LayerNorm_type="WithBias"):
+        super().__init__(inp_channels, out_channels, dim, num_blocks, num_refinement_blocks, heads,
+                         ffn_expansion_factor, bias, LayerNorm_type)
+        self.scale = scale
+        self.tail = _x4_tail(dim * 2, out_channels)
+
+    def forward(self, inp_img):
+        return self.tail(self.body(inp_img)) + F.interpolate(inp_img, scale_factor=self.scale, mode="nearest")
+
+
+class MambaRealSR11(MambaSISR6):
+    """Real-world SR net (RealSR tree): same wiring, RealSR channel-scan variant."""
+    variant = "realsr"
+
+
+class Mamber32(_OSSUNet):
+    """Deraining net: 3x3 output conv + global residual (mamber32_arch.py:608,647)."""
+    variant = "mamber32"
+
+    def __init__(self, inp_channels=3, out_channels=3, dim=48, num_blocks=(4, 6, 6, 8), num_refinement_blocks=2,
+                 heads=(1, 2, 4, 8), ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias",
+                 dual_pixel_task=False):
+        super().__init__(inp_channels, out_channels, dim, num_blocks, num_refinement_blocks, heads,
+                         ffn_expansion_factor, bias, LayerNorm_type)
+        assert not dual_pixel_task, "dual-pixel defocus deblurring is not a config of the reference's options"
+        self.output = _conv3(dim * 2, out_channels, bias)
+
+    def forward(self, inp_img):
+        return self.output(self.body(inp_img)) + inp_img
+
+
+class Mamber33(Mamber32):
+    variant = "mamber33"
+
+
+ARCHS = {"MambaSISR6": MambaSISR6, "MambaRealSR11": MambaRealSR11, "Mamber32": Mamber32, "Mamber33": Mamber33}
+
+
+def build_network(opt: dict) -> nn.Module:
+    """``network_g`` dict of a reference YAML (``type`` + kwargs) -> module, the way the
+    reference's ARCH_REGISTRY resolves it (Deraining/basicsr/models/archs/__init__.py:6-46)."""
+    opt = dict(opt)
+    return ARCHS[opt.pop("type")](**opt)

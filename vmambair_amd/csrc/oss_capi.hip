@@ -1,0 +1,129 @@
+// oss_capi.hip -- the extern "C" surface declared in include/vmambair_oss.h.
+#include <atomic>
+#include "oss_device.h"
+#include "oss_host.h"
+
+namespace oss {
+
+static std::atomic<int> g_force_fwd{-1}, g_force_bwd{-1};
+static std::atomic<int> g_last_fwd{-1}, g_last_bwd{-1};
+
+// ---- variant heuristics -----------------------------------------------------------------------
+// The forward/backward kernels are VALU-bound, so the cheapest variant in instructions per
+// (element, state) wins as long as the launch still fills 256 CUs x 4 SIMDs with >= 2 waves.
+int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes) {
+    (void)dstate; (void)elem_bytes;
+    const int rows_per_group = dim / n_groups;
+    const long rows = (long)batch * dim;
+    if (seqlen <= 256 || rows_per_group < 8) return (rows_per_group >= 16 && rows >= 4096) ? 2 : 4;
+    // 16 lanes per row (4 rows per wave): fewest scan steps, but only rows/4 waves
+    if (rows_per_group % 16 == 0 && rows / 4 >= 2048) return 2;
+    if (rows_per_group % 16 == 0 && rows / 2 >= 2048) return 1;
+    return 0;
+}
+
+int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups) {
+    (void)dstate;
+    const int rows_per_group = dim / n_groups;
+    const long rows = (long)batch * dim;
+    if (seqlen <= 256 || rows_per_group < 8) return 3;
+    if (rows_per_group % 16 == 0 && rows >= 8192) return 1;
+    return 0;
+}
+
+static int check_fwd(const oss_scan_fwd_params *p) {
+    if (!p || !p->u || !p->delta || !p->A || !p->B || !p->C) return OSS_ERR_NULL;
+    if (p->batch < 0 || p->dim <= 0 || p->seqlen < 0 || p->dstate <= 0 || p->n_groups <= 0) return OSS_ERR_SHAPE;
+    if (p->dim % p->n_groups != 0) return OSS_ERR_SHAPE;  // selective_scan.cpp:190
+    if (p->dstate > OSS_MAX_DSTATE) return OSS_ERR_DSTATE;  // selective_scan.cpp:191
+    return OSS_OK;
+}
+
+}  // namespace oss
+
+using namespace oss;
+
+extern "C" {
+
+int oss_scan_chunk(void) { return kScanChunk; }
+int oss_scan_num_chunks(int seqlen) { return seqlen <= 0 ? 0 : (seqlen + kScanChunk - 1) / kScanChunk; }
+
+int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream) {
+    int rc = check_fwd(p);
+    if (rc != OSS_OK) return rc;
+    if (!p->out || !p->x) return OSS_ERR_NULL;
+    if (p->batch == 0 || p->seqlen == 0) return OSS_OK;
+    const int eb = io == OSS_F32 ? 4 : 2;
+    int v = g_force_fwd.load();
+    if (v < 0) v = scan_fwd_pick_variant(p->batch, p->dim, p->seqlen, p->dstate, p->n_groups, eb);
+    g_last_fwd.store(v);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (io) {
+        case OSS_F32: return scan_fwd_dispatch<float>(*p, v, s);
+        case OSS_F16: return scan_fwd_dispatch<f16_t>(*p, v, s);
+        case OSS_BF16: return scan_fwd_dispatch<bf16_t>(*p, v, s);
+    }
+    return OSS_ERR_SHAPE;
+}
+
+static int bwd_variant_for(int batch, int dim, int seqlen, int dstate, int n_groups) {
+    int v = g_force_bwd.load();
+    if (v < 0) v = scan_bwd_pick_variant(batch, dim, seqlen, dstate, n_groups);
+    return v;
+}
+
+size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups) {
+    if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups) return 0;
+    // sized for the variant with the fewest rows per workgroup so that any variant fits
+    const int rows_per_group = dim / n_groups;
+    const int rows = scan_bwd_rows_per_wg(3);
+    const size_t tiles = (size_t)(rows_per_group + rows - 1) / rows;
+    const size_t floats = (size_t)batch * n_groups * tiles * 2 * dstate * seqlen + (size_t)batch * dim * (dstate + 2);
+    return floats * sizeof(float);
+}
+
+int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream) {
+    if (!p) return OSS_ERR_NULL;
+    int rc = check_fwd(&p->f);
+    if (rc != OSS_OK) return rc;
+    if (!p->dout || !p->du || !p->ddelta || !p->dA || !p->dB || !p->dC) return OSS_ERR_NULL;
+    const oss_scan_fwd_params &f = p->f;
+    if (f.batch == 0 || f.seqlen == 0) return OSS_OK;
+    if (!f.x && oss_scan_num_chunks(f.seqlen) > 1) return OSS_ERR_NULL;  // selective_scan.cpp:310
+    const int v = bwd_variant_for(f.batch, f.dim, f.seqlen, f.dstate, f.n_groups);
+    g_last_bwd.store(v);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (io) {
+        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, s);
+        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, s);
+        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, s);
+    }
+    return OSS_ERR_SHAPE;
+}
+
+void oss_scan_set_variant(int fwd_variant, int bwd_variant) {
+    g_force_fwd.store(fwd_variant);
+    g_force_bwd.store(bwd_variant);
+}
+int oss_scan_last_variant(int which) { return which == 0 ? g_last_fwd.load() : g_last_bwd.load(); }
+
+__global__ void __launch_bounds__(256) oss_copy_kernel(const f32x4 *src, f32x4 *dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+int oss_hbm_copy(const void *src, void *dst, size_t n_bytes, oss_stream_t stream) {
+    if (!src || !dst) return OSS_ERR_NULL;
+    const size_t n = n_bytes / 16;
+    if (n == 0) return OSS_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(oss_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n);
+    return (int)hipGetLastError();
+}
+
+const char *oss_version(void) { return "vmambair_oss 0.1 (gfx950)"; }
+
+}  // extern "C"

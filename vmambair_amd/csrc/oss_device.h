@@ -1,0 +1,284 @@
+// oss_device.h -- device-side building blocks of the gfx950 selective-scan kernels.
+//
+// Written for CDNA4 only: 64-lane wavefronts, DPP row/wave controls of the gfx9 ISA family
+// (row_shr, row_bcast:15/31, wave_shr/shl), v_exp_f32 / v_log_f32 transcendentals, LDS in 16-byte
+// lane-linear images.  No CUB/hipCUB, no compatibility macros.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oss {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr int kScanChunk = 256;  // time steps between saved states in x (oss_scan_chunk())
+constexpr int kNB = 16;          // states per LDS tile
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
+
+// ---------------------------------------------------------------------------------------------
+// element conversion (reference: Converter::to_float, selective_scan_common.h:56-86 -- all math
+// in fp32 whatever the I/O type)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float to_f32(f16_t x) {
+    _Float16 h;
+    __builtin_memcpy(&h, &x.v, 2);
+    return (float)h;
+}
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
+    // round-to-nearest-even, NaN preserved (same rounding as torch's float->bfloat16)
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{(uint16_t)((u >> 16) | 0x40)};
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return bf16_t{(uint16_t)(u >> 16)};
+}
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) {
+    _Float16 h = (_Float16)x;  // v_cvt_f16_f32, RNE
+    f16_t r;
+    __builtin_memcpy(&r.v, &h, 2);
+    return r;
+}
+
+// unpack a 32-bit word holding two 16-bit elements (little endian: element 0 in the low half)
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float &lo, float &hi);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t w, float &lo, float &hi) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float &lo, float &hi) {
+    lo = to_f32(f16_t{(uint16_t)(w & 0xffffu)});
+    hi = to_f32(f16_t{(uint16_t)(w >> 16)});
+}
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)from_f32<T>(lo).v | ((uint32_t)from_f32<T>(hi).v << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// I contiguous elements per lane <-> float[I].  `vec` = pointer is 16-byte aligned and all I
+// elements are in range; otherwise element-wise with zero fill beyond `valid` elements.
+// ---------------------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void load_items(const float *p, int valid, bool vec, float (&v)[I]) {
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < I / 4; ++k) {
+            f32x4 q = *reinterpret_cast<const f32x4 *>(p + 4 * k);
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < I; ++i) v[i] = (i < valid) ? p[i] : 0.f;
+    }
+}
+template <int I, typename T>
+__device__ __forceinline__ void load_items(const T *p, int valid, bool vec, float (&v)[I]) {
+    static_assert(I % 4 == 0, "");
+    if (vec) {
+        if constexpr (I % 8 == 0) {
+#pragma unroll
+            for (int k = 0; k < I / 8; ++k) {
+                u32x4 q = *reinterpret_cast<const u32x4 *>(p + 8 * k);
+                unpack2<T>(q.x, v[8 * k], v[8 * k + 1]);
+                unpack2<T>(q.y, v[8 * k + 2], v[8 * k + 3]);
+                unpack2<T>(q.z, v[8 * k + 4], v[8 * k + 5]);
+                unpack2<T>(q.w, v[8 * k + 6], v[8 * k + 7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < I / 4; ++k) {
+                u32x2 q = *reinterpret_cast<const u32x2 *>(p + 4 * k);
+                unpack2<T>(q.x, v[4 * k], v[4 * k + 1]);
+                unpack2<T>(q.y, v[4 * k + 2], v[4 * k + 3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < I; ++i) v[i] = (i < valid) ? to_f32(p[i]) : 0.f;
+    }
+}
+template <int I>
+__device__ __forceinline__ void store_items(float *p, int valid, bool vec, const float (&v)[I]) {
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < I / 4; ++k) {
+            f32x4 q = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+            *reinterpret_cast<f32x4 *>(p + 4 * k) = q;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < I; ++i)
+            if (i < valid) p[i] = v[i];
+    }
+}
+template <int I, typename T>
+__device__ __forceinline__ void store_items(T *p, int valid, bool vec, const float (&v)[I]) {
+    if (vec) {
+        if constexpr (I % 8 == 0) {
+#pragma unroll
+            for (int k = 0; k < I / 8; ++k) {
+                u32x4 q = {pack2<T>(v[8 * k], v[8 * k + 1]), pack2<T>(v[8 * k + 2], v[8 * k + 3]),
+                           pack2<T>(v[8 * k + 4], v[8 * k + 5]), pack2<T>(v[8 * k + 6], v[8 * k + 7])};
+                *reinterpret_cast<u32x4 *>(p + 8 * k) = q;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < I / 4; ++k) {
+                u32x2 q = {pack2<T>(v[4 * k], v[4 * k + 1]), pack2<T>(v[4 * k + 2], v[4 * k + 3])};
+                *reinterpret_cast<u32x2 *>(p + 4 * k) = q;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < I; ++i)
+            if (i < valid) p[i] = from_f32<T>(v[i]);
+    }
+}
+
+// vector accesses of I items need this alignment (bytes)
+template <typename T, int I> constexpr uintptr_t vec_align() { return (I * sizeof(T)) >= 16 ? 16 : 8; }
+template <typename T, int I> __device__ __forceinline__ bool vec_ok(const T *p) {
+    return (reinterpret_cast<uintptr_t>(p) & (vec_align<T, I>() - 1)) == 0;
+}
+
+template <typename T> __device__ __forceinline__ bool aligned16(const T *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+
+// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:115-118):
+//   x <= 20 ? log1p(exp(x)) : x.   `e` returns exp(x) for the backward's sigmoid.
+// log1p(e) is evaluated as log(1+e) * e / ((1+e) - 1), which keeps full relative accuracy for
+// small e with two transcendentals and one reciprocal.
+__device__ __forceinline__ float softplus_thr(float x, float &e) {
+    e = exp2_hw(x * kLog2e);
+    const float s = 1.0f + e;
+    const float d = s - 1.0f;
+    const float l = __builtin_amdgcn_logf(s) * kLn2;  // v_log_f32 is log2
+    const float r = (d == 0.f) ? e : l * (e * __builtin_amdgcn_rcpf(d));
+    return (x <= 20.f) ? r : x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DPP helpers (gfx9 encodings)
+// ---------------------------------------------------------------------------------------------
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL,
+                                                      ROW_MASK, 0xf, false));
+}
+
+// One Kogge-Stone step of the inclusive scan of the linear-recurrence monoid
+//   (P_l, h_l) o (P_r, h_r) = (P_r P_l, P_r h_l + h_r)        [left = earlier]
+// (reference operator: SSMScanOp, selective_scan_common.h:89-96).  Lanes without a source keep
+// the identity (1, 0), so the step is a no-op for them.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ void scan_step(float &P, float &h) {
+    const float hl = dpp_f32<CTRL, ROW_MASK>(0.f, h);
+    const float Pl = dpp_f32<CTRL, ROW_MASK>(1.f, P);
+    h = __builtin_fmaf(P, hl, h);
+    P = P * Pl;
+}
+
+// Hand-scheduled form of scan_step: on gfx9-family ISAs VOP2 instructions take a DPP source, and a
+// lane whose DPP source is out of range (or whose row is masked) is simply not written -- exactly
+// the identity behaviour the scan needs -- so one step is two VALU instructions
+//     h += dpp(h) * P ;  P *= dpp(P)
+// instead of the six the builtin form compiles to.  Wait states: a VALU write followed by a DPP
+// read of the same VGPR needs two intervening states (s_nop 1 up front, s_nop 0 between steps).
+#define OSS_DPP_STEP(CTRL)                                   \
+    "v_fmac_f32_dpp %0, %0, %1 " CTRL " bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"
+template <int LPR>
+__device__ __forceinline__ void segment_scan(float &P, float &h) {
+    if constexpr (LPR == 16) {
+        asm volatile("s_nop 1\n\t" OSS_DPP_STEP("row_shr:1 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:2 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:4 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:8 row_mask:0xf")
+                     : "+v"(h), "+v"(P));
+    } else if constexpr (LPR == 32) {
+        asm volatile("s_nop 1\n\t" OSS_DPP_STEP("row_shr:1 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:2 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:4 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:8 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_bcast:15 row_mask:0xa")
+                     : "+v"(h), "+v"(P));
+    } else {
+        asm volatile("s_nop 1\n\t" OSS_DPP_STEP("row_shr:1 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:2 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:4 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_shr:8 row_mask:0xf") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_bcast:15 row_mask:0xa") "s_nop 0\n\t"
+                     OSS_DPP_STEP("row_bcast:31 row_mask:0xc")
+                     : "+v"(h), "+v"(P));
+    }
+}
+#undef OSS_DPP_STEP
+
+// Builtin (compiler-scheduled) form of the same scan; kept as the readable definition and used by
+// the unit check that both forms agree.
+template <int LPR>
+__device__ __forceinline__ void segment_scan_builtin(float &P, float &h) {
+    scan_step<kDppRowShr1>(P, h);
+    scan_step<kDppRowShr2>(P, h);
+    scan_step<kDppRowShr4>(P, h);
+    scan_step<kDppRowShr8>(P, h);
+    if constexpr (LPR >= 32) scan_step<kDppRowBcast15, 0xa>(P, h);
+    if constexpr (LPR >= 64) scan_step<kDppRowBcast31, 0xc>(P, h);
+}
+
+// sum over segments of LPR lanes; every lane of the segment's LAST position holds the total.
+template <int LPR>
+__device__ __forceinline__ float segment_sum_to_last(float v) {
+    v += dpp_f32<kDppRowShr1>(0.f, v);
+    v += dpp_f32<kDppRowShr2>(0.f, v);
+    v += dpp_f32<kDppRowShr4>(0.f, v);
+    v += dpp_f32<kDppRowShr8>(0.f, v);
+    if constexpr (LPR >= 32) v += dpp_f32<kDppRowBcast15, 0xa>(0.f, v);
+    if constexpr (LPR >= 64) v += dpp_f32<kDppRowBcast31, 0xc>(0.f, v);
+    return v;
+}
+
+// value of lane-1 (whole wave); lane 0 and, through `seg_first`, every segment's first lane get `fill`.
+__device__ __forceinline__ float shift_from_prev_lane(float v, float fill, bool seg_first) {
+    const float s = dpp_f32<kDppWaveShr1>(fill, v);
+    return seg_first ? fill : s;
+}
+// value of lane+1; the segment's last lane gets `fill`.
+__device__ __forceinline__ float shift_from_next_lane(float v, float fill, bool seg_last) {
+    const float s = dpp_f32<kDppWaveShl1>(fill, v);
+    return seg_last ? fill : s;
+}
+
+// mirror a value inside segments of LPR lanes (lane p <-> LPR-1-p)
+template <int LPR>
+__device__ __forceinline__ float segment_mirror(float v, int lane) {
+    const int src = (lane & ~(LPR - 1)) | ((LPR - 1) - (lane & (LPR - 1)));
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+
+// LDS image of a [NB][TC] tile such that lane p's I items are I/4 conflict-free 16-byte reads:
+//   element (state n, position p, item i) -> n*TC + (i/4)*(LPR*4) + p*4 + (i%4)
+template <int LPR, int I>
+__device__ __forceinline__ int tile_off(int n, int p, int i) {
+    return n * (LPR * I) + (i >> 2) * (LPR * 4) + p * 4 + (i & 3);
+}
+
+}  // namespace oss

@@ -1,0 +1,430 @@
+// oss_scan_bwd.hip -- selective-scan backward for gfx950 (replaces the reference's
+// selective_scan_bwd_kernel, cus/selective_scan_bwd_kernel.cuh:66-273, and the host-side
+// zero-fills / casts around it, cus/selective_scan.cpp:319-327,347).  Arithmetic per SURVEY.md
+// Appendix A.
+//
+// Same row ownership as the forward (LPR lanes of one wave own a row for the whole sequence, I
+// items per lane, B/C of the (batch, group) staged once per chunk in LDS), chunks walked from the
+// last to the first:
+//   * forward states of the chunk are recomputed from the state saved in x every kScanChunk steps
+//     (no carry needed in this direction);
+//   * the reverse recurrence dh_t = C_t g_t + a_{t+1} dh_{t+1} is the same monoid scanned over the
+//     mirrored lane order (ds_bpermute mirror + the forward DPP scan), its carry and the delta of
+//     the chunk's first step (a_{t+1} across the chunk edge is exp2(A * delta_first), so no
+//     per-state edge value is kept) live in LDS;
+//   * dB/dC -- sums over the rows of a group -- are accumulated with LDS float atomics into a
+//     workgroup tile and written ONCE per (workgroup, chunk) as a partial with plain stores; a
+//     finishing kernel adds the partials of a group in a fixed order and casts to the I/O type.
+//     No global atomics (per-XCD L2s are not coherent: device-scope float atomics would all go to
+//     memory), no zero-filled outputs, and the result is deterministic up to the LDS add order.
+//   * dA, dD, ddelta_bias are per-(batch,row) partials reduced over batch by the finishing kernel.
+#include "oss_device.h"
+#include "oss_host.h"
+
+namespace oss {
+
+template <typename T, int LPR, int I, int NT>
+__device__ __forceinline__ void stage_tiles_b(float *sB, float *sC, const T *gB, const T *gC,
+                                              int64_t strideB, int64_t strideC, int nb, int t0, int L,
+                                              int tid) {
+    constexpr int TC = LPR * I;
+    constexpr int Q = TC / 4;
+    const bool fullchunk = (t0 + TC <= L);
+    for (int idx = tid; idx < nb * Q; idx += NT) {
+        const int n = idx / Q, k = idx - n * Q;
+        const int t = t0 + 4 * k;
+        const T *pb = gB + n * strideB + t;
+        const T *pc = gC + n * strideC + t;
+        f32x4 vb, vc;
+        constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
+        if (fullchunk && ((reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(pc)) & amask) == 0) {
+            if constexpr (sizeof(T) == 4) {
+                vb = *reinterpret_cast<const f32x4 *>(pb);
+                vc = *reinterpret_cast<const f32x4 *>(pc);
+            } else {
+                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb);
+                u32x2 qc = *reinterpret_cast<const u32x2 *>(pc);
+                float a0, a1, a2, a3;
+                unpack2<T>(qb.x, a0, a1); unpack2<T>(qb.y, a2, a3);
+                vb = f32x4{a0, a1, a2, a3};
+                unpack2<T>(qc.x, a0, a1); unpack2<T>(qc.y, a2, a3);
+                vc = f32x4{a0, a1, a2, a3};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vb[j] = (t + j < L) ? to_f32(pb[j]) : 0.f;
+                vc[j] = (t + j < L) ? to_f32(pc[j]) : 0.f;
+            }
+        }
+        const int pos = (4 * k) / I, i0 = (4 * k) % I;
+        const int off = tile_off<LPR, I>(n, pos, i0);
+        *reinterpret_cast<f32x4 *>(sB + off) = vb;
+        *reinterpret_cast<f32x4 *>(sC + off) = vc;
+    }
+}
+
+// workspace layout (floats):
+//   [0, nBC)                 dB/dC partials  [batch][group][tile][2][N][L]
+//   [nBC, nBC + batch*dim*N) dA partials     [batch][dim][N]
+//   then dD partials [batch][dim], then ddelta_bias partials [batch][dim]
+struct BwdWs {
+    float *bc, *dA, *dD, *db;
+    int tiles;
+};
+__host__ __device__ inline size_t ws_bc_floats(int batch, int G, int tiles, int N, int L) {
+    return (size_t)batch * G * tiles * 2 * N * L;
+}
+
+template <typename T, int LPR, int I, int WAVES, int NBB>
+__global__ void __launch_bounds__(WAVES * 64, (WAVES >= 8 ? 4 : 3))
+oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
+    constexpr int RPW = 64 / LPR;
+    constexpr int ROWS = WAVES * RPW;
+    constexpr int TC = LPR * I;
+    constexpr int NT = WAVES * 64;
+    static_assert(TC % kScanChunk == 0, "");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sB = smem;                    // [NBB][TC]  tile_off layout
+    float *sC = sB + NBB * TC;           // [NBB][TC]
+    float *sdB = sC + NBB * TC;          // [NBB][I][LPR]  accumulators (lane-linear per item)
+    float *sdC = sdB + NBB * TC;         // [NBB][I][LPR]
+    float *sA2 = sdC + NBB * TC;                       // [N][ROWS]
+    float *sdhc = sA2 + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dh of the first step of the later chunk
+    float *sdA = sdhc + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dA partial of the row
+    float *sdln = sdA + (size_t)p.f.dstate * ROWS;     // [ROWS]     delta of the first step of the later chunk
+
+    const oss_scan_fwd_params &f = p.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = lane & (LPR - 1);
+    const int wrow = wave * RPW + lane / LPR;
+    const bool seg_first = (pos == 0), seg_last = (pos == LPR - 1);
+
+    const int L = f.seqlen, N = f.dstate, G = f.n_groups;
+    const int rows_per_group = f.dim / G;
+    const int tiles_per_group = ws.tiles;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
+    const int g = bid % G;
+    const int b = bid / G;
+    const int row_in_group = tile * ROWS + wrow;
+    const bool row_valid = row_in_group < rows_per_group;
+    const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
+
+    const T *u_row = reinterpret_cast<const T *>(f.u) + b * f.u_batch_stride + d * f.u_d_stride;
+    const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride + d * f.delta_d_stride;
+    const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d * p.dout_d_stride;
+    T *du_row = reinterpret_cast<T *>(p.du) + b * p.du_batch_stride + d * p.du_d_stride;
+    T *dd_row = reinterpret_cast<T *>(p.ddelta) + b * p.ddelta_batch_stride + d * p.ddelta_d_stride;
+    const T *gB = reinterpret_cast<const T *>(f.B) + b * f.B_batch_stride + g * f.B_group_stride;
+    const T *gC = reinterpret_cast<const T *>(f.C) + b * f.C_batch_stride + g * f.C_group_stride;
+    const float Dd = f.D ? f.D[d] : 0.f;
+    const float bias = f.delta_bias ? f.delta_bias[d] : 0.f;
+    const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
+    const float *x_row = f.x ? f.x + ((size_t)b * f.dim + d) * n_xchunks * 2 * N : nullptr;
+    float *ws_bc = ws.bc + ((size_t)(b * G + g) * tiles_per_group + tile) * 2 * N * L;
+
+    for (int idx = tid; idx < N * ROWS; idx += NT) {
+        const int n = idx / ROWS, r = idx - n * ROWS;
+        const int rg = tile * ROWS + r;
+        const int dd = g * rows_per_group + (rg < rows_per_group ? rg : 0);
+        sA2[idx] = f.A[dd * f.A_d_stride + n] * kLog2e;
+        sdhc[idx] = 0.f;
+        sdA[idx] = 0.f;
+    }
+    if (tid < ROWS) sdln[tid] = 0.f;
+
+    float dD_acc = 0.f, db_acc = 0.f;
+    const int n_chunks = (L + TC - 1) / TC;
+    for (int c = n_chunks - 1; c >= 0; --c) {
+        const int t0 = c * TC;
+        const int tl = t0 + pos * I;
+        const int valid = max(0, min(I, L - tl));
+        const bool vec = valid == I && vec_ok<T, I>(u_row + tl) && vec_ok<T, I>(dt_row + tl) &&
+                         vec_ok<T, I>(g_row + tl) && vec_ok<T, I>(du_row + tl) && vec_ok<T, I>(dd_row + tl);
+        float uu[I], dl[I], gg[I], sig[I], w[I], Q[I], dd[I];
+        load_items<I>(u_row + tl, valid, vec, uu);
+        load_items<I>(dt_row + tl, valid, vec, dl);
+        load_items<I>(g_row + tl, valid, vec, gg);
+        if (!row_valid) {  // a row slot past the end of the group must not contribute to dB/dC
+#pragma unroll
+            for (int i = 0; i < I; ++i) { uu[i] = 0.f; gg[i] = 0.f; }
+        }
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            const float raw = dl[i] + bias;
+            float x = raw, s = 1.f;
+            if (f.delta_softplus) {
+                float e;
+                x = softplus_thr(raw, e);
+                // d softplus = sigmoid(raw) for raw <= 20, 1 above (bwd_kernel.cuh:228-241)
+                s = (raw <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+            }
+            const bool ok = i < valid;
+            dl[i] = ok ? x : 0.f;
+            sig[i] = ok ? s : 0.f;
+            w[i] = dl[i] * uu[i];
+            Q[i] = 0.f;
+            dd[i] = 0.f;
+            S += dl[i];
+        }
+        __syncthreads();  // sdln/sdhc written by the previous iteration (or the init) are visible
+        const float dln_c = sdln[wrow];  // delta of step t0+TC (first step of the later chunk), 0 past the end
+        const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
+        const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
+        const int xi = t0 / kScanChunk - 1;         // saved state entering this chunk
+
+        for (int n0 = 0; n0 < N; n0 += NBB) {
+            const int nb = min(NBB, N - n0);
+            __syncthreads();
+            stage_tiles_b<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * f.B_dstate_stride,
+                                         gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
+                                         f.C_dstate_stride, nb, t0, L, tid);
+            for (int idx = tid; idx < nb * TC / 4; idx += NT) {
+                reinterpret_cast<f32x4 *>(sdB)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+                reinterpret_cast<f32x4 *>(sdC)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            for (int nn = 0; nn < nb; ++nn) {
+                const int n = n0 + nn;
+                const float A2 = sA2[n * ROWS + wrow];
+                const float hc = (xi >= 0) ? x_row[(size_t)xi * 2 * N + 2 * n + 1] : 0.f;  // bwd_kernel.cuh:184
+                const float dhc = sdhc[n * ROWS + wrow];
+                float a[I], hh[I];
+                // ---- forward recompute: local recurrence (hh holds b_t until the state pass)
+                float h = 0.f;
+                const float *tb = sB + tile_off<LPR, I>(nn, pos, 0);
+                const float *tc = sC + tile_off<LPR, I>(nn, pos, 0);
+#pragma unroll
+                for (int k = 0; k < I / 4; ++k) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * k + j;
+                        a[i] = exp2_hw(dl[i] * A2);
+                        hh[i] = b4[j] * w[i];
+                        h = (i == 0) ? hh[0] : __builtin_fmaf(a[i], h, hh[i]);
+                    }
+                }
+                float P = exp2_hw(S * A2);
+                segment_scan<LPR>(P, h);
+                const float hfull = __builtin_fmaf(P, hc, h);
+                const float hin = shift_from_prev_lane(hfull, hc, seg_first);
+                // ---- forward states h_t in place
+                {
+                    float hp = hin;
+#pragma unroll
+                    for (int i = 0; i < I; ++i) {
+                        hp = __builtin_fmaf(a[i], hp, hh[i]);
+                        hh[i] = hp;
+                    }
+                }
+                // ---- reverse recurrence: element (a_{t+1}, C_t g_t)   (bwd_kernel.cuh:170-193)
+                const float a_edge = exp2_hw(dln_c * A2);
+                const float a_nl = shift_from_next_lane(a[0], a_edge, seg_last);
+                float dloc = 0.f;
+#pragma unroll
+                for (int k = I / 4 - 1; k >= 0; --k) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int i = 4 * k + j;
+                        const float an = (i == I - 1) ? a_nl : a[(i + 1) % I];
+                        const float cg = c4[j] * gg[i];
+                        dloc = (i == I - 1) ? cg : __builtin_fmaf(an, dloc, cg);
+                    }
+                }
+                float Pm = segment_mirror<LPR>(exp2_hw(Sshift * A2), lane);
+                float dm = segment_mirror<LPR>(dloc, lane);
+                segment_scan<LPR>(Pm, dm);
+                const float dfull_m = __builtin_fmaf(Pm, dhc, dm);       // dh at the first step of mirrored lane
+                const float dex_m = shift_from_prev_lane(dfull_m, dhc, seg_first);
+                float dh = segment_mirror<LPR>(dex_m, lane);              // dh entering this lane from the right
+                if (seg_last) sdhc[n * ROWS + wrow] = dfull_m;            // mirrored-last = first lane in time
+                // ---- reverse pass with gradients (bwd_kernel.cuh:196-206); p_t = a_t h_{t-1}
+                float dA_acc = 0.f;
+                float *accB = sdB + nn * TC + pos;
+                float *accC = sdC + nn * TC + pos;
+#pragma unroll
+                for (int k = I / 4 - 1; k >= 0; --k) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
+                    const f32x4 c4 = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        const int i = 4 * k + j;
+                        const float an = (i == I - 1) ? a_nl : a[(i + 1) % I];
+                        dh = __builtin_fmaf(an, dh, c4[j] * gg[i]);
+                        Q[i] = __builtin_fmaf(dh, b4[j], Q[i]);
+                        const float hprev = (i == 0) ? hin : hh[(i + I - 1) % I];
+                        const float r = dh * (a[i] * hprev);
+                        dd[i] = __builtin_fmaf(A2, r, dd[i]);
+                        dA_acc = __builtin_fmaf(dl[i], r, dA_acc);
+                        // rows past the end of the group carry u = dout = 0, so they add exact zeros
+                        __hip_atomic_fetch_add(accB + i * LPR, dh * w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(accC + i * LPR, gg[i] * hh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                const float dA_sum = segment_sum_to_last<LPR>(dA_acc);
+                if (seg_last) sdA[n * ROWS + wrow] += dA_sum;
+            }
+            __syncthreads();  // all rows' atomics have landed
+            // ---- write this workgroup's dB/dC partial for (chunk, state block)
+            for (int idx = tid; idx < nb * (TC / 4); idx += NT) {
+                const int nn = idx / (TC / 4), k = idx - nn * (TC / 4);
+                const int t = t0 + 4 * k;
+                if (t >= L) continue;
+                const int ps = (4 * k) / I, i0 = (4 * k) % I;
+                const float *ab = sdB + nn * TC + i0 * LPR + ps;
+                const float *ac = sdC + nn * TC + i0 * LPR + ps;
+                f32x4 vb = {ab[0], ab[LPR], ab[2 * LPR], ab[3 * LPR]};
+                f32x4 vc = {ac[0], ac[LPR], ac[2 * LPR], ac[3 * LPR]};
+                float *ob = ws_bc + (size_t)(n0 + nn) * L + t;
+                float *oc = ob + (size_t)N * L;
+                if (t + 3 < L && aligned16(ob) && aligned16(oc)) {
+                    *reinterpret_cast<f32x4 *>(ob) = vb;
+                    *reinterpret_cast<f32x4 *>(oc) = vc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t + j < L) { ob[j] = vb[j]; oc[j] = vc[j]; }
+                }
+            }
+        }
+        // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245)
+        float du[I], dv[I];
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            du[i] = __builtin_fmaf(Q[i], dl[i], Dd * gg[i]);
+            const float ddel = __builtin_fmaf(Q[i], uu[i], dd[i] * kLn2);
+            dv[i] = ddel * sig[i];
+            dD_acc = __builtin_fmaf(gg[i], uu[i], dD_acc);
+            db_acc += dv[i];
+        }
+        if (row_valid) {
+            store_items<I>(du_row + tl, valid, vec, du);
+            store_items<I>(dd_row + tl, valid, vec, dv);
+        }
+        __syncthreads();  // every lane has read sdln for this chunk
+        if (seg_first) sdln[wrow] = dl[0];
+    }
+    // ---- per-row partials over the sequence
+    const float dD_sum = segment_sum_to_last<LPR>(dD_acc);
+    const float db_sum = segment_sum_to_last<LPR>(db_acc);
+    if (seg_last && row_valid) {
+        if (ws.dD) ws.dD[(size_t)b * f.dim + d] = dD_sum;
+        if (ws.db) ws.db[(size_t)b * f.dim + d] = db_sum;
+        for (int n = 0; n < N; ++n) ws.dA[((size_t)b * f.dim + d) * N + n] = sdA[n * ROWS + wrow];
+    }
+}
+
+// dB/dC: sum the row-tile partials of each (batch, group) in tile order and cast to the I/O type
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_scan_bwd_finish_bc(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*L */, size_t total /* batch*G*N*L */) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t bg = i / nl, r = i - bg * nl;
+    const float *base = ws_bc + bg * tiles * 2 * nl + r;
+    float sb = 0.f, sc = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        sb += base[(size_t)t * 2 * nl];
+        sc += base[(size_t)t * 2 * nl + nl];
+    }
+    dB[i] = from_f32<T>(sb);
+    dC[i] = from_f32<T>(sc);
+}
+
+// dA, dD, ddelta_bias: sum over batch in batch order
+__global__ void __launch_bounds__(256)
+oss_scan_bwd_finish_w(const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA, float *dD,
+                      float *db, int batch, int dim, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nA = dim * N;
+    if (i < nA) {
+        float s = 0.f;
+        for (int b = 0; b < batch; ++b) s += ws_dA[(size_t)b * nA + i];
+        dA[i] = s;
+    } else if (i < nA + dim) {
+        const int d = i - nA;
+        if (dD) {
+            float s = 0.f;
+            for (int b = 0; b < batch; ++b) s += ws_dD[(size_t)b * dim + d];
+            dD[d] = s;
+        }
+        if (db) {
+            float s = 0.f;
+            for (int b = 0; b < batch; ++b) s += ws_db[(size_t)b * dim + d];
+            db[d] = s;
+        }
+    }
+}
+
+template <typename T, int LPR, int I, int WAVES, int NBB>
+static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream) {
+    constexpr int ROWS = WAVES * (64 / LPR);
+    constexpr int TC = LPR * I;
+    const oss_scan_fwd_params &f = p.f;
+    const int rows_per_group = f.dim / f.n_groups;
+    const int tiles = (rows_per_group + ROWS - 1) / ROWS;
+    const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen);
+    const size_t need = sizeof(float) * (n_bc + (size_t)f.batch * f.dim * (f.dstate + 2));
+    if (!p.workspace || p.workspace_bytes < need) return OSS_ERR_WORKSPACE;
+    BwdWs ws;
+    ws.bc = reinterpret_cast<float *>(p.workspace);
+    ws.dA = ws.bc + n_bc;
+    ws.dD = ws.dA + (size_t)f.batch * f.dim * f.dstate;
+    ws.db = ws.dD + (size_t)f.batch * f.dim;
+    ws.tiles = tiles;
+    float *wdD = ws.dD, *wdb = ws.db;
+    if (!p.dD) ws.dD = nullptr;
+    if (!p.ddelta_bias) ws.db = nullptr;
+
+    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
+    auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB>;
+    static size_t smem_enabled = 48 * 1024;
+    if (smem > smem_enabled) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        smem_enabled = smem;
+    }
+    const dim3 grid((unsigned)(f.batch * f.n_groups * tiles));
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p, ws);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+
+    const size_t nl = (size_t)f.dstate * f.seqlen;
+    const size_t total = (size_t)f.batch * f.n_groups * nl;
+    hipLaunchKernelGGL(oss_scan_bwd_finish_bc<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       ws.bc, reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), tiles, nl, total);
+    const int nw = f.dim * f.dstate + f.dim;
+    hipLaunchKernelGGL(oss_scan_bwd_finish_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, ws.dA,
+                       wdD, wdb, p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate);
+    return (int)hipGetLastError();
+}
+
+// variant table: (lanes per row, items per lane, waves per workgroup, states per LDS tile)
+//   0: 64 x 8 x 8,  8 states  (TC 512,  8 rows/WG, 64 KiB LDS)
+//   1: 64 x 8 x 16, 8 states  (TC 512, 16 rows/WG, 64 KiB LDS)
+//   2: 32 x 8 x 8, 16 states  (TC 256, 16 rows/WG, 64 KiB LDS)
+//   3: 64 x 4 x 4, 16 states  (TC 256,  4 rows/WG, 64 KiB LDS)  short sequences / few rows per group
+static const int kBwdRows[] = {8, 16, 16, 4};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 3) ? 3 : variant]; }
+
+template <typename T>
+int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream) {
+    switch (variant) {
+        case 0: return launch_bwd<T, 64, 8, 8, 8>(p, stream);
+        case 1: return launch_bwd<T, 64, 8, 16, 8>(p, stream);
+        case 2: return launch_bwd<T, 32, 8, 8, 16>(p, stream);
+        default: return launch_bwd<T, 64, 4, 4, 16>(p, stream);
+    }
+}
+
+template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, hipStream_t);
+template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, hipStream_t);
+template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, hipStream_t);
+
+}  // namespace oss

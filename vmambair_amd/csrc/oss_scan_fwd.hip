@@ -1,0 +1,252 @@
+// oss_scan_fwd.hip -- selective-scan forward for gfx950 (replaces the reference's
+// selective_scan_fwd_kernel, cus/selective_scan_fwd_kernel.cuh:61-172; arithmetic per SURVEY.md
+// Appendix A).
+//
+// Decomposition (MI355X-first, not the reference's block-scan-per-state):
+//   * one workgroup = one (batch b, group g, tile of ROWS rows of that group).  The B/C rows of
+//     (b, g) are shared by every row of the group, so they are staged ONCE per chunk into LDS as
+//     fp32 and re-read by all ROWS rows (the reference re-loads them from global per row).
+//   * one row (b, d) is owned by LPR consecutive lanes of ONE wave for the whole sequence; each
+//     lane owns I consecutive time steps of the current chunk (TC = LPR*I steps per chunk).  The
+//     carry between chunks never leaves the wave, so there is no block-level scan and no barrier
+//     per state: the only barriers are the two around the LDS tile refill.
+//   * per state: thread-local sequential recurrence over the I items (registers), a DPP
+//     (row_shr / row_bcast) inclusive scan of the per-lane (prod a, h) pairs over the LPR lanes,
+//     then a second sequential pass that re-runs the recurrence from the exact incoming state and
+//     accumulates y += C*h.  One v_exp_f32 per (element, state); the per-lane product of a's is
+//     exp2(A * sum(delta)) (one extra exp per lane and state) instead of I multiplies.
+#include "oss_device.h"
+#include "oss_host.h"
+
+namespace oss {
+
+// Stage nb state rows x TC steps of one (batch, group) of B and C into the LDS tiles (fp32).
+template <typename T, int LPR, int I, int NT>
+__device__ __forceinline__ void stage_tiles(float *sB, float *sC, const T *gB, const T *gC,
+                                            int64_t strideB, int64_t strideC, int nb, int t0, int L,
+                                            int tid) {
+    constexpr int TC = LPR * I;
+    constexpr int Q = TC / 4;  // 4-element groups per state row
+    const bool fullchunk = (t0 + TC <= L);
+    for (int idx = tid; idx < nb * Q; idx += NT) {
+        const int n = idx / Q, k = idx - n * Q;
+        const int t = t0 + 4 * k;
+        const T *pb = gB + n * strideB + t;
+        const T *pc = gC + n * strideC + t;
+        f32x4 vb, vc;
+        if constexpr (sizeof(T) == 4) {
+            if (fullchunk && aligned16(pb) && aligned16(pc)) {
+                vb = *reinterpret_cast<const f32x4 *>(pb);
+                vc = *reinterpret_cast<const f32x4 *>(pc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vb[j] = (t + j < L) ? to_f32(pb[j]) : 0.f;
+                    vc[j] = (t + j < L) ? to_f32(pc[j]) : 0.f;
+                }
+            }
+        } else {
+            if (fullchunk && ((reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(pc)) & 7u) == 0) {
+                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb);
+                u32x2 qc = *reinterpret_cast<const u32x2 *>(pc);
+                float a0, a1, a2, a3;
+                unpack2<T>(qb.x, a0, a1); unpack2<T>(qb.y, a2, a3);
+                vb = f32x4{a0, a1, a2, a3};
+                unpack2<T>(qc.x, a0, a1); unpack2<T>(qc.y, a2, a3);
+                vc = f32x4{a0, a1, a2, a3};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vb[j] = (t + j < L) ? to_f32(pb[j]) : 0.f;
+                    vc[j] = (t + j < L) ? to_f32(pc[j]) : 0.f;
+                }
+            }
+        }
+        const int pos = (4 * k) / I, i0 = (4 * k) % I;
+        const int off = tile_off<LPR, I>(n, pos, i0);
+        *reinterpret_cast<f32x4 *>(sB + off) = vb;
+        *reinterpret_cast<f32x4 *>(sC + off) = vc;
+    }
+}
+
+template <typename T, int LPR, int I, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
+    constexpr int RPW = 64 / LPR;      // rows per wave
+    constexpr int ROWS = WAVES * RPW;  // rows per workgroup
+    constexpr int TC = LPR * I;        // time steps per chunk
+    constexpr int NT = WAVES * 64;
+    static_assert(TC % kScanChunk == 0, "chunk must be a multiple of the x granularity");
+    static_assert(I % 4 == 0, "");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sB = smem;                 // [kNB][TC]
+    float *sC = smem + kNB * TC;      // [kNB][TC]
+    float *carH = smem + 2 * kNB * TC;               // [dstate][ROWS]   h entering the chunk
+    float *carP = carH + (size_t)p.dstate * ROWS;    // [dstate][ROWS]   prod of a since t = 0
+    float *sA2 = carP + (size_t)p.dstate * ROWS;     // [dstate][ROWS]   A * log2(e)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = lane & (LPR - 1);
+    const int wrow = wave * RPW + lane / LPR;  // row slot inside the workgroup
+    const bool seg_first = (pos == 0), seg_last = (pos == LPR - 1);
+
+    const int L = p.seqlen, N = p.dstate;
+    const int rows_per_group = p.dim / p.n_groups;
+    const int tiles_per_group = (rows_per_group + ROWS - 1) / ROWS;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
+    const int g = bid % p.n_groups;
+    const int b = bid / p.n_groups;
+    const int row_in_group = tile * ROWS + wrow;
+    const bool row_valid = row_in_group < rows_per_group;
+    const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
+
+    const T *u_row = reinterpret_cast<const T *>(p.u) + b * p.u_batch_stride + d * p.u_d_stride;
+    const T *dt_row = reinterpret_cast<const T *>(p.delta) + b * p.delta_batch_stride + d * p.delta_d_stride;
+    T *out_row = reinterpret_cast<T *>(p.out) + b * p.out_batch_stride + d * p.out_d_stride;
+    const T *gB = reinterpret_cast<const T *>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
+    const T *gC = reinterpret_cast<const T *>(p.C) + b * p.C_batch_stride + g * p.C_group_stride;
+    const float Dd = p.D ? p.D[d] : 0.f;
+    const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
+    const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
+    float *x_row = p.x + ((size_t)b * p.dim + d) * n_xchunks * 2 * N;
+
+    // carries start at (h, P) = (0, 1); A is pre-scaled once (fwd_kernel.cuh:125-127)
+    for (int idx = tid; idx < N * ROWS; idx += NT) {
+        const int n = idx / ROWS, r = idx - n * ROWS;
+        const int rg = tile * ROWS + r;
+        const int dd = g * rows_per_group + (rg < rows_per_group ? rg : 0);
+        carH[idx] = 0.f;
+        carP[idx] = 1.f;
+        sA2[idx] = p.A[dd * p.A_d_stride + n] * kLog2e;
+    }
+
+    const int n_chunks = (L + TC - 1) / TC;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int t0 = c * TC;
+        const int tl = t0 + pos * I;  // first time step of this lane
+        const int valid = max(0, min(I, L - tl));
+        const bool vec = valid == I && vec_ok<T, I>(u_row + tl) && vec_ok<T, I>(dt_row + tl) &&
+                         vec_ok<T, I>(out_row + tl);
+        float dl[I], w[I], y[I];
+        {
+            float uu[I];
+            load_items<I>(u_row + tl, valid, vec, uu);
+            load_items<I>(dt_row + tl, valid, vec, dl);
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                float x = dl[i] + bias;
+                if (p.delta_softplus) { float e; x = softplus_thr(x, e); }
+                x = (i < valid) ? x : 0.f;  // identity element beyond the end (fwd_kernel.cuh:138-142)
+                dl[i] = x;
+                w[i] = x * uu[i];
+                y[i] = Dd * uu[i];
+            }
+        }
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < I; ++i) S += dl[i];
+
+        // does this lane end on an x boundary (or hold the last element)?
+        const int tend = tl + I;  // one past this lane's last step
+        const bool writes_x = row_valid && valid > 0 && ((tend % kScanChunk) == 0 || tend >= L);
+        const int xc = (tl / kScanChunk);
+
+        for (int n0 = 0; n0 < N; n0 += kNB) {
+            const int nb = min(kNB, N - n0);
+            __syncthreads();  // everyone is done with the previous tile (and the carry init)
+            stage_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
+                                       gC + (int64_t)n0 * p.C_dstate_stride, p.B_dstate_stride,
+                                       p.C_dstate_stride, nb, t0, L, tid);
+            __syncthreads();
+            for (int nn = 0; nn < nb; ++nn) {
+                const int n = n0 + nn;
+                const float A2 = sA2[n * ROWS + wrow];
+                const float hc = carH[n * ROWS + wrow];
+                const float Pc = carP[n * ROWS + wrow];
+                float a[I], bb[I];
+                float h = 0.f;
+                const float *tb = sB + tile_off<LPR, I>(nn, pos, 0);
+#pragma unroll
+                for (int k = 0; k < I / 4; ++k) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * k + j;
+                        a[i] = exp2_hw(dl[i] * A2);
+                        bb[i] = bv[j] * w[i];
+                        h = (i == 0) ? bb[0] : __builtin_fmaf(a[i], h, bb[i]);
+                    }
+                }
+                float P = exp2_hw(S * A2);
+                segment_scan<LPR>(P, h);
+                // fold in the state entering the chunk; hfull = state after this lane's last step
+                const float hfull = __builtin_fmaf(P, hc, h);
+                const float Pfull = P * Pc;
+                float hin = shift_from_prev_lane(hfull, hc, seg_first);
+                if (seg_last) { carH[n * ROWS + wrow] = hfull; carP[n * ROWS + wrow] = Pfull; }
+                if (writes_x) {
+                    float2 st = make_float2(Pfull, hfull);
+                    *reinterpret_cast<float2 *>(x_row + (size_t)xc * 2 * N + 2 * n) = st;
+                }
+                const float *tc = sC + tile_off<LPR, I>(nn, pos, 0);
+                h = hin;
+#pragma unroll
+                for (int k = 0; k < I / 4; ++k) {
+                    const f32x4 cv = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * k + j;
+                        h = __builtin_fmaf(a[i], h, bb[i]);
+                        y[i] = __builtin_fmaf(cv[j], h, y[i]);
+                    }
+                }
+            }
+        }
+        if (row_valid) store_items<I>(out_row + tl, valid, vec, y);
+    }
+}
+
+template <typename T, int LPR, int I, int WAVES>
+static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
+    constexpr int ROWS = WAVES * (64 / LPR);
+    constexpr int TC = LPR * I;
+    const int rows_per_group = p.dim / p.n_groups;
+    const int tiles = (rows_per_group + ROWS - 1) / ROWS;
+    const size_t smem = sizeof(float) * (2 * (size_t)kNB * TC + 3 * (size_t)p.dstate * ROWS);
+    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES>;
+    static size_t smem_enabled = 48 * 1024;  // per instantiation; raised once when a launch needs more
+    if (smem > smem_enabled) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        smem_enabled = smem;
+    }
+    const dim3 grid((unsigned)(p.batch * p.n_groups * tiles));
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
+    return (int)hipGetLastError();
+}
+
+// variant table: (lanes per row, items per lane, waves per workgroup)
+//   0: 64 x 8  x 8   (TC  512,  8 rows/WG)   many waves for small batches
+//   1: 32 x 16 x 8   (TC  512, 16 rows/WG)
+//   2: 16 x 16 x 4   (TC  256, 16 rows/WG)   fewest scan steps, needs many rows
+//   3: 64 x 16 x 8   (TC 1024,  8 rows/WG)
+//   4: 64 x 4  x 4   (TC  256,  4 rows/WG)   short sequences / few rows per group
+template <typename T>
+int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t stream) {
+    switch (variant) {
+        case 0: return launch_fwd<T, 64, 8, 8>(p, stream);
+        case 1: return launch_fwd<T, 32, 16, 8>(p, stream);
+        case 2: return launch_fwd<T, 16, 16, 4>(p, stream);
+        case 3: return launch_fwd<T, 64, 16, 8>(p, stream);
+        default: return launch_fwd<T, 64, 4, 4>(p, stream);
+    }
+}
+
+template int scan_fwd_dispatch<float>(const oss_scan_fwd_params &, int, hipStream_t);
+template int scan_fwd_dispatch<bf16_t>(const oss_scan_fwd_params &, int, hipStream_t);
+template int scan_fwd_dispatch<f16_t>(const oss_scan_fwd_params &, int, hipStream_t);
+
+}  // namespace oss

@@ -1,0 +1,174 @@
+"""Torch-facing boundary of the HIP selective scan: ``torch.ops.vmambair.selective_scan_fwd / _bwd``.
+
+Mirrors the host half of the reference's native module
+(Mamba/kernels/selective_scan/csrc/selective_scan/cus/selective_scan.cpp:157-349): the same
+positional signature, the same dtype / shape / stride checks raising ``RuntimeError``
+(TORCH_CHECK, :165-215, :256-316), outputs allocated by the callee (:218-220, :319-327), launch
+on the current stream of ``u``'s device without host synchronisation (:232-233).  Differences,
+all invisible to callers:
+  * ``x`` holds one saved state every ``scan_chunk()`` = 256 steps instead of 2048;
+  * ``bwd`` needs no zero-filled outputs and returns ``dB``/``dC`` already in the input dtype
+    (the reference zero-fills five tensors and casts two, :319-327,347);
+  * ``nrows`` is accepted and ignored (the reference archs always end up with 1,
+    SRGAN/VmambaIR/archs/MambaSISR6_arch.py:57,69).
+
+No CPU implementation exists: CPU tensors are rejected exactly as the reference rejects them
+(``TORCH_CHECK(u.is_cuda())``, :174).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _capi
+
+_DT = {torch.float32: _capi.OSS_F32, torch.float16: _capi.OSS_F16, torch.bfloat16: _capi.OSS_BF16}
+
+
+def scan_chunk() -> int:
+    """Time steps between two saved states in ``x``."""
+    return int(_capi.load().oss_scan_chunk())
+
+
+def _check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _common_checks(u, delta, A, B, C, D, delta_bias):
+    # selective_scan.cpp:165-215
+    _check(u.dtype in _DT, "u must be float32, float16 or bfloat16")
+    _check(A.dtype == torch.float32, "A must be float32")
+    _check(delta.dtype == u.dtype and B.dtype == u.dtype and C.dtype == u.dtype,
+           "delta, B, C must have u's dtype")
+    for name, t in (("u", u), ("delta", delta), ("A", A), ("B", B), ("C", C)):
+        _check(t.is_cuda, f"{name} must be a CUDA/HIP tensor")
+    _check(u.dim() == 3, "u must be (batch, dim, seqlen)")
+    batch, dim, seqlen = u.shape
+    _check(A.dim() == 2 and A.shape[0] == dim, "A must be (dim, dstate)")
+    dstate = A.shape[1]
+    _check(B.dim() == 4 and C.dim() == 4, "B and C must be (batch, n_groups, dstate, seqlen)")
+    n_groups = B.shape[1]
+    _check(n_groups > 0 and dim % n_groups == 0, "dims should be dividable by n_groups")
+    _check(dstate <= 256, "selective_scan only supports state dimension <= 256")
+    _check(tuple(delta.shape) == (batch, dim, seqlen), "delta must have u's shape")
+    _check(tuple(B.shape) == (batch, n_groups, dstate, seqlen), "B has the wrong shape")
+    _check(tuple(C.shape) == (batch, n_groups, dstate, seqlen), "C has the wrong shape")
+    for name, t in (("u", u), ("delta", delta), ("B", B), ("C", C)):
+        _check(t.stride(-1) == 1 or t.size(-1) == 1, f"{name} must be contiguous in its last dimension")
+    _check(A.stride(-1) == 1 or A.size(-1) == 1, "A must be contiguous in its last dimension")
+    for name, t in (("D", D), ("delta_bias", delta_bias)):
+        if t is not None:
+            _check(t.dtype == torch.float32, f"{name} must be float32")
+            _check(t.is_cuda, f"{name} must be a CUDA/HIP tensor")
+            _check(tuple(t.shape) == (dim,), f"{name} must be (dim,)")
+            _check(t.stride(-1) == 1 or t.size(-1) == 1, f"{name} must be contiguous")
+    _check(all(t.device == u.device for t in (delta, A, B, C) + tuple(t for t in (D, delta_bias) if t is not None)),
+           "all tensors must be on the same device")
+    return batch, dim, seqlen, dstate, n_groups
+
+
+def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus):
+    batch, dim, seqlen, dstate, n_groups = dims
+    P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, seqlen, dstate, n_groups
+    P.delta_softplus = 1 if delta_softplus else 0
+    P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
+    P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
+    if out is not None:
+        P.out_batch_stride, P.out_d_stride = out.stride(0), out.stride(1)
+    P.A_d_stride = A.stride(0)
+    P.B_batch_stride, P.B_group_stride, P.B_dstate_stride = B.stride(0), B.stride(1), B.stride(2)
+    P.C_batch_stride, P.C_group_stride, P.C_dstate_stride = C.stride(0), C.stride(1), C.stride(2)
+    P.u, P.delta, P.A, P.B, P.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
+    P.D, P.delta_bias = _ptr(D), _ptr(delta_bias)
+    P.out, P.x = _ptr(out), _ptr(x)
+
+
+def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
+                       D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], delta_softplus: bool,
+                       nrows: int = 1) -> List[torch.Tensor]:
+    """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``."""
+    dims = _common_checks(u, delta, A, B, C, D, delta_bias)
+    batch, dim, seqlen, dstate, _ = dims
+    lib = _capi.load()
+    n_chunks = int(lib.oss_scan_num_chunks(seqlen))
+    out = torch.empty_like(delta)
+    if out.stride(-1) != 1 and out.size(-1) != 1:
+        out = torch.empty(delta.shape, dtype=delta.dtype, device=delta.device)
+    x = torch.empty((batch, dim, n_chunks, 2 * dstate), dtype=torch.float32, device=u.device)
+    P = _capi.ScanFwdParams()
+    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus)
+    with torch.cuda.device(u.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_scan_fwd(P, _DT[u.dtype], stream), "oss_scan_fwd")
+    return [out, x]
+
+
+def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
+                       D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], dout: torch.Tensor,
+                       x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1) -> List[Optional[torch.Tensor]]:
+    """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
+    ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent)."""
+    dims = _common_checks(u, delta, A, B, C, D, delta_bias)
+    batch, dim, seqlen, dstate, n_groups = dims
+    _check(dout.dtype == u.dtype and dout.is_cuda, "dout must be a CUDA/HIP tensor of u's dtype")
+    _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have u's shape")
+    _check(dout.stride(-1) == 1 or dout.size(-1) == 1, "dout must be contiguous in its last dimension")
+    lib = _capi.load()
+    n_chunks = int(lib.oss_scan_num_chunks(seqlen))
+    if n_chunks > 1:
+        _check(x is not None, "x is required when the sequence spans several chunks")
+    if x is not None:
+        _check(x.dtype == torch.float32 and x.is_cuda and x.is_contiguous(), "x must be a contiguous float32 tensor")
+        _check(tuple(x.shape) == (batch, dim, n_chunks, 2 * dstate), "x has the wrong shape")
+    du = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
+    ddelta = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
+    dA = torch.empty((dim, dstate), dtype=torch.float32, device=u.device)
+    dB = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
+    dC = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
+    dD = torch.empty((dim,), dtype=torch.float32, device=u.device) if D is not None else None
+    dbias = torch.empty((dim,), dtype=torch.float32, device=u.device) if delta_bias is not None else None
+    ws_bytes = int(lib.oss_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, n_groups))
+    ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.float32, device=u.device)
+    P = _capi.ScanBwdParams()
+    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus)
+    P.dout_batch_stride, P.dout_d_stride = dout.stride(0), dout.stride(1)
+    P.du_batch_stride, P.du_d_stride = du.stride(0), du.stride(1)
+    P.ddelta_batch_stride, P.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
+    P.dout, P.du, P.ddelta, P.dA = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), dA.data_ptr()
+    P.dB, P.dC, P.dD, P.ddelta_bias = dB.data_ptr(), dC.data_ptr(), _ptr(dD), _ptr(dbias)
+    P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    with torch.cuda.device(u.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
+    return [du, ddelta, dA, dB, dC, dD, dbias]
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.ops registration (GPU dispatch key only -- there is deliberately no CPU kernel)
+# ---------------------------------------------------------------------------------------------
+_LIB = torch.library.Library("vmambair", "DEF")
+_LIB.define("selective_scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, "
+            "Tensor? delta_bias, bool delta_softplus, int nrows) -> Tensor[]")
+_LIB.define("selective_scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, "
+            "Tensor? delta_bias, Tensor dout, Tensor? x, bool delta_softplus, int nrows) -> Tensor[]")
+
+
+def _fwd_op(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows):
+    return selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+
+
+def _bwd_op(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows):
+    res = selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows)
+    # Tensor[] cannot hold None: absent dD / ddelta_bias come back as empty tensors, like the
+    # reference's undefined at::Tensor (cus/selective_scan.cpp:323-326)
+    return [t if t is not None else u.new_empty(0, dtype=torch.float32) for t in res]
+
+
+_LIB.impl("selective_scan_fwd", _fwd_op, "CUDA")
+_LIB.impl("selective_scan_bwd", _bwd_op, "CUDA")

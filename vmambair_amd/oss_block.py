@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's OSS block: ``LayerNorm``, ``FeedForward`` (EFFN),
+``SS2D_1`` (Omni Selective Scan module: four spatial + two channel scan directions) and
+``MamberBlock``.
+
+Reference (read for behaviour, nothing copied):
+  SRGAN/VmambaIR/archs/MambaSISR6_arch.py:144-218 (LayerNorm, FeedForward), :222-498 (SS2D_1),
+  :502-515 (MamberBlock); Deraining/basicsr/models/archs/mamber32_arch.py:491-492 (additive
+  channel gate), mamber33_arch.py:257,487-490 (dc_inner = 2); RealSR/VmambaIR/archs/
+  MambaRealSR11_arch.py:478-534,582-657,806-817 (rank-ceil(D/16) channel scan with one row per
+  direction, S4D-initialised Ac_logs).
+
+Parameter names, shapes and initial distributions are the reference's, so released checkpoints
+(``{'params': ...}`` state dicts) load with ``strict=True``.  Both scans go through
+``vmambair_amd.selective_scan.selective_scan_fn`` -> ``torch.ops.vmambair`` (HIP only).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .selective_scan import SelectiveScanFP32, selective_scan_fn
+
+#: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
+VARIANTS = {
+    "srgan": dict(dc_inner=4, gate="mul_add"),     # MambaSISR6_arch.py:263,495-496
+    "mamber32": dict(dc_inner=4, gate="add"),      # mamber32_arch.py:260,491-492
+    "mamber33": dict(dc_inner=2, gate="mul_add"),  # mamber33_arch.py:257,487-490
+    "realsr": dict(dc_inner=None, gate="mul_add"), # MambaRealSR11_arch.py:589,806-817
+}
+
+
+class _LNBody(nn.Module):
+    def __init__(self, dim: int, with_bias: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        if with_bias:
+            self.bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.bias = None
+
+
+class LayerNorm(nn.Module):
+    """Per-pixel LayerNorm over the channel axis of an NCHW tensor, biased variance, eps 1e-5
+    (MambaSISR6_arch.py:144-195; ``BiasFree`` divides by sqrt(var + eps) without centring, :162-164)."""
+
+    def __init__(self, dim: int, LayerNorm_type: str = "WithBias"):
+        super().__init__()
+        self.with_bias = LayerNorm_type != "BiasFree"
+        self.body = _LNBody(dim, self.with_bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        xt = x.permute(0, 2, 3, 1)
+        if self.with_bias:
+            y = F.layer_norm(xt, (xt.shape[-1],), self.body.weight, self.body.bias, 1e-5)
+        else:
+            var = xt.var(-1, keepdim=True, unbiased=False)
+            y = xt / torch.sqrt(var + 1e-5) * self.body.weight
+        return y.permute(0, 3, 1, 2)
+
+
+class FeedForward(nn.Module):
+    """EFFN: 1x1 (D -> 2h) -> depth-wise 3x3 -> gelu(x1) * x2 -> 1x1 (h -> D), h = int(D * factor)
+    (MambaSISR6_arch.py:201-218)."""
+
+    def __init__(self, dim: int, ffn_expansion_factor: float, bias: bool):
+        super().__init__()
+        hidden = int(dim * ffn_expansion_factor)
+        self.project_in = nn.Conv2d(dim, hidden * 2, kernel_size=1, bias=bias)
+        self.dwconv = nn.Conv2d(hidden * 2, hidden * 2, kernel_size=3, stride=1, padding=1, groups=hidden * 2, bias=bias)
+        self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x1, x2 = self.dwconv(self.project_in(x)).chunk(2, dim=1)
+        return self.project_out(F.gelu(x1) * x2)
+
+
+def _dt_proj_init(dt_rank: int, d_inner: int, dt_scale=1.0, dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
+    """dt projection init (MambaSISR6_arch.py:337-362): weight U(-r^-0.5, r^-0.5); bias =
+    softplus^-1 of dt ~ logU[dt_min, dt_max]."""
+    std = dt_rank ** -0.5 * dt_scale
+    weight = torch.empty(d_inner, dt_rank).uniform_(-std, std)
+    dt = torch.exp(torch.rand(d_inner) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min)).clamp(min=dt_init_floor)
+    bias = dt + torch.log(-torch.expm1(-dt))
+    return weight, bias
+
+
+def _a_log_init(d_state: int, rows: int) -> torch.Tensor:
+    """S4D-real: A_log[d, n] = log(n + 1) (MambaSISR6_arch.py:365-379)."""
+    return torch.log(torch.arange(1, d_state + 1, dtype=torch.float32)).repeat(rows, 1).contiguous()
+
+
+class SS2D_1(nn.Module):
+    """Omni Selective Scan module.  ``variant`` selects the reference tree (see VARIANTS)."""
+
+    def __init__(self, d_model: int = 96, d_state: int = 16, ssm_ratio: float = 2.0, dt_rank="auto",
+                 d_conv: int = 3, conv_bias: bool = True, variant: str = "srgan", **kwargs):
+        super().__init__()
+        cfg = VARIANTS[variant]
+        self.variant = variant
+        self.gate = cfg["gate"]
+        d_expand = int(ssm_ratio * d_model)
+        d_inner = int(min(2.0, ssm_ratio) * d_model)  # ssm_rank_ratio = 2.0 (MambaSISR6_arch.py:229,256-257)
+        assert d_inner == d_expand, "low-rank SSM (d_inner < d_expand) is not used by any reference config"
+        self.d_model, self.d_inner, self.d_state = d_model, d_inner, d_state
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        self.K, self.KC = 4, 2
+        R, N = self.dt_rank, d_state
+
+        self.in_conv = nn.Conv2d(d_model, d_expand * 2, kernel_size=1)
+        self.conv2d = nn.Conv2d(d_expand, d_expand, groups=d_expand, bias=conv_bias, kernel_size=d_conv,
+                                padding=(d_conv - 1) // 2)
+        self.out_norm = LayerNorm(d_inner, "WithBias")
+        self.channel_norm = LayerNorm(d_inner, "WithBias")
+        self.out_conv = nn.Conv2d(d_expand, d_model, kernel_size=1)
+
+        # spatial branch parameters (MambaSISR6_arch.py:299-326)
+        self.x_proj_weight = nn.Parameter(torch.stack(
+            [nn.Linear(d_inner, R + 2 * N, bias=False).weight.detach() for _ in range(self.K)], dim=0))
+        inits = [_dt_proj_init(R, d_inner) for _ in range(self.K)]
+        self.dt_projs_weight = nn.Parameter(torch.stack([w for w, _ in inits], dim=0))
+        self.dt_projs_bias = nn.Parameter(torch.stack([b for _, b in inits], dim=0))
+        self.A_logs = nn.Parameter(_a_log_init(N, self.K * d_inner))
+        self.Ds = nn.Parameter(torch.ones(self.K * d_inner))
+        self.A_logs._no_weight_decay = True
+        self.Ds._no_weight_decay = True
+
+        # channel branch parameters
+        self.dc_inner = cfg["dc_inner"]
+        if self.dc_inner is not None:  # SRGAN / Deraining (MambaSISR6_arch.py:263-268,306-312,330-333)
+            dc, Rc = self.dc_inner, 6
+            self.dtc_rank, self.dc_state = Rc, 16
+            self.conv_cin = nn.Conv2d(1, dc, kernel_size=1)
+            self.conv_cout = nn.Conv2d(dc, 1, kernel_size=1)
+            self.xc_proj_weight = nn.Parameter(torch.stack(
+                [nn.Linear(dc, Rc + 2 * 16, bias=False).weight.detach() for _ in range(self.KC)], dim=0))
+            self.Dsc = nn.Parameter(torch.ones(self.KC * dc))
+            self.Ac_logs = nn.Parameter(torch.randn(self.KC * dc, 16))
+            self.dtc_projs_weight = nn.Parameter(torch.randn(self.KC, dc, Rc))
+            self.dtc_projs_bias = nn.Parameter(torch.randn(self.KC, dc))
+        else:  # RealSR (MambaRealSR11_arch.py:627-657): one row per direction, rank R, S4D init
+            self.dtc_rank, self.dc_state = R, N
+            self.xc_proj_weight = nn.Parameter(torch.stack(
+                [nn.Linear(1, R + 2 * N, bias=False).weight.detach() for _ in range(self.KC)], dim=0))
+            cinits = [_dt_proj_init(R, 1) for _ in range(self.KC)]
+            self.dtc_projs_weight = nn.Parameter(torch.stack([w for w, _ in cinits], dim=0))
+            self.dtc_projs_bias = nn.Parameter(torch.stack([b for _, b in cinits], dim=0))
+            self.Ac_logs = nn.Parameter(_a_log_init(N, self.KC))
+            self.Dsc = nn.Parameter(torch.ones(self.KC))
+            self.Ac_logs._no_weight_decay = True
+            self.Dsc._no_weight_decay = True
+
+    # -- four spatial directions (MambaSISR6_arch.py:395-436; index maps: SURVEY.md Appendix B) --
+    def forward_core(self, x: torch.Tensor) -> torch.Tensor:
+        B, Cc, H, W = x.shape
+        L = H * W
+        R, N = self.dt_rank, self.d_state
+        hw = x.flatten(2, 3)
+        wh = x.transpose(2, 3).contiguous().flatten(2, 3)
+        fwd2 = torch.stack([hw, wh], dim=1)
+        xs = torch.cat([fwd2, fwd2.flip(-1)], dim=1)                                   # (B, 4, D, L)
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        out_y = selective_scan_fn(
+            xs.reshape(B, -1, L), dts.contiguous().view(B, -1, L), -torch.exp(self.A_logs.float()), Bs, Cs, self.Ds,
+            delta_bias=self.dt_projs_bias.view(-1), delta_softplus=True).view(B, 4, -1, L)
+        # merge, in the reference's association order ((y0 + flip y2) + T y1) + T flip y3, fp32
+        inv = out_y[:, 2:4].flip(-1)
+        wh_y = out_y[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        invwh_y = inv[:, 1].reshape(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        y = out_y[:, 0].float() + inv[:, 0].float() + wh_y.float() + invwh_y.float()
+        return self.out_norm(y.view(B, Cc, H, W)).to(x.dtype)
+
+    # -- two channel directions over the pooled descriptor (MambaSISR6_arch.py:438-483) --
+    def cforward_core(self, xc: torch.Tensor) -> torch.Tensor:
+        b, d, h, w = xc.shape
+        pooled = xc.mean(dim=(2, 3))                                                    # (b, d)
+        if self.dc_inner is not None:
+            seq = pooled.view(b, 1, d, 1)
+            seq = self.conv_cin(seq).squeeze(-1)                                        # (b, dc, L = d)
+            scan = selective_scan_fn
+        else:
+            seq = pooled.view(b, 1, d)                                                  # (b, 1, L = d)
+            scan = SelectiveScanFP32.apply
+        Bn, Dn, L = seq.shape
+        Rc, N = self.dtc_rank, self.dc_state
+        xsc = torch.stack([seq, seq.flip(-1)], dim=1)                                   # (b, 2, dc, L)
+        xc_dbl = torch.einsum("bkdl,kcd->bkcl", xsc, self.xc_proj_weight)
+        dts, Bs, Cs = torch.split(xc_dbl, [Rc, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dtc_projs_weight).contiguous()
+        As = -torch.exp(self.Ac_logs.float())
+        if self.dc_inner is None:  # MambaRealSR11_arch.py:513-519: everything in fp32
+            args = (xsc.reshape(Bn, -1, L).float(), dts.view(Bn, -1, L).float(), As, Bs.contiguous().float(),
+                    Cs.contiguous().float(), self.Dsc.float(), self.dtc_projs_bias.view(-1).float(), True, 1)
+        else:
+            args = (xsc.reshape(Bn, -1, L), dts.view(Bn, -1, L), As, Bs, Cs, self.Dsc,
+                    self.dtc_projs_bias.view(-1), True, 1)
+        out_y = scan(*args).view(Bn, 2, -1, L)
+        y = out_y[:, 0].float() + out_y[:, 1].flip(-1).float()                           # (b, dc, L)
+        if self.dc_inner is not None:
+            y = self.conv_cout(y.unsqueeze(-1))                                         # (b, 1, L, 1)
+            y = y.transpose(1, 2).contiguous()                                          # (b, L = d, 1, 1)
+        else:
+            y = y.transpose(1, 2).unsqueeze(2).contiguous()                             # (b, d, 1, 1)
+        return self.channel_norm(y).to(xc.dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        xz = self.in_conv(x)
+        x, z = xz.chunk(2, dim=1)
+        z = F.silu(z)
+        x = F.silu(self.conv2d(x))
+        y2 = self.forward_core(x) * z
+        c = self.cforward_core(y2)
+        y2 = (y2 + c) if self.gate == "add" else (y2 * c + y2)
+        return self.out_conv(y2)
+
+
+class MamberBlock(nn.Module):
+    """x += SS2D_1(norm1(x)); x += EFFN(norm2(x))   (MambaSISR6_arch.py:502-515)."""
+
+    def __init__(self, dim: int, num_heads: int = 1, ffn_expansion_factor: float = 2.66, bias: bool = False,
+                 LayerNorm_type: str = "WithBias", variant: str = "srgan"):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, LayerNorm_type)
+        self.attn = SS2D_1(d_model=dim, ssm_ratio=1, variant=variant)
+        self.norm2 = LayerNorm(dim, LayerNorm_type)
+        self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x + self.attn(self.norm1(x))
+        x = x + self.ffn(self.norm2(x))
+        return x

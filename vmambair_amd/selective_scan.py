@@ -1,0 +1,83 @@
+"""Autograd boundary of the selective scan -- host-side mirror of the reference's
+``SelectiveScanFn`` / ``selective_scan_fn_v1`` (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:24-96;
+identical copies in Deraining/basicsr/models/archs/mamber32_arch.py:20-84 and
+RealSR/VmambaIR/archs/MambaRealSR11_arch.py:34-98) and of the AMP-aware ``SelectiveScan``
+(MambaRealSR11_arch.py:267-322).
+
+Same argument meaning and the same normalisations before the native call: last dimension made
+contiguous, 3-D ``B``/``C`` lifted to one group, ``D`` / ``delta_bias`` cast to fp32, the
+``dim % (n_groups * nrows) == 0`` assertion, backward always with ``nrows = 1``.  The native call
+goes through ``torch.ops.vmambair`` (HIP only).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops  # noqa: F401  (registers torch.ops.vmambair)
+
+
+def _last_contig(t: torch.Tensor) -> torch.Tensor:
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1):
+        u, delta, B, C = _last_contig(u), _last_contig(delta), _last_contig(B), _last_contig(C)
+        if D is not None:
+            D = D.contiguous()
+        ctx.squeeze_B = B.dim() == 3
+        ctx.squeeze_C = C.dim() == 3
+        if ctx.squeeze_B:
+            B = B.unsqueeze(1)
+        if ctx.squeeze_C:
+            C = C.unsqueeze(1)
+        ctx.d_dtype = None if D is None else D.dtype
+        ctx.bias_dtype = None if delta_bias is None else delta_bias.dtype
+        if D is not None and D.dtype != torch.float32:
+            D = D.float()
+        if delta_bias is not None and delta_bias.dtype != torch.float32:
+            delta_bias = delta_bias.float()
+        assert u.shape[1] % (B.shape[1] * nrows) == 0
+        assert nrows in (1, 2, 3, 4)
+        out, x, *_ = torch.ops.vmambair.selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+        ctx.delta_softplus = delta_softplus
+        ctx.nrows = nrows
+        ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
+        dout = _last_contig(dout)
+        du, ddelta, dA, dB, dC, dD, ddelta_bias, *_ = torch.ops.vmambair.selective_scan_bwd(
+            u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, 1)
+        if ctx.squeeze_B:
+            dB = dB.squeeze(1)
+        if ctx.squeeze_C:
+            dC = dC.squeeze(1)
+        dD = None if D is None else (dD if dD.dtype == ctx.d_dtype else dD.to(ctx.d_dtype))
+        ddelta_bias = None if delta_bias is None else (
+            ddelta_bias if ddelta_bias.dtype == ctx.bias_dtype else ddelta_bias.to(ctx.bias_dtype))
+        return du, ddelta, dA, dB, dC, dD, ddelta_bias, None, None
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1):
+    """Reference name: ``selective_scan_fn_v1`` (MambaSISR6_arch.py:91-96).  The gradient with
+    respect to the last state is not propagated, as in the reference."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+
+
+class SelectiveScanFP32(torch.autograd.Function):
+    """The RealSR variant: inputs are cast to fp32 under autocast before the scan
+    (``custom_fwd(cast_inputs=torch.float32)``, MambaRealSR11_arch.py:267-322)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1):
+        return SelectiveScanFn.forward(ctx, u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dout, *args):
+        return SelectiveScanFn.backward(ctx, dout, *args)
