@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of one ×4 SR 64×64→256×256 TRAINING step of the full VmambaIR UNet
+(BASELINE.json ``metric``; workload = ``configs[1]``: MambaSISR6 dim 48, blocks [15,1,1,1] + 15
+refinement, bf16 autocast, batch 8 per MI355X, fwd + L1 loss + bwd + Adam + EMA, exactly the
+reference step: SRGAN/options/MambaSISR15_x4.yml:55-90, SRGAN/VmambaIR/models/MambaSISR_model.py:120-147).
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N ...``: one process per
+  GPU, DDP over RCCL, the image batch sharded by rank (per-GPU batch fixed => weak scaling).
+Prints ONE JSON line on rank 0 with the metric, ``roofline`` (dominant scan kernel: algorithmic
+bytes / HIP-event kernel time, measured inside the timed region by the library's own events) and
+``cpu_baseline`` (the same training step on the host cores with the CPU oracle as the scan, N = 1
+only, one batch-1 step).  Synthetic data, random-init weights (no network on the box).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NET = dict(type="MambaSISR6", inp_channels=3, out_channels=3, dim=48, num_blocks=[15, 1, 1, 1],
+           num_refinement_blocks=15, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
+           LayerNorm_type="WithBias")
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_step(net, ema_params, opt, autocast_dtype, device_type):
+    params = [p for p in net.parameters()]
+
+    def step(lq, gt):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast(device_type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+            out = net(lq)
+        loss = F.l1_loss(out.float(), gt)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():  # model_ema(decay=0.999), MambaSISR_model.py:146-147
+            torch._foreach_mul_(ema_params, 0.999)
+            torch._foreach_add_(ema_params, [p.detach() for p in params], alpha=0.001)
+        return loss
+
+    return step
+
+
+def collect_prof(lib):
+    """all non-empty profiler buckets -> list of dicts"""
+    recs = []
+    for which in (0, 1):
+        for variant in range(8):
+            for io, name in ((0, "f32"), (1, "f16"), (2, "bf16")):
+                ms, n, by = C.c_double(), C.c_longlong(), C.c_double()
+                if lib.oss_prof_collect(which, variant, io, C.byref(ms), C.byref(n), C.byref(by)) != 0:
+                    continue
+                if n.value:
+                    recs.append(dict(kernel="oss_scan_fwd_kernel" if which == 0 else "oss_scan_bwd_kernel",
+                                     variant=variant, io=name, launches=n.value, total_ms=ms.value, alg_bytes=by.value))
+    return recs
+
+
+def cpu_baseline(seed=0):
+    """One batch-1 training step of the same net on the host cores, scans routed to the CPU oracle
+    (oracle/, the restatement of the reference's sequential selective_scan).  kind = "port"."""
+    from oracle import oss_oracle
+    from vmambair_amd.archs import build_network
+    import vmambair_amd.ops as ops
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oss_oracle.set_threads(cores)
+    chunk = ops.scan_chunk()
+    lib = torch.library.Library("vmambair", "IMPL")
+    lib.impl("selective_scan_fwd",
+             lambda u, d, A, B, Cc, D, b, sp, nr: oss_oracle.scan_fwd(u, d, A, B, Cc, D, b, sp, nr, chunk=chunk), "CPU")
+    lib.impl("selective_scan_bwd",
+             lambda u, d, A, B, Cc, D, b, g, x, sp, nr: [t if t is not None else torch.empty(0) for t in
+                                                        oss_oracle.scan_bwd(u, d, A, B, Cc, D, b, g, x, sp, nr)], "CPU")
+    torch.manual_seed(seed)
+    net = build_network(NET)
+    ema = [p.detach().clone() for p in net.parameters()]
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99))
+    step = make_step(net, ema, opt, None, "cpu")
+    lq, gt = torch.rand(1, 3, 64, 64), torch.rand(1, 3, 256, 256)
+    t0 = time.perf_counter()
+    step(lq, gt)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 training step (fwd+bwd+Adam+EMA), batch 1, 64x64 LQ, fp32, whole MambaSISR6 net; "
+                      "scan = oracle/oss_scan_oracle.c (OpenMP), rest = torch CPU", "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP scan has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vmambair_amd import _capi
+    from vmambair_amd.archs import build_network
+    lib = _capi.load()
+
+    torch.manual_seed(0)
+    net = build_network(NET).to(dev)
+    ema = [p.detach().clone() for p in net.parameters()]
+    model = net
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=50,
+                                                          gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
+    acdt = torch.bfloat16 if args.dtype == "bf16" else None
+    step = make_step(model, ema, opt, acdt, "cuda")
+
+    B = args.batch_per_gpu
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank shard of the synthetic batch
+    lq = torch.rand(B, 3, 64, 64, device=dev, generator=g)
+    gt = torch.rand(B, 3, 256, 256, device=dev, generator=g)
+
+    for _ in range(args.warmup):
+        step(lq, gt)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib.oss_prof_reset()
+    lib.oss_prof_enable(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(lq, gt)
+    fence()
+    dt = time.perf_counter() - t0
+    lib.oss_prof_enable(0)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        recs = collect_prof(lib)
+        roof = None
+        if recs:
+            dom = max(recs, key=lambda r: r["total_ms"])
+            avg_ms = dom["total_ms"] / dom["launches"]
+            achieved = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "kernel": f"{dom['kernel']} variant {dom['variant']} io {dom['io']}",
+                    "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+                    "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
+                    "all_scan_kernels": [
+                        {"kernel": r["kernel"], "variant": r["variant"], "io": r["io"], "launches": r["launches"],
+                         "avg_ms": round(r["total_ms"] / r["launches"], 4),
+                         "alg_GBps": round(r["alg_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in recs],
+                    "scan_ms_per_step": round(sum(r["total_ms"] for r in recs) / args.steps, 3)}
+        # achievable HBM bandwidth, same run (copy kernel, 1 GiB)
+        n = 1 << 30
+        src = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+        dst = torch.empty_like(src)
+        st = torch.cuda.current_stream().cuda_stream
+        lib.oss_hbm_copy(src.data_ptr(), dst.data_ptr(), n, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            lib.oss_hbm_copy(src.data_ptr(), dst.data_ptr(), n, st)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        if roof is not None:
+            roof["copy_kernel_GBps"] = round(copy_gbps, 1)
+        del src, dst
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline()
+            except Exception as e:  # the headline number must survive a broken baseline leg
+                cpu = {"error": str(e)[:200]}
+
+        images = world * B * args.steps
+        line = {
+            "metric": "images/sec, x4 SR 64->256 training step (fwd+bwd+Adam+EMA), full VmambaIR UNet",
+            "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: x4 SR 64x64 LQ, MambaSISR6 dim48 [15,1,1,1]+15, "
+                                   f"{args.dtype} autocast (scan arithmetic f32), batch {B} per GPU",
+                       "global_batch": world * B, "per_gpu_batch": B, "lq": [64, 64], "gt": [256, 256],
+                       "parallelism": f"dp{world}", "optimizer": "Adam 2e-4 (0.9,0.99) + EMA 0.999", "loss": "L1"},
+            "final_loss": round(loss_val, 5), "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

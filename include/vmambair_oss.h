@@ -105,6 +105,17 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
 void oss_scan_set_variant(int fwd_variant, int bwd_variant);
 int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
 
+/* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every
+ * main forward / backward kernel launch is bracketed by HIP events recorded on the launch stream.
+ * oss_prof_collect synchronises those events and returns, for one bucket (which: 0 = forward
+ * kernel, 1 = backward kernel; variant; io dtype), the summed kernel time, the number of launches
+ * and the summed ALGORITHMIC bytes (SURVEY.md section 8d formulas).
+ * Returns 0, or OSS_ERR_SHAPE for a bucket out of range. */
+void oss_prof_enable(int on);
+void oss_prof_reset(void);
+int oss_prof_collect(int which, int variant, oss_dtype io, double *total_ms, long long *launches,
+                     double *algorithmic_bytes);
+
 /* HBM copy-kernel (float4 read+write) used by bench.py to measure the achievable bandwidth in
  * the same run as the scan kernels; copies n_bytes (multiple of 16) from src to dst. */
 int oss_hbm_copy(const void *src, void *dst, size_t n_bytes, oss_stream_t stream);

@@ -1,0 +1,323 @@
+"""GPU parity tests of the HIP selective scan, THROUGH THE C ABI (vmambair_amd.ops -> ctypes ->
+libvmambair_oss.so), against the CPU oracle on the same seeded inputs and against the golden
+vectors of the reference.
+
+The grid is the reference's own (Mamba/kernels/selective_scan/test_selective_scan.py:365-502):
+itype x seqlen x delta_bias x softplus x D x groups, inputs ``A = -0.5 rand``, ``delta = 0.5 rand``,
+others ``randn``, seed 0 -- with ``dstate = 16`` (the only value the archs use) added to the
+reference's ``dstate = 1``, odd / multi-chunk lengths, strided B/C views and ragged row tiles.
+Tolerances are the reference's (:398-401,490-502) and are written next to each comparison.
+"""
+import itertools
+
+import pytest
+import torch
+
+from conftest import assert_close, golden_files, load_golden
+import vmambair_amd
+from vmambair_amd import _capi
+from oracle import oss_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+TOL = {  # (rtol, atol) per input type -- test_selective_scan.py:398-400
+    torch.float32: (6e-4, 2e-3),
+    torch.float16: (3e-3, 5e-3),
+    torch.bfloat16: (3e-2, 5e-2),
+}
+RTOLW, ATOLW = 1e-3, 1e-3  # :401
+
+
+def make_inputs(batch, dim, N, G, L, itype, has_D=True, has_bias=True, seed=0, delta_scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    A = -0.5 * torch.rand(dim, N, generator=g)
+    B = torch.randn(batch, G, N, L, generator=g).to(itype)
+    C = torch.randn(batch, G, N, L, generator=g).to(itype)
+    D = torch.randn(dim, generator=g) if has_D else None
+    bias = 0.5 * torch.rand(dim, generator=g) if has_bias else None
+    u = torch.randn(batch, dim, L, generator=g).to(itype)
+    delta = (delta_scale * torch.rand(batch, dim, L, generator=g)).to(itype)
+    dout = torch.randn(batch, dim, L, generator=g).to(itype)
+    return u, delta, A, B, C, D, bias, dout
+
+
+def to_dev(ts):
+    return [t.to(DEV) if t is not None else None for t in ts]
+
+
+def check_fwd_bwd(cpu_inputs, softplus, itype, fwd_variant=-1, bwd_variant=-1, tight=True):
+    u, delta, A, B, C, D, bias, dout = cpu_inputs
+    lib = _capi.load()
+    lib.oss_scan_set_variant(fwd_variant, bwd_variant)
+    try:
+        du_, dl_, A_, B_, C_, D_, b_, g_ = to_dev(cpu_inputs)
+        out, x = vmambair_amd.selective_scan_fwd(du_, dl_, A_, B_, C_, D_, b_, softplus, 1)
+        grads = vmambair_amd.selective_scan_bwd(du_, dl_, A_, B_, C_, D_, b_, g_, x, softplus, 1)
+        torch.cuda.synchronize()
+    finally:
+        lib.oss_scan_set_variant(-1, -1)
+    chunk = vmambair_amd.scan_chunk()
+    ref_out, ref_x = oss_oracle.scan_fwd(u, delta, A, B, C, D, bias, softplus, chunk=chunk)
+    ref = oss_oracle.scan_bwd(u, delta, A, B, C, D, bias, dout, None, softplus)
+    rtol, atol = TOL[itype]
+    assert out.dtype == itype and x.dtype == torch.float32
+    assert_close(out, ref_out, rtol, atol, "out")
+    assert_close(x[..., 1::2], ref_x[..., 1::2], 6e-4, 2e-3, "x states")       # every saved state
+    assert_close(x[..., 0::2], ref_x[..., 0::2], 1e-3, 1e-6, "x running product")
+    names = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"]
+    tols = [(rtol * 2, atol * 2), (rtol * 5, atol * 10), (RTOLW, ATOLW * 5), (rtol, atol), (rtol, atol),
+            (RTOLW, ATOLW), (RTOLW, ATOLW)]  # :490-502
+    for n, got, want, (rt, at) in zip(names, grads, ref, tols):
+        if want is None:
+            assert got is None, n
+            continue
+        if itype != torch.float32 and n in ("dA", "dD", "ddelta_bias"):
+            # sums of L*batch rounded terms: scale the absolute tolerance with the magnitude
+            at = max(at, 2e-3 * float(want.abs().max()))
+        assert_close(got, want, rt, at, n)
+    if tight and itype == torch.float32:
+        # both are fp32 implementations of the same recurrence: they agree far inside the contract
+        assert_close(out, ref_out, 1e-4, 1e-4, "out (tight)")
+        assert_close(grads[0], ref[0], 2e-4, 2e-4, "du (tight)")
+        assert_close(grads[3], ref[3], 2e-4, 2e-4, "dB (tight)")
+        assert_close(grads[4], ref[4], 2e-4, 2e-4, "dC (tight)")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_files("g1_scan_"))
+def test_golden_vectors(name):
+    """HIP path against the vectors produced by the reference itself."""
+    z = load_golden(name)
+    itype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}[str(z["itype"])]
+    sp = bool(z["delta_softplus"])
+    cast = lambda k: z[k].to(itype).to(DEV)
+    opt = lambda k: z[k].to(DEV) if k in z else None
+    u, dl, B, C, g = cast("u"), cast("delta"), cast("B"), cast("C"), cast("dout")
+    A, D, bias = z["A"].to(DEV), opt("D"), opt("delta_bias")
+    out, x = vmambair_amd.selective_scan_fwd(u, dl, A, B, C, D, bias, sp, 1)
+    du, dd, dA, dB, dC, dD, db = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, bias, g, x, sp, 1)
+    rtol, atol = TOL[itype]
+    assert_close(out, z["out"], rtol, atol, "out")
+    assert_close(x[:, :, -1, 1::2], z["last_state"], rtol, atol, "last_state")  # test_selective_scan.py:79
+    assert_close(du, z["du"], rtol * 2, atol * 2, "du")
+    assert_close(dd, z["ddelta"], rtol * 5, atol * 10, "ddelta")
+    wa = ATOLW * 5 if itype == torch.float32 else max(ATOLW * 5, 2e-3 * float(z["dA"].abs().max()))
+    assert_close(dA, z["dA"], RTOLW, wa, "dA")
+    assert_close(dB, z["dB"], rtol, atol, "dB")
+    assert_close(dC, z["dC"], rtol, atol, "dC")
+    if D is not None:
+        wd = ATOLW if itype == torch.float32 else max(ATOLW, 2e-3 * float(z["dD"].abs().max()))
+        assert_close(dD, z["dD"], RTOLW, wd, "dD")
+    if bias is not None:
+        wb = ATOLW if itype == torch.float32 else max(ATOLW, 2e-3 * float(z["ddelta_bias"].abs().max()))
+        assert_close(db, z["ddelta_bias"], RTOLW, wb, "ddelta_bias")
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "f16", "bf16"])
+@pytest.mark.parametrize("seqlen", [64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("flags", list(itertools.product([False, True], repeat=3)),
+                         ids=lambda f: "bias%d_sp%d_D%d" % tuple(int(v) for v in f))
+def test_reference_grid(itype, seqlen, flags):
+    """The reference's grid (test_selective_scan.py:365-369) at dstate 16, two groups."""
+    has_bias, softplus, has_D = flags
+    inputs = make_inputs(2, 16, 16, 2, seqlen, itype, has_D, has_bias)
+    check_fwd_bwd(inputs, softplus, itype)
+
+
+@pytest.mark.parametrize("N,G", [(1, 1), (1, 2), (16, 1), (16, 4), (24, 2), (40, 1)])
+@pytest.mark.parametrize("seqlen", [100, 777])
+def test_dstate_and_groups(N, G, seqlen):
+    """dstate = 1 is the reference grid's own value; 24 / 40 cross the 16-state LDS tile."""
+    check_fwd_bwd(make_inputs(2, 8 * G, N, G, seqlen, torch.float32), True, torch.float32)
+
+
+@pytest.mark.parametrize("seqlen", [1, 3, 37, 255, 257, 511, 513, 1061, 2048 + 37])
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_ragged_lengths(seqlen, itype):
+    """odd lengths: unaligned rows (scalar path), partial chunks, several saved states"""
+    check_fwd_bwd(make_inputs(1, 12, 16, 4, seqlen, itype), True, itype)
+
+
+@pytest.mark.parametrize("rows_per_group", [1, 3, 4, 5, 9, 17, 48])
+def test_ragged_row_tiles(rows_per_group):
+    """rows per group that do not fill a workgroup's row tile (dc_inner = 4 channel scans, D = 48)"""
+    G = 2
+    check_fwd_bwd(make_inputs(2, rows_per_group * G, 16, G, 320, torch.float32), True, torch.float32)
+
+
+@pytest.mark.parametrize("fv", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_every_forward_variant(fv, itype):
+    check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, fwd_variant=fv)
+
+
+@pytest.mark.parametrize("bv", [0, 1, 2, 3])
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_every_backward_variant(bv, itype):
+    check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, bwd_variant=bv)
+
+
+def test_channel_scan_shapes():
+    """the channel-direction calls of the archs: u (B, 2*dc_inner, D), L = D in {48..384}"""
+    for D in (48, 96, 192, 384):
+        check_fwd_bwd(make_inputs(3, 8, 16, 2, D, torch.float32, seed=D), True, torch.float32)
+    check_fwd_bwd(make_inputs(3, 2, 16, 2, 96, torch.float32, seed=7), True, torch.float32)  # RealSR: one row/dir
+
+
+def test_strided_views_like_the_archs():
+    """B, C arrive as split views of x_dbl (unit last stride, arbitrary outer strides) and u/delta as
+    views with a padded row pitch (cus/selective_scan.cpp:83-88,197-199)."""
+    torch.manual_seed(0)
+    Bsz, K, D, L, R, N = 2, 4, 8, 200, 3, 16
+    x_dbl = torch.randn(Bsz, K, R + 2 * N, L)
+    big_u = torch.randn(Bsz, K * D, L + 24)
+    big_d = 0.5 * torch.rand(Bsz, K * D, L + 8)
+    A = -0.5 * torch.rand(K * D, N)
+    Dv, bias = torch.randn(K * D), 0.5 * torch.rand(K * D)
+    dout = torch.randn(Bsz, K * D, L)
+
+    def views(xd, bu, bd):
+        _, Bs, Cs = torch.split(xd, [R, N, N], dim=2)
+        return bu[:, :, 8:8 + L], bd[:, :, 4:4 + L], Bs, Cs
+
+    u, delta, Bs, Cs = views(x_dbl, big_u, big_d)
+    ud, dd_, Bd, Cd = views(x_dbl.to(DEV), big_u.to(DEV), big_d.to(DEV))
+    assert not Bd.is_contiguous() and Bd.stride(-1) == 1 and ud.stride(1) == L + 24
+    Ad, Dd, bd, gd = (t.to(DEV) for t in (A, Dv, bias, dout))
+    out, x = vmambair_amd.selective_scan_fwd(ud, dd_, Ad, Bd, Cd, Dd, bd, True, 1)
+    grads = vmambair_amd.selective_scan_bwd(ud, dd_, Ad, Bd, Cd, Dd, bd, gd, x, True, 1)
+    ref_out, _ = oss_oracle.scan_fwd(u, delta, A, Bs, Cs, Dv, bias, True, chunk=256)
+    ref = oss_oracle.scan_bwd(u, delta, A, Bs, Cs, Dv, bias, dout, None, True)
+    assert_close(out, ref_out, 6e-4, 2e-3, "out")
+    for n, got, want in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], grads, ref):
+        assert_close(got, want, 3e-3, 2e-2, n)
+    assert grads[3].is_contiguous() and grads[3].shape == Bs.shape
+
+
+def test_softplus_threshold_branch():
+    """delta + bias straddling 20 (selective_scan_fwd_kernel.cuh:115-118, bwd_kernel.cuh:228-241)"""
+    g = torch.Generator().manual_seed(3)
+    u, _, A, B, C, D, bias, dout = make_inputs(1, 8, 16, 2, 300, torch.float32)
+    delta = 19.0 + 2.0 * torch.rand(1, 8, 300, generator=g)
+    A = A * 0.05
+    check_fwd_bwd((u, delta, A, B, C, D, bias, dout), True, torch.float32, tight=False)
+    # and far below zero (softplus -> exp), the dt-bias initialisation regime of the archs
+    delta = -8.0 + 4.0 * torch.rand(1, 8, 300, generator=g)
+    check_fwd_bwd((u, delta, A * 20, B, C, D, bias, dout), True, torch.float32)
+
+
+def test_empty_batch_and_argument_errors():
+    u, delta, A, B, C, D, bias, dout = to_dev(make_inputs(2, 8, 16, 2, 64, torch.float32))
+    out, x = vmambair_amd.selective_scan_fwd(u[:0], delta[:0], A, B[:0], C[:0], D, bias, True, 1)
+    assert out.shape == (0, 8, 64) and x.shape == (0, 8, 1, 32)
+    with pytest.raises(RuntimeError):  # dtype mismatch (selective_scan.cpp:169-172)
+        vmambair_amd.selective_scan_fwd(u, delta.half(), A, B, C, D, bias, True, 1)
+    with pytest.raises(RuntimeError):  # dim % n_groups (selective_scan.cpp:190)
+        vmambair_amd.selective_scan_fwd(u[:, :7], delta[:, :7], A[:7], B, C, None, None, True, 1)
+    with pytest.raises(RuntimeError):  # time axis must be contiguous (:183-184)
+        vmambair_amd.selective_scan_fwd(u.transpose(1, 2).contiguous().transpose(1, 2), delta, A, B, C, D, bias, True, 1)
+    with pytest.raises(RuntimeError):  # weights are fp32 (:168)
+        vmambair_amd.selective_scan_fwd(u, delta, A.half(), B, C, D, bias, True, 1)
+    with pytest.raises(RuntimeError):  # CPU tensor
+        vmambair_amd.selective_scan_fwd(u.cpu(), delta, A, B, C, D, bias, True, 1)
+    lib = _capi.load()
+    assert lib.oss_scan_fwd(None, 0, None) == -1
+
+
+def test_autograd_function_and_drop_in_module():
+    """SelectiveScanFn on the GPU vs the oracle's autograd twin; 3-D B/C (one group) are lifted and
+    squeezed back (MambaSISR6_arch.py:41-46,72-73); the drop-in module returns the same tensors."""
+    import selective_scan_cuda_core as core
+    torch.manual_seed(0)
+    u, delta, A, B, C, D, bias, dout = make_inputs(2, 8, 16, 1, 300, torch.float32)
+    B3, C3 = B[:, 0], C[:, 0]
+    leaves_cpu = [t.clone().requires_grad_() for t in (u, delta, A, B3, C3, D, bias)]
+    leaves_gpu = [t.clone().to(DEV).requires_grad_() for t in (u, delta, A, B3, C3, D, bias)]
+    y_cpu = oss_oracle.selective_scan_fn(*leaves_cpu, True)
+    y_gpu = vmambair_amd.selective_scan_fn(*leaves_gpu, True)
+    assert_close(y_gpu, y_cpu, 6e-4, 2e-3, "y")
+    y_cpu.backward(dout)
+    y_gpu.backward(dout.to(DEV))
+    for n, a, b in zip("u delta A B C D bias".split(), leaves_gpu, leaves_cpu):
+        assert a.grad.shape == b.grad.shape
+        assert_close(a.grad, b.grad, 3e-3, 2e-2, "grad " + n)
+    out, x = core.fwd(*[t.detach() for t in leaves_gpu[:3]], leaves_gpu[3].detach().unsqueeze(1),
+                      leaves_gpu[4].detach().unsqueeze(1), leaves_gpu[5].detach(), leaves_gpu[6].detach(), True, 1)
+    assert torch.equal(out, y_gpu.detach())
+    res = core.bwd(*[t.detach() for t in leaves_gpu[:3]], leaves_gpu[3].detach().unsqueeze(1),
+                   leaves_gpu[4].detach().unsqueeze(1), None, None, dout.to(DEV), x, True, 1)
+    assert len(res) == 7 and res[5] is None and res[6] is None
+
+
+def test_reruns_are_stable():
+    """No zero-filled outputs, no global atomics: a second call on the same inputs gives the same
+    du/ddelta/dA/dD/dbias bit for bit and dB/dC up to the LDS add order."""
+    ins = to_dev(make_inputs(2, 64, 16, 2, 1500, torch.float32))
+    u, delta, A, B, C, D, bias, dout = ins
+    o1, x1 = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1)
+    o2, x2 = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1)
+    assert torch.equal(o1, o2) and torch.equal(x1, x2)
+    g1 = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x1, True, 1)
+    g2 = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x1, True, 1)
+    for i in (0, 1, 2, 5, 6):
+        assert torch.equal(g1[i], g2[i])
+    for i in (3, 4):
+        assert_close(g1[i], g2[i], 1e-5, 1e-5, "dB/dC rerun")
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: size-independent properties + sampled rows against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_full_size_properties(itype):
+    """largest call of config 2: u (8, 384, 4096), B/C (8, 4, 16, 4096)"""
+    torch.manual_seed(0)
+    Bsz, KD, N, G, L = 8, 384, 16, 4, 4096
+    u = torch.randn(Bsz, KD, L, device=DEV).to(itype)
+    delta = (0.5 * torch.rand(Bsz, KD, L, device=DEV)).to(itype)
+    A = -0.5 * torch.rand(KD, N, device=DEV)
+    Bm = torch.randn(Bsz, G, N, L, device=DEV).to(itype)
+    Cm = torch.randn(Bsz, G, N, L, device=DEV).to(itype)
+    D = torch.randn(KD, device=DEV)
+    bias = 0.5 * torch.rand(KD, device=DEV)
+    out, x = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+    rtol, atol = TOL[itype]
+    # (1) causality: the first half of the outputs does not depend on the second half of the inputs,
+    #     and the state saved at the cut equals the last state of the truncated call
+    h = L // 2
+    out_h, x_h = vmambair_amd.selective_scan_fwd(u[:, :, :h].contiguous(), delta[:, :, :h].contiguous(), A,
+                                                  Bm[..., :h].contiguous(), Cm[..., :h].contiguous(), D, bias, True, 1)
+    assert torch.equal(out[:, :, :h], out_h)
+    assert torch.equal(x[:, :, : h // 256], x_h)
+    # (2) batch-permutation equivariance (rows are independent)
+    perm = torch.randperm(Bsz, device=DEV)
+    out_p, _ = vmambair_amd.selective_scan_fwd(u[perm], delta[perm], A, Bm[perm], Cm[perm], D, bias, True, 1)
+    assert torch.equal(out_p, out[perm])
+    # (3) linearity in C and the skip term: scan(C -> 2C) - D u = 2 (scan(C) - D u)
+    out2, _ = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, (2 * Cm.float()).to(itype), None, bias, True, 1)
+    out1, _ = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, Cm, None, bias, True, 1)
+    assert_close(out2, 2 * out1.float(), rtol, atol, "linearity in C")
+    # (4) sampled rows against the oracle (one group's B/C, eight rows of it)
+    b, g0, r0 = 5, 2, 40
+    rows = slice(g0 * (KD // G) + r0, g0 * (KD // G) + r0 + 8)
+    sub = [t.cpu() for t in (u[b:b + 1, rows], delta[b:b + 1, rows], A[rows], Bm[b:b + 1, g0:g0 + 1],
+                             Cm[b:b + 1, g0:g0 + 1], D[rows], bias[rows])]
+    ref_out, ref_x = oss_oracle.scan_fwd(*sub, True, chunk=256)
+    assert_close(out[b:b + 1, rows], ref_out, rtol, atol, "sampled rows")
+    assert_close(x[b:b + 1, rows][..., 1::2], ref_x[..., 1::2], 6e-4, 2e-3, "sampled states")
+    # (5) backward: linear in dout, and anti-causal (gradients at t >= T do not see dout before T)
+    dout = torch.randn(Bsz, KD, L, device=DEV).to(itype)
+    g1 = vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+    g2 = vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, (2 * dout.float()).to(itype), x, True, 1)
+    for i, n in enumerate(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"]):
+        sc = float(g1[i].float().abs().max())
+        assert_close(g2[i], 2 * g1[i].float(), 4 * rtol, 4 * atol + 1e-3 * sc, "bwd linearity " + n)
+    dz = dout.clone()
+    dz[:, :, :h] = 0
+    g3 = vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, dz, x, True, 1)
+    assert torch.equal(g3[0][:, :, h:], g1[0][:, :, h:]) and torch.equal(g3[1][:, :, h:], g1[1][:, :, h:])
+    # sampled rows of du / ddelta against the oracle
+    subg = oss_oracle.scan_bwd(*sub, dout[b:b + 1, rows].cpu(), None, True)
+    assert_close(g1[0][b:b + 1, rows], subg[0], rtol * 2, atol * 2, "sampled du")
+    assert_close(g1[1][b:b + 1, rows], subg[1], rtol * 5, atol * 10, "sampled ddelta")

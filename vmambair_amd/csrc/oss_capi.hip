@@ -1,5 +1,7 @@
 // oss_capi.hip -- the extern "C" surface declared in include/vmambair_oss.h.
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include "oss_device.h"
 #include "oss_host.h"
 
@@ -31,6 +33,59 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     return 0;
 }
 
+// ---- per-launch event timing (oss_prof_*) -----------------------------------------------------
+constexpr int kProfVariants = 8;
+struct ProfBucket {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.0, bytes = 0.0;
+    long long launches = 0;
+};
+static std::mutex g_prof_mu;
+static std::atomic<int> g_prof_on{0};
+static ProfBucket g_prof[2][kProfVariants][3];
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+struct ProfTimer : LaunchTimer {  // begin/end bracket exactly one kernel launch
+    bool on; int which, variant, io; double bytes; hipEvent_t e0{}, e1{};
+    ProfTimer(int which_, int variant_, int io_, double bytes_)
+        : on(g_prof_on.load() != 0 && variant_ >= 0 && variant_ < kProfVariants), which(which_), variant(variant_),
+          io(io_), bytes(bytes_) {}
+    void begin(hipStream_t s) override {
+        if (!on) return;
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            e0 = prof_event(); e1 = prof_event();
+        }
+        (void)hipEventRecord(e0, s);
+    }
+    void end(hipStream_t s) override {
+        if (!on) return;
+        (void)hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        ProfBucket &b = g_prof[which][variant][io];
+        b.pending.emplace_back(e0, e1);
+        b.bytes += bytes;
+        b.launches += 1;
+    }
+};
+
+// bytes a launch must move at minimum
+static double fwd_alg_bytes(const oss_scan_fwd_params &p, int s) {
+    const double BKL = (double)p.batch * p.dim * p.seqlen, BGNL = (double)p.batch * p.n_groups * p.dstate * p.seqlen;
+    const double xb = 4.0 * p.batch * p.dim * oss_scan_num_chunks(p.seqlen) * 2 * p.dstate;
+    return s * (3.0 * BKL + 2.0 * BGNL) + 4.0 * ((double)p.dim * p.dstate + 2.0 * p.dim) + xb;
+}
+static double bwd_alg_bytes(const oss_scan_fwd_params &p, int s) {
+    const double BKL = (double)p.batch * p.dim * p.seqlen, BGNL = (double)p.batch * p.n_groups * p.dstate * p.seqlen;
+    const double xb = 4.0 * p.batch * p.dim * oss_scan_num_chunks(p.seqlen) * 2 * p.dstate;
+    return s * (5.0 * BKL + 4.0 * BGNL) + 4.0 * (2.0 * p.dim * p.dstate + 4.0 * p.dim) + xb;
+}
+
 static int check_fwd(const oss_scan_fwd_params *p) {
     if (!p || !p->u || !p->delta || !p->A || !p->B || !p->C) return OSS_ERR_NULL;
     if (p->batch < 0 || p->dim <= 0 || p->seqlen < 0 || p->dstate <= 0 || p->n_groups <= 0) return OSS_ERR_SHAPE;
@@ -58,12 +113,16 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
     if (v < 0) v = scan_fwd_pick_variant(p->batch, p->dim, p->seqlen, p->dstate, p->n_groups, eb);
     g_last_fwd.store(v);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfTimer prof(0, v, (int)io, fwd_alg_bytes(*p, eb));
+    prof.begin(s);
     switch (io) {
-        case OSS_F32: return scan_fwd_dispatch<float>(*p, v, s);
-        case OSS_F16: return scan_fwd_dispatch<f16_t>(*p, v, s);
-        case OSS_BF16: return scan_fwd_dispatch<bf16_t>(*p, v, s);
+        case OSS_F32: rc = scan_fwd_dispatch<float>(*p, v, s); break;
+        case OSS_F16: rc = scan_fwd_dispatch<f16_t>(*p, v, s); break;
+        case OSS_BF16: rc = scan_fwd_dispatch<bf16_t>(*p, v, s); break;
+        default: rc = OSS_ERR_SHAPE;
     }
-    return OSS_ERR_SHAPE;
+    prof.end(s);
+    return rc;
 }
 
 static int bwd_variant_for(int batch, int dim, int seqlen, int dstate, int n_groups) {
@@ -93,12 +152,40 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     const int v = bwd_variant_for(f.batch, f.dim, f.seqlen, f.dstate, f.n_groups);
     g_last_bwd.store(v);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfTimer prof(1, v, (int)io, bwd_alg_bytes(f, io == OSS_F32 ? 4 : 2));
     switch (io) {
-        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, s);
-        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, s);
-        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, s);
+        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, s, &prof);
+        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, s, &prof);
+        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, s, &prof);
     }
     return OSS_ERR_SHAPE;
+}
+
+void oss_prof_enable(int on) { g_prof_on.store(on ? 1 : 0); }
+
+void oss_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &k : g_prof) for (auto &v : k) for (auto &b : v) {
+        for (auto &pr : b.pending) { (void)hipEventSynchronize(pr.second); g_event_pool.push_back(pr.first); g_event_pool.push_back(pr.second); }
+        b.pending.clear(); b.ms = 0.0; b.bytes = 0.0; b.launches = 0;
+    }
+}
+
+int oss_prof_collect(int which, int variant, oss_dtype io, double *total_ms, long long *launches, double *algorithmic_bytes) {
+    if (which < 0 || which > 1 || variant < 0 || variant >= kProfVariants || (int)io < 0 || (int)io > 2) return OSS_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfBucket &b = g_prof[which][variant][(int)io];
+    for (auto &pr : b.pending) {
+        (void)hipEventSynchronize(pr.second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) b.ms += ms;
+        g_event_pool.push_back(pr.first); g_event_pool.push_back(pr.second);
+    }
+    b.pending.clear();
+    if (total_ms) *total_ms = b.ms;
+    if (launches) *launches = b.launches;
+    if (algorithmic_bytes) *algorithmic_bytes = b.bytes;
+    return OSS_OK;
 }
 
 void oss_scan_set_variant(int fwd_variant, int bwd_variant) {

@@ -362,7 +362,7 @@ oss_scan_bwd_finish_w(const float *ws_dA, const float *ws_dD, const float *ws_db
 }
 
 template <typename T, int LPR, int I, int WAVES, int NBB>
-static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream) {
+static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
     constexpr int ROWS = WAVES * (64 / LPR);
     constexpr int TC = LPR * I;
     const oss_scan_fwd_params &f = p.f;
@@ -391,7 +391,9 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream) {
         smem_enabled = smem;
     }
     const dim3 grid((unsigned)(f.batch * f.n_groups * tiles));
+    if (timer) timer->begin(stream);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p, ws);
+    if (timer) timer->end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
 
@@ -414,17 +416,17 @@ static const int kBwdRows[] = {8, 16, 16, 4};
 int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 3) ? 3 : variant]; }
 
 template <typename T>
-int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream) {
+int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
     switch (variant) {
-        case 0: return launch_bwd<T, 64, 8, 8, 8>(p, stream);
-        case 1: return launch_bwd<T, 64, 8, 16, 8>(p, stream);
-        case 2: return launch_bwd<T, 32, 8, 8, 16>(p, stream);
-        default: return launch_bwd<T, 64, 4, 4, 16>(p, stream);
+        case 0: return launch_bwd<T, 64, 8, 8, 8>(p, stream, timer);
+        case 1: return launch_bwd<T, 64, 8, 16, 8>(p, stream, timer);
+        case 2: return launch_bwd<T, 32, 8, 8, 16>(p, stream, timer);
+        default: return launch_bwd<T, 64, 4, 4, 16>(p, stream, timer);
     }
 }
 
-template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, hipStream_t);
-template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, hipStream_t);
-template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, hipStream_t);
+template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *);
+template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *);
+template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *);
 
 }  // namespace oss
