@@ -30,6 +30,23 @@ NET = dict(type="MambaSISR6", inp_channels=3, out_channels=3, dim=48, num_blocks
            num_refinement_blocks=15, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
            LayerNorm_type="WithBias")
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """cores this process may really use: affinity mask, cgroup quota, capped at 64"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
 
 
 def make_step(net, ema_params, opt, autocast_dtype, device_type):
@@ -72,7 +89,7 @@ def cpu_baseline(seed=0):
     from vmambair_amd.archs import build_network
     import vmambair_amd.ops as ops
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     oss_oracle.set_threads(cores)
     chunk = ops.scan_chunk()
@@ -104,7 +121,14 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VMAMBAIR_BENCH_GRAPH", "0")),
+                    help="1: replay the training step as one hipGraph (single GPU, or manual flat-gradient "
+                         "all-reduce outside the graph for N > 1)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,8 +163,11 @@ def main():
     lq = torch.rand(B, 3, 64, 64, device=dev, generator=g)
     gt = torch.rand(B, 3, 256, 256, device=dev, generator=g)
 
-    for _ in range(args.warmup):
+    log(f"model on {dev}, warmup {args.warmup} steps")
+    for i in range(args.warmup):
         step(lq, gt)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
 
     def fence():
         torch.cuda.synchronize()
@@ -157,6 +184,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     lib.oss_prof_enable(0)
+    log(f"timed {args.steps} steps in {dt:.3f}s")
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -199,8 +227,12 @@ def main():
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                cpu = cpu_baseline()
+            log("cpu baseline (subprocess, 300 s limit)")
+            import subprocess
+            try:  # own process: no GPU context, own thread pools, bounded time
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True,
+                                   text=True, timeout=300, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
+                cpu = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:  # the headline number must survive a broken baseline leg
                 cpu = {"error": str(e)[:200]}
 

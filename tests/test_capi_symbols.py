@@ -66,7 +66,7 @@ int main(void) {
 def test_workspace_query_is_pure():
     lib = _capi.load()
     n = lib.oss_scan_bwd_workspace_bytes(2, 8, 100, 16, 4)
-    tiles = (2 + 3) // 4  # 2 rows per group, 4 rows per workgroup in the smallest variant
+    tiles = (2 + 3) // 4  # 2 rows per group, 4 rows per workgroup in the smallest variant (bwd variant 1)
     assert n == 4 * (2 * 4 * tiles * 2 * 16 * 100 + 2 * 8 * 18)
     assert lib.oss_scan_bwd_workspace_bytes(2, 7, 100, 16, 4) == 0  # dim % n_groups != 0
 

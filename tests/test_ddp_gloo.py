@@ -1,0 +1,86 @@
+"""N > 1 path on the CPU: two gloo processes, image batch sharded by rank, DDP gradient mean must
+equal the single-process gradient of the whole batch (the reference has no such test; its DDP is
+only ever exercised on 8 real GPUs -- SURVEY.md section 4)."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from conftest import install_oracle_cpu_kernel
+    install_oracle_cpu_kernel()
+    from vmambair_amd import ddp
+    from vmambair_amd.oss_block import MamberBlock
+
+    r, w, device = ddp.init_distributed()
+    assert (r, w) == (rank, world) and device.type == "cpu"
+    torch.manual_seed(0)
+    net = MamberBlock(16, variant="srgan")
+    ref_state = {k: v.clone() for k, v in net.state_dict().items()}
+    model = ddp.wrap_ddp(net, device)
+    g = torch.Generator().manual_seed(123)
+    x_all = torch.randn(4, 16, 6, 5, generator=g)
+    idx = ddp.shard_indices(4, rank, world, epoch=0)
+    assert len(idx) == 2
+    y = model(x_all[idx])
+    loss = y.square().mean()
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    red = ddp.reduce_loss_dict({"l_pix": loss})
+    if rank == 0:
+        torch.save({"grads": grads, "state": ref_state, "x": x_all, "loss": red["l_pix"]}, os.path.join(tmp, "r0.pt"))
+    # both ranks hold the same averaged gradient
+    flat = torch.cat([v.flatten() for v in grads.values()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1])
+    # shards are disjoint and cover the batch
+    all_idx = [torch.zeros_like(idx) for _ in range(world)]
+    dist.all_gather(all_idx, idx)
+    assert sorted(torch.cat(all_idx).tolist()) == [0, 1, 2, 3]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_match_single_process():
+    port = 29000 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+        blob = torch.load(os.path.join(tmp, "r0.pt"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import install_oracle_cpu_kernel
+    install_oracle_cpu_kernel()
+    from vmambair_amd.oss_block import MamberBlock
+    net = MamberBlock(16, variant="srgan")
+    net.load_state_dict(blob["state"])
+    y = net(blob["x"])
+    loss = y.square().mean()
+    loss.backward()
+    assert abs(float(loss) - blob["loss"]) < 1e-5 * max(1.0, abs(float(loss)))
+    for k, p in net.named_parameters():
+        ref = p.grad
+        got = blob["grads"][k]
+        tol = 1e-5 + 1e-4 * float(ref.abs().max())
+        assert (got - ref).abs().max() <= tol, k
+
+
+def test_shard_indices_follow_the_reference_sampler():
+    from vmambair_amd import ddp
+    # data_sampler.py:36-43 with ratio 1: randperm(total) seeded by epoch, rank-strided
+    g = torch.Generator()
+    g.manual_seed(3)
+    perm = torch.randperm(12, generator=g)
+    for r in range(4):
+        assert torch.equal(ddp.shard_indices(10, r, 4, epoch=3), (perm % 10)[r::4])

@@ -72,16 +72,17 @@ def check_fwd_bwd(cpu_inputs, softplus, itype, fwd_variant=-1, bwd_variant=-1, t
         if want is None:
             assert got is None, n
             continue
-        if itype != torch.float32 and n in ("dA", "dD", "ddelta_bias"):
-            # sums of L*batch rounded terms: scale the absolute tolerance with the magnitude
-            at = max(at, 2e-3 * float(want.abs().max()))
+        if n in ("dA", "dD", "ddelta_bias"):
+            # sums of batch*L terms of mixed sign: two fp32 summation orders differ by ~1e-6 of the
+            # LARGEST entry (the reference's absolute 5e-3 assumes its dim=768/dstate=1 grid), and
+            # 16-bit inputs add their rounding
+            at = max(at, (2e-5 if itype == torch.float32 else 2e-3) * float(want.abs().max()))
         assert_close(got, want, rt, at, n)
     if tight and itype == torch.float32:
         # both are fp32 implementations of the same recurrence: they agree far inside the contract
-        assert_close(out, ref_out, 1e-4, 1e-4, "out (tight)")
-        assert_close(grads[0], ref[0], 2e-4, 2e-4, "du (tight)")
-        assert_close(grads[3], ref[3], 2e-4, 2e-4, "dB (tight)")
-        assert_close(grads[4], ref[4], 2e-4, 2e-4, "dC (tight)")
+        # (absolute part scaled by the largest magnitude: outputs are sums with cancellation)
+        for nm, g_, r_ in (("out", out, ref_out), ("du", grads[0], ref[0]), ("dB", grads[3], ref[3]), ("dC", grads[4], ref[4])):
+            assert_close(g_, r_, 1e-4, 3e-6 * float(r_.abs().max()) + 1e-6, nm + " (tight)")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -102,7 +103,7 @@ def test_golden_vectors(name):
     assert_close(x[:, :, -1, 1::2], z["last_state"], rtol, atol, "last_state")  # test_selective_scan.py:79
     assert_close(du, z["du"], rtol * 2, atol * 2, "du")
     assert_close(dd, z["ddelta"], rtol * 5, atol * 10, "ddelta")
-    wa = ATOLW * 5 if itype == torch.float32 else max(ATOLW * 5, 2e-3 * float(z["dA"].abs().max()))
+    wa = max(ATOLW * 5, (2e-5 if itype == torch.float32 else 2e-3) * float(z["dA"].abs().max()))
     assert_close(dA, z["dA"], RTOLW, wa, "dA")
     assert_close(dB, z["dB"], rtol, atol, "dB")
     assert_close(dC, z["dC"], rtol, atol, "dC")
@@ -152,7 +153,7 @@ def test_every_forward_variant(fv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, fwd_variant=fv)
 
 
-@pytest.mark.parametrize("bv", [0, 1, 2, 3])
+@pytest.mark.parametrize("bv", [0, 1])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_every_backward_variant(bv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, bwd_variant=bv)
@@ -251,8 +252,8 @@ def test_autograd_function_and_drop_in_module():
 
 
 def test_reruns_are_stable():
-    """No zero-filled outputs, no global atomics: a second call on the same inputs gives the same
-    du/ddelta/dA/dD/dbias bit for bit and dB/dC up to the LDS add order."""
+    """No zero-filled outputs, no atomics anywhere: a second call on the same inputs gives the same
+    results bit for bit."""
     ins = to_dev(make_inputs(2, 64, 16, 2, 1500, torch.float32))
     u, delta, A, B, C, D, bias, dout = ins
     o1, x1 = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1)
@@ -260,10 +261,8 @@ def test_reruns_are_stable():
     assert torch.equal(o1, o2) and torch.equal(x1, x2)
     g1 = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x1, True, 1)
     g2 = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x1, True, 1)
-    for i in (0, 1, 2, 5, 6):
+    for i in range(7):
         assert torch.equal(g1[i], g2[i])
-    for i in (3, 4):
-        assert_close(g1[i], g2[i], 1e-5, 1e-5, "dB/dC rerun")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -27,9 +27,8 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups) {
     (void)dstate;
     const int rows_per_group = dim / n_groups;
-    const long rows = (long)batch * dim;
-    if (seqlen <= 256 || rows_per_group < 8) return 3;
-    if (rows_per_group % 16 == 0 && rows >= 8192) return 1;
+    (void)batch;
+    if (seqlen <= 256 || rows_per_group < 8) return 1;
     return 0;
 }
 
@@ -135,7 +134,7 @@ size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, 
     if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups) return 0;
     // sized for the variant with the fewest rows per workgroup so that any variant fits
     const int rows_per_group = dim / n_groups;
-    const int rows = scan_bwd_rows_per_wg(3);
+    const int rows = scan_bwd_rows_per_wg(1);
     const size_t tiles = (size_t)(rows_per_group + rows - 1) / rows;
     const size_t floats = (size_t)batch * n_groups * tiles * 2 * dstate * seqlen + (size_t)batch * dim * (dstate + 2);
     return floats * sizeof(float);

@@ -12,11 +12,14 @@
 //     mirrored lane order (ds_bpermute mirror + the forward DPP scan), its carry and the delta of
 //     the chunk's first step (a_{t+1} across the chunk edge is exp2(A * delta_first), so no
 //     per-state edge value is kept) live in LDS;
-//   * dB/dC -- sums over the rows of a group -- are accumulated with LDS float atomics into a
-//     workgroup tile and written ONCE per (workgroup, chunk) as a partial with plain stores; a
-//     finishing kernel adds the partials of a group in a fixed order and casts to the I/O type.
-//     No global atomics (per-XCD L2s are not coherent: device-scope float atomics would all go to
-//     memory), no zero-filled outputs, and the result is deterministic up to the LDS add order.
+//   * dB/dC -- sums over the rows of a group -- are reduced across the workgroup's rows through LDS
+//     slabs: every wave stores its row's I values per lane for the current state, one barrier,
+//     then wave w sums time slice w over all rows in a fixed order and writes the workgroup's
+//     partial with plain coalesced stores; a finishing kernel adds the partials of a group in tile
+//     order and casts to the I/O type.  (LDS float atomics were measured at ~200 clocks per wave
+//     instruction on gfx950 -- profiles/r01_ubench.txt -- and made the first version 20x slower;
+//     device-scope global float atomics cannot stay in the per-XCD L2s.)  No atomics anywhere, no
+//     zero-filled outputs, bit-reproducible.
 //   * dA, dD, ddelta_bias are per-(batch,row) partials reduced over batch by the finishing kernel.
 #include "oss_device.h"
 #include "oss_host.h"
@@ -84,13 +87,13 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int TC = LPR * I;
     constexpr int NT = WAVES * 64;
     static_assert(TC % kScanChunk == 0, "");
+    static_assert(LPR == 64 && NT == TC, "slab reduction: one row per wave, one time step per thread");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sB = smem;                    // [NBB][TC]  tile_off layout
     float *sC = sB + NBB * TC;           // [NBB][TC]
-    float *sdB = sC + NBB * TC;          // [NBB][I][LPR]  accumulators (lane-linear per item)
-    float *sdC = sdB + NBB * TC;         // [NBB][I][LPR]
-    float *sA2 = sdC + NBB * TC;                       // [N][ROWS]
+    float *slab = sC + NBB * TC;         // [ROWS][2][TC]  per-row dB / dC terms of the current state
+    float *sA2 = slab + ROWS * 2 * TC;                 // [N][ROWS]
     float *sdhc = sA2 + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dh of the first step of the later chunk
     float *sdA = sdhc + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dA partial of the row
     float *sdln = sdA + (size_t)p.f.dstate * ROWS;     // [ROWS]     delta of the first step of the later chunk
@@ -182,10 +185,6 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             stage_tiles_b<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * f.B_dstate_stride,
                                          gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
                                          f.C_dstate_stride, nb, t0, L, tid);
-            for (int idx = tid; idx < nb * TC / 4; idx += NT) {
-                reinterpret_cast<f32x4 *>(sdB)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
-                reinterpret_cast<f32x4 *>(sdC)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
             __syncthreads();
             for (int nn = 0; nn < nb; ++nn) {
                 const int n = n0 + nn;
@@ -245,8 +244,7 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 if (seg_last) sdhc[n * ROWS + wrow] = dfull_m;            // mirrored-last = first lane in time
                 // ---- reverse pass with gradients (bwd_kernel.cuh:196-206); p_t = a_t h_{t-1}
                 float dA_acc = 0.f;
-                float *accB = sdB + nn * TC + pos;
-                float *accC = sdC + nn * TC + pos;
+                float vB[I], vC[I];
 #pragma unroll
                 for (int k = I / 4 - 1; k >= 0; --k) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
@@ -261,34 +259,37 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                         const float r = dh * (a[i] * hprev);
                         dd[i] = __builtin_fmaf(A2, r, dd[i]);
                         dA_acc = __builtin_fmaf(dl[i], r, dA_acc);
-                        // rows past the end of the group carry u = dout = 0, so they add exact zeros
-                        __hip_atomic_fetch_add(accB + i * LPR, dh * w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(accC + i * LPR, gg[i] * hh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // rows past the end of the group carry u = dout = 0, so they contribute exact zeros
+                        vB[i] = dh * w[i];
+                        vC[i] = gg[i] * hh[i];
                     }
                 }
                 const float dA_sum = segment_sum_to_last<LPR>(dA_acc);
                 if (seg_last) sdA[n * ROWS + wrow] += dA_sum;
-            }
-            __syncthreads();  // all rows' atomics have landed
-            // ---- write this workgroup's dB/dC partial for (chunk, state block)
-            for (int idx = tid; idx < nb * (TC / 4); idx += NT) {
-                const int nn = idx / (TC / 4), k = idx - nn * (TC / 4);
-                const int t = t0 + 4 * k;
-                if (t >= L) continue;
-                const int ps = (4 * k) / I, i0 = (4 * k) % I;
-                const float *ab = sdB + nn * TC + i0 * LPR + ps;
-                const float *ac = sdC + nn * TC + i0 * LPR + ps;
-                f32x4 vb = {ab[0], ab[LPR], ab[2 * LPR], ab[3 * LPR]};
-                f32x4 vc = {ac[0], ac[LPR], ac[2 * LPR], ac[3 * LPR]};
-                float *ob = ws_bc + (size_t)(n0 + nn) * L + t;
-                float *oc = ob + (size_t)N * L;
-                if (t + 3 < L && aligned16(ob) && aligned16(oc)) {
-                    *reinterpret_cast<f32x4 *>(ob) = vb;
-                    *reinterpret_cast<f32x4 *>(oc) = vc;
-                } else {
+                // ---- cross-row reduction of dB/dC for this state through the slabs
+                __syncthreads();  // the previous state's slice sums have been read
+                {
+                    float *sb = slab + (wrow * 2) * TC + pos * I;
+                    float *sc = sb + TC;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (t + j < L) { ob[j] = vb[j]; oc[j] = vc[j]; }
+                    for (int k = 0; k < I / 4; ++k) {
+                        *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{vB[4 * k], vB[4 * k + 1], vB[4 * k + 2], vB[4 * k + 3]};
+                        *reinterpret_cast<f32x4 *>(sc + 4 * k) = f32x4{vC[4 * k], vC[4 * k + 1], vC[4 * k + 2], vC[4 * k + 3]};
+                    }
+                }
+                __syncthreads();
+                {
+                    float accb = 0.f, accc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) {  // fixed order: deterministic
+                        accb += slab[(r * 2) * TC + tid];
+                        accc += slab[(r * 2 + 1) * TC + tid];
+                    }
+                    const int t = t0 + tid;
+                    if (t < L) {
+                        ws_bc[(size_t)n * L + t] = accb;
+                        ws_bc[(size_t)(N + n) * L + t] = accc;
+                    }
                 }
             }
         }
@@ -381,7 +382,7 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     if (!p.dD) ws.dD = nullptr;
     if (!p.ddelta_bias) ws.db = nullptr;
 
-    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
     auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB>;
     static size_t smem_enabled = 48 * 1024;
     if (smem > smem_enabled) {
@@ -407,20 +408,16 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     return (int)hipGetLastError();
 }
 
-// variant table: (lanes per row, items per lane, waves per workgroup, states per LDS tile)
-//   0: 64 x 8 x 8,  8 states  (TC 512,  8 rows/WG, 64 KiB LDS)
-//   1: 64 x 8 x 16, 8 states  (TC 512, 16 rows/WG, 64 KiB LDS)
-//   2: 32 x 8 x 8, 16 states  (TC 256, 16 rows/WG, 64 KiB LDS)
-//   3: 64 x 4 x 4, 16 states  (TC 256,  4 rows/WG, 64 KiB LDS)  short sequences / few rows per group
-static const int kBwdRows[] = {8, 16, 16, 4};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 3) ? 3 : variant]; }
+// variant table: (lanes per row, items per lane = waves per workgroup, states per LDS tile)
+//   0: 64 x 8 x 8,  8 states  (TC 512, 8 rows/WG, 64 KiB LDS)
+//   1: 64 x 4 x 4, 16 states  (TC 256, 4 rows/WG, 40 KiB LDS)  short sequences / few rows per group
+static const int kBwdRows[] = {8, 4};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 1) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
     switch (variant) {
         case 0: return launch_bwd<T, 64, 8, 8, 8>(p, stream, timer);
-        case 1: return launch_bwd<T, 64, 8, 16, 8>(p, stream, timer);
-        case 2: return launch_bwd<T, 32, 8, 8, 16>(p, stream, timer);
         default: return launch_bwd<T, 64, 4, 4, 16>(p, stream, timer);
     }
 }

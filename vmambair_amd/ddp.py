@@ -1,0 +1,82 @@
+"""Data-parallel scale-out of the OSS nets: one process per GPU, image batch sharded by rank,
+gradients all-reduced (mean) by DistributedDataParallel over RCCL/xGMI.
+
+Mirrors what the reference does and nothing more: ``init_dist`` picks the device
+from the rank and calls ``init_process_group(backend='nccl')`` (*/utils/dist_util.py:10-25),
+``model_to_device`` wraps the net in DDP (Deraining/basicsr/models/base_model.py:76-82), the
+sampler hands rank ``r`` the indices ``r, r+world, ...`` of a seeded permutation
+(Deraining/basicsr/data/data_sampler.py:30-43).  The scan itself needs no collective: rows of
+different images are independent.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the 48.1 MB fp32 gradient of MambaSISR6 is one
+~0.1-0.6 ms all-reduce, far below a step, so the only tuning is a bucket large enough to keep the
+number of RCCL calls small (``bucket_cap_mb``).
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def dist_info() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun / torch.distributed.launch environment."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(backend: str | None = None) -> Tuple[int, int, torch.device]:
+    """Reference ``_init_dist_pytorch``: device = rank % n_gpus, then init_process_group.
+    ``backend`` defaults to "nccl" (= RCCL on ROCm) on GPUs and "gloo" on the CPU (tests)."""
+    rank, world, local_rank = dist_info()
+    use_gpu = torch.cuda.is_available()
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    if use_gpu:
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        device = torch.device("cuda", local_rank % torch.cuda.device_count())
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def wrap_ddp(net: torch.nn.Module, device: torch.device, bucket_cap_mb: int = 50,
+             find_unused_parameters: bool = False) -> torch.nn.Module:
+    """``model_to_device`` of the reference (base_model.py:67-85) for the distributed case."""
+    net = net.to(device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return net
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(net, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
+                                                     find_unused_parameters=find_unused_parameters,
+                                                     gradient_as_bucket_view=True)
+
+
+def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, ratio: int = 1) -> torch.Tensor:
+    """EnlargedSampler.__iter__ (data_sampler.py:36-43): epoch-seeded global permutation of
+    ``ceil(n*ratio/world)*world`` indices, rank-strided slice, modulo the dataset size."""
+    import math
+    num_samples = math.ceil(n_items * ratio / world)
+    total = num_samples * world
+    g = torch.Generator()
+    g.manual_seed(epoch)
+    idx = torch.randperm(total, generator=g)
+    return (idx % n_items)[rank:total:world]
+
+
+def reduce_loss_dict(losses: dict) -> dict:
+    """``reduce_loss_dict`` (base_model.py:353-378): reduce to rank 0 and average there."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {k: float(v) for k, v in losses.items()}
+    keys = sorted(losses)
+    t = torch.stack([losses[k].detach().float() for k in keys])
+    dist.reduce(t, dst=0)
+    if dist.get_rank() == 0:
+        t /= dist.get_world_size()
+    return {k: float(v) for k, v in zip(keys, t)}

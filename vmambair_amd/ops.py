@@ -101,6 +101,8 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     if out.stride(-1) != 1 and out.size(-1) != 1:
         out = torch.empty(delta.shape, dtype=delta.dtype, device=delta.device)
     x = torch.empty((batch, dim, n_chunks, 2 * dstate), dtype=torch.float32, device=u.device)
+    if batch == 0 or seqlen == 0:  # nothing to launch (empty tensors have no device pointer)
+        return [out, x]
     P = _capi.ScanFwdParams()
     _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus)
     with torch.cuda.device(u.device):
@@ -133,6 +135,11 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     dC = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
     dD = torch.empty((dim,), dtype=torch.float32, device=u.device) if D is not None else None
     dbias = torch.empty((dim,), dtype=torch.float32, device=u.device) if delta_bias is not None else None
+    if batch == 0 or seqlen == 0:
+        for t in (dA, dD, dbias):
+            if t is not None:
+                t.zero_()
+        return [du, ddelta, dA, dB, dC, dD, dbias]
     ws_bytes = int(lib.oss_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, n_groups))
     ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.float32, device=u.device)
     P = _capi.ScanBwdParams()
