@@ -105,6 +105,20 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
 void oss_scan_set_variant(int fwd_variant, int bwd_variant);
 int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
 
+/* Depth-wise 3x3 convolution, stride 1, zero padding 1, of the OSS block: SS2D_1.conv2d
+ * (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:286-294) and the EFFN dwconv (:209); both are
+ * nn.Conv2d(C, C, 3, padding=1, groups=C).  x, y, dy, dx: (batch, C, H, W) io dtype with contiguous
+ * H*W planes and element strides (batch, channel); weight (C, 9) and bias (C) float (bias may be
+ * NULL).  oss_dwconv3x3_fwd computes y = conv(x) + bias; with flip = 1 it applies the mirrored taps,
+ * i.e. the input gradient dx = conv_transpose(dy).  oss_dwconv3x3_wgrad overwrites dweight (C, 9)
+ * and dbias (C, or NULL) with the sums over batch and pixels. */
+int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch,
+                      int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
+                      int64_t y_batch_stride, int64_t y_channel_stride, int flip, oss_stream_t stream);
+int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, int batch,
+                        int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
+                        int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
+
 /* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every
  * main forward / backward kernel launch is bracketed by HIP events recorded on the launch stream.
  * oss_prof_collect synchronises those events and returns, for one bucket (which: 0 = forward

@@ -55,9 +55,26 @@ def install_oracle_cpu_kernel():
         res = oss_oracle.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows)
         return [t if t is not None else torch.empty(0) for t in res]
 
+    import torch.nn.functional as F
+
+    def dw_fwd(x, weight, bias):  # plain PyTorch fp32 reference of the depth-wise conv
+        return F.conv2d(x.float(), weight.float(), None if bias is None else bias.float(), padding=1,
+                        groups=x.shape[1]).to(x.dtype)
+
+    def dw_bwd(x, weight, dy, has_bias):
+        xx = x.detach().float().requires_grad_()
+        ww = weight.detach().float().requires_grad_()
+        with torch.enable_grad():
+            y = F.conv2d(xx, ww, None, padding=1, groups=x.shape[1])
+        dx, dw = torch.autograd.grad(y, (xx, ww), dy.float())
+        db = dy.float().sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)
+        return [dx.to(x.dtype), dw, db]
+
     _CPU_LIB = torch.library.Library("vmambair", "IMPL")
     _CPU_LIB.impl("selective_scan_fwd", fwd, "CPU")
     _CPU_LIB.impl("selective_scan_bwd", bwd, "CPU")
+    _CPU_LIB.impl("dwconv3x3_fwd", dw_fwd, "CPU")
+    _CPU_LIB.impl("dwconv3x3_bwd", dw_bwd, "CPU")
 
 
 @pytest.fixture(scope="session")

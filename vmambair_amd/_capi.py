@@ -50,7 +50,7 @@ class ScanBwdParams(C.Structure):
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_set_variant", "oss_scan_last_variant", "oss_prof_enable", "oss_prof_reset",
-           "oss_prof_collect", "oss_hbm_copy", "oss_version"]
+           "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_hbm_copy", "oss_version"]
 
 _lib = None
 
@@ -89,6 +89,12 @@ def load():
     lib.oss_prof_collect.restype = C.c_int
     lib.oss_prof_collect.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                      C.POINTER(C.c_double)]
+    lib.oss_dwconv3x3_fwd.restype = C.c_int
+    lib.oss_dwconv3x3_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
+        [C.c_int64] * 4 + [C.c_int, C.c_void_p]
+    lib.oss_dwconv3x3_wgrad.restype = C.c_int
+    lib.oss_dwconv3x3_wgrad.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
+        [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_version.restype = C.c_char_p

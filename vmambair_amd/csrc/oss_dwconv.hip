@@ -1,0 +1,185 @@
+// oss_dwconv.hip -- depth-wise 3x3 convolution (stride 1, zero padding 1) of the OSS block for gfx950:
+// SS2D_1.conv2d (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:286-294, groups = channels, bias) and the
+// EFFN dwconv (:209, groups = channels, no bias).  HBM-bound stencil: every plane is read once and
+// written once; the 3x3 neighbourhood comes out of L1/L2 (a 64x64 plane is 8-16 KB).
+//
+// MIOpen runs these grouped convolutions in bf16 through generic grouped-conv / naive kernels
+// (profiles/r01_rocprof_bench_eager_last_step.txt: 390 ms of a 640 ms step in one
+// grouped_conv_bwd_weight kernel); the three kernels below replace forward, input-gradient (same
+// stencil with the taps mirrored) and weight/bias-gradient.
+#include "oss_device.h"
+#include "oss_host.h"
+
+namespace oss {
+
+template <typename T> struct Vec4;  // 4 consecutive elements
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
+        f32x4 q = *reinterpret_cast<const f32x4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[4]) {
+        *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <typename T> struct Vec4 {
+    static __device__ __forceinline__ void load(const T *p, float (&v)[4]) {
+        u32x2 q = *reinterpret_cast<const u32x2 *>(p);
+        unpack2<T>(q.x, v[0], v[1]); unpack2<T>(q.y, v[2], v[3]);
+    }
+    static __device__ __forceinline__ void store(T *p, const float (&v)[4]) {
+        *reinterpret_cast<u32x2 *>(p) = u32x2{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+    }
+};
+
+// y[b,c] = stencil(x[b,c]; taps of channel c (mirrored when flip)) + bias[c]
+// x: planes contiguous (H*W), batch / channel strides in elements; y likewise.
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256)
+oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                     T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
+                     int flip) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const T *xp = x + b * xsb + c * xsc;
+    T *yp = y + b * ysb + c * ysc;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + (flip ? 8 - i : i)];
+    const float bv = bias ? bias[c] : 0.f;
+    if constexpr (VEC) {
+        const int groups_per_row = W >> 2;
+        const int g = blockIdx.x * 256 + threadIdx.x;
+        if (g >= groups_per_row * H) return;
+        const int h = g / groups_per_row, w0 = (g - h * groups_per_row) << 2;
+        float acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int hh = h + dy;
+            if (hh < 0 || hh >= H) continue;
+            const T *row = xp + (int64_t)hh * W;
+            float v[6];
+            float m[4];
+            Vec4<T>::load(row + w0, m);
+            v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+            v[0] = (w0 > 0) ? to_f32(row[w0 - 1]) : 0.f;
+            v[5] = (w0 + 4 < W) ? to_f32(row[w0 + 4]) : 0.f;
+            const float k0 = k[(dy + 1) * 3], k1 = k[(dy + 1) * 3 + 1], k2 = k[(dy + 1) * 3 + 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_fmaf(k0, v[j], __builtin_fmaf(k1, v[j + 1], __builtin_fmaf(k2, v[j + 2], acc[j])));
+        }
+        Vec4<T>::store(yp + (int64_t)h * W + w0, acc);
+    } else {
+        const int p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= H * W) return;
+        const int h = p / W, ww = p - h * W;
+        float acc = bv;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int hh = h + dy;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int wc = ww + dx;
+                if (wc < 0 || wc >= W) continue;
+                acc = __builtin_fmaf(k[(dy + 1) * 3 + dx + 1], to_f32(xp[(int64_t)hh * W + wc]), acc);
+            }
+        }
+        yp[p] = from_f32<T>(acc);
+    }
+}
+
+// dw[c][ky][kx] = sum_{b,h,w} dy[b,c,h,w] x[b,c,h+ky-1,w+kx-1];  db[c] = sum dy.  One workgroup per
+// channel walks the batch; fixed summation order (deterministic).
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw,
+                           float *__restrict__ db, int B, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb,
+                           int64_t gsc) {
+    const int c = blockIdx.x;
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    const int HW = H * W;
+    for (int b = 0; b < B; ++b) {
+        const T *xp = x + b * xsb + c * xsc;
+        const T *gp = dy + b * gsb + c * gsc;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int h = p / W, ww = p - h * W;
+            const float g = to_f32(gp[p]);
+            acc[9] += g;
+#pragma unroll
+            for (int dyy = -1; dyy <= 1; ++dyy) {
+                const int hh = h + dyy;
+                if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int wc = ww + dx;
+                    if (wc < 0 || wc >= W) continue;
+                    acc[(dyy + 1) * 3 + dx + 1] = __builtin_fmaf(g, to_f32(xp[(int64_t)hh * W + wc]), acc[(dyy + 1) * 3 + dx + 1]);
+                }
+            }
+        }
+    }
+    __shared__ float red[4][10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const float s = segment_sum_to_last<64>(acc[i]);
+        if (lane == 63) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        if (threadIdx.x < 9) dw[c * 9 + threadIdx.x] = s;
+        else if (db) db[c] = s;
+    }
+}
+
+template <typename T>
+static int dwconv_launch(const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
+                         int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s) {
+    const T *xp = reinterpret_cast<const T *>(x);
+    T *yp = reinterpret_cast<T *>(y);
+    const uintptr_t amask = sizeof(T) == 4 ? 15u : 7u;
+    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & amask) == 0 &&
+                     (xsb % 4 == 0) && (xsc % 4 == 0) && (ysb % 4 == 0) && (ysc % 4 == 0);
+    if (vec) {
+        const int groups = (W / 4) * H;
+        dim3 grid((groups + 255) / 256, C, B);
+        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip);
+    } else {
+        dim3 grid((H * W + 255) / 256, C, B);
+        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip);
+    }
+    return (int)hipGetLastError();
+}
+
+int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
+              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s) {
+    switch (io) {
+        case OSS_F32: return dwconv_launch<float>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s);
+        case OSS_F16: return dwconv_launch<f16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s);
+        case OSS_BF16: return dwconv_launch<bf16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s);
+    }
+    return OSS_ERR_SHAPE;
+}
+
+template <typename T>
+static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, int B, int C, int H, int W, int64_t xsb,
+                        int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
+    hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T>), dim3(C), dim3(256), 0, s, reinterpret_cast<const T *>(x),
+                       reinterpret_cast<const T *>(dy), dw, db, B, H, W, xsb, xsc, gsb, gsc);
+    return (int)hipGetLastError();
+}
+
+int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, int B, int C, int H, int W,
+                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
+    switch (io) {
+        case OSS_F32: return wgrad_launch<float>(x, dy, dw, db, B, C, H, W, xsb, xsc, gsb, gsc, s);
+        case OSS_F16: return wgrad_launch<f16_t>(x, dy, dw, db, B, C, H, W, xsb, xsc, gsb, gsc, s);
+        case OSS_BF16: return wgrad_launch<bf16_t>(x, dy, dw, db, B, C, H, W, xsb, xsc, gsb, gsc, s);
+    }
+    return OSS_ERR_SHAPE;
+}
+
+}  // namespace oss

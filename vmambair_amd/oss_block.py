@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .ops import dwconv3x3
 from .selective_scan import SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
@@ -73,7 +74,7 @@ class FeedForward(nn.Module):
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x1, x2 = self.dwconv(self.project_in(x)).chunk(2, dim=1)
+        x1, x2 = dwconv3x3(self.project_in(x), self.dwconv).chunk(2, dim=1)
         return self.project_out(F.gelu(x1) * x2)
 
 
@@ -211,7 +212,7 @@ class SS2D_1(nn.Module):
         xz = self.in_conv(x)
         x, z = xz.chunk(2, dim=1)
         z = F.silu(z)
-        x = F.silu(self.conv2d(x))
+        x = F.silu(dwconv3x3(x, self.conv2d))
         y2 = self.forward_core(x) * z
         c = self.cforward_core(y2)
         y2 = (y2 + c) if self.gate == "add" else (y2 * c + y2)
