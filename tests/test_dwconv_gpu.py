@@ -73,19 +73,20 @@ def test_graphed_train_step_matches_eager():
     lq = torch.rand(2, 3, 16, 16, device=DEV)
     gt = torch.rand(2, 3, 64, 64, device=DEV)
     net_g = make()
-    step = GraphedTrainStep(net_g, autocast_dtype=None, warmup=0)
+    # one eager warm-up step happens inside capture() (optimizer state must exist before capture),
+    # so the three replays are training steps 2..4
+    step = GraphedTrainStep(net_g, autocast_dtype=None, warmup=1)
     losses_g = [float(step(lq, gt)) for _ in range(3)]
     net_e = make()
     opt = torch.optim.Adam(net_e.parameters(), lr=2e-4, betas=(0.9, 0.99))
     losses_e = []
-    for _ in range(3):
+    for _ in range(4):
         opt.zero_grad(set_to_none=True)
         loss = F.l1_loss(net_e(lq), gt)
         loss.backward()
         opt.step()
         losses_e.append(float(loss))
-    assert losses_g[0] == pytest.approx(losses_e[0], rel=1e-5)
-    for a, b in zip(losses_g, losses_e):
+    for a, b in zip(losses_g, losses_e[1:]):
         assert a == pytest.approx(b, rel=2e-3)
     assert losses_g[2] < losses_g[0]
     for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
