@@ -110,6 +110,9 @@ def cpu_baseline(seed=0):
     lib.impl("dwconv3x3_bwd", dw_bwd, "CPU")
     torch.manual_seed(seed)
     net = build_network(NET)
+    for m in net.modules():  # the host baseline runs the reference's literal data flow (four flattenings)
+        if hasattr(m, "omni"):
+            m.omni = False
     ema = [p.detach().clone() for p in net.parameters()]
     opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99))
     step = make_step(net, ema, opt, None, "cpu")

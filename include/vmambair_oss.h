@@ -55,6 +55,14 @@ typedef void *oss_stream_t;
 typedef struct {
     int batch, dim, seqlen, dstate, n_groups;
     int delta_softplus;
+    /* Omni-scan direction handling without materialising the four flattenings:
+     *   rev_group_start : rows of groups g >= rev_group_start are scanned from t = L-1 down to 0, i.e.
+     *                     every time-indexed tensor of those rows/groups (u, delta, B, C, out, dout,
+     *                     du, ddelta, dB, dC) is read and written mirrored in time.  n_groups (or
+     *                     any value >= n_groups) = none: the reference's plain call.
+     *   u_row_mod       : when > 0, row d reads u[:, d % u_row_mod, :] (du still has `dim` rows), so
+     *                     that directions k and k+2 share one copy of the activations.  0 = off. */
+    int rev_group_start, u_row_mod;
     int64_t u_batch_stride, u_d_stride;
     int64_t delta_batch_stride, delta_d_stride;
     int64_t out_batch_stride, out_d_stride;
@@ -111,12 +119,13 @@ int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
  * H*W planes and element strides (batch, channel); weight (C, 9) and bias (C) float (bias may be
  * NULL).  oss_dwconv3x3_fwd computes y = conv(x) + bias; with flip = 1 it applies the mirrored taps,
  * i.e. the input gradient dx = conv_transpose(dy).  oss_dwconv3x3_wgrad overwrites dweight (C, 9)
- * and dbias (C, or NULL) with the sums over batch and pixels. */
+ * and dbias (C, or NULL) with the sums over batch and pixels; `partials` is batch*C*10 floats of
+ * scratch (no init needed). */
 int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch,
                       int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
                       int64_t y_batch_stride, int64_t y_channel_stride, int flip, oss_stream_t stream);
-int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, int batch,
-                        int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
+int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,
+                        int batch, int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
                         int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
 
 /* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every

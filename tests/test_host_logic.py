@@ -86,6 +86,7 @@ def test_direction_maps_bit_exact(monkeypatch):
     z = load_golden("g2_perm.npz")
     m = SS2D_1(d_model=2, ssm_ratio=1, variant="srgan")
     m.out_norm = torch.nn.Identity()
+    m.omni = False  # the literal reference data flow materialises xs
     seen = {}
 
     def fake_scan(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1):
@@ -117,3 +118,50 @@ def test_channel_direction_maps_bit_exact():
     assert torch.equal(xsc, z["xsc"])
     oy = z["out_y"]
     assert torch.equal(oy[:, 0] + oy[:, 1].flip(-1), z["y"])
+
+
+def test_omni_form_equals_reference_data_flow(oracle_cpu_kernel):
+    """SS2D_1.forward_core (two flattenings + mirrored scan directions) against forward_core_xs (the
+    reference's four flattenings): same numbers, and the same gradients."""
+    torch.manual_seed(0)
+    z = load_golden("g3_block_srgan_ss2d_d48.npz")
+    m = SS2D_1(d_model=48, ssm_ratio=1, variant="srgan")
+    m.load_state_dict(_state(z))
+    x = torch.randn(2, 48, 6, 10)
+    res = []
+    for omni in (True, False):
+        m.omni = omni
+        m.zero_grad()
+        xi = x.clone().requires_grad_()
+        y = m.forward_core(xi)
+        y.square().sum().backward()
+        res.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert_close(res[0][0], res[1][0], 1e-5, 1e-5, "y")
+    assert_close(res[0][1], res[1][1], 1e-4, 1e-4, "dx")
+    for k in res[1][2]:
+        assert_close(res[0][2][k], res[1][2][k], 1e-3, 1e-4 * max(1.0, float(res[1][2][k].abs().max())), k)
+
+
+def test_omni_direction_maps_bit_exact(monkeypatch):
+    """integer data through the omni path: what the kernels are asked to scan is, direction by
+    direction, exactly the reference's xs (MambaSISR6_arch.py:401-404) and the merge is G2's y."""
+    from vmambair_amd import selective_scan as ss
+    z = load_golden("g2_perm.npz")
+    m = SS2D_1(d_model=2, ssm_ratio=1, variant="srgan")
+    m.out_norm = torch.nn.Identity()
+    seen = {}
+
+    class FakeOmni:
+        @staticmethod
+        def apply(x2, delta, A, B, C, D, bias):
+            Bsz, rows, L = x2.shape
+            xs = torch.cat([x2, x2.flip(-1)], dim=1)  # what rev_group_start = 2 / u_row_mod = rows mean
+            seen["xs"] = xs.detach().clone()
+            oy = z["out_y"].view(Bsz, 4, -1, L).clone()
+            oy[:, 2:] = oy[:, 2:].flip(-1)             # the kernels store mirrored directions un-flipped
+            return oy.view(Bsz, -1, L)
+
+    monkeypatch.setattr(oss_block, "OmniScanFn", FakeOmni)
+    y = m.forward_core(z["x"])
+    assert torch.equal(seen["xs"], z["xs"])
+    assert torch.equal(y, z["y"])

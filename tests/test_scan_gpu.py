@@ -320,3 +320,67 @@ def test_full_size_properties(itype):
     subg = oss_oracle.scan_bwd(*sub, dout[b:b + 1, rows].cpu(), None, True)
     assert_close(g1[0][b:b + 1, rows], subg[0], rtol * 2, atol * 2, "sampled du")
     assert_close(g1[1][b:b + 1, rows], subg[1], rtol * 5, atol * 10, "sampled ddelta")
+
+
+# ------------------------------------------------------------------------------------------------
+# omni form: mirrored directions and shared u rows inside the kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seqlen", [64, 100, 513, 1024, 2085])
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("rows", [8, 48])
+def test_omni_scan_matches_materialised_directions(seqlen, itype, rows):
+    """omni_scan(x2, ...) == selective_scan(cat[x2, flip x2], flip of delta/B/C for k >= 2) with the
+    outputs and gradients of the mirrored directions flipped back (reference data flow:
+    MambaSISR6_arch.py:401-428)."""
+    K, N, Bsz = 4, 16, 2
+    g = torch.Generator().manual_seed(11)
+    x2 = torch.randn(Bsz, 2 * rows, seqlen, generator=g).to(itype)
+    delta = (0.5 * torch.rand(Bsz, K * rows, seqlen, generator=g)).to(itype)
+    A = -0.5 * torch.rand(K * rows, N, generator=g)
+    Bm = torch.randn(Bsz, K, N, seqlen, generator=g).to(itype)
+    Cm = torch.randn(Bsz, K, N, seqlen, generator=g).to(itype)
+    D = torch.randn(K * rows, generator=g)
+    bias = 0.5 * torch.rand(K * rows, generator=g)
+    dout = torch.randn(Bsz, K * rows, seqlen, generator=g).to(itype)
+
+    def mirror(t, per):
+        t = t.clone()
+        t[:, 2 * per:] = t[:, 2 * per:].flip(-1)
+        return t
+
+    u4 = mirror(x2.repeat(1, 2, 1), rows)
+    ref_out, ref_x = oss_oracle.scan_fwd(u4, mirror(delta, rows), A, mirror(Bm, 1), mirror(Cm, 1), D, bias, True, chunk=256)
+    ref = oss_oracle.scan_bwd(u4, mirror(delta, rows), A, mirror(Bm, 1), mirror(Cm, 1), D, bias, mirror(dout, rows), None, True)
+    dv = [t.to(DEV) for t in (x2, delta, A, Bm, Cm, D, bias)]
+    out, x = vmambair_amd.selective_scan_fwd(*dv, True, 1, rev_group_start=2, u_row_mod=2 * rows)
+    grads = vmambair_amd.selective_scan_bwd(*dv, dout.to(DEV), x, True, 1, rev_group_start=2, u_row_mod=2 * rows)
+    rtol, atol = TOL[itype]
+    assert_close(out, mirror(ref_out, rows), rtol, atol, "out")
+    assert_close(x[..., 1::2], ref_x[..., 1::2], 6e-4, 2e-3, "states")
+    assert_close(grads[0], mirror(ref[0], rows), rtol * 2, atol * 2, "du (per direction)")
+    assert_close(grads[1], mirror(ref[1], rows), rtol * 5, atol * 10, "ddelta")
+    wa = (2e-5 if itype == torch.float32 else 2e-3)
+    assert_close(grads[2], ref[2], RTOLW, max(ATOLW * 5, wa * float(ref[2].abs().max())), "dA")
+    assert_close(grads[3], mirror(ref[3], 1), rtol, atol, "dB")
+    assert_close(grads[4], mirror(ref[4], 1), rtol, atol, "dC")
+    assert_close(grads[5], ref[5], RTOLW, max(ATOLW, wa * float(ref[5].abs().max())), "dD")
+    assert_close(grads[6], ref[6], RTOLW, max(ATOLW, wa * float(ref[6].abs().max())), "dbias")
+
+
+def test_omni_block_path_equals_reference_data_flow_on_gpu():
+    from vmambair_amd.oss_block import SS2D_1
+    torch.manual_seed(0)
+    m = SS2D_1(d_model=48, ssm_ratio=1, variant="srgan").to(DEV)
+    x = torch.randn(2, 48, 16, 24, device=DEV)
+    res = []
+    for omni in (True, False):
+        m.omni = omni
+        m.zero_grad()
+        xi = x.clone().requires_grad_()
+        y = m.forward_core(xi)
+        y.square().sum().backward()
+        res.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert_close(res[0][0], res[1][0], 1e-4, 1e-4, "y")
+    assert_close(res[0][1], res[1][1], 1e-3, 1e-3, "dx")
+    for k in res[1][2]:
+        assert_close(res[0][2][k], res[1][2][k], 2e-3, 2e-4 * max(1.0, float(res[1][2][k].abs().max())), k)

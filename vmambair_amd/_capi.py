@@ -23,7 +23,7 @@ ERRORS = {
 class ScanFwdParams(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("dim", C.c_int), ("seqlen", C.c_int), ("dstate", C.c_int), ("n_groups", C.c_int),
-        ("delta_softplus", C.c_int),
+        ("delta_softplus", C.c_int), ("rev_group_start", C.c_int), ("u_row_mod", C.c_int),
         ("u_batch_stride", C.c_int64), ("u_d_stride", C.c_int64),
         ("delta_batch_stride", C.c_int64), ("delta_d_stride", C.c_int64),
         ("out_batch_stride", C.c_int64), ("out_d_stride", C.c_int64),
@@ -93,7 +93,7 @@ def load():
     lib.oss_dwconv3x3_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
         [C.c_int64] * 4 + [C.c_int, C.c_void_p]
     lib.oss_dwconv3x3_wgrad.restype = C.c_int
-    lib.oss_dwconv3x3_wgrad.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
+    lib.oss_dwconv3x3_wgrad.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
         [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]

@@ -90,6 +90,7 @@ static int check_fwd(const oss_scan_fwd_params *p) {
     if (p->batch < 0 || p->dim <= 0 || p->seqlen < 0 || p->dstate <= 0 || p->n_groups <= 0) return OSS_ERR_SHAPE;
     if (p->dim % p->n_groups != 0) return OSS_ERR_SHAPE;  // selective_scan.cpp:190
     if (p->dstate > OSS_MAX_DSTATE) return OSS_ERR_DSTATE;  // selective_scan.cpp:191
+    if (p->rev_group_start < 0 || p->u_row_mod < 0 || (p->u_row_mod > 0 && p->dim % p->u_row_mod != 0)) return OSS_ERR_SHAPE;
     return OSS_OK;
 }
 
@@ -169,12 +170,12 @@ int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const fl
                      reinterpret_cast<hipStream_t>(stream));
 }
 
-int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, int batch,
-                        int channels, int height, int width, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
+int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,
+                        int batch, int channels, int height, int width, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
                         oss_stream_t stream) {
-    if (!x || !dy || !dweight) return OSS_ERR_NULL;
-    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0) return OSS_ERR_SHAPE;
-    return dwconv3x3_wgrad(io, x, dy, dweight, dbias, batch, channels, height, width, xsb, xsc, gsb, gsc,
+    if (!x || !dy || !dweight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwconv3x3_wgrad(io, x, dy, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, gsb, gsc,
                            reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -149,6 +149,95 @@ template <typename T, int I> __device__ __forceinline__ bool vec_ok(const T *p) 
     return (reinterpret_cast<uintptr_t>(p) & (vec_align<T, I>() - 1)) == 0;
 }
 
+// LDS image of a [NB][TC] tile such that lane p's I items are I/4 conflict-free 16-byte reads:
+//   element (state n, position p, item i) -> n*TC + (i/4)*(LPR*4) + p*4 + (i%4)
+template <int LPR, int I>
+__device__ __forceinline__ int tile_off(int n, int p, int i) {
+    return n * (LPR * I) + (i >> 2) * (LPR * 4) + p * 4 + (i & 3);
+}
+
+// I items of one lane at scan positions tl .. tl+I-1 of a row of length L.  Forward rows read
+// memory tl+i; time-reversed rows read memory L-1-(tl+i) (one contiguous block, mirrored in
+// registers).  Positions >= L read as 0.
+template <int I, typename T>
+__device__ __forceinline__ void load_items_dir(const T *row, int tl, int valid, int L, bool rev, float (&v)[I]) {
+    if (!rev) {
+        const T *p = row + tl;
+        load_items<I>(p, valid, valid == I && vec_ok<T, I>(p), v);
+    } else if (valid == I) {
+        const T *p = row + (L - tl - I);
+        float tmp[I];
+        load_items<I>(p, I, vec_ok<T, I>(p), tmp);
+#pragma unroll
+        for (int i = 0; i < I; ++i) v[i] = tmp[I - 1 - i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < I; ++i) v[i] = (i < valid) ? to_f32(row[L - 1 - tl - i]) : 0.f;
+    }
+}
+template <int I, typename T>
+__device__ __forceinline__ void store_items_dir(T *row, int tl, int valid, int L, bool rev, const float (&v)[I]) {
+    if (!rev) {
+        T *p = row + tl;
+        store_items<I>(p, valid, valid == I && vec_ok<T, I>(p), v);
+    } else if (valid == I) {
+        T *p = row + (L - tl - I);
+        float tmp[I];
+#pragma unroll
+        for (int i = 0; i < I; ++i) tmp[i] = v[I - 1 - i];
+        store_items<I>(p, I, vec_ok<T, I>(p), tmp);
+    } else {
+#pragma unroll
+        for (int i = 0; i < I; ++i)
+            if (i < valid) row[L - 1 - tl - i] = from_f32<T>(v[i]);
+    }
+}
+
+// Stage nb state rows x TC scan positions of one (batch, group) of B and C into the LDS tiles as
+// fp32 (tile_off image).  `rev`: scan position s reads memory L-1-s.
+template <typename T, int LPR, int I, int NT>
+__device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB, const T *gC, int64_t strideB,
+                                               int64_t strideC, int nb, int t0, int L, bool rev, int tid) {
+    constexpr int TC = LPR * I;
+    constexpr int Q = TC / 4;  // 4-position groups per state row
+    const bool fullchunk = (t0 + TC <= L);
+    constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
+    for (int idx = tid; idx < nb * Q; idx += NT) {
+        const int n = idx / Q, k = idx - n * Q;
+        const int s0 = t0 + 4 * k;                       // first scan position of the group
+        const int m0 = rev ? (L - 4 - s0) : s0;          // lowest memory index of the group
+        const T *pb = gB + n * strideB + m0;
+        const T *pc = gC + n * strideC + m0;
+        float b4[4], c4[4];
+        if (fullchunk && ((reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(pc)) & amask) == 0) {
+            if constexpr (sizeof(T) == 4) {
+                f32x4 qb = *reinterpret_cast<const f32x4 *>(pb), qc = *reinterpret_cast<const f32x4 *>(pc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { b4[j] = qb[j]; c4[j] = qc[j]; }
+            } else {
+                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb), qc = *reinterpret_cast<const u32x2 *>(pc);
+                unpack2<T>(qb.x, b4[0], b4[1]); unpack2<T>(qb.y, b4[2], b4[3]);
+                unpack2<T>(qc.x, c4[0], c4[1]); unpack2<T>(qc.y, c4[2], c4[3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // memory index m0 + j; valid iff its scan position < L
+                const int m = m0 + j;
+                const bool ok = m >= 0 && m < L;
+                b4[j] = ok ? to_f32(gB[n * strideB + m]) : 0.f;
+                c4[j] = ok ? to_f32(gC[n * strideC + m]) : 0.f;
+            }
+        }
+        f32x4 vb, vc;
+        if (rev) { vb = f32x4{b4[3], b4[2], b4[1], b4[0]}; vc = f32x4{c4[3], c4[2], c4[1], c4[0]}; }
+        else     { vb = f32x4{b4[0], b4[1], b4[2], b4[3]}; vc = f32x4{c4[0], c4[1], c4[2], c4[3]}; }
+        const int pos = (4 * k) / I, i0 = (4 * k) % I;
+        const int off = tile_off<LPR, I>(n, pos, i0);
+        *reinterpret_cast<f32x4 *>(sB + off) = vb;
+        *reinterpret_cast<f32x4 *>(sC + off) = vc;
+    }
+}
+
 template <typename T> __device__ __forceinline__ bool aligned16(const T *p) {
     return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
@@ -274,11 +363,5 @@ __device__ __forceinline__ float segment_mirror(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
 }
 
-// LDS image of a [NB][TC] tile such that lane p's I items are I/4 conflict-free 16-byte reads:
-//   element (state n, position p, item i) -> n*TC + (i/4)*(LPR*4) + p*4 + (i%4)
-template <int LPR, int I>
-__device__ __forceinline__ int tile_off(int n, int p, int i) {
-    return n * (LPR * I) + (i >> 2) * (LPR * 4) + p * 4 + (i & 3);
-}
 
 }  // namespace oss

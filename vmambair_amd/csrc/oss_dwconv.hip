@@ -88,21 +88,47 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
     }
 }
 
-// dw[c][ky][kx] = sum_{b,h,w} dy[b,c,h,w] x[b,c,h+ky-1,w+kx-1];  db[c] = sum dy.  One workgroup per
-// channel walks the batch; fixed summation order (deterministic).
-template <typename T>
+// dw[c][ky][kx] = sum_{b,h,w} dy[b,c,h,w] x[b,c,h+ky-1,w+kx-1];  db[c] = sum dy.
+// Stage 1: one workgroup per (channel, batch) plane writes 10 partial sums; stage 2 adds the batch
+// partials in batch order (deterministic, no atomics).
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256)
-oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ dw,
-                           float *__restrict__ db, int B, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb,
-                           int64_t gsc) {
-    const int c = blockIdx.x;
+oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part /*[B][C][10]*/,
+                           int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc) {
+    const int c = blockIdx.x, b = blockIdx.y;
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-    const int HW = H * W;
-    for (int b = 0; b < B; ++b) {
-        const T *xp = x + b * xsb + c * xsc;
-        const T *gp = dy + b * gsb + c * gsc;
+    const T *xp = x + b * xsb + c * xsc;
+    const T *gp = dy + b * gsb + c * gsc;
+    if constexpr (VEC) {
+        const int gpr = W >> 2, ngroups = gpr * H;
+        for (int g = threadIdx.x; g < ngroups; g += 256) {
+            const int h = g / gpr, w0 = (g - h * gpr) << 2;
+            float gv[4];
+            Vec4<T>::load(gp + (int64_t)h * W + w0, gv);
+            acc[9] += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+#pragma unroll
+            for (int dyy = -1; dyy <= 1; ++dyy) {
+                const int hh = h + dyy;
+                if (hh < 0 || hh >= H) continue;
+                const T *row = xp + (int64_t)hh * W;
+                float v[6], m[4];
+                Vec4<T>::load(row + w0, m);
+                v[1] = m[0]; v[2] = m[1]; v[3] = m[2]; v[4] = m[3];
+                v[0] = (w0 > 0) ? to_f32(row[w0 - 1]) : 0.f;
+                v[5] = (w0 + 4 < W) ? to_f32(row[w0 + 4]) : 0.f;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float a = acc[(dyy + 1) * 3 + dx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a = __builtin_fmaf(gv[j], v[j + dx], a);
+                    acc[(dyy + 1) * 3 + dx] = a;
+                }
+            }
+        }
+    } else {
+        const int HW = H * W;
         for (int p = threadIdx.x; p < HW; p += 256) {
             const int h = p / W, ww = p - h * W;
             const float g = to_f32(gp[p]);
@@ -128,11 +154,20 @@ oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, fl
         if (lane == 63) red[wave][i] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 10) {
-        const float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        if (threadIdx.x < 9) dw[c * 9 + threadIdx.x] = s;
-        else if (db) db[c] = s;
-    }
+    if (threadIdx.x < 10)
+        part[((size_t)b * C + c) * 10 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256)
+oss_dwconv3x3_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int B, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // over C*10
+    if (i >= C * 10) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[(size_t)b * C * 10 + i];
+    const int c = i / 10, k = i - c * 10;
+    if (k < 9) dw[c * 9 + k] = s;
+    else if (db) db[c] = s;
 }
 
 template <typename T>
@@ -165,19 +200,27 @@ int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, vo
 }
 
 template <typename T>
-static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, int B, int C, int H, int W, int64_t xsb,
-                        int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
-    hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T>), dim3(C), dim3(256), 0, s, reinterpret_cast<const T *>(x),
-                       reinterpret_cast<const T *>(dy), dw, db, B, H, W, xsb, xsc, gsb, gsc);
+static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H, int W,
+                        int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
+    const T *xp = reinterpret_cast<const T *>(x);
+    const T *gp = reinterpret_cast<const T *>(dy);
+    const uintptr_t amask = sizeof(T) == 4 ? 15u : 7u;
+    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(gp)) & amask) == 0 &&
+                     (xsb % 4 == 0) && (xsc % 4 == 0) && (gsb % 4 == 0) && (gsc % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, true>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc);
+    else
+        hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, false>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc);
+    hipLaunchKernelGGL(oss_dwconv3x3_wgrad_finish, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, dw, db, B, C);
     return (int)hipGetLastError();
 }
 
-int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, int B, int C, int H, int W,
-                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
+int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
+                    int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
     switch (io) {
-        case OSS_F32: return wgrad_launch<float>(x, dy, dw, db, B, C, H, W, xsb, xsc, gsb, gsc, s);
-        case OSS_F16: return wgrad_launch<f16_t>(x, dy, dw, db, B, C, H, W, xsb, xsc, gsb, gsc, s);
-        case OSS_BF16: return wgrad_launch<bf16_t>(x, dy, dw, db, B, C, H, W, xsb, xsc, gsb, gsc, s);
+        case OSS_F32: return wgrad_launch<float>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s);
+        case OSS_F16: return wgrad_launch<f16_t>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s);
+        case OSS_BF16: return wgrad_launch<bf16_t>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s);
     }
     return OSS_ERR_SHAPE;
 }

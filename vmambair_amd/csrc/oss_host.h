@@ -22,7 +22,7 @@ int scan_bwd_rows_per_wg(int variant);
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups);
 int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
               int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s);
-int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, int B, int C, int H, int W,
-                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
+int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
+                    int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

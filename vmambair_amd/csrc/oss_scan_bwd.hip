@@ -26,47 +26,6 @@
 
 namespace oss {
 
-template <typename T, int LPR, int I, int NT>
-__device__ __forceinline__ void stage_tiles_b(float *sB, float *sC, const T *gB, const T *gC,
-                                              int64_t strideB, int64_t strideC, int nb, int t0, int L,
-                                              int tid) {
-    constexpr int TC = LPR * I;
-    constexpr int Q = TC / 4;
-    const bool fullchunk = (t0 + TC <= L);
-    for (int idx = tid; idx < nb * Q; idx += NT) {
-        const int n = idx / Q, k = idx - n * Q;
-        const int t = t0 + 4 * k;
-        const T *pb = gB + n * strideB + t;
-        const T *pc = gC + n * strideC + t;
-        f32x4 vb, vc;
-        constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
-        if (fullchunk && ((reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(pc)) & amask) == 0) {
-            if constexpr (sizeof(T) == 4) {
-                vb = *reinterpret_cast<const f32x4 *>(pb);
-                vc = *reinterpret_cast<const f32x4 *>(pc);
-            } else {
-                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb);
-                u32x2 qc = *reinterpret_cast<const u32x2 *>(pc);
-                float a0, a1, a2, a3;
-                unpack2<T>(qb.x, a0, a1); unpack2<T>(qb.y, a2, a3);
-                vb = f32x4{a0, a1, a2, a3};
-                unpack2<T>(qc.x, a0, a1); unpack2<T>(qc.y, a2, a3);
-                vc = f32x4{a0, a1, a2, a3};
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                vb[j] = (t + j < L) ? to_f32(pb[j]) : 0.f;
-                vc[j] = (t + j < L) ? to_f32(pc[j]) : 0.f;
-            }
-        }
-        const int pos = (4 * k) / I, i0 = (4 * k) % I;
-        const int off = tile_off<LPR, I>(n, pos, i0);
-        *reinterpret_cast<f32x4 *>(sB + off) = vb;
-        *reinterpret_cast<f32x4 *>(sC + off) = vc;
-    }
-}
-
 // workspace layout (floats):
 //   [0, nBC)                 dB/dC partials  [batch][group][tile][2][N][L]
 //   [nBC, nBC + batch*dim*N) dA partials     [batch][dim][N]
@@ -114,8 +73,10 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     const int row_in_group = tile * ROWS + wrow;
     const bool row_valid = row_in_group < rows_per_group;
     const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
+    const bool rev = g >= f.rev_group_start;
+    const int d_u = f.u_row_mod > 0 ? d % f.u_row_mod : d;
 
-    const T *u_row = reinterpret_cast<const T *>(f.u) + b * f.u_batch_stride + d * f.u_d_stride;
+    const T *u_row = reinterpret_cast<const T *>(f.u) + b * f.u_batch_stride + d_u * f.u_d_stride;
     const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride + d * f.delta_d_stride;
     const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d * p.dout_d_stride;
     T *du_row = reinterpret_cast<T *>(p.du) + b * p.du_batch_stride + d * p.du_d_stride;
@@ -144,12 +105,10 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;
         const int valid = max(0, min(I, L - tl));
-        const bool vec = valid == I && vec_ok<T, I>(u_row + tl) && vec_ok<T, I>(dt_row + tl) &&
-                         vec_ok<T, I>(g_row + tl) && vec_ok<T, I>(du_row + tl) && vec_ok<T, I>(dd_row + tl);
         float uu[I], dl[I], gg[I], sig[I], w[I], Q[I], dd[I];
-        load_items<I>(u_row + tl, valid, vec, uu);
-        load_items<I>(dt_row + tl, valid, vec, dl);
-        load_items<I>(g_row + tl, valid, vec, gg);
+        load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+        load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+        load_items_dir<I>(g_row, tl, valid, L, rev, gg);
         if (!row_valid) {  // a row slot past the end of the group must not contribute to dB/dC
 #pragma unroll
             for (int i = 0; i < I; ++i) { uu[i] = 0.f; gg[i] = 0.f; }
@@ -182,9 +141,9 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         for (int n0 = 0; n0 < N; n0 += NBB) {
             const int nb = min(NBB, N - n0);
             __syncthreads();
-            stage_tiles_b<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * f.B_dstate_stride,
-                                         gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
-                                         f.C_dstate_stride, nb, t0, L, tid);
+            stage_bc_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * f.B_dstate_stride,
+                                          gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
+                                          f.C_dstate_stride, nb, t0, L, rev, tid);
             __syncthreads();
             for (int nn = 0; nn < nb; ++nn) {
                 const int n = n0 + nn;
@@ -285,10 +244,11 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                         accb += slab[(r * 2) * TC + tid];
                         accc += slab[(r * 2 + 1) * TC + tid];
                     }
-                    const int t = t0 + tid;
+                    const int t = t0 + tid;  // scan position; mirrored groups store at L-1-t
                     if (t < L) {
-                        ws_bc[(size_t)n * L + t] = accb;
-                        ws_bc[(size_t)(N + n) * L + t] = accc;
+                        const int tm = rev ? (L - 1 - t) : t;
+                        ws_bc[(size_t)n * L + tm] = accb;
+                        ws_bc[(size_t)(N + n) * L + tm] = accc;
                     }
                 }
             }
@@ -304,8 +264,8 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             db_acc += dv[i];
         }
         if (row_valid) {
-            store_items<I>(du_row + tl, valid, vec, du);
-            store_items<I>(dd_row + tl, valid, vec, dv);
+            store_items_dir<I>(du_row, tl, valid, L, rev, du);
+            store_items_dir<I>(dd_row, tl, valid, L, rev, dv);
         }
         __syncthreads();  // every lane has read sdln for this chunk
         if (seg_first) sdln[wrow] = dl[0];

@@ -20,55 +20,6 @@
 
 namespace oss {
 
-// Stage nb state rows x TC steps of one (batch, group) of B and C into the LDS tiles (fp32).
-template <typename T, int LPR, int I, int NT>
-__device__ __forceinline__ void stage_tiles(float *sB, float *sC, const T *gB, const T *gC,
-                                            int64_t strideB, int64_t strideC, int nb, int t0, int L,
-                                            int tid) {
-    constexpr int TC = LPR * I;
-    constexpr int Q = TC / 4;  // 4-element groups per state row
-    const bool fullchunk = (t0 + TC <= L);
-    for (int idx = tid; idx < nb * Q; idx += NT) {
-        const int n = idx / Q, k = idx - n * Q;
-        const int t = t0 + 4 * k;
-        const T *pb = gB + n * strideB + t;
-        const T *pc = gC + n * strideC + t;
-        f32x4 vb, vc;
-        if constexpr (sizeof(T) == 4) {
-            if (fullchunk && aligned16(pb) && aligned16(pc)) {
-                vb = *reinterpret_cast<const f32x4 *>(pb);
-                vc = *reinterpret_cast<const f32x4 *>(pc);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    vb[j] = (t + j < L) ? to_f32(pb[j]) : 0.f;
-                    vc[j] = (t + j < L) ? to_f32(pc[j]) : 0.f;
-                }
-            }
-        } else {
-            if (fullchunk && ((reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(pc)) & 7u) == 0) {
-                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb);
-                u32x2 qc = *reinterpret_cast<const u32x2 *>(pc);
-                float a0, a1, a2, a3;
-                unpack2<T>(qb.x, a0, a1); unpack2<T>(qb.y, a2, a3);
-                vb = f32x4{a0, a1, a2, a3};
-                unpack2<T>(qc.x, a0, a1); unpack2<T>(qc.y, a2, a3);
-                vc = f32x4{a0, a1, a2, a3};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    vb[j] = (t + j < L) ? to_f32(pb[j]) : 0.f;
-                    vc[j] = (t + j < L) ? to_f32(pc[j]) : 0.f;
-                }
-            }
-        }
-        const int pos = (4 * k) / I, i0 = (4 * k) % I;
-        const int off = tile_off<LPR, I>(n, pos, i0);
-        *reinterpret_cast<f32x4 *>(sB + off) = vb;
-        *reinterpret_cast<f32x4 *>(sC + off) = vc;
-    }
-}
-
 template <typename T, int LPR, int I, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
@@ -101,8 +52,10 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
     const int row_in_group = tile * ROWS + wrow;
     const bool row_valid = row_in_group < rows_per_group;
     const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
+    const bool rev = g >= p.rev_group_start;                       // time-mirrored direction
+    const int d_u = p.u_row_mod > 0 ? d % p.u_row_mod : d;          // directions sharing one copy of u
 
-    const T *u_row = reinterpret_cast<const T *>(p.u) + b * p.u_batch_stride + d * p.u_d_stride;
+    const T *u_row = reinterpret_cast<const T *>(p.u) + b * p.u_batch_stride + d_u * p.u_d_stride;
     const T *dt_row = reinterpret_cast<const T *>(p.delta) + b * p.delta_batch_stride + d * p.delta_d_stride;
     T *out_row = reinterpret_cast<T *>(p.out) + b * p.out_batch_stride + d * p.out_d_stride;
     const T *gB = reinterpret_cast<const T *>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
@@ -127,13 +80,11 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;  // first time step of this lane
         const int valid = max(0, min(I, L - tl));
-        const bool vec = valid == I && vec_ok<T, I>(u_row + tl) && vec_ok<T, I>(dt_row + tl) &&
-                         vec_ok<T, I>(out_row + tl);
         float dl[I], w[I], y[I];
         {
             float uu[I];
-            load_items<I>(u_row + tl, valid, vec, uu);
-            load_items<I>(dt_row + tl, valid, vec, dl);
+            load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+            load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
 #pragma unroll
             for (int i = 0; i < I; ++i) {
                 float x = dl[i] + bias;
@@ -156,9 +107,9 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         for (int n0 = 0; n0 < N; n0 += kNB) {
             const int nb = min(kNB, N - n0);
             __syncthreads();  // everyone is done with the previous tile (and the carry init)
-            stage_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
-                                       gC + (int64_t)n0 * p.C_dstate_stride, p.B_dstate_stride,
-                                       p.C_dstate_stride, nb, t0, L, tid);
+            stage_bc_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
+                                          gC + (int64_t)n0 * p.C_dstate_stride, p.B_dstate_stride,
+                                          p.C_dstate_stride, nb, t0, L, rev, tid);
             __syncthreads();
             for (int nn = 0; nn < nb; ++nn) {
                 const int n = n0 + nn;
@@ -204,7 +155,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
                 }
             }
         }
-        if (row_valid) store_items<I>(out_row + tl, valid, vec, y);
+        if (row_valid) store_items_dir<I>(out_row, tl, valid, L, rev, y);
     }
 }
 

@@ -40,7 +40,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _common_checks(u, delta, A, B, C, D, delta_bias):
+def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0):
     # selective_scan.cpp:165-215
     _check(u.dtype in _DT, "u must be float32, float16 or bfloat16")
     _check(A.dtype == torch.float32, "A must be float32")
@@ -50,6 +50,9 @@ def _common_checks(u, delta, A, B, C, D, delta_bias):
         _check(t.is_cuda, f"{name} must be a CUDA/HIP tensor")
     _check(u.dim() == 3, "u must be (batch, dim, seqlen)")
     batch, dim, seqlen = u.shape
+    if u_row_mod:  # omni form: directions k and k + K/2 share the rows of u
+        _check(dim == u_row_mod and A.dim() == 2 and A.shape[0] % u_row_mod == 0, "u must be (batch, u_row_mod, seqlen)")
+        dim = A.shape[0]
     _check(A.dim() == 2 and A.shape[0] == dim, "A must be (dim, dstate)")
     dstate = A.shape[1]
     _check(B.dim() == 4 and C.dim() == 4, "B and C must be (batch, n_groups, dstate, seqlen)")
@@ -73,10 +76,12 @@ def _common_checks(u, delta, A, B, C, D, delta_bias):
     return batch, dim, seqlen, dstate, n_groups
 
 
-def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus):
+def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start=None, u_row_mod=0):
     batch, dim, seqlen, dstate, n_groups = dims
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, seqlen, dstate, n_groups
     P.delta_softplus = 1 if delta_softplus else 0
+    P.rev_group_start = n_groups if rev_group_start is None else int(rev_group_start)
+    P.u_row_mod = int(u_row_mod)
     P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
     P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
     if out is not None:
@@ -91,9 +96,10 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus)
 
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], delta_softplus: bool,
-                       nrows: int = 1) -> List[torch.Tensor]:
-    """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``."""
-    dims = _common_checks(u, delta, A, B, C, D, delta_bias)
+                       nrows: int = 1, rev_group_start: Optional[int] = None, u_row_mod: int = 0) -> List[torch.Tensor]:
+    """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``.
+    ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling, see include/vmambair_oss.h."""
+    dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod)
     batch, dim, seqlen, dstate, _ = dims
     lib = _capi.load()
     n_chunks = int(lib.oss_scan_num_chunks(seqlen))
@@ -104,7 +110,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     if batch == 0 or seqlen == 0:  # nothing to launch (empty tensors have no device pointer)
         return [out, x]
     P = _capi.ScanFwdParams()
-    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus)
+    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod)
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_fwd(P, _DT[u.dtype], stream), "oss_scan_fwd")
@@ -113,10 +119,12 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
 
 def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], dout: torch.Tensor,
-                       x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1) -> List[Optional[torch.Tensor]]:
+                       x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1,
+                       rev_group_start: Optional[int] = None, u_row_mod: int = 0) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
-    ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent)."""
-    dims = _common_checks(u, delta, A, B, C, D, delta_bias)
+    ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
+    form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``."""
+    dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod)
     batch, dim, seqlen, dstate, n_groups = dims
     _check(dout.dtype == u.dtype and dout.is_cuda, "dout must be a CUDA/HIP tensor of u's dtype")
     _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have u's shape")
@@ -143,7 +151,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     ws_bytes = int(lib.oss_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, n_groups))
     ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.float32, device=u.device)
     P = _capi.ScanBwdParams()
-    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus)
+    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod)
     P.dout_batch_stride, P.dout_d_stride = dout.stride(0), dout.stride(1)
     P.du_batch_stride, P.du_d_stride = du.stride(0), du.stride(1)
     P.ddelta_batch_stride, P.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
@@ -179,6 +187,25 @@ def _bwd_op(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows):
 
 _LIB.impl("selective_scan_fwd", _fwd_op, "CUDA")
 _LIB.impl("selective_scan_bwd", _bwd_op, "CUDA")
+
+# omni form: time-mirrored groups and shared u rows handled inside the kernels (no xs / flips)
+_LIB.define("omni_scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
+            "bool delta_softplus, int rev_group_start, int u_row_mod) -> Tensor[]")
+_LIB.define("omni_scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
+            "Tensor dout, Tensor? x, bool delta_softplus, int rev_group_start, int u_row_mod) -> Tensor[]")
+
+
+def _omni_fwd_op(u, delta, A, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
+    return selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, 1, rev_group_start, u_row_mod)
+
+
+def _omni_bwd_op(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod):
+    res = selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, 1, rev_group_start, u_row_mod)
+    return [t if t is not None else u.new_empty(0, dtype=torch.float32) for t in res]
+
+
+_LIB.impl("omni_scan_fwd", _omni_fwd_op, "CUDA")
+_LIB.impl("omni_scan_bwd", _omni_bwd_op, "CUDA")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -222,13 +249,14 @@ def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_b
     dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
     dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if has_bias else None
+    part = torch.empty((B, Cc, 10), dtype=torch.float32, device=x.device)
     lib = _capi.load()
     with torch.cuda.device(x.device):
         st = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_dwconv3x3_fwd(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), B, Cc, H, W,
                                           dy.stride(0), dy.stride(1), dx.stride(0), dx.stride(1), 1, st),
                     "oss_dwconv3x3_fwd(flip)")
-        _capi.check(lib.oss_dwconv3x3_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), B, Cc, H, W,
+        _capi.check(lib.oss_dwconv3x3_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B, Cc, H, W,
                                             x.stride(0), x.stride(1), dy.stride(0), dy.stride(1), st), "oss_dwconv3x3_wgrad")
     return [dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 

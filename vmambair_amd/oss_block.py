@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .ops import dwconv3x3
-from .selective_scan import SelectiveScanFP32, selective_scan_fn
+from .selective_scan import CrossScan2, OmniScanFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
 VARIANTS = {
@@ -108,6 +108,7 @@ class SS2D_1(nn.Module):
         self.d_model, self.d_inner, self.d_state = d_model, d_inner, d_state
         self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
         self.K, self.KC = 4, 2
+        self.omni = True  # False: literal reference data flow (forward_core_xs)
         R, N = self.dt_rank, d_state
 
         self.in_conv = nn.Conv2d(d_model, d_expand * 2, kernel_size=1)
@@ -155,6 +156,30 @@ class SS2D_1(nn.Module):
 
     # -- four spatial directions (MambaSISR6_arch.py:395-436; index maps: SURVEY.md Appendix B) --
     def forward_core(self, x: torch.Tensor) -> torch.Tensor:
+        """Omni form: two flattenings of x instead of the four of ``cross_scan_2d``; the projections of
+        directions 2/3 are computed on the un-flipped rows (a column of a matmul does not depend on
+        its position) and the scan kernels walk those directions backwards.  Same values as
+        ``forward_core_xs`` (the literal reference data flow, kept for the bit-exact index-map test)."""
+        if not self.omni:
+            return self.forward_core_xs(x)
+        B, Cc, H, W = x.shape
+        L = H * W
+        R, N = self.dt_rank, self.d_state
+        x2 = CrossScan2.apply(x)                                                       # (B, 2, D, L)
+        z01 = torch.einsum("bjdl,jcd->bjcl", x2, self.x_proj_weight[0:2])
+        z23 = torch.einsum("bjdl,jcd->bjcl", x2, self.x_proj_weight[2:4])
+        x_dbl = torch.cat([z01, z23], dim=1)                                           # (B, 4, R+2N, L)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        out = OmniScanFn.apply(x2.view(B, -1, L), dts.contiguous().view(B, -1, L), -torch.exp(self.A_logs.float()),
+                               Bs, Cs, self.Ds, self.dt_projs_bias.view(-1)).view(B, 4, -1, L)
+        # merge in the reference's association order ((y0 + flip y2) + T y1) + T flip y3, fp32
+        y = out[:, 0].float() + out[:, 2].float()
+        y = y + out[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
+        y = y + out[:, 3].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
+        return self.out_norm(y.view(B, Cc, H, W)).to(x.dtype)
+
+    def forward_core_xs(self, x: torch.Tensor) -> torch.Tensor:
         B, Cc, H, W = x.shape
         L = H * W
         R, N = self.dt_rank, self.d_state

@@ -81,3 +81,52 @@ class SelectiveScanFP32(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dout, *args):
         return SelectiveScanFn.backward(ctx, dout, *args)
+
+
+class OmniScanFn(torch.autograd.Function):
+    """The four spatial directions of the OSS module in ONE scan call without materialising the four
+    flattenings (reference: ``cross_scan_2d`` + ``selective_scan`` + un-flip, MambaSISR6_arch.py:399-428).
+
+    ``x2``    (B, 2*D, L): rows ``[row-major flattening | column-major flattening]`` of the activations;
+    ``delta`` (B, 4*D, L), ``B``/``C`` (B, 4, N, L): per direction k, stored in the memory order of
+              direction ``k % 2`` (i.e. NOT flipped for k = 2, 3).
+    Directions 2 and 3 are scanned from the last position to the first inside the kernels
+    (``rev_group_start = 2``) and read the rows of directions 0 and 1 (``u_row_mod = 2*D``); the output
+    (B, 4*D, L) is likewise stored un-flipped, so ``out[:, 2]`` already is ``flip(out_y[:, 2])`` of
+    the reference."""
+
+    @staticmethod
+    def forward(ctx, x2, delta, A, B, C, D, delta_bias):
+        x2, delta, B, C = _last_contig(x2), _last_contig(delta), _last_contig(B), _last_contig(C)
+        rows = x2.shape[1]
+        out, x = torch.ops.vmambair.omni_scan_fwd(x2, delta, A, B, C, D.float(), delta_bias.float(), True, 2, rows)
+        ctx.rows = rows
+        ctx.save_for_backward(x2, delta, A, B, C, D, delta_bias, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
+        du, ddelta, dA, dB, dC, dD, dbias = torch.ops.vmambair.omni_scan_bwd(
+            x2, delta, A, B, C, D.float(), delta_bias.float(), _last_contig(dout), x, True, 2, ctx.rows)
+        dx2 = du[:, :ctx.rows] + du[:, ctx.rows:]  # directions k and k+2 share the rows of x2
+        return dx2, ddelta, dA, dB, dC, dD.to(D.dtype), dbias.to(delta_bias.dtype)
+
+
+class CrossScan2(torch.autograd.Function):
+    """x (B, D, H, W) -> (B, 2, D, H*W): row-major and column-major flattenings (the only two copies
+    of the activations the omni scan needs).  Index maps: SURVEY.md Appendix B, k = 0, 1."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, D, H, W = x.shape
+        ctx.shape = (B, D, H, W)
+        x2 = x.new_empty((B, 2, D, H * W))
+        x2[:, 0].copy_(x.reshape(B, D, H * W))
+        x2[:, 1].view(B, D, W, H).copy_(x.transpose(2, 3))
+        return x2
+
+    @staticmethod
+    def backward(ctx, g):
+        B, D, H, W = ctx.shape
+        return g[:, 0].reshape(B, D, H, W) + g[:, 1].reshape(B, D, W, H).transpose(2, 3)
