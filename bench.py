@@ -87,27 +87,13 @@ def cpu_baseline(seed=0):
     (oracle/, the restatement of the reference's sequential selective_scan).  kind = "port"."""
     from oracle import oss_oracle
     from vmambair_amd.archs import build_network
-    import vmambair_amd.ops as ops
+    import vmambair_amd.ops  # noqa: F401
 
     cores = usable_cores()
     torch.set_num_threads(cores)
     oss_oracle.set_threads(cores)
-    chunk = ops.scan_chunk()
-    lib = torch.library.Library("vmambair", "IMPL")
-    lib.impl("selective_scan_fwd",
-             lambda u, d, A, B, Cc, D, b, sp, nr: oss_oracle.scan_fwd(u, d, A, B, Cc, D, b, sp, nr, chunk=chunk), "CPU")
-    lib.impl("selective_scan_bwd",
-             lambda u, d, A, B, Cc, D, b, g, x, sp, nr: [t if t is not None else torch.empty(0) for t in
-                                                        oss_oracle.scan_bwd(u, d, A, B, Cc, D, b, g, x, sp, nr)], "CPU")
-    # the depth-wise convs of the block have HIP kernels only: on the host they are plain torch convs
-    lib.impl("dwconv3x3_fwd", lambda x, w, b: F.conv2d(x, w, b, padding=1, groups=x.shape[1]), "CPU")
-
-    def dw_bwd(x, w, dy, has_bias):
-        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1, groups=x.shape[1])
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1, groups=x.shape[1])
-        return [dx, dw, dy.sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)]
-
-    lib.impl("dwconv3x3_bwd", dw_bwd, "CPU")
+    from oracle import cpu_twins
+    cpu_twins.install()  # CPU dispatch of torch.ops.vmambair = oracle / plain torch references
     torch.manual_seed(seed)
     net = build_network(NET)
     for m in net.modules():  # the host baseline runs the reference's literal data flow (four flattenings)
@@ -133,7 +119,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("VMAMBAIR_BENCH_GRAPH", "0")),
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("VMAMBAIR_BENCH_GRAPH", "1")),
                     help="1: replay the training step as one hipGraph (single GPU, or manual flat-gradient "
                          "all-reduce outside the graph for N > 1)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)

@@ -94,6 +94,9 @@ typedef struct {
     float *ddelta_bias;     /* (dim) or NULL, overwritten                                      */
     void *workspace;        /* oss_scan_bwd_workspace_bytes() bytes of scratch, no init needed */
     size_t workspace_bytes;
+    int dout_row_mod;       /* > 0: row d reads dout[:, d % dout_row_mod, :] (the merge hands the same
+                               gradient to directions k and k + 2); 0 = off                        */
+    int reserved_;
 } oss_scan_bwd_params;
 
 /* Time steps between two saved states in `x` (the reference's is 2048,
@@ -127,6 +130,30 @@ int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const fl
 int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,
                         int batch, int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
                         int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
+
+/* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
+ * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3
+ * column-major) -> y (batch, D, H, W) float = ((o0 + o2) + T o1) + T o3, the reference's association
+ * order.  batch * D must be < 65536. */
+int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream);
+
+/* Per-pixel LayerNorm over the channel axis, NCHW in / NCHW out (LayerNorm of the OSS block,
+ * SRGAN/VmambaIR/archs/MambaSISR6_arch.py:144-195: biased variance, eps inside the sqrt; bias == NULL
+ * selects the BiasFree form x / sqrt(var + eps) * w).  x: (batch, C, pixels) of type x_type with element
+ * strides (batch, channel), pixels contiguous; y (and dgate) contiguous (batch, C, pixels) of y_type;
+ * gate of y_type with its own (batch, channel) strides; weight / bias / dweight / dbias float (C).
+ * gate != NULL fuses y = LN(x) * silu(gate)
+ * (SS2D_1: y1 * act(z), :488-493).  mean / rstd: (batch, pixels) float, written by fwd, read by bwd.
+ * bwd: partials = ceil(pixels / 256) * batch * 2 * C floats of scratch. */
+int oss_ln_nchw_fwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
+                    const void *gate, void *y, float *mean, float *rstd, int batch, int channels, int pixels,
+                    int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
+                    int64_t gate_channel_stride, float eps, oss_stream_t stream);
+int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
+                    const void *gate, const void *dy, const float *mean, const float *rstd, void *dx, void *dgate,
+                    float *dweight, float *dbias, float *partials, int batch, int channels, int pixels,
+                    int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
+                    int64_t gate_channel_stride, oss_stream_t stream);
 
 /* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every
  * main forward / backward kernel launch is bracketed by HIP events recorded on the launch stream.

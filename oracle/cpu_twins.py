@@ -1,0 +1,126 @@
+"""CPU twins of every ``torch.ops.vmambair`` op (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+The product registers GPU kernels only.  ``install()`` registers, for the CPU dispatch key, the
+oracle (selective scan: oracle/oss_scan_oracle.c; omni form: the same oracle on materialised
+direction tensors) and plain PyTorch fp32 references (depth-wise conv, NCHW LayerNorm) so that the
+host-side mirrors of the reference modules can be exercised without a GPU.  Importers: tests/ and
+bench.py's cpu_baseline leg only.
+"""
+import torch
+import torch.nn.functional as F
+
+_CPU_LIB = None
+
+
+def install():
+    global _CPU_LIB
+    if _CPU_LIB is not None:
+        return
+    import vmambair_amd.ops  # noqa: F401  defines the ops
+    from oracle import oss_oracle
+
+    chunk = vmambair_amd.ops.scan_chunk()
+
+    def fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows):
+        return oss_oracle.scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows, chunk=chunk)
+
+    def bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows):
+        res = oss_oracle.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows)
+        return [t if t is not None else torch.empty(0) for t in res]
+
+    import torch.nn.functional as F
+
+    def dw_fwd(x, weight, bias):  # plain PyTorch fp32 reference of the depth-wise conv
+        return F.conv2d(x.float(), weight.float(), None if bias is None else bias.float(), padding=1,
+                        groups=x.shape[1]).to(x.dtype)
+
+    def dw_bwd(x, weight, dy, has_bias):
+        xx = x.detach().float().requires_grad_()
+        ww = weight.detach().float().requires_grad_()
+        with torch.enable_grad():
+            y = F.conv2d(xx, ww, None, padding=1, groups=x.shape[1])
+        dx, dw = torch.autograd.grad(y, (xx, ww), dy.float())
+        db = dy.float().sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)
+        return [dx.to(x.dtype), dw, db]
+
+    def _mirror(t, G_or_rows, start, per):  # flip time of groups >= start (per rows each)
+        t = t.clone()
+        t[:, start * per:] = t[:, start * per:].flip(-1)
+        return t
+
+    def omni_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
+        """oracle twin of the omni form: materialise what the kernels read implicitly"""
+        dim, G = A.shape[0], B.shape[1]
+        per = dim // G
+        uu = u.repeat(1, dim // u_row_mod, 1) if u_row_mod else u
+        uu, dd = _mirror(uu, G, rev_group_start, per), _mirror(delta, G, rev_group_start, per)
+        Bm, Cm = _mirror(B, G, rev_group_start, 1), _mirror(C, G, rev_group_start, 1)
+        out, x = oss_oracle.scan_fwd(uu, dd, A, Bm, Cm, D, delta_bias, delta_softplus, 1, chunk=chunk)
+        return [_mirror(out, G, rev_group_start, per), x]
+
+    def merge4(out, H, W):
+        Bsz, _, Dn, L = out.shape
+        o = out.float()
+        y = o[:, 0] + o[:, 2]
+        y = y + o[:, 1].reshape(Bsz, Dn, W, H).transpose(2, 3).reshape(Bsz, Dn, L)
+        y = y + o[:, 3].reshape(Bsz, Dn, W, H).transpose(2, 3).reshape(Bsz, Dn, L)
+        return y.view(Bsz, Dn, H, W)
+
+    def omni_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod, dout_row_mod):
+        dim, G = A.shape[0], B.shape[1]
+        per = dim // G
+        if dout_row_mod:
+            dout = dout.repeat(1, dim // dout_row_mod, 1)
+        uu = u.repeat(1, dim // u_row_mod, 1) if u_row_mod else u
+        uu, dd = _mirror(uu, G, rev_group_start, per), _mirror(delta, G, rev_group_start, per)
+        Bm, Cm = _mirror(B, G, rev_group_start, 1), _mirror(C, G, rev_group_start, 1)
+        gg = _mirror(dout, G, rev_group_start, per)
+        du, ddl, dA, dB, dC, dD, db = oss_oracle.scan_bwd(uu, dd, A, Bm, Cm, D, delta_bias, gg, None, delta_softplus)
+        res = [_mirror(du, G, rev_group_start, per), _mirror(ddl, G, rev_group_start, per), dA,
+               _mirror(dB, G, rev_group_start, 1), _mirror(dC, G, rev_group_start, 1), dD, db]
+        return [t if t is not None else torch.empty(0) for t in res]
+
+    def _ln_ref(x, weight, bias, gate):
+        """plain PyTorch fp32 reference of the NCHW LayerNorm (+ silu gate), differentiable"""
+        xf = x.float()
+        mu = xf.mean(1, keepdim=True)
+        var = xf.var(1, keepdim=True, unbiased=False)
+        rstd = (var + 1e-5).rsqrt()
+        w = weight.float().view(1, -1, 1, 1)
+        y = (xf - mu) * rstd * w + bias.float().view(1, -1, 1, 1) if bias is not None else xf * rstd * w
+        if gate is not None:
+            y = y * F.silu(gate.float())
+        return y, mu, rstd
+
+    codes = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}
+
+    def ln_fwd(x, weight, bias, gate, out_code):
+        y, mu, rstd = _ln_ref(x, weight, bias, gate)
+        B, C, H, W = x.shape
+        return [y.to(codes[out_code]), mu.reshape(B, H * W), rstd.reshape(B, H * W)]
+
+    def ln_bwd(x, weight, bias, gate, dy, mean, rstd):
+        leaves = [x.detach().float().requires_grad_(), weight.detach().float().requires_grad_()]
+        bb = bias.detach().float().requires_grad_() if bias is not None else None
+        gg = gate.detach().float().requires_grad_() if gate is not None else None
+        with torch.enable_grad():
+            y, _, _ = _ln_ref(leaves[0], leaves[1], bb, gg)
+        ins = leaves + ([bb] if bb is not None else []) + ([gg] if gg is not None else [])
+        gr = list(torch.autograd.grad(y, ins, dy.float()))
+        dx, dw = gr.pop(0), gr.pop(0)
+        db = gr.pop(0) if bb is not None else torch.empty(0)
+        dg = gr.pop(0).to(dy.dtype) if gg is not None else torch.empty(0)
+        return [dx.to(x.dtype), dg, dw, db]
+
+    _CPU_LIB = torch.library.Library("vmambair", "IMPL")
+    _CPU_LIB.impl("ln_nchw_fwd", ln_fwd, "CPU")
+    _CPU_LIB.impl("ln_nchw_bwd", ln_bwd, "CPU")
+    _CPU_LIB.impl("omni_scan_fwd", omni_fwd, "CPU")
+    _CPU_LIB.impl("omni_scan_bwd", omni_bwd, "CPU")
+    _CPU_LIB.impl("merge4", merge4, "CPU")
+    _CPU_LIB.impl("selective_scan_fwd", fwd, "CPU")
+    _CPU_LIB.impl("selective_scan_bwd", bwd, "CPU")
+    _CPU_LIB.impl("dwconv3x3_fwd", dw_fwd, "CPU")
+    _CPU_LIB.impl("dwconv3x3_bwd", dw_bwd, "CPU")
+
+

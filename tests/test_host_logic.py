@@ -162,6 +162,7 @@ def test_omni_direction_maps_bit_exact(monkeypatch):
             return oy.view(Bsz, -1, L)
 
     monkeypatch.setattr(oss_block, "OmniScanFn", FakeOmni)
+    m.fused_merge = False  # look at the scan's inputs and the merge separately
     y = m.forward_core(z["x"])
     assert torch.equal(seen["xs"], z["xs"])
     assert torch.equal(y, z["y"])

@@ -149,6 +149,7 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     const oss_scan_fwd_params &f = p->f;
     if (f.batch == 0 || f.seqlen == 0) return OSS_OK;
     if (!f.x && oss_scan_num_chunks(f.seqlen) > 1) return OSS_ERR_NULL;  // selective_scan.cpp:310
+    if (p->dout_row_mod < 0 || (p->dout_row_mod > 0 && f.dim % p->dout_row_mod != 0)) return OSS_ERR_SHAPE;
     const int v = bwd_variant_for(f.batch, f.dim, f.seqlen, f.dstate, f.n_groups);
     g_last_bwd.store(v);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -177,6 +178,32 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_wgrad(io, x, dy, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, gsb, gsc,
                            reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
+    if (!out || !y) return OSS_ERR_NULL;
+    if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;
+    return merge4(io, out, y, batch, D, height, width, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate,
+                    void *y, float *mean, float *rstd, int batch, int channels, int pixels, int64_t xsb, int64_t xsc,
+                    int64_t gsb, int64_t gsc, float eps, oss_stream_t stream) {
+    if (!x || !weight || !y || !mean || !rstd) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return ln_nchw_fwd(xt, yt, x, weight, bias, gate, y, mean, rstd, batch, channels, pixels, xsb, xsc, gsb, gsc, eps,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate,
+                    const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dweight,
+                    float *dbias, float *partials, int batch, int channels, int pixels, int64_t xsb, int64_t xsc,
+                    int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    if (!x || !weight || !dy || !mean || !rstd || !dx || !dweight || !partials) return OSS_ERR_NULL;
+    if (gate && !dgate) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
+    return ln_nchw_bwd(xt, yt, x, weight, bias, gate, dy, mean, rstd, dx, dgate, dweight, dbias, partials, batch, channels,
+                       pixels, xsb, xsc, gsb, gsc, reinterpret_cast<hipStream_t>(stream));
 }
 
 void oss_prof_enable(int on) { g_prof_on.store(on ? 1 : 0); }

@@ -24,5 +24,12 @@ int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, vo
               int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s);
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
                     int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
+int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate, void *y,
+                float *mean, float *rstd, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
+                hipStream_t s);
+int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
+                const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
+                float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
+int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

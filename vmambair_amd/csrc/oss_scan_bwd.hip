@@ -78,7 +78,8 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 
     const T *u_row = reinterpret_cast<const T *>(f.u) + b * f.u_batch_stride + d_u * f.u_d_stride;
     const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride + d * f.delta_d_stride;
-    const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d * p.dout_d_stride;
+    const int d_g = p.dout_row_mod > 0 ? d % p.dout_row_mod : d;
+    const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d_g * p.dout_d_stride;
     T *du_row = reinterpret_cast<T *>(p.du) + b * p.du_batch_stride + d * p.du_d_stride;
     T *dd_row = reinterpret_cast<T *>(p.ddelta) + b * p.ddelta_batch_stride + d * p.ddelta_d_stride;
     const T *gB = reinterpret_cast<const T *>(f.B) + b * f.B_batch_stride + g * f.B_group_stride;

@@ -120,14 +120,15 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
 def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], dout: torch.Tensor,
                        x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1,
-                       rev_group_start: Optional[int] = None, u_row_mod: int = 0) -> List[Optional[torch.Tensor]]:
+                       rev_group_start: Optional[int] = None, u_row_mod: int = 0,
+                       dout_row_mod: int = 0) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``."""
     dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod)
     batch, dim, seqlen, dstate, n_groups = dims
     _check(dout.dtype == u.dtype and dout.is_cuda, "dout must be a CUDA/HIP tensor of u's dtype")
-    _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have u's shape")
+    _check(tuple(dout.shape) == (batch, dout_row_mod or dim, seqlen), "dout must have u's shape")
     _check(dout.stride(-1) == 1 or dout.size(-1) == 1, "dout must be contiguous in its last dimension")
     lib = _capi.load()
     n_chunks = int(lib.oss_scan_num_chunks(seqlen))
@@ -158,6 +159,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     P.dout, P.du, P.ddelta, P.dA = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), dA.data_ptr()
     P.dB, P.dC, P.dD, P.ddelta_bias = dB.data_ptr(), dC.data_ptr(), _ptr(dD), _ptr(dbias)
     P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    P.dout_row_mod = int(dout_row_mod)
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
@@ -192,20 +194,39 @@ _LIB.impl("selective_scan_bwd", _bwd_op, "CUDA")
 _LIB.define("omni_scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
             "bool delta_softplus, int rev_group_start, int u_row_mod) -> Tensor[]")
 _LIB.define("omni_scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
-            "Tensor dout, Tensor? x, bool delta_softplus, int rev_group_start, int u_row_mod) -> Tensor[]")
+            "Tensor dout, Tensor? x, bool delta_softplus, int rev_group_start, int u_row_mod, int dout_row_mod) -> Tensor[]")
+_LIB.define("merge4(Tensor out, int H, int W) -> Tensor")
 
 
 def _omni_fwd_op(u, delta, A, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
     return selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, 1, rev_group_start, u_row_mod)
 
 
-def _omni_bwd_op(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod):
-    res = selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, 1, rev_group_start, u_row_mod)
+def _omni_bwd_op(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod, dout_row_mod):
+    res = selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, 1, rev_group_start, u_row_mod,
+                             dout_row_mod)
     return [t if t is not None else u.new_empty(0, dtype=torch.float32) for t in res]
+
+
+def merge4(out: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """(B, 4, D, H*W) un-flipped omni-scan outputs -> (B, D, H, W) fp32, reference association order."""
+    _check(out.is_cuda and out.dim() == 4 and out.shape[1] == 4 and out.shape[3] == H * W and out.dtype in _DT,
+           "merge4: out must be a (B, 4, D, H*W) GPU tensor")
+    out = out.contiguous()
+    B, _, D, L = out.shape
+    y = torch.empty((B, D, H, W), dtype=torch.float32, device=out.device)
+    if out.numel() == 0:
+        return y
+    lib = _capi.load()
+    with torch.cuda.device(out.device):
+        _capi.check(lib.oss_merge4(_DT[out.dtype], out.data_ptr(), y.data_ptr(), B, D, H, W,
+                                   torch.cuda.current_stream().cuda_stream), "oss_merge4")
+    return y
 
 
 _LIB.impl("omni_scan_fwd", _omni_fwd_op, "CUDA")
 _LIB.impl("omni_scan_bwd", _omni_bwd_op, "CUDA")
+_LIB.impl("merge4", merge4, "CUDA")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -286,3 +307,105 @@ class DWConv3x3Fn(torch.autograd.Function):
 def dwconv3x3(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
     """Run a ``nn.Conv2d(C, C, 3, padding=1, groups=C)`` module's parameters through the HIP kernels."""
     return DWConv3x3Fn.apply(x, conv.weight, conv.bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# per-pixel LayerNorm over channels, NCHW in / NCHW out, optional fused  * silu(gate)
+# ---------------------------------------------------------------------------------------------
+_CODE_DT = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}
+_LN_PAIRS = {(torch.float32, torch.float32), (torch.float32, torch.float16), (torch.float32, torch.bfloat16),
+             (torch.float16, torch.float32), (torch.float16, torch.float16), (torch.bfloat16, torch.float32),
+             (torch.bfloat16, torch.bfloat16)}
+
+
+def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
+                out_code: int) -> List[torch.Tensor]:
+    """-> [y (B, C, H, W) of dtype ``out_code``, mean (B, H*W), rstd (B, H*W)]; eps = 1e-5."""
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "ln_nchw: x must be a (B, C, H, W) GPU tensor")
+    out_dtype = _CODE_DT[int(out_code)]
+    _check((x.dtype, out_dtype) in _LN_PAIRS, f"ln_nchw: unsupported dtype pair {x.dtype} -> {out_dtype}")
+    B, Cc, H, W = x.shape
+    P = H * W
+    x = _planes(x)
+    w = weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    if gate is not None:
+        gate = _planes(gate)
+        if gate.dtype != out_dtype:
+            gate = gate.to(out_dtype)
+    y = torch.empty((B, Cc, H, W), dtype=out_dtype, device=x.device)
+    mean = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        return [y, mean, rstd]
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_ln_nchw_fwd(_DT[x.dtype], _DT[out_dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
+                                        y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, Cc, P, x.stride(0), x.stride(1),
+                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1),
+                                        1e-5, st), "oss_ln_nchw_fwd")
+    return [y, mean, rstd]
+
+
+def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
+                dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor) -> List[torch.Tensor]:
+    """-> [dx (x dtype), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty]"""
+    B, Cc, H, W = x.shape
+    P = H * W
+    x = _planes(x)
+    dy = dy.contiguous()
+    w = weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    if gate is not None:
+        gate = _planes(gate)
+        if gate.dtype != dy.dtype:
+            gate = gate.to(dy.dtype)
+    dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device) if gate is not None else None
+    dw = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if bias is not None else None
+    nblk = ((P + 255) // 256) * B
+    part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=x.device)
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_ln_nchw_bwd(_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
+                                        dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dgate),
+                                        dw.data_ptr(), _ptr(db), part.data_ptr(), B, Cc, P, x.stride(0), x.stride(1),
+                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1), st),
+                    "oss_ln_nchw_bwd")
+    e = x.new_empty(0, dtype=torch.float32)
+    return [dx, dgate if dgate is not None else e, dw, db if db is not None else e]
+
+
+_LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
+_LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd) -> Tensor[]")
+_LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
+_LIB.impl("ln_nchw_bwd", ln_nchw_bwd, "CUDA")
+_DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+class LayerNormNCHWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gate, out_dtype):
+        y, mean, rstd = torch.ops.vmambair.ln_nchw_fwd(x, weight, bias, gate, _DT_CODE[out_dtype])
+        ctx.has_bias, ctx.has_gate = bias is not None, gate is not None
+        ctx.save_for_backward(x, weight, bias, gate, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, gate, mean, rstd = ctx.saved_tensors
+        dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd)
+        return (dx, dw.to(weight.dtype), db.to(bias.dtype) if ctx.has_bias else None,
+                dgate.to(gate.dtype) if ctx.has_gate else None, None)
+
+
+def layer_norm_nchw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                    gate: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """LN over channels of an NCHW tensor (optionally times silu(gate)).  ``out_dtype`` defaults to the
+    autocast dtype when autocast is on (what the consumer conv would cast to anyway), else x.dtype."""
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype)

@@ -21,8 +21,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import dwconv3x3
-from .selective_scan import CrossScan2, OmniScanFn, SelectiveScanFP32, selective_scan_fn
+from .ops import dwconv3x3, layer_norm_nchw
+from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
 VARIANTS = {
@@ -52,14 +52,9 @@ class LayerNorm(nn.Module):
         self.with_bias = LayerNorm_type != "BiasFree"
         self.body = _LNBody(dim, self.with_bias)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        xt = x.permute(0, 2, 3, 1)
-        if self.with_bias:
-            y = F.layer_norm(xt, (xt.shape[-1],), self.body.weight, self.body.bias, 1e-5)
-        else:
-            var = xt.var(-1, keepdim=True, unbiased=False)
-            y = xt / torch.sqrt(var + 1e-5) * self.body.weight
-        return y.permute(0, 3, 1, 2)
+    def forward(self, x: torch.Tensor, gate: torch.Tensor = None, out_dtype: torch.dtype = None) -> torch.Tensor:
+        """NCHW in, NCHW out, no permutes (HIP kernel).  ``gate``: fused ``* silu(gate)`` epilogue."""
+        return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype)
 
 
 class FeedForward(nn.Module):
@@ -109,6 +104,7 @@ class SS2D_1(nn.Module):
         self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
         self.K, self.KC = 4, 2
         self.omni = True  # False: literal reference data flow (forward_core_xs)
+        self.fused_merge = True  # scan + cross-merge as one autograd node (HIP merge kernel)
         R, N = self.dt_rank, d_state
 
         self.in_conv = nn.Conv2d(d_model, d_expand * 2, kernel_size=1)
@@ -155,13 +151,13 @@ class SS2D_1(nn.Module):
             self.Dsc._no_weight_decay = True
 
     # -- four spatial directions (MambaSISR6_arch.py:395-436; index maps: SURVEY.md Appendix B) --
-    def forward_core(self, x: torch.Tensor) -> torch.Tensor:
+    def forward_core(self, x: torch.Tensor, gate: torch.Tensor = None) -> torch.Tensor:
         """Omni form: two flattenings of x instead of the four of ``cross_scan_2d``; the projections of
         directions 2/3 are computed on the un-flipped rows (a column of a matmul does not depend on
         its position) and the scan kernels walk those directions backwards.  Same values as
         ``forward_core_xs`` (the literal reference data flow, kept for the bit-exact index-map test)."""
         if not self.omni:
-            return self.forward_core_xs(x)
+            return self.forward_core_xs(x, gate)
         B, Cc, H, W = x.shape
         L = H * W
         R, N = self.dt_rank, self.d_state
@@ -171,15 +167,26 @@ class SS2D_1(nn.Module):
         x_dbl = torch.cat([z01, z23], dim=1)                                           # (B, 4, R+2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
-        out = OmniScanFn.apply(x2.view(B, -1, L), dts.contiguous().view(B, -1, L), -torch.exp(self.A_logs.float()),
-                               Bs, Cs, self.Ds, self.dt_projs_bias.view(-1)).view(B, 4, -1, L)
-        # merge in the reference's association order ((y0 + flip y2) + T y1) + T flip y3, fp32
-        y = out[:, 0].float() + out[:, 2].float()
-        y = y + out[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
-        y = y + out[:, 3].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
-        return self.out_norm(y.view(B, Cc, H, W)).to(x.dtype)
+        args = (x2.view(B, -1, L), dts.contiguous().view(B, -1, L), -torch.exp(self.A_logs.float()), Bs, Cs, self.Ds,
+                self.dt_projs_bias.view(-1))
+        if self.fused_merge:
+            # scan + merge ((y0 + flip y2) + T y1) + T flip y3 in fp32 as one autograd node
+            y = OmniScanMergeFn.apply(*args, H, W)
+        else:
+            out = OmniScanFn.apply(*args).view(B, 4, -1, L)
+            y = out[:, 0].float() + out[:, 2].float()
+            y = y + out[:, 1].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
+            y = y + out[:, 3].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
+        return self._out_norm(y.view(B, Cc, H, W), x.dtype, gate)
 
-    def forward_core_xs(self, x: torch.Tensor) -> torch.Tensor:
+    def _out_norm(self, y, dtype, gate):
+        """out_norm(y).to(x.dtype) [* silu(gate)]  (MambaSISR6_arch.py:433-434,488-493)"""
+        if isinstance(self.out_norm, LayerNorm):
+            return self.out_norm(y, gate=gate, out_dtype=dtype)
+        y = self.out_norm(y).to(dtype)  # tests swap in an Identity to look at the merge alone
+        return y if gate is None else y * F.silu(gate)
+
+    def forward_core_xs(self, x: torch.Tensor, gate: torch.Tensor = None) -> torch.Tensor:
         B, Cc, H, W = x.shape
         L = H * W
         R, N = self.dt_rank, self.d_state
@@ -198,7 +205,7 @@ class SS2D_1(nn.Module):
         wh_y = out_y[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
         invwh_y = inv[:, 1].reshape(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
         y = out_y[:, 0].float() + inv[:, 0].float() + wh_y.float() + invwh_y.float()
-        return self.out_norm(y.view(B, Cc, H, W)).to(x.dtype)
+        return self._out_norm(y.view(B, Cc, H, W), x.dtype, gate)
 
     # -- two channel directions over the pooled descriptor (MambaSISR6_arch.py:438-483) --
     def cforward_core(self, xc: torch.Tensor) -> torch.Tensor:
@@ -231,14 +238,13 @@ class SS2D_1(nn.Module):
             y = y.transpose(1, 2).contiguous()                                          # (b, L = d, 1, 1)
         else:
             y = y.transpose(1, 2).unsqueeze(2).contiguous()                             # (b, d, 1, 1)
-        return self.channel_norm(y).to(xc.dtype)
+        return self.channel_norm(y, out_dtype=xc.dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         xz = self.in_conv(x)
         x, z = xz.chunk(2, dim=1)
-        z = F.silu(z)
         x = F.silu(dwconv3x3(x, self.conv2d))
-        y2 = self.forward_core(x) * z
+        y2 = self.forward_core(x, gate=z)  # out_norm(merge) * silu(z), fused in the LayerNorm kernel
         c = self.cforward_core(y2)
         y2 = (y2 + c) if self.gate == "add" else (y2 * c + y2)
         return self.out_conv(y2)

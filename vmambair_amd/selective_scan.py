@@ -108,7 +108,7 @@ class OmniScanFn(torch.autograd.Function):
     def backward(ctx, dout):
         x2, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
         du, ddelta, dA, dB, dC, dD, dbias = torch.ops.vmambair.omni_scan_bwd(
-            x2, delta, A, B, C, D.float(), delta_bias.float(), _last_contig(dout), x, True, 2, ctx.rows)
+            x2, delta, A, B, C, D.float(), delta_bias.float(), _last_contig(dout), x, True, 2, ctx.rows, 0)
         dx2 = du[:, :ctx.rows] + du[:, ctx.rows:]  # directions k and k+2 share the rows of x2
         return dx2, ddelta, dA, dB, dC, dD.to(D.dtype), dbias.to(delta_bias.dtype)
 
@@ -130,3 +130,34 @@ class CrossScan2(torch.autograd.Function):
     def backward(ctx, g):
         B, D, H, W = ctx.shape
         return g[:, 0].reshape(B, D, H, W) + g[:, 1].reshape(B, D, W, H).transpose(2, 3)
+
+
+class OmniScanMergeFn(torch.autograd.Function):
+    """``OmniScanFn`` followed by the cross-merge of the four directions (MambaSISR6_arch.py:427-430),
+    as one autograd node: forward = scan kernel + merge kernel -> y (B, D, H, W) fp32; the (B, 4D, L)
+    scan output is a temporary.  Backward: the merge hands the same gradient to directions k and
+    k + 2 (row-major for k = 0, column-major for k = 1), so only the two flattenings of ``dy`` are
+    built and the backward kernel reads them with ``dout_row_mod = 2*D``."""
+
+    @staticmethod
+    def forward(ctx, x2, delta, A, B, C, D, delta_bias, H, W):
+        x2, delta, B, C = _last_contig(x2), _last_contig(delta), _last_contig(B), _last_contig(C)
+        rows = x2.shape[1]
+        out, x = torch.ops.vmambair.omni_scan_fwd(x2, delta, A, B, C, D.float(), delta_bias.float(), True, 2, rows)
+        ctx.rows, ctx.hw = rows, (H, W)
+        ctx.save_for_backward(x2, delta, A, B, C, D, delta_bias, x)
+        Bsz, _, L = out.shape
+        return torch.ops.vmambair.merge4(out.view(Bsz, 4, rows // 2, L), H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
+        H, W = ctx.hw
+        Bsz, Dn = dy.shape[0], dy.shape[1]
+        g2 = dy.new_empty((Bsz, 2, Dn, H * W), dtype=x2.dtype)   # grads of ``out_y.float()``: back to the scan dtype
+        g2[:, 0].copy_(dy.reshape(Bsz, Dn, H * W))
+        g2[:, 1].view(Bsz, Dn, W, H).copy_(dy.transpose(2, 3))
+        du, ddelta, dA, dB, dC, dD, dbias = torch.ops.vmambair.omni_scan_bwd(
+            x2, delta, A, B, C, D.float(), delta_bias.float(), g2.view(Bsz, 2 * Dn, H * W), x, True, 2, ctx.rows, 2 * Dn)
+        dx2 = du[:, :ctx.rows] + du[:, ctx.rows:]
+        return dx2, ddelta, dA, dB, dC, dD.to(D.dtype), dbias.to(delta_bias.dtype), None, None
