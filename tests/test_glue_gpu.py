@@ -39,16 +39,16 @@ def test_layernorm_nchw(shape, xdt, ydt, with_bias, with_gate):
     gate = torch.randn(shape).to(ydt) if with_gate else None
     dy = torch.randn(shape).to(ydt)
     # reference in fp32 on the CPU
-    xr = x.float().requires_grad_()
+    xr = x.float().clone().requires_grad_()
     wr = w.clone().requires_grad_()
     br = b.clone().requires_grad_() if with_bias else None
-    gr = gate.float().requires_grad_() if with_gate else None
+    gr = gate.float().clone().requires_grad_() if with_gate else None
     yr = ln_ref(xr, wr, br, gr)
     yr.backward(dy.float())
-    xd = x.to(DEV).requires_grad_()
-    wd = w.to(DEV).requires_grad_()
-    bd = b.to(DEV).requires_grad_() if with_bias else None
-    gd = gate.to(DEV).requires_grad_() if with_gate else None
+    xd = x.detach().to(DEV).requires_grad_()
+    wd = w.detach().to(DEV).requires_grad_()
+    bd = b.detach().to(DEV).requires_grad_() if with_bias else None
+    gd = gate.detach().to(DEV).requires_grad_() if with_gate else None
     y = ops.layer_norm_nchw(xd, wd, bd, gd, ydt)
     assert y.dtype == ydt and y.shape == x.shape
     y.backward(dy.to(DEV))
