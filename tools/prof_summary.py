@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace rocpd database into text (runs on the GPU box: the .db itself
+is too large to ship back).  Usage: prof_summary.py <results.db> <out.txt> [window_ms]"""
+import sqlite3
+import sys
+
+
+def main():
+    db_path, out_path = sys.argv[1], sys.argv[2]
+    window_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 150.0
+    cur = sqlite3.connect(db_path).cursor()
+    lines = []
+    rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
+                            "from kernels group by name order by 3 desc"))
+    tot = sum(r[2] for r in rows)
+    lines.append(f"# whole run: {sum(r[1] for r in rows)} kernel launches, {tot:.1f} ms of kernel time, {len(rows)} distinct kernels")
+    lines.append("# total_ms  share  launches  avg_us  min_us  max_us  kernel")
+    for r in rows:
+        lines.append(f"{r[2]:10.2f} {100 * r[2] / tot:5.1f}% {r[1]:7d} {r[3]:9.1f} {r[4]:9.1f} {r[5]:9.1f}  {r[0]}")
+    t_end = cur.execute("select max(end) from kernels where name like '%oss_scan_bwd_kernel%'").fetchone()[0]
+    if t_end:
+        w0 = t_end - window_ms * 1e6
+        rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels "
+                                "where start>=? and end<=? group by name order by 3 desc", (w0, t_end + 2e6)))
+        tot = sum(r[2] for r in rows)
+        lines.append("")
+        lines.append(f"# last {window_ms:.0f} ms before the final scan-backward kernel (~ one training step): "
+                     f"{sum(r[1] for r in rows)} launches, {tot:.1f} ms kernel-busy")
+        for r in rows:
+            lines.append(f"{r[2]:10.2f} {100 * r[2] / tot:5.1f}% {r[1]:7d} {r[3]:9.1f}  {r[0]}")
+    open(out_path, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:3]))
+
+
+if __name__ == "__main__":
+    main()
