@@ -63,6 +63,9 @@ typedef struct {
      *   u_row_mod       : when > 0, row d reads u[:, d % u_row_mod, :] (du still has `dim` rows), so
      *                     that directions k and k+2 share one copy of the activations.  0 = off. */
     int rev_group_start, u_row_mod;
+    /* a_log_form != 0: the `A` pointer holds A_log and the kernels use A = -exp(A_log) (the archs'
+     * `As = -torch.exp(self.A_logs.float())`, MambaSISR6_arch.py:415); bwd then returns dA_log. */
+    int a_log_form, reserved0_;
     int64_t u_batch_stride, u_d_stride;
     int64_t delta_batch_stride, delta_d_stride;
     int64_t out_batch_stride, out_d_stride;

@@ -48,8 +48,9 @@ def install():
         t[:, start * per:] = t[:, start * per:].flip(-1)
         return t
 
-    def omni_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
+    def omni_fwd(u, delta, A_log, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
         """oracle twin of the omni form: materialise what the kernels read implicitly"""
+        A = -torch.exp(A_log.float())
         dim, G = A.shape[0], B.shape[1]
         per = dim // G
         uu = u.repeat(1, dim // u_row_mod, 1) if u_row_mod else u
@@ -66,7 +67,8 @@ def install():
         y = y + o[:, 3].reshape(Bsz, Dn, W, H).transpose(2, 3).reshape(Bsz, Dn, L)
         return y.view(Bsz, Dn, H, W)
 
-    def omni_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod, dout_row_mod):
+    def omni_bwd(u, delta, A_log, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod, dout_row_mod):
+        A = -torch.exp(A_log.float())
         dim, G = A.shape[0], B.shape[1]
         per = dim // G
         if dout_row_mod:
@@ -76,7 +78,7 @@ def install():
         Bm, Cm = _mirror(B, G, rev_group_start, 1), _mirror(C, G, rev_group_start, 1)
         gg = _mirror(dout, G, rev_group_start, per)
         du, ddl, dA, dB, dC, dD, db = oss_oracle.scan_bwd(uu, dd, A, Bm, Cm, D, delta_bias, gg, None, delta_softplus)
-        res = [_mirror(du, G, rev_group_start, per), _mirror(ddl, G, rev_group_start, per), dA,
+        res = [_mirror(du, G, rev_group_start, per), _mirror(ddl, G, rev_group_start, per), dA * A,
                _mirror(dB, G, rev_group_start, 1), _mirror(dC, G, rev_group_start, 1), dD, db]
         return [t if t is not None else torch.empty(0) for t in res]
 

@@ -166,3 +166,26 @@ def test_omni_direction_maps_bit_exact(monkeypatch):
     y = m.forward_core(z["x"])
     assert torch.equal(seen["xs"], z["xs"])
     assert torch.equal(y, z["y"])
+
+
+@pytest.mark.parametrize("variant", ["srgan", "mamber32", "mamber33", "realsr"])
+def test_whole_module_omni_equals_reference_data_flow(variant, oracle_cpu_kernel):
+    """SS2D_1 end to end (spatial + channel branches, gates): omni forms vs the literal reference flow"""
+    torch.manual_seed(1)
+    m = SS2D_1(d_model=32, ssm_ratio=1, variant=variant)
+    x = torch.randn(2, 32, 5, 7)
+    res = []
+    for omni in (True, False):
+        m.omni = omni
+        m.zero_grad()
+        xi = x.clone().requires_grad_()
+        y = m(xi)
+        y.square().sum().backward()
+        res.append((y.detach(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert_close(res[0][0], res[1][0], 1e-4, 1e-5, "y")
+    assert_close(res[0][1], res[1][1], 1e-3, 1e-4, "dx")
+    assert set(res[0][2]) == set(res[1][2])
+    for k in res[1][2]:
+        if k.endswith("conv_cout.bias"):
+            continue  # exact gradient 0 (constant before a LayerNorm)
+        assert_close(res[0][2][k], res[1][2][k], 2e-3, 2e-4 * max(1.0, float(res[1][2][k].abs().max())), k)

@@ -24,6 +24,7 @@ class ScanFwdParams(C.Structure):
     _fields_ = [
         ("batch", C.c_int), ("dim", C.c_int), ("seqlen", C.c_int), ("dstate", C.c_int), ("n_groups", C.c_int),
         ("delta_softplus", C.c_int), ("rev_group_start", C.c_int), ("u_row_mod", C.c_int),
+        ("a_log_form", C.c_int), ("reserved0_", C.c_int),
         ("u_batch_stride", C.c_int64), ("u_d_stride", C.c_int64),
         ("delta_batch_stride", C.c_int64), ("delta_d_stride", C.c_int64),
         ("out_batch_stride", C.c_int64), ("out_d_stride", C.c_int64),

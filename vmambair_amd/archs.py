@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .oss_block import MamberBlock
+from .oss_block import MamberBlock, conv1x1
 
 
 def _conv3(cin: int, cout: int, bias: bool) -> nn.Conv2d:
@@ -92,8 +92,8 @@ class _OSSUNet(nn.Module):
         e2 = self.encoder_level2(self.down1_2(e1))
         e3 = self.encoder_level3(self.down2_3(e2))
         lat = self.latent(self.down3_4(e3))
-        d3 = self.decoder_level3(self.reduce_chan_level3(torch.cat([self.up4_3(lat), e3], 1)))
-        d2 = self.decoder_level2(self.reduce_chan_level2(torch.cat([self.up3_2(d3), e2], 1)))
+        d3 = self.decoder_level3(conv1x1(torch.cat([self.up4_3(lat), e3], 1), self.reduce_chan_level3))
+        d2 = self.decoder_level2(conv1x1(torch.cat([self.up3_2(d3), e2], 1), self.reduce_chan_level2))
         d1 = self.decoder_level1(torch.cat([self.up2_1(d2), e1], 1))
         return self.refinement(d1)
 

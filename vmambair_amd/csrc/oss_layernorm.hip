@@ -114,12 +114,20 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 
 __global__ void __launch_bounds__(256)
 oss_ln_nchw_bwd_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int nblk, int C) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+    // 64 outputs x 4 slices of the partial list per workgroup; slices combined in a fixed order
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 2 * C + i];
-    if (i < C) dw[i] = s;
-    else if (db) db[i - C] = s;
+    if (i < 2 * C)
+        for (int k = slice; k < nblk; k += 4) s += part[(size_t)k * 2 * C + i];
+    red[slice][col] = s;
+    __syncthreads();
+    if (slice == 0 && i < 2 * C) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (i < C) dw[i] = t;
+        else if (db) db[i - C] = t;
+    }
 }
 
 template <typename TX, typename TY>
@@ -158,7 +166,7 @@ static int ln_bwd_t(const void *x, const float *w, const float *bias, const void
         if (gate) hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, false, true>), grid, dim3(256), smem, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
         else      hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, false, false>), grid, dim3(256), smem, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
     }
-    hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 255) / 256), dim3(256), 0, s, part, dw, db, nblk, C);
+    hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 63) / 64), dim3(256), 0, s, part, dw, db, nblk, C);
     return (int)hipGetLastError();
 }
 

@@ -94,7 +94,8 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         const int n = idx / ROWS, r = idx - n * ROWS;
         const int rg = tile * ROWS + r;
         const int dd = g * rows_per_group + (rg < rows_per_group ? rg : 0);
-        sA2[idx] = f.A[dd * f.A_d_stride + n] * kLog2e;
+        const float av = f.A[dd * f.A_d_stride + n];
+        sA2[idx] = (f.a_log_form ? -__expf(av) : av) * kLog2e;
         sdhc[idx] = 0.f;
         sdA[idx] = 0.f;
     }
@@ -301,12 +302,13 @@ oss_scan_bwd_finish_bc(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /*
 // dA, dD, ddelta_bias: sum over batch in batch order
 __global__ void __launch_bounds__(256)
 oss_scan_bwd_finish_w(const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA, float *dD,
-                      float *db, int batch, int dim, int N) {
+                      float *db, int batch, int dim, int N, const float *A_log, int64_t A_d_stride) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int nA = dim * N;
     if (i < nA) {
         float s = 0.f;
         for (int b = 0; b < batch; ++b) s += ws_dA[(size_t)b * nA + i];
+        if (A_log) s *= -__expf(A_log[(i / N) * A_d_stride + (i % N)]);  // d/dA_log of A = -exp(A_log)
         dA[i] = s;
     } else if (i < nA + dim) {
         const int d = i - nA;
@@ -365,7 +367,8 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
                        ws.bc, reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), tiles, nl, total);
     const int nw = f.dim * f.dstate + f.dim;
     hipLaunchKernelGGL(oss_scan_bwd_finish_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, ws.dA,
-                       wdD, wdb, p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate);
+                       wdD, wdb, p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr,
+                       f.A_d_stride);
     return (int)hipGetLastError();
 }
 

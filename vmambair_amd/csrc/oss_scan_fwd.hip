@@ -72,7 +72,8 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         const int dd = g * rows_per_group + (rg < rows_per_group ? rg : 0);
         carH[idx] = 0.f;
         carP[idx] = 1.f;
-        sA2[idx] = p.A[dd * p.A_d_stride + n] * kLog2e;
+        const float av = p.A[dd * p.A_d_stride + n];
+        sA2[idx] = (p.a_log_form ? -__expf(av) : av) * kLog2e;
     }
 
     const int n_chunks = (L + TC - 1) / TC;

@@ -76,12 +76,14 @@ def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0):
     return batch, dim, seqlen, dstate, n_groups
 
 
-def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start=None, u_row_mod=0):
+def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start=None, u_row_mod=0,
+              a_log_form=False):
     batch, dim, seqlen, dstate, n_groups = dims
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, seqlen, dstate, n_groups
     P.delta_softplus = 1 if delta_softplus else 0
     P.rev_group_start = n_groups if rev_group_start is None else int(rev_group_start)
     P.u_row_mod = int(u_row_mod)
+    P.a_log_form = 1 if a_log_form else 0
     P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
     P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
     if out is not None:
@@ -96,7 +98,8 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
 
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], delta_softplus: bool,
-                       nrows: int = 1, rev_group_start: Optional[int] = None, u_row_mod: int = 0) -> List[torch.Tensor]:
+                       nrows: int = 1, rev_group_start: Optional[int] = None, u_row_mod: int = 0,
+                       a_log_form: bool = False) -> List[torch.Tensor]:
     """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``.
     ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling, see include/vmambair_oss.h."""
     dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod)
@@ -110,7 +113,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     if batch == 0 or seqlen == 0:  # nothing to launch (empty tensors have no device pointer)
         return [out, x]
     P = _capi.ScanFwdParams()
-    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod)
+    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form)
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_fwd(P, _DT[u.dtype], stream), "oss_scan_fwd")
@@ -121,7 +124,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], dout: torch.Tensor,
                        x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1,
                        rev_group_start: Optional[int] = None, u_row_mod: int = 0,
-                       dout_row_mod: int = 0) -> List[Optional[torch.Tensor]]:
+                       dout_row_mod: int = 0, a_log_form: bool = False) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``."""
@@ -152,7 +155,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     ws_bytes = int(lib.oss_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, n_groups))
     ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.float32, device=u.device)
     P = _capi.ScanBwdParams()
-    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod)
+    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form)
     P.dout_batch_stride, P.dout_d_stride = dout.stride(0), dout.stride(1)
     P.du_batch_stride, P.du_d_stride = du.stride(0), du.stride(1)
     P.ddelta_batch_stride, P.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
@@ -191,20 +194,21 @@ _LIB.impl("selective_scan_fwd", _fwd_op, "CUDA")
 _LIB.impl("selective_scan_bwd", _bwd_op, "CUDA")
 
 # omni form: time-mirrored groups and shared u rows handled inside the kernels (no xs / flips)
-_LIB.define("omni_scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
+_LIB.define("omni_scan_fwd(Tensor u, Tensor delta, Tensor A_log, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
             "bool delta_softplus, int rev_group_start, int u_row_mod) -> Tensor[]")
-_LIB.define("omni_scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
+_LIB.define("omni_scan_bwd(Tensor u, Tensor delta, Tensor A_log, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, "
             "Tensor dout, Tensor? x, bool delta_softplus, int rev_group_start, int u_row_mod, int dout_row_mod) -> Tensor[]")
 _LIB.define("merge4(Tensor out, int H, int W) -> Tensor")
 
 
-def _omni_fwd_op(u, delta, A, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
-    return selective_scan_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, 1, rev_group_start, u_row_mod)
+def _omni_fwd_op(u, delta, A_log, B, C, D, delta_bias, delta_softplus, rev_group_start, u_row_mod):
+    # the omni ops take A_log and evaluate A = -exp(A_log) inside the kernels
+    return selective_scan_fwd(u, delta, A_log, B, C, D, delta_bias, delta_softplus, 1, rev_group_start, u_row_mod, True)
 
 
-def _omni_bwd_op(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod, dout_row_mod):
-    res = selective_scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, 1, rev_group_start, u_row_mod,
-                             dout_row_mod)
+def _omni_bwd_op(u, delta, A_log, B, C, D, delta_bias, dout, x, delta_softplus, rev_group_start, u_row_mod, dout_row_mod):
+    res = selective_scan_bwd(u, delta, A_log, B, C, D, delta_bias, dout, x, delta_softplus, 1, rev_group_start, u_row_mod,
+                             dout_row_mod, True)
     return [t if t is not None else u.new_empty(0, dtype=torch.float32) for t in res]
 
 

@@ -57,6 +57,19 @@ class LayerNorm(nn.Module):
         return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype)
 
 
+def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """A ``nn.Conv2d(Cin, Cout, 1)`` module's parameters applied as ONE dense GEMM on the NCHW tensor:
+    ``y[b] = W (Cout x Cin) @ x[b] (Cin x H*W)`` -- hipBLASLt / MFMA directly, no NCHW<->NHWC transposes
+    and no im2col (the in_conv / out_conv / project_in / project_out of the block,
+    MambaSISR6_arch.py:205,211,281,329).  Same math as the conv; under autocast the GEMM runs in bf16."""
+    B, Cin, H, W = x.shape
+    w = conv.weight.view(conv.out_channels, Cin)
+    y = torch.matmul(w, x.reshape(B, Cin, H * W))
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1).to(y.dtype)
+    return y.view(B, conv.out_channels, H, W)
+
+
 class FeedForward(nn.Module):
     """EFFN: 1x1 (D -> 2h) -> depth-wise 3x3 -> gelu(x1) * x2 -> 1x1 (h -> D), h = int(D * factor)
     (MambaSISR6_arch.py:201-218)."""
@@ -69,8 +82,8 @@ class FeedForward(nn.Module):
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x1, x2 = dwconv3x3(self.project_in(x), self.dwconv).chunk(2, dim=1)
-        return self.project_out(F.gelu(x1) * x2)
+        x1, x2 = dwconv3x3(conv1x1(x, self.project_in), self.dwconv).chunk(2, dim=1)
+        return conv1x1(F.gelu(x1) * x2, self.project_out)
 
 
 def _dt_proj_init(dt_rank: int, d_inner: int, dt_scale=1.0, dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
@@ -167,8 +180,8 @@ class SS2D_1(nn.Module):
         x_dbl = torch.cat([z01, z23], dim=1)                                           # (B, 4, R+2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
-        args = (x2.view(B, -1, L), dts.contiguous().view(B, -1, L), -torch.exp(self.A_logs.float()), Bs, Cs, self.Ds,
-                self.dt_projs_bias.view(-1))
+        args = (x2.view(B, -1, L), dts.contiguous().view(B, -1, L), self.A_logs, Bs, Cs, self.Ds,
+                self.dt_projs_bias.view(-1))  # A = -exp(A_logs) is evaluated inside the kernels
         if self.fused_merge:
             # scan + merge ((y0 + flip y2) + T y1) + T flip y3 in fp32 as one autograd node
             y = OmniScanMergeFn.apply(*args, H, W)
@@ -209,6 +222,36 @@ class SS2D_1(nn.Module):
 
     # -- two channel directions over the pooled descriptor (MambaSISR6_arch.py:438-483) --
     def cforward_core(self, xc: torch.Tensor) -> torch.Tensor:
+        """Omni form of the channel branch: the 1->dc_inner lift is an affine map, both directions are
+        projected from the un-flipped rows and direction 1 is walked backwards inside the scan
+        kernels (no stack / flip / conv launches on these tiny tensors).  Same values as
+        ``cforward_core_ref`` (the literal reference data flow)."""
+        if not self.omni:
+            return self.cforward_core_ref(xc)
+        b, d, h, w = xc.shape
+        pooled = xc.mean(dim=(2, 3))                                                    # (b, L = d)
+        Rc, N = self.dtc_rank, self.dc_state
+        if self.dc_inner is not None:
+            dc = self.dc_inner
+            seq = torch.addcmul(self.conv_cin.bias.view(1, dc, 1).to(pooled.dtype), pooled.unsqueeze(1),
+                                self.conv_cin.weight.view(1, dc, 1).to(pooled.dtype))   # conv_cin on a 1-channel map
+        else:
+            dc = 1
+            seq = pooled.view(b, 1, d)
+        fp32 = self.dc_inner is None  # RealSR runs this scan in fp32 (MambaRealSR11_arch.py:513-519)
+        z = torch.einsum("kcj,bjl->bkcl", self.xc_proj_weight, seq)                      # (b, 2, Rc+2N, L)
+        dts, Bs, Cs = torch.split(z, [Rc, N, N], dim=2)
+        dts = torch.einsum("bkrl,kjr->bkjl", dts, self.dtc_projs_weight).reshape(b, 2 * dc, d)
+        if fp32:
+            seq, dts, Bs, Cs = seq.float(), dts.float(), Bs.float(), Cs.float()
+        out = OmniScanFn.apply(seq, dts, self.Ac_logs, Bs, Cs, self.Dsc, self.dtc_projs_bias.view(-1)).view(b, 2, dc, d)
+        y = out[:, 0].float() + out[:, 1].float()                                       # direction 1 is stored un-flipped
+        if self.dc_inner is not None:
+            y = torch.matmul(self.conv_cout.weight.view(1, dc), y) + self.conv_cout.bias  # conv_cout: (b, 1, L)
+        y = F.layer_norm(y.reshape(b, d), (d,), self.channel_norm.body.weight, self.channel_norm.body.bias, 1e-5)
+        return y.view(b, d, 1, 1).to(xc.dtype)
+
+    def cforward_core_ref(self, xc: torch.Tensor) -> torch.Tensor:
         b, d, h, w = xc.shape
         pooled = xc.mean(dim=(2, 3))                                                    # (b, d)
         if self.dc_inner is not None:
@@ -238,16 +281,17 @@ class SS2D_1(nn.Module):
             y = y.transpose(1, 2).contiguous()                                          # (b, L = d, 1, 1)
         else:
             y = y.transpose(1, 2).unsqueeze(2).contiguous()                             # (b, d, 1, 1)
-        return self.channel_norm(y, out_dtype=xc.dtype)
+        return F.layer_norm(y.reshape(b, d), (d,), self.channel_norm.body.weight, self.channel_norm.body.bias,
+                            1e-5).view(b, d, 1, 1).to(xc.dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        xz = self.in_conv(x)
+        xz = conv1x1(x, self.in_conv)
         x, z = xz.chunk(2, dim=1)
         x = F.silu(dwconv3x3(x, self.conv2d))
         y2 = self.forward_core(x, gate=z)  # out_norm(merge) * silu(z), fused in the LayerNorm kernel
         c = self.cforward_core(y2)
         y2 = (y2 + c) if self.gate == "add" else (y2 * c + y2)
-        return self.out_conv(y2)
+        return conv1x1(y2, self.out_conv)
 
 
 class MamberBlock(nn.Module):

@@ -96,10 +96,12 @@ class OmniScanFn(torch.autograd.Function):
     the reference."""
 
     @staticmethod
-    def forward(ctx, x2, delta, A, B, C, D, delta_bias):
+    def forward(ctx, x2, delta, A, B, C, D, delta_bias):  # A = A_log (A = -exp(A_log) is evaluated in-kernel)
         x2, delta, B, C = _last_contig(x2), _last_contig(delta), _last_contig(B), _last_contig(C)
         rows = x2.shape[1]
-        out, x = torch.ops.vmambair.omni_scan_fwd(x2, delta, A, B, C, D.float(), delta_bias.float(), True, 2, rows)
+        ctx.rev = B.shape[1] // 2  # second half of the directions is time-mirrored (4 spatial / 2 channel)
+        out, x = torch.ops.vmambair.omni_scan_fwd(x2, delta, A.float(), B, C, D.float(), delta_bias.float(), True,
+                                                   ctx.rev, rows)
         ctx.rows = rows
         ctx.save_for_backward(x2, delta, A, B, C, D, delta_bias, x)
         return out
@@ -108,7 +110,7 @@ class OmniScanFn(torch.autograd.Function):
     def backward(ctx, dout):
         x2, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
         du, ddelta, dA, dB, dC, dD, dbias = torch.ops.vmambair.omni_scan_bwd(
-            x2, delta, A, B, C, D.float(), delta_bias.float(), _last_contig(dout), x, True, 2, ctx.rows, 0)
+            x2, delta, A.float(), B, C, D.float(), delta_bias.float(), _last_contig(dout), x, True, ctx.rev, ctx.rows, 0)
         dx2 = du[:, :ctx.rows] + du[:, ctx.rows:]  # directions k and k+2 share the rows of x2
         return dx2, ddelta, dA, dB, dC, dD.to(D.dtype), dbias.to(delta_bias.dtype)
 
@@ -140,10 +142,10 @@ class OmniScanMergeFn(torch.autograd.Function):
     built and the backward kernel reads them with ``dout_row_mod = 2*D``."""
 
     @staticmethod
-    def forward(ctx, x2, delta, A, B, C, D, delta_bias, H, W):
+    def forward(ctx, x2, delta, A, B, C, D, delta_bias, H, W):  # A = A_log
         x2, delta, B, C = _last_contig(x2), _last_contig(delta), _last_contig(B), _last_contig(C)
         rows = x2.shape[1]
-        out, x = torch.ops.vmambair.omni_scan_fwd(x2, delta, A, B, C, D.float(), delta_bias.float(), True, 2, rows)
+        out, x = torch.ops.vmambair.omni_scan_fwd(x2, delta, A.float(), B, C, D.float(), delta_bias.float(), True, 2, rows)
         ctx.rows, ctx.hw = rows, (H, W)
         ctx.save_for_backward(x2, delta, A, B, C, D, delta_bias, x)
         Bsz, _, L = out.shape
@@ -158,6 +160,6 @@ class OmniScanMergeFn(torch.autograd.Function):
         g2[:, 0].copy_(dy.reshape(Bsz, Dn, H * W))
         g2[:, 1].view(Bsz, Dn, W, H).copy_(dy.transpose(2, 3))
         du, ddelta, dA, dB, dC, dD, dbias = torch.ops.vmambair.omni_scan_bwd(
-            x2, delta, A, B, C, D.float(), delta_bias.float(), g2.view(Bsz, 2 * Dn, H * W), x, True, 2, ctx.rows, 2 * Dn)
+            x2, delta, A.float(), B, C, D.float(), delta_bias.float(), g2.view(Bsz, 2 * Dn, H * W), x, True, 2, ctx.rows, 2 * Dn)
         dx2 = du[:, :ctx.rows] + du[:, ctx.rows:]
         return dx2, ddelta, dA, dB, dC, dD.to(D.dtype), dbias.to(delta_bias.dtype), None, None
