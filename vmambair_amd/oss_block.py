@@ -58,16 +58,12 @@ class LayerNorm(nn.Module):
 
 
 def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    """A ``nn.Conv2d(Cin, Cout, 1)`` module's parameters applied as ONE dense GEMM on the NCHW tensor:
-    ``y[b] = W (Cout x Cin) @ x[b] (Cin x H*W)`` -- hipBLASLt / MFMA directly, no NCHW<->NHWC transposes
-    and no im2col (the in_conv / out_conv / project_in / project_out of the block,
-    MambaSISR6_arch.py:205,211,281,329).  Same math as the conv; under autocast the GEMM runs in bf16."""
-    B, Cin, H, W = x.shape
-    w = conv.weight.view(conv.out_channels, Cin)
-    y = torch.matmul(w, x.reshape(B, Cin, H * W))
-    if conv.bias is not None:
-        y = y + conv.bias.view(1, -1, 1).to(y.dtype)
-    return y.view(B, conv.out_channels, H, W)
+    """The 1x1 convolutions of the block (in_conv / out_conv / project_in / project_out,
+    MambaSISR6_arch.py:205,211,281,329) are dense GEMMs: they stay on the vendor library (MIOpen
+    implicit-GEMM / hipBLASLt on MFMA).  A broadcast ``torch.matmul(W, x)`` formulation was measured
+    SLOWER here (profiles/r01_rocprof_bench_v6_matmul_summary.txt: 113 us per GEMM + expand copies),
+    so this is the plain conv call, kept behind one function for the next round's own MFMA kernel."""
+    return conv(x)
 
 
 class FeedForward(nn.Module):
