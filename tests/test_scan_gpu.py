@@ -354,6 +354,7 @@ def test_omni_scan_matches_materialised_directions(seqlen, itype, rows):
     dv = [t.to(DEV) for t in (x2, delta, A, Bm, Cm, D, bias)]
     out, x = vmambair_amd.selective_scan_fwd(*dv, True, 1, rev_group_start=2, u_row_mod=2 * rows)
     grads = vmambair_amd.selective_scan_bwd(*dv, dout.to(DEV), x, True, 1, rev_group_start=2, u_row_mod=2 * rows)
+    rtol, atol = TOL[itype]
     # the same call with A handed over as A_log (A = -exp(A_log) in-kernel) and dout shared by k, k+2
     A_log = torch.log(-A).to(DEV)
     out_l, x_l = vmambair_amd.selective_scan_fwd(dv[0], dv[1], A_log, *dv[3:], True, 1, rev_group_start=2,
