@@ -39,6 +39,13 @@ def _worker(rank, world, port, tmp):
     loss.backward()
     grads = {k: p.grad.clone() for k, p in net.named_parameters()}
     red = ddp.reduce_loss_dict({"l_pix": loss})
+    # the captured-step path: local backward without DDP hooks + ONE flat all-reduce must give the same
+    net2 = MamberBlock(16, variant="srgan")
+    net2.load_state_dict(ref_state)
+    net2(x_all[idx]).square().mean().backward()
+    ddp.allreduce_grads_flat(list(net2.parameters()))
+    for (k, p2) in net2.named_parameters():
+        assert torch.allclose(p2.grad, grads[k], rtol=1e-5, atol=1e-7), k
     if rank == 0:
         torch.save({"grads": grads, "state": ref_state, "x": x_all, "loss": red["l_pix"]}, os.path.join(tmp, "r0.pt"))
     # both ranks hold the same averaged gradient

@@ -7,10 +7,14 @@ SRGAN/options/MambaSISR15_x4.yml:26-33), so the whole step -- forward, L1 loss, 
 EMA: exactly ``optimize_parameters`` of the reference (SRGAN/VmambaIR/models/MambaSISR_model.py:120-147)
 -- is captured once into a hipGraph and replayed.
 
-Multi-GPU: the graph holds forward + backward only and accumulates into ONE flat gradient buffer
-(every ``p.grad`` is a view of it); after the replay the flat buffer is all-reduced with a single
-RCCL call (48.1 MB for MambaSISR6 -- xGMI-link-bound ~0.1-0.6 ms), then a second graph
-applies Adam + EMA.  No DDP hooks inside a capture, no per-bucket calls.
+Gradients are never accumulated: ``p.grad`` is cleared (a host-side pointer reset, no kernel) before
+the captured backward, so autograd hands every parameter its gradient tensor as-is instead of
+launching one add per parameter tensor (the net has ~1450 of them).
+
+Multi-GPU: the graph holds forward + backward only; after the replay the gradients are packed into
+ONE flat buffer, all-reduced with a single RCCL call (48.1 MB for MambaSISR6 -- xGMI-link-bound
+~0.1-0.6 ms) and scattered back, then a second graph applies Adam + EMA.  No DDP hooks
+inside a capture, no per-bucket calls.
 """
 from __future__ import annotations
 
@@ -33,14 +37,6 @@ class GraphedTrainStep:
         self.loss_fn = loss_fn
         self.ema_decay = ema_decay
         self.warmup = warmup
-        # one flat fp32 gradient buffer; every p.grad is a view of it
-        total = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(total, device=self.device, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            assert p.dtype == torch.float32
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
         self.ema = [p.detach().clone() for p in self.params]
         self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, fused=True, capturable=True)
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
@@ -49,7 +45,8 @@ class GraphedTrainStep:
 
     # ---- pieces ------------------------------------------------------------------------------
     def _fwd_bwd(self):
-        self.flat_grad.zero_()
+        for p in self.params:  # host-side only: the backward then assigns instead of accumulating
+            p.grad = None
         with torch.autocast("cuda", dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
             out = self.net(self.static_lq)
         loss = self.loss_fn(out.float(), self.static_gt)
@@ -64,8 +61,8 @@ class GraphedTrainStep:
 
     def _allreduce(self):
         if self.world > 1:
-            dist.all_reduce(self.flat_grad)
-            self.flat_grad.div_(self.world)
+            from .ddp import allreduce_grads_flat
+            allreduce_grads_flat(self.params)
 
     # ---- capture -----------------------------------------------------------------------------
     def capture(self, lq: torch.Tensor, gt: torch.Tensor) -> None:
