@@ -58,7 +58,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # VMAMBAIR_LIB: timing experiments only (tools/build_experiment.sh)
+    return os.environ.get("VMAMBAIR_LIB") or _build.LIB_PATH
 
 
 def load():

@@ -56,6 +56,7 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     float *sdhc = sA2 + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dh of the first step of the later chunk
     float *sdA = sdhc + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dA partial of the row
     float *sdln = sdA + (size_t)p.f.dstate * ROWS;     // [ROWS]     delta of the first step of the later chunk
+    float *shc = sdln + ROWS;                          // [N][ROWS]  forward state entering the current chunk
 
     const oss_scan_fwd_params &f = p.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,11 +135,17 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             dd[i] = 0.f;
             S += dl[i];
         }
+        // saved forward state entering this chunk (bwd_kernel.cuh:184): fetched once per chunk by the
+        // row's own lanes, long before the first state needs it
+        {
+            const int xi_ = t0 / kScanChunk - 1;
+            for (int n = pos; n < N; n += LPR)
+                shc[n * ROWS + wrow] = (xi_ >= 0) ? x_row[(size_t)xi_ * 2 * N + 2 * n + 1] : 0.f;
+        }
         __syncthreads();  // sdln/sdhc written by the previous iteration (or the init) are visible
         const float dln_c = sdln[wrow];  // delta of step t0+TC (first step of the later chunk), 0 past the end
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
         const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
-        const int xi = t0 / kScanChunk - 1;         // saved state entering this chunk
 
         for (int n0 = 0; n0 < N; n0 += NBB) {
             const int nb = min(NBB, N - n0);
@@ -150,7 +157,7 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             for (int nn = 0; nn < nb; ++nn) {
                 const int n = n0 + nn;
                 const float A2 = sA2[n * ROWS + wrow];
-                const float hc = (xi >= 0) ? x_row[(size_t)xi * 2 * N + 2 * n + 1] : 0.f;  // bwd_kernel.cuh:184
+                const float hc = shc[n * ROWS + wrow];
                 const float dhc = sdhc[n * ROWS + wrow];
                 float a[I], hh[I];
                 // ---- forward recompute: local recurrence (hh holds b_t until the state pass)
@@ -227,6 +234,7 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 }
                 const float dA_sum = segment_sum_to_last<LPR>(dA_acc);
                 if (seg_last) sdA[n * ROWS + wrow] += dA_sum;
+#ifndef OSS_EXP_NO_REDUCE  // (timing experiments only: tools/build_experiment.sh)
                 // ---- cross-row reduction of dB/dC for this state through the slabs
                 __syncthreads();  // the previous state's slice sums have been read
                 {
@@ -253,6 +261,9 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                         ws_bc[(size_t)(N + n) * L + tm] = accc;
                     }
                 }
+#else
+                if (vB[0] + vC[I - 1] == 12345.678f) ws_bc[0] = vB[1];  // keep the values alive
+#endif
             }
         }
         // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245)
@@ -345,7 +356,7 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     if (!p.dD) ws.dD = nullptr;
     if (!p.ddelta_bias) ws.db = nullptr;
 
-    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)ROWS * TC + 4 * (size_t)f.dstate * ROWS + ROWS);
     auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB>;
     static size_t smem_enabled = 48 * 1024;
     if (smem > smem_enabled) {
