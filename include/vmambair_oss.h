@@ -134,6 +134,23 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
                         int batch, int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
                         int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
 
+/* 1x1 convolutions of the OSS block (in_conv / out_conv / project_in / project_out,
+ * MambaSISR6_arch.py:205,211,281,329) as MFMA GEMMs on NCHW tensors; io = OSS_BF16 or OSS_F16 (fp32
+ * I/O is rejected with OSS_ERR_SHAPE: it stays on the vendor conv).  weight: float (Cout, Cin)
+ * contiguous (master weights, converted in the loader); x / dy: (batch, C, pixels) io dtype, pixels
+ * contiguous, element strides (batch, channel); y / dx contiguous.
+ *   fwd  : y  = W x + bias            dgrad: dx = W^T dy
+ *   wgrad: dweight (Cout, Cin) float = sum_{b,p} dy x^T, `partials` =
+ *          oss_conv1x1_wgrad_partial_floats() floats of scratch. */
+int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout,
+                    int cin, int pixels, int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
+int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
+                      int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
+size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels);
+int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *partials, int batch, int cout,
+                      int cin, int pixels, int64_t dy_batch_stride, int64_t dy_channel_stride, int64_t x_batch_stride,
+                      int64_t x_channel_stride, oss_stream_t stream);
+
 /* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
  * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3
  * column-major) -> y (batch, D, H, W) float = ((o0 + o2) + T o1) + T o3, the reference's association

@@ -110,3 +110,49 @@ def test_fused_scan_merge_node_equals_separate_ops():
     assert_close(res[0][1], res[1][1], 1e-4, 1e-4, "dx")
     for k in res[1][2]:
         assert_close(res[0][2][k], res[1][2][k], 1e-3, 1e-4 * max(1.0, float(res[1][2][k].abs().max())), k)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 192, 64, 64), (1, 48, 96, 16, 24), (2, 127, 48, 8, 8), (1, 96, 254, 12, 10),
+                                            (3, 5, 7, 3, 5), (1, 255, 96, 16, 16), (2, 384, 384, 8, 8)])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_conv1x1_mfma(dt, B, Cin, Cout, H, W, has_bias):
+    """MFMA 1x1 convolution (fwd, input grad, weight grad) against F.conv2d in fp32 on the same
+    16-bit-rounded activations (MambaSISR6_arch.py:205,211,281,329)."""
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, H, W).to(dt)
+    w = torch.randn(Cout, Cin, 1, 1) * (Cin ** -0.5)
+    b = torch.randn(Cout) if has_bias else None
+    dy = torch.randn(B, Cout, H, W).to(dt)
+    xr = x.float().clone().requires_grad_()
+    wr = w.to(dt).float().clone().requires_grad_()   # the kernel rounds the master weights to the I/O type
+    br = b.clone().requires_grad_() if has_bias else None
+    yr = F.conv2d(xr, wr, br)
+    yr.backward(dy.float())
+    xd = x.detach().to(DEV).requires_grad_()
+    wd = w.detach().to(DEV).requires_grad_()
+    bd = b.detach().to(DEV).requires_grad_() if has_bias else None
+    y = ops.Conv1x1Fn.apply(xd, wd, bd)
+    assert y.dtype == dt and y.shape == (B, Cout, H, W)
+    y.backward(dy.to(DEV))
+    rt, at = (2e-2, 3e-2) if dt == torch.bfloat16 else (3e-3, 5e-3)
+    assert_close(y, yr, rt, at, "y")
+    assert_close(xd.grad, xr.grad, rt, at * 2, "dx")
+    sw = float(wr.grad.abs().max())
+    assert_close(wd.grad, wr.grad, rt, 2e-3 * sw, "dw")  # fp32 accumulation of exact 16-bit products
+    if has_bias:
+        assert_close(bd.grad, br.grad, 1e-3, 1e-3 * float(br.grad.abs().max()), "db")
+
+
+def test_conv1x1_on_strided_views_and_autocast():
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(32, 48, 1).to(DEV)
+    big = torch.randn(2, 64, 16, 16, device=DEV)
+    x = big[:, 16:48]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops.conv1x1(x, conv)
+        yref = conv(x)
+    assert y.dtype == torch.bfloat16
+    assert_close(y, yref, 2e-2, 3e-2, "autocast conv1x1 vs vendor conv")
+    y32 = ops.conv1x1(x, conv)  # fp32 activations outside autocast: vendor path, fp32 out
+    assert y32.dtype == torch.float32

@@ -180,6 +180,34 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
                            reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout,
+                    int cin, int pixels, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    if (!x || !weight || !y) return OSS_ERR_NULL;
+    if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return conv1x1(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, cin, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
+                      int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    if (!dy || !weight || !dx) return OSS_ERR_NULL;
+    if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    // dx[ci] = sum_co W[co][ci] dy[co]: the same GEMM with the weights read transposed
+    return conv1x1(io, dy, weight, nullptr, dx, batch, cin, cout, pixels, gsb, gsc, 1, cin, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels) {
+    if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0) return 0;
+    return (size_t)batch * conv1x1_wgrad_slabs(pixels) * cout * cin;
+}
+
+int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *partials, int batch, int cout,
+                      int cin, int pixels, int64_t gsb, int64_t gsc, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    if (!dy || !x || !dweight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return conv1x1_wgrad(io, dy, x, dweight, partials, batch, cout, cin, pixels, gsb, gsc, xsb, xsc,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
     if (!out || !y) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;

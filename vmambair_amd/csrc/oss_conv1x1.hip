@@ -1,0 +1,197 @@
+// oss_conv1x1.hip -- the dense 1x1 projections of the OSS block on the CDNA4 matrix cores:
+// in_conv / out_conv of SS2D_1 and project_in / project_out of the EFFN
+// (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:205,211,281,329), directly on NCHW tensors.
+//
+// These are the only GEMM-shaped ops of the block.  The vendor conv path spends 4 launches forward and
+// ~8 backward per projection on NCHW<->NHWC transposes, weight casts and bias tensor-ops around one
+// implicit-GEMM kernel (profiles/r01_rocprof_bench_v8_summary.txt), which is what bounds a 64x64
+// training step.  Here: ONE launch forward (fp32 master weights converted to bf16 in the loader, bias
+// fused), one for the input gradient (same kernel, weights read transposed), one split-K launch + a
+// finishing launch for the weight gradient.
+//
+// MFMA: v_mfma_f32_32x32x16_{bf16,f16}, one 32 x 32 output tile per wave-instruction group, fp32
+// accumulation.  Operand maps (cdna_hip_programming.md section 3): lane l holds A[i = l & 31][k = 8 (l >> 5) .. +8] and
+// B[k = 8 (l >> 5) .. +8][j = l & 31]; D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31], r in [0,16).
+//   forward / dgrad: rows = output channels, cols = 32 consecutive pixels, k = input channels.  The
+//     activation operand needs 8 channels of ONE pixel per lane while NCHW stores pixels contiguously:
+//     8 two-byte loads per lane, each coalesced over the 32 pixel lanes (64-byte segments).
+//   wgrad: k = pixels, so both operands are 16-byte contiguous loads (dy rows and x rows).
+#include "oss_device.h"
+#include "oss_host.h"
+
+namespace oss {
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
+                                                       __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<f16_t> {
+    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, a),
+                                                      __builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ short to_bits(float v) { return (short)from_f32<T>(v).v; }
+
+// y[b, m, p] = sum_k W(m, k) x[b, k, p] (+ bias[m]);  W(m, k) = w[m * ws_m + k * ws_k] (fp32 master weights).
+//   forward: M = Cout, K = Cin, ws_m = Cin, ws_k = 1;  dgrad: M = Cin, K = Cout, ws_m = 1, ws_k = Cin.
+// x: (B, K, P) with strides (xsb, xsk), pixels contiguous; y: (B, M, P) contiguous.
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ y,
+                   int M, int K, int P, int64_t xsb, int64_t xsk, int64_t ws_m, int64_t ws_k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= P) return;
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + col;
+    const bool pok = p < P;
+    const T *xb = x + b * xsb + (pok ? p : 0);
+    T *yb = y + (size_t)b * M * P;
+    const int ksteps = (K + 15) >> 4;
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        const int mrow = m0 + col;  // A-operand row of this lane
+        const bool mok = mrow < M;
+        const float *wrow = w + (mok ? mrow : 0) * ws_m;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int k0 = ks * 16 + kg * 8;
+            s16x8 af, bf;
+            // clamped addresses + selects instead of predicated loads: no branches in the k loop
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                const bool kok = k < K;
+                const int kc = kok ? k : K - 1;
+                const float wv = wrow[kc * ws_k];
+                const short xv = (short)xb[kc * xsk].v;
+                af[e] = (mok && kok) ? to_bits<T>(wv) : (short)0;
+                bf[e] = (pok && kok) ? xv : (short)0;
+            }
+            acc = Mfma<T>::run(af, bf, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row < M && pok) {
+                const float v = acc[r] + (bias ? bias[row] : 0.f);
+                yb[(size_t)row * P + p] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// partial[slab][m][n] = sum over the slab's pixels of dy[b, m, p] x[b, n, p];  slabs = B * ceil(P / SLAB)
+constexpr int kWgradSlab = 512;
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
+                         int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int pbeg = slab * kWgradSlab, pend = min(P, pbeg + kWgradSlab);
+    const int col = lane & 31, kg = lane >> 5;
+    const int mt = (M + 31) >> 5, nt = (N + 31) >> 5;
+    const T *gb = dy + b * gsb;
+    const T *xb = x + b * xsb;
+    float *pb = part + ((size_t)(b * gridDim.x + slab)) * M * N;
+    const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
+                         (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0);
+    for (int tile = wave; tile < mt * nt; tile += 4) {
+        const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
+        const int mrow = m0 + col, nrow = n0 + col;
+        const bool mok = mrow < M, nok = nrow < N;
+        const T *ga = gb + (mok ? mrow : 0) * gsm;
+        const T *xa = xb + (nok ? nrow : 0) * xsn;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int pk = pbeg; pk < pend; pk += 16) {
+            const int k0 = pk + kg * 8;
+            s16x8 af, bf;
+            if (aligned && k0 + 8 <= pend) {
+                const u32x4 qa = *reinterpret_cast<const u32x4 *>(ga + k0);
+                const u32x4 qb = *reinterpret_cast<const u32x4 *>(xa + k0);
+                af = mok ? __builtin_bit_cast(s16x8, qa) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                bf = nok ? __builtin_bit_cast(s16x8, qb) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool kok = (k0 + e) < pend;
+                    const int kc = kok ? k0 + e : pend - 1;
+                    const short av = (short)ga[kc].v, bv = (short)xa[kc].v;
+                    af[e] = (mok && kok) ? av : (short)0;
+                    bf[e] = (nok && kok) ? bv : (short)0;
+                }
+            }
+            acc = Mfma<T>::run(af, bf, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const int cn = n0 + col;
+            if (row < M && cn < N) pb[(size_t)row * N + cn] = acc[r];
+        }
+    }
+}
+
+// dW[m][n] = sum over slabs (fixed order)
+__global__ void __launch_bounds__(256)
+oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, int nslab, size_t mn) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += part[(size_t)k * mn + i];
+    dw[i] = s;
+}
+
+int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
+            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s) {
+    dim3 grid((P + 127) / 128, B);
+    switch (io) {
+        case OSS_BF16:
+            hipLaunchKernelGGL(oss_conv1x1_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), w, bias,
+                               reinterpret_cast<bf16_t *>(y), M, K, P, xsb, xsk, ws_m, ws_k);
+            break;
+        case OSS_F16:
+            hipLaunchKernelGGL(oss_conv1x1_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(x), w, bias,
+                               reinterpret_cast<f16_t *>(y), M, K, P, xsb, xsk, ws_m, ws_k);
+            break;
+        default: return OSS_ERR_SHAPE;  // fp32 I/O stays on the vendor conv (no reduced-precision path for fp32)
+    }
+    return (int)hipGetLastError();
+}
+
+int conv1x1_wgrad_slabs(int P) { return (P + kWgradSlab - 1) / kWgradSlab; }
+
+int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
+                  int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s) {
+    const int slabs = conv1x1_wgrad_slabs(P);
+    dim3 grid(slabs, B);
+    switch (io) {
+        case OSS_BF16:
+            hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(dy),
+                               reinterpret_cast<const bf16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn);
+            break;
+        case OSS_F16:
+            hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(dy),
+                               reinterpret_cast<const f16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn);
+            break;
+        default: return OSS_ERR_SHAPE;
+    }
+    const size_t mn = (size_t)M * N;
+    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, part, dw, slabs * B, mn);
+    return (int)hipGetLastError();
+}
+
+}  // namespace oss

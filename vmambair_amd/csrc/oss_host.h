@@ -31,5 +31,10 @@ int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
                 float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
 int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, hipStream_t s);
+int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
+            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s);
+int conv1x1_wgrad_slabs(int P);
+int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
+                  int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

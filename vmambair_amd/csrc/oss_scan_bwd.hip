@@ -56,7 +56,6 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     float *sdhc = sA2 + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dh of the first step of the later chunk
     float *sdA = sdhc + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dA partial of the row
     float *sdln = sdA + (size_t)p.f.dstate * ROWS;     // [ROWS]     delta of the first step of the later chunk
-    float *shc = sdln + ROWS;                          // [N][ROWS]  forward state entering the current chunk
 
     const oss_scan_fwd_params &f = p.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,13 +134,7 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             dd[i] = 0.f;
             S += dl[i];
         }
-        // saved forward state entering this chunk (bwd_kernel.cuh:184): fetched once per chunk by the
-        // row's own lanes, long before the first state needs it
-        {
-            const int xi_ = t0 / kScanChunk - 1;
-            for (int n = pos; n < N; n += LPR)
-                shc[n * ROWS + wrow] = (xi_ >= 0) ? x_row[(size_t)xi_ * 2 * N + 2 * n + 1] : 0.f;
-        }
+        const int xi = t0 / kScanChunk - 1;  // saved forward state entering this chunk (bwd_kernel.cuh:184)
         __syncthreads();  // sdln/sdhc written by the previous iteration (or the init) are visible
         const float dln_c = sdln[wrow];  // delta of step t0+TC (first step of the later chunk), 0 past the end
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
@@ -157,7 +150,9 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             for (int nn = 0; nn < nb; ++nn) {
                 const int n = n0 + nn;
                 const float A2 = sA2[n * ROWS + wrow];
-                const float hc = shc[n * ROWS + wrow];
+                // issued here, consumed after the first pass and the scan: the latency is covered (a per-chunk
+                // prefetch through LDS measured 10 % slower, profiles/r01_sweep_v3_bwd.txt)
+                const float hc = (xi >= 0) ? x_row[(size_t)xi * 2 * N + 2 * n + 1] : 0.f;
                 const float dhc = sdhc[n * ROWS + wrow];
                 float a[I], hh[I];
                 // ---- forward recompute: local recurrence (hh holds b_t until the state pass)
@@ -293,28 +288,11 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     }
 }
 
-// dB/dC: sum the row-tile partials of each (batch, group) in tile order and cast to the I/O type
-template <typename T>
-__global__ void __launch_bounds__(256)
-oss_scan_bwd_finish_bc(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*L */, size_t total /* batch*G*N*L */) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const size_t bg = i / nl, r = i - bg * nl;
-    const float *base = ws_bc + bg * tiles * 2 * nl + r;
-    float sb = 0.f, sc = 0.f;
-    for (int t = 0; t < tiles; ++t) {
-        sb += base[(size_t)t * 2 * nl];
-        sc += base[(size_t)t * 2 * nl + nl];
-    }
-    dB[i] = from_f32<T>(sb);
-    dC[i] = from_f32<T>(sc);
-}
-
-// dA, dD, ddelta_bias: sum over batch in batch order
-__global__ void __launch_bounds__(256)
-oss_scan_bwd_finish_w(const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA, float *dD,
-                      float *db, int batch, int dim, int N, const float *A_log, int64_t A_d_stride) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// dA, dD, ddelta_bias: sum over batch in batch order (device function: runs in the trailing blocks
+// of the finishing launch)
+__device__ __forceinline__ void finish_w(int i, const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA,
+                                         float *dD, float *db, int batch, int dim, int N, const float *A_log,
+                                         int64_t A_d_stride) {
     const int nA = dim * N;
     if (i < nA) {
         float s = 0.f;
@@ -334,6 +312,31 @@ oss_scan_bwd_finish_w(const float *ws_dA, const float *ws_dD, const float *ws_db
             db[d] = s;
         }
     }
+}
+
+// ONE finishing launch: blocks [0, nblk_bc) add the row-tile partials of dB/dC in tile order and
+// cast to the I/O type; the remaining blocks reduce the weight-gradient partials over batch.
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*L */, size_t total /* batch*G*N*L */,
+                    unsigned nblk_bc, const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA, float *dD,
+                    float *db, int batch, int dim, int N, const float *A_log, int64_t A_d_stride) {
+    if (blockIdx.x >= nblk_bc) {
+        finish_w((int)((blockIdx.x - nblk_bc) * 256 + threadIdx.x), ws_dA, ws_dD, ws_db, dA, dD, db, batch, dim, N, A_log,
+                 A_d_stride);
+        return;
+    }
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t bg = i / nl, r = i - bg * nl;
+    const float *base = ws_bc + bg * tiles * 2 * nl + r;
+    float sb = 0.f, sc = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        sb += base[(size_t)t * 2 * nl];
+        sc += base[(size_t)t * 2 * nl + nl];
+    }
+    dB[i] = from_f32<T>(sb);
+    dC[i] = from_f32<T>(sc);
 }
 
 template <typename T, int LPR, int I, int WAVES, int NBB>
@@ -356,7 +359,7 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     if (!p.dD) ws.dD = nullptr;
     if (!p.ddelta_bias) ws.db = nullptr;
 
-    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)ROWS * TC + 4 * (size_t)f.dstate * ROWS + ROWS);
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
     auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB>;
     static size_t smem_enabled = 48 * 1024;
     if (smem > smem_enabled) {
@@ -374,12 +377,11 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 
     const size_t nl = (size_t)f.dstate * f.seqlen;
     const size_t total = (size_t)f.batch * f.n_groups * nl;
-    hipLaunchKernelGGL(oss_scan_bwd_finish_bc<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       ws.bc, reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), tiles, nl, total);
-    const int nw = f.dim * f.dstate + f.dim;
-    hipLaunchKernelGGL(oss_scan_bwd_finish_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, ws.dA,
-                       wdD, wdb, p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr,
-                       f.A_d_stride);
+    const unsigned nblk_bc = (unsigned)((total + 255) / 256);
+    const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + 255) / 256);
+    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(nblk_bc + nblk_w), dim3(256), 0, stream, ws.bc,
+                       reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), tiles, nl, total, nblk_bc, ws.dA, wdD, wdb,
+                       p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr, f.A_d_stride);
     return (int)hipGetLastError();
 }
 

@@ -413,3 +413,78 @@ def layer_norm_nchw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.
     if out_dtype is None:
         out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
     return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# 1x1 convolutions of the OSS block as MFMA GEMMs on NCHW (bf16 / fp16 I/O, fp32 master weights)
+# ---------------------------------------------------------------------------------------------
+def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.conv2d(x, weight, bias)`` for a (Cout, Cin, 1, 1) weight; x bf16/fp16 (B, Cin, H, W)."""
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "conv1x1: x must be bf16/fp16 on the GPU")
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    _check(tuple(weight.shape) == (Cout, Cin, 1, 1), "conv1x1: weight must be (Cout, Cin, 1, 1)")
+    x = _planes(x)
+    w = weight.detach().float().reshape(Cout, Cin).contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+    if x.numel() == 0:
+        return y
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        _capi.check(lib.oss_conv1x1_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), B, Cout, Cin, H * W,
+                                        x.stride(0), x.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_fwd")
+    return y
+
+
+def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor) -> List[torch.Tensor]:
+    """-> [dx (x dtype), dweight (Cout, Cin, 1, 1) fp32]"""
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    P = H * W
+    x, dy = _planes(x), _planes(dy)
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    w = weight.detach().float().reshape(Cout, Cin).contiguous()
+    dx = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
+    dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
+    lib = _capi.load()
+    part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
+                                          dy.stride(0), dy.stride(1), st), "oss_conv1x1_dgrad")
+        _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), part.data_ptr(), B, Cout,
+                                          Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), st), "oss_conv1x1_wgrad")
+    return [dx, dw.view(Cout, Cin, 1, 1)]
+
+
+_LIB.define("conv1x1_fwd(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
+_LIB.define("conv1x1_bwd(Tensor x, Tensor weight, Tensor dy) -> Tensor[]")
+_LIB.impl("conv1x1_fwd", conv1x1_fwd, "CUDA")
+_LIB.impl("conv1x1_bwd", conv1x1_bwd, "CUDA")
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return torch.ops.vmambair.conv1x1_fwd(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw = torch.ops.vmambair.conv1x1_bwd(x, weight, dy)
+        db = dy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias else None
+        return dx, dw.to(weight.dtype), db
+
+
+def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
+    """A ``nn.Conv2d(Cin, Cout, 1)`` module's parameters through the MFMA kernels when the activations
+    are 16-bit (autocast training / fp16 inference); fp32 activations stay on the vendor conv."""
+    if x.is_cuda and torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_dtype("cuda"))
+    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
+        return Conv1x1Fn.apply(x, conv.weight, conv.bias)
+    return conv(x)

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import dwconv3x3, layer_norm_nchw
+from .ops import conv1x1, dwconv3x3, layer_norm_nchw
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
@@ -55,15 +55,6 @@ class LayerNorm(nn.Module):
     def forward(self, x: torch.Tensor, gate: torch.Tensor = None, out_dtype: torch.dtype = None) -> torch.Tensor:
         """NCHW in, NCHW out, no permutes (HIP kernel).  ``gate``: fused ``* silu(gate)`` epilogue."""
         return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype)
-
-
-def conv1x1(x: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    """The 1x1 convolutions of the block (in_conv / out_conv / project_in / project_out,
-    MambaSISR6_arch.py:205,211,281,329) are dense GEMMs: they stay on the vendor library (MIOpen
-    implicit-GEMM / hipBLASLt on MFMA).  A broadcast ``torch.matmul(W, x)`` formulation was measured
-    SLOWER here (profiles/r01_rocprof_bench_v6_matmul_summary.txt: 113 us per GEMM + expand copies),
-    so this is the plain conv call, kept behind one function for the next round's own MFMA kernel."""
-    return conv(x)
 
 
 class FeedForward(nn.Module):
