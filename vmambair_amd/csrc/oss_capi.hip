@@ -183,7 +183,7 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
 int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout,
                     int cin, int pixels, int64_t xsb, int64_t xsc, oss_stream_t stream) {
     if (!x || !weight || !y) return OSS_ERR_NULL;
-    if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535 || cout > 32 * 65535) return OSS_ERR_SHAPE;
     return conv1x1(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, cin, 1, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -43,12 +43,15 @@ template <typename T> __device__ __forceinline__ short to_bits(float v) { return
 // y[b, m, p] = sum_k W(m, k) x[b, k, p] (+ bias[m]);  W(m, k) = w[m * ws_m + k * ws_k] (fp32 master weights).
 //   forward: M = Cout, K = Cin, ws_m = Cin, ws_k = 1;  dgrad: M = Cin, K = Cout, ws_m = 1, ws_k = Cin.
 // x: (B, K, P) with strides (xsb, xsk), pixels contiguous; y: (B, M, P) contiguous.
+// One wave = one 32 (rows) x 32 (pixels) output tile over the full K: grid (pixel blocks of 4 waves,
+// batch, row tiles), so that small images (64 pixels at the UNet's level 4) still spread over the chip.
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ y,
                    int M, int K, int P, int64_t xsb, int64_t xsk, int64_t ws_m, int64_t ws_k) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
+    const int m0 = blockIdx.z * 32;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     if (p0 >= P) return;
     const int col = lane & 31, kg = lane >> 5;
@@ -56,18 +59,30 @@ oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const f
     const bool pok = p < P;
     const T *xb = x + b * xsb + (pok ? p : 0);
     T *yb = y + (size_t)b * M * P;
-    const int ksteps = (K + 15) >> 4;
-    for (int m0 = 0; m0 < M; m0 += 32) {
-        const int mrow = m0 + col;  // A-operand row of this lane
-        const bool mok = mrow < M;
-        const float *wrow = w + (mok ? mrow : 0) * ws_m;
-        f32x16 acc;
+    const int mrow = m0 + col;  // A-operand row of this lane
+    const bool mok = mrow < M;
+    const float *wrow = w + (mok ? mrow : 0) * ws_m;
+    const bool wvec = (ws_k == 1) && ((reinterpret_cast<uintptr_t>(wrow) & 15u) == 0) && (K % 8 == 0);
+    f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int k0 = ks * 16 + kg * 8;
-            s16x8 af, bf;
-            // clamped addresses + selects instead of predicated loads: no branches in the k loop
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ksteps = (K + 15) >> 4;
+
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int k0 = ks * 16 + kg * 8;
+        s16x8 af, bf;
+        if (wvec && k0 + 8 <= K) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wrow + k0);
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wrow + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                af[e] = mok ? to_bits<T>(w0[e]) : (short)0;
+                af[4 + e] = mok ? to_bits<T>(w1[e]) : (short)0;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bf[e] = pok ? (short)xb[(k0 + e) * xsk].v : (short)0;
+        } else {
+            // clamped addresses + selects instead of predicated loads: no branches per element
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = k0 + e;
@@ -78,15 +93,15 @@ oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const f
                 af[e] = (mok && kok) ? to_bits<T>(wv) : (short)0;
                 bf[e] = (pok && kok) ? xv : (short)0;
             }
-            acc = Mfma<T>::run(af, bf, acc);
         }
+        acc = Mfma<T>::run(af, bf, acc);
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (row < M && pok) {
-                const float v = acc[r] + (bias ? bias[row] : 0.f);
-                yb[(size_t)row * P + p] = from_f32<T>(v);
-            }
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (row < M && pok) {
+            const float v = acc[r] + (bias ? bias[row] : 0.f);
+            yb[(size_t)row * P + p] = from_f32<T>(v);
         }
     }
 }
@@ -107,7 +122,9 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
     float *pb = part + ((size_t)(b * gridDim.x + slab)) * M * N;
     const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
                          (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0);
-    for (int tile = wave; tile < mt * nt; tile += 4) {
+    {
+        const int tile = blockIdx.z * 4 + wave;  // one 32 x 32 tile of dW per wave
+        if (tile >= mt * nt) return;
         const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
         const int mrow = m0 + col, nrow = n0 + col;
         const bool mok = mrow < M, nok = nrow < N;
@@ -116,6 +133,7 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
         for (int pk = pbeg; pk < pend; pk += 16) {
             const int k0 = pk + kg * 8;
             s16x8 af, bf;
@@ -157,7 +175,7 @@ oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw,
 
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s) {
-    dim3 grid((P + 127) / 128, B);
+    dim3 grid((P + 127) / 128, B, (M + 31) / 32);
     switch (io) {
         case OSS_BF16:
             hipLaunchKernelGGL(oss_conv1x1_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), w, bias,
@@ -177,7 +195,8 @@ int conv1x1_wgrad_slabs(int P) { return (P + kWgradSlab - 1) / kWgradSlab; }
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
                   int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s) {
     const int slabs = conv1x1_wgrad_slabs(P);
-    dim3 grid(slabs, B);
+    const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    dim3 grid(slabs, B, (tiles + 3) / 4);
     switch (io) {
         case OSS_BF16:
             hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(dy),
