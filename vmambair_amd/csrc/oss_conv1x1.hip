@@ -106,6 +106,83 @@ oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const f
     }
 }
 
+// K <= 16 * KS form: the activation fragments of the wave's 32 pixels are loaded ONCE for the whole K
+// into registers and reused for `mt_per_wave` row tiles (the 2-byte strided activation loads are the
+// expensive part; the weights come out of L1/L2).  WT = false: W(m, k) = w[m * K + k], two 16-byte
+// loads per k-step (needs K % 8 == 0); WT = true (input gradient): W(m, k) = w[k * M + m].
+template <typename T, int KS, bool WT>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                         T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= P) return;
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + col;
+    const bool pok = p < P;
+    const T *xb = x + b * xsb + (pok ? p : 0);
+    T *yb = y + (size_t)b * M * P;
+    const int ksteps = (K + 15) >> 4;
+    s16x8 bfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + kg * 8 + e;
+            const bool kok = k < K;
+            const short xv = (short)xb[(kok ? k : K - 1) * xsk].v;
+            bfr[ks][e] = (pok && kok) ? xv : (short)0;
+        }
+    }
+    const int mt_total = (M + 31) >> 5;
+    const int mt_end = min(mt_total, (int)(blockIdx.z + 1) * mt_per_wave);
+    for (int mt = blockIdx.z * mt_per_wave; mt < mt_end; ++mt) {
+        const int m0 = mt * 32;
+        const int mrow = m0 + col;
+        const bool mok = mrow < M;
+        const int mc = mok ? mrow : 0;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                const int k0 = ks * 16 + kg * 8;
+                s16x8 af;
+                if constexpr (!WT) {
+                    const bool kok = k0 + 8 <= K;
+                    const float *wp = w + mc * K + (kok ? k0 : 0);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        af[e] = (mok && kok) ? to_bits<T>(w0[e]) : (short)0;
+                        af[4 + e] = (mok && kok) ? to_bits<T>(w1[e]) : (short)0;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = k0 + e;
+                        const bool kok = k < K;
+                        const float wv = w[(kok ? k : K - 1) * M + mc];
+                        af[e] = (mok && kok) ? to_bits<T>(wv) : (short)0;
+                    }
+                }
+                acc = Mfma<T>::run(af, bfr[ks], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row < M && pok) {
+                const float v = acc[r] + (bias ? bias[row] : 0.f);
+                yb[(size_t)row * P + p] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
 // partial[slab][m][n] = sum over the slab's pixels of dy[b, m, p] x[b, n, p];  slabs = B * ceil(P / SLAB)
 constexpr int kWgradSlab = 512;
 template <typename T>
@@ -173,17 +250,46 @@ oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw,
     dw[i] = s;
 }
 
+template <typename T>
+static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, int B, int M, int K, int P, int64_t xsb,
+                           int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s) {
+    const int pblocks = (P + 127) / 128, mt = (M + 31) / 32;
+    const bool wt = (ws_m == 1 && ws_k == M);          // input gradient: weights read transposed
+    const bool plain = (ws_k == 1 && ws_m == K);
+    const bool reuse_ok = K <= 16 * 12 && xsk < (1 << 24) && (size_t)M * K < (1u << 30) &&
+                          (wt || (plain && K % 8 == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0));
+    if (reuse_ok) {
+        // enough waves to fill 256 CUs x 4 SIMDs twice, otherwise as few activation re-loads as possible
+        const long waves_p = (long)B * ((P + 31) / 32);
+        int split = (int)((2048 + waves_p - 1) / waves_p);
+        if (split < 1) split = 1;
+        if (split > mt) split = mt;
+        const int per = (mt + split - 1) / split;
+        dim3 grid(pblocks, B, (mt + per - 1) / per);
+        const int xk = (int)xsk;
+        if (K <= 16 * 6) {
+            if (wt) hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 6, true>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
+            else    hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 6, false>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
+        } else {
+            if (wt) hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 12, true>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
+            else    hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 12, false>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
+        }
+    } else {
+        dim3 grid(pblocks, B, mt);
+        hipLaunchKernelGGL(oss_conv1x1_kernel<T>, grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xsk, ws_m, ws_k);
+    }
+}
+
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s) {
-    dim3 grid((P + 127) / 128, B, (M + 31) / 32);
     switch (io) {
         case OSS_BF16:
-            hipLaunchKernelGGL(oss_conv1x1_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), w, bias,
-                               reinterpret_cast<bf16_t *>(y), M, K, P, xsb, xsk, ws_m, ws_k);
+            conv1x1_launch<bf16_t>(reinterpret_cast<const bf16_t *>(x), w, bias, reinterpret_cast<bf16_t *>(y), B, M, K, P, xsb,
+                                   xsk, ws_m, ws_k, s);
             break;
         case OSS_F16:
-            hipLaunchKernelGGL(oss_conv1x1_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(x), w, bias,
-                               reinterpret_cast<f16_t *>(y), M, K, P, xsb, xsk, ws_m, ws_k);
+            conv1x1_launch<f16_t>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
+                                  ws_m, ws_k, s);
             break;
         default: return OSS_ERR_SHAPE;  // fp32 I/O stays on the vendor conv (no reduced-precision path for fp32)
     }
