@@ -144,7 +144,8 @@ def test_conv1x1_mfma(dt, B, Cin, Cout, H, W, has_bias):
         assert_close(bd.grad, br.grad, 1e-3, 1e-3 * float(br.grad.abs().max()), "db")
 
 
-def test_conv1x1_on_strided_views_and_autocast():
+def test_conv1x1_on_strided_views_and_autocast(monkeypatch):
+    monkeypatch.setattr(ops, "CONV1X1_IMPL", "mfma")
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(32, 48, 1).to(DEV)
     big = torch.randn(2, 64, 16, 16, device=DEV)

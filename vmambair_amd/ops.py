@@ -17,6 +17,7 @@ No CPU implementation exists: CPU tensors are rejected exactly as the reference 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -480,11 +481,21 @@ class Conv1x1Fn(torch.autograd.Function):
         return dx, dw.to(weight.dtype), db
 
 
+#: "vendor" (default) or "mfma".  The hand-written MFMA kernels are correct (tests/test_glue_gpu.py) and
+#: cut ~30 launches per block, but their operand loads (2-byte strided reads of the NCHW activations)
+#: make them slower than the vendor implicit-GEMM path end to end (137 vs 122 ms per step,
+#: profiles/r01_rocprof_bench_v10_mfma_conv_reuse_summary.txt); they stay opt-in until the operands
+#: are staged through LDS (ds_read_b64_tr_b16).
+CONV1X1_IMPL = os.environ.get("VMAMBAIR_CONV1X1", "vendor")
+
+
 def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
-    """A ``nn.Conv2d(Cin, Cout, 1)`` module's parameters through the MFMA kernels when the activations
-    are 16-bit (autocast training / fp16 inference); fp32 activations stay on the vendor conv."""
-    if x.is_cuda and torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
-        x = x.to(torch.get_autocast_dtype("cuda"))
-    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16):
-        return Conv1x1Fn.apply(x, conv.weight, conv.bias)
+    """The 1x1 projections of the block (in_conv / out_conv / project_in / project_out,
+    MambaSISR6_arch.py:205,211,281,329).  Dense GEMMs: vendor conv (MIOpen implicit GEMM on MFMA) by
+    default; ``VMAMBAIR_CONV1X1=mfma`` routes 16-bit activations to the in-tree MFMA kernels."""
+    if CONV1X1_IMPL == "mfma" and x.is_cuda:
+        if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        if x.dtype in (torch.bfloat16, torch.float16):
+            return Conv1x1Fn.apply(x, conv.weight, conv.bias)
     return conv(x)
