@@ -216,26 +216,28 @@ class SS2D_1(nn.Module):
         if not self.omni:
             return self.cforward_core_ref(xc)
         b, d, h, w = xc.shape
-        pooled = xc.mean(dim=(2, 3))                                                    # (b, L = d)
         Rc, N = self.dtc_rank, self.dc_state
-        if self.dc_inner is not None:
-            dc = self.dc_inner
-            seq = torch.addcmul(self.conv_cin.bias.view(1, dc, 1).to(pooled.dtype), pooled.unsqueeze(1),
-                                self.conv_cin.weight.view(1, dc, 1).to(pooled.dtype))   # conv_cin on a 1-channel map
-        else:
-            dc = 1
-            seq = pooled.view(b, 1, d)
-        fp32 = self.dc_inner is None  # RealSR runs this scan in fp32 (MambaRealSR11_arch.py:513-519)
-        z = torch.einsum("kcj,bjl->bkcl", self.xc_proj_weight, seq)                      # (b, 2, Rc+2N, L)
-        dts, Bs, Cs = torch.split(z, [Rc, N, N], dim=2)
-        dts = torch.einsum("bkrl,kjr->bkjl", dts, self.dtc_projs_weight).reshape(b, 2 * dc, d)
-        if fp32:
-            seq, dts, Bs, Cs = seq.float(), dts.float(), Bs.float(), Cs.float()
-        out = OmniScanFn.apply(seq, dts, self.Ac_logs, Bs, Cs, self.Dsc, self.dtc_projs_bias.view(-1)).view(b, 2, dc, d)
-        y = out[:, 0].float() + out[:, 1].float()                                       # direction 1 is stored un-flipped
-        if self.dc_inner is not None:
-            y = torch.matmul(self.conv_cout.weight.view(1, dc), y) + self.conv_cout.bias  # conv_cout: (b, 1, L)
-        y = F.layer_norm(y.reshape(b, d), (d,), self.channel_norm.body.weight, self.channel_norm.body.bias, 1e-5)
+        # (b, 2*dc_inner, <=384) tensors: the whole branch runs in fp32 outside autocast -- the reference
+        # trains in fp32 (its RealSR variant forces fp32 here even under AMP, MambaRealSR11_arch.py:513-519)
+        # and every 16-bit round trip on these tiny tensors is a kernel launch, not a saving
+        with torch.autocast("cuda", enabled=False):
+            pooled = xc.mean(dim=(2, 3), dtype=torch.float32)                          # (b, L = d)
+            if self.dc_inner is not None:
+                dc = self.dc_inner
+                seq = torch.addcmul(self.conv_cin.bias.float().view(1, dc, 1), pooled.unsqueeze(1),
+                                    self.conv_cin.weight.float().view(1, dc, 1))       # conv_cin on a 1-channel map
+            else:
+                dc = 1
+                seq = pooled.view(b, 1, d)
+            z = torch.einsum("kcj,bjl->bkcl", self.xc_proj_weight.float(), seq)          # (b, 2, Rc+2N, L)
+            dts, Bs, Cs = torch.split(z, [Rc, N, N], dim=2)
+            dts = torch.einsum("bkrl,kjr->bkjl", dts, self.dtc_projs_weight.float()).reshape(b, 2 * dc, d)
+            out = OmniScanFn.apply(seq, dts, self.Ac_logs, Bs, Cs, self.Dsc, self.dtc_projs_bias.view(-1)).view(b, 2, dc, d)
+            y = out[:, 0] + out[:, 1]                                                   # direction 1 is stored un-flipped
+            if self.dc_inner is not None:
+                y = torch.matmul(self.conv_cout.weight.float().view(1, dc), y) + self.conv_cout.bias.float()  # (b, 1, L)
+            y = F.layer_norm(y.reshape(b, d), (d,), self.channel_norm.body.weight.float(),
+                             self.channel_norm.body.bias.float(), 1e-5)
         return y.view(b, d, 1, 1).to(xc.dtype)
 
     def cforward_core_ref(self, xc: torch.Tensor) -> torch.Tensor:
@@ -277,7 +279,7 @@ class SS2D_1(nn.Module):
         x = F.silu(dwconv3x3(x, self.conv2d))
         y2 = self.forward_core(x, gate=z)  # out_norm(merge) * silu(z), fused in the LayerNorm kernel
         c = self.cforward_core(y2)
-        y2 = (y2 + c) if self.gate == "add" else (y2 * c + y2)
+        y2 = (y2 + c) if self.gate == "add" else torch.addcmul(y2, y2, c)  # y2 * c + y2
         return conv1x1(y2, self.out_conv)
 
 

@@ -11,6 +11,13 @@ Gradients are never accumulated: ``p.grad`` is cleared (a host-side pointer rese
 the captured backward, so autograd hands every parameter its gradient tensor as-is instead of
 launching one add per parameter tensor (the net has ~1450 of them).
 
+16-bit shadow weights: under autocast every conv / projection weight would be cast fp32 -> bf16 by its
+own kernel in the forward and its gradient cast back by another one in the backward (~40 launches per
+block).  Instead all such parameters get a 16-bit shadow leaf that is refreshed by ONE multi-tensor
+copy per step; the net runs on the shadows (``torch.func.functional_call``) and their gradients are
+converted to the fp32 master gradients by one more multi-tensor copy.  Numerically identical to
+autocast (the same rounding of the same master weights every step).
+
 Multi-GPU: the graph holds forward + backward only; after the replay the gradients are packed into
 ONE flat buffer, all-reduced with a single RCCL call (48.1 MB for MambaSISR6 -- xGMI-link-bound
 ~0.1-0.6 ms) and scattered back, then a second graph applies Adam + EMA.  No DDP hooks
@@ -27,7 +34,7 @@ import torch.distributed as dist
 class GraphedTrainStep:
     def __init__(self, net: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), ema_decay: float = 0.999,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3):
+                 loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -37,6 +44,23 @@ class GraphedTrainStep:
         self.loss_fn = loss_fn
         self.ema_decay = ema_decay
         self.warmup = warmup
+        # 16-bit shadows of the parameters autocast would cast per use (conv weights / biases and the
+        # projection matrices of SS2D_1); norms, A_logs, D, dt biases and the fp32 channel branch stay fp32
+        self.shadow = {}
+        if shadow_weights and autocast_dtype is not None:
+            mods = dict(net.named_modules())
+            for name, p in net.named_parameters():
+                owner, leaf = name.rsplit(".", 1) if "." in name else ("", name)
+                m = mods.get(owner)
+                if ".conv_cin." in name or ".conv_cout." in name:
+                    continue  # consumed in fp32 by the channel branch
+                dense_conv = isinstance(m, torch.nn.Conv2d) and m.groups == 1  # depth-wise convs run on our fp32-weight kernel
+                if dense_conv or leaf in ("x_proj_weight", "dt_projs_weight"):
+                    self.shadow[name] = (p, torch.empty_like(p, dtype=autocast_dtype).requires_grad_())
+        self._masters = [m for m, _ in self.shadow.values()]
+        self._shadows = [s for _, s in self.shadow.values()]
+        self._master_grads = [torch.zeros_like(m) for m in self._masters]
+        self._shadow_map = {n: s for n, (_, s) in self.shadow.items()}
         self.ema = [p.detach().clone() for p in self.params]
         self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, fused=True, capturable=True)
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
@@ -47,10 +71,23 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         for p in self.params:  # host-side only: the backward then assigns instead of accumulating
             p.grad = None
+        for s_ in self._shadows:
+            s_.grad = None
+        if self._shadows:
+            with torch.no_grad():
+                torch._foreach_copy_(self._shadows, self._masters)  # fp32 -> 16-bit, one multi-tensor kernel
         with torch.autocast("cuda", dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
-            out = self.net(self.static_lq)
+            if self._shadows:
+                out = torch.func.functional_call(self.net, self._shadow_map, (self.static_lq,))
+            else:
+                out = self.net(self.static_lq)
         loss = self.loss_fn(out.float(), self.static_gt)
         loss.backward()
+        if self._shadows:
+            with torch.no_grad():
+                torch._foreach_copy_(self._master_grads, [s_.grad for s_ in self._shadows])
+            for m, g in zip(self._masters, self._master_grads):
+                m.grad = g
         return loss.detach()
 
     def _opt_ema(self):
