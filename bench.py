@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VMAMBAIR_BENCH_GRAPH", "1")),
                     help="1: replay the training step as one hipGraph (single GPU, or manual flat-gradient "
                          "all-reduce outside the graph for N > 1)")
+    ap.add_argument("--skip-roofline", action="store_true",
+                    help="graph mode: do not run the trailing eager steps that time the scan kernels (profiling runs)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -199,7 +201,9 @@ def main():
     log(f"timed {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.item())
     prof_note = "HIP events around every scan kernel launch inside the timed region"
-    if args.graph:
+    if args.graph and args.skip_roofline:
+        prof_steps = 1
+    elif args.graph:
         # kernels inside a replayed graph cannot be bracketed by host-recorded events: time the very
         # same kernels on the same tensors with eager steps right after the timed region
         ema2 = [p.detach().clone() for p in net.parameters()]
