@@ -91,8 +91,9 @@ typedef struct {
     const void *dout;       /* (batch, dim, seqlen) io dtype                                   */
     void *du, *ddelta;      /* (batch, dim, seqlen) io dtype                                   */
     float *dA;              /* (dim, dstate) contiguous, overwritten                           */
-    void *dB, *dC;          /* (batch, n_groups, dstate, seqlen) CONTIGUOUS, io dtype,
-                               overwritten (the cast of selective_scan.cpp:347 is fused)        */
+    void *dB, *dC;          /* (batch, n_groups, dstate, seqlen) io dtype, overwritten (the cast of
+                               selective_scan.cpp:347 is fused); contiguous unless
+                               dBC_group_stride is set                                          */
     float *dD;              /* (dim) or NULL, overwritten                                      */
     float *ddelta_bias;     /* (dim) or NULL, overwritten                                      */
     void *workspace;        /* oss_scan_bwd_workspace_bytes() bytes of scratch, no init needed */
@@ -100,6 +101,9 @@ typedef struct {
     int dout_row_mod;       /* > 0: row d reads dout[:, d % dout_row_mod, :] (the merge hands the same
                                gradient to directions k and k + 2); 0 = off                        */
     int reserved_;
+    int64_t dBC_group_stride; /* element stride between (batch, group) blocks of dB and of dC; the batch
+                                 stride is n_groups times it.  0 = dstate * seqlen (contiguous).  Lets
+                                 the caller have dB / dC written into the rows of a wider buffer.  */
 } oss_scan_bwd_params;
 
 /* Time steps between two saved states in `x` (the reference's is 2048,
@@ -151,6 +155,34 @@ int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweigh
                       int cin, int pixels, int64_t dy_batch_stride, int64_t dy_channel_stride, int64_t x_batch_stride,
                       int64_t x_channel_stride, oss_stream_t stream);
 
+/* The two in-block projections of the spatial branch (MambaSISR6_arch.py:406-411), omni form, and the
+ * flattenings around them.  Layouts (all contiguous, io dtype): x2 (batch, 2, D, L) = the row-major
+ * and column-major flattenings of the (batch, D, H, W) activations (k = 0, 1;
+ * directions 2, 3 are the same rows walked backwards by the scan); xdbl (batch, 4, C, L) with
+ * C = R + 2 dstate rows per direction: R dt rows, then B, then C of the scan; dts (batch, 4, D, L).
+ * Weights are float: x_proj_weight (4, C, D), dt_projs_weight (4, D, R).
+ *   oss_cross_scan2 : x (batch, D, H, W) of in_type (contiguous planes, element strides batch / channel)
+ *                     -> x2 of out_type        (replaces the stack / transpose / flip of :395-404)
+ *   oss_cross_merge2: dx (batch, D, H, W) = g2[:, 0] + transpose(g2[:, 1])   (its adjoint)
+ *   oss_proj_fwd    : xdbl[b,k,c,:] = sum_d x_proj_weight[k,c,d] x2[b,k%2,d,:], rounded to io;
+ *                     dts[b,k,d,:]  = sum_r dt_projs_weight[k,d,r] xdbl[b,k,r,:]
+ *   oss_proj_dgrad  : dxdbl holds dB / dC of the scan backward in its rows c >= R on entry; the dt rows
+ *                     are filled with dt_projs_weight^T ddts, then
+ *                     dx2[b,j] = sum_{k in {j,j+2}} (x_proj_weight[k]^T dxdbl[b,k] + du[b,k]) (du may be NULL)
+ *   oss_proj_wgrad  : both weight gradients (float, overwritten) as split-K MFMA products; io =
+ *                     OSS_BF16 / OSS_F16 only (OSS_ERR_SHAPE for float: callers use a vendor GEMM);
+ *                     partials = oss_proj_wgrad_partial_floats() floats of scratch. */
+int oss_cross_scan2(oss_dtype in_type, oss_dtype out_type, const void *x, void *x2, int batch, int D, int height, int width,
+                    int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
+int oss_cross_merge2(oss_dtype io, const void *g2, void *dx, int batch, int D, int height, int width, oss_stream_t stream);
+int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const float *dt_projs_weight, void *xdbl, void *dts,
+                 int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
+int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *x_proj_weight,
+                   const float *dt_projs_weight, void *dx2, int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
+size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen);
+int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
+                   float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
+
 /* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
  * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3
  * column-major) -> y (batch, D, H, W) float = ((o0 + o2) + T o1) + T o3, the reference's association
@@ -164,7 +196,9 @@ int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int he
  * gate of y_type with its own (batch, channel) strides; weight / bias / dweight / dbias float (C).
  * gate != NULL fuses y = LN(x) * silu(gate)
  * (SS2D_1: y1 * act(z), :488-493).  mean / rstd: (batch, pixels) float, written by fwd, read by bwd.
- * bwd: partials = ceil(pixels / 256) * batch * 2 * C floats of scratch. */
+ * bwd: partials = oss_ln_nchw_bwd_partial_floats(batch, channels, pixels) floats of scratch
+ * (per-workgroup dweight / dbias sums, combined in a fixed order by a finishing kernel). */
+size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels);
 int oss_ln_nchw_fwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
                     const void *gate, void *y, float *mean, float *rstd, int batch, int channels, int pixels,
                     int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,

@@ -114,7 +114,50 @@ def install():
         dg = gr.pop(0).to(dy.dtype) if gg is not None else torch.empty(0)
         return [dx.to(x.dtype), dg, dw, db]
 
+    def _core_ref(x, wx, wdt, A_logs, Ds, dt_bias):
+        """literal reference data flow of SS2D_1.forward_core up to out_norm (MambaSISR6_arch.py:395-431) on
+        the oracle scan, differentiable: four materialised directions, flips and transposes"""
+        B, D, H, W = x.shape
+        L = H * W
+        R, N = wdt.shape[2], A_logs.shape[1]
+        hw = x.flatten(2, 3)
+        wh = x.transpose(2, 3).contiguous().flatten(2, 3)
+        fwd2 = torch.stack([hw, wh], dim=1)
+        xs = torch.cat([fwd2, fwd2.flip(-1)], dim=1)
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, wx)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, wdt)
+        out = oss_oracle.OracleScanFn.apply(xs.reshape(B, -1, L), dts.reshape(B, -1, L), -torch.exp(A_logs), Bs.contiguous(),
+                                            Cs.contiguous(), Ds, dt_bias.reshape(-1), True).view(B, 4, -1, L)
+        inv = out[:, 2:4].flip(-1)
+        wh_y = out[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        invwh_y = inv[:, 1].reshape(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        return (out[:, 0] + inv[:, 0] + wh_y + invwh_y).view(B, D, H, W)
+
+    def core_fwd(x, wx, wdt, A_logs, Ds, dt_bias):
+        B, D, H, W = x.shape
+        R = wdt.shape[2]
+        xf = x.float()
+        with torch.no_grad():
+            y = _core_ref(xf, wx.float(), wdt.float(), A_logs.float(), Ds.float(), dt_bias.float())
+            x2 = torch.stack([xf.flatten(2, 3), xf.transpose(2, 3).contiguous().flatten(2, 3)], dim=1)
+            xdbl = torch.cat([torch.einsum("bjdl,jcd->bjcl", x2, wx[0:2].float()),
+                              torch.einsum("bjdl,jcd->bjcl", x2, wx[2:4].float())], dim=1)
+            dts = torch.einsum("bkrl,kdr->bkdl", xdbl[:, :, :R], wdt.float()).reshape(B, 4 * D, H * W)
+        return [y, x2.to(x.dtype), xdbl.to(x.dtype), dts.to(x.dtype), torch.empty(0)]
+
+    def core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias):
+        B, _, D, L = x2.shape
+        H, W = dy.shape[2], dy.shape[3]
+        leaves = [t.detach().float().requires_grad_() for t in (x2[:, 0].reshape(B, D, H, W), wx, wdt, A_logs, Ds, dt_bias)]
+        with torch.enable_grad():
+            y = _core_ref(*leaves)
+        gr = torch.autograd.grad(y, leaves, dy.float())
+        return [gr[0].to(x2.dtype), gr[1], gr[2], gr[3], gr[4], gr[5]]
+
     _CPU_LIB = torch.library.Library("vmambair", "IMPL")
+    _CPU_LIB.impl("ss2d_core_fwd", core_fwd, "CPU")
+    _CPU_LIB.impl("ss2d_core_bwd", core_bwd, "CPU")
     _CPU_LIB.impl("ln_nchw_fwd", ln_fwd, "CPU")
     _CPU_LIB.impl("ln_nchw_bwd", ln_bwd, "CPU")
     _CPU_LIB.impl("omni_scan_fwd", omni_fwd, "CPU")

@@ -25,7 +25,8 @@ def ln_ref(x, w, b, gate):
     return y if gate is None else y * F.silu(gate.float())
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 16, 24), (1, 96, 64, 64), (3, 384, 8, 8), (2, 7, 5, 3), (4, 48, 1, 1)])
+@pytest.mark.parametrize("shape", [(2, 48, 16, 24), (1, 96, 64, 64), (3, 384, 8, 8), (2, 7, 5, 3), (4, 48, 1, 1),
+                                   (2, 768, 8, 8), (1, 400, 3, 5), (2, 192, 9, 11)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)],
                          ids=["f32-f32", "f32-bf16", "bf16-bf16"])
 @pytest.mark.parametrize("with_bias", [True, False])

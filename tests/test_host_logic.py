@@ -163,6 +163,7 @@ def test_omni_direction_maps_bit_exact(monkeypatch):
 
     monkeypatch.setattr(oss_block, "OmniScanFn", FakeOmni)
     m.fused_merge = False  # look at the scan's inputs and the merge separately
+    m.fused_core = False
     y = m.forward_core(z["x"])
     assert torch.equal(seen["xs"], z["xs"])
     assert torch.equal(y, z["y"])

@@ -46,14 +46,16 @@ class ScanBwdParams(C.Structure):
         ("dB", C.c_void_p), ("dC", C.c_void_p), ("dD", C.c_void_p), ("ddelta_bias", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dout_row_mod", C.c_int), ("reserved_", C.c_int),
+        ("dBC_group_stride", C.c_int64),
     ]
 
 
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_set_variant", "oss_scan_last_variant", "oss_prof_enable", "oss_prof_reset",
-           "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
-           "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_hbm_copy", "oss_version"]
+           "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
+           "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
+           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_hbm_copy", "oss_version"]
 
 _lib = None
 
@@ -101,6 +103,8 @@ def load():
         [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_ln_nchw_fwd.restype = C.c_int
     lib.oss_ln_nchw_fwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
+    lib.oss_ln_nchw_bwd_partial_floats.restype = C.c_size_t
+    lib.oss_ln_nchw_bwd_partial_floats.argtypes = [C.c_int] * 3
     lib.oss_ln_nchw_bwd.restype = C.c_int
     lib.oss_ln_nchw_bwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 12 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_merge4.restype = C.c_int
@@ -113,6 +117,18 @@ def load():
     lib.oss_conv1x1_wgrad_partial_floats.argtypes = [C.c_int] * 4
     lib.oss_conv1x1_wgrad.restype = C.c_int
     lib.oss_conv1x1_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_void_p]
+    lib.oss_cross_scan2.restype = C.c_int
+    lib.oss_cross_scan2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 2 + [C.c_void_p]
+    lib.oss_cross_merge2.restype = C.c_int
+    lib.oss_cross_merge2.argtypes = [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    lib.oss_proj_fwd.restype = C.c_int
+    lib.oss_proj_fwd.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]
+    lib.oss_proj_dgrad.restype = C.c_int
+    lib.oss_proj_dgrad.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]
+    lib.oss_proj_wgrad_partial_floats.restype = C.c_size_t
+    lib.oss_proj_wgrad_partial_floats.argtypes = [C.c_int] * 5
+    lib.oss_proj_wgrad.restype = C.c_int
+    lib.oss_proj_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_version.restype = C.c_char_p

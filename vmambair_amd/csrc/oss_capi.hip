@@ -208,6 +208,58 @@ int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweigh
                          reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen) {
+    if (batch <= 0 || D <= 0 || C <= 0 || R <= 0 || seqlen <= 0) return 0;
+    // the two weight gradients run one after the other on the same scratch
+    const size_t slabs = (size_t)batch * conv1x1_wgrad_slabs(seqlen);
+    const size_t a = slabs * 2 * (2 * (size_t)C) * D, b = slabs * 4 * (size_t)D * R;
+    return a > b ? a : b;
+}
+
+int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const float *dt_projs_weight, void *xdbl, void *dts,
+                 int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
+    if (!x2 || !x_proj_weight || !dt_projs_weight || !xdbl || !dts) return OSS_ERR_NULL;
+    if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
+    return proj_fwd(io, x2, x_proj_weight, dt_projs_weight, xdbl, dts, batch, D, C, R, seqlen, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *x_proj_weight,
+                   const float *dt_projs_weight, void *dx2, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
+    if (!ddts || !dxdbl || !x_proj_weight || !dt_projs_weight || !dx2) return OSS_ERR_NULL;
+    if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
+    return proj_dgrad(io, ddts, dxdbl, du, x_proj_weight, dt_projs_weight, dx2, batch, D, C, R, seqlen,
+                      reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
+                   float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
+    if (!x2 || !xdbl || !dxdbl || !ddts || !dx_proj_weight || !ddt_projs_weight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t L = seqlen;
+    // x_proj_weight: one problem per flattening j; its 2C rows are the rows of directions j and j + 2 of dxdbl
+    int e = conv1x1_wgrad(io, dxdbl, x2, dx_proj_weight, partials, batch, 2 * C, D, seqlen, 4 * C * L, L, 2 * D * L, L, s,
+                          /*G*/ 2, /*gsg*/ C * L, /*xsg*/ D * L, /*Mh*/ C, /*gs_hi*/ 2 * C * L);
+    if (e) return e;
+    // dt_projs_weight: one problem per direction k: ddts[:, k] (D rows) x the dt rows of xdbl[:, k] (R rows)
+    return conv1x1_wgrad(io, ddts, xdbl, ddt_projs_weight, partials, batch, D, R, seqlen, 4 * D * L, L, 4 * C * L, L, s,
+                         /*G*/ 4, /*gsg*/ D * L, /*xsg*/ C * L, /*Mh*/ D, 0);
+}
+
+int oss_cross_scan2(oss_dtype in_type, oss_dtype out_type, const void *x, void *x2, int batch, int D, int height, int width,
+                    int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream) {
+    if (!x || !x2) return OSS_ERR_NULL;
+    if (batch <= 0 || D <= 0 || height <= 0 || width <= 0) return OSS_ERR_SHAPE;
+    return cross_scan2(in_type, out_type, x, x2, batch, D, height, width, x_batch_stride, x_channel_stride,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_cross_merge2(oss_dtype io, const void *g2, void *dx, int batch, int D, int height, int width, oss_stream_t stream) {
+    if (!g2 || !dx) return OSS_ERR_NULL;
+    if (batch <= 0 || D <= 0 || height <= 0 || width <= 0) return OSS_ERR_SHAPE;
+    return cross_merge2(io, g2, dx, batch, D, height, width, reinterpret_cast<hipStream_t>(stream));
+}
+
 int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
     if (!out || !y) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;
@@ -232,6 +284,11 @@ int oss_ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weig
     if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
     return ln_nchw_bwd(xt, yt, x, weight, bias, gate, dy, mean, rstd, dx, dgate, dweight, dbias, partials, batch, channels,
                        pixels, xsb, xsc, gsb, gsc, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels) {
+    if (batch <= 0 || channels <= 0 || pixels <= 0) return 0;
+    return ln_nchw_bwd_partial_floats(batch, channels, pixels);
 }
 
 void oss_prof_enable(int on) { g_prof_on.store(on ? 1 : 0); }

@@ -183,29 +183,34 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
     }
 }
 
-// partial[slab][m][n] = sum over the slab's pixels of dy[b, m, p] x[b, n, p];  slabs = B * ceil(P / SLAB)
+// partial[slab][g][m][n] = sum over the slab's pixels of dy_g[b, m, p] x_g[b, n, p];  slabs = B * ceil(P / SLAB).
+// G independent problems per launch (group g: dy + g gsg, x + g xsg); row m of dy sits at
+// (m / Mh) gs_hi + (m % Mh) gsm, so that one problem can take its rows from two places (the two scan
+// directions that share a flattening, oss_proj.hip).
 constexpr int kWgradSlab = 512;
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
-                         int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn) {
+                         int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
+                         int64_t gs_hi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y, slab = blockIdx.x;
+    const int b = blockIdx.y / G, g = blockIdx.y - b * G, slab = blockIdx.x;
     const int pbeg = slab * kWgradSlab, pend = min(P, pbeg + kWgradSlab);
     const int col = lane & 31, kg = lane >> 5;
     const int mt = (M + 31) >> 5, nt = (N + 31) >> 5;
-    const T *gb = dy + b * gsb;
-    const T *xb = x + b * xsb;
-    float *pb = part + ((size_t)(b * gridDim.x + slab)) * M * N;
+    const T *gb = dy + b * gsb + g * gsg;
+    const T *xb = x + b * xsb + g * xsg;
+    float *pb = part + ((size_t)(b * gridDim.x + slab) * G + g) * M * N;
     const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
-                         (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0);
+                         (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0) && (gs_hi % 8 == 0);
     {
         const int tile = blockIdx.z * 4 + wave;  // one 32 x 32 tile of dW per wave
         if (tile >= mt * nt) return;
         const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
         const int mrow = m0 + col, nrow = n0 + col;
         const bool mok = mrow < M, nok = nrow < N;
-        const T *ga = gb + (mok ? mrow : 0) * gsm;
+        const int mr = mok ? mrow : 0;
+        const T *ga = gb + (mr / Mh) * gs_hi + (mr % Mh) * gsm;
         const T *xa = xb + (nok ? nrow : 0) * xsn;
         f32x16 acc;
 #pragma unroll
@@ -240,14 +245,16 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
     }
 }
 
-// dW[m][n] = sum over slabs (fixed order)
+// dW[g][m][n] = sum over slabs (fixed order); output row of (g, m) = ((m / Mh) G + g) Mh + m % Mh
 __global__ void __launch_bounds__(256)
-oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, int nslab, size_t mn) {
+oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, int nslab, size_t mn, int G, int N, int Mh) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
     if (i >= mn) return;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += part[(size_t)k * mn + i];
-    dw[i] = s;
+    for (int k = 0; k < nslab; ++k) s += part[((size_t)k * G + g) * mn + i];
+    const size_t m = i / N, n = i - m * N;
+    dw[(((m / Mh) * G + g) * Mh + m % Mh) * N + n] = s;
 }
 
 template <typename T>
@@ -299,23 +306,27 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
 int conv1x1_wgrad_slabs(int P) { return (P + kWgradSlab - 1) / kWgradSlab; }
 
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
-                  int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s) {
+                  int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G, int64_t gsg, int64_t xsg, int Mh,
+                  int64_t gs_hi) {
+    if (G < 1 || (size_t)B * G > 65535) return OSS_ERR_SHAPE;
+    if (Mh <= 0 || Mh > M) Mh = M;
     const int slabs = conv1x1_wgrad_slabs(P);
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-    dim3 grid(slabs, B, (tiles + 3) / 4);
+    dim3 grid(slabs, B * G, (tiles + 3) / 4);
     switch (io) {
         case OSS_BF16:
             hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(dy),
-                               reinterpret_cast<const bf16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn);
+                               reinterpret_cast<const bf16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi);
             break;
         case OSS_F16:
             hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(dy),
-                               reinterpret_cast<const f16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn);
+                               reinterpret_cast<const f16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi);
             break;
         default: return OSS_ERR_SHAPE;
     }
     const size_t mn = (size_t)M * N;
-    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, part, dw, slabs * B, mn);
+    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 255) / 256), G), dim3(256), 0, s, part, dw, slabs * B, mn,
+                       G, N, Mh);
     return (int)hipGetLastError();
 }
 

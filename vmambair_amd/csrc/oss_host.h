@@ -27,6 +27,7 @@ int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, floa
 int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate, void *y,
                 float *mean, float *rstd, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
                 hipStream_t s);
+size_t ln_nchw_bwd_partial_floats(int B, int C, int P);
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
                 float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
@@ -35,6 +36,14 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s);
 int conv1x1_wgrad_slabs(int P);
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
-                  int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s);
+                  int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G = 1, int64_t gsg = 0, int64_t xsg = 0,
+                  int Mh = 0, int64_t gs_hi = 0);
+int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
+             int L, hipStream_t s);
+int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,
+               int D, int C, int R, int L, hipStream_t s);
+int cross_scan2(oss_dtype it, oss_dtype ot, const void *x, void *x2, int B, int D, int H, int W, int64_t xsb, int64_t xsc,
+                hipStream_t s);
+int cross_merge2(oss_dtype io, const void *g2, void *dx, int B, int D, int H, int W, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

@@ -320,7 +320,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*L */, size_t total /* batch*G*N*L */,
                     unsigned nblk_bc, const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA, float *dD,
-                    float *db, int batch, int dim, int N, const float *A_log, int64_t A_d_stride) {
+                    float *db, int batch, int dim, int N, const float *A_log, int64_t A_d_stride, size_t out_group_stride) {
     if (blockIdx.x >= nblk_bc) {
         finish_w((int)((blockIdx.x - nblk_bc) * 256 + threadIdx.x), ws_dA, ws_dD, ws_db, dA, dD, db, batch, dim, N, A_log,
                  A_d_stride);
@@ -335,8 +335,8 @@ oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*
         sb += base[(size_t)t * 2 * nl];
         sc += base[(size_t)t * 2 * nl + nl];
     }
-    dB[i] = from_f32<T>(sb);
-    dC[i] = from_f32<T>(sc);
+    dB[bg * out_group_stride + r] = from_f32<T>(sb);
+    dC[bg * out_group_stride + r] = from_f32<T>(sc);
 }
 
 template <typename T, int LPR, int I, int WAVES, int NBB>
@@ -381,7 +381,8 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + 255) / 256);
     hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(nblk_bc + nblk_w), dim3(256), 0, stream, ws.bc,
                        reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), tiles, nl, total, nblk_bc, ws.dA, wdD, wdb,
-                       p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr, f.A_d_stride);
+                       p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr, f.A_d_stride,
+                       p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : nl);
     return (int)hipGetLastError();
 }
 

@@ -125,7 +125,8 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], dout: torch.Tensor,
                        x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1,
                        rev_group_start: Optional[int] = None, u_row_mod: int = 0,
-                       dout_row_mod: int = 0, a_log_form: bool = False) -> List[Optional[torch.Tensor]]:
+                       dout_row_mod: int = 0, a_log_form: bool = False,
+                       dbc_into: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``."""
@@ -144,8 +145,16 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     du = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
     ddelta = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
     dA = torch.empty((dim, dstate), dtype=torch.float32, device=u.device)
-    dB = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
-    dC = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
+    if dbc_into is not None:
+        # (batch, n_groups, R + 2 dstate, seqlen): dB / dC land in its last 2 dstate rows (oss_proj_dgrad fills the rest)
+        rows = dbc_into.shape[2]
+        _check(dbc_into.is_contiguous() and dbc_into.dtype == u.dtype and
+               tuple(dbc_into.shape) == (batch, n_groups, rows, seqlen) and rows > 2 * dstate, "dbc_into has the wrong layout")
+        dB = dbc_into[:, :, rows - 2 * dstate:rows - dstate]
+        dC = dbc_into[:, :, rows - dstate:]
+    else:
+        dB = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
+        dC = torch.empty((batch, n_groups, dstate, seqlen), dtype=u.dtype, device=u.device)
     dD = torch.empty((dim,), dtype=torch.float32, device=u.device) if D is not None else None
     dbias = torch.empty((dim,), dtype=torch.float32, device=u.device) if delta_bias is not None else None
     if batch == 0 or seqlen == 0:
@@ -164,6 +173,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     P.dB, P.dC, P.dD, P.ddelta_bias = dB.data_ptr(), dC.data_ptr(), _ptr(dD), _ptr(dbias)
     P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     P.dout_row_mod = int(dout_row_mod)
+    P.dBC_group_stride = 0 if dbc_into is None else dbc_into.stride(1)
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
@@ -227,6 +237,177 @@ def merge4(out: torch.Tensor, H: int, W: int) -> torch.Tensor:
         _capi.check(lib.oss_merge4(_DT[out.dtype], out.data_ptr(), y.data_ptr(), B, D, H, W,
                                    torch.cuda.current_stream().cuda_stream), "oss_merge4")
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# spatial branch of SS2D_1 as ONE op pair: flattenings + projections + omni scan + cross-merge
+# ---------------------------------------------------------------------------------------------
+def core_supported(D: int, R: int, N: int) -> bool:
+    """shapes the projection kernels cover (oss_proj.hip: <= 32 rows per wave, dt rank <= 32, <= 64-row slices);
+    every reference config is inside (D = 2 * 48 * 2^level, R = D / 32, N = 16)."""
+    nw = 4 if D <= 192 else (8 if D <= 384 else 16)
+    return R <= 32 and (2 * (R + 2 * N) + nw - 1) // nw <= 32 and (((D + nw - 1) // nw + 7) & ~7) <= 64
+
+
+def _dims_core(x, x_proj_weight, dt_projs_weight, A_logs):
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "ss2d_core: x must be a (B, D, H, W) GPU tensor")
+    B, D, H, W = x.shape
+    K, Cc, D2 = x_proj_weight.shape
+    R = dt_projs_weight.shape[2]
+    N = A_logs.shape[1]
+    _check(K == 4 and D2 == D and tuple(dt_projs_weight.shape) == (4, D, R) and Cc == R + 2 * N and
+           tuple(A_logs.shape) == (4 * D, N), "ss2d_core: parameter shapes do not match SS2D_1's")
+    return B, D, H, W, Cc, R, N
+
+
+def cross_scan2(x: torch.Tensor, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """(B, D, H, W) -> (B, 2, D, H*W): row-major and column-major flattenings (directions 0 / 1; 2 / 3 are the
+    same rows walked backwards by the scan).  fp32 input may be narrowed to ``out_dtype`` on the way."""
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "cross_scan2: x must be a (B, D, H, W) GPU tensor")
+    out_dtype = out_dtype or x.dtype
+    _check(out_dtype == x.dtype or x.dtype == torch.float32, "cross_scan2: only fp32 input can change dtype")
+    B, D, H, W = x.shape
+    x = _planes(x)
+    x2 = torch.empty((B, 2, D, H * W), dtype=out_dtype, device=x.device)
+    if x.numel():
+        with torch.cuda.device(x.device):
+            _capi.check(_capi.load().oss_cross_scan2(_DT[x.dtype], _DT[out_dtype], x.data_ptr(), x2.data_ptr(), B, D, H, W,
+                                                     x.stride(0), x.stride(1), torch.cuda.current_stream().cuda_stream),
+                        "oss_cross_scan2")
+    return x2
+
+
+def cross_merge2(g2: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """adjoint of ``cross_scan2``: (B, 2, D, H*W) -> (B, D, H, W) = g2[:, 0] + transpose(g2[:, 1])"""
+    _check(g2.is_cuda and g2.dim() == 4 and g2.shape[1] == 2 and g2.shape[3] == H * W and g2.dtype in _DT,
+           "cross_merge2: g2 must be a (B, 2, D, H*W) GPU tensor")
+    g2 = g2.contiguous()
+    B, _, D, _ = g2.shape
+    dx = torch.empty((B, D, H, W), dtype=g2.dtype, device=g2.device)
+    if g2.numel():
+        with torch.cuda.device(g2.device):
+            _capi.check(_capi.load().oss_cross_merge2(_DT[g2.dtype], g2.data_ptr(), dx.data_ptr(), B, D, H, W,
+                                                      torch.cuda.current_stream().cuda_stream), "oss_cross_merge2")
+    return dx
+
+
+def _proj_weights(x_proj_weight, dt_projs_weight):
+    return x_proj_weight.detach().float().contiguous(), dt_projs_weight.detach().float().contiguous()
+
+
+def proj_fwd(x2: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor) -> List[torch.Tensor]:
+    """x2 (B, 2, D, L) -> [xdbl (B, 4, R + 2N, L), dts (B, 4 D, L)] (MambaSISR6_arch.py:406-411, omni form)"""
+    B, _, D, L = x2.shape
+    Cc, R = x_proj_weight.shape[1], dt_projs_weight.shape[2]
+    wx, wdt = _proj_weights(x_proj_weight, dt_projs_weight)
+    x2 = x2.contiguous()
+    xdbl = torch.empty((B, 4, Cc, L), dtype=x2.dtype, device=x2.device)
+    dts = torch.empty((B, 4 * D, L), dtype=x2.dtype, device=x2.device)
+    if x2.numel():
+        with torch.cuda.device(x2.device):
+            _capi.check(_capi.load().oss_proj_fwd(_DT[x2.dtype], x2.data_ptr(), wx.data_ptr(), wdt.data_ptr(), xdbl.data_ptr(),
+                                                  dts.data_ptr(), B, D, Cc, R, L, torch.cuda.current_stream().cuda_stream),
+                        "oss_proj_fwd")
+    return [xdbl, dts]
+
+
+def proj_dgrad(ddts: torch.Tensor, dxdbl: torch.Tensor, du: Optional[torch.Tensor], x_proj_weight: torch.Tensor,
+               dt_projs_weight: torch.Tensor) -> torch.Tensor:
+    """fills the dt rows of ``dxdbl`` (B, 4, C, L) in place (its B / C rows hold dB / dC on entry) and returns
+    dx2 (B, 2, D, L) = x_proj^T dxdbl (+ du) summed over the two directions of each flattening."""
+    B, _, Cc, L = dxdbl.shape
+    D, R = dt_projs_weight.shape[1], dt_projs_weight.shape[2]
+    wx, wdt = _proj_weights(x_proj_weight, dt_projs_weight)
+    _check(dxdbl.is_contiguous() and ddts.is_contiguous() and (du is None or du.is_contiguous()), "proj_dgrad: contiguous inputs")
+    dx2 = torch.empty((B, 2, D, L), dtype=dxdbl.dtype, device=dxdbl.device)
+    if dx2.numel():
+        with torch.cuda.device(dxdbl.device):
+            _capi.check(_capi.load().oss_proj_dgrad(_DT[dxdbl.dtype], ddts.data_ptr(), dxdbl.data_ptr(), _ptr(du), wx.data_ptr(),
+                                                    wdt.data_ptr(), dx2.data_ptr(), B, D, Cc, R, L,
+                                                    torch.cuda.current_stream().cuda_stream), "oss_proj_dgrad")
+    return dx2
+
+
+def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: torch.Tensor, R: int) -> List[torch.Tensor]:
+    """-> [dx_proj_weight (4, C, D), ddt_projs_weight (4, D, R)] fp32"""
+    B, _, D, L = x2.shape
+    Cc = xdbl.shape[2]
+    dev = x2.device
+    if x2.dtype == torch.float32:
+        # fp32 I/O: the two weight gradients are plain library GEMMs (the MFMA split-K kernels are 16-bit)
+        dz = dxdbl.view(B, 2, 2, Cc, L)   # [b, kk, j]: direction k = j + 2 kk
+        dwx = torch.einsum("bhjcl,bjdl->hjcd", dz, x2).reshape(4, Cc, D)
+        dwdt = torch.einsum("bkdl,bkrl->kdr", ddts.view(B, 4, D, L), xdbl[:, :, :R])
+        return [dwx, dwdt]
+    lib = _capi.load()
+    dwx = torch.empty((4, Cc, D), dtype=torch.float32, device=dev)
+    dwdt = torch.empty((4, D, R), dtype=torch.float32, device=dev)
+    part = torch.empty((max(1, lib.oss_proj_wgrad_partial_floats(B, D, Cc, R, L)),), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), ddts.data_ptr(),
+                                       dwx.data_ptr(), dwdt.data_ptr(), part.data_ptr(), B, D, Cc, R, L,
+                                       torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
+    return [dwx, dwdt]
+
+
+def ss2d_core_fwd(x: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor, A_logs: torch.Tensor,
+                  Ds: torch.Tensor, dt_bias: torch.Tensor) -> List[torch.Tensor]:
+    """``SS2D_1.forward_core`` up to (not including) ``out_norm`` (MambaSISR6_arch.py:395-431), omni form ->
+    ``[y (B, D, H, W) fp32, x2, xdbl, dts, states]`` (the last four are what the backward needs)."""
+    B, D, H, W, Cc, R, N = _dims_core(x, x_proj_weight, dt_projs_weight, A_logs)
+    L = H * W
+    if x.numel() == 0:
+        e = x.new_empty
+        return [e((B, D, H, W), dtype=torch.float32), e((B, 2, D, L)), e((B, 4, Cc, L)), e((B, 4 * D, L)), e(0, dtype=torch.float32)]
+    x2 = cross_scan2(x)
+    xdbl, dts = proj_fwd(x2, x_proj_weight, dt_projs_weight)
+    out, states = selective_scan_fwd(x2.view(B, 2 * D, L), dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:],
+                                     Ds.detach().float(), dt_bias.detach().float().reshape(-1), True, 1, 2, 2 * D, True)
+    y = merge4(out.view(B, 4, D, L), H, W)
+    return [y, x2, xdbl, dts, states]
+
+
+def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: torch.Tensor, states: torch.Tensor,
+                  x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor, A_logs: torch.Tensor, Ds: torch.Tensor,
+                  dt_bias: torch.Tensor) -> List[torch.Tensor]:
+    """-> [dx (B, D, H, W) io dtype, dx_proj_weight, ddt_projs_weight, dA_logs, dDs, ddt_bias] (fp32)"""
+    B, _, D, L = x2.shape
+    H, W = dy.shape[2], dy.shape[3]
+    Cc, R, N = xdbl.shape[2], dt_projs_weight.shape[2], A_logs.shape[1]
+    # the merge hands the same gradient to directions k and k + 2: two flattenings of dy, read with dout_row_mod
+    g2 = cross_scan2(dy, x2.dtype)
+    dxdbl = torch.empty((B, 4, Cc, L), dtype=x2.dtype, device=x2.device)
+    du, ddts, dA, _, _, dD, dbias = selective_scan_bwd(
+        x2.view(B, 2 * D, L), dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:], Ds.detach().float(),
+        dt_bias.detach().float().reshape(-1), g2.view(B, 2 * D, L), states, True, 1, 2, 2 * D, 2 * D, True, dbc_into=dxdbl)
+    dx2 = proj_dgrad(ddts, dxdbl, du, x_proj_weight, dt_projs_weight)
+    dx = cross_merge2(dx2, H, W)
+    dwx, dwdt = proj_wgrad(x2, xdbl, dxdbl, ddts, R)
+    return [dx, dwx, dwdt, dA, dD, dbias.view(4, D)]
+
+
+_LIB.define("ss2d_core_fwd(Tensor x, Tensor x_proj_weight, Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias) -> Tensor[]")
+_LIB.define("ss2d_core_bwd(Tensor dy, Tensor x2, Tensor xdbl, Tensor dts, Tensor states, Tensor x_proj_weight, "
+            "Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias) -> Tensor[]")
+_LIB.impl("ss2d_core_fwd", ss2d_core_fwd, "CUDA")
+_LIB.impl("ss2d_core_bwd", ss2d_core_bwd, "CUDA")
+
+
+class SS2DCoreFn(torch.autograd.Function):
+    """Spatial branch of SS2D_1 (flatten x2 -> x_proj -> dt_proj -> four-direction scan -> cross-merge) as one
+    autograd node on the HIP kernels: 5 launches forward, 10 backward."""
+
+    @staticmethod
+    def forward(ctx, x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias):
+        y, x2, xdbl, dts, states = torch.ops.vmambair.ss2d_core_fwd(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias)
+        ctx.save_for_backward(x2, xdbl, dts, states, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias = ctx.saved_tensors
+        dx, dwx, dwdt, dA, dD, dbias = torch.ops.vmambair.ss2d_core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias)
+        return (dx, dwx.to(wx.dtype), dwdt.to(wdt.dtype), dA.to(A_logs.dtype), dD.to(Ds.dtype), dbias.to(dt_bias.dtype))
 
 
 _LIB.impl("omni_scan_fwd", _omni_fwd_op, "CUDA")
@@ -370,9 +551,8 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device) if gate is not None else None
     dw = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if bias is not None else None
-    nblk = ((P + 255) // 256) * B
-    part = torch.empty((nblk, 2, Cc), dtype=torch.float32, device=x.device)
     lib = _capi.load()
+    part = torch.empty((max(1, lib.oss_ln_nchw_bwd_partial_floats(B, Cc, P)),), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         st = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_ln_nchw_bwd(_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),

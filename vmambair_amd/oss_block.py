@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import conv1x1, dwconv3x3, layer_norm_nchw
+from .ops import SS2DCoreFn, conv1x1, core_supported, dwconv3x3, layer_norm_nchw
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
@@ -105,6 +105,7 @@ class SS2D_1(nn.Module):
         self.K, self.KC = 4, 2
         self.omni = True  # False: literal reference data flow (forward_core_xs)
         self.fused_merge = True  # scan + cross-merge as one autograd node (HIP merge kernel)
+        self.fused_core = True   # ... and the flattenings and projections in front of it (SS2DCoreFn)
         R, N = self.dt_rank, d_state
 
         self.in_conv = nn.Conv2d(d_model, d_expand * 2, kernel_size=1)
@@ -158,6 +159,10 @@ class SS2D_1(nn.Module):
         ``forward_core_xs`` (the literal reference data flow, kept for the bit-exact index-map test)."""
         if not self.omni:
             return self.forward_core_xs(x, gate)
+        if self.fused_core and core_supported(self.d_inner, self.dt_rank, self.d_state):
+            # flattenings + both projections + scan + merge as one autograd node on the HIP kernels
+            y = SS2DCoreFn.apply(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
+            return self._out_norm(y, x.dtype, gate)
         B, Cc, H, W = x.shape
         L = H * W
         R, N = self.dt_rank, self.d_state
