@@ -180,6 +180,9 @@ int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const
 int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *x_proj_weight,
                    const float *dt_projs_weight, void *dx2, int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
 size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen);
+/* 16-bit I/O runs oss_proj_fwd / _dgrad on the matrix cores (MFMA); float I/O, or force_vector_alu != 0
+ * (tests, A-B timing), on the vector-ALU kernels.  Same results up to the summation order. */
+void oss_proj_set_path(int force_vector_alu);
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
 

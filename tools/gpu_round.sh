@@ -11,6 +11,8 @@ for leg in $LEGS; do
     ubench) timeout 120 ./tools/ubench > gpurun_out/ubench.txt 2>&1; echo "rc=$?";;
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.txt 2>&1; echo "rc=$?"; tail -2 gpurun_out/smoke.txt;;
     pytest) timeout 1200 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/pytest.txt 2>&1; echo "rc=$?"; tail -5 gpurun_out/pytest.txt;;
+    opbench) timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/opbench.txt;;
+    benchmfma) VMAMBAIR_CONV1X1=mfma timeout ${BENCH_TIMEOUT:-700} python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_mfma.txt 2>gpurun_out/bench_mfma.err; echo "rc=$?"; tail -1 gpurun_out/bench_mfma.txt | cut -c1-260;;
     sweep)  timeout 600 python tools/scan_sweep.py ${SWEEP_ARGS:---quick} > gpurun_out/sweep.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/sweep.txt;;
     bench)  timeout ${BENCH_TIMEOUT:-700} python bench.py ${BENCH_ARGS:---steps 5 --warmup 2} > gpurun_out/bench.txt 2>gpurun_out/bench.err; echo "rc=$?"; tail -2 gpurun_out/bench.txt; tail -12 gpurun_out/bench.err;;
     prof)   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --skip-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err" ); echo "rc=$?"; python tools/prof_summary.py gpurun_out/prof/bench_results.db gpurun_out/prof_summary.txt ${PROF_WINDOW_MS:-150}; rm -rf gpurun_out/prof; tail -1 gpurun_out/prof_bench.txt | cut -c1-200;;

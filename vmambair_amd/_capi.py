@@ -55,7 +55,7 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bw
            "oss_scan_bwd", "oss_scan_set_variant", "oss_scan_last_variant", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
-           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_hbm_copy", "oss_version"]
+           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_hbm_copy", "oss_version"]
 
 _lib = None
 
@@ -127,6 +127,8 @@ def load():
     lib.oss_proj_dgrad.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]
     lib.oss_proj_wgrad_partial_floats.restype = C.c_size_t
     lib.oss_proj_wgrad_partial_floats.argtypes = [C.c_int] * 5
+    lib.oss_proj_set_path.restype = None
+    lib.oss_proj_set_path.argtypes = [C.c_int]
     lib.oss_proj_wgrad.restype = C.c_int
     lib.oss_proj_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int

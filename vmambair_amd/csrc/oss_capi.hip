@@ -231,6 +231,8 @@ int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, 
                       reinterpret_cast<hipStream_t>(stream));
 }
 
+void oss_proj_set_path(int force_vector_alu) { proj_force_valu(force_vector_alu); }
+
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
     if (!x2 || !xdbl || !dxdbl || !ddts || !dx_proj_weight || !ddt_projs_weight || !partials) return OSS_ERR_NULL;

@@ -18,27 +18,9 @@
 //   wgrad: k = pixels, so both operands are 16-byte contiguous loads (dy rows and x rows).
 #include "oss_device.h"
 #include "oss_host.h"
+#include "oss_mfma.h"
 
 namespace oss {
-
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16_t> {
-    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
-                                                       __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mfma<f16_t> {
-    static __device__ __forceinline__ f32x16 run(s16x8 a, s16x8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, a),
-                                                      __builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, b), c, 0, 0, 0);
-    }
-};
-
-template <typename T> __device__ __forceinline__ short to_bits(float v) { return (short)from_f32<T>(v).v; }
 
 // y[b, m, p] = sum_k W(m, k) x[b, k, p] (+ bias[m]);  W(m, k) = w[m * ws_m + k * ws_k] (fp32 master weights).
 //   forward: M = Cout, K = Cin, ws_m = Cin, ws_k = 1;  dgrad: M = Cin, K = Cout, ws_m = 1, ws_k = Cin.

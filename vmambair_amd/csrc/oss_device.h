@@ -35,11 +35,11 @@ __device__ __forceinline__ float to_f32(f16_t x) {
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
-    // round-to-nearest-even, NaN preserved (same rounding as torch's float->bfloat16)
-    uint32_t u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{(uint16_t)((u >> 16) | 0x40)};
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return bf16_t{(uint16_t)(u >> 16)};
+    // v_cvt_pk_bf16_f32 (gfx950): round-to-nearest-even, NaN stays NaN -- torch's float->bfloat16 rounding
+    const __bf16 h = (__bf16)x;
+    bf16_t r;
+    __builtin_memcpy(&r.v, &h, 2);
+    return r;
 }
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) {
     _Float16 h = (_Float16)x;  // v_cvt_f16_f32, RNE
@@ -60,6 +60,14 @@ template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t w, float &lo
 }
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return (uint32_t)from_f32<T>(lo).v | ((uint32_t)from_f32<T>(hi).v << 16);
+}
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = __builtin_convertvector(f32x2{lo, hi}, bf16x2);  // one v_cvt_pk_bf16_f32
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
 }
 
 // ---------------------------------------------------------------------------------------------

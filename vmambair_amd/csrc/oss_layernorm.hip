@@ -173,17 +173,20 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 
 __global__ void __launch_bounds__(256)
 oss_ln_nchw_bwd_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int nblk, int C) {
-    // 64 outputs x 4 slices of the partial list per workgroup; slices combined in a fixed order
-    __shared__ float red[4][64];
-    const int col = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + col;
+    // 16 outputs x 16 slices of the partial list per workgroup (2C / 16 workgroups: enough of them to pull the
+    // partials at bandwidth); slices combined in a fixed order
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
     float s = 0.f;
     if (i < 2 * C)
-        for (int k = slice; k < nblk; k += 4) s += part[(size_t)k * 2 * C + i];
+        for (int k = slice; k < nblk; k += 16) s += part[(size_t)k * 2 * C + i];
     red[slice][col] = s;
     __syncthreads();
     if (slice == 0 && i < 2 * C) {
-        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][col];
         if (i < C) dw[i] = t;
         else if (db) db[i - C] = t;
     }
@@ -232,7 +235,7 @@ static int ln_bwd_t(const void *x, const float *w, const float *bias, const void
         if (gate) hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, true, 0>), grid, block, 0, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
         else      hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, false, 0>), grid, block, 0, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
     }
-    hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 63) / 64), dim3(256), 0, s, part, dw, db, nblk, C);
+    hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 15) / 16), dim3(256), 0, s, part, dw, db, nblk, C);
     return (int)hipGetLastError();
 }
 

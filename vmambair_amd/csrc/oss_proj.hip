@@ -14,68 +14,34 @@
 // a GEMM.  Weights are the fp32 master parameters; activations / gradients are the I/O type T.
 #include "oss_device.h"
 #include "oss_host.h"
+#include "oss_mfma.h"
 
 namespace oss {
 
 constexpr int kProjMaxWaves = 16;
 
-// acc_r += sum_e W[off_r + e] * x[e] for four rows r of a wave-uniform fp32 table and eight lane values x:
-// the 4 x 8 weights go through the scalar cache into SGPRs and are consumed as SGPR FMA operands.  Written
-// as one asm block because the compiler's scheduler otherwise hoists every scalar load of the unrolled
-// loop above the FMAs and spills the SGPRs to VGPR lanes.  off_r: BYTE offsets from `base`.
-__device__ __forceinline__ void fma_rows4x8(float &a0, float &a1, float &a2, float &a3, const float (&x)[8], const float *base,
-                                            uint32_t off0, uint32_t off1, uint32_t off2, uint32_t off3) {
-    asm volatile(
-        "s_load_dwordx8 s[36:43], %12, %13\n\t"
-        "s_load_dwordx8 s[44:51], %12, %14\n\t"
-        "s_load_dwordx8 s[52:59], %12, %15\n\t"
-        "s_load_dwordx8 s[60:67], %12, %16\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_fmac_f32 %0, s36, %4\n\t"
-        "v_fmac_f32 %1, s44, %4\n\t"
-        "v_fmac_f32 %2, s52, %4\n\t"
-        "v_fmac_f32 %3, s60, %4\n\t"
-        "v_fmac_f32 %0, s37, %5\n\t"
-        "v_fmac_f32 %1, s45, %5\n\t"
-        "v_fmac_f32 %2, s53, %5\n\t"
-        "v_fmac_f32 %3, s61, %5\n\t"
-        "v_fmac_f32 %0, s38, %6\n\t"
-        "v_fmac_f32 %1, s46, %6\n\t"
-        "v_fmac_f32 %2, s54, %6\n\t"
-        "v_fmac_f32 %3, s62, %6\n\t"
-        "v_fmac_f32 %0, s39, %7\n\t"
-        "v_fmac_f32 %1, s47, %7\n\t"
-        "v_fmac_f32 %2, s55, %7\n\t"
-        "v_fmac_f32 %3, s63, %7\n\t"
-        "v_fmac_f32 %0, s40, %8\n\t"
-        "v_fmac_f32 %1, s48, %8\n\t"
-        "v_fmac_f32 %2, s56, %8\n\t"
-        "v_fmac_f32 %3, s64, %8\n\t"
-        "v_fmac_f32 %0, s41, %9\n\t"
-        "v_fmac_f32 %1, s49, %9\n\t"
-        "v_fmac_f32 %2, s57, %9\n\t"
-        "v_fmac_f32 %3, s65, %9\n\t"
-        "v_fmac_f32 %0, s42, %10\n\t"
-        "v_fmac_f32 %1, s50, %10\n\t"
-        "v_fmac_f32 %2, s58, %10\n\t"
-        "v_fmac_f32 %3, s66, %10\n\t"
-        "v_fmac_f32 %0, s43, %11\n\t"
-        "v_fmac_f32 %1, s51, %11\n\t"
-        "v_fmac_f32 %2, s59, %11\n\t"
-        "v_fmac_f32 %3, s67, %11\n\t"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(base), "s"(off0), "s"(off1),
-          "s"(off2), "s"(off3)
-        : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67");
+// cooperative copy of `rows` x `cols` floats (cols % 4 == 0, 16-byte aligned rows) from a row-major global
+// table (row r at src + row_off(r)) into LDS rows of `ld` floats
+template <typename RowOff>
+__device__ __forceinline__ void stage_rows(float *dst, int ld, const float *src, RowOff row_off, int rows, int cols) {
+    const int c4 = cols >> 2;
+    for (int i = threadIdx.x; i < rows * c4; i += blockDim.x) {
+        const int r = i / c4, c = (i - r * c4) << 2;
+        *reinterpret_cast<f32x4 *>(dst + r * ld + c) = *reinterpret_cast<const f32x4 *>(src + row_off(r) + c);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward: x2 (B, 2, D, L) -> xdbl (B, 4, C, L), dts (B, 4, D, L);  grid (ceil(L/64), 2, B)
+// forward: x2 (B, 2, D, L) -> xdbl (B, 4, C, L), dts (B, 4, D, L);  grid (ceil(L/64), 2, B).
+// The 2C x D weight block of the workgroup's two directions goes through LDS in slabs of DC columns
+// (it is far larger than the scalar cache, and every wave of the workgroup walks all of it); a wave reads
+// its rows' weights as uniform 16-byte LDS loads.  Dynamic LDS: 2C * DC floats.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NQ, int RMAX>
 __global__ void __launch_bounds__(1024)
 oss_proj_fwd_kernel(const T *__restrict__ x2, const float *__restrict__ Wx, const float *__restrict__ Wdt,
-                    T *__restrict__ xdbl, T *__restrict__ dts, int D, int C, int R, int L) {
+                    T *__restrict__ xdbl, T *__restrict__ dts, int D, int C, int R, int L, int DC) {
+    extern __shared__ float wl[];        // [2C][DC]
     __shared__ float zl[2 * RMAX * 64];  // the dt rows of both directions, [kk][r][lane]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -85,42 +51,63 @@ oss_proj_fwd_kernel(const T *__restrict__ x2, const float *__restrict__ Wx, cons
     const int pc = ok ? p : L - 1;
     const T *xb = x2 + ((size_t)(b * 2 + j) * D) * L + pc;
     const int rows2 = 2 * C;
+    auto wrow = [&](int q) { const int kk = q >= C ? 1 : 0; return (size_t)((j + 2 * kk) * C + (q - kk * C)) * D; };
 
     float acc[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) acc[i] = 0.f;
     // wave w owns rows q = w, w + nw, ... of the 2C rows (q < C: direction j, else direction j + 2);
     // rows past the end are clamped (computed and dropped) so the FMA loop has no branches
-    uint32_t woff[NQ];
+    int qoff[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int q = min(wave + i * nw, rows2 - 1);
-        const int kk = q >= C ? 1 : 0, c = q - kk * C;
-        woff[i] = (uint32_t)(((j + 2 * kk) * C + c) * D);
-    }
-    int d0 = 0;
-    T xraw[8];  // the next chunk of 8 activations, loaded one iteration ahead
-    if (D >= 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xraw[e] = xb[(size_t)e * L];
-    }
-    for (; d0 + 8 <= D; d0 += 8) {
-        float xv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = to_f32(xraw[e]);
-        if (d0 + 16 <= D) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xraw[e] = xb[(size_t)(d0 + 8 + e) * L];
+    for (int i = 0; i < NQ; ++i) qoff[i] = min(wave + i * nw, rows2 - 1) * DC;
+
+    const bool vec = (D % 4 == 0) && (DC % 8 == 0);
+    for (int s0 = 0; s0 < D; s0 += DC) {
+        const int cols = min(DC, D - s0);
+        __syncthreads();  // the previous slab is no longer read
+        if (vec && cols % 4 == 0) {
+            stage_rows(wl, DC, Wx + s0, wrow, rows2, cols);
+        } else {
+            for (int i = threadIdx.x; i < rows2 * cols; i += blockDim.x) {
+                const int r = i / cols, c = i - r * cols;
+                wl[r * DC + c] = Wx[wrow(r) + s0 + c];
+            }
         }
+        __syncthreads();
+        int dl = 0;
+        T xraw[8];  // the next chunk of 8 activations, loaded one iteration ahead
+        if (cols >= 8) {
 #pragma unroll
-        for (int i = 0; i < NQ; i += 4)
-            fma_rows4x8(acc[i], acc[i + 1], acc[i + 2], acc[i + 3], xv, Wx, (woff[i] + d0) * 4u, (woff[i + 1] + d0) * 4u,
-                        (woff[i + 2] + d0) * 4u, (woff[i + 3] + d0) * 4u);
-    }
-    for (; d0 < D; ++d0) {
-        const float xv = to_f32(xb[(size_t)d0 * L]);
+            for (int e = 0; e < 8; ++e) xraw[e] = xb[(size_t)(s0 + e) * L];
+        }
+        for (; dl + 8 <= cols; dl += 8) {
+            float xv[8];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) acc[i] = __builtin_fmaf(Wx[(size_t)woff[i] + d0], xv, acc[i]);
+            for (int e = 0; e < 8; ++e) xv[e] = to_f32(xraw[e]);
+            if (dl + 16 <= cols) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xraw[e] = xb[(size_t)(s0 + dl + 8 + e) * L];
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const f32x4 wa = *reinterpret_cast<const f32x4 *>(wl + qoff[i] + dl);
+                const f32x4 wb = *reinterpret_cast<const f32x4 *>(wl + qoff[i] + dl + 4);
+                acc[i] = __builtin_fmaf(wa.x, xv[0], acc[i]);
+                acc[i] = __builtin_fmaf(wa.y, xv[1], acc[i]);
+                acc[i] = __builtin_fmaf(wa.z, xv[2], acc[i]);
+                acc[i] = __builtin_fmaf(wa.w, xv[3], acc[i]);
+                acc[i] = __builtin_fmaf(wb.x, xv[4], acc[i]);
+                acc[i] = __builtin_fmaf(wb.y, xv[5], acc[i]);
+                acc[i] = __builtin_fmaf(wb.z, xv[6], acc[i]);
+                acc[i] = __builtin_fmaf(wb.w, xv[7], acc[i]);
+            }
+        }
+        for (; dl < cols; ++dl) {
+            const float xv = to_f32(xb[(size_t)(s0 + dl) * L]);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) acc[i] = __builtin_fmaf(wl[qoff[i] + dl], xv, acc[i]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -157,13 +144,13 @@ oss_proj_fwd_kernel(const T *__restrict__ x2, const float *__restrict__ Wx, cons
 // dB / dC of the scan backward -- this kernel fills the dt rows:
 //   dxdbl[b,k,r,l] = sum_d dt_w[k,d,r] ddts[b,k,d,l]
 //   dx2[b,j,d,l]   = sum_{k in {j, j+2}} ( sum_c x_w[k,c,d] dxdbl[b,k,c,l] + du[b,k,d,l] )
-// du (B, 4, D, L) = the scan's own gradient w.r.t. u (NULL: none).  Dynamic LDS: (nw R + 2C) * 64 floats.
+// du (B, 4, D, L) = the scan's own gradient w.r.t. u (NULL: none).  Dynamic LDS: proj_dgrad_lds_bytes().
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DS, int RMAX>
-__global__ void __launch_bounds__(1024)
+template <typename T, int DS, int RMAX, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 oss_proj_dgrad_kernel(const T *__restrict__ ddts, T *__restrict__ dxdbl, const T *__restrict__ du,
                       const float *__restrict__ Wx, const float *__restrict__ Wdt, T *__restrict__ dx2, int D, int C, int R,
-                      int L, int slice) {
+                      int L, int slice, int QC) {
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
@@ -171,8 +158,8 @@ oss_proj_dgrad_kernel(const T *__restrict__ ddts, T *__restrict__ dxdbl, const T
     const int p = blockIdx.x * 64 + lane;
     const bool ok = p < L;
     const int pc = ok ? p : L - 1;
-    float *red = sm;                       // [nw][R][64]
-    float *v = sm + (size_t)nw * R * 64;   // [2C][64]: dxdbl rows of both directions, this lane's time step
+    float *v = sm;                          // [2C][64]: dxdbl rows of both directions, this lane's time step
+    float *red = sm + (size_t)2 * C * 64;   // [nw][R][64]; dead after phase A, then the weight slab lives here
 
     // A: dt rows.  Wave w sums over d = w, w + nw, ...; the waves are combined through LDS in a fixed order.
     float pa[2][RMAX];
@@ -213,27 +200,48 @@ oss_proj_dgrad_kernel(const T *__restrict__ ddts, T *__restrict__ dxdbl, const T
         if (c >= R) v[q * 64 + lane] = to_f32(dxdbl[((size_t)(b * 4 + j + 2 * kk) * C + c) * L + pc]);
     }
     __syncthreads();
-    // C: wave w owns the rows d in [w * slice, (w + 1) * slice) of dx2
+    // C: wave w owns the rows d in [w * slice, (w + 1) * slice) of dx2.  The weight rows go through LDS in slabs
+    // of QC rows x D (aliasing the dead reduction buffer), read back as uniform 16-byte loads.
     const int dbeg = wave * slice;
     float acc[DS];
 #pragma unroll
     for (int i = 0; i < DS; ++i) acc[i] = 0.f;
-    if (dbeg + DS <= D) {  // full slice: unconditional wide scalar loads
-        for (int q = 0; q < 2 * C; ++q) {
-            const int kk = q >= C ? 1 : 0, c = q - kk * C;
-            const float val = v[q * 64 + lane];
-            const float *wr = Wx + ((size_t)((j + 2 * kk) * C + c)) * D + dbeg;
-#pragma unroll
-            for (int i = 0; i < DS; ++i) acc[i] = __builtin_fmaf(wr[i], val, acc[i]);
+    auto wrow = [&](int q) { const int kk = q >= C ? 1 : 0; return (size_t)((j + 2 * kk) * C + (q - kk * C)) * D; };
+    float *wl = v + (size_t)2 * C * 64;  // [QC][D]
+    const bool full = dbeg + DS <= D && slice == DS && (D % 4 == 0);
+    for (int q0 = 0; q0 < 2 * C; q0 += QC) {
+        const int nq = min(QC, 2 * C - q0);
+        __syncthreads();
+        if (D % 4 == 0) {
+            stage_rows(wl, D, Wx, [&](int r) { return wrow(q0 + r); }, nq, D);
+        } else {
+            for (int i = threadIdx.x; i < nq * D; i += blockDim.x) {
+                const int r = i / D, c = i - r * D;
+                wl[r * D + c] = Wx[wrow(q0 + r) + c];
+            }
         }
-    } else if (dbeg < D) {
-        for (int q = 0; q < 2 * C; ++q) {
-            const int kk = q >= C ? 1 : 0, c = q - kk * C;
-            const float val = v[q * 64 + lane];
-            const float *wr = Wx + ((size_t)((j + 2 * kk) * C + c)) * D;
+        __syncthreads();
+        if (full) {
+            for (int q = 0; q < nq; ++q) {
+                const float val = v[(q0 + q) * 64 + lane];
+                const float *wr = wl + q * D + dbeg;
 #pragma unroll
-            for (int i = 0; i < DS; ++i)
-                if (i < slice && dbeg + i < D) acc[i] = __builtin_fmaf(wr[dbeg + i], val, acc[i]);
+                for (int i = 0; i < DS; i += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wr + i);
+                    acc[i] = __builtin_fmaf(w4.x, val, acc[i]);
+                    acc[i + 1] = __builtin_fmaf(w4.y, val, acc[i + 1]);
+                    acc[i + 2] = __builtin_fmaf(w4.z, val, acc[i + 2]);
+                    acc[i + 3] = __builtin_fmaf(w4.w, val, acc[i + 3]);
+                }
+            }
+        } else if (dbeg < D) {
+            for (int q = 0; q < nq; ++q) {
+                const float val = v[(q0 + q) * 64 + lane];
+                const float *wr = wl + q * D;
+#pragma unroll
+                for (int i = 0; i < DS; ++i)
+                    if (i < slice && dbeg + i < D) acc[i] = __builtin_fmaf(wr[dbeg + i], val, acc[i]);
+            }
         }
     }
 #pragma unroll
@@ -244,6 +252,209 @@ oss_proj_dgrad_kernel(const T *__restrict__ ddts, T *__restrict__ dxdbl, const T
             if (du) s += to_f32(du[((size_t)(b * 4 + j) * D + d) * L + p]) + to_f32(du[((size_t)(b * 4 + j + 2) * D + d) * L + p]);
             dx2[((size_t)(b * 2 + j) * D + d) * L + p] = from_f32<T>(s);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit I/O: the same two products on the matrix cores (v_mfma_f32_32x32x16), one wave = 32 time steps.
+//   forward : xdbl[b, k(q), c(q), p] = sum_d Wx[q, d] x2[b, j, d, p]       rows q of the 2C (directions j, j + 2)
+//   gradient: dx2[b, j, d, p] = sum_q Wx[q, d] dxdbl[b, k(q), c(q), p] + du[b, j, d, p] + du[b, j + 2, d, p]
+// The activation operand needs 8 rows of ONE time step per lane while rows are stored time-contiguous:
+// 8 two-byte loads per lane and k-step, each coalesced over the 32 lanes of a half wave.  They are loaded
+// once per wave for the whole contraction (KS k-steps, in registers) and reused for every 32-row tile of
+// the output; the fp32 master weights come out of L1/L2 and are narrowed on the fly (v_cvt_pk).
+// grid (ceil(L / 128), 2 * splits, B): 4 waves = 4 x 32 time steps; `per` output tiles per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KS>
+__global__ void __launch_bounds__(256)
+oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx, T *__restrict__ xdbl, int D, int C, int L,
+                         int per) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.y & 1, split = blockIdx.y >> 1, b = blockIdx.z;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= L) return;
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + col;
+    const bool pok = p < L;
+    const T *xb = x2 + ((size_t)(b * 2 + j) * D) * L + (pok ? p : 0);
+    const int ksteps = (D + 15) >> 4;
+    s16x8 bfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + kg * 8 + e;
+            const bool kok = k < D;
+            const short xv = (short)xb[(size_t)(kok ? k : D - 1) * L].v;
+            bfr[ks][e] = (pok && kok) ? xv : (short)0;
+        }
+    }
+    const int M = 2 * C, mt_total = (M + 31) >> 5;
+    const int mt_end = min(mt_total, (split + 1) * per);
+    const bool wvec = (D % 8 == 0) && ((reinterpret_cast<uintptr_t>(Wx) & 15u) == 0);
+    for (int mt = split * per; mt < mt_end; ++mt) {
+        const int q = mt * 32 + col;  // A-operand row of this lane
+        const bool qok = q < M;
+        const int qc = qok ? q : 0, kk = qc >= C ? 1 : 0;
+        const float *wrow = Wx + ((size_t)((j + 2 * kk) * C + (qc - kk * C))) * D;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                const int k0 = ks * 16 + kg * 8;
+                s16x8 af;
+                if (wvec) {
+                    const bool kok = k0 + 8 <= D;
+                    const float *wp = wrow + (kok ? k0 : 0);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+                    af = (qok && kok) ? cvt8<T>(w0, w1) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool kok = k0 + e < D;
+                        af[e] = (qok && kok) ? to_bits<T>(wrow[kok ? k0 + e : 0]) : (short)0;
+                    }
+                }
+                acc = Mfma<T>::run(af, bfr[ks], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row < M && pok) {
+                const int k2 = row >= C ? 1 : 0;
+                xdbl[((size_t)(b * 4 + j + 2 * k2) * C + (row - k2 * C)) * L + p] = from_f32<T>(acc[r]);
+            }
+        }
+    }
+}
+
+template <typename T, int KS>
+__global__ void __launch_bounds__(256)
+oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du, const float *__restrict__ Wx,
+                           T *__restrict__ dx2, int D, int C, int L, int per) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.y & 1, split = blockIdx.y >> 1, b = blockIdx.z;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= L) return;
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + col;
+    const bool pok = p < L;
+    const int K = 2 * C, ksteps = (K + 15) >> 4;
+    // 32-bit offsets from per-batch / per-flattening bases (one address VGPR per load)
+    const T *zb = dxdbl + ((size_t)(b * 4 + j) * C) * L;   // row q of the 2C: q L (+ C L for q >= C: direction j + 2)
+    const float *wb = Wx + (size_t)j * C * D;              // row q: q D (+ C D for q >= C)
+    const uint32_t CL = (uint32_t)C * L, CD = (uint32_t)C * D;
+    const uint32_t pp = pok ? p : 0;
+    s16x8 bfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + kg * 8 + e;
+            const bool kok = k < K;
+            const uint32_t q = kok ? k : 0;
+            const short zv = (short)zb[q * (uint32_t)L + (q >= (uint32_t)C ? CL : 0u) + pp].v;
+            bfr[ks][e] = (pok && kok) ? zv : (short)0;
+        }
+    }
+    const int mt_total = (D + 31) >> 5;
+    const int mt_end = min(mt_total, (split + 1) * per);
+#pragma unroll 1
+    for (int mt = split * per; mt < mt_end; ++mt) {
+        const int d = mt * 32 + col;  // A-operand row (a row of dx2) of this lane
+        const bool dok = d < D;
+        const uint32_t dc = dok ? d : 0;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                float wv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {  // W^T: 32 consecutive d per k -> 128-byte rows
+                    const int k = ks * 16 + kg * 8 + e;
+                    const bool kok = k < K;
+                    const uint32_t q = kok ? k : 0;
+                    const float w1 = wb[q * (uint32_t)D + (q >= (uint32_t)C ? CD : 0u) + dc];
+                    wv[e] = (dok && kok) ? w1 : 0.f;
+                }
+                const s16x8 af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+                acc = Mfma<T>::run(af, bfr[ks], acc);
+            }
+        }
+        const T *du0 = du ? du + ((size_t)(b * 4 + j) * D) * L : nullptr;
+        T *ob = dx2 + ((size_t)(b * 2 + j) * D) * L;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row < D && pok) {
+                float v = acc[r];
+                const uint32_t o = (uint32_t)row * L + p;
+                if (du) v += to_f32(du0[o]) + to_f32(du0[(size_t)2 * D * L + o]);
+                ob[o] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// dts[b, k, d, p] = sum_r Wdt[k, d, r] xdbl[b, k, r, p]   (dt_proj on the ROUNDED dt rows; write-bound: the
+// (B, 4D, L) result is the largest tensor of the block).  grid (ceil(L/64), 4, B); wave w owns d = w, w + nw, ...
+template <typename T, int RMAX>
+__global__ void __launch_bounds__(1024)
+oss_dt_fwd_kernel(const T *__restrict__ xdbl, const float *__restrict__ Wdt, T *__restrict__ dts, int D, int C, int R, int L) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < L;
+    const int pc = ok ? p : L - 1;
+    float zr[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) zr[r] = r < R ? to_f32(xdbl[((size_t)(b * 4 + k) * C + r) * L + pc]) : 0.f;
+    for (int d = wave; d < D; d += nw) {
+        const float *wr = Wdt + ((size_t)k * D + d) * R;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+            if (r < R) s = __builtin_fmaf(wr[r], zr[r], s);
+        if (ok) dts[((size_t)(b * 4 + k) * D + d) * L + p] = from_f32<T>(s);
+    }
+}
+
+// dxdbl[b, k, r, p] = sum_d Wdt[k, d, r] ddts[b, k, d, p]  (r < R; the other rows of dxdbl are not touched).
+// Wave w sums d = w, w + nw, ...; the waves are combined through LDS in a fixed order.  LDS: nw * R * 64 floats.
+template <typename T, int RMAX>
+__global__ void __launch_bounds__(1024)
+oss_dt_dgrad_kernel(const T *__restrict__ ddts, const float *__restrict__ Wdt, T *__restrict__ dxdbl, int D, int C, int R, int L) {
+    extern __shared__ float red[];  // [nw][R][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int k = blockIdx.y, b = blockIdx.z;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < L;
+    const int pc = ok ? p : L - 1;
+    float pa[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) pa[r] = 0.f;
+    for (int d = wave; d < D; d += nw) {
+        const float g = to_f32(ddts[((size_t)(b * 4 + k) * D + d) * L + pc]);
+        const float *wr = Wdt + ((size_t)k * D + d) * R;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+            if (r < R) pa[r] = __builtin_fmaf(wr[r], g, pa[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+        if (r < R) red[(wave * R + r) * 64 + lane] = pa[r];
+    __syncthreads();
+    for (int r = wave; r < R; r += nw) {
+        float s = 0.f;
+        for (int w2 = 0; w2 < nw; ++w2) s += red[(w2 * R + r) * 64 + lane];
+        if (ok) dxdbl[((size_t)(b * 4 + k) * C + r) * L + p] = from_f32<T>(s);
     }
 }
 
@@ -311,9 +522,22 @@ oss_cross_merge2_kernel(const T *__restrict__ g2, T *__restrict__ dx, int D, int
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+static int g_proj_force_valu = 0;  // tests: run 16-bit I/O through the vector-ALU kernels too
 static int proj_waves(int D) { return D <= 192 ? 4 : (D <= 384 ? 8 : 16); }
+// input gradient: 24-row slices (24 accumulators + 6 uniform 16-byte weight loads in flight) while 16 waves allow it
+static int proj_dgrad_waves(int D) { return D <= 96 ? 4 : (D <= 192 ? 8 : 16); }
 
-size_t proj_dgrad_lds_bytes(int D, int C, int R) { return sizeof(float) * 64 * ((size_t)proj_waves(D) * R + 2 * (size_t)C); }
+// weight rows per LDS slab of the input-gradient kernel (<= 48 KiB)
+static int proj_dgrad_qc(int D, int C) { return max(1, min(2 * C, 12288 / D)); }
+size_t proj_dgrad_lds_bytes(int D, int C, int R) {
+    const size_t red = (size_t)proj_dgrad_waves(D) * R * 64, slab = (size_t)proj_dgrad_qc(D, C) * D;
+    return sizeof(float) * (2 * (size_t)C * 64 + (red > slab ? red : slab));
+}
+// columns per LDS slab of the forward kernel: D split into equal parts of <= 128, multiple of 8
+static int proj_fwd_dc(int D) {
+    const int parts = (D + 127) / 128;
+    return (((D + parts - 1) / parts) + 7) & ~7;
+}
 
 template <typename K>
 static int enable_lds(K kern, size_t bytes) {
@@ -331,7 +555,19 @@ static int proj_fwd_t(const void *x2, const float *Wx, const float *Wdt, void *x
     dim3 grid((L + 63) / 64, 2, B), block(64 * nw);
     const T *xp = reinterpret_cast<const T *>(x2);
     T *zp = reinterpret_cast<T *>(xdbl), *dp = reinterpret_cast<T *>(dts);
-#define OSS_PROJ_FWD(NQ_, RM_) hipLaunchKernelGGL((oss_proj_fwd_kernel<T, NQ_, RM_>), grid, block, 0, s, xp, Wx, Wdt, zp, dp, D, C, R, L)
+    const int dc = proj_fwd_dc(D);
+    const size_t smem = sizeof(float) * 2 * (size_t)C * dc;
+#define OSS_PROJ_FWD(NQ_, RM_)                                                                              \
+    do {                                                                                                    \
+        auto kern = oss_proj_fwd_kernel<T, NQ_, RM_>;                                                       \
+        static size_t enabled = 48 * 1024;                                                                  \
+        if (smem > enabled) {                                                                               \
+            const int e = enable_lds(kern, smem);                                                           \
+            if (e) return e;                                                                                \
+            enabled = smem;                                                                                 \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kern, grid, block, smem, s, xp, Wx, Wdt, zp, dp, D, C, R, L, dc);               \
+    } while (0)
     if (R <= 8) {
         if (nq <= 12) OSS_PROJ_FWD(12, 8); else if (nq <= 20) OSS_PROJ_FWD(20, 8); else OSS_PROJ_FWD(32, 8);
     } else {
@@ -341,11 +577,11 @@ static int proj_fwd_t(const void *x2, const float *Wx, const float *Wdt, void *x
     return (int)hipGetLastError();
 }
 
-template <typename T, int DS, int RMAX>
+template <typename T, int DS, int RMAX, int MAXT>
 static int proj_dgrad_launch(const T *ddts, T *dxdbl, const T *du, const float *Wx, const float *Wdt, T *dx2, int B, int D, int C,
                              int R, int L, int nw, int slice, hipStream_t s) {
     const size_t smem = proj_dgrad_lds_bytes(D, C, R);
-    auto kern = oss_proj_dgrad_kernel<T, DS, RMAX>;
+    auto kern = oss_proj_dgrad_kernel<T, DS, RMAX, MAXT>;
     static size_t enabled = 48 * 1024;
     if (smem > enabled) {
         const int e = enable_lds(kern, smem);
@@ -353,29 +589,97 @@ static int proj_dgrad_launch(const T *ddts, T *dxdbl, const T *du, const float *
         enabled = smem;
     }
     dim3 grid((L + 63) / 64, 2, B), block(64 * nw);
-    hipLaunchKernelGGL(kern, grid, block, smem, s, ddts, dxdbl, du, Wx, Wdt, dx2, D, C, R, L, slice);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, ddts, dxdbl, du, Wx, Wdt, dx2, D, C, R, L, slice, proj_dgrad_qc(D, C));
     return (int)hipGetLastError();
 }
 
 template <typename T>
 static int proj_dgrad_t(const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B, int D,
                         int C, int R, int L, hipStream_t s) {
-    const int nw = proj_waves(D);
+    const int nw = proj_dgrad_waves(D);
     const int slice = (((D + nw - 1) / nw) + 7) & ~7;
     if (slice > 64 || R > 32 || B > 65535) return OSS_ERR_SHAPE;
     const T *gp = reinterpret_cast<const T *>(ddts), *up = reinterpret_cast<const T *>(du);
     T *zp = reinterpret_cast<T *>(dxdbl), *xp = reinterpret_cast<T *>(dx2);
-#define OSS_PROJ_DG(DS_, RM_) return proj_dgrad_launch<T, DS_, RM_>(gp, zp, up, Wx, Wdt, xp, B, D, C, R, L, nw, slice, s)
+#define OSS_PROJ_DG(DS_, RM_, MT_) return proj_dgrad_launch<T, DS_, RM_, MT_>(gp, zp, up, Wx, Wdt, xp, B, D, C, R, L, nw, slice, s)
     if (R <= 8) {
-        if (slice <= 24) OSS_PROJ_DG(24, 8); else if (slice <= 48) OSS_PROJ_DG(48, 8); else OSS_PROJ_DG(64, 8);
+        if (nw == 4) OSS_PROJ_DG(24, 8, 256);
+        if (nw == 8) OSS_PROJ_DG(24, 8, 512);
+        if (slice <= 24) OSS_PROJ_DG(24, 8, 1024); else if (slice <= 48) OSS_PROJ_DG(48, 8, 1024); else OSS_PROJ_DG(64, 8, 1024);
     } else {
-        if (slice <= 24) OSS_PROJ_DG(24, 32); else if (slice <= 48) OSS_PROJ_DG(48, 32); else OSS_PROJ_DG(64, 32);
+        if (nw == 4) OSS_PROJ_DG(24, 32, 256);
+        if (nw == 8) OSS_PROJ_DG(24, 32, 512);
+        if (slice <= 24) OSS_PROJ_DG(24, 32, 1024); else if (slice <= 48) OSS_PROJ_DG(48, 32, 1024); else OSS_PROJ_DG(64, 32, 1024);
     }
 #undef OSS_PROJ_DG
 }
 
+// output tiles per workgroup: as few activation re-loads as possible once the chip is full (2 waves per SIMD)
+static int mfma_tiles_per_wg(int B, int L, int mt) {
+    const long waves = 2L * B * ((L + 31) / 32);
+    long split = (2048 + waves - 1) / waves;
+    if (split < 1) split = 1;
+    if (split > mt) split = mt;
+    return (int)((mt + split - 1) / split);
+}
+
+static int dt_waves(int B, int L, int D) {
+    // enough waves to fill the chip at the deep levels (few time steps), 4 per workgroup where there are plenty
+    const long wgs = 4L * B * ((L + 63) / 64);
+    int nw = 4;
+    while (nw < 16 && wgs * nw < 2048 && nw * 8 <= D) nw *= 2;
+    return nw;
+}
+
+template <typename T>
+static int proj_fwd_mfma_t(const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
+                           int L, hipStream_t s) {
+    const T *xp = reinterpret_cast<const T *>(x2);
+    T *zp = reinterpret_cast<T *>(xdbl), *dp = reinterpret_cast<T *>(dts);
+    const int mt = (2 * C + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
+    dim3 grid((L + 127) / 128, 2 * splits, B);
+    const int ks = (D + 15) / 16;
+    if (ks <= 6)       hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 6>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
+    else if (ks <= 12) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 12>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
+    else if (ks <= 24) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 24>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
+    else               hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 48>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
+    const int nw = dt_waves(B, L, D);
+    dim3 g2((L + 63) / 64, 4, B);
+    if (R <= 8) hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 8>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
+    else        hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 32>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,
+                             int D, int C, int R, int L, hipStream_t s) {
+    const T *gp = reinterpret_cast<const T *>(ddts), *up = reinterpret_cast<const T *>(du);
+    T *zp = reinterpret_cast<T *>(dxdbl), *xp = reinterpret_cast<T *>(dx2);
+    const int nw = dt_waves(B, L, D);
+    dim3 g1((L + 63) / 64, 4, B);
+    const size_t smem = sizeof(float) * 64 * (size_t)nw * R;
+    if (smem > 48 * 1024) return OSS_ERR_SHAPE;
+    if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
+    else        hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
+    const int mt = (D + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
+    dim3 grid((L + 127) / 128, 2 * splits, B);
+    const int ks = (2 * C + 15) / 16;
+    if (ks <= 5)      hipLaunchKernelGGL((oss_proj_dgrad_mfma_kernel<T, 5>), grid, dim3(256), 0, s, zp, up, Wx, xp, D, C, L, per);
+    else if (ks <= 8) hipLaunchKernelGGL((oss_proj_dgrad_mfma_kernel<T, 8>), grid, dim3(256), 0, s, zp, up, Wx, xp, D, C, L, per);
+    else              hipLaunchKernelGGL((oss_proj_dgrad_mfma_kernel<T, 16>), grid, dim3(256), 0, s, zp, up, Wx, xp, D, C, L, per);
+    return (int)hipGetLastError();
+}
+
+// 16-bit I/O and shapes the register-resident operands cover -> matrix-core path
+static bool proj_mfma_ok(oss_dtype io, int B, int D, int C, int R) {
+    return io != OSS_F32 && D <= 16 * 48 && 2 * C <= 16 * 16 && R <= 32 && B <= 65535 && g_proj_force_valu == 0;
+}
+
 int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
              int L, hipStream_t s) {
+    if (proj_mfma_ok(io, B, D, C, R))
+        return io == OSS_BF16 ? proj_fwd_mfma_t<bf16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s)
+                              : proj_fwd_mfma_t<f16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
     switch (io) {
         case OSS_F32: return proj_fwd_t<float>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
         case OSS_F16: return proj_fwd_t<f16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
@@ -386,6 +690,9 @@ int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, vo
 
 int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,
                int D, int C, int R, int L, hipStream_t s) {
+    if (proj_mfma_ok(io, B, D, C, R))
+        return io == OSS_BF16 ? proj_dgrad_mfma_t<bf16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s)
+                              : proj_dgrad_mfma_t<f16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);
     switch (io) {
         case OSS_F32: return proj_dgrad_t<float>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);
         case OSS_F16: return proj_dgrad_t<f16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);
@@ -393,6 +700,8 @@ int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, cons
     }
     return OSS_ERR_SHAPE;
 }
+
+void proj_force_valu(int on) { g_proj_force_valu = on ? 1 : 0; }
 
 template <typename TI, typename TO>
 static int cross_scan2_t(const void *x, void *x2, int B, int D, int H, int W, int64_t xsb, int64_t xsc, hipStream_t s) {

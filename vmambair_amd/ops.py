@@ -245,8 +245,9 @@ def merge4(out: torch.Tensor, H: int, W: int) -> torch.Tensor:
 def core_supported(D: int, R: int, N: int) -> bool:
     """shapes the projection kernels cover (oss_proj.hip: <= 32 rows per wave, dt rank <= 32, <= 64-row slices);
     every reference config is inside (D = 2 * 48 * 2^level, R = D / 32, N = 16)."""
-    nw = 4 if D <= 192 else (8 if D <= 384 else 16)
-    return R <= 32 and (2 * (R + 2 * N) + nw - 1) // nw <= 32 and (((D + nw - 1) // nw + 7) & ~7) <= 64
+    nw = 4 if D <= 192 else (8 if D <= 384 else 16)       # forward: rows of x_dbl per wave
+    nwd = 4 if D <= 96 else (8 if D <= 192 else 16)       # input gradient: rows of dx2 per wave
+    return R <= 32 and (2 * (R + 2 * N) + nw - 1) // nw <= 32 and (((D + nwd - 1) // nwd + 7) & ~7) <= 64
 
 
 def _dims_core(x, x_proj_weight, dt_projs_weight, A_logs):
@@ -289,6 +290,11 @@ def cross_merge2(g2: torch.Tensor, H: int, W: int) -> torch.Tensor:
             _capi.check(_capi.load().oss_cross_merge2(_DT[g2.dtype], g2.data_ptr(), dx.data_ptr(), B, D, H, W,
                                                       torch.cuda.current_stream().cuda_stream), "oss_cross_merge2")
     return dx
+
+
+def proj_set_path(force_vector_alu: bool) -> None:
+    """tests / A-B timing: run 16-bit projections on the vector-ALU kernels instead of the matrix cores"""
+    _capi.load().oss_proj_set_path(1 if force_vector_alu else 0)
 
 
 def _proj_weights(x_proj_weight, dt_projs_weight):
