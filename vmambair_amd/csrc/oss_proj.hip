@@ -655,10 +655,10 @@ static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, cons
                              int D, int C, int R, int L, hipStream_t s) {
     const T *gp = reinterpret_cast<const T *>(ddts), *up = reinterpret_cast<const T *>(du);
     T *zp = reinterpret_cast<T *>(dxdbl), *xp = reinterpret_cast<T *>(dx2);
-    const int nw = dt_waves(B, L, D);
+    int nw = dt_waves(B, L, D);
+    while (nw > 1 && sizeof(float) * 64 * (size_t)nw * R > 48 * 1024) nw >>= 1;  // cross-wave reduction buffer <= 48 KiB
     dim3 g1((L + 63) / 64, 4, B);
     const size_t smem = sizeof(float) * 64 * (size_t)nw * R;
-    if (smem > 48 * 1024) return OSS_ERR_SHAPE;
     if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
     else        hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
     const int mt = (D + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
