@@ -13,28 +13,49 @@ from vmambair_amd import ops  # noqa: E402
 DEV = "cuda:0"
 
 
-def timeit(fn, iters=30, warm=5):
-    for _ in range(warm):
-        fn()
+def timeit(fn, reps=20, replays=5, warm=3):
+    """GPU time per call: `reps` calls captured into one hipGraph (no host launch cost in the number), replayed"""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(replays):
+        g.replay()
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1000.0 / iters
+    return a.elapsed_time(b) * 1000.0 / (reps * replays)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--quick", action="store_true")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     torch.manual_seed(0)
     B = 8
     rows = []
-    for (dm, H) in [(48, 64), (96, 64), (96, 32), (192, 16), (384, 8)]:
+    shapes = [(48, 64), (96, 64)] if args.quick else [(48, 64), (96, 64), (96, 32), (192, 16), (384, 8)]
+    from vmambair_amd import _capi
+    tiny_a, tiny_b = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    lib = _capi.load()
+    rows.append(("-", "tiny kernel (graph node floor)",
+                 timeit(lambda: lib.oss_hbm_copy(tiny_b.data_ptr(), tiny_a.data_ptr(), 256, torch.cuda.current_stream().cuda_stream))))
+    big_a, big_b = torch.zeros(1 << 26, device=DEV), torch.zeros(1 << 26, device=DEV)
+    us = timeit(lambda: lib.oss_hbm_copy(big_b.data_ptr(), big_a.data_ptr(), 1 << 28, torch.cuda.current_stream().cuda_stream))
+    rows.append(("-", f"copy 256 MiB ({2 * (1 << 28) / us / 1e6:.2f} TB/s)", us))
+    for (dm, H) in shapes:
         D, L = 2 * dm, H * H
         R, N = max(1, -(-dm // 16)), 16
         Cc = R + 2 * N

@@ -113,7 +113,11 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
         for (int e = 0; e < 8; ++e) {
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < K;
+#ifdef OSS_EXP_CONV_NOLOAD  // (timing experiments only: tools/build_experiment.sh)
+            const short xv = (short)(lane * 3 + k);
+#else
             const short xv = (short)xb[(kok ? k : K - 1) * xsk].v;
+#endif
             bfr[ks][e] = (pok && kok) ? xv : (short)0;
         }
     }
@@ -135,8 +139,12 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
                 if constexpr (!WT) {
                     const bool kok = k0 + 8 <= K;
                     const float *wp = w + mc * K + (kok ? k0 : 0);
+#ifdef OSS_EXP_CONV_NOW
+                    const f32x4 w0 = {(float)lane, 1.f, 2.f, (float)mt}, w1 = {3.f, (float)ks, 4.f, 5.f};
+#else
                     const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp);
                     const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         af[e] = (mok && kok) ? to_bits<T>(w0[e]) : (short)0;
@@ -157,9 +165,184 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+#ifdef OSS_EXP_CONV_NOSTORE
+            if (row < M && pok && acc[r] == 123456.789f) {
+#else
             if (row < M && pok) {
+#endif
                 const float v = acc[r] + (bias ? bias[row] : 0.f);
                 yb[(size_t)row * P + p] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// Pixel-pair form of the kernel above (P even, 4-byte aligned rows): one wave = 64 pixels as TWO MFMA column
+// tiles that interleave -- tile A holds the even pixels p0 + 2c, tile B the odd ones p0 + 2c + 1 (c = lane & 31).
+// One 4-byte load per lane and channel feeds both tiles (128-byte row segments instead of 64), one weight
+// fragment feeds two MFMAs, and the epilogue packs the two tiles' results into one 4-byte store per lane and
+// row (the 2-byte stores of the single-tile form were ~40% of its time: profiles/r01_conv_ablation.txt).
+// wvec: weights readable as two 16-byte loads per fragment (K % 8 == 0, aligned); else element-wise.
+// Pixel-pair form, whole K in registers (K <= 16 KS): the row tiles are produced one after the other
+// (low register pressure, high occupancy); `mt_per_wave` of them per workgroup.
+template <typename T, int KS, bool WT, bool WVEC>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                        T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    if (p0 >= P) return;
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + 2 * col;  // even pixel of this lane's pair
+    const bool pok = p < P;      // P is even: the odd pixel is in range too
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x + b * xsb + (pok ? p : 0));
+    const int xsw = xsk >> 1;    // row stride in 4-byte words
+    T *yb = y + (size_t)b * M * P;
+    const int ksteps = (K + 15) >> 4;
+    s16x8 bfa[KS], bfb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + kg * 8 + e;
+            const bool kok = k < K;
+            const uint32_t v = (pok && kok) ? xw[(kok ? k : K - 1) * xsw] : 0u;
+            bfa[ks][e] = (short)(v & 0xffffu);
+            bfb[ks][e] = (short)(v >> 16);
+        }
+    }
+    const int mt_total = (M + 31) >> 5;
+    const int mt_end = min(mt_total, (int)(blockIdx.z + 1) * mt_per_wave);
+    for (int mt = blockIdx.z * mt_per_wave; mt < mt_end; ++mt) {
+        const int m0 = mt * 32;
+        const int mrow = m0 + col;
+        const bool mok = mrow < M;
+        const int mc = mok ? mrow : 0;
+        f32x16 acca, accb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                const int k0 = ks * 16 + kg * 8;
+                s16x8 af;
+                if constexpr (!WT && WVEC) {
+                    const bool kok = k0 + 8 <= K;
+                    const float *wp = w + mc * K + (kok ? k0 : 0);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+                    af = (mok && kok) ? cvt8<T>(w0, w1) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                } else {
+                    float wv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = k0 + e;
+                        const bool kok = k < K;
+                        const int kc = kok ? k : K - 1;
+                        const float w1 = WT ? w[kc * M + mc] : w[mc * K + kc];
+                        wv[e] = (mok && kok) ? w1 : 0.f;
+                    }
+                    af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+                }
+                acca = Mfma<T>::run(af, bfa[ks], acca);
+                accb = Mfma<T>::run(af, bfb[ks], accb);
+            }
+        }
+        uint32_t *yw = reinterpret_cast<uint32_t *>(yb + p);
+        const int psw = P >> 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row < M && pok) {
+                const float bv = bias ? bias[row] : 0.f;
+                yw[(size_t)row * psw] = pack2<T>(acca[r] + bv, accb[r] + bv);
+            }
+        }
+    }
+}
+
+// K is walked in chunks of KS k-steps (KS * 16 channels) whose activation fragments live in registers; up to MT
+// output row tiles per workgroup are accumulated across the chunks, so any K and M are covered by one kernel
+// (grid.z splits M into groups of <= MT tiles).
+template <typename T, int KS, int MT, bool WT, bool WVEC>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                        T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    if (p0 >= P) return;
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + 2 * col;  // even pixel of this lane's pair
+    const bool pok = p < P;      // P is even: the odd pixel is in range too
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x + b * xsb + (pok ? p : 0));
+    const int xsw = xsk >> 1;    // row stride in 4-byte words
+    T *yb = y + (size_t)b * M * P;
+    const int mt0 = blockIdx.z * MT;
+    f32x16 acca[MT], accb[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acca[t][r] = 0.f; accb[t][r] = 0.f; }
+
+    for (int kc = 0; kc < K; kc += KS * 16) {
+        s16x8 bfa[KS], bfb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kc + ks * 16 + kg * 8 + e;
+                const bool kok = k < K;
+                const uint32_t v = (pok && kok) ? xw[(kok ? k : K - 1) * xsw] : 0u;
+                bfa[ks][e] = (short)(v & 0xffffu);
+                bfb[ks][e] = (short)(v >> 16);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int mrow = (mt0 + t) * 32 + col;
+            const bool mok = mrow < M;
+            const int mc = mok ? mrow : 0;
+            if ((mt0 + t) * 32 < M) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int k0 = kc + ks * 16 + kg * 8;
+                    if (kc + ks * 16 < K) {
+                        s16x8 af;
+                        if constexpr (!WT && WVEC) {
+                            const bool kok = k0 + 8 <= K;
+                            const float *wp = w + mc * K + (kok ? k0 : 0);
+                            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+                            af = (mok && kok) ? cvt8<T>(w0, w1) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        } else {
+                            float wv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int k = k0 + e;
+                                const bool kok = k < K;
+                                const int kcl = kok ? k : K - 1;
+                                const float w1 = WT ? w[kcl * M + mc] : w[mc * K + kcl];
+                                wv[e] = (mok && kok) ? w1 : 0.f;
+                            }
+                            af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+                        }
+                        acca[t] = Mfma<T>::run(af, bfa[ks], acca[t]);
+                        accb[t] = Mfma<T>::run(af, bfb[ks], accb[t]);
+                    }
+                }
+            }
+        }
+    }
+    uint32_t *yw = reinterpret_cast<uint32_t *>(yb + p);
+    const int psw = P >> 1;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            if (row < M && pok) {
+                const float bv = bias ? bias[row] : 0.f;
+                yw[(size_t)row * psw] = pack2<T>(acca[t][r] + bv, accb[t][r] + bv);
             }
         }
     }
@@ -198,7 +381,25 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-        for (int pk = pbeg; pk < pend; pk += 16) {
+        int pk = pbeg;
+        if (aligned) {
+            // 4 k-steps (64 pixels) per iteration: all eight 16-byte loads are issued before the first MFMA needs them
+            for (; pk + 64 <= pend; pk += 64) {
+                u32x4 qa[4], qb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    qa[u] = *reinterpret_cast<const u32x4 *>(ga + pk + u * 16 + kg * 8);
+                    qb[u] = *reinterpret_cast<const u32x4 *>(xa + pk + u * 16 + kg * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const s16x8 af = mok ? __builtin_bit_cast(s16x8, qa[u]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    const s16x8 bf = nok ? __builtin_bit_cast(s16x8, qb[u]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    acc = Mfma<T>::run(af, bf, acc);
+                }
+            }
+        }
+        for (; pk < pend; pk += 16) {
             const int k0 = pk + kg * 8;
             s16x8 af, bf;
             if (aligned && k0 + 8 <= pend) {
@@ -227,16 +428,37 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
     }
 }
 
-// dW[g][m][n] = sum over slabs (fixed order); output row of (g, m) = ((m / Mh) G + g) Mh + m % Mh
+// dW[g][m][n] = sum over slabs (fixed order); output row of (g, m) = ((m / Mh) G + g) Mh + m % Mh.
+// 64 outputs x 4 slices of the slab list per workgroup: slice s adds slabs s, s + 4, ... (4 loads in flight),
+// the four slice sums are combined in a fixed order.
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, int nslab, size_t mn, int G, int N, int Mh) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][64];
+    const int colx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + colx;
     const int g = blockIdx.y;
-    if (i >= mn) return;
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += part[((size_t)k * G + g) * mn + i];
-    const size_t m = i / N, n = i - m * N;
-    dw[(((m / Mh) * G + g) * Mh + m % Mh) * N + n] = s;
+    if (i < mn) {
+        const float *pp = part + (size_t)g * mn + i;
+        const size_t st = (size_t)G * mn;
+        int k = slice;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; k + 12 < nslab; k += 16) {
+            s0 += pp[(size_t)k * st];
+            s1 += pp[(size_t)(k + 4) * st];
+            s2 += pp[(size_t)(k + 8) * st];
+            s3 += pp[(size_t)(k + 12) * st];
+        }
+        for (; k < nslab; k += 4) s0 += pp[(size_t)k * st];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[slice][colx] = s;
+    __syncthreads();
+    if (slice == 0 && i < mn) {
+        const float t = (red[0][colx] + red[1][colx]) + (red[2][colx] + red[3][colx]);
+        const size_t m = i / N, n = i - m * N;
+        dw[(((m / Mh) * G + g) * Mh + m % Mh) * N + n] = t;
+    }
 }
 
 template <typename T>
@@ -245,6 +467,42 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
     const int pblocks = (P + 127) / 128, mt = (M + 31) / 32;
     const bool wt = (ws_m == 1 && ws_k == M);          // input gradient: weights read transposed
     const bool plain = (ws_k == 1 && ws_m == K);
+    // pixel-pair form: even P, even row strides, 4-byte aligned bases
+    const bool pair_ok = P % 2 == 0 && xsk % 2 == 0 && xsb % 2 == 0 && xsk < (1 << 24) && (size_t)M * K < (1u << 30) &&
+                         (wt || plain) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 3u) == 0;
+    if (pair_ok) {
+        const bool wvec = plain && K % 8 == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0;
+        const int pb = (P + 255) / 256;
+        const long waves_p = (long)B * ((P + 63) / 64);
+        const int xk = (int)xsk;
+        if (K <= 16 * 12) {
+            // whole K in registers: enough workgroups to fill the chip twice, otherwise as few activation re-loads as possible
+            int split = (int)((2048 + waves_p - 1) / waves_p);
+            if (split < 1) split = 1;
+            if (split > mt) split = mt;
+            const int per = (mt + split - 1) / split;
+            dim3 grid(pb, B, (mt + per - 1) / per);
+#define OSS_PAIR1(KS_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pair_kernel<T, KS_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per)
+#define OSS_PAIR(KS_) do { if (wt) OSS_PAIR1(KS_, true, false); else if (wvec) OSS_PAIR1(KS_, false, true); else OSS_PAIR1(KS_, false, false); } while (0)
+            if (K <= 16 * 3)      OSS_PAIR(3);
+            else if (K <= 16 * 6) OSS_PAIR(6);
+            else                  OSS_PAIR(12);
+#undef OSS_PAIR
+#undef OSS_PAIR1
+        } else {
+            // K in chunks of 128: up to 3 row tiles accumulate per workgroup (fewest re-loads that still fill the chip)
+            int per = 3;
+            while (per > 1 && waves_p * ((mt + per - 1) / per) < 2048) --per;
+            if (per > mt) per = mt;
+            dim3 grid(pb, B, (mt + per - 1) / per);
+#define OSS_PAIR1(MT_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pairk_kernel<T, 8, MT_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk)
+#define OSS_PAIR(MT_) do { if (wt) OSS_PAIR1(MT_, true, false); else if (wvec) OSS_PAIR1(MT_, false, true); else OSS_PAIR1(MT_, false, false); } while (0)
+            if (per == 1) OSS_PAIR(1); else if (per == 2) OSS_PAIR(2); else OSS_PAIR(3);
+#undef OSS_PAIR
+#undef OSS_PAIR1
+        }
+        return;
+    }
     const bool reuse_ok = K <= 16 * 12 && xsk < (1 << 24) && (size_t)M * K < (1u << 30) &&
                           (wt || (plain && K % 8 == 0 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0));
     if (reuse_ok) {
@@ -307,7 +565,7 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
         default: return OSS_ERR_SHAPE;
     }
     const size_t mn = (size_t)M * N;
-    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 255) / 256), G), dim3(256), 0, s, part, dw, slabs * B, mn,
+    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 63) / 64), G), dim3(256), 0, s, part, dw, slabs * B, mn,
                        G, N, Mh);
     return (int)hipGetLastError();
 }

@@ -15,6 +15,7 @@ constexpr int kScanChunk = 256;  // time steps between saved states in x (oss_sc
 constexpr int kNB = 16;          // states per LDS tile
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -63,11 +64,32 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float 
 }
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const bf16x2 h = __builtin_convertvector(f32x2{lo, hi}, bf16x2);  // one v_cvt_pk_bf16_f32
     uint32_t u;
     __builtin_memcpy(&u, &h, 4);
     return u;
+}
+
+// V consecutive elements per lane as one access (V = 2: 4-byte accesses for the 16-bit types -- a wave's 2-byte
+// accesses move 128 bytes per instruction and were what bounded these kernels)
+template <typename T, int V> __device__ __forceinline__ void load_v(const T *p, float (&v)[V]) {
+    if constexpr (V == 1) {
+        v[0] = to_f32(*p);
+    } else if constexpr (sizeof(T) == 4) {
+        const f32x2 q = *reinterpret_cast<const f32x2 *>(p);
+        v[0] = q.x; v[1] = q.y;
+    } else {
+        unpack2<T>(*reinterpret_cast<const uint32_t *>(p), v[0], v[1]);
+    }
+}
+template <typename T, int V> __device__ __forceinline__ void store_v(T *p, const float (&v)[V]) {
+    if constexpr (V == 1) {
+        *p = from_f32<T>(v[0]);
+    } else if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<f32x2 *>(p) = f32x2{v[0], v[1]};
+    } else {
+        *reinterpret_cast<uint32_t *>(p) = pack2<T>(v[0], v[1]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

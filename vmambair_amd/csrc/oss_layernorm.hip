@@ -23,69 +23,113 @@ __device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_r
 
 constexpr int kLnMaxWaves = 16;
 
-// sum over the workgroup's waves of one value per pixel (lane); fixed order
-__device__ __forceinline__ float ln_cross_wave_sum(float *red /*[kLnMaxWaves][64]*/, float v, int wave, int lane, int nw) {
-    red[wave * 64 + lane] = v;
+// sum over the workgroup's waves of V values per lane; fixed order.  red: [kLnMaxWaves][V][64]
+template <int V>
+__device__ __forceinline__ void ln_cross_wave_sum(float *red, float (&v)[V], int wave, int lane, int nw) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[(wave * V + i) * 64 + lane] = v[i];
     __syncthreads();
-    float t = 0.f;
-    for (int k = 0; k < nw; ++k) t += red[k * 64 + lane];
-    return t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        float t = 0.f;
+        for (int k = 0; k < nw; ++k) t += red[(k * V + i) * 64 + lane];
+        v[i] = t;
+    }
 }
 
 // x: (B, C, P) with element strides (xsb, xsc), pixels contiguous.  y/gate: contiguous (B, C, P).
 // CPW > 0: channels per wave held in registers (needs C <= CPW * NW); CPW == 0: streaming.
-template <typename TX, typename TY, bool GATE, int CPW>
-__global__ void __launch_bounds__(1024)
+// V: consecutive pixels per lane (2: 4-/8-byte accesses; needs even P and even strides); MAXT: 64 * waves bound.
+template <typename TX, typename TY, bool GATE, int CPW, int V, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                        const TY *__restrict__ gate, TY *__restrict__ y, float *__restrict__ mean_out,
                        float *__restrict__ rstd_out, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps) {
-    __shared__ float red[2][kLnMaxWaves * 64];
+    __shared__ float red[2][kLnMaxWaves * 64 * V];
     constexpr int NI = CPW > 0 ? CPW : 1;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
-    const bool ok = p < P;
-    const int pc = ok ? p : P - 1;
+    const int p = (blockIdx.x * 64 + lane) * V;
+    const bool ok = p < P;  // V == 2 only with P even: a pair is in range as a whole
+    const int pc = ok ? p : 0;
     const TX *xp = x + b * xsb + pc;
     const TY *gp = GATE ? gate + b * gsb + pc : nullptr;
     const bool with_bias = bias != nullptr;
-    float xv[NI], zv[NI];
-    float s = 0.f;
+    float xv[NI][V], zv[NI][V];
+    float s[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) s[i] = 0.f;
     if constexpr (CPW > 0) {
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {  // clamped index: all loads issue back to back
             const int c = wave + i * nw, cc = c < C ? c : C - 1;
-            xv[i] = to_f32(xp[cc * xsc]);
-            if constexpr (GATE) zv[i] = to_f32(gp[cc * gsc]);
+            load_v<TX, V>(xp + cc * xsc, xv[i]);
+            if constexpr (GATE) load_v<TY, V>(gp + cc * gsc, zv[i]);
         }
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) s += (wave + i * nw < C) ? xv[i] : 0.f;
+        for (int i = 0; i < CPW; ++i)
+#pragma unroll
+            for (int u = 0; u < V; ++u) s[u] += (wave + i * nw < C) ? xv[i][u] : 0.f;
     } else {
-        for (int c = wave; c < C; c += nw) s += to_f32(xp[c * xsc]);
+        for (int c = wave; c < C; c += nw) {
+            float t[V];
+            load_v<TX, V>(xp + c * xsc, t);
+#pragma unroll
+            for (int u = 0; u < V; ++u) s[u] += t[u];
+        }
     }
-    const float mu = ln_cross_wave_sum(red[0], s, wave, lane, nw) / (float)C;
-    float v = 0.f;
+    ln_cross_wave_sum<V>(red[0], s, wave, lane, nw);
+    float mu[V], q[V], rstd[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) { mu[u] = s[u] / (float)C; q[u] = 0.f; }
     if constexpr (CPW > 0) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const float d = (wave + i * nw < C) ? xv[i] - mu : 0.f; v = __builtin_fmaf(d, d, v); }
+        for (int i = 0; i < CPW; ++i)
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                const float d = (wave + i * nw < C) ? xv[i][u] - mu[u] : 0.f;
+                q[u] = __builtin_fmaf(d, d, q[u]);
+            }
     } else {
-        for (int c = wave; c < C; c += nw) { const float d = to_f32(xp[c * xsc]) - mu; v = __builtin_fmaf(d, d, v); }
+        for (int c = wave; c < C; c += nw) {
+            float t[V];
+            load_v<TX, V>(xp + c * xsc, t);
+#pragma unroll
+            for (int u = 0; u < V; ++u) { const float d = t[u] - mu[u]; q[u] = __builtin_fmaf(d, d, q[u]); }
+        }
     }
-    const float rstd = 1.0f / sqrtf(ln_cross_wave_sum(red[1], v, wave, lane, nw) / (float)C + eps);
-    if (wave == 0 && ok) { mean_out[(size_t)b * P + p] = mu; rstd_out[(size_t)b * P + p] = rstd; }
+    ln_cross_wave_sum<V>(red[1], q, wave, lane, nw);
+#pragma unroll
+    for (int u = 0; u < V; ++u) rstd[u] = 1.0f / sqrtf(q[u] / (float)C + eps);
+    if (wave == 0 && ok) {
+        store_v<float, V>(mean_out + (size_t)b * P + p, mu);
+        store_v<float, V>(rstd_out + (size_t)b * P + p, rstd);
+    }
     TY *yp = y + (size_t)b * C * P + pc;
-    auto emit = [&](int c, float xval, float zval) {
-        // BiasFree (MambaSISR6_arch.py:160-164) divides x (not x - mu) by sigma
-        float o = with_bias ? (xval - mu) * rstd * w[c] + bias[c] : xval * rstd * w[c];
-        if constexpr (GATE) o *= silu_f(zval);
-        if (ok) yp[(size_t)c * P] = from_f32<TY>(o);
+    auto emit = [&](int c, const float (&xval)[V], const float (&zval)[V]) {
+        const float wc = w[c], bc = with_bias ? bias[c] : 0.f;
+        float o[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            // BiasFree (MambaSISR6_arch.py:160-164) divides x (not x - mu) by sigma
+            o[u] = with_bias ? (xval[u] - mu[u]) * rstd[u] * wc + bc : xval[u] * rstd[u] * wc;
+            if constexpr (GATE) o[u] *= silu_f(zval[u]);
+        }
+        if (ok) store_v<TY, V>(yp + (size_t)c * P, o);
     };
     if constexpr (CPW > 0) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) emit(c, xv[i], GATE ? zv[i] : 0.f); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) emit(c, xv[i], zv[i]); }
     } else {
-        for (int c = wave; c < C; c += nw) emit(c, to_f32(xp[c * xsc]), GATE ? to_f32(gp[c * gsc]) : 0.f);
+        for (int c = wave; c < C; c += nw) {
+            float t[V], z[V];
+            load_v<TX, V>(xp + c * xsc, t);
+#pragma unroll
+            for (int u = 0; u < V; ++u) z[u] = 0.f;
+            if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
+            emit(c, t, z);
+        }
     }
 }
 
@@ -95,79 +139,115 @@ oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 //             dx = rstd g - (x - mu) rstd^3 mean(g x)
 // A channel belongs to one wave, so its dweight / dbias partial is a plain 64-lane sum, stored straight
 // to part[blk][2][C].
-template <typename TX, typename TY, bool GATE, int CPW>
-__global__ void __launch_bounds__(1024)
+template <typename TX, typename TY, bool GATE, int CPW, int V, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                        const TY *__restrict__ gate, const TY *__restrict__ dy, const float *__restrict__ mean_in,
                        const float *__restrict__ rstd_in, TX *__restrict__ dx, TY *__restrict__ dgate,
                        float *__restrict__ part /*[nblk][2][C]*/, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb,
                        int64_t gsc) {
-    __shared__ float red[2][kLnMaxWaves * 64];
+    __shared__ float red[2][kLnMaxWaves * 64 * V];
     constexpr int NI = CPW > 0 ? CPW : 1;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+    const int p = (blockIdx.x * 64 + lane) * V;
     const bool ok = p < P;
-    const int pc = ok ? p : P - 1;
+    const int pc = ok ? p : 0;
     const TX *xp = x + b * xsb + pc;
     const TY *gyp = dy + (size_t)b * C * P + pc;
     const TY *gp = GATE ? gate + b * gsb + pc : nullptr;
     const bool with_bias = bias != nullptr;
-    const float mu = mean_in[(size_t)b * P + pc], rstd = rstd_in[(size_t)b * P + pc];
+    float mu[V], rstd[V];
+    load_v<float, V>(mean_in + (size_t)b * P + pc, mu);
+    load_v<float, V>(rstd_in + (size_t)b * P + pc, rstd);
     const float okf = ok ? 1.f : 0.f;
     float *pw_out = part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
-    float xv[NI], gv[NI], zv[NI];  // x, dy, gate
-    float s1 = 0.f, s2 = 0.f;
-    auto first = [&](int c, float xval, float gy, float zval) {
-        const float xh = with_bias ? (xval - mu) * rstd : xval * rstd;
-        float g = gy * okf;
-        if constexpr (GATE) g *= silu_f(zval);
-        const float pw = segment_sum_to_last<64>(g * xh);
-        const float pb = segment_sum_to_last<64>(g);
+    float xv[NI][V], gv[NI][V], zv[NI][V];  // x, dy, gate
+    float s1[V], s2[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+    auto first = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
+        const float wc = w[c];
+        float aw = 0.f, ab = 0.f;
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            const float xh = with_bias ? (xval[u] - mu[u]) * rstd[u] : xval[u] * rstd[u];
+            float g = gy[u] * okf;
+            if constexpr (GATE) g *= silu_f(zval[u]);
+            aw = __builtin_fmaf(g, xh, aw);
+            ab += g;
+            const float gw = g * wc;
+            s1[u] += gw;
+            s2[u] = __builtin_fmaf(gw, with_bias ? xh : xval[u], s2[u]);
+        }
+        const float pw = segment_sum_to_last<64>(aw);
+        const float pb = segment_sum_to_last<64>(ab);
         if (lane == 63) { pw_out[c] = pw; pw_out[C + c] = pb; }
-        const float gw = g * w[c];
-        s1 += gw;
-        s2 = __builtin_fmaf(gw, with_bias ? xh : xval, s2);
     };
     if constexpr (CPW > 0) {
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             const int c = wave + i * nw, cc = c < C ? c : C - 1;
-            xv[i] = to_f32(xp[cc * xsc]);
-            gv[i] = to_f32(gyp[(size_t)cc * P]);
-            if constexpr (GATE) zv[i] = to_f32(gp[cc * gsc]);
+            load_v<TX, V>(xp + cc * xsc, xv[i]);
+            load_v<TY, V>(gyp + (size_t)cc * P, gv[i]);
+            if constexpr (GATE) load_v<TY, V>(gp + cc * gsc, zv[i]);
         }
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) first(c, xv[i], gv[i], GATE ? zv[i] : 0.f); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) first(c, xv[i], gv[i], zv[i]); }
     } else {
-        for (int c = wave; c < C; c += nw)
-            first(c, to_f32(xp[c * xsc]), to_f32(gyp[(size_t)c * P]), GATE ? to_f32(gp[c * gsc]) : 0.f);
+        for (int c = wave; c < C; c += nw) {
+            float t[V], g[V], z[V];
+            load_v<TX, V>(xp + c * xsc, t);
+            load_v<TY, V>(gyp + (size_t)c * P, g);
+#pragma unroll
+            for (int u = 0; u < V; ++u) z[u] = 0.f;
+            if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
+            first(c, t, g, z);
+        }
     }
-    const float m1 = ln_cross_wave_sum(red[0], s1, wave, lane, nw) / (float)C;
-    const float m2 = ln_cross_wave_sum(red[1], s2, wave, lane, nw) / (float)C;
+    ln_cross_wave_sum<V>(red[0], s1, wave, lane, nw);
+    ln_cross_wave_sum<V>(red[1], s2, wave, lane, nw);
+    float m1[V], m2[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) { m1[u] = s1[u] / (float)C; m2[u] = s2[u] / (float)C; }
     TX *dxp = dx + (size_t)b * C * P + pc;
     TY *dgp = GATE ? dgate + (size_t)b * C * P + pc : nullptr;
-    auto second = [&](int c, float xval, float gy, float zval) {
-        const float xh = (xval - mu) * rstd;
-        float g = gy;
-        if constexpr (GATE) {
-            const float sg = __builtin_amdgcn_rcpf(1.f + exp2_hw(-zval * kLog2e));  // sigmoid(z)
-            const float sl = zval * sg;
-            const float o = with_bias ? xh * w[c] + bias[c] : xval * rstd * w[c];  // LN output before the gate
-            if (ok) dgp[(size_t)c * P] = from_f32<TY>(gy * o * (sg + sl * (1.f - sg)));
-            g *= sl;
+    auto second = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
+        const float wc = w[c], bc = with_bias ? bias[c] : 0.f;
+        float d[V], dg[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            const float xh = (xval[u] - mu[u]) * rstd[u];
+            float g = gy[u];
+            if constexpr (GATE) {
+                const float sg = __builtin_amdgcn_rcpf(1.f + exp2_hw(-zval[u] * kLog2e));  // sigmoid(z)
+                const float sl = zval[u] * sg;
+                const float o = with_bias ? xh * wc + bc : xval[u] * rstd[u] * wc;  // LN output before the gate
+                dg[u] = gy[u] * o * (sg + sl * (1.f - sg));
+                g *= sl;
+            }
+            const float gw = g * wc;
+            d[u] = with_bias ? rstd[u] * (gw - m1[u] - xh * m2[u]) : rstd[u] * gw - xh * rstd[u] * rstd[u] * m2[u];
         }
-        const float gw = g * w[c];
-        const float d = with_bias ? rstd * (gw - m1 - xh * m2) : rstd * gw - xh * rstd * rstd * m2;
-        if (ok) dxp[(size_t)c * P] = from_f32<TX>(d);
+        if (ok) {
+            store_v<TX, V>(dxp + (size_t)c * P, d);
+            if constexpr (GATE) store_v<TY, V>(dgp + (size_t)c * P, dg);
+        }
     };
     if constexpr (CPW > 0) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) second(c, xv[i], gv[i], GATE ? zv[i] : 0.f); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) second(c, xv[i], gv[i], zv[i]); }
     } else {
-        for (int c = wave; c < C; c += nw)
-            second(c, to_f32(xp[c * xsc]), to_f32(gyp[(size_t)c * P]), GATE ? to_f32(gp[c * gsc]) : 0.f);
+        for (int c = wave; c < C; c += nw) {
+            float t[V], g[V], z[V];
+            load_v<TX, V>(xp + c * xsc, t);
+            load_v<TY, V>(gyp + (size_t)c * P, g);
+#pragma unroll
+            for (int u = 0; u < V; ++u) z[u] = 0.f;
+            if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
+            second(c, t, g, z);
+        }
     }
 }
 
@@ -197,23 +277,38 @@ constexpr int kLnCPW = 24;
 // waves per workgroup: the fewest of 4 / 8 / 16 that keep a wave's channels in registers
 static int ln_waves(int C) { return C <= 4 * kLnCPW ? 4 : (C <= 8 * kLnCPW ? 8 : 16); }
 static bool ln_cached(int C) { return C <= kLnMaxWaves * kLnCPW; }
+// two pixels per lane: needs pair-aligned rows, and the register room of <= 8 waves per workgroup
+static bool ln_pairs(int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, const void *a, const void *b2,
+                     const void *c2, const void *d2) {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(c2) |
+                         reinterpret_cast<uintptr_t>(d2);
+    return ln_cached(C) && ln_waves(C) <= 8 && P % 2 == 0 && xsb % 2 == 0 && xsc % 2 == 0 && gsb % 2 == 0 && gsc % 2 == 0 &&
+           (al & 7u) == 0;
+}
+static int ln_tile(bool pairs) { return pairs ? 128 : 64; }
 
 size_t ln_nchw_bwd_partial_floats(int B, int C, int P) { return (size_t)((P + 63) / 64) * B * 2 * C; }
+
+#define OSS_LN_LAUNCH(KERN, GATE_, ...)                                                                         \
+    do {                                                                                                        \
+        if (!ln_cached(C))   hipLaunchKernelGGL((KERN<TX, TY, GATE_, 0, 1, 1024>), grid, block, 0, s, __VA_ARGS__);      \
+        else if (!pairs)     hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW, 1, 1024>), grid, block, 0, s, __VA_ARGS__); \
+        else if (nw == 4)    hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW, 2, 256>), grid, block, 0, s, __VA_ARGS__);  \
+        else                 hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW, 2, 512>), grid, block, 0, s, __VA_ARGS__);  \
+    } while (0)
 
 template <typename TX, typename TY>
 static int ln_fwd_t(const void *x, const float *w, const float *bias, const void *gate, void *y, float *mean, float *rstd,
                     int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps, hipStream_t s) {
-    dim3 grid((P + 63) / 64, B), block(64 * ln_waves(C));
+    const int nw = ln_waves(C);
+    const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, y, mean) && (reinterpret_cast<uintptr_t>(rstd) & 7u) == 0;
+    const int tile = ln_tile(pairs);
+    dim3 grid((P + tile - 1) / tile, B), block(64 * nw);
     const TX *xp = reinterpret_cast<const TX *>(x);
     const TY *gp = reinterpret_cast<const TY *>(gate);
     TY *yp = reinterpret_cast<TY *>(y);
-    if (ln_cached(C)) {
-        if (gate) hipLaunchKernelGGL((oss_ln_nchw_fwd_kernel<TX, TY, true, kLnCPW>), grid, block, 0, s, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
-        else      hipLaunchKernelGGL((oss_ln_nchw_fwd_kernel<TX, TY, false, kLnCPW>), grid, block, 0, s, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
-    } else {
-        if (gate) hipLaunchKernelGGL((oss_ln_nchw_fwd_kernel<TX, TY, true, 0>), grid, block, 0, s, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
-        else      hipLaunchKernelGGL((oss_ln_nchw_fwd_kernel<TX, TY, false, 0>), grid, block, 0, s, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
-    }
+    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_fwd_kernel, true, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
+    else      OSS_LN_LAUNCH(oss_ln_nchw_fwd_kernel, false, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
     return (int)hipGetLastError();
 }
 
@@ -221,20 +316,19 @@ template <typename TX, typename TY>
 static int ln_bwd_t(const void *x, const float *w, const float *bias, const void *gate, const void *dy, const float *mean,
                     const float *rstd, void *dx, void *dgate, float *dw, float *db, float *part, int B, int C, int P,
                     int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
-    dim3 grid((P + 63) / 64, B), block(64 * ln_waves(C));
+    const int nw = ln_waves(C);
+    const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, dy, dx) &&
+                       ((reinterpret_cast<uintptr_t>(dgate) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 7u) == 0;
+    const int tile = ln_tile(pairs);
+    dim3 grid((P + tile - 1) / tile, B), block(64 * nw);
     const int nblk = grid.x * grid.y;
     const TX *xp = reinterpret_cast<const TX *>(x);
     const TY *gp = reinterpret_cast<const TY *>(gate);
     const TY *dyp = reinterpret_cast<const TY *>(dy);
     TX *dxp = reinterpret_cast<TX *>(dx);
     TY *dgp = reinterpret_cast<TY *>(dgate);
-    if (ln_cached(C)) {
-        if (gate) hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, true, kLnCPW>), grid, block, 0, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
-        else      hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, false, kLnCPW>), grid, block, 0, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
-    } else {
-        if (gate) hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, true, 0>), grid, block, 0, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
-        else      hipLaunchKernelGGL((oss_ln_nchw_bwd_kernel<TX, TY, false, 0>), grid, block, 0, s, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
-    }
+    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, true, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
+    else      OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, false, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc);
     hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 15) / 16), dim3(256), 0, s, part, dw, db, nblk, C);
     return (int)hipGetLastError();
 }

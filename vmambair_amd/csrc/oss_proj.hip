@@ -265,28 +265,32 @@ oss_proj_dgrad_kernel(const T *__restrict__ ddts, T *__restrict__ dxdbl, const T
 // the output; the fp32 master weights come out of L1/L2 and are narrowed on the fly (v_cvt_pk).
 // grid (ceil(L / 128), 2 * splits, B): 4 waves = 4 x 32 time steps; `per` output tiles per workgroup.
 // ---------------------------------------------------------------------------------------------
+// One wave = 64 time steps as two interleaved MFMA column tiles (even steps p0 + 2c / odd steps p0 + 2c + 1):
+// one 4-byte load per lane and row feeds both, results leave as 4-byte stores (L even; see oss_conv1x1.hip).
 template <typename T, int KS>
 __global__ void __launch_bounds__(256)
 oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx, T *__restrict__ xdbl, int D, int C, int L,
                          int per) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.y & 1, split = blockIdx.y >> 1, b = blockIdx.z;
-    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
     if (p0 >= L) return;
     const int col = lane & 31, kg = lane >> 5;
-    const int p = p0 + col;
+    const int p = p0 + 2 * col;
     const bool pok = p < L;
-    const T *xb = x2 + ((size_t)(b * 2 + j) * D) * L + (pok ? p : 0);
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x2 + ((size_t)(b * 2 + j) * D) * L + (pok ? p : 0));
+    const int lw = L >> 1;
     const int ksteps = (D + 15) >> 4;
-    s16x8 bfr[KS];
+    s16x8 bfa[KS], bfb[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < D;
-            const short xv = (short)xb[(size_t)(kok ? k : D - 1) * L].v;
-            bfr[ks][e] = (pok && kok) ? xv : (short)0;
+            const uint32_t v = (pok && kok) ? xw[(size_t)(kok ? k : D - 1) * lw] : 0u;
+            bfa[ks][e] = (short)(v & 0xffffu);
+            bfb[ks][e] = (short)(v >> 16);
         }
     }
     const int M = 2 * C, mt_total = (M + 31) >> 5;
@@ -297,9 +301,9 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
         const bool qok = q < M;
         const int qc = qok ? q : 0, kk = qc >= C ? 1 : 0;
         const float *wrow = Wx + ((size_t)((j + 2 * kk) * C + (qc - kk * C))) * D;
-        f32x16 acc;
+        f32x16 acca, accb;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
@@ -317,7 +321,8 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
                         af[e] = (qok && kok) ? to_bits<T>(wrow[kok ? k0 + e : 0]) : (short)0;
                     }
                 }
-                acc = Mfma<T>::run(af, bfr[ks], acc);
+                acca = Mfma<T>::run(af, bfa[ks], acca);
+                accb = Mfma<T>::run(af, bfb[ks], accb);
             }
         }
 #pragma unroll
@@ -325,7 +330,8 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
             const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (row < M && pok) {
                 const int k2 = row >= C ? 1 : 0;
-                xdbl[((size_t)(b * 4 + j + 2 * k2) * C + (row - k2 * C)) * L + p] = from_f32<T>(acc[r]);
+                *reinterpret_cast<uint32_t *>(xdbl + ((size_t)(b * 4 + j + 2 * k2) * C + (row - k2 * C)) * L + p) =
+                    pack2<T>(acca[r], accb[r]);
             }
         }
     }
@@ -337,18 +343,17 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
                            T *__restrict__ dx2, int D, int C, int L, int per) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.y & 1, split = blockIdx.y >> 1, b = blockIdx.z;
-    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
     if (p0 >= L) return;
     const int col = lane & 31, kg = lane >> 5;
-    const int p = p0 + col;
+    const int p = p0 + 2 * col;
     const bool pok = p < L;
     const int K = 2 * C, ksteps = (K + 15) >> 4;
     // 32-bit offsets from per-batch / per-flattening bases (one address VGPR per load)
-    const T *zb = dxdbl + ((size_t)(b * 4 + j) * C) * L;   // row q of the 2C: q L (+ C L for q >= C: direction j + 2)
+    const uint32_t *zw = reinterpret_cast<const uint32_t *>(dxdbl + ((size_t)(b * 4 + j) * C) * L + (pok ? p : 0));
     const float *wb = Wx + (size_t)j * C * D;              // row q: q D (+ C D for q >= C)
-    const uint32_t CL = (uint32_t)C * L, CD = (uint32_t)C * D;
-    const uint32_t pp = pok ? p : 0;
-    s16x8 bfr[KS];
+    const uint32_t lw = (uint32_t)L >> 1, CLw = (uint32_t)C * lw, CD = (uint32_t)C * D;
+    s16x8 bfa[KS], bfb[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -356,8 +361,9 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < K;
             const uint32_t q = kok ? k : 0;
-            const short zv = (short)zb[q * (uint32_t)L + (q >= (uint32_t)C ? CL : 0u) + pp].v;
-            bfr[ks][e] = (pok && kok) ? zv : (short)0;
+            const uint32_t v = (pok && kok) ? zw[q * lw + (q >= (uint32_t)C ? CLw : 0u)] : 0u;  // row q (+ C L: direction j + 2)
+            bfa[ks][e] = (short)(v & 0xffffu);
+            bfb[ks][e] = (short)(v >> 16);
         }
     }
     const int mt_total = (D + 31) >> 5;
@@ -367,9 +373,9 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
         const int d = mt * 32 + col;  // A-operand row (a row of dx2) of this lane
         const bool dok = d < D;
         const uint32_t dc = dok ? d : 0;
-        f32x16 acc;
+        f32x16 acca, accb;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
@@ -383,78 +389,110 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
                     wv[e] = (dok && kok) ? w1 : 0.f;
                 }
                 const s16x8 af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
-                acc = Mfma<T>::run(af, bfr[ks], acc);
+                acca = Mfma<T>::run(af, bfa[ks], acca);
+                accb = Mfma<T>::run(af, bfb[ks], accb);
             }
         }
-        const T *du0 = du ? du + ((size_t)(b * 4 + j) * D) * L : nullptr;
-        T *ob = dx2 + ((size_t)(b * 2 + j) * D) * L;
+        const uint32_t *du0 = du ? reinterpret_cast<const uint32_t *>(du + ((size_t)(b * 4 + j) * D) * L + p) : nullptr;
+        uint32_t *ob = reinterpret_cast<uint32_t *>(dx2 + ((size_t)(b * 2 + j) * D) * L + p);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (row < D && pok) {
-                float v = acc[r];
-                const uint32_t o = (uint32_t)row * L + p;
-                if (du) v += to_f32(du0[o]) + to_f32(du0[(size_t)2 * D * L + o]);
-                ob[o] = from_f32<T>(v);
+                float va = acca[r], vb = accb[r];
+                const size_t o = (size_t)row * lw;
+                if (du) {
+                    float a0, a1, b0, b1;
+                    unpack2<T>(du0[o], a0, a1);
+                    unpack2<T>(du0[(size_t)D * L + o], b0, b1);  // direction j + 2: 2 D rows further
+                    va += a0 + b0;
+                    vb += a1 + b1;
+                }
+                ob[o] = pack2<T>(va, vb);
             }
         }
     }
 }
 
 // dts[b, k, d, p] = sum_r Wdt[k, d, r] xdbl[b, k, r, p]   (dt_proj on the ROUNDED dt rows; write-bound: the
-// (B, 4D, L) result is the largest tensor of the block).  grid (ceil(L/64), 4, B); wave w owns d = w, w + nw, ...
-template <typename T, int RMAX>
+// (B, 4D, L) result is the largest tensor of the block).  grid (ceil(L / (64 V)), 4, B); lane = V consecutive time
+// steps; wave w owns d = w, w + nw, ...
+template <typename T, int RMAX, int V>
 __global__ void __launch_bounds__(1024)
 oss_dt_fwd_kernel(const T *__restrict__ xdbl, const float *__restrict__ Wdt, T *__restrict__ dts, int D, int C, int R, int L) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int k = blockIdx.y, b = blockIdx.z;
-    const int p = blockIdx.x * 64 + lane;
-    const bool ok = p < L;
-    const int pc = ok ? p : L - 1;
-    float zr[RMAX];
+    const int p = (blockIdx.x * 64 + lane) * V;
+    const bool ok = p < L;  // V == 2 only with L even: the pair is in range as a whole
+    const int pc = ok ? p : 0;
+    float zr[RMAX][V];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) zr[r] = r < R ? to_f32(xdbl[((size_t)(b * 4 + k) * C + r) * L + pc]) : 0.f;
+    for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) zr[r][i] = 0.f;
+        if (r < R) load_v<T, V>(xdbl + ((size_t)(b * 4 + k) * C + r) * L + pc, zr[r]);
+    }
     for (int d = wave; d < D; d += nw) {
         const float *wr = Wdt + ((size_t)k * D + d) * R;
-        float s = 0.f;
+        float s[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) s[i] = 0.f;
 #pragma unroll
         for (int r = 0; r < RMAX; ++r)
-            if (r < R) s = __builtin_fmaf(wr[r], zr[r], s);
-        if (ok) dts[((size_t)(b * 4 + k) * D + d) * L + p] = from_f32<T>(s);
+            if (r < R) {
+                const float wv = wr[r];
+#pragma unroll
+                for (int i = 0; i < V; ++i) s[i] = __builtin_fmaf(wv, zr[r][i], s[i]);
+            }
+        if (ok) store_v<T, V>(dts + ((size_t)(b * 4 + k) * D + d) * L + p, s);
     }
 }
 
 // dxdbl[b, k, r, p] = sum_d Wdt[k, d, r] ddts[b, k, d, p]  (r < R; the other rows of dxdbl are not touched).
-// Wave w sums d = w, w + nw, ...; the waves are combined through LDS in a fixed order.  LDS: nw * R * 64 floats.
-template <typename T, int RMAX>
+// Wave w sums d = w, w + nw, ...; the waves are combined through LDS in a fixed order.  LDS: nw * R * 64 V floats.
+template <typename T, int RMAX, int V>
 __global__ void __launch_bounds__(1024)
 oss_dt_dgrad_kernel(const T *__restrict__ ddts, const float *__restrict__ Wdt, T *__restrict__ dxdbl, int D, int C, int R, int L) {
-    extern __shared__ float red[];  // [nw][R][64]
+    extern __shared__ float red[];  // [nw][R][64 V]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int k = blockIdx.y, b = blockIdx.z;
-    const int p = blockIdx.x * 64 + lane;
+    const int p = (blockIdx.x * 64 + lane) * V;
     const bool ok = p < L;
-    const int pc = ok ? p : L - 1;
-    float pa[RMAX];
+    const int pc = ok ? p : 0;
+    float pa[RMAX][V];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) pa[r] = 0.f;
+    for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+        for (int i = 0; i < V; ++i) pa[r][i] = 0.f;
     for (int d = wave; d < D; d += nw) {
-        const float g = to_f32(ddts[((size_t)(b * 4 + k) * D + d) * L + pc]);
+        float g[V];
+        load_v<T, V>(ddts + ((size_t)(b * 4 + k) * D + d) * L + pc, g);
         const float *wr = Wdt + ((size_t)k * D + d) * R;
 #pragma unroll
         for (int r = 0; r < RMAX; ++r)
-            if (r < R) pa[r] = __builtin_fmaf(wr[r], g, pa[r]);
+            if (r < R) {
+                const float wv = wr[r];
+#pragma unroll
+                for (int i = 0; i < V; ++i) pa[r][i] = __builtin_fmaf(wv, g[i], pa[r][i]);
+            }
     }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
-        if (r < R) red[(wave * R + r) * 64 + lane] = pa[r];
+        if (r < R) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) red[((wave * R + r) * V + i) * 64 + lane] = pa[r][i];
+        }
     __syncthreads();
     for (int r = wave; r < R; r += nw) {
-        float s = 0.f;
-        for (int w2 = 0; w2 < nw; ++w2) s += red[(w2 * R + r) * 64 + lane];
-        if (ok) dxdbl[((size_t)(b * 4 + k) * C + r) * L + p] = from_f32<T>(s);
+        float s[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            s[i] = 0.f;
+            for (int w2 = 0; w2 < nw; ++w2) s[i] += red[((w2 * R + r) * V + i) * 64 + lane];
+        }
+        if (ok) store_v<T, V>(dxdbl + ((size_t)(b * 4 + k) * C + r) * L + p, s);
     }
 }
 
@@ -616,7 +654,7 @@ static int proj_dgrad_t(const void *ddts, void *dxdbl, const void *du, const flo
 
 // output tiles per workgroup: as few activation re-loads as possible once the chip is full (2 waves per SIMD)
 static int mfma_tiles_per_wg(int B, int L, int mt) {
-    const long waves = 2L * B * ((L + 31) / 32);
+    const long waves = 2L * B * ((L + 63) / 64);
     long split = (2048 + waves - 1) / waves;
     if (split < 1) split = 1;
     if (split > mt) split = mt;
@@ -625,7 +663,7 @@ static int mfma_tiles_per_wg(int B, int L, int mt) {
 
 static int dt_waves(int B, int L, int D) {
     // enough waves to fill the chip at the deep levels (few time steps), 4 per workgroup where there are plenty
-    const long wgs = 4L * B * ((L + 63) / 64);
+    const long wgs = 4L * B * ((L + 127) / 128);
     int nw = 4;
     while (nw < 16 && wgs * nw < 2048 && nw * 8 <= D) nw *= 2;
     return nw;
@@ -637,16 +675,16 @@ static int proj_fwd_mfma_t(const void *x2, const float *Wx, const float *Wdt, vo
     const T *xp = reinterpret_cast<const T *>(x2);
     T *zp = reinterpret_cast<T *>(xdbl), *dp = reinterpret_cast<T *>(dts);
     const int mt = (2 * C + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
-    dim3 grid((L + 127) / 128, 2 * splits, B);
+    dim3 grid((L + 255) / 256, 2 * splits, B);
     const int ks = (D + 15) / 16;
     if (ks <= 6)       hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 6>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else if (ks <= 12) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 12>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else if (ks <= 24) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 24>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else               hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 48>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     const int nw = dt_waves(B, L, D);
-    dim3 g2((L + 63) / 64, 4, B);
-    if (R <= 8) hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 8>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
-    else        hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 32>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
+    dim3 g2((L + 127) / 128, 4, B);  // L is even here: two time steps per lane
+    if (R <= 8) hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 8, 2>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
+    else        hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 32, 2>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
     return (int)hipGetLastError();
 }
 
@@ -656,13 +694,13 @@ static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, cons
     const T *gp = reinterpret_cast<const T *>(ddts), *up = reinterpret_cast<const T *>(du);
     T *zp = reinterpret_cast<T *>(dxdbl), *xp = reinterpret_cast<T *>(dx2);
     int nw = dt_waves(B, L, D);
-    while (nw > 1 && sizeof(float) * 64 * (size_t)nw * R > 48 * 1024) nw >>= 1;  // cross-wave reduction buffer <= 48 KiB
-    dim3 g1((L + 63) / 64, 4, B);
-    const size_t smem = sizeof(float) * 64 * (size_t)nw * R;
-    if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
-    else        hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
+    while (nw > 1 && sizeof(float) * 128 * (size_t)nw * R > 48 * 1024) nw >>= 1;  // cross-wave reduction buffer <= 48 KiB
+    dim3 g1((L + 127) / 128, 4, B);
+    const size_t smem = sizeof(float) * 128 * (size_t)nw * R;
+    if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
+    else        hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
     const int mt = (D + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
-    dim3 grid((L + 127) / 128, 2 * splits, B);
+    dim3 grid((L + 255) / 256, 2 * splits, B);
     const int ks = (2 * C + 15) / 16;
     if (ks <= 5)      hipLaunchKernelGGL((oss_proj_dgrad_mfma_kernel<T, 5>), grid, dim3(256), 0, s, zp, up, Wx, xp, D, C, L, per);
     else if (ks <= 8) hipLaunchKernelGGL((oss_proj_dgrad_mfma_kernel<T, 8>), grid, dim3(256), 0, s, zp, up, Wx, xp, D, C, L, per);
@@ -671,13 +709,13 @@ static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, cons
 }
 
 // 16-bit I/O and shapes the register-resident operands cover -> matrix-core path
-static bool proj_mfma_ok(oss_dtype io, int B, int D, int C, int R) {
-    return io != OSS_F32 && D <= 16 * 48 && 2 * C <= 16 * 16 && R <= 32 && B <= 65535 && g_proj_force_valu == 0;
+static bool proj_mfma_ok(oss_dtype io, int B, int D, int C, int R, int L) {
+    return io != OSS_F32 && L % 2 == 0 && D <= 16 * 48 && 2 * C <= 16 * 16 && R <= 32 && B <= 65535 && g_proj_force_valu == 0;
 }
 
 int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
              int L, hipStream_t s) {
-    if (proj_mfma_ok(io, B, D, C, R))
+    if (proj_mfma_ok(io, B, D, C, R, L))
         return io == OSS_BF16 ? proj_fwd_mfma_t<bf16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s)
                               : proj_fwd_mfma_t<f16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
     switch (io) {
@@ -690,7 +728,7 @@ int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, vo
 
 int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,
                int D, int C, int R, int L, hipStream_t s) {
-    if (proj_mfma_ok(io, B, D, C, R))
+    if (proj_mfma_ok(io, B, D, C, R, L))
         return io == OSS_BF16 ? proj_dgrad_mfma_t<bf16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s)
                               : proj_dgrad_mfma_t<f16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);
     switch (io) {
