@@ -144,16 +144,17 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
  * contiguous (master weights, converted in the loader); x / dy: (batch, C, pixels) io dtype, pixels
  * contiguous, element strides (batch, channel); y / dx contiguous.
  *   fwd  : y  = W x + bias            dgrad: dx = W^T dy
- *   wgrad: dweight (Cout, Cin) float = sum_{b,p} dy x^T, `partials` =
+ *   wgrad: dweight (Cout, Cin) float = sum_{b,p} dy x^T and, when dbias != NULL, dbias (Cout) float =
+ *          sum_{b,p} dy (an all-ones row appended to x inside the kernel); `partials` =
  *          oss_conv1x1_wgrad_partial_floats() floats of scratch. */
 int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout,
                     int cin, int pixels, int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
 int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
                       int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
 size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels);
-int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *partials, int batch, int cout,
-                      int cin, int pixels, int64_t dy_batch_stride, int64_t dy_channel_stride, int64_t x_batch_stride,
-                      int64_t x_channel_stride, oss_stream_t stream);
+int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *dbias, float *partials, int batch,
+                      int cout, int cin, int pixels, int64_t dy_batch_stride, int64_t dy_channel_stride,
+                      int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
 
 /* The two in-block projections of the spatial branch (MambaSISR6_arch.py:406-411), omni form, and the
  * flattenings around them.  Layouts (all contiguous, io dtype): x2 (batch, 2, D, L) = the row-major

@@ -83,7 +83,7 @@ def main():
             if dt != torch.float32:
                 rows.append((tag, f"{name} mfma fwd", timeit(lambda: ops.conv1x1_fwd(inp, w, bias))))
                 dy = torch.randn(B, co, H, H, device=DEV).to(dt)
-                rows.append((tag, f"{name} mfma bwd", timeit(lambda: ops.conv1x1_bwd(inp, w, dy))))
+                rows.append((tag, f"{name} mfma bwd", timeit(lambda: ops.conv1x1_bwd(inp, w, dy, True))))
                 xi = inp.clone().requires_grad_()
                 wi, bi = w16.clone().requires_grad_(), b16.clone().requires_grad_()
 

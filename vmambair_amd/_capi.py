@@ -116,7 +116,7 @@ def load():
     lib.oss_conv1x1_wgrad_partial_floats.restype = C.c_size_t
     lib.oss_conv1x1_wgrad_partial_floats.argtypes = [C.c_int] * 4
     lib.oss_conv1x1_wgrad.restype = C.c_int
-    lib.oss_conv1x1_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_void_p]
+    lib.oss_conv1x1_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_cross_scan2.restype = C.c_int
     lib.oss_cross_scan2.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_int64] * 2 + [C.c_void_p]
     lib.oss_cross_merge2.restype = C.c_int

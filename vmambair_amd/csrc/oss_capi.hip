@@ -197,15 +197,15 @@ int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *d
 
 size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels) {
     if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0) return 0;
-    return (size_t)batch * conv1x1_wgrad_slabs(pixels) * cout * cin;
+    return (size_t)batch * conv1x1_wgrad_slabs(pixels) * cout * (cin + 1);  // + 1: the dbias column
 }
 
-int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *partials, int batch, int cout,
-                      int cin, int pixels, int64_t gsb, int64_t gsc, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *dbias, float *partials, int batch,
+                      int cout, int cin, int pixels, int64_t gsb, int64_t gsc, int64_t xsb, int64_t xsc, oss_stream_t stream) {
     if (!dy || !x || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return conv1x1_wgrad(io, dy, x, dweight, partials, batch, cout, cin, pixels, gsb, gsc, xsb, xsc,
-                         reinterpret_cast<hipStream_t>(stream));
+                         reinterpret_cast<hipStream_t>(stream), 1, 0, 0, 0, 0, dbias);
 }
 
 size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen) {

@@ -357,15 +357,17 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
                          int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
-                         int64_t gs_hi) {
+                         int64_t gs_hi, int NB /* N, or N + 1: a virtual all-ones row of x whose column of dW is dbias */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y / G, g = blockIdx.y - b * G, slab = blockIdx.x;
     const int pbeg = slab * kWgradSlab, pend = min(P, pbeg + kWgradSlab);
     const int col = lane & 31, kg = lane >> 5;
-    const int mt = (M + 31) >> 5, nt = (N + 31) >> 5;
+    const int mt = (M + 31) >> 5, nt = (NB + 31) >> 5;
     const T *gb = dy + b * gsb + g * gsg;
     const T *xb = x + b * xsb + g * xsg;
-    float *pb = part + ((size_t)(b * gridDim.x + slab) * G + g) * M * N;
+    float *pb = part + ((size_t)(b * gridDim.x + slab) * G + g) * M * NB;
+    const short kOne = (short)from_f32<T>(1.0f).v;  // 1.0 in the I/O type
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0}, ones8 = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
     const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
                          (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0) && (gs_hi % 8 == 0);
     {
@@ -373,7 +375,7 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         if (tile >= mt * nt) return;
         const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
         const int mrow = m0 + col, nrow = n0 + col;
-        const bool mok = mrow < M, nok = nrow < N;
+        const bool mok = mrow < M, nok = nrow < N, one = nrow == N && NB > N;
         const int mr = mok ? mrow : 0;
         const T *ga = gb + (mr / Mh) * gs_hi + (mr % Mh) * gsm;
         const T *xa = xb + (nok ? nrow : 0) * xsn;
@@ -393,8 +395,8 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const s16x8 af = mok ? __builtin_bit_cast(s16x8, qa[u]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    const s16x8 bf = nok ? __builtin_bit_cast(s16x8, qb[u]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    const s16x8 af = mok ? __builtin_bit_cast(s16x8, qa[u]) : zero8;
+                    const s16x8 bf = nok ? __builtin_bit_cast(s16x8, qb[u]) : (one ? ones8 : zero8);
                     acc = Mfma<T>::run(af, bf, acc);
                 }
             }
@@ -405,8 +407,8 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
             if (aligned && k0 + 8 <= pend) {
                 const u32x4 qa = *reinterpret_cast<const u32x4 *>(ga + k0);
                 const u32x4 qb = *reinterpret_cast<const u32x4 *>(xa + k0);
-                af = mok ? __builtin_bit_cast(s16x8, qa) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                bf = nok ? __builtin_bit_cast(s16x8, qb) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                af = mok ? __builtin_bit_cast(s16x8, qa) : zero8;
+                bf = nok ? __builtin_bit_cast(s16x8, qb) : (one ? ones8 : zero8);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -414,7 +416,7 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
                     const int kc = kok ? k0 + e : pend - 1;
                     const short av = (short)ga[kc].v, bv = (short)xa[kc].v;
                     af[e] = (mok && kok) ? av : (short)0;
-                    bf[e] = (nok && kok) ? bv : (short)0;
+                    bf[e] = kok ? (nok ? bv : (one ? kOne : (short)0)) : (short)0;
                 }
             }
             acc = Mfma<T>::run(af, bf, acc);
@@ -423,7 +425,7 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             const int cn = n0 + col;
-            if (row < M && cn < N) pb[(size_t)row * N + cn] = acc[r];
+            if (row < M && cn < NB) pb[(size_t)row * NB + cn] = acc[r];
         }
     }
 }
@@ -432,7 +434,8 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
 // 64 outputs x 4 slices of the slab list per workgroup: slice s adds slabs s, s + 4, ... (4 loads in flight),
 // the four slice sums are combined in a fixed order.
 __global__ void __launch_bounds__(256)
-oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, int nslab, size_t mn, int G, int N, int Mh) {
+oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int nslab, size_t mn,
+                         int G, int N, int Mh, int NB) {
     __shared__ float red[4][64];
     const int colx = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + colx;
@@ -456,8 +459,10 @@ oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw,
     __syncthreads();
     if (slice == 0 && i < mn) {
         const float t = (red[0][colx] + red[1][colx]) + (red[2][colx] + red[3][colx]);
-        const size_t m = i / N, n = i - m * N;
-        dw[(((m / Mh) * G + g) * Mh + m % Mh) * N + n] = t;
+        const size_t m = i / NB, n = i - m * NB;
+        const size_t row = ((m / Mh) * G + g) * Mh + m % Mh;
+        if (n < (size_t)N) dw[row * N + n] = t;
+        else db[row] = t;
     }
 }
 
@@ -547,26 +552,27 @@ int conv1x1_wgrad_slabs(int P) { return (P + kWgradSlab - 1) / kWgradSlab; }
 
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
                   int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G, int64_t gsg, int64_t xsg, int Mh,
-                  int64_t gs_hi) {
+                  int64_t gs_hi, float *db) {
+    const int NB = N + (db ? 1 : 0);
     if (G < 1 || (size_t)B * G > 65535) return OSS_ERR_SHAPE;
     if (Mh <= 0 || Mh > M) Mh = M;
     const int slabs = conv1x1_wgrad_slabs(P);
-    const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    const int tiles = ((M + 31) / 32) * ((NB + 31) / 32);
     dim3 grid(slabs, B * G, (tiles + 3) / 4);
     switch (io) {
         case OSS_BF16:
             hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(dy),
-                               reinterpret_cast<const bf16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi);
+                               reinterpret_cast<const bf16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB);
             break;
         case OSS_F16:
             hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(dy),
-                               reinterpret_cast<const f16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi);
+                               reinterpret_cast<const f16_t *>(x), part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB);
             break;
         default: return OSS_ERR_SHAPE;
     }
-    const size_t mn = (size_t)M * N;
-    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 63) / 64), G), dim3(256), 0, s, part, dw, slabs * B, mn,
-                       G, N, Mh);
+    const size_t mn = (size_t)M * NB;
+    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 63) / 64), G), dim3(256), 0, s, part, dw, db, slabs * B, mn,
+                       G, N, Mh, NB);
     return (int)hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
 int conv1x1_wgrad_slabs(int P);
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
                   int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G = 1, int64_t gsg = 0, int64_t xsg = 0,
-                  int Mh = 0, int64_t gs_hi = 0);
+                  int Mh = 0, int64_t gs_hi = 0, float *db = nullptr);
 int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
              int L, hipStream_t s);
 int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,

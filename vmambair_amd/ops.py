@@ -624,8 +624,8 @@ def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
-def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor) -> List[torch.Tensor]:
-    """-> [dx (x dtype), dweight (Cout, Cin, 1, 1) fp32]"""
+def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bias: bool = False) -> List[torch.Tensor]:
+    """-> [dx (x dtype), dweight (Cout, Cin, 1, 1) fp32, dbias (Cout) fp32 or empty]"""
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     P = H * W
@@ -635,19 +635,21 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor) -> List
     w = weight.detach().float().reshape(Cout, Cin).contiguous()
     dx = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
     dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
     lib = _capi.load()
     part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         st = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
                                           dy.stride(0), dy.stride(1), st), "oss_conv1x1_dgrad")
-        _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), part.data_ptr(), B, Cout,
-                                          Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), st), "oss_conv1x1_wgrad")
-    return [dx, dw.view(Cout, Cin, 1, 1)]
+        _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
+                                          Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), st),
+                    "oss_conv1x1_wgrad")
+    return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 
 _LIB.define("conv1x1_fwd(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
-_LIB.define("conv1x1_bwd(Tensor x, Tensor weight, Tensor dy) -> Tensor[]")
+_LIB.define("conv1x1_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias) -> Tensor[]")
 _LIB.impl("conv1x1_fwd", conv1x1_fwd, "CUDA")
 _LIB.impl("conv1x1_bwd", conv1x1_bwd, "CUDA")
 
@@ -662,23 +664,22 @@ class Conv1x1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dx, dw = torch.ops.vmambair.conv1x1_bwd(x, weight, dy)
-        db = dy.sum(dim=(0, 2, 3), dtype=torch.float32) if ctx.has_bias else None
-        return dx, dw.to(weight.dtype), db
+        dx, dw, db = torch.ops.vmambair.conv1x1_bwd(x, weight, dy, ctx.has_bias)
+        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None)
 
 
-#: "vendor" (default) or "mfma".  The hand-written MFMA kernels are correct (tests/test_glue_gpu.py) and
-#: cut ~30 launches per block, but their operand loads (2-byte strided reads of the NCHW activations)
-#: make them slower than the vendor implicit-GEMM path end to end (137 vs 122 ms per step,
-#: profiles/r01_rocprof_bench_v10_mfma_conv_reuse_summary.txt); they stay opt-in until the operands
-#: are staged through LDS (ds_read_b64_tr_b16).
-CONV1X1_IMPL = os.environ.get("VMAMBAIR_CONV1X1", "vendor")
+#: "mfma" (default) or "vendor".  16-bit activations go to the in-tree MFMA kernels (pixel-pair tiles: 4-byte
+#: activation loads and result stores, fp32 master weights narrowed in the loader, split-K weight gradient):
+#: 1 launch forward, 3 backward, against ~4 + ~8 of the vendor path (NCHW<->NHWC transposes, casts, tensor-ops
+#: around one implicit-GEMM kernel) and faster per call (profiles/r01_opbench_v14.txt).  float32 activations
+#: always take the vendor conv.  ``VMAMBAIR_CONV1X1=vendor`` keeps everything on the vendor path (A-B timing).
+CONV1X1_IMPL = os.environ.get("VMAMBAIR_CONV1X1", "mfma")
 
 
 def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
     """The 1x1 projections of the block (in_conv / out_conv / project_in / project_out,
-    MambaSISR6_arch.py:205,211,281,329).  Dense GEMMs: vendor conv (MIOpen implicit GEMM on MFMA) by
-    default; ``VMAMBAIR_CONV1X1=mfma`` routes 16-bit activations to the in-tree MFMA kernels."""
+    MambaSISR6_arch.py:205,211,281,329): in-tree MFMA kernels for 16-bit activations (under autocast fp32
+    inputs are narrowed first, as autocast would), vendor conv otherwise."""
     if CONV1X1_IMPL == "mfma" and x.is_cuda:
         if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype("cuda"))

@@ -30,6 +30,8 @@ from typing import Callable, Optional
 import torch
 import torch.distributed as dist
 
+from . import ops as _ops
+
 
 class GraphedTrainStep:
     def __init__(self, net: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), ema_decay: float = 0.999,
@@ -55,6 +57,9 @@ class GraphedTrainStep:
                 if ".conv_cin." in name or ".conv_cout." in name:
                     continue  # consumed in fp32 by the channel branch
                 dense_conv = isinstance(m, torch.nn.Conv2d) and m.groups == 1  # depth-wise convs run on our fp32-weight kernel
+                if dense_conv and m.kernel_size == (1, 1) and _ops.CONV1X1_IMPL == "mfma" and owner.rsplit(".", 1)[-1] in (
+                        "in_conv", "out_conv", "project_in", "project_out", "reduce_chan_level2", "reduce_chan_level3"):
+                    continue  # the MFMA 1x1 kernels read the fp32 masters and narrow them in their loader
                 if dense_conv or leaf in ("x_proj_weight", "dt_projs_weight"):
                     self.shadow[name] = (p, torch.empty_like(p, dtype=autocast_dtype).requires_grad_())
         self._masters = [m for m, _ in self.shadow.values()]
