@@ -187,6 +187,46 @@ void oss_proj_set_path(int force_vector_alu);
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
 
+/* Channel branch of SS2D_1 (MambaSISR6_arch.py:438-483; RealSR form MambaRealSR11_arch.py:758-817) between the
+ * pooled descriptor and the gate vector c, one launch per direction of autograd (oss_channel.hip).  All float.
+ * L = d_inner (the scan runs over the channels), dc = dc_inner (1 for the RealSR form, then cin_* / cout_* are
+ * NULL and seq = pooled), Rc = the channel dt rank, Cc = Rc + 32 (dc_state is 16 in every reference config). */
+typedef struct {
+    int B, L, dc, Rc, Cc, reserved_;
+    const float *pooled;            /* (B, L): mean of y2 over the pixels                                   */
+    const float *cin_w, *cin_b;     /* conv_cin (dc) weight / bias, or NULL                                  */
+    const float *Wxc;               /* xc_proj_weight (2, Cc, dc)                                            */
+    const float *Wdtc;              /* dtc_projs_weight (2, dc, Rc)                                          */
+    const float *dt_bias;           /* dtc_projs_bias (2 dc)                                                 */
+    const float *A_logs;            /* Ac_logs (2 dc, 16)                                                    */
+    const float *Dsc;               /* (2 dc)                                                                */
+    const float *cout_w, *cout_b;   /* conv_cout (dc) weight / (1) bias, or NULL                             */
+    const float *cn_w, *cn_b;       /* channel_norm weight / bias (L)                                        */
+    float *zt;                      /* (B, 2, L, Cc)   saved: projections, c fastest                         */
+    float *dts;                     /* (B, 2 dc, L)    saved: dt_proj output before bias / softplus          */
+    float *hs;                      /* (B, 2 dc, L, 16) saved: the scan state after every step               */
+    float *y;                       /* (B, 2 dc, L)    saved: scan outputs (direction 1 stored un-flipped)   */
+    float *yc;                      /* (B, L)          saved: LayerNorm input                                */
+    float *stat;                    /* (B, 2)          saved: LayerNorm mean, rstd                           */
+    float *c;                       /* (B, L)          OUT: the gate vector                                  */
+} oss_chan_params;
+int oss_chan_fwd(const oss_chan_params *p, oss_stream_t stream);
+/* gc: gradient of c (B, L).  OUT dpooled (B, L); grads: oss_chan_grad_floats() floats = the parameter gradients
+ * summed over the batch in batch order, laid out [cn_w L | cn_b L | cout_w dc | cout_b 1 | Ac_logs 2 dc 16 |
+ * Dsc 2 dc | dt_bias 2 dc | Wdtc 2 dc Rc | Wxc 2 Cc dc | cin_w dc | cin_b dc]; scratch:
+ * oss_chan_bwd_scratch_floats() floats. */
+size_t oss_chan_grad_floats(int L, int dc, int Rc, int Cc);
+size_t oss_chan_bwd_scratch_floats(int B, int L, int dc, int Rc, int Cc);
+int oss_chan_bwd(const oss_chan_params *p, const float *gc, float *dpooled, float *grads, float *scratch, oss_stream_t stream);
+/* out[b, c] = alpha * sum_p a[b, c, p] * (bmul ? bmul[b, c, p] : 1)  (pooling, and the gate's gradient);
+ * y[b, c, p] = x[b, c, p] * (mul ? 1 + mul[b, c] : 1) + (add ? alpha * add[b, c] : 0)  (the gate and its adjoint).
+ * a, bmul, x: io dtype, contiguous planes, element strides (batch, channel); y contiguous. */
+int oss_rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int batch, int channels, int pixels,
+               int64_t a_batch_stride, int64_t a_channel_stride, int64_t b_batch_stride, int64_t b_channel_stride, float alpha,
+               oss_stream_t stream);
+int oss_row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int batch, int channels,
+                   int pixels, int64_t x_batch_stride, int64_t x_channel_stride, float alpha, oss_stream_t stream);
+
 /* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
  * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3
  * column-major) -> y (batch, D, H, W) float = ((o0 + o2) + T o1) + T o3, the reference's association

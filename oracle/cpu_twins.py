@@ -155,7 +155,59 @@ def install():
         gr = torch.autograd.grad(y, leaves, dy.float())
         return [gr[0].to(x2.dtype), gr[1], gr[2], gr[3], gr[4], gr[5]]
 
+    def _chan_ref(y2, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b, cn_w, cn_b, mul_mode):
+        """literal reference data flow of the channel branch + gate (MambaSISR6_arch.py:438-496; RealSR form
+        MambaRealSR11_arch.py:758-817) on the oracle scan, differentiable: stack / flip of the two directions"""
+        b, d, H, W = y2.shape
+        pooled = y2.mean(dim=(2, 3))
+        if cin_w is not None:
+            dc = cin_w.shape[0]
+            seq = F.conv2d(pooled.view(b, 1, d, 1), cin_w.view(dc, 1, 1, 1), cin_b).squeeze(-1)      # (b, dc, L = d)
+        else:
+            dc = 1
+            seq = pooled.view(b, 1, d)
+        Rc, N = Wdtc.shape[2], A_logs.shape[1]
+        xsc = torch.stack([seq, seq.flip(-1)], dim=1)
+        z = torch.einsum("bkdl,kcd->bkcl", xsc, Wxc)
+        dts, Bs, Cs = torch.split(z, [Rc, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, Wdtc).contiguous()
+        out = oss_oracle.OracleScanFn.apply(xsc.reshape(b, -1, d), dts.view(b, -1, d), -torch.exp(A_logs), Bs.contiguous(),
+                                            Cs.contiguous(), Dsc, dt_bias.reshape(-1), True).view(b, 2, dc, d)
+        y = out[:, 0] + out[:, 1].flip(-1)
+        if cout_w is not None:
+            y = F.conv2d(y.unsqueeze(-1), cout_w.view(1, dc, 1, 1), cout_b).view(b, d)
+        else:
+            y = y.reshape(b, d)
+        c = F.layer_norm(y, (d,), cn_w, cn_b, 1e-5).view(b, d, 1, 1)
+        return (y2 * c + y2) if mul_mode else (y2 + c), c.view(b, d)
+
+    def chan_fwd(y2, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b, cn_w, cn_b, mul_mode):
+        f = lambda t: None if t is None else t.float()
+        with torch.no_grad():
+            out, c = _chan_ref(y2.float(), f(cin_w), f(cin_b), Wxc.float(), Wdtc.float(), dt_bias.float(), A_logs.float(),
+                               Dsc.float(), f(cout_w), f(cout_b), cn_w.float(), cn_b.float(), mul_mode)
+        e = torch.empty(0)
+        return [out.to(y2.dtype), c, e, e, e, e, e, e, e]
+
+    def chan_bwd(g, y2, c, pooled, zt, dts, hs, y, yc, stat, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
+                 cn_w, cn_b, mul_mode):
+        prm = [cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b, cn_w, cn_b]
+        leaves = [y2.detach().float().requires_grad_()] + [None if t is None else t.detach().float().requires_grad_() for t in prm]
+        with torch.enable_grad():
+            out, _ = _chan_ref(*leaves, mul_mode)
+        live = [t for t in leaves if t is not None]
+        gr = dict(zip([id(t) for t in live], torch.autograd.grad(out, live, g.float(), allow_unused=True)))
+        get = lambda t, n: torch.zeros(n) if t is None else (gr[id(t)] if gr[id(t)] is not None else torch.zeros_like(t)).reshape(-1)
+        dc = Wdtc.shape[1]
+        lv = leaves[1:]
+        # flat layout of oss_chan_bwd: cn_w, cn_b, cout_w, cout_b, A_logs, Dsc, dt_bias, Wdtc, Wxc, cin_w, cin_b
+        flat = torch.cat([get(lv[9], 0), get(lv[10], 0), get(lv[7], dc), get(lv[8], 1), get(lv[5], 0), get(lv[6], 0),
+                          get(lv[4], 0), get(lv[3], 0), get(lv[2], 0), get(lv[0], dc), get(lv[1], dc)])
+        return [gr[id(leaves[0])].to(y2.dtype), flat]
+
     _CPU_LIB = torch.library.Library("vmambair", "IMPL")
+    _CPU_LIB.impl("chan_gate_fwd", chan_fwd, "CPU")
+    _CPU_LIB.impl("chan_gate_bwd", chan_bwd, "CPU")
     _CPU_LIB.impl("ss2d_core_fwd", core_fwd, "CPU")
     _CPU_LIB.impl("ss2d_core_bwd", core_bwd, "CPU")
     _CPU_LIB.impl("ln_nchw_fwd", ln_fwd, "CPU")

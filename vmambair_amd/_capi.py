@@ -50,12 +50,19 @@ class ScanBwdParams(C.Structure):
     ]
 
 
+class ChanParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_int), ("dc", C.c_int), ("Rc", C.c_int), ("Cc", C.c_int), ("reserved_", C.c_int)] + \
+        [(n, C.c_void_p) for n in ("pooled", "cin_w", "cin_b", "Wxc", "Wdtc", "dt_bias", "A_logs", "Dsc", "cout_w", "cout_b",
+                                    "cn_w", "cn_b", "zt", "dts", "hs", "y", "yc", "stat", "c")]
+
+
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_set_variant", "oss_scan_last_variant", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
-           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_hbm_copy", "oss_version"]
+           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
+           "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_hbm_copy", "oss_version"]
 
 _lib = None
 
@@ -131,6 +138,18 @@ def load():
     lib.oss_proj_set_path.argtypes = [C.c_int]
     lib.oss_proj_wgrad.restype = C.c_int
     lib.oss_proj_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]
+    lib.oss_chan_fwd.restype = C.c_int
+    lib.oss_chan_fwd.argtypes = [C.POINTER(ChanParams), C.c_void_p]
+    lib.oss_chan_grad_floats.restype = C.c_size_t
+    lib.oss_chan_grad_floats.argtypes = [C.c_int] * 4
+    lib.oss_chan_bwd_scratch_floats.restype = C.c_size_t
+    lib.oss_chan_bwd_scratch_floats.argtypes = [C.c_int] * 5
+    lib.oss_chan_bwd.restype = C.c_int
+    lib.oss_chan_bwd.argtypes = [C.POINTER(ChanParams)] + [C.c_void_p] * 5
+    lib.oss_rowsum.restype = C.c_int
+    lib.oss_rowsum.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
+    lib.oss_row_affine.restype = C.c_int
+    lib.oss_row_affine.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_int64] * 2 + [C.c_float, C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_version.restype = C.c_char_p

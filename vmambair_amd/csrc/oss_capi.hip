@@ -262,6 +262,33 @@ int oss_cross_merge2(oss_dtype io, const void *g2, void *dx, int batch, int D, i
     return cross_merge2(io, g2, dx, batch, D, height, width, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_chan_fwd(const oss_chan_params *p, oss_stream_t stream) {
+    if (!p) return OSS_ERR_NULL;
+    return chan_fwd(*p, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t oss_chan_grad_floats(int L, int dc, int Rc, int Cc) { return chan_grad_floats(L, dc, Rc, Cc); }
+size_t oss_chan_bwd_scratch_floats(int B, int L, int dc, int Rc, int Cc) { return chan_bwd_scratch_floats(B, L, dc, Rc, Cc); }
+
+int oss_chan_bwd(const oss_chan_params *p, const float *gc, float *dpooled, float *grads, float *scratch, oss_stream_t stream) {
+    if (!p) return OSS_ERR_NULL;
+    return chan_bwd(*p, gc, dpooled, grads, scratch, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int batch, int channels, int pixels, int64_t asb,
+               int64_t asc, int64_t bsb, int64_t bsc, float alpha, oss_stream_t stream) {
+    if (!a || !out) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || pixels <= 0) return OSS_ERR_SHAPE;
+    return rowsum(io, a, bmul, out, batch, channels, pixels, asb, asc, bsb, bsc, alpha, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int batch, int channels, int pixels,
+                   int64_t xsb, int64_t xsc, float alpha, oss_stream_t stream) {
+    if (!x || !y) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || pixels <= 0) return OSS_ERR_SHAPE;
+    return row_affine(io, x, mul, add, y, batch, channels, pixels, xsb, xsc, alpha, reinterpret_cast<hipStream_t>(stream));
+}
+
 int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
     if (!out || !y) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;

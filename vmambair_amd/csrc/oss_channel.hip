@@ -1,0 +1,390 @@
+// oss_channel.hip -- the channel branch of SS2D_1 (the two channel-direction scans of the Omni Selective Scan,
+// SRGAN/VmambaIR/archs/MambaSISR6_arch.py:438-483,495-496; RealSR rank-R form MambaRealSR11_arch.py:758-817):
+//   pooled[b, l] = mean over pixels of y2[b, l]                (l runs over the d_inner channels: L = d_inner)
+//   seq[i, l]    = cin_w[i] pooled[l] + cin_b[i]               (the 1 -> dc_inner lift; identity for RealSR)
+//   z[k, c, l]   = sum_i xc_proj[k, c, i] seq[i, l];  dts[k, i, l] = sum_r dtc_w[k, i, r] z[k, r, l]
+//   y[k, i, :]   = selective scan of row (k, i) over l (k = 1: from l = L-1 down to 0), A = -exp(Ac_logs), D = Dsc
+//   yc[l]        = sum_i cout_w[i] (y[0, i, l] + y[1, i, l]) + cout_b;   c = LayerNorm_l(yc)
+//   out          = y2 * c + y2   ("mul_add")   or   y2 + c   ("add")
+// Everything between the pooling and the gate is a few thousand numbers per image.  The reference (and any
+// op-by-op port) spends ~15 launches forward and ~20 backward on it; here: one workgroup per image does the
+// whole thing in one launch per direction of autograd, plus row reductions / row-affine passes over the
+// (B, d, H, W) tensor at both ends.  fp32 throughout (the RealSR tree forces fp32 here even under AMP).
+//
+// Scan layout inside the workgroup: wave k = direction k, lane = (row i of the direction) * 16 + state n; the
+// time loop is serial (L <= 768 steps), sums over the 16 states are DPP row reductions, sums over the rows of
+// a direction cross the 16-lane rows with ds_bpermute.  The states h[row, l, n] of every step are kept in HBM
+// for the backward recurrence (it needs h_{t-1}; 8 x 768 x 16 floats per image at most).
+#include "oss_device.h"
+#include "oss_host.h"
+
+namespace oss {
+
+constexpr int kChN = 16;  // dc_state of every reference config
+
+__device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/, int tid) {
+    const float w = segment_sum_to_last<64>(v);
+    __syncthreads();  // red may still be read from a previous call
+    if ((tid & 63) == 63) red[tid >> 6] = w;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// sum over the rows i of a direction (lanes n, 16 + n, 32 + n, 48 + n); every lane gets the total
+__device__ __forceinline__ float sum_over_rows(float v, int lane) {
+    v += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_int(v)));
+    v += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+oss_chan_fwd_kernel(oss_chan_params p) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
+    const bool lift = p.cin_w != nullptr;
+    float *seq = sm;                 // [dc][L]
+    float *ybuf = seq + dc * L;      // [2 dc][L]
+    float *ycs = ybuf + 2 * dc * L;  // [L]
+    float *red = ycs + L;            // [4]
+    for (int l = tid; l < L; l += 256) {
+        const float pl = p.pooled[(size_t)b * L + l];
+        for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
+    }
+    __syncthreads();
+    float *zb = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
+    for (int idx = tid; idx < 2 * L * Cc; idx += 256) {
+        const int k = idx / (L * Cc), rem = idx - k * L * Cc, l = rem / Cc, c = rem - l * Cc;
+        float s = 0.f;
+        for (int i = 0; i < dc; ++i) s = __builtin_fmaf(p.Wxc[(k * Cc + c) * dc + i], seq[i * L + l], s);
+        zb[idx] = s;
+    }
+    __syncthreads();
+    float *db = p.dts + (size_t)b * 2 * dc * L;
+    for (int idx = tid; idx < 2 * dc * L; idx += 256) {
+        const int row = idx / L, l = idx - row * L, k = row / dc;
+        float s = 0.f;
+        for (int r = 0; r < Rc; ++r) s = __builtin_fmaf(p.Wdtc[row * Rc + r], zb[(k * L + l) * Cc + r], s);
+        db[idx] = s;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < 2) {
+        const int k = wave, i = lane >> 4, n = lane & 15;
+        const bool act = i < dc;
+        const int row = k * dc + (act ? i : 0);
+        const float A2 = -__expf(p.A_logs[row * kChN + n]) * kLog2e;
+        const float Dv = p.Dsc[row], bias = p.dt_bias[row];
+        const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
+        float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
+        float h = 0.f;
+        for (int t = 0; t < L; ++t) {
+            const int l = k ? L - 1 - t : t;
+            float e;
+            const float dl = softplus_thr(dr[l] + bias, e);
+            const float u = ur[l];
+            const float *zr = zb + (k * L + l) * Cc + Rc;
+            const float Bv = zr[n], Cv = zr[kChN + n];
+            h = __builtin_fmaf(exp2_hw(dl * A2), h, dl * Bv * u);
+            if (act) hr[l * kChN + n] = h;
+            const float tot = segment_sum_to_last<16>(Cv * h);
+            if (n == 15 && act) ybuf[row * L + l] = __builtin_fmaf(Dv, u, tot);
+        }
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        float s = lift ? p.cout_b[0] : 0.f;
+        for (int i = 0; i < dc; ++i) s = __builtin_fmaf(lift ? p.cout_w[i] : 1.f, ybuf[i * L + l] + ybuf[(dc + i) * L + l], s);
+        ycs[l] = s;
+        part += s;
+    }
+    for (int idx = tid; idx < 2 * dc * L; idx += 256) p.y[(size_t)b * 2 * dc * L + idx] = ybuf[idx];
+    const float mu = block_sum_256(part, red, tid) / (float)L;
+    float q = 0.f;
+    for (int l = tid; l < L; l += 256) { const float d = ycs[l] - mu; q = __builtin_fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(block_sum_256(q, red, tid) / (float)L + 1e-5f);
+    for (int l = tid; l < L; l += 256) {
+        p.yc[(size_t)b * L + l] = ycs[l];
+        p.c[(size_t)b * L + l] = __builtin_fmaf((ycs[l] - mu) * rstd, p.cn_w[l], p.cn_b[l]);
+    }
+    if (tid == 0) { p.stat[b * 2] = mu; p.stat[b * 2 + 1] = rstd; }
+}
+
+// gradient slots of one image in gpart (B, NP); oss_chan_grad_floats() = NP
+struct ChanSlots {
+    int cnw, cnb, coutw, coutb, dA, dD, dbias, wdtc, wxc, cinw, cinb, total;
+    __host__ __device__ ChanSlots(int L, int dc, int Rc, int Cc) {
+        cnw = 0; cnb = L; coutw = 2 * L; coutb = coutw + dc; dA = coutb + 1; dD = dA + 2 * dc * kChN; dbias = dD + 2 * dc;
+        wdtc = dbias + 2 * dc; wxc = wdtc + 2 * dc * Rc; cinw = wxc + 2 * Cc * dc; cinb = cinw + dc; total = cinb + dc;
+    }
+};
+
+__global__ void __launch_bounds__(256)
+oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): grad of c*/, float *__restrict__ dpool,
+                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
+    const bool lift = p.cin_w != nullptr;
+    const ChanSlots sl(L, dc, Rc, Cc);
+    float *seq = sm;              // [dc][L]
+    float *dys = seq + dc * L;    // [L]   grad of yc
+    float *dsq = dys + L;         // [dc][L] grad of seq
+    float *red = dsq + dc * L;    // [4]
+    float *gp = gpart + (size_t)b * sl.total;
+    const float mu = p.stat[b * 2], rstd = p.stat[b * 2 + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int l = tid; l < L; l += 256) {
+        const float pl = p.pooled[(size_t)b * L + l];
+        for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
+        const float g0 = gc[(size_t)b * L + l], xh = (p.yc[(size_t)b * L + l] - mu) * rstd, g = g0 * p.cn_w[l];
+        gp[sl.cnw + l] = g0 * xh;
+        gp[sl.cnb + l] = g0;
+        s1 += g;
+        s2 = __builtin_fmaf(g, xh, s2);
+    }
+    const float m1 = block_sum_256(s1, red, tid) / (float)L;
+    const float m2 = block_sum_256(s2, red, tid) / (float)L;
+    for (int l = tid; l < L; l += 256) {
+        const float xh = (p.yc[(size_t)b * L + l] - mu) * rstd, g = gc[(size_t)b * L + l] * p.cn_w[l];
+        dys[l] = rstd * (g - m1 - xh * m2);
+    }
+    __syncthreads();
+    const float *yb = p.y + (size_t)b * 2 * dc * L;
+    if (lift) {
+        for (int i = 0; i < dc; ++i) {
+            float a = 0.f;
+            for (int l = tid; l < L; l += 256) a = __builtin_fmaf(dys[l], yb[i * L + l] + yb[(dc + i) * L + l], a);
+            const float t = block_sum_256(a, red, tid);
+            if (tid == 0) gp[sl.coutw + i] = t;
+        }
+        float a = 0.f;
+        for (int l = tid; l < L; l += 256) a += dys[l];
+        const float t = block_sum_256(a, red, tid);
+        if (tid == 0) gp[sl.coutb] = t;
+    } else if (tid < dc + 1) {
+        gp[sl.coutw + tid] = 0.f;  // dc slots + the bias slot (unused without the lift)
+    }
+    const float *zb = p.zt + (size_t)b * 2 * L * Cc;
+    const float *db = p.dts + (size_t)b * 2 * dc * L;
+    float *dzb = dzt + (size_t)b * 2 * L * Cc;
+    float *ddb = ddts + (size_t)b * 2 * dc * L;
+    float *dub = dug + (size_t)b * 2 * dc * L;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave < 2) {
+        const int k = wave, i = lane >> 4, n = lane & 15;
+        const bool act = i < dc;
+        const int row = k * dc + (act ? i : 0);
+        const float A = -__expf(p.A_logs[row * kChN + n]), A2 = A * kLog2e;
+        const float Dv = p.Dsc[row], bias = p.dt_bias[row];
+        const float cw = act ? (lift ? p.cout_w[i] : 1.f) : 0.f;
+        const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
+        const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
+        float carry = 0.f, dA = 0.f, dD = 0.f, dbs = 0.f;
+        for (int t = L - 1; t >= 0; --t) {
+            const int l = k ? L - 1 - t : t, lp = k ? l + 1 : l - 1;
+            const float x = dr[l] + bias;
+            float e;
+            const float dl = softplus_thr(x, e);
+            const float sig = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+            const float u = ur[l];
+            const float *zr = zb + (k * L + l) * Cc + Rc;
+            const float Bv = zr[n], Cv = zr[kChN + n];
+            const float a = exp2_hw(dl * A2);
+            const float h = hr[l * kChN + n], hp = t > 0 ? hr[lp * kChN + n] : 0.f;
+            const float dyv = cw * dys[l];
+            const float dh = __builtin_fmaf(dyv, Cv, carry);
+            const float dCs = sum_over_rows(dyv * h, lane);
+            const float dBs = sum_over_rows(dh * dl * u, lane);
+            if (i == 0) {
+                float *dz = dzb + (k * L + l) * Cc + Rc;
+                dz[n] = dBs;
+                dz[kChN + n] = dCs;
+            }
+            const float ddl = segment_sum_to_last<16>(dh * __builtin_fmaf(A * a, hp, Bv * u));
+            const float du = segment_sum_to_last<16>(dh * dl * Bv);
+            dA = __builtin_fmaf(dh * dl * a, hp, dA);
+            carry = a * dh;
+            if (n == 15 && act) {
+                const float ddt = ddl * sig;
+                ddb[row * L + l] = ddt;
+                dub[row * L + l] = __builtin_fmaf(dyv, Dv, du);
+                dbs += ddt;
+                dD = __builtin_fmaf(dyv, u, dD);
+            }
+        }
+        if (act) {
+            gp[sl.dA + row * kChN + n] = dA * A;  // d/dA_log: A = -exp(A_log)
+            if (n == 15) { gp[sl.dD + row] = dD; gp[sl.dbias + row] = dbs; }
+        }
+    }
+    __syncthreads();
+    // dt rows of dz
+    for (int idx = tid; idx < 2 * L * Rc; idx += 256) {
+        const int k = idx / (L * Rc), rem = idx - k * L * Rc, l = rem / Rc, r = rem - l * Rc;
+        float s = 0.f;
+        for (int i = 0; i < dc; ++i) s = __builtin_fmaf(p.Wdtc[(k * dc + i) * Rc + r], ddb[(k * dc + i) * L + l], s);
+        dzb[(k * L + l) * Cc + r] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < dc * L; idx += 256) {
+        const int i = idx / L, l = idx - i * L;
+        float s = dub[i * L + l] + dub[(dc + i) * L + l];
+        for (int k = 0; k < 2; ++k) {
+            const float *dz = dzb + (k * L + l) * Cc;
+            for (int c = 0; c < Cc; ++c) s = __builtin_fmaf(p.Wxc[(k * Cc + c) * dc + i], dz[c], s);
+        }
+        dsq[idx] = s;
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += 256) {
+        float s = 0.f;
+        for (int i = 0; i < dc; ++i) s = lift ? __builtin_fmaf(p.cin_w[i], dsq[i * L + l], s) : s + dsq[i * L + l];
+        dpool[(size_t)b * L + l] = s;
+    }
+    // parameter gradients that are sums over l: one output per thread
+    const int n_wdtc = 2 * dc * Rc, n_wxc = 2 * Cc * dc;
+    for (int o = tid; o < n_wdtc + n_wxc + 2 * dc; o += 256) {
+        float s = 0.f;
+        if (o < n_wdtc) {
+            const int row = o / Rc, r = o - row * Rc, k = row / dc;
+            for (int l = 0; l < L; ++l) s = __builtin_fmaf(ddb[row * L + l], zb[(k * L + l) * Cc + r], s);
+            gp[sl.wdtc + o] = s;
+        } else if (o < n_wdtc + n_wxc) {
+            const int q = o - n_wdtc, i = q % dc, kc = q / dc, k = kc / Cc, c = kc - k * Cc;
+            for (int l = 0; l < L; ++l) s = __builtin_fmaf(dzb[(k * L + l) * Cc + c], seq[i * L + l], s);
+            gp[sl.wxc + q] = s;
+        } else {
+            const int q = o - n_wdtc - n_wxc, i = q % dc;
+            if (lift) {
+                if (q < dc) { for (int l = 0; l < L; ++l) s = __builtin_fmaf(dsq[i * L + l], p.pooled[(size_t)b * L + l], s); }
+                else        { for (int l = 0; l < L; ++l) s += dsq[i * L + l]; }
+            }
+            gp[sl.cinw + q] = s;
+        }
+    }
+}
+
+// gsum[j] = sum_b gpart[b][j] in batch order
+__global__ void __launch_bounds__(256)
+oss_chan_grad_finish(const float *__restrict__ gpart, float *__restrict__ gsum, int B, int NP) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= NP) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += gpart[(size_t)b * NP + j];
+    gsum[j] = s;
+}
+
+// out[row] = alpha * sum_p a[row, p] * (bmul ? bmul[row, p] : 1);  rows = batch * channels, planes contiguous
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_rowsum_kernel(const T *__restrict__ a, const T *__restrict__ bmul, float *__restrict__ out, int C, int P, int64_t asb,
+                  int64_t asc, int64_t bsb, int64_t bsc, float alpha) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row / C, c = row - b * C, tid = threadIdx.x;
+    const T *ap = a + b * asb + c * asc;
+    const T *bp = bmul ? bmul + b * bsb + c * bsc : nullptr;
+    float s = 0.f;
+    const bool vec = (P % 8 == 0) && ((reinterpret_cast<uintptr_t>(ap) | reinterpret_cast<uintptr_t>(bp)) & 15u) == 0;
+    if (vec) {
+        for (int p = tid * 8; p < P; p += 2048) {
+            float av[8], bv[8];
+            load_items<8>(ap + p, 8, true, av);
+            if (bp) load_items<8>(bp + p, 8, true, bv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s = bp ? __builtin_fmaf(av[i], bv[i], s) : s + av[i];
+        }
+    } else {
+        for (int p = tid; p < P; p += 256) s = bp ? __builtin_fmaf(to_f32(ap[p]), to_f32(bp[p]), s) : s + to_f32(ap[p]);
+    }
+    const float t = block_sum_256(s, red, tid);
+    if (tid == 0) out[row] = t * alpha;
+}
+
+// y[row, p] = x[row, p] * (mul ? 1 + mul[row] : 1) + (add ? alpha * add[row] : 0)
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_row_affine_kernel(const T *__restrict__ x, const float *__restrict__ mul, const float *__restrict__ add, T *__restrict__ y,
+                      int C, int P, int64_t xsb, int64_t xsc, float alpha) {
+    const int row = blockIdx.y, b = row / C, c = row - b * C;
+    const T *xp = x + b * xsb + c * xsc;
+    T *yp = y + (size_t)row * P;
+    const float sc = mul ? 1.f + mul[row] : 1.f, sh = add ? alpha * add[row] : 0.f;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p >= P) return;
+    const bool vec = (P % 8 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & 15u) == 0;
+    float v[8];
+    const int valid = min(8, P - p);
+    load_items<8>(xp + p, valid, vec, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = __builtin_fmaf(v[i], sc, sh);
+    store_items<8>(yp + p, valid, vec, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+size_t chan_grad_floats(int L, int dc, int Rc, int Cc) { return (size_t)ChanSlots(L, dc, Rc, Cc).total; }
+
+static int chan_check(const oss_chan_params &p) {
+    if (p.B <= 0 || p.L <= 0 || p.dc < 1 || p.dc > 4 || p.Rc < 1 || p.Cc != p.Rc + 2 * kChN) return OSS_ERR_SHAPE;
+    if (!p.pooled || !p.Wxc || !p.Wdtc || !p.dt_bias || !p.A_logs || !p.Dsc || !p.cn_w || !p.cn_b || !p.zt || !p.dts || !p.hs ||
+        !p.y || !p.yc || !p.stat || !p.c)
+        return OSS_ERR_NULL;
+    if ((p.cin_w != nullptr) != (p.cout_w != nullptr)) return OSS_ERR_NULL;
+    if (p.cin_w && (!p.cin_b || !p.cout_b)) return OSS_ERR_NULL;
+    return 0;
+}
+
+int chan_fwd(const oss_chan_params &p, hipStream_t s) {
+    if (int e = chan_check(p)) return e;
+    const size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + 4);
+    if (smem > 48 * 1024) return OSS_ERR_SHAPE;
+    hipLaunchKernelGGL(oss_chan_fwd_kernel, dim3(p.B), dim3(256), smem, s, p);
+    return (int)hipGetLastError();
+}
+
+int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsum, float *scratch, hipStream_t s) {
+    if (int e = chan_check(p)) return e;
+    if (!gc || !dpool || !gsum || !scratch) return OSS_ERR_NULL;
+    const size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + 4);
+    if (smem > 48 * 1024) return OSS_ERR_SHAPE;
+    const size_t np = chan_grad_floats(p.L, p.dc, p.Rc, p.Cc);
+    float *gpart = scratch;
+    float *dzt = gpart + (size_t)p.B * np;
+    float *ddts = dzt + (size_t)p.B * 2 * p.L * p.Cc;
+    float *dug = ddts + (size_t)p.B * 2 * p.dc * p.L;
+    hipLaunchKernelGGL(oss_chan_bwd_kernel, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
+    hipLaunchKernelGGL(oss_chan_grad_finish, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, gsum, p.B, (int)np);
+    return (int)hipGetLastError();
+}
+
+size_t chan_bwd_scratch_floats(int B, int L, int dc, int Rc, int Cc) {
+    return (size_t)B * (chan_grad_floats(L, dc, Rc, Cc) + 2 * (size_t)L * Cc + 4 * (size_t)dc * L);
+}
+
+int rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int B, int C, int P, int64_t asb, int64_t asc, int64_t bsb,
+           int64_t bsc, float alpha, hipStream_t s) {
+    dim3 grid(B * C);
+    switch (io) {
+        case OSS_F32: hipLaunchKernelGGL(oss_rowsum_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const float *>(a), reinterpret_cast<const float *>(bmul), out, C, P, asb, asc, bsb, bsc, alpha); break;
+        case OSS_F16: hipLaunchKernelGGL(oss_rowsum_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(a), reinterpret_cast<const f16_t *>(bmul), out, C, P, asb, asc, bsb, bsc, alpha); break;
+        case OSS_BF16: hipLaunchKernelGGL(oss_rowsum_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(a), reinterpret_cast<const bf16_t *>(bmul), out, C, P, asb, asc, bsb, bsc, alpha); break;
+        default: return OSS_ERR_SHAPE;
+    }
+    return (int)hipGetLastError();
+}
+
+int row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int B, int C, int P, int64_t xsb,
+               int64_t xsc, float alpha, hipStream_t s) {
+    if ((long)B * C > 65535) return OSS_ERR_SHAPE;
+    dim3 grid((P + 2047) / 2048, B * C);
+    switch (io) {
+        case OSS_F32: hipLaunchKernelGGL(oss_row_affine_kernel<float>, grid, dim3(256), 0, s, reinterpret_cast<const float *>(x), mul, add, reinterpret_cast<float *>(y), C, P, xsb, xsc, alpha); break;
+        case OSS_F16: hipLaunchKernelGGL(oss_row_affine_kernel<f16_t>, grid, dim3(256), 0, s, reinterpret_cast<const f16_t *>(x), mul, add, reinterpret_cast<f16_t *>(y), C, P, xsb, xsc, alpha); break;
+        case OSS_BF16: hipLaunchKernelGGL(oss_row_affine_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(x), mul, add, reinterpret_cast<bf16_t *>(y), C, P, xsb, xsc, alpha); break;
+        default: return OSS_ERR_SHAPE;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace oss

@@ -46,5 +46,13 @@ void proj_force_valu(int on);
 int cross_scan2(oss_dtype it, oss_dtype ot, const void *x, void *x2, int B, int D, int H, int W, int64_t xsb, int64_t xsc,
                 hipStream_t s);
 int cross_merge2(oss_dtype io, const void *g2, void *dx, int B, int D, int H, int W, hipStream_t s);
+size_t chan_grad_floats(int L, int dc, int Rc, int Cc);
+size_t chan_bwd_scratch_floats(int B, int L, int dc, int Rc, int Cc);
+int chan_fwd(const oss_chan_params &p, hipStream_t s);
+int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsum, float *scratch, hipStream_t s);
+int rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int B, int C, int P, int64_t asb, int64_t asc, int64_t bsb,
+           int64_t bsc, float alpha, hipStream_t s);
+int row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int B, int C, int P, int64_t xsb,
+               int64_t xsc, float alpha, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import SS2DCoreFn, conv1x1, core_supported, dwconv3x3, layer_norm_nchw
+from .ops import ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, layer_norm_nchw
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
@@ -106,6 +106,7 @@ class SS2D_1(nn.Module):
         self.omni = True  # False: literal reference data flow (forward_core_xs)
         self.fused_merge = True  # scan + cross-merge as one autograd node (HIP merge kernel)
         self.fused_core = True   # ... and the flattenings and projections in front of it (SS2DCoreFn)
+        self.fused_channel = True  # channel branch + gate as one autograd node (ChannelGateFn)
         R, N = self.dt_rank, d_state
 
         self.in_conv = nn.Conv2d(d_model, d_expand * 2, kernel_size=1)
@@ -283,6 +284,16 @@ class SS2D_1(nn.Module):
         x, z = xz.chunk(2, dim=1)
         x = F.silu(dwconv3x3(x, self.conv2d))
         y2 = self.forward_core(x, gate=z)  # out_norm(merge) * silu(z), fused in the LayerNorm kernel
+        if self.omni and self.fused_channel and y2.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
+                chan_supported(self.dc_inner or 1, self.dc_state, self.d_inner):
+            # pooling + channel scans + LayerNorm + gate as one autograd node (oss_channel.hip)
+            lift = self.dc_inner is not None
+            y2 = ChannelGateFn.apply(
+                y2, self.conv_cin.weight if lift else None, self.conv_cin.bias if lift else None, self.xc_proj_weight,
+                self.dtc_projs_weight, self.dtc_projs_bias, self.Ac_logs, self.Dsc, self.conv_cout.weight if lift else None,
+                self.conv_cout.bias if lift else None, self.channel_norm.body.weight, self.channel_norm.body.bias,
+                self.gate != "add")
+            return conv1x1(y2, self.out_conv)
         c = self.cforward_core(y2)
         y2 = (y2 + c) if self.gate == "add" else torch.addcmul(y2, y2, c)  # y2 * c + y2
         return conv1x1(y2, self.out_conv)
