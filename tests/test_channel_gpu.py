@@ -87,7 +87,7 @@ def test_fused_channel_branch_against_oracle_twin(variant, oracle_cpu_kernel):
         mm = m.to(dev)
         pr = dict(mm.named_parameters())
         args = [pr[n] if (lift or not n.startswith("conv_c")) else None for n in names]
-        yi = y2.to(dev).requires_grad_()
+        yi = y2.detach().clone().to(dev).requires_grad_()
         mm.zero_grad()
         out = ops.ChannelGateFn.apply(yi, *args, mm.gate != "add")
         out.backward(g.to(dev))
