@@ -227,6 +227,14 @@ int oss_rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int ba
 int oss_row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int batch, int channels,
                    int pixels, int64_t x_batch_stride, int64_t x_channel_stride, float alpha, oss_stream_t stream);
 
+/* Gate of the EFFN (MambaSISR6_arch.py:213-217): h (batch, 2, half_elems) = the two channel halves of
+ * dwconv(project_in(x)) (halves contiguous, element batch stride given); out (batch, half_elems) = gelu(h[:, 0]) * h[:, 1]
+ * with the exact (erf) gelu; bwd writes the gradient of both halves, dh (batch, 2, half_elems) contiguous. */
+int oss_gelu_gate_fwd(oss_dtype io, const void *h, void *out, int batch, size_t half_elems, int64_t h_batch_stride,
+                      oss_stream_t stream);
+int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int batch, size_t half_elems,
+                      int64_t h_batch_stride, int64_t dout_batch_stride, oss_stream_t stream);
+
 /* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
  * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3
  * column-major) -> y (batch, D, H, W) float = ((o0 + o2) + T o1) + T o3, the reference's association

@@ -205,7 +205,20 @@ def install():
                           get(lv[4], 0), get(lv[3], 0), get(lv[2], 0), get(lv[0], dc), get(lv[1], dc)])
         return [gr[id(leaves[0])].to(y2.dtype), flat]
 
+    def gg_fwd(h):
+        x1, x2 = h.float().chunk(2, dim=1)
+        return (F.gelu(x1) * x2).to(h.dtype)
+
+    def gg_bwd(h, dout):
+        hh = h.detach().float().requires_grad_()
+        with torch.enable_grad():
+            x1, x2 = hh.chunk(2, dim=1)
+            o = F.gelu(x1) * x2
+        return torch.autograd.grad(o, hh, dout.float())[0].to(h.dtype)
+
     _CPU_LIB = torch.library.Library("vmambair", "IMPL")
+    _CPU_LIB.impl("gelu_gate_fwd", gg_fwd, "CPU")
+    _CPU_LIB.impl("gelu_gate_bwd", gg_bwd, "CPU")
     _CPU_LIB.impl("chan_gate_fwd", chan_fwd, "CPU")
     _CPU_LIB.impl("chan_gate_bwd", chan_bwd, "CPU")
     _CPU_LIB.impl("ss2d_core_fwd", core_fwd, "CPU")

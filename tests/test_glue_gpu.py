@@ -158,3 +158,31 @@ def test_conv1x1_on_strided_views_and_autocast(monkeypatch):
     assert_close(y, yref, 2e-2, 3e-2, "autocast conv1x1 vs vendor conv")
     y32 = ops.conv1x1(x, conv)  # fp32 activations outside autocast: vendor path, fp32 out
     assert y32.dtype == torch.float32
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 254, 16, 16), (1, 6, 3, 5), (3, 16, 8, 8), (2, 510, 4, 4)])
+def test_gelu_gate(dt, shape):
+    """gelu(x1) * x2 of the EFFN (MambaSISR6_arch.py:213-217) against F.gelu in fp32, forward and backward"""
+    torch.manual_seed(0)
+    B, C2, H, W = shape
+    h = (torch.randn(shape) * 2).to(dt)
+    dy = torch.randn(B, C2 // 2, H, W).to(dt)
+    hr = h.float().clone().requires_grad_()
+    x1, x2 = hr.chunk(2, dim=1)
+    yr = F.gelu(x1) * x2
+    yr.backward(dy.float())
+    hd = h.detach().to(DEV).requires_grad_()
+    y = ops.gelu_gate(hd)
+    y.backward(dy.to(DEV))
+    lo = dt == torch.float32
+    assert_close(y, yr, 1e-5 if lo else 1e-2, 1e-5 if lo else 2e-2, "y")
+    assert_close(hd.grad, hr.grad, 1e-4 if lo else 1e-2, 1e-5 if lo else 3e-2, "dh")
+
+
+def test_gelu_gate_on_batch_strided_input():
+    torch.manual_seed(1)
+    big = torch.randn(2, 3, 8, 4, 4, device=DEV)
+    h = big[:, 1]                                   # per-batch block contiguous, batch stride 3x larger
+    x1, x2 = h.chunk(2, dim=1)
+    assert_close(ops.gelu_gate(h), F.gelu(x1) * x2, 1e-5, 1e-5, "strided")

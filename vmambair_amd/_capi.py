@@ -62,7 +62,8 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bw
            "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
-           "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_hbm_copy", "oss_version"]
+           "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
+           "oss_gelu_gate_bwd", "oss_hbm_copy", "oss_version"]
 
 _lib = None
 
@@ -150,6 +151,10 @@ def load():
     lib.oss_rowsum.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
     lib.oss_row_affine.restype = C.c_int
     lib.oss_row_affine.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_int64] * 2 + [C.c_float, C.c_void_p]
+    lib.oss_gelu_gate_fwd.restype = C.c_int
+    lib.oss_gelu_gate_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int64, C.c_void_p]
+    lib.oss_gelu_gate_bwd.restype = C.c_int
+    lib.oss_gelu_gate_bwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_version.restype = C.c_char_p

@@ -289,6 +289,20 @@ int oss_row_affine(oss_dtype io, const void *x, const float *mul, const float *a
     return row_affine(io, x, mul, add, y, batch, channels, pixels, xsb, xsc, alpha, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_gelu_gate_fwd(oss_dtype io, const void *h, void *out, int batch, size_t half_elems, int64_t h_batch_stride,
+                      oss_stream_t stream) {
+    if (!h || !out) return OSS_ERR_NULL;
+    if (batch <= 0 || half_elems == 0) return OSS_ERR_SHAPE;
+    return gelu_gate_fwd(io, h, out, batch, half_elems, h_batch_stride, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int batch, size_t half_elems,
+                      int64_t h_batch_stride, int64_t dout_batch_stride, oss_stream_t stream) {
+    if (!h || !dout || !dh) return OSS_ERR_NULL;
+    if (batch <= 0 || half_elems == 0) return OSS_ERR_SHAPE;
+    return gelu_gate_bwd(io, h, dout, dh, batch, half_elems, h_batch_stride, dout_batch_stride, reinterpret_cast<hipStream_t>(stream));
+}
+
 int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
     if (!out || !y) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;

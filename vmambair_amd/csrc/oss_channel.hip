@@ -21,6 +21,7 @@
 namespace oss {
 
 constexpr int kChN = 16;  // dc_state of every reference config
+constexpr int kChU = 16;  // scan steps whose operands are fetched together
 
 __device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/, int tid) {
     const float w = segment_sum_to_last<64>(v);
@@ -77,17 +78,31 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
         float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float h = 0.f;
-        for (int t = 0; t < L; ++t) {
-            const int l = k ? L - 1 - t : t;
-            float e;
-            const float dl = softplus_thr(dr[l] + bias, e);
-            const float u = ur[l];
-            const float *zr = zb + (k * L + l) * Cc + Rc;
-            const float Bv = zr[n], Cv = zr[kChN + n];
-            h = __builtin_fmaf(exp2_hw(dl * A2), h, dl * Bv * u);
-            if (act) hr[l * kChN + n] = h;
-            const float tot = segment_sum_to_last<16>(Cv * h);
-            if (n == 15 && act) ybuf[row * L + l] = __builtin_fmaf(Dv, u, tot);
+        // the loads of a step do not depend on the recurrence: fetch kChU steps at once, then walk them
+        for (int t0 = 0; t0 < L; t0 += kChU) {
+            float xs[kChU], us[kChU], Bs[kChU], Cs[kChU];
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = min(t0 + j, L - 1), l = k ? L - 1 - t : t;
+                const float *zr = zb + (k * L + l) * Cc + Rc;
+                xs[j] = dr[l];
+                us[j] = ur[l];
+                Bs[j] = zr[n];
+                Cs[j] = zr[kChN + n];
+            }
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = t0 + j;
+                if (t < L) {
+                    const int l = k ? L - 1 - t : t;
+                    float e;
+                    const float dl = softplus_thr(xs[j] + bias, e);
+                    h = __builtin_fmaf(exp2_hw(dl * A2), h, dl * Bs[j] * us[j]);
+                    if (act) hr[l * kChN + n] = h;
+                    const float tot = segment_sum_to_last<16>(Cs[j] * h);
+                    if (n == 15 && act) ybuf[row * L + l] = __builtin_fmaf(Dv, us[j], tot);
+                }
+            }
         }
     }
     __syncthreads();
@@ -180,36 +195,57 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
         const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float carry = 0.f, dA = 0.f, dD = 0.f, dbs = 0.f;
-        for (int t = L - 1; t >= 0; --t) {
-            const int l = k ? L - 1 - t : t, lp = k ? l + 1 : l - 1;
-            const float x = dr[l] + bias;
-            float e;
-            const float dl = softplus_thr(x, e);
-            const float sig = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
-            const float u = ur[l];
-            const float *zr = zb + (k * L + l) * Cc + Rc;
-            const float Bv = zr[n], Cv = zr[kChN + n];
-            const float a = exp2_hw(dl * A2);
-            const float h = hr[l * kChN + n], hp = t > 0 ? hr[lp * kChN + n] : 0.f;
-            const float dyv = cw * dys[l];
-            const float dh = __builtin_fmaf(dyv, Cv, carry);
-            const float dCs = sum_over_rows(dyv * h, lane);
-            const float dBs = sum_over_rows(dh * dl * u, lane);
-            if (i == 0) {
-                float *dz = dzb + (k * L + l) * Cc + Rc;
-                dz[n] = dBs;
-                dz[kChN + n] = dCs;
+        for (int t0 = L - 1; t0 >= 0; t0 -= kChU) {   // steps t0, t0 - 1, ..., fetched kChU at a time
+            float xs[kChU], us[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1], gy[kChU];
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
+                const float *zr = zb + (k * L + l) * Cc + Rc;
+                xs[j] = dr[l];
+                us[j] = ur[l];
+                Bs[j] = zr[n];
+                Cs[j] = zr[kChN + n];
+                hv[j] = hr[l * kChN + n];
+                gy[j] = dys[l];
             }
-            const float ddl = segment_sum_to_last<16>(dh * __builtin_fmaf(A * a, hp, Bv * u));
-            const float du = segment_sum_to_last<16>(dh * dl * Bv);
-            dA = __builtin_fmaf(dh * dl * a, hp, dA);
-            carry = a * dh;
-            if (n == 15 && act) {
-                const float ddt = ddl * sig;
-                ddb[row * L + l] = ddt;
-                dub[row * L + l] = __builtin_fmaf(dyv, Dv, du);
-                dbs += ddt;
-                dD = __builtin_fmaf(dyv, u, dD);
+            {
+                const int t = t0 - kChU;  // the state before the chunk's last step
+                const int tc = max(t, 0), l = k ? L - 1 - tc : tc;
+                hv[kChU] = t >= 0 ? hr[l * kChN + n] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = t0 - j;
+                if (t >= 0) {
+                    const int l = k ? L - 1 - t : t;
+                    const float x = xs[j] + bias;
+                    float e;
+                    const float dl = softplus_thr(x, e);
+                    const float sig = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                    const float u = us[j], Bv = Bs[j], Cv = Cs[j];
+                    const float a = exp2_hw(dl * A2);
+                    const float h = hv[j], hp = t > 0 ? hv[j + 1] : 0.f;
+                    const float dyv = cw * gy[j];
+                    const float dh = __builtin_fmaf(dyv, Cv, carry);
+                    const float dCs = sum_over_rows(dyv * h, lane);
+                    const float dBs = sum_over_rows(dh * dl * u, lane);
+                    if (i == 0) {
+                        float *dz = dzb + (k * L + l) * Cc + Rc;
+                        dz[n] = dBs;
+                        dz[kChN + n] = dCs;
+                    }
+                    const float ddl = segment_sum_to_last<16>(dh * __builtin_fmaf(A * a, hp, Bv * u));
+                    const float du = segment_sum_to_last<16>(dh * dl * Bv);
+                    dA = __builtin_fmaf(dh * dl * a, hp, dA);
+                    carry = a * dh;
+                    if (n == 15 && act) {
+                        const float ddt = ddl * sig;
+                        ddb[row * L + l] = ddt;
+                        dub[row * L + l] = __builtin_fmaf(dyv, Dv, du);
+                        dbs += ddt;
+                        dD = __builtin_fmaf(dyv, u, dD);
+                    }
+                }
             }
         }
         if (act) {
@@ -231,6 +267,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         float s = dub[i * L + l] + dub[(dc + i) * L + l];
         for (int k = 0; k < 2; ++k) {
             const float *dz = dzb + (k * L + l) * Cc;
+#pragma unroll 8
             for (int c = 0; c < Cc; ++c) s = __builtin_fmaf(p.Wxc[(k * Cc + c) * dc + i], dz[c], s);
         }
         dsq[idx] = s;
@@ -247,10 +284,12 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         float s = 0.f;
         if (o < n_wdtc) {
             const int row = o / Rc, r = o - row * Rc, k = row / dc;
+#pragma unroll 8
             for (int l = 0; l < L; ++l) s = __builtin_fmaf(ddb[row * L + l], zb[(k * L + l) * Cc + r], s);
             gp[sl.wdtc + o] = s;
         } else if (o < n_wdtc + n_wxc) {
             const int q = o - n_wdtc, i = q % dc, kc = q / dc, k = kc / Cc, c = kc - k * Cc;
+#pragma unroll 8
             for (int l = 0; l < L; ++l) s = __builtin_fmaf(dzb[(k * L + l) * Cc + c], seq[i * L + l], s);
             gp[sl.wxc + q] = s;
         } else {

@@ -54,5 +54,7 @@ int rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int B, int
            int64_t bsc, float alpha, hipStream_t s);
 int row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int B, int C, int P, int64_t xsb,
                int64_t xsc, float alpha, hipStream_t s);
+int gelu_gate_fwd(oss_dtype io, const void *h, void *out, int B, size_t n, int64_t hsb, hipStream_t s);
+int gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int B, size_t n, int64_t hsb, int64_t gsb, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, layer_norm_nchw
+from .ops import ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, gelu_gate, layer_norm_nchw
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
@@ -69,8 +69,8 @@ class FeedForward(nn.Module):
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x1, x2 = dwconv3x3(conv1x1(x, self.project_in), self.dwconv).chunk(2, dim=1)
-        return conv1x1(F.gelu(x1) * x2, self.project_out)
+        h = dwconv3x3(conv1x1(x, self.project_in), self.dwconv)
+        return conv1x1(gelu_gate(h), self.project_out)  # gelu(x1) * x2 on the two channel halves, one kernel
 
 
 def _dt_proj_init(dt_rank: int, d_inner: int, dt_scale=1.0, dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
