@@ -143,12 +143,14 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
  * I/O is rejected with OSS_ERR_SHAPE: it stays on the vendor conv).  weight: float (Cout, Cin)
  * contiguous (master weights, converted in the loader); x / dy: (batch, C, pixels) io dtype, pixels
  * contiguous, element strides (batch, channel); y / dx contiguous.
- *   fwd  : y  = W x + bias            dgrad: dx = W^T dy
+ *   fwd  : y  = W x + bias (+ residual, contiguous like y: the skip connection of the block, MambaSISR6_arch.py:515-516)
+ *   dgrad: dx = W^T dy
  *   wgrad: dweight (Cout, Cin) float = sum_{b,p} dy x^T and, when dbias != NULL, dbias (Cout) float =
  *          sum_{b,p} dy (an all-ones row appended to x inside the kernel); `partials` =
  *          oss_conv1x1_wgrad_partial_floats() floats of scratch. */
-int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout,
-                    int cin, int pixels, int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
+int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *residual, void *y,
+                    int batch, int cout, int cin, int pixels, int64_t x_batch_stride, int64_t x_channel_stride,
+                    oss_stream_t stream);
 int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
                       int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
 size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels);
@@ -249,7 +251,8 @@ int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int he
  * gate != NULL fuses y = LN(x) * silu(gate)
  * (SS2D_1: y1 * act(z), :488-493).  mean / rstd: (batch, pixels) float, written by fwd, read by bwd.
  * bwd: partials = oss_ln_nchw_bwd_partial_floats(batch, channels, pixels) floats of scratch
- * (per-workgroup dweight / dbias sums, combined in a fixed order by a finishing kernel). */
+ * (per-workgroup dweight / dbias sums, combined in a fixed order by a finishing kernel).  skip_grad (x_type,
+ * contiguous like dx, or NULL) is added to dx: the gradient arriving over the block's skip connection. */
 size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels);
 int oss_ln_nchw_fwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
                     const void *gate, void *y, float *mean, float *rstd, int batch, int channels, int pixels,
@@ -257,7 +260,7 @@ int oss_ln_nchw_fwd(oss_dtype x_type, oss_dtype y_type, const void *x, const flo
                     int64_t gate_channel_stride, float eps, oss_stream_t stream);
 int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
                     const void *gate, const void *dy, const float *mean, const float *rstd, void *dx, void *dgate,
-                    float *dweight, float *dbias, float *partials, int batch, int channels, int pixels,
+                    float *dweight, float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels,
                     int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
                     int64_t gate_channel_stride, oss_stream_t stream);
 

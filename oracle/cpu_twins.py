@@ -101,7 +101,7 @@ def install():
         B, C, H, W = x.shape
         return [y.to(codes[out_code]), mu.reshape(B, H * W), rstd.reshape(B, H * W)]
 
-    def ln_bwd(x, weight, bias, gate, dy, mean, rstd):
+    def ln_bwd(x, weight, bias, gate, dy, mean, rstd, skip_grad=None):
         leaves = [x.detach().float().requires_grad_(), weight.detach().float().requires_grad_()]
         bb = bias.detach().float().requires_grad_() if bias is not None else None
         gg = gate.detach().float().requires_grad_() if gate is not None else None
@@ -112,6 +112,8 @@ def install():
         dx, dw = gr.pop(0), gr.pop(0)
         db = gr.pop(0) if bb is not None else torch.empty(0)
         dg = gr.pop(0).to(dy.dtype) if gg is not None else torch.empty(0)
+        if skip_grad is not None:
+            dx = dx + skip_grad.float()
         return [dx.to(x.dtype), dg, dw, db]
 
     def _core_ref(x, wx, wdt, A_logs, Ds, dt_bias):

@@ -186,3 +186,38 @@ def test_gelu_gate_on_batch_strided_input():
     h = big[:, 1]                                   # per-batch block contiguous, batch stride 3x larger
     x1, x2 = h.chunk(2, dim=1)
     assert_close(ops.gelu_gate(h), F.gelu(x1) * x2, 1e-5, 1e-5, "strided")
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 96, 7, 5), (2, 400, 4, 4)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_layernorm_passthrough_adds_the_skip_gradient(shape, dt):
+    """x + f(norm(x)): the skip connection's gradient enters the LayerNorm node and is added inside its kernel"""
+    torch.manual_seed(3)
+    B, C, H, W = shape
+    x = torch.randn(shape).to(dt)
+    w, b = torch.randn(C) * 0.5 + 1, torch.randn(C)
+    dy, ds = torch.randn(shape).to(dt), torch.randn(shape).to(dt)
+    xr = x.float().clone().requires_grad_()
+    (ln_ref(xr, w, b, None) * dy.float()).sum().backward()
+    want = xr.grad + ds.float()
+    xd = x.detach().to(DEV).requires_grad_()
+    y, alias = ops.layer_norm_nchw(xd, w.to(DEV), b.to(DEV), None, dt, passthrough=True)
+    assert alias.data_ptr() == xd.data_ptr()
+    ((y.float() * dy.to(DEV).float()).sum() + (alias.float() * ds.to(DEV).float()).sum()).backward()
+    lo = dt == torch.float32
+    assert_close(xd.grad, want, 1e-3 if lo else 3e-2, 1e-3 if lo else 6e-2, "dx + skip")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 48, 16, 16), (1, 127, 48, 8, 8), (2, 5, 7, 3, 5), (1, 384, 96, 4, 4)])
+def test_conv1x1_with_fused_residual(B, Cin, Cout, H, W):
+    torch.manual_seed(4)
+    dt = torch.bfloat16
+    x, res = torch.randn(B, Cin, H, W).to(dt), torch.randn(B, Cout, H, W).to(dt)
+    w, b = torch.randn(Cout, Cin, 1, 1) * Cin ** -0.5, torch.randn(Cout)
+    dy = torch.randn(B, Cout, H, W).to(dt)
+    want = F.conv2d(x.float(), w.to(dt).float(), b) + res.float()
+    xd, rd = x.to(DEV).requires_grad_(), res.to(DEV).requires_grad_()
+    y = ops.Conv1x1Fn.apply(xd, w.to(DEV), b.to(DEV), rd)
+    assert_close(y, want, 2e-2, 3e-2, "conv + residual")
+    y.backward(dy.to(DEV))
+    assert torch.equal(rd.grad.cpu(), dy), "the residual's gradient is dy itself"

@@ -46,6 +46,14 @@ def main():
         lines.append(f"# idle gaps in that window: {total_gap / 1e3:.1f} ms in total; by the kernel that FOLLOWS the gap (count, total ms, max us)")
         for name, a in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
             lines.append(f"{a[1] / 1e3:10.2f} ms {a[0]:6d} gaps  avg {a[1] / a[0]:7.1f} us  max {a[2]:8.1f} us  {name}")
+        # kernel sequence of the last ~2 block backwards + the following optimizer: what runs between scan-backward kernels
+        big = list(cur.execute("select start from kernels where name like '%oss_scan_bwd_kernel%' and name not like '%float,%' order by start desc limit 3"))
+        if len(big) == 3:
+            seq = list(cur.execute("select name, start, end from kernels where start>=? and start<=? order by start", (big[2][0], big[0][0])))
+            lines.append("")
+            lines.append(f"# kernel sequence between the last three main scan-backward launches ({len(seq)} kernels): dur_us  name")
+            for name, st, en in seq:
+                lines.append(f"  {(en - st) / 1e3:8.1f}  {name[:150]}")
     open(out_path, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:3]))
 

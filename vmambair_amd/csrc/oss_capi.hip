@@ -180,11 +180,12 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
                            reinterpret_cast<hipStream_t>(stream));
 }
 
-int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout,
-                    int cin, int pixels, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *residual, void *y,
+                    int batch, int cout, int cin, int pixels, int64_t xsb, int64_t xsc, oss_stream_t stream) {
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535 || cout > 32 * 65535) return OSS_ERR_SHAPE;
-    return conv1x1(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, cin, 1, reinterpret_cast<hipStream_t>(stream));
+    return conv1x1(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, cin, 1, reinterpret_cast<hipStream_t>(stream),
+                   residual);
 }
 
 int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
@@ -320,13 +321,13 @@ int oss_ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weig
 
 int oss_ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate,
                     const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dweight,
-                    float *dbias, float *partials, int batch, int channels, int pixels, int64_t xsb, int64_t xsc,
-                    int64_t gsb, int64_t gsc, oss_stream_t stream) {
+                    float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels, int64_t xsb,
+                    int64_t xsc, int64_t gsb, int64_t gsc, oss_stream_t stream) {
     if (!x || !weight || !dy || !mean || !rstd || !dx || !dweight || !partials) return OSS_ERR_NULL;
     if (gate && !dgate) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
     return ln_nchw_bwd(xt, yt, x, weight, bias, gate, dy, mean, rstd, dx, dgate, dweight, dbias, partials, batch, channels,
-                       pixels, xsb, xsc, gsb, gsc, reinterpret_cast<hipStream_t>(stream));
+                       pixels, xsb, xsc, gsb, gsc, reinterpret_cast<hipStream_t>(stream), skip_grad);
 }
 
 size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels) {

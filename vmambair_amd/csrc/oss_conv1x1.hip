@@ -30,7 +30,7 @@ namespace oss {
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ y,
-                   int M, int K, int P, int64_t xsb, int64_t xsk, int64_t ws_m, int64_t ws_k) {
+                   int M, int K, int P, int64_t xsb, int64_t xsk, int64_t ws_m, int64_t ws_k, const T *__restrict__ res) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int m0 = blockIdx.z * 32;
@@ -82,7 +82,8 @@ oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const f
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
         if (row < M && pok) {
-            const float v = acc[r] + (bias ? bias[row] : 0.f);
+            float v = acc[r] + (bias ? bias[row] : 0.f);
+            if (res) v += to_f32(res[(size_t)b * M * P + (size_t)row * P + p]);  // fused residual: y = W x + bias + res
             yb[(size_t)row * P + p] = from_f32<T>(v);
         }
     }
@@ -95,7 +96,7 @@ oss_conv1x1_kernel(const T *__restrict__ x, const float *__restrict__ w, const f
 template <typename T, int KS, bool WT>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                         T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave) {
+                         T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave, const T *__restrict__ res) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
@@ -170,7 +171,8 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
 #else
             if (row < M && pok) {
 #endif
-                const float v = acc[r] + (bias ? bias[row] : 0.f);
+                float v = acc[r] + (bias ? bias[row] : 0.f);
+                if (res) v += to_f32(res[(size_t)b * M * P + (size_t)row * P + p]);  // fused residual: y = W x + bias + res
                 yb[(size_t)row * P + p] = from_f32<T>(v);
             }
         }
@@ -188,7 +190,7 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
 template <typename T, int KS, bool WT, bool WVEC>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                        T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave) {
+                        T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave, const T *__restrict__ res) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int p0 = (blockIdx.x * 4 + wave) * 64;
@@ -255,7 +257,14 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (row < M && pok) {
                 const float bv = bias ? bias[row] : 0.f;
-                yw[(size_t)row * psw] = pack2<T>(acca[r] + bv, accb[r] + bv);
+                float va = acca[r] + bv, vb = accb[r] + bv;
+                if (res) {
+                    float r0, r1;
+                    unpack2<T>(reinterpret_cast<const uint32_t *>(res + (size_t)b * M * P + p)[(size_t)row * psw], r0, r1);
+                    va += r0;
+                    vb += r1;
+                }
+                yw[(size_t)row * psw] = pack2<T>(va, vb);
             }
         }
     }
@@ -267,7 +276,7 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
 template <typename T, int KS, int MT, bool WT, bool WVEC>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                        T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk) {
+                        T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, const T *__restrict__ res) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int p0 = (blockIdx.x * 4 + wave) * 64;
@@ -342,7 +351,14 @@ oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, c
             const int row = (mt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (row < M && pok) {
                 const float bv = bias ? bias[row] : 0.f;
-                yw[(size_t)row * psw] = pack2<T>(acca[t][r] + bv, accb[t][r] + bv);
+                float va = acca[t][r] + bv, vb = accb[t][r] + bv;
+                if (res) {
+                    float r0, r1;
+                    unpack2<T>(reinterpret_cast<const uint32_t *>(res + (size_t)b * M * P + p)[(size_t)row * psw], r0, r1);
+                    va += r0;
+                    vb += r1;
+                }
+                yw[(size_t)row * psw] = pack2<T>(va, vb);
             }
         }
     }
@@ -468,7 +484,7 @@ oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw,
 
 template <typename T>
 static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, int B, int M, int K, int P, int64_t xsb,
-                           int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s) {
+                           int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const T *res) {
     const int pblocks = (P + 127) / 128, mt = (M + 31) / 32;
     const bool wt = (ws_m == 1 && ws_k == M);          // input gradient: weights read transposed
     const bool plain = (ws_k == 1 && ws_m == K);
@@ -487,7 +503,7 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
             if (split > mt) split = mt;
             const int per = (mt + split - 1) / split;
             dim3 grid(pb, B, (mt + per - 1) / per);
-#define OSS_PAIR1(KS_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pair_kernel<T, KS_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per)
+#define OSS_PAIR1(KS_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pair_kernel<T, KS_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res)
 #define OSS_PAIR(KS_) do { if (wt) OSS_PAIR1(KS_, true, false); else if (wvec) OSS_PAIR1(KS_, false, true); else OSS_PAIR1(KS_, false, false); } while (0)
             if (K <= 16 * 3)      OSS_PAIR(3);
             else if (K <= 16 * 6) OSS_PAIR(6);
@@ -500,7 +516,7 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
             while (per > 1 && waves_p * ((mt + per - 1) / per) < 2048) --per;
             if (per > mt) per = mt;
             dim3 grid(pb, B, (mt + per - 1) / per);
-#define OSS_PAIR1(MT_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pairk_kernel<T, 8, MT_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk)
+#define OSS_PAIR1(MT_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pairk_kernel<T, 8, MT_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, res)
 #define OSS_PAIR(MT_) do { if (wt) OSS_PAIR1(MT_, true, false); else if (wvec) OSS_PAIR1(MT_, false, true); else OSS_PAIR1(MT_, false, false); } while (0)
             if (per == 1) OSS_PAIR(1); else if (per == 2) OSS_PAIR(2); else OSS_PAIR(3);
 #undef OSS_PAIR
@@ -520,28 +536,28 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
         dim3 grid(pblocks, B, (mt + per - 1) / per);
         const int xk = (int)xsk;
         if (K <= 16 * 6) {
-            if (wt) hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 6, true>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
-            else    hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 6, false>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
+            if (wt) hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 6, true>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res);
+            else    hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 6, false>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res);
         } else {
-            if (wt) hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 12, true>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
-            else    hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 12, false>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per);
+            if (wt) hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 12, true>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res);
+            else    hipLaunchKernelGGL((oss_conv1x1_reuse_kernel<T, 12, false>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res);
         }
     } else {
         dim3 grid(pblocks, B, mt);
-        hipLaunchKernelGGL(oss_conv1x1_kernel<T>, grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xsk, ws_m, ws_k);
+        hipLaunchKernelGGL(oss_conv1x1_kernel<T>, grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xsk, ws_m, ws_k, res);
     }
 }
 
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
-            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s) {
+            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const void *res) {
     switch (io) {
         case OSS_BF16:
             conv1x1_launch<bf16_t>(reinterpret_cast<const bf16_t *>(x), w, bias, reinterpret_cast<bf16_t *>(y), B, M, K, P, xsb,
-                                   xsk, ws_m, ws_k, s);
+                                   xsk, ws_m, ws_k, s, reinterpret_cast<const bf16_t *>(res));
             break;
         case OSS_F16:
             conv1x1_launch<f16_t>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
-                                  ws_m, ws_k, s);
+                                  ws_m, ws_k, s, reinterpret_cast<const f16_t *>(res));
             break;
         default: return OSS_ERR_SHAPE;  // fp32 I/O stays on the vendor conv (no reduced-precision path for fp32)
     }

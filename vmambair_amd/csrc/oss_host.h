@@ -30,10 +30,11 @@ int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const
 size_t ln_nchw_bwd_partial_floats(int B, int C, int P);
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
-                float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
+                float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s,
+                const void *res = nullptr);
 int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, hipStream_t s);
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
-            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s);
+            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const void *res = nullptr);
 int conv1x1_wgrad_slabs(int P);
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
                   int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G = 1, int64_t gsg = 0, int64_t xsg = 0,

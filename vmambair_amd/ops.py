@@ -732,8 +732,8 @@ def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
-                dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor) -> List[torch.Tensor]:
-    """-> [dx (x dtype), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty]"""
+                dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, skip_grad: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """-> [dx (x dtype) (+ skip_grad), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty]"""
     B, Cc, H, W = x.shape
     P = H * W
     x = _planes(x)
@@ -744,6 +744,8 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         gate = _planes(gate)
         if gate.dtype != dy.dtype:
             gate = gate.to(dy.dtype)
+    if skip_grad is not None:
+        skip_grad = skip_grad.to(x.dtype).contiguous()
     dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
     dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device) if gate is not None else None
     dw = torch.empty((Cc,), dtype=torch.float32, device=x.device)
@@ -754,7 +756,7 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         st = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_ln_nchw_bwd(_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
                                         dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dgate),
-                                        dw.data_ptr(), _ptr(db), part.data_ptr(), B, Cc, P, x.stride(0), x.stride(1),
+                                        dw.data_ptr(), _ptr(db), part.data_ptr(), _ptr(skip_grad), B, Cc, P, x.stride(0), x.stride(1),
                                         0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1), st),
                     "oss_ln_nchw_bwd")
     e = x.new_empty(0, dtype=torch.float32)
@@ -762,42 +764,50 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 _LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
-_LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd) -> Tensor[]")
+_LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd, "
+            "Tensor? skip_grad) -> Tensor[]")
 _LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
 _LIB.impl("ln_nchw_bwd", ln_nchw_bwd, "CUDA")
 _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
 class LayerNormNCHWFn(torch.autograd.Function):
+    """``passthrough``: also return ``x`` itself (an alias) as a second output.  A block that computes
+    ``x + f(norm(x))`` feeds that alias into the sum, so the gradient of the skip connection arrives HERE and is
+    added to dx inside the backward kernel instead of by a separate accumulation kernel."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, gate, out_dtype):
+    def forward(ctx, x, weight, bias, gate, out_dtype, passthrough=False):
         y, mean, rstd = torch.ops.vmambair.ln_nchw_fwd(x, weight, bias, gate, _DT_CODE[out_dtype])
         ctx.has_bias, ctx.has_gate = bias is not None, gate is not None
         ctx.save_for_backward(x, weight, bias, gate, mean, rstd)
-        return y
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, weight, bias, gate, mean, rstd = ctx.saved_tensors
-        dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd)
+        if dy is None:  # only the alias was used
+            return dskip, None, None, None, None, None
+        dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd, dskip)
         return (dx, dw.to(weight.dtype), db.to(bias.dtype) if ctx.has_bias else None,
-                dgate.to(gate.dtype) if ctx.has_gate else None, None)
+                dgate.to(gate.dtype) if ctx.has_gate else None, None, None)
 
 
 def layer_norm_nchw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                    gate: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                    gate: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, passthrough: bool = False):
     """LN over channels of an NCHW tensor (optionally times silu(gate)).  ``out_dtype`` defaults to the
     autocast dtype when autocast is on (what the consumer conv would cast to anyway), else x.dtype."""
     if out_dtype is None:
         out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-    return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype)
+    return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype, passthrough)
 
 
 # ---------------------------------------------------------------------------------------------
 # 1x1 convolutions of the OSS block as MFMA GEMMs on NCHW (bf16 / fp16 I/O, fp32 master weights)
 # ---------------------------------------------------------------------------------------------
-def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """``F.conv2d(x, weight, bias)`` for a (Cout, Cin, 1, 1) weight; x bf16/fp16 (B, Cin, H, W)."""
+def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.conv2d(x, weight, bias) [+ residual]`` for a (Cout, Cin, 1, 1) weight; x bf16/fp16 (B, Cin, H, W)."""
     _check(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "conv1x1: x must be bf16/fp16 on the GPU")
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
@@ -805,13 +815,16 @@ def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     x = _planes(x)
     w = weight.detach().float().reshape(Cout, Cin).contiguous()
     b = None if bias is None else bias.detach().float().contiguous()
+    if residual is not None:
+        _check(tuple(residual.shape) == (B, Cout, H, W), "conv1x1: residual must have the output's shape")
+        residual = residual.to(x.dtype).contiguous()
     y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
     if x.numel() == 0:
         return y
     lib = _capi.load()
     with torch.cuda.device(x.device):
-        _capi.check(lib.oss_conv1x1_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), B, Cout, Cin, H * W,
-                                        x.stride(0), x.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_fwd")
+        _capi.check(lib.oss_conv1x1_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(residual), y.data_ptr(), B, Cout, Cin,
+                                        H * W, x.stride(0), x.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_fwd")
     return y
 
 
@@ -839,7 +852,7 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
     return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 
-_LIB.define("conv1x1_fwd(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
+_LIB.define("conv1x1_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? residual) -> Tensor")
 _LIB.define("conv1x1_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias) -> Tensor[]")
 _LIB.impl("conv1x1_fwd", conv1x1_fwd, "CUDA")
 _LIB.impl("conv1x1_bwd", conv1x1_bwd, "CUDA")
@@ -847,16 +860,16 @@ _LIB.impl("conv1x1_bwd", conv1x1_bwd, "CUDA")
 
 class Conv1x1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.has_bias = bias is not None
+    def forward(ctx, x, weight, bias, residual=None):
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, weight)
-        return torch.ops.vmambair.conv1x1_fwd(x, weight, bias)
+        return torch.ops.vmambair.conv1x1_fwd(x, weight, bias, residual)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx, dw, db = torch.ops.vmambair.conv1x1_bwd(x, weight, dy, ctx.has_bias)
-        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None)
+        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), (dy if ctx.has_res else None)
 
 
 #: "mfma" (default) or "vendor".  16-bit activations go to the in-tree MFMA kernels (pixel-pair tiles: 4-byte
@@ -867,13 +880,15 @@ class Conv1x1Fn(torch.autograd.Function):
 CONV1X1_IMPL = os.environ.get("VMAMBAIR_CONV1X1", "mfma")
 
 
-def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
+def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The 1x1 projections of the block (in_conv / out_conv / project_in / project_out,
     MambaSISR6_arch.py:205,211,281,329): in-tree MFMA kernels for 16-bit activations (under autocast fp32
-    inputs are narrowed first, as autocast would), vendor conv otherwise."""
+    inputs are narrowed first, as autocast would), vendor conv otherwise.  ``residual``: the block's skip
+    connection, added in the kernel's epilogue (``x + attn(norm1(x))``, :515-516)."""
     if CONV1X1_IMPL == "mfma" and x.is_cuda:
         if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype("cuda"))
         if x.dtype in (torch.bfloat16, torch.float16):
-            return Conv1x1Fn.apply(x, conv.weight, conv.bias)
-    return conv(x)
+            return Conv1x1Fn.apply(x, conv.weight, conv.bias, residual)
+    y = conv(x)
+    return y if residual is None else residual + y

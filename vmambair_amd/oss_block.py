@@ -52,9 +52,9 @@ class LayerNorm(nn.Module):
         self.with_bias = LayerNorm_type != "BiasFree"
         self.body = _LNBody(dim, self.with_bias)
 
-    def forward(self, x: torch.Tensor, gate: torch.Tensor = None, out_dtype: torch.dtype = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, gate: torch.Tensor = None, out_dtype: torch.dtype = None, passthrough: bool = False):
         """NCHW in, NCHW out, no permutes (HIP kernel).  ``gate``: fused ``* silu(gate)`` epilogue."""
-        return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype)
+        return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype, passthrough)
 
 
 class FeedForward(nn.Module):
@@ -68,9 +68,9 @@ class FeedForward(nn.Module):
         self.dwconv = nn.Conv2d(hidden * 2, hidden * 2, kernel_size=3, stride=1, padding=1, groups=hidden * 2, bias=bias)
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
         h = dwconv3x3(conv1x1(x, self.project_in), self.dwconv)
-        return conv1x1(gelu_gate(h), self.project_out)  # gelu(x1) * x2 on the two channel halves, one kernel
+        return conv1x1(gelu_gate(h), self.project_out, residual)  # gelu(x1) * x2 on the two channel halves, one kernel
 
 
 def _dt_proj_init(dt_rank: int, d_inner: int, dt_scale=1.0, dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
@@ -279,7 +279,8 @@ class SS2D_1(nn.Module):
         return F.layer_norm(y.reshape(b, d), (d,), self.channel_norm.body.weight, self.channel_norm.body.bias,
                             1e-5).view(b, d, 1, 1).to(xc.dtype)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+        """``residual``: the block's skip connection, added in the epilogue of the out_conv kernel"""
         xz = conv1x1(x, self.in_conv)
         x, z = xz.chunk(2, dim=1)
         x = F.silu(dwconv3x3(x, self.conv2d))
@@ -293,10 +294,10 @@ class SS2D_1(nn.Module):
                 self.dtc_projs_weight, self.dtc_projs_bias, self.Ac_logs, self.Dsc, self.conv_cout.weight if lift else None,
                 self.conv_cout.bias if lift else None, self.channel_norm.body.weight, self.channel_norm.body.bias,
                 self.gate != "add")
-            return conv1x1(y2, self.out_conv)
+            return conv1x1(y2, self.out_conv, residual)
         c = self.cforward_core(y2)
         y2 = (y2 + c) if self.gate == "add" else torch.addcmul(y2, y2, c)  # y2 * c + y2
-        return conv1x1(y2, self.out_conv)
+        return conv1x1(y2, self.out_conv, residual)
 
 
 class MamberBlock(nn.Module):
@@ -311,6 +312,9 @@ class MamberBlock(nn.Module):
         self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = x + self.attn(self.norm1(x))
-        x = x + self.ffn(self.norm2(x))
-        return x
+        # x + f(norm(x)): the sum happens in the epilogue of f's last 1x1 conv, and the skip connection's gradient
+        # re-enters through the LayerNorm node (``passthrough``), which adds it to dx inside its backward kernel
+        n1, skip = self.norm1(x, passthrough=True)
+        x = self.attn(n1, residual=skip)
+        n2, skip = self.norm2(x, passthrough=True)
+        return self.ffn(n2, residual=skip)

@@ -60,7 +60,9 @@ class GraphedTrainStep:
                 if dense_conv and m.kernel_size == (1, 1) and _ops.CONV1X1_IMPL == "mfma" and owner.rsplit(".", 1)[-1] in (
                         "in_conv", "out_conv", "project_in", "project_out", "reduce_chan_level2", "reduce_chan_level3"):
                     continue  # the MFMA 1x1 kernels read the fp32 masters and narrow them in their loader
-                if dense_conv or leaf in ("x_proj_weight", "dt_projs_weight"):
+                # x_proj_weight / dt_projs_weight: the fused spatial core (SS2DCoreFn) reads the fp32 masters
+                fused_proj = getattr(m, "fused_core", False) and getattr(m, "omni", False)
+                if dense_conv or (leaf in ("x_proj_weight", "dt_projs_weight") and not fused_proj):
                     self.shadow[name] = (p, torch.empty_like(p, dtype=autocast_dtype).requires_grad_())
         self._masters = [m for m, _ in self.shadow.values()]
         self._shadows = [s for _, s in self.shadow.values()]
