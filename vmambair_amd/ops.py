@@ -889,6 +889,8 @@ def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, residual: Optional[torch.Ten
         if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype("cuda"))
         if x.dtype in (torch.bfloat16, torch.float16):
+            if residual is not None and residual.dtype != x.dtype:  # e.g. an fp32 stream: keep torch's type promotion
+                return residual + Conv1x1Fn.apply(x, conv.weight, conv.bias, None)
             return Conv1x1Fn.apply(x, conv.weight, conv.bias, residual)
     y = conv(x)
     return y if residual is None else residual + y
