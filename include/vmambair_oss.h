@@ -237,6 +237,21 @@ int oss_gelu_gate_fwd(oss_dtype io, const void *h, void *out, int batch, size_t 
 int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int batch, size_t half_elems,
                       int64_t h_batch_stride, int64_t dout_batch_stride, oss_stream_t stream);
 
+/* Adam + EMA of the training step (MambaSISR_model.py:120-147: torch.optim.Adam without amsgrad / weight decay,
+ * then ema = decay * ema + (1 - decay) * param) as one elementwise launch over a chunk table in device memory:
+ * one entry per <= OSS_ADAM_CHUNK consecutive elements of one parameter tensor (all float; ema may be NULL).
+ * state: 3 floats in device memory {step count, 1 - beta1^t, 1 - beta2^t}; the call advances the step count
+ * first (so the launch pair can be replayed inside a hipGraph). */
+#define OSS_ADAM_CHUNK 2048
+typedef struct {
+    void *param;
+    const void *grad;
+    void *exp_avg, *exp_avg_sq, *ema;
+    int n, reserved_;
+} oss_adam_chunk;
+int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
+                      float ema_decay, oss_stream_t stream);
+
 /* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
  * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3
  * column-major) -> y (batch, D, H, W) float = ((o0 + o2) + T o1) + T o3, the reference's association

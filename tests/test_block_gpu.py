@@ -71,3 +71,27 @@ def test_block_under_bf16_autocast_trains():
     ref = z["dx"]
     rel = (x.grad.cpu() - ref).norm() / ref.norm()
     assert rel < 0.1, f"bf16 input grad relative error {rel:.3f}"
+
+
+def test_fused_adam_ema_matches_torch_adam():
+    """oss_adam_ema_step vs torch.optim.Adam + the foreach EMA of the reference's optimize_parameters"""
+    from vmambair_amd.optim import FusedAdamEMA
+    torch.manual_seed(0)
+    shapes = [(5,), (3, 7), (2049,), (48, 96, 1, 1), (1,), (4096,)]
+    pa = [torch.randn(s, device=DEV) for s in shapes]
+    pb = [p.clone() for p in pa]
+    ema_a = [p.clone() for p in pa]
+    ema_b = [p.clone() for p in pb]
+    opt = torch.optim.Adam(pb, lr=2e-2, betas=(0.9, 0.99))
+    fo = FusedAdamEMA(pa, ema_a, lr=2e-2, betas=(0.9, 0.99), ema_decay=0.9)
+    for step in range(4):
+        grads = [torch.randn(s, device=DEV) * (step + 1) for s in shapes]
+        for p, q, g in zip(pa, pb, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        fo.step()
+        opt.step()
+        torch._foreach_mul_(ema_b, 0.9)
+        torch._foreach_add_(ema_b, pb, alpha=0.1)
+    for p, q, e, f in zip(pa, pb, ema_a, ema_b):
+        assert_close(p, q, 1e-5, 1e-6, "param")
+        assert_close(e, f, 1e-5, 1e-6, "ema")

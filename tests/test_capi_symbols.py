@@ -45,10 +45,11 @@ def test_struct_layout_matches_header():
 #include <stddef.h>
 #include "vmambair_oss.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(oss_scan_fwd_params), offsetof(oss_scan_fwd_params, u_batch_stride),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(oss_scan_fwd_params), offsetof(oss_scan_fwd_params, u_batch_stride),
          offsetof(oss_scan_fwd_params, u), offsetof(oss_scan_fwd_params, x), sizeof(oss_scan_bwd_params),
          offsetof(oss_scan_bwd_params, dout_batch_stride), offsetof(oss_scan_bwd_params, dout),
-         offsetof(oss_scan_bwd_params, workspace_bytes));
+         offsetof(oss_scan_bwd_params, workspace_bytes), offsetof(oss_scan_bwd_params, dBC_group_stride),
+         sizeof(oss_chan_params), offsetof(oss_chan_params, pooled), offsetof(oss_chan_params, zt), offsetof(oss_chan_params, c));
   return 0; }'''
     import tempfile
     with tempfile.TemporaryDirectory() as td:
@@ -57,9 +58,10 @@ int main(void) {
         exe = os.path.join(td, "probe")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
-    F, B = _capi.ScanFwdParams, _capi.ScanBwdParams
+    F, B, Ch = _capi.ScanFwdParams, _capi.ScanBwdParams, _capi.ChanParams
     want = [ctypes.sizeof(F), F.u_batch_stride.offset, F.u.offset, F.x.offset, ctypes.sizeof(B),
-            B.dout_batch_stride.offset, B.dout.offset, B.workspace_bytes.offset]
+            B.dout_batch_stride.offset, B.dout.offset, B.workspace_bytes.offset, B.dBC_group_stride.offset,
+            ctypes.sizeof(Ch), Ch.pooled.offset, Ch.zt.offset, Ch.c.offset]
     assert got == want
 
 

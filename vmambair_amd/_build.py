@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvmambair_oss.so")
 SOURCES = ["oss_capi.hip", "oss_scan_fwd.hip", "oss_scan_bwd.hip", "oss_dwconv.hip", "oss_layernorm.hip", "oss_merge.hip", "oss_conv1x1.hip",
-           "oss_proj.hip", "oss_channel.hip", "oss_ffn.hip"]
+           "oss_proj.hip", "oss_channel.hip", "oss_ffn.hip", "oss_optim.hip"]
 HEADERS = ["oss_device.h", "oss_host.h", "oss_mfma.h", os.path.join("..", "..", "include", "vmambair_oss.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
 

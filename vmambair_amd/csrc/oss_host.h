@@ -57,5 +57,7 @@ int row_affine(oss_dtype io, const void *x, const float *mul, const float *add, 
                int64_t xsc, float alpha, hipStream_t s);
 int gelu_gate_fwd(oss_dtype io, const void *h, void *out, int B, size_t n, int64_t hsb, hipStream_t s);
 int gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int B, size_t n, int64_t hsb, int64_t gsb, hipStream_t s);
+int adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
+                  float ema_decay, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

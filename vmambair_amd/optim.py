@@ -1,0 +1,65 @@
+"""Adam + EMA of the training step as one HIP launch (``oss_adam_ema_step``, vmambair_amd/csrc/oss_optim.hip).
+
+Mirrors what the reference's ``optimize_parameters`` does after ``backward`` (SRGAN/VmambaIR/models/
+MambaSISR_model.py:138-147): ``optimizer_g.step()`` with ``torch.optim.Adam(lr, betas)`` (no weight decay, no
+amsgrad -- options/MambaSISR15_x4.yml:71-75) followed by ``model_ema(decay)``.  State layout and arithmetic equal
+``torch.optim.Adam``'s (``exp_avg``, ``exp_avg_sq``, step count), so a run can switch between the two.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _capi
+
+
+class FusedAdamEMA:
+    def __init__(self, params: Sequence[torch.Tensor], ema: Optional[Sequence[torch.Tensor]] = None, lr: float = 2e-4,
+                 betas=(0.9, 0.99), eps: float = 1e-8, ema_decay: float = 0.999):
+        self.params: List[torch.Tensor] = list(params)
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.params), \
+            "FusedAdamEMA: contiguous fp32 GPU parameters only"
+        self.ema = list(ema) if ema is not None else None
+        assert self.ema is None or len(self.ema) == len(self.params)
+        self.lr, self.betas, self.eps, self.ema_decay = lr, betas, eps, ema_decay
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        dev = self.params[0].device
+        self.state = torch.zeros(3, dtype=torch.float32, device=dev)   # step, 1 - beta1^t, 1 - beta2^t
+        self._sig = None            # grad pointers the device table was built for
+        self._n = sum((p.numel() + _capi.ADAM_CHUNK - 1) // _capi.ADAM_CHUNK for p in self.params)
+        nbytes = self._n * C.sizeof(_capi.AdamChunk)
+        # allocated up front (no allocation may happen inside a stream capture); the pinned copy stays alive because a
+        # captured host-to-device memcpy node re-reads it on every replay
+        self._host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self._table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def _build(self):
+        rows = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            assert g is not None and g.dtype == torch.float32 and g.is_contiguous(), "FusedAdamEMA: every parameter needs an fp32 grad"
+            e = self.ema[i].data_ptr() if self.ema is not None else 0
+            for off in range(0, p.numel(), _capi.ADAM_CHUNK):
+                n = min(_capi.ADAM_CHUNK, p.numel() - off)
+                b = off * 4
+                rows.append((p.data_ptr() + b, g.data_ptr() + b, self.exp_avg[i].data_ptr() + b,
+                             self.exp_avg_sq[i].data_ptr() + b, e + b if e else 0, n, 0))
+        assert len(rows) == self._n
+        arr = (_capi.AdamChunk * len(rows))(*[_capi.AdamChunk(*r) for r in rows])
+        C.memmove(self._host.data_ptr(), C.addressof(arr), C.sizeof(arr))
+        self._table.copy_(self._host, non_blocking=True)   # inside a stream capture this becomes a memcpy node of the graph
+
+    @torch.no_grad()
+    def step(self) -> None:
+        sig = tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in self.params)
+        if sig != self._sig:   # eager mode: new grad tensors every step; under a hipGraph the addresses are fixed
+            self._build()
+            self._sig = sig
+        lib = _capi.load()
+        with torch.cuda.device(self.params[0].device):
+            _capi.check(lib.oss_adam_ema_step(self._table.data_ptr(), self._n, self.state.data_ptr(), self.lr, self.betas[0],
+                                              self.betas[1], self.eps, self.ema_decay, torch.cuda.current_stream().cuda_stream),
+                        "oss_adam_ema_step")

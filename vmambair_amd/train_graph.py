@@ -36,7 +36,8 @@ from . import ops as _ops
 class GraphedTrainStep:
     def __init__(self, net: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), ema_decay: float = 0.999,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True):
+                 loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
+                 fused_optimizer: bool = True):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -69,7 +70,14 @@ class GraphedTrainStep:
         self._master_grads = [torch.zeros_like(m) for m in self._masters]
         self._shadow_map = {n: s for n, (_, s) in self.shadow.items()}
         self.ema = [p.detach().clone() for p in self.params]
-        self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, fused=True, capturable=True)
+        # Adam + EMA: one HIP launch over a chunk table (vmambair_amd/optim.py) or torch's fused multi-tensor Adam + foreach EMA
+        self.fopt = None
+        self.opt = None
+        if fused_optimizer and all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params):
+            from .optim import FusedAdamEMA
+            self.fopt = FusedAdamEMA(self.params, self.ema, lr=lr, betas=betas, ema_decay=ema_decay)
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, fused=True, capturable=True)
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
@@ -98,6 +106,9 @@ class GraphedTrainStep:
         return loss.detach()
 
     def _opt_ema(self):
+        if self.fopt is not None:
+            self.fopt.step()
+            return
         self.opt.step()
         with torch.no_grad():  # model_ema(decay) of the reference
             torch._foreach_mul_(self.ema, self.ema_decay)
