@@ -153,10 +153,16 @@ def test_every_forward_variant(fv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, fwd_variant=fv)
 
 
-@pytest.mark.parametrize("bv", [0, 1])
+@pytest.mark.parametrize("bv", [0, 1, 2, 3])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_every_backward_variant(bv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, bwd_variant=bv)
+
+
+@pytest.mark.parametrize("dstate", [1, 5, 16])
+def test_backward_two_states_at_a_time_with_odd_state_counts(dstate):
+    """variant 2 walks the states in pairs; an odd count leaves a single state at the end of a tile"""
+    check_fwd_bwd(make_inputs(2, 16, dstate, 2, 700, torch.float32), True, torch.float32, bwd_variant=2)
 
 
 def test_channel_scan_shapes():

@@ -21,15 +21,20 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     // 16 lanes per row (4 rows per wave): fewest scan steps, but only rows/4 waves
     if (rows_per_group % 16 == 0 && rows / 4 >= 2048) return 2;
     if (rows_per_group % 16 == 0 && rows / 2 >= 2048) return 1;
+    // <= one 8-row workgroup per CU and a long sequence: 16 items per lane (half the chunk hand-overs; u:(8,192,4096)
+    // bf16 0.065 ms against 0.077, profiles/r01_sweep_v4_bwd_variants.txt)
+    if (seqlen >= 1024 && (long)batch * n_groups * ((rows_per_group + 7) / 8) <= 256) return 3;
     return 0;
 }
 
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups) {
     (void)dstate;
     const int rows_per_group = dim / n_groups;
-    (void)batch;
     if (seqlen <= 256 || rows_per_group < 8) return 1;
-    return 0;
+    // <= one 8-row workgroup per CU: nothing is gained by leaving register room for a second one, so take the
+    // build without spills (u:(8,192,4096): 0.196 ms against 0.229, profiles/r01_sweep_v4_bwd_variants.txt)
+    const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
+    return wgs <= 256 ? 3 : 0;
 }
 
 // ---- per-launch event timing (oss_prof_*) -----------------------------------------------------

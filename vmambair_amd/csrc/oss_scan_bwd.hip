@@ -38,8 +38,12 @@ __host__ __device__ inline size_t ws_bc_floats(int batch, int G, int tiles, int 
     return (size_t)batch * G * tiles * 2 * N * L;
 }
 
-template <typename T, int LPR, int I, int WAVES, int NBB>
-__global__ void __launch_bounds__(WAVES * 64, (WAVES >= 8 ? 4 : 3))
+// SPS: states walked together between two barriers (2: two independent dependency chains per wave for the
+// scheduler to interleave and half the barriers, at twice the slab LDS and ~2x the registers -- for grids
+// that cannot fill the chip with waves anyway)
+// MINW: waves per SIMD the register allocation must leave room for (4: <= 128 VGPRs, 2: <= 256)
+template <typename T, int LPR, int I, int WAVES, int NBB, int SPS, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW)
 oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int RPW = 64 / LPR;
     constexpr int ROWS = WAVES * RPW;
@@ -51,8 +55,8 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sB = smem;                    // [NBB][TC]  tile_off layout
     float *sC = sB + NBB * TC;           // [NBB][TC]
-    float *slab = sC + NBB * TC;         // [ROWS][2][TC]  per-row dB / dC terms of the current state
-    float *sA2 = slab + ROWS * 2 * TC;                 // [N][ROWS]
+    float *slab = sC + NBB * TC;         // [SPS][ROWS][2][TC]  per-row dB / dC terms of the current state(s)
+    float *sA2 = slab + SPS * ROWS * 2 * TC;           // [N][ROWS]
     float *sdhc = sA2 + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dh of the first step of the later chunk
     float *sdA = sdhc + (size_t)p.f.dstate * ROWS;     // [N][ROWS]  dA partial of the row
     float *sdln = sdA + (size_t)p.f.dstate * ROWS;     // [ROWS]     delta of the first step of the later chunk
@@ -147,7 +151,8 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                                           gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
                                           f.C_dstate_stride, nb, t0, L, rev, tid);
             __syncthreads();
-            for (int nn = 0; nn < nb; ++nn) {
+            // everything of one state up to its dB / dC terms (vB, vC); accumulates Q, dd, sdA, stores sdhc
+            auto state_pass = [&](int nn, float (&vB)[I], float (&vC)[I]) {
                 const int n = n0 + nn;
                 const float A2 = sA2[n * ROWS + wrow];
                 // issued here, consumed after the first pass and the scan: the latency is covered (a per-chunk
@@ -207,7 +212,6 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 if (seg_last) sdhc[n * ROWS + wrow] = dfull_m;            // mirrored-last = first lane in time
                 // ---- reverse pass with gradients (bwd_kernel.cuh:196-206); p_t = a_t h_{t-1}
                 float dA_acc = 0.f;
-                float vB[I], vC[I];
 #pragma unroll
                 for (int k = I / 4 - 1; k >= 0; --k) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
@@ -229,35 +233,50 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 }
                 const float dA_sum = segment_sum_to_last<LPR>(dA_acc);
                 if (seg_last) sdA[n * ROWS + wrow] += dA_sum;
+            };
+            for (int nn = 0; nn < nb; nn += SPS) {
+                float vB[SPS][I], vC[SPS][I];
+                const bool two = SPS == 2 && nn + 1 < nb;
+                state_pass(nn, vB[0], vC[0]);
+                if constexpr (SPS == 2) {
+                    if (two) state_pass(nn + 1, vB[1], vC[1]);
+                }
 #ifndef OSS_EXP_NO_REDUCE  // (timing experiments only: tools/build_experiment.sh)
-                // ---- cross-row reduction of dB/dC for this state through the slabs
-                __syncthreads();  // the previous state's slice sums have been read
-                {
-                    float *sb = slab + (wrow * 2) * TC + pos * I;
-                    float *sc = sb + TC;
+                // ---- cross-row reduction of dB/dC for these states through the slabs
+                __syncthreads();  // the previous states' slice sums have been read
 #pragma unroll
-                    for (int k = 0; k < I / 4; ++k) {
-                        *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{vB[4 * k], vB[4 * k + 1], vB[4 * k + 2], vB[4 * k + 3]};
-                        *reinterpret_cast<f32x4 *>(sc + 4 * k) = f32x4{vC[4 * k], vC[4 * k + 1], vC[4 * k + 2], vC[4 * k + 3]};
+                for (int q = 0; q < SPS; ++q) {
+                    if (q == 0 || two) {
+                        float *sb = slab + ((q * ROWS + wrow) * 2) * TC + pos * I;
+                        float *sc = sb + TC;
+#pragma unroll
+                        for (int k = 0; k < I / 4; ++k) {
+                            *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{vB[q][4 * k], vB[q][4 * k + 1], vB[q][4 * k + 2], vB[q][4 * k + 3]};
+                            *reinterpret_cast<f32x4 *>(sc + 4 * k) = f32x4{vC[q][4 * k], vC[q][4 * k + 1], vC[q][4 * k + 2], vC[q][4 * k + 3]};
+                        }
                     }
                 }
                 __syncthreads();
-                {
-                    float accb = 0.f, accc = 0.f;
 #pragma unroll
-                    for (int r = 0; r < ROWS; ++r) {  // fixed order: deterministic
-                        accb += slab[(r * 2) * TC + tid];
-                        accc += slab[(r * 2 + 1) * TC + tid];
-                    }
-                    const int t = t0 + tid;  // scan position; mirrored groups store at L-1-t
-                    if (t < L) {
-                        const int tm = rev ? (L - 1 - t) : t;
-                        ws_bc[(size_t)n * L + tm] = accb;
-                        ws_bc[(size_t)(N + n) * L + tm] = accc;
+                for (int q = 0; q < SPS; ++q) {
+                    if (q == 0 || two) {
+                        const int n = n0 + nn + q;
+                        float accb = 0.f, accc = 0.f;
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) {  // fixed order: deterministic
+                            accb += slab[((q * ROWS + r) * 2) * TC + tid];
+                            accc += slab[((q * ROWS + r) * 2 + 1) * TC + tid];
+                        }
+                        const int t = t0 + tid;  // scan position; mirrored groups store at L-1-t
+                        if (t < L) {
+                            const int tm = rev ? (L - 1 - t) : t;
+                            ws_bc[(size_t)n * L + tm] = accb;
+                            ws_bc[(size_t)(N + n) * L + tm] = accc;
+                        }
                     }
                 }
 #else
-                if (vB[0] + vC[I - 1] == 12345.678f) ws_bc[0] = vB[1];  // keep the values alive
+                if (vB[0][0] + vC[0][I - 1] == 12345.678f) ws_bc[0] = vB[0][1];  // keep the values alive
 #endif
             }
         }
@@ -339,7 +358,7 @@ oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*
     dC[bg * out_group_stride + r] = from_f32<T>(sc);
 }
 
-template <typename T, int LPR, int I, int WAVES, int NBB>
+template <typename T, int LPR, int I, int WAVES, int NBB, int SPS, int MINW>
 static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
     constexpr int ROWS = WAVES * (64 / LPR);
     constexpr int TC = LPR * I;
@@ -359,8 +378,8 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     if (!p.dD) ws.dD = nullptr;
     if (!p.ddelta_bias) ws.db = nullptr;
 
-    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
-    auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB>;
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)SPS * ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
+    auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB, SPS, MINW>;
     static size_t smem_enabled = 48 * 1024;
     if (smem > smem_enabled) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -389,14 +408,18 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 // variant table: (lanes per row, items per lane = waves per workgroup, states per LDS tile)
 //   0: 64 x 8 x 8,  8 states  (TC 512, 8 rows/WG, 64 KiB LDS)
 //   1: 64 x 4 x 4, 16 states  (TC 256, 4 rows/WG, 40 KiB LDS)  short sequences / few rows per group
-static const int kBwdRows[] = {8, 4};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 1) ? 1 : variant]; }
+//   2: variant 0 walking two states at a time (96 KiB LDS, <= 256 VGPRs): grids of <= ~1 workgroup per CU
+//   3: variant 0 with <= 256 VGPRs (no spills; 2 waves per SIMD)
+static const int kBwdRows[] = {8, 4, 8, 8};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 3) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
     switch (variant) {
-        case 0: return launch_bwd<T, 64, 8, 8, 8>(p, stream, timer);
-        default: return launch_bwd<T, 64, 4, 4, 16>(p, stream, timer);
+        case 0: return launch_bwd<T, 64, 8, 8, 8, 1, 4>(p, stream, timer);
+        case 2: return launch_bwd<T, 64, 8, 8, 8, 2, 2>(p, stream, timer);
+        case 3: return launch_bwd<T, 64, 8, 8, 8, 1, 2>(p, stream, timer);
+        default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }
 
