@@ -66,7 +66,7 @@ def main():
             D = torch.randn(KD, device=dev)
             bias = 0.5 * torch.rand(KD, device=dev)
             dout = torch.randn(B, KD, L, device=dev).to(dt)
-            for which, variants in ((0, range(5)), (1, range(4))):
+            for which, variants in ((0, range(7)), (1, range(5))):
                 for v in variants:
                     lib.oss_scan_set_variant(v if which == 0 else -1, v if which == 1 else -1)
                     try:

@@ -24,6 +24,8 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     // <= one 8-row workgroup per CU and a long sequence: 16 items per lane (half the chunk hand-overs; u:(8,192,4096)
     // bf16 0.065 ms against 0.077, profiles/r01_sweep_v4_bwd_variants.txt)
     if (seqlen >= 1024 && (long)batch * n_groups * ((rows_per_group + 7) / 8) <= 256) return 3;
+    // 12-row workgroups when they give <= one workgroup per CU (u:(8,384,4096) bf16: 0.081 ms against 0.113)
+    if (seqlen >= 1024 && rows_per_group >= 12 && (long)batch * n_groups * ((rows_per_group + 11) / 12) <= 256) return 6;
     return 0;
 }
 
@@ -34,7 +36,10 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     // <= one 8-row workgroup per CU: nothing is gained by leaving register room for a second one, so take the
     // build without spills (u:(8,192,4096): 0.196 ms against 0.229, profiles/r01_sweep_v4_bwd_variants.txt)
     const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
-    return wgs <= 256 ? 3 : 0;
+    if (wgs <= 256) return 3;
+    // more rows per workgroup: fewer dB / dC partial tiles and an even load (u:(8,384,4096) bf16: 0.271 ms against
+    // 0.355; u:(32,384,4096): 1.07 against 1.14)
+    return rows_per_group >= 12 ? 4 : 0;
 }
 
 // ---- per-launch event timing (oss_prof_*) -----------------------------------------------------

@@ -50,7 +50,7 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int TC = LPR * I;
     constexpr int NT = WAVES * 64;
     static_assert(TC % kScanChunk == 0, "");
-    static_assert(LPR == 64 && NT == TC, "slab reduction: one row per wave, one time step per thread");
+    static_assert(LPR == 64, "slab reduction: one row per wave");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sB = smem;                    // [NBB][TC]  tile_off layout
@@ -261,17 +261,19 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 for (int q = 0; q < SPS; ++q) {
                     if (q == 0 || two) {
                         const int n = n0 + nn + q;
-                        float accb = 0.f, accc = 0.f;
+                        for (int ts = tid; ts < TC; ts += NT) {  // one time step per thread (TC / NT passes)
+                            float accb = 0.f, accc = 0.f;
 #pragma unroll
-                        for (int r = 0; r < ROWS; ++r) {  // fixed order: deterministic
-                            accb += slab[((q * ROWS + r) * 2) * TC + tid];
-                            accc += slab[((q * ROWS + r) * 2 + 1) * TC + tid];
-                        }
-                        const int t = t0 + tid;  // scan position; mirrored groups store at L-1-t
-                        if (t < L) {
-                            const int tm = rev ? (L - 1 - t) : t;
-                            ws_bc[(size_t)n * L + tm] = accb;
-                            ws_bc[(size_t)(N + n) * L + tm] = accc;
+                            for (int r = 0; r < ROWS; ++r) {  // fixed order: deterministic
+                                accb += slab[((q * ROWS + r) * 2) * TC + ts];
+                                accc += slab[((q * ROWS + r) * 2 + 1) * TC + ts];
+                            }
+                            const int t = t0 + ts;  // scan position; mirrored groups store at L-1-t
+                            if (t < L) {
+                                const int tm = rev ? (L - 1 - t) : t;
+                                ws_bc[(size_t)n * L + tm] = accb;
+                                ws_bc[(size_t)(N + n) * L + tm] = accc;
+                            }
                         }
                     }
                 }
@@ -410,8 +412,9 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 //   1: 64 x 4 x 4, 16 states  (TC 256, 4 rows/WG, 40 KiB LDS)  short sequences / few rows per group
 //   2: variant 0 walking two states at a time (96 KiB LDS, <= 256 VGPRs): grids of <= ~1 workgroup per CU
 //   3: variant 0 with <= 256 VGPRs (no spills; 2 waves per SIMD)
-static const int kBwdRows[] = {8, 4, 8, 8};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 3) ? 1 : variant]; }
+//   4: 64 x 8 x 12 (12 rows/WG, 3 waves per SIMD, no spills): row counts that give <= 256 such workgroups
+static const int kBwdRows[] = {8, 4, 8, 8, 12};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 4) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
@@ -419,6 +422,7 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
         case 0: return launch_bwd<T, 64, 8, 8, 8, 1, 4>(p, stream, timer);
         case 2: return launch_bwd<T, 64, 8, 8, 8, 2, 2>(p, stream, timer);
         case 3: return launch_bwd<T, 64, 8, 8, 8, 1, 2>(p, stream, timer);
+        case 4: return launch_bwd<T, 64, 8, 12, 8, 1, 3>(p, stream, timer);
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }

@@ -186,6 +186,7 @@ static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
 //   2: 16 x 16 x 4   (TC  256, 16 rows/WG)   fewest scan steps, needs many rows
 //   3: 64 x 16 x 8   (TC 1024,  8 rows/WG)
 //   4: 64 x 4  x 4   (TC  256,  4 rows/WG)   short sequences / few rows per group
+//   5: 64 x 8  x 12  (TC  512, 12 rows/WG), 6: 64 x 16 x 12 (TC 1024, 12 rows/WG): row counts that give <= 256 such workgroups
 template <typename T>
 int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t stream) {
     switch (variant) {
@@ -193,6 +194,8 @@ int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t str
         case 1: return launch_fwd<T, 32, 16, 8>(p, stream);
         case 2: return launch_fwd<T, 16, 16, 4>(p, stream);
         case 3: return launch_fwd<T, 64, 16, 8>(p, stream);
+        case 5: return launch_fwd<T, 64, 8, 12>(p, stream);   // 12 rows per workgroup: one workgroup per CU at 3072 rows
+        case 6: return launch_fwd<T, 64, 16, 12>(p, stream);
         default: return launch_fwd<T, 64, 4, 4>(p, stream);
     }
 }
