@@ -51,11 +51,11 @@ def main():
     print(json.dumps({"copy_kernel_GBps": round(copy_gbs, 1)}), flush=True)
     del src, dst
 
-    shapes = [(8, 384, 4096, 4), (32, 384, 4096, 4), (8, 192, 4096, 4)]
+    shapes = [(8, 384, 4096, 4), (8, 192, 4096, 4), (8, 768, 1024, 4), (8, 1536, 256, 4)]
     if not args.quick:
         shapes += [(8, 768, 256, 4), (8, 8, 96, 2), (4, 384, 16384, 4)]
     for (B, KD, L, G) in shapes:
-        for dname in (["f32", "bf16"] if not args.quick else ["f32", "bf16"]):
+        for dname in (["f32", "bf16"] if not args.quick else ["bf16"]):
             dt, io = DT[dname]
             torch.manual_seed(0)
             u = torch.randn(B, KD, L, device=dev).to(dt)
@@ -66,7 +66,7 @@ def main():
             D = torch.randn(KD, device=dev)
             bias = 0.5 * torch.rand(KD, device=dev)
             dout = torch.randn(B, KD, L, device=dev).to(dt)
-            for which, variants in ((0, range(7)), (1, range(5))):
+            for which, variants in ((0, (0, 3, 5, 6, 7)), (1, (0, 3, 4, 5))):
                 for v in variants:
                     lib.oss_scan_set_variant(v if which == 0 else -1, v if which == 1 else -1)
                     try:

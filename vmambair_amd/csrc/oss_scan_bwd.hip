@@ -413,8 +413,9 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 //   2: variant 0 walking two states at a time (96 KiB LDS, <= 256 VGPRs): grids of <= ~1 workgroup per CU
 //   3: variant 0 with <= 256 VGPRs (no spills; 2 waves per SIMD)
 //   4: 64 x 8 x 12 (12 rows/WG, 3 waves per SIMD, no spills): row counts that give <= 256 such workgroups
-static const int kBwdRows[] = {8, 4, 8, 8, 12};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 4) ? 1 : variant]; }
+//   5: 64 x 8 x 6  (6 rows/WG, no spills): 48-row groups at batch 8 = exactly 256 workgroups
+static const int kBwdRows[] = {8, 4, 8, 8, 12, 6};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 5) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
@@ -423,6 +424,7 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
         case 2: return launch_bwd<T, 64, 8, 8, 8, 2, 2>(p, stream, timer);
         case 3: return launch_bwd<T, 64, 8, 8, 8, 1, 2>(p, stream, timer);
         case 4: return launch_bwd<T, 64, 8, 12, 8, 1, 3>(p, stream, timer);
+        case 5: return launch_bwd<T, 64, 8, 6, 8, 1, 2>(p, stream, timer);
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }

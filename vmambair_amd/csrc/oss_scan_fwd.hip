@@ -196,6 +196,7 @@ int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t str
         case 3: return launch_fwd<T, 64, 16, 8>(p, stream);
         case 5: return launch_fwd<T, 64, 8, 12>(p, stream);   // 12 rows per workgroup: one workgroup per CU at 3072 rows
         case 6: return launch_fwd<T, 64, 16, 12>(p, stream);
+        case 7: return launch_fwd<T, 64, 16, 6>(p, stream);
         default: return launch_fwd<T, 64, 4, 4>(p, stream);
     }
 }
