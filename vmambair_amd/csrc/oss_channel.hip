@@ -38,8 +38,10 @@ __device__ __forceinline__ float sum_over_rows(float v, int lane) {
     return v;
 }
 
+// use_lds: the projections z and dts also live in LDS for this kernel's own reads (they are written to HBM for the
+// backward either way); without it every phase pays a round trip through L2
 __global__ void __launch_bounds__(256)
-oss_chan_fwd_kernel(oss_chan_params p) {
+oss_chan_fwd_kernel(oss_chan_params p, int use_lds) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
     const bool lift = p.cin_w != nullptr;
@@ -52,20 +54,24 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
     }
     __syncthreads();
-    float *zb = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
+    float *zg = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
+    float *dg = p.dts + (size_t)b * 2 * dc * L;
+    float *zb = use_lds ? red + 4 : zg;
+    float *db = use_lds ? zb + 2 * L * Cc : dg;
     for (int idx = tid; idx < 2 * L * Cc; idx += 256) {
         const int k = idx / (L * Cc), rem = idx - k * L * Cc, l = rem / Cc, c = rem - l * Cc;
         float s = 0.f;
         for (int i = 0; i < dc; ++i) s = __builtin_fmaf(p.Wxc[(k * Cc + c) * dc + i], seq[i * L + l], s);
         zb[idx] = s;
+        if (use_lds) zg[idx] = s;
     }
     __syncthreads();
-    float *db = p.dts + (size_t)b * 2 * dc * L;
     for (int idx = tid; idx < 2 * dc * L; idx += 256) {
         const int row = idx / L, l = idx - row * L, k = row / dc;
         float s = 0.f;
         for (int r = 0; r < Rc; ++r) s = __builtin_fmaf(p.Wdtc[row * Rc + r], zb[(k * L + l) * Cc + r], s);
         db[idx] = s;
+        if (use_lds) dg[idx] = s;
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -78,28 +84,33 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
         float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float h = 0.f;
-        // the loads of a step do not depend on the recurrence: fetch kChU steps at once, then walk them
+        // per chunk of kChU steps: (1) fetch + everything that does not depend on the recurrence (softplus, exp, B u),
+        // (2) the recurrence itself -- one dependent FMA per step, (3) the outputs (independent reductions)
         for (int t0 = 0; t0 < L; t0 += kChU) {
-            float xs[kChU], us[kChU], Bs[kChU], Cs[kChU];
+            float av[kChU], bu[kChU], us[kChU], Cs[kChU], hv[kChU];
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = min(t0 + j, L - 1), l = k ? L - 1 - t : t;
                 const float *zr = zb + (k * L + l) * Cc + Rc;
-                xs[j] = dr[l];
+                float e;
+                const float dl = softplus_thr(dr[l] + bias, e);
                 us[j] = ur[l];
-                Bs[j] = zr[n];
+                av[j] = exp2_hw(dl * A2);
+                bu[j] = dl * zr[n] * us[j];
                 Cs[j] = zr[kChN + n];
+            }
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                h = __builtin_fmaf(av[j], h, bu[j]);   // steps past the end repeat the last one; their results are dropped
+                hv[j] = h;
             }
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = t0 + j;
                 if (t < L) {
                     const int l = k ? L - 1 - t : t;
-                    float e;
-                    const float dl = softplus_thr(xs[j] + bias, e);
-                    h = __builtin_fmaf(exp2_hw(dl * A2), h, dl * Bs[j] * us[j]);
-                    if (act) hr[l * kChN + n] = h;
-                    const float tot = segment_sum_to_last<16>(Cs[j] * h);
+                    if (act) hr[l * kChN + n] = hv[j];
+                    const float tot = segment_sum_to_last<16>(Cs[j] * hv[j]);
                     if (n == 15 && act) ybuf[row * L + l] = __builtin_fmaf(Dv, us[j], tot);
                 }
             }
@@ -136,7 +147,8 @@ struct ChanSlots {
 
 __global__ void __launch_bounds__(256)
 oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): grad of c*/, float *__restrict__ dpool,
-                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug) {
+                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug,
+                    int use_lds /* the three scratch arrays live in LDS instead of HBM */) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
     const bool lift = p.cin_w != nullptr;
@@ -181,9 +193,9 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     }
     const float *zb = p.zt + (size_t)b * 2 * L * Cc;
     const float *db = p.dts + (size_t)b * 2 * dc * L;
-    float *dzb = dzt + (size_t)b * 2 * L * Cc;
-    float *ddb = ddts + (size_t)b * 2 * dc * L;
-    float *dub = dug + (size_t)b * 2 * dc * L;
+    float *dzb = use_lds ? red + 4 : dzt + (size_t)b * 2 * L * Cc;
+    float *ddb = use_lds ? dzb + 2 * L * Cc : ddts + (size_t)b * 2 * dc * L;
+    float *dub = use_lds ? ddb + 2 * dc * L : dug + (size_t)b * 2 * dc * L;
     const int wave = tid >> 6, lane = tid & 63;
     if (wave < 2) {
         const int k = wave, i = lane >> 4, n = lane & 15;
@@ -196,17 +208,23 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float carry = 0.f, dA = 0.f, dD = 0.f, dbs = 0.f;
         for (int t0 = L - 1; t0 >= 0; t0 -= kChU) {   // steps t0, t0 - 1, ..., fetched kChU at a time
-            float xs[kChU], us[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1], gy[kChU];
+            // (1) fetch + recurrence-independent terms, (2) the reverse recurrence (two dependent FMAs per step),
+            // (3) the gradients of the step (independent of each other)
+            float us[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1], dyv[kChU], dls[kChU], sg[kChU], av[kChU], dhv[kChU];
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
                 const float *zr = zb + (k * L + l) * Cc + Rc;
-                xs[j] = dr[l];
+                const float x = dr[l] + bias;
+                float e;
+                dls[j] = softplus_thr(x, e);
+                sg[j] = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                av[j] = exp2_hw(dls[j] * A2);
                 us[j] = ur[l];
                 Bs[j] = zr[n];
                 Cs[j] = zr[kChN + n];
                 hv[j] = hr[l * kChN + n];
-                gy[j] = dys[l];
+                dyv[j] = t0 - j >= 0 ? cw * dys[l] : 0.f;
             }
             {
                 const int t = t0 - kChU;  // the state before the chunk's last step
@@ -215,19 +233,19 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
             }
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
+                const bool on = t0 - j >= 0;
+                const float dh = __builtin_fmaf(dyv[j], Cs[j], carry);
+                dhv[j] = dh;
+                carry = on ? av[j] * dh : carry;
+            }
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
                 const int t = t0 - j;
                 if (t >= 0) {
                     const int l = k ? L - 1 - t : t;
-                    const float x = xs[j] + bias;
-                    float e;
-                    const float dl = softplus_thr(x, e);
-                    const float sig = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
-                    const float u = us[j], Bv = Bs[j], Cv = Cs[j];
-                    const float a = exp2_hw(dl * A2);
+                    const float dl = dls[j], u = us[j], Bv = Bs[j], a = av[j], dh = dhv[j];
                     const float h = hv[j], hp = t > 0 ? hv[j + 1] : 0.f;
-                    const float dyv = cw * gy[j];
-                    const float dh = __builtin_fmaf(dyv, Cv, carry);
-                    const float dCs = sum_over_rows(dyv * h, lane);
+                    const float dCs = sum_over_rows(dyv[j] * h, lane);
                     const float dBs = sum_over_rows(dh * dl * u, lane);
                     if (i == 0) {
                         float *dz = dzb + (k * L + l) * Cc + Rc;
@@ -237,13 +255,12 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
                     const float ddl = segment_sum_to_last<16>(dh * __builtin_fmaf(A * a, hp, Bv * u));
                     const float du = segment_sum_to_last<16>(dh * dl * Bv);
                     dA = __builtin_fmaf(dh * dl * a, hp, dA);
-                    carry = a * dh;
                     if (n == 15 && act) {
-                        const float ddt = ddl * sig;
+                        const float ddt = ddl * sg[j];
                         ddb[row * L + l] = ddt;
-                        dub[row * L + l] = __builtin_fmaf(dyv, Dv, du);
+                        dub[row * L + l] = __builtin_fmaf(dyv[j], Dv, du);
                         dbs += ddt;
-                        dD = __builtin_fmaf(dyv, u, dD);
+                        dD = __builtin_fmaf(dyv[j], u, dD);
                     }
                 }
             }
@@ -364,6 +381,12 @@ oss_row_affine_kernel(const T *__restrict__ x, const float *__restrict__ mul, co
 // ---------------------------------------------------------------------------------------------
 size_t chan_grad_floats(int L, int dc, int Rc, int Cc) { return (size_t)ChanSlots(L, dc, Rc, Cc).total; }
 
+constexpr size_t kChanLdsMax = 96 * 1024;
+static int chan_enable_lds(const void *kern, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChanLdsMax);
+}
+
 static int chan_check(const oss_chan_params &p) {
     if (p.B <= 0 || p.L <= 0 || p.dc < 1 || p.dc > 4 || p.Rc < 1 || p.Cc != p.Rc + 2 * kChN) return OSS_ERR_SHAPE;
     if (!p.pooled || !p.Wxc || !p.Wdtc || !p.dt_bias || !p.A_logs || !p.Dsc || !p.cn_w || !p.cn_b || !p.zt || !p.dts || !p.hs ||
@@ -376,23 +399,31 @@ static int chan_check(const oss_chan_params &p) {
 
 int chan_fwd(const oss_chan_params &p, hipStream_t s) {
     if (int e = chan_check(p)) return e;
-    const size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + 4);
+    size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + 4);
     if (smem > 48 * 1024) return OSS_ERR_SHAPE;
-    hipLaunchKernelGGL(oss_chan_fwd_kernel, dim3(p.B), dim3(256), smem, s, p);
+    const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 2 * (size_t)p.dc * p.L);
+    const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
+    if (use_lds) smem += extra;
+    if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel), smem)) return e;
+    hipLaunchKernelGGL(oss_chan_fwd_kernel, dim3(p.B), dim3(256), smem, s, p, use_lds);
     return (int)hipGetLastError();
 }
 
 int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsum, float *scratch, hipStream_t s) {
     if (int e = chan_check(p)) return e;
     if (!gc || !dpool || !gsum || !scratch) return OSS_ERR_NULL;
-    const size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + 4);
+    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + 4);
     if (smem > 48 * 1024) return OSS_ERR_SHAPE;
+    const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 4 * (size_t)p.dc * p.L);
+    const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
+    if (use_lds) smem += extra;
+    if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel), smem)) return e;
     const size_t np = chan_grad_floats(p.L, p.dc, p.Rc, p.Cc);
     float *gpart = scratch;
     float *dzt = gpart + (size_t)p.B * np;
     float *ddts = dzt + (size_t)p.B * 2 * p.L * p.Cc;
     float *dug = ddts + (size_t)p.B * 2 * p.dc * p.L;
-    hipLaunchKernelGGL(oss_chan_bwd_kernel, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
+    hipLaunchKernelGGL(oss_chan_bwd_kernel, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, use_lds);
     hipLaunchKernelGGL(oss_chan_grad_finish, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, gsum, p.B, (int)np);
     return (int)hipGetLastError();
 }
