@@ -40,8 +40,11 @@ __device__ __forceinline__ float sum_over_rows(float v, int lane) {
 
 // use_lds: the projections z and dts also live in LDS for this kernel's own reads (they are written to HBM for the
 // backward either way); without it every phase pays a round trip through L2
+// (a template parameter, not a runtime pointer select: generic-address loads would tie the LDS and vector-memory
+// wait counters together inside the serial scan loop)
+template <bool use_lds>
 __global__ void __launch_bounds__(256)
-oss_chan_fwd_kernel(oss_chan_params p, int use_lds) {
+oss_chan_fwd_kernel(oss_chan_params p) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
     const bool lift = p.cin_w != nullptr;
@@ -56,8 +59,8 @@ oss_chan_fwd_kernel(oss_chan_params p, int use_lds) {
     __syncthreads();
     float *zg = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
     float *dg = p.dts + (size_t)b * 2 * dc * L;
-    float *zb = use_lds ? red + 4 : zg;
-    float *db = use_lds ? zb + 2 * L * Cc : dg;
+    float *zb, *db;
+    if constexpr (use_lds) { zb = red + 4; db = zb + 2 * L * Cc; } else { zb = zg; db = dg; }
     for (int idx = tid; idx < 2 * L * Cc; idx += 256) {
         const int k = idx / (L * Cc), rem = idx - k * L * Cc, l = rem / Cc, c = rem - l * Cc;
         float s = 0.f;
@@ -145,10 +148,10 @@ struct ChanSlots {
     }
 };
 
+template <bool use_lds /* the three scratch arrays live in LDS instead of HBM */>
 __global__ void __launch_bounds__(256)
 oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): grad of c*/, float *__restrict__ dpool,
-                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug,
-                    int use_lds /* the three scratch arrays live in LDS instead of HBM */) {
+                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
     const bool lift = p.cin_w != nullptr;
@@ -193,9 +196,12 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     }
     const float *zb = p.zt + (size_t)b * 2 * L * Cc;
     const float *db = p.dts + (size_t)b * 2 * dc * L;
-    float *dzb = use_lds ? red + 4 : dzt + (size_t)b * 2 * L * Cc;
-    float *ddb = use_lds ? dzb + 2 * L * Cc : ddts + (size_t)b * 2 * dc * L;
-    float *dub = use_lds ? ddb + 2 * dc * L : dug + (size_t)b * 2 * dc * L;
+    float *dzb, *ddb, *dub;
+    if constexpr (use_lds) {
+        dzb = red + 4; ddb = dzb + 2 * L * Cc; dub = ddb + 2 * dc * L;
+    } else {
+        dzb = dzt + (size_t)b * 2 * L * Cc; ddb = ddts + (size_t)b * 2 * dc * L; dub = dug + (size_t)b * 2 * dc * L;
+    }
     const int wave = tid >> 6, lane = tid & 63;
     if (wave < 2) {
         const int k = wave, i = lane >> 4, n = lane & 15;
@@ -404,8 +410,12 @@ int chan_fwd(const oss_chan_params &p, hipStream_t s) {
     const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 2 * (size_t)p.dc * p.L);
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
-    if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel), smem)) return e;
-    hipLaunchKernelGGL(oss_chan_fwd_kernel, dim3(p.B), dim3(256), smem, s, p, use_lds);
+    if (use_lds) {
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel<true>), smem)) return e;
+        hipLaunchKernelGGL(oss_chan_fwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p);
+    } else {
+        hipLaunchKernelGGL(oss_chan_fwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p);
+    }
     return (int)hipGetLastError();
 }
 
@@ -417,13 +427,15 @@ int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsu
     const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 4 * (size_t)p.dc * p.L);
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
-    if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel), smem)) return e;
+    if (use_lds)
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<true>), smem)) return e;
     const size_t np = chan_grad_floats(p.L, p.dc, p.Rc, p.Cc);
     float *gpart = scratch;
     float *dzt = gpart + (size_t)p.B * np;
     float *ddts = dzt + (size_t)p.B * 2 * p.L * p.Cc;
     float *dug = ddts + (size_t)p.B * 2 * p.dc * p.L;
-    hipLaunchKernelGGL(oss_chan_bwd_kernel, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, use_lds);
+    if (use_lds) hipLaunchKernelGGL(oss_chan_bwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
+    else         hipLaunchKernelGGL(oss_chan_bwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
     hipLaunchKernelGGL(oss_chan_grad_finish, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, gsum, p.B, (int)np);
     return (int)hipGetLastError();
 }

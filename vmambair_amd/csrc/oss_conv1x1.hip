@@ -400,23 +400,15 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
         int pk = pbeg;
-        if (aligned && pk + 64 <= pend) {
-            // 4 k-steps (64 pixels) per iteration, double-buffered: the eight 16-byte loads of the NEXT iteration are
-            // in flight while the four MFMAs of this one run
-            u32x4 qa[4], qb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                qa[u] = *reinterpret_cast<const u32x4 *>(ga + pk + u * 16 + kg * 8);
-                qb[u] = *reinterpret_cast<const u32x4 *>(xa + pk + u * 16 + kg * 8);
-            }
+        if (aligned) {
+            // 4 k-steps (64 pixels) per iteration: all eight 16-byte loads are issued before the first MFMA needs them
+            // (explicit double-buffering of the next iteration's loads measured no better: 13.0 vs 12.3 us)
             for (; pk + 64 <= pend; pk += 64) {
-                u32x4 na[4], nb[4];
-                const bool more = pk + 128 <= pend;
-                const int pn = more ? pk + 64 : pk;  // (re-reads the current block on the last pass: harmless, keeps the loop branch-free)
+                u32x4 qa[4], qb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    na[u] = *reinterpret_cast<const u32x4 *>(ga + pn + u * 16 + kg * 8);
-                    nb[u] = *reinterpret_cast<const u32x4 *>(xa + pn + u * 16 + kg * 8);
+                    qa[u] = *reinterpret_cast<const u32x4 *>(ga + pk + u * 16 + kg * 8);
+                    qb[u] = *reinterpret_cast<const u32x4 *>(xa + pk + u * 16 + kg * 8);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -424,8 +416,6 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
                     const s16x8 bf = nok ? __builtin_bit_cast(s16x8, qb[u]) : (one ? ones8 : zero8);
                     acc = Mfma<T>::run(af, bf, acc);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { qa[u] = na[u]; qb[u] = nb[u]; }
             }
         }
         for (; pk < pend; pk += 16) {
