@@ -1,0 +1,27 @@
+"""A few launches of the dominant scan call of the headline workload (u:(8,384,4096) bf16, omni form as SS2D_1 issues
+it) -- the target of tools/pmc_traffic.sh (rocprofv3 --pmc passes) so that the counter output stays small."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vmambair_amd import ops  # noqa: E402
+
+dev = "cuda:0"
+torch.manual_seed(0)
+B, D, L, N = 8, 96, 4096, 16
+dt = torch.bfloat16
+x2 = torch.randn(B, 2 * D, L, device=dev).to(dt)
+delta = (torch.randn(B, 4 * D, L, device=dev) * 0.5).to(dt)
+A_log = torch.log(torch.arange(1, N + 1, device=dev).float()).repeat(4 * D, 1).contiguous()
+Bm = torch.randn(B, 4, N, L, device=dev).to(dt)
+Cm = torch.randn(B, 4, N, L, device=dev).to(dt)
+Dv = torch.ones(4 * D, device=dev)
+bias = torch.randn(4 * D, device=dev) * 0.1
+g2 = torch.randn(B, 2 * D, L, device=dev).to(dt)
+for _ in range(int(os.environ.get("REPS", "6"))):
+    out, st = ops.selective_scan_fwd(x2, delta, A_log, Bm, Cm, Dv, bias, True, 1, 2, 2 * D, True)
+    res = ops.selective_scan_bwd(x2, delta, A_log, Bm, Cm, Dv, bias, g2, st, True, 1, 2, 2 * D, 2 * D, True)
+torch.cuda.synchronize()
+print("done", float(out.float().abs().mean()), float(res[0].float().abs().mean()))
