@@ -130,13 +130,18 @@ int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
  * NULL).  oss_dwconv3x3_fwd computes y = conv(x) + bias; with flip = 1 it applies the mirrored taps,
  * i.e. the input gradient dx = conv_transpose(dy).  oss_dwconv3x3_wgrad overwrites dweight (C, 9)
  * and dbias (C, or NULL) with the sums over batch and pixels; `partials` is batch*C*10 floats of
- * scratch (no init needed). */
-int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch,
+ * scratch (no init needed).
+ * Fused activation (SS2D_1: x = act(conv2d(x)), MambaSISR6_arch.py:486): with pre_silu != NULL (contiguous (batch, C, H, W))
+ * the forward stores the convolution there and y = silu(convolution); the weight-gradient call given the same pre_silu
+ * uses dy * silu'(pre_silu) as the gradient reaching the convolution and also writes it to dpre (contiguous), which is then
+ * the input of the flip = 1 call that produces dx. */
+int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, void *pre_silu, int batch,
                       int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
                       int64_t y_batch_stride, int64_t y_channel_stride, int flip, oss_stream_t stream);
 int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,
-                        int batch, int channels, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride,
-                        int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
+                        const void *pre_silu, void *dpre, int batch, int channels, int height, int width,
+                        int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride, int64_t dy_channel_stride,
+                        oss_stream_t stream);
 
 /* 1x1 convolutions of the OSS block (in_conv / out_conv / project_in / project_out,
  * MambaSISR6_arch.py:205,211,281,329) as MFMA GEMMs on NCHW tensors; io = OSS_BF16 or OSS_F16 (fp32

@@ -30,17 +30,23 @@ def install():
 
     import torch.nn.functional as F
 
-    def dw_fwd(x, weight, bias):  # plain PyTorch fp32 reference of the depth-wise conv
-        return F.conv2d(x.float(), weight.float(), None if bias is None else bias.float(), padding=1,
-                        groups=x.shape[1]).to(x.dtype)
+    def dw_fwd(x, weight, bias, act):  # plain PyTorch fp32 reference of the depth-wise conv (+ silu)
+        pre = F.conv2d(x.float(), weight.float(), None if bias is None else bias.float(), padding=1, groups=x.shape[1])
+        return [(F.silu(pre) if act else pre).to(x.dtype), pre.to(x.dtype) if act else torch.empty(0)]
 
-    def dw_bwd(x, weight, dy, has_bias):
+    def dw_bwd(x, weight, dy, has_bias, pre=None):
         xx = x.detach().float().requires_grad_()
         ww = weight.detach().float().requires_grad_()
+        g = dy.float()
+        if pre is not None and pre.numel():
+            pp = pre.detach().float().requires_grad_()
+            with torch.enable_grad():
+                a = F.silu(pp)
+            g = torch.autograd.grad(a, pp, g)[0]
         with torch.enable_grad():
             y = F.conv2d(xx, ww, None, padding=1, groups=x.shape[1])
-        dx, dw = torch.autograd.grad(y, (xx, ww), dy.float())
-        db = dy.float().sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)
+        dx, dw = torch.autograd.grad(y, (xx, ww), g)
+        db = g.sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)
         return [dx.to(x.dtype), dw, db]
 
     def _mirror(t, G_or_rows, start, per):  # flip time of groups >= start (per rows each)

@@ -111,11 +111,10 @@ def load():
     lib.oss_prof_collect.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                      C.POINTER(C.c_double)]
     lib.oss_dwconv3x3_fwd.restype = C.c_int
-    lib.oss_dwconv3x3_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
+    lib.oss_dwconv3x3_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
         [C.c_int64] * 4 + [C.c_int, C.c_void_p]
     lib.oss_dwconv3x3_wgrad.restype = C.c_int
-    lib.oss_dwconv3x3_wgrad.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
-        [C.c_int64] * 4 + [C.c_void_p]
+    lib.oss_dwconv3x3_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_ln_nchw_fwd.restype = C.c_int
     lib.oss_ln_nchw_fwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
     lib.oss_ln_nchw_bwd_partial_floats.restype = C.c_size_t

@@ -172,22 +172,22 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     return OSS_ERR_SHAPE;
 }
 
-int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch,
+int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, void *pre_silu, int batch,
                       int channels, int height, int width, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip,
                       oss_stream_t stream) {
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3(io, x, weight, bias, y, batch, channels, height, width, xsb, xsc, ysb, ysc, flip,
-                     reinterpret_cast<hipStream_t>(stream));
+                     reinterpret_cast<hipStream_t>(stream), pre_silu);
 }
 
 int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,
-                        int batch, int channels, int height, int width, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
-                        oss_stream_t stream) {
+                        const void *pre_silu, void *dpre, int batch, int channels, int height, int width, int64_t xsb,
+                        int64_t xsc, int64_t gsb, int64_t gsc, oss_stream_t stream) {
     if (!x || !dy || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_wgrad(io, x, dy, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, gsb, gsc,
-                           reinterpret_cast<hipStream_t>(stream));
+                           reinterpret_cast<hipStream_t>(stream), pre_silu, dpre);
 }
 
 int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *residual, void *y,

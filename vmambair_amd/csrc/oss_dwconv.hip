@@ -12,6 +12,11 @@
 
 namespace oss {
 
+__device__ __forceinline__ float sigmoid_f32(float z) { return __builtin_amdgcn_rcpf(1.f + exp2_hw(-z * kLog2e)); }
+__device__ __forceinline__ float silu_f32(float z) { return z * sigmoid_f32(z); }
+// d silu(z) / dz
+__device__ __forceinline__ float dsilu_f32(float z) { const float s = sigmoid_f32(z); return s * __builtin_fmaf(z, 1.f - s, 1.f); }
+
 template <typename T> struct Vec4;  // 4 consecutive elements
 template <> struct Vec4<float> {
     static __device__ __forceinline__ void load(const float *p, float (&v)[4]) {
@@ -37,10 +42,11 @@ template <typename T, bool VEC>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                      T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
-                     int flip) {
+                     int flip, T *__restrict__ pre /* contiguous (B, C, H, W) or NULL: the conv output before silu; y = silu(conv) */) {
     const int c = blockIdx.y, b = blockIdx.z;
     const T *xp = x + b * xsb + c * xsc;
     T *yp = y + b * ysb + c * ysc;
+    T *pp = pre ? pre + ((size_t)b * C + c) * H * W : nullptr;
     float k[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + (flip ? 8 - i : i)];
@@ -67,6 +73,11 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
             for (int j = 0; j < 4; ++j)
                 acc[j] = __builtin_fmaf(k0, v[j], __builtin_fmaf(k1, v[j + 1], __builtin_fmaf(k2, v[j + 2], acc[j])));
         }
+        if (pp) {  // fused activation: keep the pre-activation for the backward, emit silu
+            Vec4<T>::store(pp + (int64_t)h * W + w0, acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = silu_f32(acc[j]);
+        }
         Vec4<T>::store(yp + (int64_t)h * W + w0, acc);
     } else {
         const int p = blockIdx.x * 256 + threadIdx.x;
@@ -84,6 +95,10 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
                 acc = __builtin_fmaf(k[(dy + 1) * 3 + dx + 1], to_f32(xp[(int64_t)hh * W + wc]), acc);
             }
         }
+        if (pp) {
+            pp[p] = from_f32<T>(acc);
+            acc = silu_f32(acc);
+        }
         yp[p] = from_f32<T>(acc);
     }
 }
@@ -94,8 +109,12 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part /*[B][C][10]*/,
-                           int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc) {
+                           int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
+                           const T *__restrict__ pre, T *__restrict__ dpre /* fused silu: the gradient that reaches the conv is
+                           dy * silu'(pre); it is also written to dpre (contiguous) for the input-gradient pass */) {
     const int c = blockIdx.x, b = blockIdx.y;
+    const T *pp = pre ? pre + ((size_t)b * C + c) * H * W : nullptr;
+    T *qp = pre ? dpre + ((size_t)b * C + c) * H * W : nullptr;
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
@@ -107,6 +126,15 @@ oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, fl
             const int h = g / gpr, w0 = (g - h * gpr) << 2;
             float gv[4];
             Vec4<T>::load(gp + (int64_t)h * W + w0, gv);
+            if (pp) {
+                float pv[4];
+                Vec4<T>::load(pp + (int64_t)h * W + w0, pv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] *= dsilu_f32(pv[j]);
+                Vec4<T>::store(qp + (int64_t)h * W + w0, gv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] = to_f32(from_f32<T>(gv[j]));  // the input-gradient pass sees the rounded value
+            }
             acc[9] += (gv[0] + gv[1]) + (gv[2] + gv[3]);
 #pragma unroll
             for (int dyy = -1; dyy <= 1; ++dyy) {
@@ -131,7 +159,12 @@ oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, fl
         const int HW = H * W;
         for (int p = threadIdx.x; p < HW; p += 256) {
             const int h = p / W, ww = p - h * W;
-            const float g = to_f32(gp[p]);
+            float g = to_f32(gp[p]);
+            if (pp) {
+                const T gq = from_f32<T>(g * dsilu_f32(to_f32(pp[p])));
+                qp[p] = gq;
+                g = to_f32(gq);
+            }
             acc[9] += g;
 #pragma unroll
             for (int dyy = -1; dyy <= 1; ++dyy) {
@@ -172,55 +205,60 @@ oss_dwconv3x3_wgrad_finish(const float *__restrict__ part, float *__restrict__ d
 
 template <typename T>
 static int dwconv_launch(const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
-                         int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s) {
+                         int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre) {
     const T *xp = reinterpret_cast<const T *>(x);
     T *yp = reinterpret_cast<T *>(y);
+    T *prp = reinterpret_cast<T *>(pre);
     const uintptr_t amask = sizeof(T) == 4 ? 15u : 7u;
-    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp)) & amask) == 0 &&
+    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp) | reinterpret_cast<uintptr_t>(prp)) & amask) == 0 &&
                      (xsb % 4 == 0) && (xsc % 4 == 0) && (ysb % 4 == 0) && (ysc % 4 == 0);
     if (vec) {
         const int groups = (W / 4) * H;
         dim3 grid((groups + 255) / 256, C, B);
-        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip);
+        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp);
     } else {
         dim3 grid((H * W + 255) / 256, C, B);
-        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip);
+        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp);
     }
     return (int)hipGetLastError();
 }
 
 int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
-              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s) {
+              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre) {
     switch (io) {
-        case OSS_F32: return dwconv_launch<float>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s);
-        case OSS_F16: return dwconv_launch<f16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s);
-        case OSS_BF16: return dwconv_launch<bf16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s);
+        case OSS_F32: return dwconv_launch<float>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre);
+        case OSS_F16: return dwconv_launch<f16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre);
+        case OSS_BF16: return dwconv_launch<bf16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre);
     }
     return OSS_ERR_SHAPE;
 }
 
 template <typename T>
 static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H, int W,
-                        int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
+                        int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre, void *dpre) {
     const T *xp = reinterpret_cast<const T *>(x);
     const T *gp = reinterpret_cast<const T *>(dy);
+    const T *prp = reinterpret_cast<const T *>(pre);
+    T *dpp = reinterpret_cast<T *>(dpre);
     const uintptr_t amask = sizeof(T) == 4 ? 15u : 7u;
-    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(gp)) & amask) == 0 &&
+    const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(gp) | reinterpret_cast<uintptr_t>(prp) |
+                                         reinterpret_cast<uintptr_t>(dpp)) & amask) == 0 &&
                      (xsb % 4 == 0) && (xsc % 4 == 0) && (gsb % 4 == 0) && (gsc % 4 == 0);
     if (vec)
-        hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, true>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc);
+        hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, true>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
     else
-        hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, false>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc);
+        hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, false>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
     hipLaunchKernelGGL(oss_dwconv3x3_wgrad_finish, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, dw, db, B, C);
     return (int)hipGetLastError();
 }
 
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
-                    int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s) {
+                    int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre, void *dpre) {
+    if ((pre != nullptr) != (dpre != nullptr)) return OSS_ERR_NULL;
     switch (io) {
-        case OSS_F32: return wgrad_launch<float>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s);
-        case OSS_F16: return wgrad_launch<f16_t>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s);
-        case OSS_BF16: return wgrad_launch<bf16_t>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s);
+        case OSS_F32: return wgrad_launch<float>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s, pre, dpre);
+        case OSS_F16: return wgrad_launch<f16_t>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s, pre, dpre);
+        case OSS_BF16: return wgrad_launch<bf16_t>(x, dy, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, s, pre, dpre);
     }
     return OSS_ERR_SHAPE;
 }

@@ -21,9 +21,10 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
 int scan_bwd_rows_per_wg(int variant);
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups);
 int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
-              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s);
+              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre = nullptr);
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
-                    int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
+                    int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre = nullptr,
+                    void *dpre = nullptr);
 int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate, void *y,
                 float *mean, float *rstd, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
                 hipStream_t s);

@@ -283,7 +283,7 @@ class SS2D_1(nn.Module):
         """``residual``: the block's skip connection, added in the epilogue of the out_conv kernel"""
         xz = conv1x1(x, self.in_conv)
         x, z = xz.chunk(2, dim=1)
-        x = F.silu(dwconv3x3(x, self.conv2d))
+        x = dwconv3x3(x, self.conv2d, act=True)  # act(conv2d(x)), silu in the conv's epilogue
         y2 = self.forward_core(x, gate=z)  # out_norm(merge) * silu(z), fused in the LayerNorm kernel
         if self.omni and self.fused_channel and y2.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
                 chan_supported(self.dc_inner or 1, self.dc_state, self.d_inner):

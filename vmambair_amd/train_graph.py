@@ -37,12 +37,15 @@ class GraphedTrainStep:
     def __init__(self, net: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), ema_decay: float = 0.999,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
                  loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
-                 fused_optimizer: bool = True):
+                 fused_optimizer: bool = True, split_graphs: bool = False):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
         assert self.device.type == "cuda", "graph capture needs a GPU"
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # two graphs (forward+backward | optimizer) with the gradient all-reduce between them: always for world > 1;
+        # ``split_graphs`` forces the same structure on one GPU (tests)
+        self.split = self.world > 1 or split_graphs
         self.autocast_dtype = autocast_dtype
         self.loss_fn = loss_fn
         self.ema_decay = ema_decay
@@ -135,9 +138,9 @@ class GraphedTrainStep:
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb):
             self.static_loss = self._fwd_bwd()
-            if self.world == 1:
+            if not self.split:
                 self._opt_ema()
-        if self.world > 1:
+        if self.split:
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt):
                 self._opt_ema()
@@ -149,7 +152,7 @@ class GraphedTrainStep:
         self.static_lq.copy_(lq, non_blocking=True)
         self.static_gt.copy_(gt, non_blocking=True)
         self.graph_fb.replay()
-        if self.world > 1:
+        if self.split:
             self._allreduce()
             self.graph_opt.replay()
         return self.static_loss
