@@ -180,20 +180,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     }
     __syncthreads();
     const float *yb = p.y + (size_t)b * 2 * dc * L;
-    if (lift) {
-        for (int i = 0; i < dc; ++i) {
-            float a = 0.f;
-            for (int l = tid; l < L; l += 256) a = __builtin_fmaf(dys[l], yb[i * L + l] + yb[(dc + i) * L + l], a);
-            const float t = block_sum_256(a, red, tid);
-            if (tid == 0) gp[sl.coutw + i] = t;
-        }
-        float a = 0.f;
-        for (int l = tid; l < L; l += 256) a += dys[l];
-        const float t = block_sum_256(a, red, tid);
-        if (tid == 0) gp[sl.coutb] = t;
-    } else if (tid < dc + 1) {
-        gp[sl.coutw + tid] = 0.f;  // dc slots + the bias slot (unused without the lift)
-    }
+    // (the conv_cout gradients are wave-level sums done by waves 2 and 3 while waves 0 and 1 run the scans, below)
     const float *zb = p.zt + (size_t)b * 2 * L * Cc;
     const float *db = p.dts + (size_t)b * 2 * dc * L;
     float *dzb, *ddb, *dub;
@@ -213,29 +200,39 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
         const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float carry = 0.f, dA = 0.f, dD = 0.f, dbs = 0.f;
-        for (int t0 = L - 1; t0 >= 0; t0 -= kChU) {   // steps t0, t0 - 1, ..., fetched kChU at a time
-            // (1) fetch + recurrence-independent terms, (2) the reverse recurrence (two dependent FMAs per step),
-            // (3) the gradients of the step (independent of each other)
-            float us[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1], dyv[kChU], dls[kChU], sg[kChU], av[kChU], dhv[kChU];
+        // raw operands of the steps t0, t0 - 1, ...: fetched one chunk ahead of the arithmetic
+        auto fetch = [&](int t0, float (&xs)[kChU], float (&Bs)[kChU], float (&Cs)[kChU], float (&hv)[kChU + 1]) {
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
                 const float *zr = zb + (k * L + l) * Cc + Rc;
-                const float x = dr[l] + bias;
+                xs[j] = dr[l];
+                Bs[j] = zr[n];
+                Cs[j] = zr[kChN + n];
+                hv[j] = hr[l * kChN + n];
+            }
+            const int t = t0 - kChU;  // the state before the chunk's last step
+            const int tc = max(t, 0), l = k ? L - 1 - tc : tc;
+            hv[kChU] = t >= 0 ? hr[l * kChN + n] : 0.f;
+        };
+        float xs[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1];
+        fetch(L - 1, xs, Bs, Cs, hv);
+        for (int t0 = L - 1; t0 >= 0; t0 -= kChU) {
+            float nxs[kChU], nBs[kChU], nCs[kChU], nhv[kChU + 1];
+            if (t0 - kChU >= 0) fetch(t0 - kChU, nxs, nBs, nCs, nhv);
+            // (1) recurrence-independent terms, (2) the reverse recurrence (two dependent FMAs per step),
+            // (3) the gradients of the step (independent of each other)
+            float us[kChU], dyv[kChU], dls[kChU], sg[kChU], av[kChU], dhv[kChU];
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
+                const float x = xs[j] + bias;
                 float e;
                 dls[j] = softplus_thr(x, e);
                 sg[j] = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
                 av[j] = exp2_hw(dls[j] * A2);
                 us[j] = ur[l];
-                Bs[j] = zr[n];
-                Cs[j] = zr[kChN + n];
-                hv[j] = hr[l * kChN + n];
                 dyv[j] = t0 - j >= 0 ? cw * dys[l] : 0.f;
-            }
-            {
-                const int t = t0 - kChU;  // the state before the chunk's last step
-                const int tc = max(t, 0), l = k ? L - 1 - tc : tc;
-                hv[kChU] = t >= 0 ? hr[l * kChN + n] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
@@ -270,10 +267,28 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
                     }
                 }
             }
+            if (t0 - kChU >= 0) {
+#pragma unroll
+                for (int j = 0; j < kChU; ++j) { xs[j] = nxs[j]; Bs[j] = nBs[j]; Cs[j] = nCs[j]; hv[j] = nhv[j]; }
+                hv[kChU] = nhv[kChU];
+            }
         }
         if (act) {
             gp[sl.dA + row * kChN + n] = dA * A;  // d/dA_log: A = -exp(A_log)
             if (n == 15) { gp[sl.dD + row] = dD; gp[sl.dbias + row] = dbs; }
+        }
+    }
+    else {
+        // waves 2, 3: gradients of conv_cout (sums over l of dyc * (y0 + y1), and of dyc), no workgroup barrier needed
+        const int wl = tid - 128;  // 0 .. 127
+        for (int o = wl >> 6; o < dc + 1; o += 2) {   // wave 2: outputs 0, 2, 4; wave 3: outputs 1, 3
+            float a = 0.f;
+            if (lift) {
+                for (int l = wl & 63; l < L; l += 64)
+                    a = o < dc ? __builtin_fmaf(dys[l], yb[o * L + l] + yb[(dc + o) * L + l], a) : a + dys[l];
+            }
+            const float t = segment_sum_to_last<64>(a);
+            if ((wl & 63) == 63) gp[sl.coutw + o] = t;   // slot dc = conv_cout.bias
         }
     }
     __syncthreads();
