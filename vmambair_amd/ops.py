@@ -17,6 +17,7 @@ No CPU implementation exists: CPU tensors are rejected exactly as the reference 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional
 
@@ -25,6 +26,34 @@ import torch
 from . import _capi
 
 _DT = {torch.float32: _capi.OSS_F32, torch.float16: _capi.OSS_F16, torch.bfloat16: _capi.OSS_BF16}
+
+
+# Weight gradients are needed by nobody before the optimizer: a training step may hand them a second stream so that
+# they overlap the input-gradient chain (vmambair_amd/train_graph.py joins the stream before the optimizer runs).
+_WGRAD_SIDE: Optional[torch.cuda.Stream] = None
+
+
+@contextlib.contextmanager
+def wgrad_side_stream(stream: Optional[torch.cuda.Stream]):
+    """Inside this context the weight-gradient launches of the in-tree backward ops go to ``stream`` (forked from the
+    current stream).  The caller must make the current stream wait for ``stream`` before reading any weight gradient."""
+    global _WGRAD_SIDE
+    prev, _WGRAD_SIDE = _WGRAD_SIDE, stream
+    try:
+        yield
+    finally:
+        _WGRAD_SIDE = prev
+
+
+def _fork_for_wgrad(*inputs: torch.Tensor):
+    """-> a context under which to allocate the weight-gradient outputs and launch their kernels"""
+    side = _WGRAD_SIDE
+    if side is None:
+        return contextlib.nullcontext()
+    side.wait_stream(torch.cuda.current_stream())
+    for t in inputs:
+        t.record_stream(side)   # the allocator must not hand these blocks out again before the side stream is done
+    return torch.cuda.stream(side)
 
 
 def scan_chunk() -> int:
@@ -346,13 +375,14 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
         dwdt = torch.einsum("bkdl,bkrl->kdr", ddts.view(B, 4, D, L), xdbl[:, :, :R])
         return [dwx, dwdt]
     lib = _capi.load()
-    dwx = torch.empty((4, Cc, D), dtype=torch.float32, device=dev)
-    dwdt = torch.empty((4, D, R), dtype=torch.float32, device=dev)
-    part = torch.empty((max(1, lib.oss_proj_wgrad_partial_floats(B, D, Cc, R, L)),), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), ddts.data_ptr(),
-                                       dwx.data_ptr(), dwdt.data_ptr(), part.data_ptr(), B, D, Cc, R, L,
-                                       torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
+        with _fork_for_wgrad(x2, xdbl, dxdbl, ddts):
+            dwx = torch.empty((4, Cc, D), dtype=torch.float32, device=dev)
+            dwdt = torch.empty((4, D, R), dtype=torch.float32, device=dev)
+            part = torch.empty((max(1, lib.oss_proj_wgrad_partial_floats(B, D, Cc, R, L)),), dtype=torch.float32, device=dev)
+            _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), ddts.data_ptr(),
+                                           dwx.data_ptr(), dwdt.data_ptr(), part.data_ptr(), B, D, Cc, R, L,
+                                           torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
     return [dwx, dwdt]
 
 
@@ -465,21 +495,23 @@ def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_b
         dy = dy.to(x.dtype)
     act = pre is not None and pre.numel() > 0
     dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
-    dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if has_bias else None
-    part = torch.empty((B, Cc, 10), dtype=torch.float32, device=x.device)
     dpre = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device) if act else None
     lib = _capi.load()
     with torch.cuda.device(x.device):
-        st = torch.cuda.current_stream().cuda_stream
-        # weight gradient first: with the fused activation it also produces the gradient the input-gradient pass convolves
-        _capi.check(lib.oss_dwconv3x3_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(),
-                                            pre.data_ptr() if act else None, _ptr(dpre), B, Cc, H, W, x.stride(0), x.stride(1),
-                                            dy.stride(0), dy.stride(1), st), "oss_dwconv3x3_wgrad")
+        # weight gradient: with the fused activation it also produces the gradient the input-gradient pass convolves
+        # (so it stays on the main stream); without it, it may overlap the input gradient on the side stream
+        with (contextlib.nullcontext() if act else _fork_for_wgrad(x, dy)):
+            dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+            db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if has_bias else None
+            part = torch.empty((B, Cc, 10), dtype=torch.float32, device=x.device)
+            _capi.check(lib.oss_dwconv3x3_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(),
+                                                pre.data_ptr() if act else None, _ptr(dpre), B, Cc, H, W, x.stride(0), x.stride(1),
+                                                dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream),
+                        "oss_dwconv3x3_wgrad")
         g = dpre if act else dy
         _capi.check(lib.oss_dwconv3x3_fwd(_DT[x.dtype], g.data_ptr(), w.data_ptr(), None, dx.data_ptr(), None, B, Cc, H, W,
-                                          g.stride(0), g.stride(1), dx.stride(0), dx.stride(1), 1, st),
-                    "oss_dwconv3x3_fwd(flip)")
+                                          g.stride(0), g.stride(1), dx.stride(0), dx.stride(1), 1,
+                                          torch.cuda.current_stream().cuda_stream), "oss_dwconv3x3_fwd(flip)")
     return [dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 
@@ -849,17 +881,17 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
         dy = dy.to(x.dtype)
     w = weight.detach().float().reshape(Cout, Cin).contiguous()
     dx = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
-    dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
     lib = _capi.load()
-    part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        st = torch.cuda.current_stream().cuda_stream
+        with _fork_for_wgrad(x, dy):
+            dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
+            db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
+            part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
+            _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
+                                              Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
+                                              torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
         _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
-                                          dy.stride(0), dy.stride(1), st), "oss_conv1x1_dgrad")
-        _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
-                                          Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1), st),
-                    "oss_conv1x1_wgrad")
+                                          dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
     return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 

@@ -37,7 +37,7 @@ class GraphedTrainStep:
     def __init__(self, net: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), ema_decay: float = 0.999,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
                  loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
-                 fused_optimizer: bool = True, split_graphs: bool = False):
+                 fused_optimizer: bool = True, split_graphs: bool = False, overlap_wgrads: bool = True):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -81,6 +81,8 @@ class GraphedTrainStep:
             self.fopt = FusedAdamEMA(self.params, self.ema, lr=lr, betas=betas, ema_decay=ema_decay)
         else:
             self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, fused=True, capturable=True)
+        # weight gradients (needed only by the optimizer) run on a second stream next to the input-gradient chain
+        self.wside = torch.cuda.Stream(device=self.device) if overlap_wgrads else None
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
@@ -100,7 +102,10 @@ class GraphedTrainStep:
             else:
                 out = self.net(self.static_lq)
         loss = self.loss_fn(out.float(), self.static_gt)
-        loss.backward()
+        with _ops.wgrad_side_stream(self.wside):
+            loss.backward()
+        if self.wside is not None:
+            torch.cuda.current_stream().wait_stream(self.wside)   # join before anything reads a weight gradient
         if self._shadows:
             with torch.no_grad():
                 torch._foreach_copy_(self._master_grads, [s_.grad for s_ in self._shadows])
