@@ -78,7 +78,7 @@ def test_graphed_train_step_matches_eager(split, acdt):
     net_g = make()
     # one eager warm-up step happens inside capture() (optimizer state must exist before capture),
     # so the three replays are training steps 2..4
-    step = GraphedTrainStep(net_g, autocast_dtype=acdt, warmup=1, split_graphs=split)
+    step = GraphedTrainStep(net_g, autocast_dtype=acdt, warmup=1, split_graphs=split, overlap_wgrads=split)  # two-graph case also forks the weight-gradient stream
     losses_g = [float(step(lq, gt)) for _ in range(3)]
     net_e = make()
     opt = torch.optim.Adam(net_e.parameters(), lr=2e-4, betas=(0.9, 0.99))
