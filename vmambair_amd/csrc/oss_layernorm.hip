@@ -283,6 +283,13 @@ constexpr int kLnCPW = 24;
 
 // waves per workgroup: the fewest of 4 / 8 / 16 that keep a wave's channels in registers
 static int ln_waves(int C) { return C <= 4 * kLnCPW ? 4 : (C <= 8 * kLnCPW ? 8 : 16); }
+// ... and 8 instead of 4 when 4 would leave the chip short of waves (a 64x64 patch at batch 8 is 256 tiles of 128 pixels:
+// one 4-wave workgroup per CU, i.e. one wave per SIMD and nothing to hide the load latency behind)
+static int ln_waves(int B, int C, int P) {
+    int nw = ln_waves(C);
+    if (nw == 4 && C >= 48 && (long)B * ((P + 127) / 128) * 4 < 2048) nw = 8;
+    return nw;
+}
 static bool ln_cached(int C) { return C <= kLnMaxWaves * kLnCPW; }
 // two pixels per lane: needs pair-aligned rows, and the register room of <= 8 waves per workgroup
 static bool ln_pairs(int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, const void *a, const void *b2,
@@ -307,7 +314,7 @@ size_t ln_nchw_bwd_partial_floats(int B, int C, int P) { return (size_t)((P + 63
 template <typename TX, typename TY>
 static int ln_fwd_t(const void *x, const float *w, const float *bias, const void *gate, void *y, float *mean, float *rstd,
                     int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps, hipStream_t s) {
-    const int nw = ln_waves(C);
+    const int nw = ln_waves(B, C, P);
     const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, y, mean) && (reinterpret_cast<uintptr_t>(rstd) & 7u) == 0;
     const int tile = ln_tile(pairs);
     dim3 grid((P + tile - 1) / tile, B), block(64 * nw);
@@ -323,7 +330,7 @@ template <typename TX, typename TY>
 static int ln_bwd_t(const void *x, const float *w, const float *bias, const void *gate, const void *dy, const float *mean,
                     const float *rstd, void *dx, void *dgate, float *dw, float *db, float *part, int B, int C, int P,
                     int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res) {
-    const int nw = ln_waves(C);
+    const int nw = ln_waves(B, C, P);
     const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, dy, dx) &&
                        ((reinterpret_cast<uintptr_t>(dgate) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) |
                          reinterpret_cast<uintptr_t>(res)) & 7u) == 0;
