@@ -499,7 +499,7 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
         const int xk = (int)xsk;
         if (K <= 16 * 12) {
             // whole K in registers: enough workgroups to fill the chip twice, otherwise as few activation re-loads as possible
-            int split = (int)((2048 + waves_p - 1) / waves_p);
+            int split = (int)((4096 + waves_p - 1) / waves_p);
             if (split < 1) split = 1;
             if (split > mt) split = mt;
             const int per = (mt + split - 1) / split;
@@ -514,7 +514,7 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
         } else {
             // K in chunks of 128: up to 3 row tiles accumulate per workgroup (fewest re-loads that still fill the chip)
             int per = 3;
-            while (per > 1 && waves_p * ((mt + per - 1) / per) < 2048) --per;
+            while (per > 1 && waves_p * ((mt + per - 1) / per) < 4096) --per;
             if (per > mt) per = mt;
             dim3 grid(pb, B, (mt + per - 1) / per);
 #define OSS_PAIR1(MT_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pairk_kernel<T, 8, MT_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, res)

@@ -287,7 +287,7 @@ static int ln_waves(int C) { return C <= 4 * kLnCPW ? 4 : (C <= 8 * kLnCPW ? 8 :
 // one 4-wave workgroup per CU, i.e. one wave per SIMD and nothing to hide the load latency behind)
 static int ln_waves(int B, int C, int P) {
     int nw = ln_waves(C);
-    if (nw == 4 && C >= 48 && (long)B * ((P + 127) / 128) * 4 < 2048) nw = 8;
+    if (nw == 4 && C >= 48 && (long)B * ((P + 127) / 128) * 4 < 4096) nw = 8;
     return nw;
 }
 static bool ln_cached(int C) { return C <= kLnMaxWaves * kLnCPW; }

@@ -655,7 +655,7 @@ static int proj_dgrad_t(const void *ddts, void *dxdbl, const void *du, const flo
 // output tiles per workgroup: as few activation re-loads as possible once the chip is full (2 waves per SIMD)
 static int mfma_tiles_per_wg(int B, int L, int mt) {
     const long waves = 2L * B * ((L + 63) / 64);
-    long split = (2048 + waves - 1) / waves;
+    long split = (4096 + waves - 1) / waves;
     if (split < 1) split = 1;
     if (split > mt) split = mt;
     return (int)((mt + split - 1) / split);
@@ -665,7 +665,7 @@ static int dt_waves(int B, int L, int D) {
     // enough waves to fill the chip at the deep levels (few time steps), 4 per workgroup where there are plenty
     const long wgs = 4L * B * ((L + 127) / 128);
     int nw = 4;
-    while (nw < 16 && wgs * nw < 2048 && nw * 8 <= D) nw *= 2;
+    while (nw < 16 && wgs * nw < 16384 && nw * 8 <= D) nw *= 2;
     return nw;
 }
 
