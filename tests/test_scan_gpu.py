@@ -153,7 +153,7 @@ def test_every_forward_variant(fv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, fwd_variant=fv)
 
 
-@pytest.mark.parametrize("bv", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("bv", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_every_backward_variant(bv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, bwd_variant=bv)

@@ -51,7 +51,7 @@ def main():
     print(json.dumps({"copy_kernel_GBps": round(copy_gbs, 1)}), flush=True)
     del src, dst
 
-    shapes = [(8, 384, 4096, 4), (8, 192, 4096, 4), (8, 768, 1024, 4), (8, 1536, 256, 4)]
+    shapes = [(8, 192, 4096, 4)]
     if not args.quick:
         shapes += [(8, 768, 256, 4), (8, 8, 96, 2), (4, 384, 16384, 4)]
     for (B, KD, L, G) in shapes:
@@ -66,7 +66,7 @@ def main():
             D = torch.randn(KD, device=dev)
             bias = 0.5 * torch.rand(KD, device=dev)
             dout = torch.randn(B, KD, L, device=dev).to(dt)
-            for which, variants in ((0, (0, 3, 5, 6, 7)), (1, (0, 3, 4, 5))):
+            for which, variants in ((0, (0, 6)), (1, (3, 7))):
                 for v in variants:
                     lib.oss_scan_set_variant(v if which == 0 else -1, v if which == 1 else -1)
                     try:

@@ -414,8 +414,8 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 //   3: variant 0 with <= 256 VGPRs (no spills; 2 waves per SIMD)
 //   4: 64 x 8 x 12 (12 rows/WG, 3 waves per SIMD, no spills): row counts that give <= 256 such workgroups
 //   5: 64 x 8 x 6  (6 rows/WG, no spills): 48-row groups at batch 8 = exactly 256 workgroups
-static const int kBwdRows[] = {8, 4, 8, 8, 12, 6};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 5) ? 1 : variant]; }
+static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 7) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
@@ -425,6 +425,8 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
         case 3: return launch_bwd<T, 64, 8, 8, 8, 1, 2>(p, stream, timer);
         case 4: return launch_bwd<T, 64, 8, 12, 8, 1, 3>(p, stream, timer);
         case 5: return launch_bwd<T, 64, 8, 6, 8, 1, 2>(p, stream, timer);
+        case 6: return launch_bwd<T, 64, 8, 12, 16, 1, 3>(p, stream, timer);   // variant 4 staging all 16 states at once
+        case 7: return launch_bwd<T, 64, 8, 8, 16, 1, 2>(p, stream, timer);    // variant 3 likewise
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }
