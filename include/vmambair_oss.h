@@ -242,6 +242,25 @@ int oss_gelu_gate_fwd(oss_dtype io, const void *h, void *out, int batch, size_t 
 int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int batch, size_t half_elems,
                       int64_t h_batch_stride, int64_t dout_batch_stride, oss_stream_t stream);
 
+/* Deferred finishing.  Every two-stage reduction of the backward kernels (split-K slabs of oss_conv1x1_wgrad /
+ * oss_proj_wgrad, per-workgroup partials of oss_ln_nchw_bwd, oss_dwconv3x3_wgrad, oss_chan_bwd) normally ends with a
+ * small finishing launch that adds the partial vectors in a fixed order (~12 such launches per OSS block).  After
+ * oss_set_defer_finish(1) those launches are not issued: each call registers its reduction with the library instead
+ * (scratch buffers and gradient outputs must then stay alive and unread), and oss_flush_finishes runs ALL of them as
+ * one launch: it writes the chunk table (oss_deferred_chunks() entries of sizeof(oss_sum_chunk) bytes, one per <= 64
+ * outputs) into host_table (pinned; must stay alive if the call is captured into a hipGraph), copies it to
+ * device_table on the stream and launches the summation there.  Same fixed summation order on every run.
+ * oss_set_defer_finish(0/1) also drops whatever was registered and not flushed. */
+typedef struct {
+    const void *src;   /* partial vector 0 */
+    void *dst;         /* output of element j0 */
+    int64_t stride;    /* floats between consecutive partial vectors */
+    int j0, n, K, reserved_;
+} oss_sum_chunk;
+void oss_set_defer_finish(int on);
+size_t oss_deferred_chunks(void);
+int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chunks, oss_stream_t stream);
+
 /* Adam + EMA of the training step (MambaSISR_model.py:120-147: torch.optim.Adam without amsgrad / weight decay,
  * then ema = decay * ema + (1 - decay) * param) as one elementwise launch over a chunk table in device memory:
  * one entry per <= OSS_ADAM_CHUNK consecutive elements of one parameter tensor (all float; ema may be NULL).

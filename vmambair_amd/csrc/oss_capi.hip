@@ -2,6 +2,8 @@
 #include <atomic>
 #include <mutex>
 #include <vector>
+#include <cstring>
+#include <algorithm>
 #include "oss_device.h"
 #include "oss_host.h"
 
@@ -13,6 +15,24 @@ static std::atomic<int> g_last_fwd{-1}, g_last_bwd{-1};
 // ---- variant heuristics -----------------------------------------------------------------------
 // The forward/backward kernels are VALU-bound, so the cheapest variant in instructions per
 // (element, state) wins as long as the launch still fills 256 CUs x 4 SIMDs with >= 2 waves.
+static std::atomic<int> g_defer_finish{0};
+static std::mutex g_defer_mu;
+static std::vector<oss_sum_chunk> g_defer_chunks;
+bool defer_finish() { return g_defer_finish.load() != 0; }
+void defer_sum(const float *src, int K, size_t stride, size_t V, float *dst0, size_t n0, float *dst1) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    for (size_t j = 0; j < V;) {   // chunks of <= 64 outputs that do not straddle the dst0 / dst1 boundary
+        const size_t lim = j < n0 ? n0 : V;
+        const size_t n = std::min<size_t>(64, lim - j);
+        oss_sum_chunk c;
+        c.src = src;
+        c.dst = j < n0 ? dst0 + j : dst1 + (j - n0);
+        c.stride = (int64_t)stride;
+        c.j0 = (int)j; c.n = (int)n; c.K = K; c.reserved_ = 0;
+        g_defer_chunks.push_back(c);
+        j += n;
+    }
+}
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes) {
     (void)dstate; (void)elem_bytes;
     const int rows_per_group = dim / n_groups;
@@ -221,10 +241,10 @@ int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweigh
 
 size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen) {
     if (batch <= 0 || D <= 0 || C <= 0 || R <= 0 || seqlen <= 0) return 0;
-    // the two weight gradients run one after the other on the same scratch
+    // the two weight gradients keep separate scratch regions (their finishing may be deferred)
     const size_t slabs = (size_t)batch * conv1x1_wgrad_slabs(seqlen);
     const size_t a = slabs * 2 * (2 * (size_t)C) * D, b = slabs * 4 * (size_t)D * R;
-    return a > b ? a : b;
+    return a + b;
 }
 
 int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const float *dt_projs_weight, void *xdbl, void *dts,
@@ -255,7 +275,8 @@ int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *d
                           /*G*/ 2, /*gsg*/ C * L, /*xsg*/ D * L, /*Mh*/ C, /*gs_hi*/ 2 * C * L);
     if (e) return e;
     // dt_projs_weight: one problem per direction k: ddts[:, k] (D rows) x the dt rows of xdbl[:, k] (R rows)
-    return conv1x1_wgrad(io, ddts, xdbl, ddt_projs_weight, partials, batch, D, R, seqlen, 4 * D * L, L, 4 * C * L, L, s,
+    float *part2 = partials + (size_t)batch * conv1x1_wgrad_slabs(seqlen) * 2 * (2 * (size_t)C) * D;
+    return conv1x1_wgrad(io, ddts, xdbl, ddt_projs_weight, part2, batch, D, R, seqlen, 4 * D * L, L, 4 * C * L, L, s,
                          /*G*/ 4, /*gsg*/ D * L, /*xsg*/ C * L, /*Mh*/ D, 0);
 }
 
@@ -312,6 +333,29 @@ int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, i
     if (!h || !dout || !dh) return OSS_ERR_NULL;
     if (batch <= 0 || half_elems == 0) return OSS_ERR_SHAPE;
     return gelu_gate_bwd(io, h, dout, dh, batch, half_elems, h_batch_stride, dout_batch_stride, reinterpret_cast<hipStream_t>(stream));
+}
+
+void oss_set_defer_finish(int on) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_defer_finish.store(on ? 1 : 0);
+    g_defer_chunks.clear();
+}
+size_t oss_deferred_chunks(void) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    return g_defer_chunks.size();
+}
+int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chunks, oss_stream_t stream) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    const size_t n = g_defer_chunks.size();
+    if (n == 0) return 0;
+    if (!host_table || !device_table) return OSS_ERR_NULL;
+    if (n > capacity_chunks) return OSS_ERR_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::memcpy(host_table, g_defer_chunks.data(), n * sizeof(oss_sum_chunk));
+    hipError_t e = hipMemcpyAsync(device_table, host_table, n * sizeof(oss_sum_chunk), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    g_defer_chunks.clear();
+    return sum_partials_multi(reinterpret_cast<const oss_sum_chunk *>(device_table), (int)n, s);
 }
 
 int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,

@@ -451,7 +451,10 @@ int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsu
     float *dug = ddts + (size_t)p.B * 2 * p.dc * p.L;
     if (use_lds) hipLaunchKernelGGL(oss_chan_bwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
     else         hipLaunchKernelGGL(oss_chan_bwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
-    hipLaunchKernelGGL(oss_chan_grad_finish, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, gsum, p.B, (int)np);
+    if (defer_finish())
+        defer_sum(gpart, p.B, np, np, gsum, np, nullptr);
+    else
+        hipLaunchKernelGGL(oss_chan_grad_finish, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, gpart, gsum, p.B, (int)np);
     return (int)hipGetLastError();
 }
 

@@ -381,7 +381,9 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
     const int mt = (M + 31) >> 5, nt = (NB + 31) >> 5;
     const T *gb = dy + b * gsb + g * gsg;
     const T *xb = x + b * xsb + g * xsg;
-    float *pb = part + ((size_t)(b * gridDim.x + slab) * G + g) * M * NB;
+    // one partial vector per (batch, slab): [G * M rows in DESTINATION order][N], then (NB > N) the M dbias sums
+    const size_t pvec = (size_t)G * M * N + (NB > N ? M : 0);
+    float *pb = part + (size_t)(b * gridDim.x + slab) * pvec;
     const short kOne = (short)from_f32<T>(1.0f).v;  // 1.0 in the I/O type
     const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0}, ones8 = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
     const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
@@ -442,44 +444,44 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             const int cn = n0 + col;
-            if (row < M && cn < NB) pb[(size_t)row * NB + cn] = acc[r];
+            if (row < M && cn < NB) {
+                const size_t drow = ((size_t)(row / Mh) * G + g) * Mh + row % Mh;  // destination row of (group g, row)
+                if (cn < N) pb[drow * N + cn] = acc[r];
+                else pb[(size_t)G * M * N + row] = acc[r];   // dbias (only ever with G == 1)
+            }
         }
     }
 }
 
-// dW[g][m][n] = sum over slabs (fixed order); output row of (g, m) = ((m / Mh) G + g) Mh + m % Mh.
+// out[j] = sum over the nslab partial vectors (fixed order), j < nw -> dw[j], else db[j - nw].
 // 64 outputs x 4 slices of the slab list per workgroup: slice s adds slabs s, s + 4, ... (4 loads in flight),
 // the four slice sums are combined in a fixed order.
 __global__ void __launch_bounds__(256)
-oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int nslab, size_t mn,
-                         int G, int N, int Mh, int NB) {
+oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int nslab, size_t pvec,
+                         size_t nw) {
     __shared__ float red[4][64];
     const int colx = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + colx;
-    const int g = blockIdx.y;
     float s = 0.f;
-    if (i < mn) {
-        const float *pp = part + (size_t)g * mn + i;
-        const size_t st = (size_t)G * mn;
+    if (i < pvec) {
+        const float *pp = part + i;
         int k = slice;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         for (; k + 12 < nslab; k += 16) {
-            s0 += pp[(size_t)k * st];
-            s1 += pp[(size_t)(k + 4) * st];
-            s2 += pp[(size_t)(k + 8) * st];
-            s3 += pp[(size_t)(k + 12) * st];
+            s0 += pp[(size_t)k * pvec];
+            s1 += pp[(size_t)(k + 4) * pvec];
+            s2 += pp[(size_t)(k + 8) * pvec];
+            s3 += pp[(size_t)(k + 12) * pvec];
         }
-        for (; k < nslab; k += 4) s0 += pp[(size_t)k * st];
+        for (; k < nslab; k += 4) s0 += pp[(size_t)k * pvec];
         s = (s0 + s1) + (s2 + s3);
     }
     red[slice][colx] = s;
     __syncthreads();
-    if (slice == 0 && i < mn) {
+    if (slice == 0 && i < pvec) {
         const float t = (red[0][colx] + red[1][colx]) + (red[2][colx] + red[3][colx]);
-        const size_t m = i / NB, n = i - m * NB;
-        const size_t row = ((m / Mh) * G + g) * Mh + m % Mh;
-        if (n < (size_t)N) dw[row * N + n] = t;
-        else db[row] = t;
+        if (i < nw) dw[i] = t;
+        else db[i - nw] = t;
     }
 }
 
@@ -587,9 +589,13 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
             break;
         default: return OSS_ERR_SHAPE;
     }
-    const size_t mn = (size_t)M * NB;
-    hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((mn + 63) / 64), G), dim3(256), 0, s, part, dw, db, slabs * B, mn,
-                       G, N, Mh, NB);
+    if (db && G != 1) return OSS_ERR_SHAPE;
+    const size_t nw = (size_t)G * M * N, pvec = nw + (db ? M : 0);
+    if (defer_finish())
+        defer_sum(part, slabs * B, pvec, pvec, dw, nw, db);
+    else
+        hipLaunchKernelGGL(oss_conv1x1_wgrad_finish, dim3((unsigned)((pvec + 63) / 64)), dim3(256), 0, s, part, dw, db, slabs * B,
+                           pvec, nw);
     return (int)hipGetLastError();
 }
 

@@ -187,8 +187,9 @@ oss_dwconv3x3_wgrad_kernel(const T *__restrict__ x, const T *__restrict__ dy, fl
         if (lane == 63) red[wave][i] = s;
     }
     __syncthreads();
+    // one partial vector per batch element: [C][9] tap sums, then the C bias sums
     if (threadIdx.x < 10)
-        part[((size_t)b * C + c) * 10 + threadIdx.x] =
+        part[(size_t)b * C * 10 + (threadIdx.x < 9 ? (size_t)c * 9 + threadIdx.x : (size_t)9 * C + c)] =
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
@@ -198,9 +199,8 @@ oss_dwconv3x3_wgrad_finish(const float *__restrict__ part, float *__restrict__ d
     if (i >= C * 10) return;
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += part[(size_t)b * C * 10 + i];
-    const int c = i / 10, k = i - c * 10;
-    if (k < 9) dw[c * 9 + k] = s;
-    else if (db) db[c] = s;
+    if (i < 9 * C) dw[i] = s;
+    else if (db) db[i - 9 * C] = s;
 }
 
 template <typename T>
@@ -248,7 +248,10 @@ static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, flo
         hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, true>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
     else
         hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, false>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
-    hipLaunchKernelGGL(oss_dwconv3x3_wgrad_finish, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, dw, db, B, C);
+    if (defer_finish())
+        defer_sum(part, B, (size_t)C * 10, (size_t)C * (db ? 10 : 9), dw, (size_t)C * 9, db);
+    else
+        hipLaunchKernelGGL(oss_dwconv3x3_wgrad_finish, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, dw, db, B, C);
     return (int)hipGetLastError();
 }
 

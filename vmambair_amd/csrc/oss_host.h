@@ -58,6 +58,11 @@ int row_affine(oss_dtype io, const void *x, const float *mul, const float *add, 
                int64_t xsc, float alpha, hipStream_t s);
 int gelu_gate_fwd(oss_dtype io, const void *h, void *out, int B, size_t n, int64_t hsb, hipStream_t s);
 int gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int B, size_t n, int64_t hsb, int64_t gsb, hipStream_t s);
+// oss_set_defer_finish(1): the launchers do not run their finishing kernels; they register the reduction instead
+// (out[j] = sum_{k<K} src[k * stride + j], j < n0 -> dst0[j], else dst1[j - n0]) and oss_flush_finishes runs them all
+bool defer_finish();
+void defer_sum(const float *src, int K, size_t stride, size_t V, float *dst0, size_t n0, float *dst1);
+int sum_partials_multi(const oss_sum_chunk *chunks, int n_chunks, hipStream_t s);
 int adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
                   float ema_decay, hipStream_t s);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);

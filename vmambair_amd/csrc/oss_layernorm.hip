@@ -345,7 +345,10 @@ static int ln_bwd_t(const void *x, const float *w, const float *bias, const void
     TY *dgp = reinterpret_cast<TY *>(dgate);
     if (gate) OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, true, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp);
     else      OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, false, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp);
-    hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 15) / 16), dim3(256), 0, s, part, dw, db, nblk, C);
+    if (defer_finish())
+        defer_sum(part, nblk, (size_t)2 * C, (size_t)(db ? 2 : 1) * C, dw, (size_t)C, db);
+    else
+        hipLaunchKernelGGL(oss_ln_nchw_bwd_finish, dim3((2 * C + 15) / 16), dim3(256), 0, s, part, dw, db, nblk, C);
     return (int)hipGetLastError();
 }
 

@@ -53,6 +53,40 @@ oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__re
     }
 }
 
+// One launch for ALL deferred partial-sum reductions of a backward pass (weight-gradient split-K slabs, per-workgroup
+// LayerNorm / depth-wise-conv / channel-branch partials): chunk c = 64 consecutive outputs of one reduction,
+// out[j] = sum_{k < K} src[k * stride + j] in a fixed order (4 slices of the k range, combined in a fixed order).
+__global__ void __launch_bounds__(256)
+oss_sum_partials_kernel(const oss_sum_chunk *__restrict__ chunks) {
+    __shared__ float red[4][64];
+    const oss_sum_chunk c = chunks[blockIdx.x];
+    const int colx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const float *src = reinterpret_cast<const float *>(c.src);
+    float s = 0.f;
+    if (colx < c.n) {
+        const float *pp = src + c.j0 + colx;
+        const size_t st = (size_t)c.stride;
+        int k = slice;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; k + 12 < c.K; k += 16) {
+            s0 += pp[(size_t)k * st];
+            s1 += pp[(size_t)(k + 4) * st];
+            s2 += pp[(size_t)(k + 8) * st];
+            s3 += pp[(size_t)(k + 12) * st];
+        }
+        for (; k < c.K; k += 4) s0 += pp[(size_t)k * st];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[slice][colx] = s;
+    __syncthreads();
+    if (slice == 0 && colx < c.n) reinterpret_cast<float *>(c.dst)[colx] = (red[0][colx] + red[1][colx]) + (red[2][colx] + red[3][colx]);
+}
+
+int sum_partials_multi(const oss_sum_chunk *chunks, int n_chunks, hipStream_t s) {
+    hipLaunchKernelGGL(oss_sum_partials_kernel, dim3(n_chunks), dim3(256), 0, s, chunks);
+    return (int)hipGetLastError();
+}
+
 int adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
                   float ema_decay, hipStream_t s) {
     hipLaunchKernelGGL(oss_adam_tick_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2);

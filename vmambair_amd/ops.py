@@ -45,6 +45,56 @@ def wgrad_side_stream(stream: Optional[torch.cuda.Stream]):
         _WGRAD_SIDE = prev
 
 
+# Deferred finishing (include/vmambair_oss.h: oss_set_defer_finish / oss_flush_finishes): inside ``deferred_finishes()`` the
+# backward ops skip their small finishing launches; ``flush_finishes`` runs them all as one launch.  The scratch buffers
+# (and outputs) of the deferred reductions are kept alive here until then.
+_DEFER_KEEP: Optional[list] = None
+
+
+@contextlib.contextmanager
+def deferred_finishes():
+    """Defer every partial-sum finishing launch issued inside the context; the caller MUST call ``flush_finishes`` (with the
+    context still open) before any weight gradient is read."""
+    global _DEFER_KEEP
+    lib = _capi.load()
+    assert _DEFER_KEEP is None, "deferred_finishes() does not nest"
+    _DEFER_KEEP = []
+    lib.oss_set_defer_finish(1)
+    try:
+        yield
+    finally:
+        lib.oss_set_defer_finish(0)
+        _DEFER_KEEP = None
+
+
+def _keep(*tensors) -> None:
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.extend(t for t in tensors if t is not None)
+
+
+class FinishTable:
+    """pinned host + device buffers for the chunk table of ``oss_flush_finishes`` (allocated outside any stream capture)"""
+
+    def __init__(self, device, capacity_chunks: int):
+        self.capacity = int(capacity_chunks)
+        nbytes = max(1, self.capacity) * _capi.SUM_CHUNK_BYTES
+        self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def pending_finish_chunks() -> int:
+    return int(_capi.load().oss_deferred_chunks())
+
+
+def flush_finishes(table: FinishTable) -> None:
+    lib = _capi.load()
+    with torch.cuda.device(table.dev.device):
+        _capi.check(lib.oss_flush_finishes(table.host.data_ptr(), table.dev.data_ptr(), table.capacity,
+                                           torch.cuda.current_stream().cuda_stream), "oss_flush_finishes")
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.clear()
+
+
 def _fork_for_wgrad(*inputs: torch.Tensor):
     """-> a context under which to allocate the weight-gradient outputs and launch their kernels"""
     side = _WGRAD_SIDE
@@ -383,6 +433,7 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
             _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), ddts.data_ptr(),
                                            dwx.data_ptr(), dwdt.data_ptr(), part.data_ptr(), B, D, Cc, R, L,
                                            torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
+            _keep(part, dwx, dwdt)
     return [dwx, dwdt]
 
 
@@ -508,6 +559,7 @@ def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_b
                                                 pre.data_ptr() if act else None, _ptr(dpre), B, Cc, H, W, x.stride(0), x.stride(1),
                                                 dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream),
                         "oss_dwconv3x3_wgrad")
+            _keep(part, dw, db)
         g = dpre if act else dy
         _capi.check(lib.oss_dwconv3x3_fwd(_DT[x.dtype], g.data_ptr(), w.data_ptr(), None, dx.data_ptr(), None, B, Cc, H, W,
                                           g.stride(0), g.stride(1), dx.stride(0), dx.stride(1), 1,
@@ -687,6 +739,7 @@ def chan_gate_bwd(g: torch.Tensor, y2: torch.Tensor, c: torch.Tensor, pooled: to
                                    g.stride(0), g.stride(1), y2.stride(0), y2.stride(1), 1.0, st), "oss_rowsum")
         _capi.check(lib.oss_chan_bwd(_chan_params(B, d, pooled, prm, (zt, dts, hs, y, yc, stat), c), gc.data_ptr(),
                                      dpool.data_ptr(), grads.data_ptr(), scratch.data_ptr(), st), "oss_chan_bwd")
+        _keep(scratch, grads)
         # dy2 = g * (1 + c) [or g] + dpooled / (H W)
         _capi.check(lib.oss_row_affine(_DT[y2.dtype], g.data_ptr(), c.data_ptr() if mul_mode else None, dpool.data_ptr(),
                                        dy2.data_ptr(), B, d, H * W, g.stride(0), g.stride(1), 1.0 / (H * W), st), "oss_row_affine")
@@ -802,6 +855,7 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
                                         dw.data_ptr(), _ptr(db), part.data_ptr(), _ptr(skip_grad), B, Cc, P, x.stride(0), x.stride(1),
                                         0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1), st),
                     "oss_ln_nchw_bwd")
+    _keep(part, dw, db)
     e = x.new_empty(0, dtype=torch.float32)
     return [dx, dgate if dgate is not None else e, dw, db if db is not None else e]
 
@@ -890,6 +944,7 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
             _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
                                               Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
                                               torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
+            _keep(part, dw, db)
         _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
                                           dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
     return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]

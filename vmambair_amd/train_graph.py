@@ -37,7 +37,8 @@ class GraphedTrainStep:
     def __init__(self, net: torch.nn.Module, lr: float = 2e-4, betas=(0.9, 0.99), ema_decay: float = 0.999,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
                  loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
-                 fused_optimizer: bool = True, split_graphs: bool = False, overlap_wgrads: bool = False):
+                 fused_optimizer: bool = True, split_graphs: bool = False, overlap_wgrads: bool = False,
+                 defer_finishes: bool = True):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -85,6 +86,10 @@ class GraphedTrainStep:
         # Measured SLOWER inside the hipGraph on this stack (138.5 vs 141.5 images/s: the cross-stream edges cost more
         # than the overlap of these 5-20 us kernels buys), hence off by default
         self.wside = torch.cuda.Stream(device=self.device) if overlap_wgrads else None
+        # the ~12 small partial-sum finishing launches per block (weight-gradient slabs, LayerNorm / depth-wise conv /
+        # channel partials) run as ONE launch at the end of the backward (oss_flush_finishes)
+        self.defer = defer_finishes
+        self.ftable = None
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
@@ -104,8 +109,20 @@ class GraphedTrainStep:
             else:
                 out = self.net(self.static_lq)
         loss = self.loss_fn(out.float(), self.static_gt)
-        with _ops.wgrad_side_stream(self.wside):
-            loss.backward()
+        if self.defer:
+            with _ops.deferred_finishes():
+                with _ops.wgrad_side_stream(self.wside):
+                    loss.backward()
+                if self.wside is not None:
+                    torch.cuda.current_stream().wait_stream(self.wside)
+                n = _ops.pending_finish_chunks()
+                if self.ftable is None or self.ftable.capacity < n:   # first (eager, warm-up) step: sizes the table
+                    assert not torch.cuda.is_current_stream_capturing(), "the finish table must exist before the capture"
+                    self.ftable = _ops.FinishTable(self.device, n)
+                _ops.flush_finishes(self.ftable)
+        else:
+            with _ops.wgrad_side_stream(self.wside):
+                loss.backward()
         if self.wside is not None:
             torch.cuda.current_stream().wait_stream(self.wside)   # join before anything reads a weight gradient
         if self._shadows:
