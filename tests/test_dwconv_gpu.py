@@ -154,6 +154,8 @@ def test_deferred_finishing_gives_the_same_gradients(acdt):
                 loss.backward()
                 n = ops.pending_finish_chunks()
                 assert n > 0
+                # a deferred gradient holds no data yet: each must have been adopted as its leaf's .grad, not copied
+                assert ops.orphaned_deferred_outputs(net.parameters()) == 0
                 ops.flush_finishes(ops.FinishTable(DEV, n))
                 assert ops.pending_finish_chunks() == 0
         else:
@@ -162,6 +164,11 @@ def test_deferred_finishing_gives_the_same_gradients(acdt):
 
     ref, got = grads(False), grads(True)
     assert set(ref) == set(got)
+    # fp32: summation order only; bf16: the library 3x3 convolutions are not run-to-run deterministic to the last 16-bit ulp
+    tol = 2e-6 if acdt is None else 1e-2
+    wrong = []
     for k in ref:
         sc = max(float(ref[k].abs().max()), 1e-12)
-        assert_close(got[k], ref[k], 1e-4, 2e-6 * sc + 1e-9, k)
+        if float((got[k] - ref[k]).abs().max()) > tol * sc + 1e-9:
+            wrong.append((k, float((got[k] - ref[k]).abs().max()), sc))
+    assert not wrong, wrong

@@ -48,28 +48,48 @@ def wgrad_side_stream(stream: Optional[torch.cuda.Stream]):
 # Deferred finishing (include/vmambair_oss.h: oss_set_defer_finish / oss_flush_finishes): inside ``deferred_finishes()`` the
 # backward ops skip their small finishing launches; ``flush_finishes`` runs them all as one launch.  The scratch buffers
 # (and outputs) of the deferred reductions are kept alive here until then.
+#
+# CONTRACT: a deferred output (a weight / bias gradient) holds no valid data until the flush, so nothing may READ it
+# before: it has to reach its leaf's ``.grad`` by being adopted, not copied.  autograd's AccumulateGrad adopts an incoming
+# gradient only when the leaf has no ``.grad`` yet (set ``p.grad = None`` before the backward), dtype and layout match
+# the leaf, and nobody else references the tensor object -- hence ``_keep`` stores storage ALIASES (``detach()``), never
+# the returned tensors themselves.  ``orphaned_deferred_outputs`` checks the contract after a backward.
 _DEFER_KEEP: Optional[list] = None
+_DEFER_OUTS: Optional[list] = None
 
 
 @contextlib.contextmanager
 def deferred_finishes():
     """Defer every partial-sum finishing launch issued inside the context; the caller MUST call ``flush_finishes`` (with the
     context still open) before any weight gradient is read."""
-    global _DEFER_KEEP
+    global _DEFER_KEEP, _DEFER_OUTS
     lib = _capi.load()
     assert _DEFER_KEEP is None, "deferred_finishes() does not nest"
-    _DEFER_KEEP = []
+    _DEFER_KEEP, _DEFER_OUTS = [], []
     lib.oss_set_defer_finish(1)
     try:
         yield
     finally:
         lib.oss_set_defer_finish(0)
-        _DEFER_KEEP = None
+        _DEFER_KEEP = _DEFER_OUTS = None
 
 
-def _keep(*tensors) -> None:
+def _keep(scratch: torch.Tensor, *outs) -> None:
+    """keep the storages of a deferred reduction (its partials and its outputs) alive until the flush"""
     if _DEFER_KEEP is not None:
-        _DEFER_KEEP.extend(t for t in tensors if t is not None)
+        _DEFER_KEEP.append(scratch)
+        for t in outs:
+            if t is not None:
+                _DEFER_KEEP.append(t.detach())   # an alias: the returned tensor itself must stay unshared (see CONTRACT)
+                _DEFER_OUTS.append(t.untyped_storage().data_ptr())
+
+
+def orphaned_deferred_outputs(leaves) -> int:
+    """-> how many outputs deferred so far (since the last flush) are NOT the storage of some leaf's ``.grad``: those were
+    copied (cast / accumulated / cloned) before they held data, i.e. the CONTRACT above is broken for them.  Call after the
+    backward, before ``flush_finishes``."""
+    owned = {p.grad.untyped_storage().data_ptr() for p in leaves if p.grad is not None}
+    return sum(1 for ptr in (_DEFER_OUTS or ()) if ptr not in owned)
 
 
 class FinishTable:
@@ -93,6 +113,7 @@ def flush_finishes(table: FinishTable) -> None:
                                            torch.cuda.current_stream().cuda_stream), "oss_flush_finishes")
     if _DEFER_KEEP is not None:
         _DEFER_KEEP.clear()
+        _DEFER_OUTS.clear()
 
 
 def _fork_for_wgrad(*inputs: torch.Tensor):

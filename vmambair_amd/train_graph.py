@@ -115,6 +115,10 @@ class GraphedTrainStep:
                     loss.backward()
                 if self.wside is not None:
                     torch.cuda.current_stream().wait_stream(self.wside)
+                if not torch.cuda.is_current_stream_capturing():   # eager warm-up steps: every deferred gradient was adopted
+                    lost = _ops.orphaned_deferred_outputs(list(self.params) + self._shadows)
+                    if lost:
+                        raise RuntimeError(f"{lost} deferred weight gradients were copied before the flush (see ops.py CONTRACT)")
                 n = _ops.pending_finish_chunks()
                 if self.ftable is None or self.ftable.capacity < n:   # first (eager, warm-up) step: sizes the table
                     assert not torch.cuda.is_current_stream_capturing(), "the finish table must exist before the capture"
