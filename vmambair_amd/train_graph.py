@@ -47,6 +47,10 @@ class GraphedTrainStep:
         # two graphs (forward+backward | optimizer) with the gradient all-reduce between them: always for world > 1;
         # ``split_graphs`` forces the same structure on one GPU (tests)
         self.split = self.world > 1 or split_graphs
+        # split mode: the first graph ends by packing every gradient into ONE persistent fp32 buffer (a multi-tensor copy,
+        # captured) and re-points ``p.grad`` at views of it, so that the only work between the two graphs is a single
+        # all-reduce of that buffer -- no per-step host loop over the ~1450 gradient tensors, no unpack
+        self._flat = self._flat_views = None
         self.autocast_dtype = autocast_dtype
         self.loss_fn = loss_fn
         self.ema_decay = ema_decay
@@ -134,7 +138,21 @@ class GraphedTrainStep:
                 torch._foreach_copy_(self._master_grads, [s_.grad for s_ in self._shadows])
             for m, g in zip(self._masters, self._master_grads):
                 m.grad = g
+        if self.split:
+            self._pack_grads()
         return loss.detach()
+
+    def _pack_grads(self):
+        grads = [p.grad for p in self.params]
+        if self._flat is None:
+            assert not torch.cuda.is_current_stream_capturing(), "the flat gradient buffer must exist before the capture"
+            assert all(g is not None and g.dtype == torch.float32 for g in grads), "split mode needs an fp32 grad per parameter"
+            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=self.device)
+            self._flat_views = [v.view_as(g) for v, g in zip(self._flat.split([g.numel() for g in grads]), grads)]
+        with torch.no_grad():
+            torch._foreach_copy_(self._flat_views, grads)
+        for p, v in zip(self.params, self._flat_views):
+            p.grad = v
 
     def _opt_ema(self):
         if self.fopt is not None:
@@ -146,9 +164,9 @@ class GraphedTrainStep:
             torch._foreach_add_(self.ema, [p.detach() for p in self.params], alpha=1.0 - self.ema_decay)
 
     def _allreduce(self):
-        if self.world > 1:
-            from .ddp import allreduce_grads_flat
-            allreduce_grads_flat(self.params)
+        if self.world > 1:   # gradients already sit in self._flat (see _pack_grads): one collective, mean over ranks
+            dist.all_reduce(self._flat)
+            self._flat.div_(self.world)
 
     # ---- capture -----------------------------------------------------------------------------
     def capture(self, lq: torch.Tensor, gt: torch.Tensor) -> None:
