@@ -153,16 +153,18 @@ def test_every_forward_variant(fv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, fwd_variant=fv)
 
 
-@pytest.mark.parametrize("bv", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("bv", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_every_backward_variant(bv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, bwd_variant=bv)
 
 
-@pytest.mark.parametrize("dstate", [1, 5, 16])
-def test_backward_two_states_at_a_time_with_odd_state_counts(dstate):
-    """variant 2 walks the states in pairs; an odd count leaves a single state at the end of a tile"""
-    check_fwd_bwd(make_inputs(2, 16, dstate, 2, 700, torch.float32), True, torch.float32, bwd_variant=2)
+@pytest.mark.parametrize("dstate", [1, 5, 16, 19])
+@pytest.mark.parametrize("bv", [2, 8, 9])
+def test_backward_two_states_at_a_time_with_odd_state_counts(dstate, bv):
+    """variants 2, 8, 9 walk the states in pairs (8, 9: packed fp32 with a zero padding state); an odd count leaves a
+    single state at the end of a tile, 19 > one staging tile of variant 9 and > two of variant 8"""
+    check_fwd_bwd(make_inputs(2, 16, dstate, 2, 700, torch.float32), True, torch.float32, bwd_variant=bv)
 
 
 def test_channel_scan_shapes():
@@ -334,7 +336,19 @@ def test_full_size_properties(itype):
 @pytest.mark.parametrize("seqlen", [64, 100, 513, 1024, 2085])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("rows", [8, 48])
-def test_omni_scan_matches_materialised_directions(seqlen, itype, rows):
+@pytest.mark.parametrize("bv", [-1, 8, 9], ids=["auto", "pair12", "pair8"])
+def test_omni_scan_matches_materialised_directions(seqlen, itype, rows, bv):
+    if bv >= 0 and seqlen not in (100, 2085):
+        pytest.skip("forced backward variants: shortest ragged and longest lengths only")
+    lib = _capi.load()
+    lib.oss_scan_set_variant(-1, bv)
+    try:
+        _omni_scan_case(seqlen, itype, rows)
+    finally:
+        lib.oss_scan_set_variant(-1, -1)
+
+
+def _omni_scan_case(seqlen, itype, rows):
     """omni_scan(x2, ...) == selective_scan(cat[x2, flip x2], flip of delta/B/C for k >= 2) with the
     outputs and gradients of the mirrored directions flipped back (reference data flow:
     MambaSISR6_arch.py:401-428)."""

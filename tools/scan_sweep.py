@@ -31,6 +31,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--fwd-variants", default="0,6")
+    ap.add_argument("--bwd-variants", default="3,7")
+    ap.add_argument("--shapes", default="", help="B,KD,L,G;... (default: the headline shapes)")
     args = ap.parse_args()
     lib = _capi.load()
     dev = "cuda:0"
@@ -54,6 +57,10 @@ def main():
     shapes = [(8, 192, 4096, 4)]
     if not args.quick:
         shapes += [(8, 768, 256, 4), (8, 8, 96, 2), (4, 384, 16384, 4)]
+    if args.shapes:
+        shapes = [tuple(int(v) for v in sh.split(",")) for sh in args.shapes.split(";")]
+    fvs = tuple(int(v) for v in args.fwd_variants.split(",") if v != "")
+    bvs = tuple(int(v) for v in args.bwd_variants.split(",") if v != "")
     for (B, KD, L, G) in shapes:
         for dname in (["f32", "bf16"] if not args.quick else ["bf16"]):
             dt, io = DT[dname]
@@ -66,7 +73,7 @@ def main():
             D = torch.randn(KD, device=dev)
             bias = 0.5 * torch.rand(KD, device=dev)
             dout = torch.randn(B, KD, L, device=dev).to(dt)
-            for which, variants in ((0, (0, 6)), (1, (3, 7))):
+            for which, variants in ((0, fvs), (1, bvs)):
                 for v in variants:
                     lib.oss_scan_set_variant(v if which == 0 else -1, v if which == 1 else -1)
                     try:

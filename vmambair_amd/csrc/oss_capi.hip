@@ -1,5 +1,6 @@
 // oss_capi.hip -- the extern "C" surface declared in include/vmambair_oss.h.
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include <cstring>
@@ -49,21 +50,32 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     return 0;
 }
 
+// VMAMBAIR_SCAN_BWD_PAIR=0/1: A-B switch for the packed two-states-per-pass backward (variants 8 / 9)
+static bool bwd_pair_enabled() {
+    static const int on = [] {
+        const char *e = std::getenv("VMAMBAIR_SCAN_BWD_PAIR");
+        return e ? std::atoi(e) : 0;
+    }();
+    return on != 0;
+}
+
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups) {
     const int rows_per_group = dim / n_groups;
     if (seqlen <= 256 || rows_per_group < 8) return 1;
+    const bool pair = bwd_pair_enabled() && dstate >= 2;
     // <= one 8-row workgroup per CU: nothing is gained by leaving register room for a second one, so take the
     // build without spills (u:(8,192,4096): 0.196 ms against 0.229, profiles/r01_sweep_v4_bwd_variants.txt)
     const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
-    if (wgs <= 256) return 3;
+    if (wgs <= 256) return pair ? 9 : 3;
     // more rows per workgroup: fewer dB / dC partial tiles and an even load (u:(8,384,4096) bf16: 0.271 ms against
     // 0.355; u:(32,384,4096): 1.07 against 1.14)
     // (variant 6 = 4 with all 16 states staged at once: 0.2655 against 0.275 ms)
-    return rows_per_group >= 12 ? (dstate <= 16 ? 6 : 4) : 0;
+    if (rows_per_group >= 12) return pair ? 8 : (dstate <= 16 ? 6 : 4);
+    return pair ? 9 : 0;
 }
 
 // ---- per-launch event timing (oss_prof_*) -----------------------------------------------------
-constexpr int kProfVariants = 8;
+constexpr int kProfVariants = 12;
 struct ProfBucket {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0.0, bytes = 0.0;

@@ -360,51 +360,91 @@ oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*
     dC[bg * out_group_stride + r] = from_f32<T>(sc);
 }
 
-template <typename T, int LPR, int I, int WAVES, int NBB, int SPS, int MINW>
-static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
-    constexpr int ROWS = WAVES * (64 / LPR);
-    constexpr int TC = LPR * I;
+}  // namespace oss
+#include "oss_scan_bwd_pair.h"
+namespace oss {
+
+// workspace carving shared by the launchers; -> OSS_OK or OSS_ERR_WORKSPACE
+static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, float *&wdD, float *&wdb) {
     const oss_scan_fwd_params &f = p.f;
     const int rows_per_group = f.dim / f.n_groups;
-    const int tiles = (rows_per_group + ROWS - 1) / ROWS;
+    const int tiles = (rows_per_group + rows_per_wg - 1) / rows_per_wg;
     const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen);
     const size_t need = sizeof(float) * (n_bc + (size_t)f.batch * f.dim * (f.dstate + 2));
     if (!p.workspace || p.workspace_bytes < need) return OSS_ERR_WORKSPACE;
-    BwdWs ws;
     ws.bc = reinterpret_cast<float *>(p.workspace);
     ws.dA = ws.bc + n_bc;
     ws.dD = ws.dA + (size_t)f.batch * f.dim * f.dstate;
     ws.db = ws.dD + (size_t)f.batch * f.dim;
     ws.tiles = tiles;
-    float *wdD = ws.dD, *wdb = ws.db;
+    wdD = ws.dD; wdb = ws.db;
     if (!p.dD) ws.dD = nullptr;
     if (!p.ddelta_bias) ws.db = nullptr;
+    return OSS_OK;
+}
 
-    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)SPS * ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
-    auto kern = oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB, SPS, MINW>;
-    static size_t smem_enabled = 48 * 1024;
+template <typename T>
+static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *wdD, float *wdb, hipStream_t stream) {
+    const oss_scan_fwd_params &f = p.f;
+    const size_t nl = (size_t)f.dstate * f.seqlen;
+    const size_t total = (size_t)f.batch * f.n_groups * nl;
+    const unsigned nblk_bc = (unsigned)((total + 255) / 256);
+    const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + 255) / 256);
+    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(nblk_bc + nblk_w), dim3(256), 0, stream, ws.bc,
+                       reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), ws.tiles, nl, total, nblk_bc, ws.dA, wdD, wdb,
+                       p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr, f.A_d_stride,
+                       p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : nl);
+    return (int)hipGetLastError();
+}
+
+template <typename K>
+static int launch_main(K kern, size_t smem, size_t &smem_enabled, unsigned nblocks, int nthreads,
+                       const oss_scan_bwd_params &p, const BwdWs &ws, hipStream_t stream, LaunchTimer *timer) {
     if (smem > smem_enabled) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         smem_enabled = smem;
     }
-    const dim3 grid((unsigned)(f.batch * f.n_groups * tiles));
     if (timer) timer->begin(stream);
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p, ws);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nthreads), smem, stream, p, ws);
     if (timer) timer->end(stream);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-
-    const size_t nl = (size_t)f.dstate * f.seqlen;
-    const size_t total = (size_t)f.batch * f.n_groups * nl;
-    const unsigned nblk_bc = (unsigned)((total + 255) / 256);
-    const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + 255) / 256);
-    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(nblk_bc + nblk_w), dim3(256), 0, stream, ws.bc,
-                       reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), tiles, nl, total, nblk_bc, ws.dA, wdD, wdb,
-                       p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr, f.A_d_stride,
-                       p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : nl);
     return (int)hipGetLastError();
+}
+
+template <typename T, int LPR, int I, int WAVES, int NBB, int SPS, int MINW>
+static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
+    constexpr int ROWS = WAVES * (64 / LPR);
+    constexpr int TC = LPR * I;
+    const oss_scan_fwd_params &f = p.f;
+    BwdWs ws;
+    float *wdD, *wdb;
+    int rc = carve_ws(p, ROWS, ws, wdD, wdb);
+    if (rc != OSS_OK) return rc;
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)SPS * ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
+    static size_t smem_enabled = 48 * 1024;
+    rc = launch_main(oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB, SPS, MINW>, smem, smem_enabled,
+                     (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
+    if (rc != OSS_OK) return rc;
+    return launch_finish<T>(p, ws, wdD, wdb, stream);
+}
+
+// two states per pass in packed fp32 (oss_scan_bwd_pair.h)
+template <typename T, int I, int WAVES, int NBB, int MINW>
+static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
+    constexpr int TC = 64 * I;
+    const oss_scan_fwd_params &f = p.f;
+    BwdWs ws;
+    float *wdD, *wdb;
+    int rc = carve_ws(p, WAVES, ws, wdD, wdb);
+    if (rc != OSS_OK) return rc;
+    const size_t np = (size_t)((f.dstate + 1) & ~1);
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + 3 * np * WAVES + WAVES);
+    static size_t smem_enabled = 48 * 1024;
+    rc = launch_main(oss_scan_bwd_pair_kernel<T, I, WAVES, NBB, MINW>, smem, smem_enabled,
+                     (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
+    if (rc != OSS_OK) return rc;
+    return launch_finish<T>(p, ws, wdD, wdb, stream);
 }
 
 // variant table: (lanes per row, items per lane = waves per workgroup, states per LDS tile)
@@ -414,8 +454,10 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 //   3: variant 0 with <= 256 VGPRs (no spills; 2 waves per SIMD)
 //   4: 64 x 8 x 12 (12 rows/WG, 3 waves per SIMD, no spills): row counts that give <= 256 such workgroups
 //   5: 64 x 8 x 6  (6 rows/WG, no spills): 48-row groups at batch 8 = exactly 256 workgroups
-static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 7) ? 1 : variant]; }
+//   8: two states per pass in packed fp32, 12 rows/WG (130 KiB LDS, 3 waves per SIMD)     oss_scan_bwd_pair.h
+//   9: likewise, 8 rows/WG, all 16 states staged at once (<= 256 VGPRs)
+static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8, 12, 8};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 9) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
@@ -427,6 +469,8 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
         case 5: return launch_bwd<T, 64, 8, 6, 8, 1, 2>(p, stream, timer);
         case 6: return launch_bwd<T, 64, 8, 12, 16, 1, 3>(p, stream, timer);   // variant 4 staging all 16 states at once
         case 7: return launch_bwd<T, 64, 8, 8, 16, 1, 2>(p, stream, timer);    // variant 3 likewise
+        case 8: return launch_bwd_pair<T, 8, 12, 8, 3>(p, stream, timer);
+        case 9: return launch_bwd_pair<T, 8, 8, 16, 2>(p, stream, timer);
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }
