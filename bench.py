@@ -238,10 +238,12 @@ def main():
             achieved = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
             kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}"
             traffic, traffic_note = None, "no PMC record for this kernel build"
+            valu_busy = None
             try:  # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
                 rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
                 if kkey in rec:
                     traffic = int(rec[kkey]["fetch_bytes"] + rec[kkey]["write_bytes"])
+                    valu_busy = rec[kkey].get("valu_busy")
                     traffic_note = ("FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch of this kernel at u:(8,384,4096), "
                                     "profiles/r01_pmc_scan_traffic.txt; the excess over alg_bytes is the per-row-tile dB/dC "
                                     "partials (written here, re-read by the finishing kernel) and B/C re-read per row tile")
@@ -250,6 +252,10 @@ def main():
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": kkey,
+                    # the scan is a recurrence with ~29 vector-ALU instructions per (element, state): its roof is the VALU
+                    # issue rate, not HBM -- share of the kernel with a SIMD's VALU issuing, from the SQ counters
+                    # (profiles/r01_pmc_sq_scan.txt, tools/pmc_sq.sh); DESIGN.md section 5
+                    "valu_busy": valu_busy,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
                     "all_scan_kernels": [

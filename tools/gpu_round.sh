@@ -13,6 +13,7 @@ for leg in $LEGS; do
     pytest) timeout 1200 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/pytest.txt 2>&1; echo "rc=$?"; tail -5 gpurun_out/pytest.txt;;
     scantest) timeout 600 python -m pytest tests/test_scan_gpu.py -m gpu -q -p no:cacheprovider -k "${SCANTEST_K:-variant or odd_state or omni}" > gpurun_out/scantest.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/scantest.txt; grep -E "^(FAILED|ERROR)" gpurun_out/scantest.txt | head -20;;
     pairab) for v in 0 1; do VMAMBAIR_SCAN_BWD_PAIR=$v VMAMBAIR_SCAN_FWD_PAIR=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_pair$v.txt 2>gpurun_out/bench_pair$v.err; echo "pair=$v rc=$?"; tail -1 gpurun_out/bench_pair$v.txt | cut -c1-200; done;;
+    libab)  for lib in "" "$GRAFT_REPO_ROOT/vmambair_amd/lib/libvmambair_oss_exp_${EXP_LIB:-NOSLP}.so"; do tag=$([ -z "$lib" ] && echo base || echo exp); VMAMBAIR_LIB=$lib timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_lib_$tag.txt 2>gpurun_out/bench_lib_$tag.err; echo "lib=$tag rc=$?"; tail -1 gpurun_out/bench_lib_$tag.txt | cut -c1-200; VMAMBAIR_LIB=$lib timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench_$tag.txt 2>&1; echo "opbench rc=$?"; done;;
     opbench) timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/opbench.txt;;
     benchmfma) VMAMBAIR_CONV1X1=mfma timeout ${BENCH_TIMEOUT:-700} python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_mfma.txt 2>gpurun_out/bench_mfma.err; echo "rc=$?"; tail -1 gpurun_out/bench_mfma.txt | cut -c1-260;;
     sweep)  timeout 600 python tools/scan_sweep.py ${SWEEP_ARGS:---quick} > gpurun_out/sweep.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/sweep.txt;;

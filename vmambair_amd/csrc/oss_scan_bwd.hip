@@ -214,8 +214,13 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 float dA_acc = 0.f;
 #pragma unroll
                 for (int k = I / 4 - 1; k >= 0; --k) {
+#ifdef OSS_EXP_NO_REREAD  // (timing experiments only: tools/build_experiment.sh) sensitivity to the B/C tile reads
+                    const f32x4 b4 = f32x4{dl[4 * k], dl[4 * k + 1], dl[4 * k + 2], dl[4 * k + 3]};
+                    const f32x4 c4 = f32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+#else
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
                     const f32x4 c4 = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
+#endif
 #pragma unroll
                     for (int j = 3; j >= 0; --j) {
                         const int i = 4 * k + j;
