@@ -190,3 +190,42 @@ def test_whole_module_omni_equals_reference_data_flow(variant, oracle_cpu_kernel
         if k.endswith("conv_cout.bias"):
             continue  # exact gradient 0 (constant before a LayerNorm)
         assert_close(res[0][2][k], res[1][2][k], 2e-3, 2e-4 * max(1.0, float(res[1][2][k].abs().max())), k)
+
+
+def test_deferred_gradient_adoption_contract():
+    """ops.deferred_finishes(): an unfinished gradient must be ADOPTED as the leaf's .grad (same storage), never cloned
+    -- autograd clones when anybody else still references the returned tensor object, which is why ops._keep stores
+    storage aliases.  Exercised here on the CPU with a stand-in Function (no kernels involved)."""
+    import torch
+    from vmambair_amd import ops
+
+    made = []
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            return x * w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            dw = torch.full((4,), 7.0)
+            scratch = torch.zeros(8)
+            if MODE == "alias":
+                ops._keep(scratch, dw)                       # what the real ops do
+            else:
+                ops._DEFER_KEEP.extend([scratch, dw])        # the bug this guards against: a second owner of `dw`
+                ops._DEFER_OUTS.append(dw.untyped_storage().data_ptr())
+            made.append(dw.data_ptr())
+            return g, dw
+
+    for MODE, want_orphans in (("alias", 0), ("same-object", 1)):
+        made.clear()
+        w = torch.nn.Parameter(torch.ones(4))
+        x = torch.ones(3, requires_grad=True)
+        ops._DEFER_KEEP, ops._DEFER_OUTS = [], []
+        try:
+            Fn.apply(x, w).sum().backward()
+            assert (w.grad.data_ptr() == made[0]) == (want_orphans == 0)
+            assert ops.orphaned_deferred_outputs([w]) == want_orphans
+        finally:
+            ops._DEFER_KEEP = ops._DEFER_OUTS = None
