@@ -22,7 +22,10 @@ def ref(x, w, b, dy):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("shape", [(2, 48, 64, 64), (1, 254, 16, 24), (3, 5, 7, 9), (2, 96, 12, 10), (1, 3, 1, 1), (2, 8, 33, 4)])
+@pytest.mark.parametrize("shape", [(2, 48, 64, 64), (1, 254, 16, 24), (3, 5, 7, 9), (2, 96, 12, 10), (1, 3, 1, 1), (2, 8, 33, 4),
+                                   # 16-bit I/O: the 8-pixels-per-lane kernels (W / 8 lanes per row = 4, 1, 16, 64, 2 with a ragged
+                                   # last workgroup) next to widths they must leave to the 4-pixel kernels (24, 12, 4)
+                                   (2, 16, 32, 32), (3, 8, 8, 8), (1, 4, 6, 128), (1, 2, 5, 512), (2, 5, 37, 16)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_dwconv_matches_torch(dtype, shape, has_bias):
     torch.manual_seed(0)
@@ -47,16 +50,18 @@ def test_dwconv_matches_torch(dtype, shape, has_bias):
         assert_close(bd.grad, rdb, 1e-4 if dtype == torch.float32 else 2e-2, (1e-5 if dtype == torch.float32 else 5e-3) * max(float(rdb.abs().max()), 1.0), "db")
 
 
-def test_dwconv_on_chunk_views():
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_dwconv_on_chunk_views(dt):
     """the block feeds the conv a channel chunk of in_conv's output (batch stride 2*C*H*W)"""
     torch.manual_seed(1)
-    xz = torch.randn(2, 32, 16, 16, device=DEV)
+    xz = torch.randn(2, 32, 16, 16, device=DEV).to(dt)
     x = xz.chunk(2, dim=1)[1]
     assert not x.is_contiguous()
     w = torch.randn(16, 1, 3, 3, device=DEV)
     b = torch.randn(16, device=DEV)
     y, _ = ops.dwconv3x3_fwd(x, w, b)
-    assert_close(y, F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1, groups=16), 1e-5, 1e-5, "chunk view")
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert_close(y, F.conv2d(x.float().cpu(), w.cpu(), b.cpu(), padding=1, groups=16).to(dt), tol, tol, "chunk view")
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["one_graph", "two_graphs"])
@@ -108,7 +113,7 @@ def test_graphed_train_step_matches_eager(split, acdt):
         assert bad <= 0.01 * tot, f"{bad} of {tot} weights differ by more than one Adam step"
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 6, 5, 7), (2, 96, 8, 12)])
+@pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 6, 5, 7), (2, 96, 8, 12), (2, 12, 64, 64), (1, 3, 9, 32)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_dwconv_with_fused_silu(shape, dt):
     """act(conv2d(x)) of SS2D_1 (MambaSISR6_arch.py:486): silu in the conv epilogue, its derivative in the weight-gradient pass"""

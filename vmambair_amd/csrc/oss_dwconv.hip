@@ -7,6 +7,7 @@
 // (profiles/r01_rocprof_bench_eager_last_step.txt: 390 ms of a 640 ms step in one
 // grouped_conv_bwd_weight kernel); the three kernels below replace forward, input-gradient (same
 // stencil with the taps mirrored) and weight/bias-gradient.
+#include <initializer_list>
 #include "oss_device.h"
 #include "oss_host.h"
 
@@ -101,6 +102,148 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
         }
         yp[p] = from_f32<T>(acc);
     }
+}
+
+// ---- 16-bit I/O, 8 pixels per lane ------------------------------------------------------------------------------
+// One 16-byte access per lane and image row, and the two halo pixels of a lane's 8-pixel group come from the
+// neighbouring lanes by DPP (wave_shr / wave_shl) instead of two more (2-byte) loads: 3 load instructions per 8 outputs
+// against 9 per 4 in the kernel above, which is what bounds it (2-byte-per-lane global accesses move 128 B per wave
+// instruction on gfx950).  Needs W % 8 == 0 with W / 8 (lanes per image row) dividing 64, so that a row's groups never
+// straddle a wave, and 16-byte aligned planes.
+template <typename T>
+__device__ __forceinline__ void load8(const T *p, float (&v)[8]) {
+    const u32x4 q = *reinterpret_cast<const u32x4 *>(p);
+    unpack2<T>(q.x, v[0], v[1]); unpack2<T>(q.y, v[2], v[3]); unpack2<T>(q.z, v[4], v[5]); unpack2<T>(q.w, v[6], v[7]);
+}
+template <typename T>
+__device__ __forceinline__ void store8(T *p, const float (&v)[8]) {
+    *reinterpret_cast<u32x4 *>(p) = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+}
+// v[0..9] = pixels w0-1 .. w0+8 of image row h + dy (zeros outside the image); every lane of the wave must call it
+template <typename T>
+__device__ __forceinline__ void row10(const T *plane, int h, int dy, int H, int W, int w0, bool first, bool last, float (&v)[10]) {
+    const int hh = h + dy;
+    const bool ok = hh >= 0 && hh < H;
+    float m[8];
+    load8<T>(plane + (int64_t)(ok ? hh : h) * W + w0, m);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j + 1] = ok ? m[j] : 0.f;
+    v[0] = shift_from_prev_lane(v[8], 0.f, first);
+    v[9] = shift_from_next_lane(v[1], 0.f, last);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                          T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
+                          int flip, T *__restrict__ pre) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const T *xp = x + b * xsb + c * xsc;
+    T *yp = y + b * ysb + c * ysc;
+    T *pp = pre ? pre + ((size_t)b * C + c) * H * W : nullptr;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + (flip ? 8 - i : i)];
+    const float bv = bias ? bias[c] : 0.f;
+    const int lpr = W >> 3, ngroups = lpr * H;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < ngroups;
+    const int gc = live ? g : ngroups - 1;     // dead lanes of the last workgroup shadow the last group (no stores)
+    const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
+    const bool first = cg == 0, last = cg == lpr - 1;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bv;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        float v[10];
+        row10<T>(xp, h, dy, H, W, w0, first, last, v);
+        const float k0 = k[(dy + 1) * 3], k1 = k[(dy + 1) * 3 + 1], k2 = k[(dy + 1) * 3 + 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[j] = __builtin_fmaf(k0, v[j], __builtin_fmaf(k1, v[j + 1], __builtin_fmaf(k2, v[j + 2], acc[j])));
+    }
+    if (!live) return;
+    if (pp) {  // fused activation: keep the pre-activation for the backward, emit silu
+        store8<T>(pp + (int64_t)h * W + w0, acc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = silu_f32(acc[j]);
+    }
+    store8<T>(yp + (int64_t)h * W + w0, acc);
+}
+
+// weight / bias gradient partials of one (channel, batch) plane, same access scheme
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_dwconv3x3_wgrad_wide_kernel(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part /*[B][C][10]*/,
+                                int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
+                                const T *__restrict__ pre, T *__restrict__ dpre) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const T *pp = pre ? pre + ((size_t)b * C + c) * H * W : nullptr;
+    T *qp = pre ? dpre + ((size_t)b * C + c) * H * W : nullptr;
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    const T *xp = x + b * xsb + c * xsc;
+    const T *gp = dy + b * gsb + c * gsc;
+    const int lpr = W >> 3, ngroups = lpr * H;
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {   // uniform trip count: every lane takes part in the DPP halo exchange
+        const int g = g0 + threadIdx.x;
+        const bool live = g < ngroups;
+        const int gc = live ? g : ngroups - 1;
+        const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
+        const bool first = cg == 0, last = cg == lpr - 1;
+        float gv[8];
+        load8<T>(gp + (int64_t)h * W + w0, gv);
+        if (pp) {
+            float pv[8];
+            load8<T>(pp + (int64_t)h * W + w0, pv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] *= dsilu_f32(pv[j]);
+            if (live) store8<T>(qp + (int64_t)h * W + w0, gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j]));  // the input-gradient pass sees the rounded value
+        }
+        if (!live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = 0.f;
+        }
+        acc[9] += ((gv[0] + gv[1]) + (gv[2] + gv[3])) + ((gv[4] + gv[5]) + (gv[6] + gv[7]));
+#pragma unroll
+        for (int dyy = -1; dyy <= 1; ++dyy) {
+            float v[10];
+            row10<T>(xp, h, dyy, H, W, w0, first, last, v);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float a = acc[(dyy + 1) * 3 + dx];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a = __builtin_fmaf(gv[j], v[j + dx], a);
+                acc[(dyy + 1) * 3 + dx] = a;
+            }
+        }
+    }
+    __shared__ float red[4][10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const float s = segment_sum_to_last<64>(acc[i]);
+        if (lane == 63) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10)
+        part[(size_t)b * C * 10 + (threadIdx.x < 9 ? (size_t)c * 9 + threadIdx.x : (size_t)9 * C + c)] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// the 8-pixel kernels apply when a row's W / 8 lane groups tile a wave and every plane / row start is 16-byte aligned
+template <typename T>
+static bool wide_ok(int W, std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
+    if (sizeof(T) != 2 || W % 8 != 0 || W > 512 || (64 % (W / 8)) != 0) return false;
+    for (const void *p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
+    for (int64_t st : strides)
+        if (st % 8 != 0) return false;
+    return true;
 }
 
 // dw[c][ky][kx] = sum_{b,h,w} dy[b,c,h,w] x[b,c,h+ky-1,w+kx-1];  db[c] = sum dy.
@@ -209,6 +352,13 @@ static int dwconv_launch(const void *x, const float *w, const float *bias, void 
     const T *xp = reinterpret_cast<const T *>(x);
     T *yp = reinterpret_cast<T *>(y);
     T *prp = reinterpret_cast<T *>(pre);
+    if constexpr (sizeof(T) == 2) {
+        if (wide_ok<T>(W, {xp, yp, prp}, {xsb, xsc, ysb, ysc})) {
+            dim3 grid(((W / 8) * H + 255) / 256, C, B);
+            hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp);
+            return (int)hipGetLastError();
+        }
+    }
     const uintptr_t amask = sizeof(T) == 4 ? 15u : 7u;
     const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(yp) | reinterpret_cast<uintptr_t>(prp)) & amask) == 0 &&
                      (xsb % 4 == 0) && (xsc % 4 == 0) && (ysb % 4 == 0) && (ysc % 4 == 0);
@@ -244,7 +394,14 @@ static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, flo
     const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(xp) | reinterpret_cast<uintptr_t>(gp) | reinterpret_cast<uintptr_t>(prp) |
                                          reinterpret_cast<uintptr_t>(dpp)) & amask) == 0 &&
                      (xsb % 4 == 0) && (xsc % 4 == 0) && (gsb % 4 == 0) && (gsc % 4 == 0);
-    if (vec)
+    bool wide = false;
+    if constexpr (sizeof(T) == 2) wide = wide_ok<T>(W, {xp, gp, prp, dpp}, {xsb, xsc, gsb, gsc});
+    if constexpr (sizeof(T) == 2) {
+        if (wide)
+            hipLaunchKernelGGL((oss_dwconv3x3_wgrad_wide_kernel<T>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
+    }
+    if (wide) {
+    } else if (vec)
         hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, true>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
     else
         hipLaunchKernelGGL((oss_dwconv3x3_wgrad_kernel<T, false>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
