@@ -47,6 +47,13 @@ __global__ void __launch_bounds__(256)
 oss_chan_fwd_kernel(oss_chan_params p) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
+#ifdef OSS_EXP_CHAN_TIMING  // (timing experiments only: tools/build_experiment.sh) phase stamps in shader cycles -> zt[0..7]
+    long long ts_[8]; int ns_ = 0;
+#define OSS_STAMP() do { ts_[ns_++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define OSS_STAMP() do { } while (0)
+#endif
+    OSS_STAMP();
     const bool lift = p.cin_w != nullptr;
     float *seq = sm;                 // [dc][L]
     float *ybuf = seq + dc * L;      // [2 dc][L]
@@ -57,26 +64,64 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
     }
     __syncthreads();
+    OSS_STAMP();
     float *zg = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
     float *dg = p.dts + (size_t)b * 2 * dc * L;
-    float *zb, *db;
-    if constexpr (use_lds) { zb = red + 4; db = zb + 2 * L * Cc; } else { zb = zg; db = dg; }
-    for (int idx = tid; idx < 2 * L * Cc; idx += 256) {
-        const int k = idx / (L * Cc), rem = idx - k * L * Cc, l = rem / Cc, c = rem - l * Cc;
-        float s = 0.f;
-        for (int i = 0; i < dc; ++i) s = __builtin_fmaf(p.Wxc[(k * Cc + c) * dc + i], seq[i * L + l], s);
-        zb[idx] = s;
-        if (use_lds) zg[idx] = s;
+    float *zb, *db, *dlsF = nullptr;   // dlsF [2 dc][L]: softplus(dts + bias), computed once per (row, l) for the 16 state lanes
+    if constexpr (use_lds) { zb = red + 4; db = zb + 2 * L * Cc; dlsF = db + 2 * dc * L; } else { zb = zg; db = dg; }
+    // z[k][l][c] = sum_i Wxc[k][c][i] seq[i][l]: a thread keeps the dc weights of its column (k, c) in registers and walks l
+    // (one output per iteration with its index arithmetic and dc dependent L2 loads measured 13 of the kernel's 32 us at
+    // L = 96, profiles/r01_chan_phase_timing.txt)
+    {
+        const int ncol = 2 * Cc;
+        const int tpc = ncol >= 256 ? 1 : 256 / ncol;          // threads per column
+        for (int col = tid % (ncol < 256 ? ncol : 256); col < ncol; col += 256) {
+            const int sub = ncol < 256 ? tid / ncol : 0;
+            if (sub >= tpc) break;
+            float wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[i] = i < dc ? p.Wxc[col * dc + i] : 0.f;
+            const int k = col / Cc, c = col - k * Cc;
+            for (int l = sub; l < L; l += tpc) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < dc) s = __builtin_fmaf(wv[i], seq[i * L + l], s);
+                zb[(k * L + l) * Cc + c] = s;
+                if (use_lds) zg[(k * L + l) * Cc + c] = s;
+            }
+        }
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * dc * L; idx += 256) {
-        const int row = idx / L, l = idx - row * L, k = row / dc;
-        float s = 0.f;
-        for (int r = 0; r < Rc; ++r) s = __builtin_fmaf(p.Wdtc[row * Rc + r], zb[(k * L + l) * Cc + r], s);
-        db[idx] = s;
-        if (use_lds) dg[idx] = s;
+    OSS_STAMP();
+    // dts[row][l] = sum_r Wdtc[row][r] z[k][l][r]: 256 / (2 dc) threads per row, the row's first 8 weights in registers
+    {
+        const int nrow = 2 * dc, tpr = 256 / nrow;      // dc <= 4: >= 32 threads per row
+        const int row = tid / tpr, sub = tid - row * tpr;
+        if (row < nrow) {
+            const int k = row / dc;
+            const float brow = p.dt_bias[row];
+            float wr[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wr[r] = r < Rc ? p.Wdtc[row * Rc + r] : 0.f;
+            for (int l = sub; l < L; l += tpr) {
+                const float *zr = zb + (k * L + l) * Cc;
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r < Rc) s = __builtin_fmaf(wr[r], zr[r], s);
+                for (int r = 8; r < Rc; ++r) s = __builtin_fmaf(p.Wdtc[row * Rc + r], zr[r], s);
+                db[row * L + l] = s;
+                if constexpr (use_lds) {
+                    dg[row * L + l] = s;
+                    float e;
+                    dlsF[row * L + l] = softplus_thr(s + brow, e);
+                }
+            }
+        }
     }
     __syncthreads();
+    OSS_STAMP();
     const int wave = tid >> 6, lane = tid & 63;
     if (wave < 2) {
         const int k = wave, i = lane >> 4, n = lane & 15;
@@ -84,7 +129,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         const int row = k * dc + (act ? i : 0);
         const float A2 = -__expf(p.A_logs[row * kChN + n]) * kLog2e;
         const float Dv = p.Dsc[row], bias = p.dt_bias[row];
-        const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
+        const float *dr = (use_lds ? dlsF : db) + row * L, *ur = seq + (act ? i : 0) * L;
         float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float h = 0.f;
         // per chunk of kChU steps: (1) fetch + everything that does not depend on the recurrence (softplus, exp, B u),
@@ -95,8 +140,8 @@ oss_chan_fwd_kernel(oss_chan_params p) {
             for (int j = 0; j < kChU; ++j) {
                 const int t = min(t0 + j, L - 1), l = k ? L - 1 - t : t;
                 const float *zr = zb + (k * L + l) * Cc + Rc;
-                float e;
-                const float dl = softplus_thr(dr[l] + bias, e);
+                float dl;
+                if constexpr (use_lds) { dl = dr[l]; } else { float e; dl = softplus_thr(dr[l] + bias, e); }
                 us[j] = ur[l];
                 av[j] = exp2_hw(dl * A2);
                 bu[j] = dl * zr[n] * us[j];
@@ -120,6 +165,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         }
     }
     __syncthreads();
+    OSS_STAMP();
     float part = 0.f;
     for (int l = tid; l < L; l += 256) {
         float s = lift ? p.cout_b[0] : 0.f;
@@ -137,6 +183,13 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         p.c[(size_t)b * L + l] = __builtin_fmaf((ycs[l] - mu) * rstd, p.cn_w[l], p.cn_b[l]);
     }
     if (tid == 0) { p.stat[b * 2] = mu; p.stat[b * 2 + 1] = rstd; }
+#ifdef OSS_EXP_CHAN_TIMING
+    OSS_STAMP();
+    __syncthreads();
+    if (b == 0 && tid == 0)
+        for (int q = 1; q < ns_; ++q) zg[q - 1] = (float)(ts_[q] - ts_[q - 1]);
+#endif
+#undef OSS_STAMP
 }
 
 // gradient slots of one image in gpart (B, NP); oss_chan_grad_floats() = NP
@@ -151,16 +204,48 @@ struct ChanSlots {
 template <bool use_lds /* the three scratch arrays live in LDS instead of HBM */>
 __global__ void __launch_bounds__(256)
 oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): grad of c*/, float *__restrict__ dpool,
-                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug) {
+                    float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug,
+                    int stage_zdt /* the dt columns of z fit in LDS next to everything else */) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
+#ifdef OSS_EXP_CHAN_TIMING  // phase stamps -> gpart[b = 0][0..] (the other images write zeros there)
+    long long ts_[10]; int ns_ = 0;
+#define OSS_STAMP() do { ts_[ns_++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define OSS_STAMP() do { } while (0)
+#endif
+    OSS_STAMP();
     const bool lift = p.cin_w != nullptr;
     const ChanSlots sl(L, dc, Rc, Cc);
     float *seq = sm;              // [dc][L]
     float *dys = seq + dc * L;    // [L]   grad of yc
     float *dsq = dys + L;         // [dc][L] grad of seq
     float *red = dsq + dc * L;    // [4]
+    float *sWx = red + 4;         // [2][Cc][dc]  xc_proj weights (read 2 Cc times per output of the dseq pass)
+    float *zdt = sWx + 2 * Cc * dc;   // [2][L][Rc]  the dt columns of z (operands of the dtc_projs weight gradient)
+    float *lds_end = zdt + (stage_zdt ? 2 * L * Rc : 0);
     float *gp = gpart + (size_t)b * sl.total;
+    for (int idx = tid; idx < 2 * Cc * dc; idx += 256) sWx[idx] = p.Wxc[idx];
+    if (stage_zdt) {
+        const float *zsrc = p.zt + (size_t)b * 2 * L * Cc;
+        for (int kl = tid; kl < 2 * L; kl += 256)
+            for (int r = 0; r < Rc; ++r) zdt[kl * Rc + r] = zsrc[kl * Cc + r];
+    }
+    const float *db = p.dts + (size_t)b * 2 * dc * L;
+    float *dzb, *ddb, *dub, *dlsL = nullptr, *sgsL = nullptr;
+    if constexpr (use_lds) {
+        dzb = lds_end; ddb = dzb + 2 * L * Cc; dub = ddb + 2 * dc * L;
+        dlsL = dub + 2 * dc * L; sgsL = dlsL + 2 * dc * L;
+        // softplus(dts + bias) and its derivative once per (row, l) instead of once per state lane inside the serial scan
+        for (int idx = tid; idx < 2 * dc * L; idx += 256) {
+            const float x = db[idx] + p.dt_bias[idx / L];
+            float e;
+            dlsL[idx] = softplus_thr(x, e);
+            sgsL[idx] = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+        }
+    } else {
+        dzb = dzt + (size_t)b * 2 * L * Cc; ddb = ddts + (size_t)b * 2 * dc * L; dub = dug + (size_t)b * 2 * dc * L;
+    }
     const float mu = p.stat[b * 2], rstd = p.stat[b * 2 + 1];
     float s1 = 0.f, s2 = 0.f;
     for (int l = tid; l < L; l += 256) {
@@ -179,16 +264,10 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         dys[l] = rstd * (g - m1 - xh * m2);
     }
     __syncthreads();
+    OSS_STAMP();
     const float *yb = p.y + (size_t)b * 2 * dc * L;
     // (the conv_cout gradients are wave-level sums done by waves 2 and 3 while waves 0 and 1 run the scans, below)
     const float *zb = p.zt + (size_t)b * 2 * L * Cc;
-    const float *db = p.dts + (size_t)b * 2 * dc * L;
-    float *dzb, *ddb, *dub;
-    if constexpr (use_lds) {
-        dzb = red + 4; ddb = dzb + 2 * L * Cc; dub = ddb + 2 * dc * L;
-    } else {
-        dzb = dzt + (size_t)b * 2 * L * Cc; ddb = ddts + (size_t)b * 2 * dc * L; dub = dug + (size_t)b * 2 * dc * L;
-    }
     const int wave = tid >> 6, lane = tid & 63;
     if (wave < 2) {
         const int k = wave, i = lane >> 4, n = lane & 15;
@@ -197,7 +276,8 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         const float A = -__expf(p.A_logs[row * kChN + n]), A2 = A * kLog2e;
         const float Dv = p.Dsc[row], bias = p.dt_bias[row];
         const float cw = act ? (lift ? p.cout_w[i] : 1.f) : 0.f;
-        const float *dr = db + row * L, *ur = seq + (act ? i : 0) * L;
+        const float *dr = (use_lds ? dlsL : db) + row * L, *ur = seq + (act ? i : 0) * L;
+        const float *sgr = use_lds ? sgsL + row * L : nullptr;
         const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
         float carry = 0.f, dA = 0.f, dD = 0.f, dbs = 0.f;
         // raw operands of the steps t0, t0 - 1, ...: fetched one chunk ahead of the arithmetic
@@ -226,10 +306,15 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
-                const float x = xs[j] + bias;
-                float e;
-                dls[j] = softplus_thr(x, e);
-                sg[j] = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                if constexpr (use_lds) {
+                    dls[j] = xs[j];
+                    sg[j] = sgr[l];
+                } else {
+                    const float x = xs[j] + bias;
+                    float e;
+                    dls[j] = softplus_thr(x, e);
+                    sg[j] = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                }
                 av[j] = exp2_hw(dls[j] * A2);
                 us[j] = ur[l];
                 dyv[j] = t0 - j >= 0 ? cw * dys[l] : 0.f;
@@ -292,12 +377,26 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         }
     }
     __syncthreads();
+    OSS_STAMP();
     // dt rows of dz
-    for (int idx = tid; idx < 2 * L * Rc; idx += 256) {
-        const int k = idx / (L * Rc), rem = idx - k * L * Rc, l = rem / Rc, r = rem - l * Rc;
-        float s = 0.f;
-        for (int i = 0; i < dc; ++i) s = __builtin_fmaf(p.Wdtc[(k * dc + i) * Rc + r], ddb[(k * dc + i) * L + l], s);
-        dzb[(k * L + l) * Cc + r] = s;
+    {   // a thread keeps the dc weights of its column (k, r) in registers and walks l
+        const int ncol = 2 * Rc;
+        const int tpc = ncol >= 256 ? 1 : 256 / ncol;
+        for (int col = tid % (ncol < 256 ? ncol : 256); col < ncol; col += 256) {
+            const int sub = ncol < 256 ? tid / ncol : 0;
+            if (sub >= tpc) break;
+            const int k = col / Rc, r = col - k * Rc;
+            float wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[i] = i < dc ? p.Wdtc[(k * dc + i) * Rc + r] : 0.f;
+            for (int l = sub; l < L; l += tpc) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < dc) s = __builtin_fmaf(wv[i], ddb[(k * dc + i) * L + l], s);
+                dzb[(k * L + l) * Cc + r] = s;
+            }
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < dc * L; idx += 256) {
@@ -305,25 +404,33 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         float s = dub[i * L + l] + dub[(dc + i) * L + l];
         for (int k = 0; k < 2; ++k) {
             const float *dz = dzb + (k * L + l) * Cc;
+            const float *wx = sWx + k * Cc * dc + i;
 #pragma unroll 8
-            for (int c = 0; c < Cc; ++c) s = __builtin_fmaf(p.Wxc[(k * Cc + c) * dc + i], dz[c], s);
+            for (int c = 0; c < Cc; ++c) s = __builtin_fmaf(wx[c * dc], dz[c], s);
         }
         dsq[idx] = s;
     }
     __syncthreads();
+    OSS_STAMP();
     for (int l = tid; l < L; l += 256) {
         float s = 0.f;
         for (int i = 0; i < dc; ++i) s = lift ? __builtin_fmaf(p.cin_w[i], dsq[i * L + l], s) : s + dsq[i * L + l];
         dpool[(size_t)b * L + l] = s;
     }
+    OSS_STAMP();
     // parameter gradients that are sums over l: one output per thread
     const int n_wdtc = 2 * dc * Rc, n_wxc = 2 * Cc * dc;
     for (int o = tid; o < n_wdtc + n_wxc + 2 * dc; o += 256) {
         float s = 0.f;
         if (o < n_wdtc) {
             const int row = o / Rc, r = o - row * Rc, k = row / dc;
+            if (stage_zdt) {
 #pragma unroll 8
-            for (int l = 0; l < L; ++l) s = __builtin_fmaf(ddb[row * L + l], zb[(k * L + l) * Cc + r], s);
+                for (int l = 0; l < L; ++l) s = __builtin_fmaf(ddb[row * L + l], zdt[(k * L + l) * Rc + r], s);
+            } else {
+#pragma unroll 8
+                for (int l = 0; l < L; ++l) s = __builtin_fmaf(ddb[row * L + l], zb[(k * L + l) * Cc + r], s);
+            }
             gp[sl.wdtc + o] = s;
         } else if (o < n_wdtc + n_wxc) {
             const int q = o - n_wdtc, i = q % dc, kc = q / dc, k = kc / Cc, c = kc - k * Cc;
@@ -339,6 +446,13 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
             gp[sl.cinw + q] = s;
         }
     }
+#ifdef OSS_EXP_CHAN_TIMING
+    OSS_STAMP();
+    __syncthreads();
+    if (tid == 0)
+        for (int q = 1; q < ns_; ++q) gp[q - 1] = b == 0 ? (float)(ts_[q] - ts_[q - 1]) : 0.f;
+#endif
+#undef OSS_STAMP
 }
 
 // gsum[j] = sum_b gpart[b][j] in batch order
@@ -422,7 +536,7 @@ int chan_fwd(const oss_chan_params &p, hipStream_t s) {
     if (int e = chan_check(p)) return e;
     size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + 4);
     if (smem > 48 * 1024) return OSS_ERR_SHAPE;
-    const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 2 * (size_t)p.dc * p.L);
+    const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 4 * (size_t)p.dc * p.L);
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
     if (use_lds) {
@@ -437,20 +551,26 @@ int chan_fwd(const oss_chan_params &p, hipStream_t s) {
 int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsum, float *scratch, hipStream_t s) {
     if (int e = chan_check(p)) return e;
     if (!gc || !dpool || !gsum || !scratch) return OSS_ERR_NULL;
-    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + 4);
-    if (smem > 48 * 1024) return OSS_ERR_SHAPE;
-    const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 4 * (size_t)p.dc * p.L);
+    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + 4 + 2 * (size_t)p.Cc * p.dc);
+    if (smem > kChanLdsMax) return OSS_ERR_SHAPE;
+    const size_t zdt_bytes = sizeof(float) * 2 * (size_t)p.L * p.Rc;
+    const int stage_zdt = smem + zdt_bytes <= kChanLdsMax ? 1 : 0;
+    if (stage_zdt) smem += zdt_bytes;
+    const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 8 * (size_t)p.dc * p.L);
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
-    if (use_lds)
+    if (use_lds) {
         if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<true>), smem)) return e;
+    } else {
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<false>), smem)) return e;
+    }
     const size_t np = chan_grad_floats(p.L, p.dc, p.Rc, p.Cc);
     float *gpart = scratch;
     float *dzt = gpart + (size_t)p.B * np;
     float *ddts = dzt + (size_t)p.B * 2 * p.L * p.Cc;
     float *dug = ddts + (size_t)p.B * 2 * p.dc * p.L;
-    if (use_lds) hipLaunchKernelGGL(oss_chan_bwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
-    else         hipLaunchKernelGGL(oss_chan_bwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug);
+    if (use_lds) hipLaunchKernelGGL(oss_chan_bwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, stage_zdt);
+    else         hipLaunchKernelGGL(oss_chan_bwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, stage_zdt);
     if (defer_finish())
         defer_sum(gpart, p.B, np, np, gsum, np, nullptr);
     else
