@@ -82,6 +82,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[i] = i < dc ? p.Wxc[col * dc + i] : 0.f;
             const int k = col / Cc, c = col - k * Cc;
+#pragma unroll 4
             for (int l = sub; l < L; l += tpc) {
                 float s = 0.f;
 #pragma unroll
@@ -104,6 +105,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
             float wr[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) wr[r] = r < Rc ? p.Wdtc[row * Rc + r] : 0.f;
+#pragma unroll 2
             for (int l = sub; l < L; l += tpr) {
                 const float *zr = zb + (k * L + l) * Cc;
                 float s = 0.f;
@@ -237,6 +239,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         dzb = lds_end; ddb = dzb + 2 * L * Cc; dub = ddb + 2 * dc * L;
         dlsL = dub + 2 * dc * L; sgsL = dlsL + 2 * dc * L;
         // softplus(dts + bias) and its derivative once per (row, l) instead of once per state lane inside the serial scan
+#pragma unroll 4
         for (int idx = tid; idx < 2 * dc * L; idx += 256) {
             const float x = db[idx] + p.dt_bias[idx / L];
             float e;
@@ -389,6 +392,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
             float wv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[i] = i < dc ? p.Wdtc[(k * dc + i) * Rc + r] : 0.f;
+#pragma unroll 4
             for (int l = sub; l < L; l += tpc) {
                 float s = 0.f;
 #pragma unroll
