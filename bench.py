@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--micro-streams", type=int, default=int(os.environ.get("VMAMBAIR_MICRO_STREAMS", "1")),
+                    help="micro-batches of the per-GPU batch run as parallel branches of the step's graph (train_graph.py)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VMAMBAIR_BENCH_GRAPH", "1")),
                     help="1: replay the training step as one hipGraph (single GPU, or manual flat-gradient "
                          "all-reduce outside the graph for N > 1)")
@@ -170,7 +172,8 @@ def main():
         if world > 1:  # same initial weights on every rank (DDP's constructor broadcast)
             for p_ in net.parameters():
                 dist.broadcast(p_.data, 0)
-        step = GraphedTrainStep(net, lr=2e-4, betas=(0.9, 0.99), ema_decay=0.999, autocast_dtype=acdt)
+        step = GraphedTrainStep(net, lr=2e-4, betas=(0.9, 0.99), ema_decay=0.999, autocast_dtype=acdt,
+                                micro_streams=args.micro_streams)
         log("capturing the training step")
         step.capture(lq, gt)
         log("captured")

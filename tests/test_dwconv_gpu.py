@@ -64,12 +64,14 @@ def test_dwconv_on_chunk_views(dt):
     assert_close(y, F.conv2d(x.float().cpu(), w.cpu(), b.cpu(), padding=1, groups=16).to(dt), tol, tol, "chunk view")
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["one_graph", "two_graphs"])
+@pytest.mark.parametrize("mode", ["one_graph", "two_graphs", "two_branches"])
 @pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
-def test_graphed_train_step_matches_eager(split, acdt):
+def test_graphed_train_step_matches_eager(mode, acdt):
     """vmambair_amd.train_graph: the hipGraph replay of fwd+loss+bwd+Adam+EMA gives the same weights
     as the eager step (same kernels, same order).  ``two_graphs``: the multi-GPU structure (forward+backward |
-    all-reduce | optimizer) on one GPU; bf16: autocast with shadow weights."""
+    all-reduce | optimizer) on one GPU; ``two_branches``: the batch as two micro-batches on parallel branches of the
+    graph; bf16: autocast with shadow weights."""
+    split = mode == "two_graphs"
     from vmambair_amd.archs import MambaSISR6
     from vmambair_amd.train_graph import GraphedTrainStep
 
@@ -83,7 +85,8 @@ def test_graphed_train_step_matches_eager(split, acdt):
     net_g = make()
     # one eager warm-up step happens inside capture() (optimizer state must exist before capture),
     # so the three replays are training steps 2..4
-    step = GraphedTrainStep(net_g, autocast_dtype=acdt, warmup=1, split_graphs=split, overlap_wgrads=split)  # two-graph case also forks the weight-gradient stream
+    step = GraphedTrainStep(net_g, autocast_dtype=acdt, warmup=1, split_graphs=split, overlap_wgrads=split,  # two-graph case also forks the weight-gradient stream
+                            micro_streams=2 if mode == "two_branches" else 1)
     losses_g = [float(step(lq, gt)) for _ in range(3)]
     net_e = make()
     opt = torch.optim.Adam(net_e.parameters(), lr=2e-4, betas=(0.9, 0.99))
@@ -178,4 +181,35 @@ def test_deferred_finishing_gives_the_same_gradients(acdt):
         sc = max(float(ref[k].abs().max()), 1e-12)
         if float((got[k] - ref[k]).abs().max()) > tol * sc + 1e-9:
             wrong.append((k, float((got[k] - ref[k]).abs().max()), sc))
+    assert not wrong, wrong
+
+
+@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("split", [False, True], ids=["one_graph", "two_graphs"])
+def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
+    """GraphedTrainStep(micro_streams=2): forward + backward of the two half batches on two streams, gradients added --
+    must equal the gradients of the undivided batch (mean loss; nothing in the nets couples the images of a batch)"""
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    lq = torch.rand(4, 3, 32, 32, device=DEV)
+    gt = torch.rand(4, 3, 128, 128, device=DEV)
+    got = {}
+    for M in (1, 2):
+        st = GraphedTrainStep(net, autocast_dtype=acdt, warmup=1, micro_streams=M, split_graphs=split)
+        st.static_lq, st.static_gt = lq.clone(), gt.clone()
+        loss = st._fwd_bwd()
+        torch.cuda.synchronize()
+        got[M] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert got[2][0] == pytest.approx(got[1][0], rel=1e-5 if acdt is None else 1e-2)
+    tol = 2e-5 if acdt is None else 5e-2
+    wrong = []
+    for k, ref in got[1][1].items():
+        if k.endswith("conv_cout.bias"):
+            continue   # mathematically zero: rounding noise only
+        sc = max(float(ref.abs().max()), 1e-12)
+        d = float((got[2][1][k] - ref).abs().max())
+        if d > tol * sc + 1e-9:
+            wrong.append((k, d, sc))
     assert not wrong, wrong

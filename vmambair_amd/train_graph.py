@@ -38,7 +38,7 @@ class GraphedTrainStep:
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
                  loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
                  fused_optimizer: bool = True, split_graphs: bool = False, overlap_wgrads: bool = False,
-                 defer_finishes: bool = True):
+                 defer_finishes: bool = True, micro_streams: int = 1):
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -93,13 +93,52 @@ class GraphedTrainStep:
         # the ~12 small partial-sum finishing launches per block (weight-gradient slabs, LayerNorm / depth-wise conv /
         # channel partials) run as ONE launch at the end of the backward (oss_flush_finishes)
         self.defer = defer_finishes
-        self.ftable = None
+        # micro_streams = M > 1: the batch is cut into M micro-batches whose forward + backward run as M parallel branches
+        # of the graph (one HIP stream each, ONE fork and ONE join per step); their gradients are added before the
+        # optimizer, so the step equals the full-batch step (mean loss; no cross-image statistics anywhere in the nets).
+        # At batch 8 most kernels of the step are too small to fill 256 CUs: two half-size launches side by side do.
+        # Every branch runs the net on its own leaf tensors (aliases of the parameters / shadows) so that each backward
+        # ASSIGNS its gradients -- no per-tensor accumulation kernels.
+        self.nmicro = max(1, int(micro_streams))
+        assert not (self.nmicro > 1 and overlap_wgrads), "micro_streams and overlap_wgrads are alternatives"
+        self.mstreams = [torch.cuda.Stream(device=self.device) for _ in range(self.nmicro)] if self.nmicro > 1 else []
+        self._names = [n for n, p in net.named_parameters() if p.requires_grad]
+        self._leaf_sets = []
+        if self.nmicro > 1:
+            named = dict(net.named_parameters())
+            for _ in range(self.nmicro):
+                self._leaf_sets.append({n: self._shadow_map.get(n, named[n]).detach().requires_grad_() for n in self._names})
+            self._shadow_tmp = [torch.zeros_like(m) for m in self._masters]
+        self.ftables = [None] * self.nmicro
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
 
     # ---- pieces ------------------------------------------------------------------------------
+    def _backward(self, loss, leaves, slot: int = 0):
+        """backward of one (micro-)batch on the current stream; ``leaves``: the tensors whose .grad it fills"""
+        if not self.defer:
+            with _ops.wgrad_side_stream(self.wside):
+                loss.backward()
+            return
+        with _ops.deferred_finishes():
+            with _ops.wgrad_side_stream(self.wside):
+                loss.backward()
+            if self.wside is not None:
+                torch.cuda.current_stream().wait_stream(self.wside)
+            if not torch.cuda.is_current_stream_capturing():   # eager warm-up steps: every deferred gradient was adopted
+                lost = _ops.orphaned_deferred_outputs(leaves)
+                if lost:
+                    raise RuntimeError(f"{lost} deferred weight gradients were copied before the flush (see ops.py CONTRACT)")
+            n = _ops.pending_finish_chunks()
+            if self.ftables[slot] is None or self.ftables[slot].capacity < n:   # first (eager, warm-up) step: sizes the table
+                assert not torch.cuda.is_current_stream_capturing(), "the finish table must exist before the capture"
+                self.ftables[slot] = _ops.FinishTable(self.device, n)
+            _ops.flush_finishes(self.ftables[slot])
+
     def _fwd_bwd(self):
+        if self.nmicro > 1:
+            return self._fwd_bwd_micro()
         for p in self.params:  # host-side only: the backward then assigns instead of accumulating
             p.grad = None
         for s_ in self._shadows:
@@ -113,24 +152,7 @@ class GraphedTrainStep:
             else:
                 out = self.net(self.static_lq)
         loss = self.loss_fn(out.float(), self.static_gt)
-        if self.defer:
-            with _ops.deferred_finishes():
-                with _ops.wgrad_side_stream(self.wside):
-                    loss.backward()
-                if self.wside is not None:
-                    torch.cuda.current_stream().wait_stream(self.wside)
-                if not torch.cuda.is_current_stream_capturing():   # eager warm-up steps: every deferred gradient was adopted
-                    lost = _ops.orphaned_deferred_outputs(list(self.params) + self._shadows)
-                    if lost:
-                        raise RuntimeError(f"{lost} deferred weight gradients were copied before the flush (see ops.py CONTRACT)")
-                n = _ops.pending_finish_chunks()
-                if self.ftable is None or self.ftable.capacity < n:   # first (eager, warm-up) step: sizes the table
-                    assert not torch.cuda.is_current_stream_capturing(), "the finish table must exist before the capture"
-                    self.ftable = _ops.FinishTable(self.device, n)
-                _ops.flush_finishes(self.ftable)
-        else:
-            with _ops.wgrad_side_stream(self.wside):
-                loss.backward()
+        self._backward(loss, list(self.params) + self._shadows)
         if self.wside is not None:
             torch.cuda.current_stream().wait_stream(self.wside)   # join before anything reads a weight gradient
         if self._shadows:
@@ -141,6 +163,53 @@ class GraphedTrainStep:
         if self.split:
             self._pack_grads()
         return loss.detach()
+
+    def _fwd_bwd_micro(self):
+        cur = torch.cuda.current_stream()
+        M = self.nmicro
+        B = self.static_lq.shape[0]
+        assert B % M == 0, f"batch {B} does not split into {M} micro-batches"
+        mb = B // M
+        if self._shadows:
+            with torch.no_grad():
+                torch._foreach_copy_(self._shadows, self._masters)
+        losses = []
+        for m, st in enumerate(self.mstreams):
+            leaves = self._leaf_sets[m]
+            for t in leaves.values():
+                t.grad = None
+            st.wait_stream(cur)                      # fork
+            with torch.cuda.stream(st):
+                lq, gt = self.static_lq[m * mb:(m + 1) * mb], self.static_gt[m * mb:(m + 1) * mb]
+                with torch.autocast("cuda", dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
+                    out = torch.func.functional_call(self.net, leaves, (lq,))
+                loss = self.loss_fn(out.float(), gt) / M     # mean over the whole batch = mean of the micro-batch means
+                self._backward(loss, list(leaves.values()), m)
+                losses.append(loss.detach())
+        for st in self.mstreams:
+            cur.wait_stream(st)                      # join
+        shadowed = set(self._shadow_map)
+        with torch.no_grad():
+            plain = [n for n in self._names if n not in shadowed]
+            g0 = [self._leaf_sets[0][n].grad for n in plain]
+            for m in range(1, M):
+                torch._foreach_add_(g0, [self._leaf_sets[m][n].grad for n in plain])
+            if self._shadows:
+                sn = list(self._shadow_map)
+                torch._foreach_copy_(self._master_grads, [self._leaf_sets[0][n].grad for n in sn])   # 16-bit -> fp32
+                for m in range(1, M):
+                    torch._foreach_copy_(self._shadow_tmp, [self._leaf_sets[m][n].grad for n in sn])
+                    torch._foreach_add_(self._master_grads, self._shadow_tmp)
+            total = losses[0]
+            for l_ in losses[1:]:
+                total = total + l_
+        named = dict(zip(plain, g0))
+        mg = dict(zip(self._shadow_map, self._master_grads))
+        for n, p in zip(self._names, self.params):
+            p.grad = mg[n] if n in mg else named[n]
+        if self.split:
+            self._pack_grads()
+        return total
 
     def _pack_grads(self):
         grads = [p.grad for p in self.params]
