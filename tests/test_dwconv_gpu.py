@@ -210,6 +210,6 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
             continue   # mathematically zero: rounding noise only
         sc = max(float(ref.abs().max()), 1e-12)
         d = float((got[2][1][k] - ref).abs().max())
-        if d > tol * sc + 1e-9:
+        if d > tol * sc + (1e-9 if acdt is None else 1e-6):   # bf16: gradients of ~1e-6 are rounding noise of the 16-bit activations
             wrong.append((k, d, sc))
     assert not wrong, wrong
