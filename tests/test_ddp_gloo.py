@@ -46,6 +46,23 @@ def _worker(rank, world, port, tmp):
     ddp.allreduce_grads_flat(list(net2.parameters()))
     for (k, p2) in net2.named_parameters():
         assert torch.allclose(p2.grad, grads[k], rtol=1e-5, atol=1e-7), k
+    # ... and so must the persistent flat buffer of the captured step (pack once per step, all-reduce in place,
+    # the optimizer reads views of the buffer)
+    net3 = MamberBlock(16, variant="srgan")
+    net3.load_state_dict(ref_state)
+    fg = None
+    for _ in range(2):   # two steps: the buffer is built at the first and re-used
+        for p3 in net3.parameters():
+            p3.grad = None
+        net3(x_all[idx]).square().mean().backward()
+        if fg is None:
+            fg = ddp.FlatGrads(list(net3.parameters()))
+        fg.pack()
+        fg.allreduce_mean()
+        base = fg.flat.untyped_storage().data_ptr()
+        for (k, p3) in net3.named_parameters():
+            assert p3.grad.untyped_storage().data_ptr() == base, k
+            assert torch.allclose(p3.grad, grads[k], rtol=1e-5, atol=1e-7), k
     if rank == 0:
         torch.save({"grads": grads, "state": ref_state, "x": x_all, "loss": red["l_pix"]}, os.path.join(tmp, "r0.pt"))
     # both ranks hold the same averaged gradient

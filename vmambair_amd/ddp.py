@@ -82,6 +82,34 @@ def reduce_loss_dict(losses: dict) -> dict:
     return {k: float(v) for k, v in zip(keys, t)}
 
 
+class FlatGrads:
+    """One persistent flat fp32 buffer holding every gradient of ``params`` (the captured training step,
+    train_graph.py): ``pack`` copies the freshly produced gradients into it with one multi-tensor copy and
+    re-points ``p.grad`` at views of the buffer, so that the data-parallel exchange is a single all-reduce of
+    ``flat`` with no per-step loop over the ~1450 tensors and nothing to unpack afterwards (the optimizer reads
+    the views).  Built from the first set of gradients it sees; shapes must not change afterwards."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        grads = [p.grad for p in self.params]
+        assert all(g is not None and g.dtype == torch.float32 for g in grads), "FlatGrads needs an fp32 grad per parameter"
+        self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
+        self.views = [v.view_as(g) for v, g in zip(self.flat.split([g.numel() for g in grads]), grads)]
+
+    def pack(self) -> None:
+        with torch.no_grad():
+            torch._foreach_copy_(self.views, [p.grad for p in self.params])
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def allreduce_mean(self) -> None:
+        """mean over ranks, in place (a no-op without an initialised process group / with one rank)"""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        dist.all_reduce(self.flat)
+        self.flat.div_(dist.get_world_size())
+
+
 def allreduce_grads_flat(params) -> None:
     """Average the gradients of ``params`` over all ranks with ONE collective: pack into a flat fp32
     buffer, all-reduce (sum), divide, scatter back in place.  Used between the two hipGraphs of the

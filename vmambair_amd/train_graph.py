@@ -50,7 +50,7 @@ class GraphedTrainStep:
         # split mode: the first graph ends by packing every gradient into ONE persistent fp32 buffer (a multi-tensor copy,
         # captured) and re-points ``p.grad`` at views of it, so that the only work between the two graphs is a single
         # all-reduce of that buffer -- no per-step host loop over the ~1450 gradient tensors, no unpack
-        self._flat = self._flat_views = None
+        self._flat = None   # ddp.FlatGrads
         self.autocast_dtype = autocast_dtype
         self.loss_fn = loss_fn
         self.ema_decay = ema_decay
@@ -212,16 +212,11 @@ class GraphedTrainStep:
         return total
 
     def _pack_grads(self):
-        grads = [p.grad for p in self.params]
         if self._flat is None:
             assert not torch.cuda.is_current_stream_capturing(), "the flat gradient buffer must exist before the capture"
-            assert all(g is not None and g.dtype == torch.float32 for g in grads), "split mode needs an fp32 grad per parameter"
-            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=self.device)
-            self._flat_views = [v.view_as(g) for v, g in zip(self._flat.split([g.numel() for g in grads]), grads)]
-        with torch.no_grad():
-            torch._foreach_copy_(self._flat_views, grads)
-        for p, v in zip(self.params, self._flat_views):
-            p.grad = v
+            from .ddp import FlatGrads
+            self._flat = FlatGrads(self.params)
+        self._flat.pack()
 
     def _opt_ema(self):
         if self.fopt is not None:
@@ -233,9 +228,8 @@ class GraphedTrainStep:
             torch._foreach_add_(self.ema, [p.detach() for p in self.params], alpha=1.0 - self.ema_decay)
 
     def _allreduce(self):
-        if self.world > 1:   # gradients already sit in self._flat (see _pack_grads): one collective, mean over ranks
-            dist.all_reduce(self._flat)
-            self._flat.div_(self.world)
+        if self.world > 1:   # gradients already sit in the flat buffer (see _pack_grads): one collective, mean over ranks
+            self._flat.allreduce_mean()
 
     # ---- capture -----------------------------------------------------------------------------
     def capture(self, lq: torch.Tensor, gt: torch.Tensor) -> None:
