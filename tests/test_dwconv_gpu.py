@@ -203,7 +203,9 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
         torch.cuda.synchronize()
         got[M] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
     assert got[2][0] == pytest.approx(got[1][0], rel=1e-5 if acdt is None else 1e-2)
-    tol = 2e-5 if acdt is None else 5e-2
+    # fp32: the vendor library may pick different solvers for the 3x3 convolutions at batch 4 and batch 2 (measured: up to
+    # 4e-4 of a gradient's scale between runs); a lost or doubled micro-batch would be an error of 0.5
+    tol = 2e-3 if acdt is None else 5e-2
     wrong = []
     for k, ref in got[1][1].items():
         if k.endswith("conv_cout.bias"):
