@@ -174,12 +174,15 @@ def test_deferred_finishing_gives_the_same_gradients(acdt):
     assert set(ref) == set(got)
     # fp32: summation order only; bf16: the library 3x3 convolutions are not run-to-run deterministic to the last 16-bit ulp
     tol = 2e-5 if acdt is None else 5e-2
+    # bf16: the vendor 3x3 convolutions are not run-to-run deterministic to the last 16-bit ulp, and the small gradients of
+    # the channel branch (differences of large terms) inherit that as noise of ~1e-3 of the LARGEST gradient in the net
+    floor = 1e-9 if acdt is None else 2e-3 * max(float(v.abs().max()) for v in ref.values())
     wrong = []
     for k in ref:
         if k.endswith("conv_cout.bias"):
             continue   # mathematically zero (the channel LayerNorm removes it): rounding noise only
         sc = max(float(ref[k].abs().max()), 1e-12)
-        if float((got[k] - ref[k]).abs().max()) > tol * sc + 1e-9:
+        if float((got[k] - ref[k]).abs().max()) > tol * sc + floor:
             wrong.append((k, float((got[k] - ref[k]).abs().max()), sc))
     assert not wrong, wrong
 
@@ -206,12 +209,14 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
     # fp32: the vendor library may pick different solvers for the 3x3 convolutions at batch 4 and batch 2 (measured: up to
     # 4e-4 of a gradient's scale between runs); a lost or doubled micro-batch would be an error of 0.5
     tol = 2e-3 if acdt is None else 5e-2
+    # bf16: noise floor of the small channel-branch gradients, see test_deferred_finishing_gives_the_same_gradients
+    floor = 1e-9 if acdt is None else 2e-3 * max(float(v.abs().max()) for v in got[1][1].values())
     wrong = []
     for k, ref in got[1][1].items():
         if k.endswith("conv_cout.bias"):
             continue   # mathematically zero: rounding noise only
         sc = max(float(ref.abs().max()), 1e-12)
         d = float((got[2][1][k] - ref).abs().max())
-        if d > tol * sc + (1e-9 if acdt is None else 1e-6):   # bf16: gradients of ~1e-6 are rounding noise of the 16-bit activations
+        if d > tol * sc + floor:
             wrong.append((k, d, sc))
     assert not wrong, wrong
