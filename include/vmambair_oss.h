@@ -119,7 +119,9 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
 size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups);
 int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream);
 
-/* Kernel-variant override for tuning / A-B benches: -1 = heuristic (default). */
+/* Kernel-variant override for tuning / A-B benches: -1 = heuristic (default).  Forward variants 0..7, backward variants 0..9
+ * (tables in oss_scan_fwd.hip / oss_scan_bwd.hip; 8 and 9 = two states per pass in packed fp32, oss_scan_bwd_pair.h).  An
+ * unknown number falls back to the small-shape variant. */
 void oss_scan_set_variant(int fwd_variant, int bwd_variant);
 int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
 
