@@ -106,11 +106,16 @@ def cpu_baseline(seed=0):
     opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99))
     step = make_step(net, ema, opt, None, "cpu")
     lq, gt = torch.rand(1, 3, 64, 64), torch.rand(1, 3, 256, 256)
-    t0 = time.perf_counter()
-    step(lq, gt)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "1 training step (fwd+bwd+Adam+EMA), batch 1, 64x64 LQ, fp32, whole MambaSISR6 net; "
+    step(lq, gt)   # untimed: thread pools, allocator, first-call set-up
+    n, t0 = 0, time.perf_counter()
+    while True:    # a bounded sample: whole steps until >= 10 s of host work
+        step(lq, gt)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= 10.0 or n >= 8:
+            break
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} training steps (fwd+bwd+Adam+EMA) after one untimed, batch 1, 64x64 LQ, fp32, whole MambaSISR6 net; "
                       "scan = oracle/oss_scan_oracle.c (OpenMP), rest = torch CPU", "seconds": round(dt, 2)}
 
 
