@@ -161,6 +161,10 @@ int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const floa
 int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
                       int64_t dy_batch_stride, int64_t dy_channel_stride, oss_stream_t stream);
 size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels);
+/* Tuning override of oss_conv1x1_wgrad / oss_proj_wgrad: MFMA tiles per wave, 0 = 1 x 1 (default), 12 / 21 / 22 = rows x columns
+ * of 32 x 32 tiles (fewer re-reads of the operands, fewer waves).  Same results up to the summation order; initial value from
+ * the environment variable VMAMBAIR_WGRAD_TILE. */
+void oss_conv1x1_wgrad_set_tile(int mode);
 int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *dbias, float *partials, int batch,
                       int cout, int cin, int pixels, int64_t dy_batch_stride, int64_t dy_channel_stride,
                       int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);

@@ -275,6 +275,7 @@ int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, 
 }
 
 void oss_proj_set_path(int force_vector_alu) { proj_force_valu(force_vector_alu); }
+void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
 
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {

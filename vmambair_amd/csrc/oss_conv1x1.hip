@@ -16,6 +16,8 @@
 //     activation operand needs 8 channels of ONE pixel per lane while NCHW stores pixels contiguously:
 //     8 two-byte loads per lane, each coalesced over the 32 pixel lanes (64-byte segments).
 //   wgrad: k = pixels, so both operands are 16-byte contiguous loads (dy rows and x rows).
+#include <atomic>
+#include <cstdlib>
 #include "oss_device.h"
 #include "oss_host.h"
 #include "oss_mfma.h"
@@ -567,6 +569,149 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
     return (int)hipGetLastError();
 }
 
+// The same partial product with TM x TN MFMA tiles (32 TM rows of dW x 32 TN columns) per wave: a wave then reads its 32 TM
+// rows of dy and 32 TN rows of x once for TM TN tiles, so the launch re-reads dy ceil(NB / 32 TN) times and x
+// ceil(M / 32 TM) times instead of ceil(NB / 32) and ceil(M / 32).  The 1 x 1 kernel above moves 22 MB through L2 for the
+// 9.4 MB of a (96 x 48, 8 x 4096 pixels) problem and runs at about the speed that traffic allows; 2 x 2 moves 12.6 MB.
+// OPT-IN (VMAMBAIR_WGRAD_TILE = 12 | 21 | 22) until measured on the box; identical partial layout and finishing.
+template <typename T, int TM, int TN>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_wgrad_tiles_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
+                               int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
+                               int64_t gs_hi, int NB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y / G, g = blockIdx.y - b * G, slab = blockIdx.x;
+    const int pbeg = slab * kWgradSlab, pend = min(P, pbeg + kWgradSlab);
+    const int col = lane & 31, kg = lane >> 5;
+    const int mt = (M + 32 * TM - 1) / (32 * TM), nt = (NB + 32 * TN - 1) / (32 * TN);
+    const T *gb = dy + b * gsb + g * gsg;
+    const T *xb = x + b * xsb + g * xsg;
+    const size_t pvec = (size_t)G * M * N + (NB > N ? M : 0);
+    float *pb = part + (size_t)(b * gridDim.x + slab) * pvec;
+    const short kOne = (short)from_f32<T>(1.0f).v;
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0}, ones8 = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
+    const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
+                         (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0) && (gs_hi % 8 == 0);
+    const int tile = blockIdx.z * 4 + wave;  // one (32 TM) x (32 TN) tile of dW per wave
+    if (tile >= mt * nt) return;
+    const int m0 = (tile / nt) * 32 * TM, n0 = (tile % nt) * 32 * TN;
+    const T *ga[TM];
+    const T *xa[TN];
+    bool mok[TM], nok[TN], one[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow = m0 + 32 * i + col;
+        mok[i] = mrow < M;
+        const int mr = mok[i] ? mrow : 0;
+        ga[i] = gb + (mr / Mh) * gs_hi + (mr % Mh) * gsm;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nrow = n0 + 32 * j + col;
+        nok[j] = nrow < N;
+        one[j] = nrow == N && NB > N;
+        xa[j] = xb + (nok[j] ? nrow : 0) * xsn;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // operand fragments of one 16-pixel k-step (8 pixels per lane half) for every row tile / column tile
+    auto frag = [&](const T *row, int k0, bool ok, bool ones, bool fast) -> s16x8 {
+        if (fast) {
+            const u32x4 q = *reinterpret_cast<const u32x4 *>(row + k0);
+            return ok ? __builtin_bit_cast(s16x8, q) : (ones ? ones8 : zero8);
+        }
+        s16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool kok = (k0 + e) < pend;
+            const int kc = kok ? k0 + e : pend - 1;
+            const short v = (short)row[kc].v;
+            f[e] = kok ? (ok ? v : (ones ? kOne : (short)0)) : (short)0;
+        }
+        return f;
+    };
+    int pk = pbeg;
+    if (aligned) {
+        for (; pk + 32 <= pend; pk += 32) {   // 2 k-steps per iteration: 2 (TM + TN) 16-byte loads in flight
+            s16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[u][i] = frag(ga[i], pk + u * 16 + kg * 8, mok[i], false, true);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[u][j] = frag(xa[j], pk + u * 16 + kg * 8, nok[j], one[j], true);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(af[u][i], bf[u][j], acc[i][j]);
+        }
+    }
+    for (; pk < pend; pk += 16) {
+        const int k0 = pk + kg * 8;
+        const bool fast = aligned && k0 + 8 <= pend;
+        s16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = frag(ga[i], k0, mok[i], false, fast);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = frag(xa[j], k0, nok[j], one[j], fast);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int cn = n0 + 32 * j + col;
+                if (row < M && cn < NB) {
+                    const size_t drow = ((size_t)(row / Mh) * G + g) * Mh + row % Mh;
+                    if (cn < N) pb[drow * N + cn] = acc[i][j][r];
+                    else pb[(size_t)G * M * N + row] = acc[i][j][r];
+                }
+            }
+}
+
+// 0 = the 1 x 1 kernel (default); 12, 21, 22 = TM x TN tiles per wave.  Initial value from VMAMBAIR_WGRAD_TILE,
+// changed at run time by oss_conv1x1_wgrad_set_tile (tests, A-B timing)
+static std::atomic<int> g_wgrad_tile{-1};
+static int wgrad_tile_mode() {
+    int m = g_wgrad_tile.load();
+    if (m < 0) {
+        const char *e = std::getenv("VMAMBAIR_WGRAD_TILE");
+        const int v = e ? std::atoi(e) : 0;
+        m = (v == 12 || v == 21 || v == 22) ? v : 0;
+        g_wgrad_tile.store(m);
+    }
+    return m;
+}
+void conv1x1_wgrad_set_tile(int mode) { g_wgrad_tile.store((mode == 12 || mode == 21 || mode == 22) ? mode : 0); }
+
+template <typename T>
+static void wgrad_tiles_launch(int mode, const T *dy, const T *x, float *part, int B, int M, int N, int P, int64_t gsb, int64_t gsm,
+                               int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh, int64_t gs_hi, int NB,
+                               int slabs, hipStream_t s) {
+    const int tm = mode / 10, tn = mode % 10;
+    const int tiles = ((M + 32 * tm - 1) / (32 * tm)) * ((NB + 32 * tn - 1) / (32 * tn));
+    dim3 grid(slabs, B * G, (tiles + 3) / 4);
+#define OSS_WG(TM_, TN_) hipLaunchKernelGGL((oss_conv1x1_wgrad_tiles_kernel<T, TM_, TN_>), grid, dim3(256), 0, s, dy, x, part, M, N, P, \
+                                            gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB)
+    if (mode == 12) OSS_WG(1, 2); else if (mode == 21) OSS_WG(2, 1); else OSS_WG(2, 2);
+#undef OSS_WG
+}
+
 int conv1x1_wgrad_slabs(int P) { return (P + kWgradSlab - 1) / kWgradSlab; }
 
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
@@ -578,6 +723,15 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
     const int slabs = conv1x1_wgrad_slabs(P);
     const int tiles = ((M + 31) / 32) * ((NB + 31) / 32);
     dim3 grid(slabs, B * G, (tiles + 3) / 4);
+    const int tmode = wgrad_tile_mode();
+    if (tmode && (io == OSS_BF16 || io == OSS_F16)) {
+        if (io == OSS_BF16)
+            wgrad_tiles_launch<bf16_t>(tmode, reinterpret_cast<const bf16_t *>(dy), reinterpret_cast<const bf16_t *>(x), part, B, M, N, P,
+                                       gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB, slabs, s);
+        else
+            wgrad_tiles_launch<f16_t>(tmode, reinterpret_cast<const f16_t *>(dy), reinterpret_cast<const f16_t *>(x), part, B, M, N, P,
+                                      gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB, slabs, s);
+    } else
     switch (io) {
         case OSS_BF16:
             hipLaunchKernelGGL(oss_conv1x1_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(dy),
