@@ -41,7 +41,7 @@ shape = st.tuples(st.integers(1, 2),                                   # batch
                   st.one_of(st.integers(1, 70), st.sampled_from([255, 256, 257, 300, 513])))  # length (chunk = 256)
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=40, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
 @given(shape=shape, softplus=st.booleans(), has_d=st.booleans(), has_bias=st.booleans(), seed=st.integers(0, 2 ** 16))
 def test_oracle_equals_the_float64_restatement(shape, softplus, has_d, has_bias, seed):
     Bsz, G, rows, N, L = shape
