@@ -18,10 +18,14 @@ copy per step; the net runs on the shadows (``torch.func.functional_call``) and 
 converted to the fp32 master gradients by one more multi-tensor copy.  Numerically identical to
 autocast (the same rounding of the same master weights every step).
 
-Multi-GPU: the graph holds forward + backward only; after the replay the gradients are packed into
-ONE flat buffer, all-reduced with a single RCCL call (48.1 MB for MambaSISR6 -- xGMI-link-bound
-~0.1-0.6 ms) and scattered back, then a second graph applies Adam + EMA.  No DDP hooks
-inside a capture, no per-bucket calls.
+Multi-GPU: the first graph holds forward + backward and ends by packing every gradient into ONE
+persistent flat buffer (``ddp.FlatGrads``; ``p.grad`` then points at views of it); between the graphs
+that buffer is all-reduced with a single RCCL call (48.1 MB for MambaSISR6 -- xGMI-link-bound
+~0.1-0.6 ms) and divided in place; a second graph applies Adam + EMA reading the views.
+No DDP hooks inside a capture, no per-bucket calls, no per-step host loop over the gradient tensors.
+
+Deferred finishing (``defer_finishes``), the adoption contract that goes with it and the optional
+micro-batch branches (``micro_streams``) are described at their code below and in ops.py.
 """
 from __future__ import annotations
 
