@@ -20,6 +20,10 @@ Fixture families:
   g2_perm.npz       the four spatial direction maps and the merge, on integer data (bit-exact)
   g3_block_*.npz    OSS block (SS2D_1 / MamberBlock variants): state_dict, input, output, grads
   g4_net_*.npz      whole small UNet forward
+  g3_block_*_d96 / _d384 / _cfg1 / realsr_fp16   (round 2) production widths, BASELINE config 1, fp16-exact RealSR block
+  g5_psnr.npz, g5_ckpt_*.pth, g5_net_psnr.npz    (round 2) the reference's calculate_psnr / tensor2img / save_network
+  g6_tiles_*.npz    (round 2) RealESRGANer.pre_process/tile_process/post_process and MambaSISRModel2.test run on
+                    position-coded images with a recording stand-in for the network
 """
 import ast
 import importlib.util
@@ -276,9 +280,224 @@ def make_g4():
     save("g4_net_mamber32_d8.npz", **arrays)
 
 
+# --------------------------------------------------------------------------------------------
+# round 2: production widths, BASELINE config 1, fp16-exact RealSR block
+# --------------------------------------------------------------------------------------------
+def _h(t):
+    """round to the fp16 grid (values stay fp32): inputs / weights both sides can hold exactly in 16 bits"""
+    return t.half().float()
+
+
+def run_block_compact(arch, tag, dim, shape, seed=0, grad_stride=1, io_stride=1, half_exact=True):
+    """MamberBlock(dim) with fp16-exact weights and input; stores the state dict as float16, y / dx (optionally
+    every ``io_stride``-th pixel row and column) and every ``grad_stride``-th element of each flattened parameter
+    gradient -- small files for large widths."""
+    torch.manual_seed(seed)
+    m = arch.MamberBlock(dim=dim, num_heads=1, ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias")
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith(("body.weight", "body.bias", "Ds", "Dsc")):
+                p_.data = p_.data.clone() + 0.1 * torch.randn(p_.shape)
+            if half_exact:
+                p_.data = _h(p_.data)
+    x = _h(torch.randn(*shape)).requires_grad_()
+    y = m(x)
+    g = _h(torch.randn_like(y))
+    y.backward(g)
+    s = io_stride
+    arrays = {"x": x.detach().half(), "dy": g.half(), "y": y[..., ::s, ::s], "dx": x.grad[..., ::s, ::s],
+              "io_stride": np.array(s), "grad_stride": np.array(grad_stride)}
+    for k, v in m.state_dict().items():
+        arrays["sd." + k] = v.half()
+    for k, p_ in m.named_parameters():
+        gr = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        arrays["grad." + k] = gr.reshape(-1)[::grad_stride]
+        arrays["gradmax." + k] = gr.abs().max()
+    save(f"g3_block_{tag}.npz", **arrays)
+
+
+def make_g3w():
+    sr = load_arch("SRGAN")
+    run_block_compact(sr, "srgan_mamber_d96", 96, (2, 96, 10, 12), seed=3)            # decoder-1 / refinement width
+    run_block_compact(sr, "srgan_mamber_d384", 384, (1, 384, 6, 8), seed=4, grad_stride=7)  # latent width, EFFN 1021
+    m32 = load_arch("mamber32")
+    run_block_compact(m32, "mamber32_d192", 192, (1, 192, 8, 6), seed=5, grad_stride=3)
+    rs = load_arch("RealSR")
+    run_block_compact(rs, "realsr_fp16_d48", 48, (1, 48, 12, 10), seed=6)
+
+
+def make_g3c1():
+    """BASELINE.json configs[0]: x2 SR, 48x48 LQ, d_state 16, ONE OSS block, batch 2 (the reference CPU fallback case)"""
+    sr = load_arch("SRGAN")
+    import time
+    t0 = time.time()
+    run_block_compact(sr, "srgan_mamber_cfg1", 48, (2, 48, 48, 48), seed=0, io_stride=2)
+    print(f"config-1 block fwd+bwd through selective_scan_ref: {time.time() - t0:.1f} s")
+
+
+# --------------------------------------------------------------------------------------------
+# round 2: G5 -- checkpoint format and PSNR (f4)
+# --------------------------------------------------------------------------------------------
+def _extract(path, names, ns, cls=None):
+    """compile the named FunctionDefs (module level, or methods of ``cls``) out of a reference file into ``ns``"""
+    tree = ast.parse(open(path).read(), filename=path)
+    body = tree.body
+    if cls is not None:
+        body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0].body
+    wanted = [n for n in body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(wanted) == len(names), (path, names)
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def load_ref_metrics():
+    mf = load_by_path("ref_matlab_functions", f"{REF}/Deraining/basicsr/utils/matlab_functions.py")
+    ns = {"np": np, "torch": torch, "bgr2ycbcr": mf.bgr2ycbcr}
+    _extract(f"{REF}/Deraining/basicsr/metrics/metric_util.py", ["reorder_image", "to_y_channel"], ns)
+    _extract(f"{REF}/Deraining/basicsr/metrics/psnr_ssim.py", ["calculate_psnr"], ns)
+    import math
+    cv2 = types.SimpleNamespace(COLOR_RGB2BGR=4, cvtColor=lambda img, code: np.ascontiguousarray(img[..., ::-1]))
+    ns2 = {"np": np, "torch": torch, "math": math, "cv2": cv2, "make_grid": None}
+    _extract(f"{REF}/SRGAN/VmambaIR/utils/img_util.py", ["tensor2img"], ns2)
+    return ns["calculate_psnr"], ns2["tensor2img"], ns["to_y_channel"]
+
+
+def load_ref_ckpt_io():
+    import logging
+    from copy import deepcopy
+    ns = {"os": os, "torch": torch, "logger": logging.getLogger("ref"), "deepcopy": deepcopy, "master_only": lambda f: f}
+    _extract(f"{REF}/Deraining/basicsr/models/base_model.py",
+             ["save_network", "load_network", "_print_different_keys_loading"], ns, cls="BaseModel")
+    return ns
+
+
+def make_g5():
+    psnr, tensor2img, to_y = load_ref_metrics()
+    rng = np.random.RandomState(0)
+    cases = {}
+    # (a) uint8 HWC BGR pairs, the SRGAN validation path (tensor2img -> calculate_psnr crop 4, Y channel)
+    for i, (h, w) in enumerate([(40, 52), (33, 47)]):
+        a = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.randint(-12, 13, a.shape), 0, 255).astype(np.uint8)
+        cases[f"u8_{i}.a"], cases[f"u8_{i}.b"] = a, b
+        for crop in (0, 4):
+            for yc in (False, True):
+                cases[f"u8_{i}.psnr_c{crop}_y{int(yc)}"] = np.float64(psnr(a, b, crop, "HWC", yc))
+    # (b) float tensors in [0, 1] (the Deraining path hands torch tensors: psnr_ssim.py:38-45)
+    ta = torch.from_numpy(rng.rand(1, 3, 24, 28).astype(np.float32))
+    tb = (ta + 0.03 * torch.from_numpy(rng.randn(1, 3, 24, 28).astype(np.float32))).clamp(0, 1)
+    cases["f32.a"], cases["f32.b"] = ta.numpy(), tb.numpy()
+    for crop in (0, 4):
+        cases[f"f32.psnr_c{crop}_y0"] = np.float64(psnr(ta, tb, crop, "HWC", False))
+    # (c) tensor2img on out-of-range float tensors (clamp, round-half-even, RGB->BGR)
+    tt = torch.from_numpy((rng.rand(1, 3, 9, 11) * 1.4 - 0.2).astype(np.float32))
+    cases["t2i.in"], cases["t2i.out"] = tt.numpy(), tensor2img([tt])
+    # (d) Y channel of a float BGR image in [0, 255]
+    yb = (rng.rand(7, 5, 3) * 255).astype(np.float64)
+    cases["y.in"], cases["y.out"] = yb, to_y(yb)
+    np.savez_compressed(os.path.join(OUT, "g5_psnr.npz"), **cases)
+    print("wrote g5_psnr.npz")
+
+    # checkpoint written by the reference's own save_network: {'params': ..., 'params_ema': ...}
+    io = load_ref_ckpt_io()
+    sr = load_arch("SRGAN")
+    torch.manual_seed(0)
+    net = sr.MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    torch.manual_seed(1)
+    ema = sr.MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    self_ = types.SimpleNamespace(opt={"path": {"models": OUT}}, get_bare_model=lambda n: n)
+    self_._print_different_keys_loading = lambda *a, **k: io["_print_different_keys_loading"](self_, *a, **k)
+    io["save_network"](self_, [net, ema], "g5_ckpt_mambasisr6_d8", 7, param_key=["params", "params_ema"])
+    os.replace(os.path.join(OUT, "g5_ckpt_mambasisr6_d8_7.pth"), os.path.join(OUT, "g5_ckpt_mambasisr6_d8.pth"))
+    print("wrote g5_ckpt_mambasisr6_d8.pth", os.path.getsize(os.path.join(OUT, "g5_ckpt_mambasisr6_d8.pth")) // 1024, "KiB")
+    # forward of the EMA weights + the validation metric on it (nondist_validation: tensor2img both, crop 4, Y)
+    x = torch.rand(1, 3, 16, 24)
+    gt = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        y_ema, y_par = ema(x), net(x)
+    vals = {}
+    for name, y in (("ema", y_ema), ("params", y_par)):
+        # clones: on CPU float tensors the reference's tensor2img clamps its argument in place (img_util.py:68)
+        vals[f"psnr_{name}"] = np.float64(psnr(tensor2img([y.clone()]), tensor2img([gt.clone()]), 4, "HWC", True))
+    save("g5_net_psnr.npz", x=x, gt=gt, y_ema=y_ema, y_params=y_par, **vals)
+    # our writer must produce a file the reference's load_network accepts (checked here, in the build container)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    try:
+        from vmambair_amd import checkpoint as ck
+        from vmambair_amd.archs import MambaSISR6
+        ours = MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+        ck.load_network(ours, os.path.join(OUT, "g5_ckpt_mambasisr6_d8.pth"), strict=True, param_key="params_ema")
+        tmp = os.path.join("/tmp", "ours_roundtrip.pth")
+        ck.save_network([ours, ours], tmp, param_key=["params", "params_ema"])
+        back = sr.MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+        io["load_network"](self_, back, tmp, True, "params_ema")
+        with torch.no_grad():
+            assert torch.equal(back(x), y_ema)
+        print("our save_network output loads through the reference's load_network: forward identical")
+    except ImportError as e:
+        print("(vmambair_amd.checkpoint not importable yet:", e, ")")
+
+
+# --------------------------------------------------------------------------------------------
+# round 2: G6 -- tiling rules (f3), run on position-coded images with a recording stand-in net
+# --------------------------------------------------------------------------------------------
+class _Recorder(torch.nn.Module):
+    """context-dependent stand-in: nearest upsampling plus a term that depends on the whole window it was given"""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.scale, self.shapes = scale, []
+
+    def forward(self, t):
+        self.shapes.append(tuple(t.shape[-2:]))
+        return F.interpolate(t.float(), scale_factor=self.scale, mode="nearest") + 1000.0 * t.float().mean() \
+            + 7.0 * float(t.shape[-1]) + 3.0 * float(t.shape[-2])
+
+
+def make_g6():
+    import contextlib
+    import io as _io
+    import math
+    ns = {"torch": torch, "np": np, "F": F, "math": math}
+    _extract(f"{REF}/RealSR/VmambaIR/utils.py", ["pre_process", "tile_process", "post_process"], ns, cls="RealESRGANer")
+    rng = np.random.RandomState(0)
+    out = {}
+    cases = [(37, 53, 4, 16, 4, 0), (37, 53, 4, 16, 4, 10), (64, 64, 4, 32, 8, 0), (45, 31, 2, 16, 6, 5), (20, 90, 4, 128, 16, 10)]
+    for i, (h, w, scale, tile, pad, pre) in enumerate(cases):
+        img = rng.rand(h, w, 3).astype(np.float32)
+        model = _Recorder(scale)
+        s = types.SimpleNamespace(scale=scale, tile_size=tile, tile_pad=pad, pre_pad=pre, mod_scale=None, half=False,
+                                  device=torch.device("cpu"), model=model)
+        with contextlib.redirect_stdout(_io.StringIO()):
+            ns["pre_process"](s, img)
+            padded = s.img.clone()
+            ns["tile_process"](s)
+            res = ns["post_process"](s)
+        out[f"realsr_{i}.cfg"] = np.array([h, w, scale, tile, pad, pre])
+        out[f"realsr_{i}.img"] = img
+        out[f"realsr_{i}.padded"] = padded.numpy()
+        out[f"realsr_{i}.shapes"] = np.array(model.shapes)
+        out[f"realsr_{i}.out"] = res.numpy()
+    ns2 = {"torch": torch, "F": F}
+    _extract(f"{REF}/SRGAN/VmambaIR/models/MambaSISR2_model.py", ["test"], ns2, cls="MambaSISRModel2")
+    for i, (h, w, scale) in enumerate([(64, 64, 4), (100, 70, 4), (129, 64, 2), (40, 200, 4)]):
+        lq = torch.from_numpy(rng.rand(1, 3, h, w).astype(np.float32))
+        model = _Recorder(scale)
+        model.train = lambda *a, **k: None
+        model.eval = lambda *a, **k: None
+        s = types.SimpleNamespace(lq=lq, opt={"scale": scale}, net_g=model)
+        ns2["test"](s)
+        out[f"srgan_{i}.cfg"] = np.array([h, w, scale])
+        out[f"srgan_{i}.lq"] = lq.numpy()
+        out[f"srgan_{i}.shapes"] = np.array(model.shapes)
+        out[f"srgan_{i}.out"] = s.output.numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_tiles.npz"), **out)
+    print("wrote g6_tiles.npz", os.path.getsize(os.path.join(OUT, "g6_tiles.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g3w", "g3c1", "g5", "g6"]
     if "g1" in which:
         make_g1()
     if "g2" in which:
@@ -287,3 +506,6 @@ if __name__ == "__main__":
         make_g3()
     if "g4" in which:
         make_g4()
+    for k, fn in (("g3w", make_g3w), ("g3c1", make_g3c1), ("g5", make_g5), ("g6", make_g6)):
+        if k in which:
+            fn()

@@ -1,0 +1,113 @@
+"""Checkpoint files of the reference's training loops, read and written by the drop-in modules.
+
+The reference stores a network as ``torch.save({param_key: state_dict, ...})`` with ``param_key`` in
+{``'params'``, ``'params_ema'``} and every ``module.`` prefix (DataParallel / DDP wrappers) removed
+(``BaseModel.save_network``, Deraining/basicsr/models/base_model.py:213-244; the SRGAN / RealSR trees use
+pip-basicsr's identical method, and ``RealESRGANer`` reads the same files preferring ``params_ema``,
+RealSR/VmambaIR/utils.py:57-63).  ``load_network`` (:281-309) picks ``param_key`` (falling back to
+``'params'`` when the file has no ``'params_ema'``), strips ``module.`` again and calls
+``load_state_dict(strict=...)``; with ``strict=False`` entries whose SIZE differs are set aside instead of
+raising (``_print_different_keys_loading``, :246-279).
+
+Because the modules under ``vmambair_amd`` keep the reference's parameter names and shapes, a released
+``net_g_*.pth`` loads with ``strict=True`` and a file written here loads in the reference (checked against
+the reference's own reader by tests/golden/make_golden.py, fixture ``g5_ckpt_mambasisr6_d8.pth``).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+log = logging.getLogger("vmambair_amd.checkpoint")
+
+
+def bare_model(net: torch.nn.Module) -> torch.nn.Module:
+    """the module under DataParallel / DistributedDataParallel (base_model.py:135-142)"""
+    if isinstance(net, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+        net = net.module
+    return net
+
+
+def _strip_module(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    out = OrderedDict()
+    for k, v in sd.items():
+        out[k[7:] if k.startswith("module.") else k] = v
+    return out
+
+
+def network_state(net: torch.nn.Module) -> "OrderedDict[str, torch.Tensor]":
+    """CPU state dict without ``module.`` prefixes: what ``save_network`` stores per key (:231-236)"""
+    return OrderedDict((k, v.detach().cpu()) for k, v in _strip_module(bare_model(net).state_dict()).items())
+
+
+def save_network(net: Union[torch.nn.Module, Sequence[torch.nn.Module]], save_path: str,
+                 param_key: Union[str, Sequence[str]] = "params") -> str:
+    """``BaseModel.save_network``: one file, one state dict per ``param_key`` (``[net_g, net_g_ema]`` with
+    ``['params', 'params_ema']`` is what the training loops write).  Written atomically."""
+    nets = list(net) if isinstance(net, (list, tuple)) else [net]
+    keys = list(param_key) if isinstance(param_key, (list, tuple)) else [param_key]
+    if len(nets) != len(keys):
+        raise ValueError("The lengths of net and param_key should be the same.")
+    blob = {k: network_state(n) for n, k in zip(nets, keys)}
+    os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+    tmp = save_path + ".tmp"
+    torch.save(blob, tmp)
+    os.replace(tmp, save_path)
+    return save_path
+
+
+def save_iteration(net, models_dir: str, net_label: str, current_iter: int, param_key="params") -> str:
+    """file naming of the reference: ``{label}_{iter}.pth``, ``latest`` for iteration -1 (:225-228)"""
+    it = "latest" if current_iter == -1 else current_iter
+    return save_network(net, os.path.join(models_dir, f"{net_label}_{it}.pth"), param_key)
+
+
+def read_state(load_path: str, param_key: Optional[str] = "params") -> "OrderedDict[str, torch.Tensor]":
+    """the state dict ``load_network`` would hand to ``load_state_dict`` (key choice + ``module.`` stripping)"""
+    blob = torch.load(load_path, map_location="cpu", weights_only=True)
+    if param_key is not None:
+        if param_key not in blob and "params" in blob:
+            log.info("Loading: %s does not exist, use params.", param_key)
+            param_key = "params"
+        blob = blob[param_key]
+    return _strip_module(blob)
+
+
+def different_keys(net: torch.nn.Module, state: Dict[str, torch.Tensor], strict: bool = True) -> Dict[str, List[str]]:
+    """``_print_different_keys_loading``: names only in the net / only in the file; with ``strict=False`` the
+    same-name-different-size entries are renamed ``<key>.ignore`` in ``state`` so that they are not loaded."""
+    cur = bare_model(net).state_dict()
+    res = {"missing_in_file": sorted(set(cur) - set(state)), "unexpected_in_file": sorted(set(state) - set(cur)),
+           "size_mismatch": []}
+    for v in res["missing_in_file"]:
+        log.warning("Current net - loaded net: %s", v)
+    for v in res["unexpected_in_file"]:
+        log.warning("Loaded net - current net: %s", v)
+    if not strict:
+        for k in sorted(set(cur) & set(state)):
+            if cur[k].size() != state[k].size():
+                log.warning("Size different, ignore [%s]: crt_net: %s; load_net: %s", k, tuple(cur[k].shape), tuple(state[k].shape))
+                state[k + ".ignore"] = state.pop(k)
+                res["size_mismatch"].append(k)
+    return res
+
+
+def load_network(net: torch.nn.Module, load_path: str, strict: bool = True, param_key: Optional[str] = "params"):
+    """``BaseModel.load_network``.  Raises ``RuntimeError`` on any name / size difference when ``strict``
+    (``load_state_dict``'s own error), returns its ``_IncompatibleKeys`` otherwise."""
+    state = read_state(load_path, param_key)
+    different_keys(net, state, strict)
+    return bare_model(net).load_state_dict(state, strict=strict)
+
+
+def load_for_inference(net: torch.nn.Module, load_path: str) -> str:
+    """``RealESRGANer.__init__``: prefer ``params_ema``, strict (RealSR/VmambaIR/utils.py:57-63) -> key used"""
+    blob = torch.load(load_path, map_location="cpu", weights_only=True)
+    key = "params_ema" if "params_ema" in blob else "params"
+    bare_model(net).load_state_dict(_strip_module(blob[key]), strict=True)
+    net.eval()
+    return key

@@ -10,9 +10,12 @@ pass of each shape is captured once and replayed for every tile of that shape --
 """
 from __future__ import annotations
 
-from typing import Dict, Iterator, Optional, Tuple
+import math
+from typing import Dict, Iterator, List, Optional, Tuple
 
+import numpy as np
 import torch
+import torch.nn.functional as F
 
 
 def tile_plan(height: int, width: int, tile: int, pad: int) -> Iterator[Tuple[int, int, int, int, int, int, int, int]]:
@@ -84,3 +87,136 @@ class TiledSR:
             oy, ox = (y0 - py0) * s, (x0 - px0) * s          # the cell's own area inside the enlarged padded tile
             out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[:, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
         return out
+
+
+class GraphedForward:
+    """``net(x)`` under ``no_grad`` (+ autocast), one hipGraph per input shape -- shared by the drivers below."""
+
+    def __init__(self, net: torch.nn.Module, autocast_dtype: Optional[torch.dtype], use_graph: bool = True):
+        self._drv = TiledSR(net, 1, tile=1 << 30, tile_pad=0, autocast_dtype=autocast_dtype, use_graph=use_graph)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        return self._drv._run_tile(x)
+
+    @property
+    def n_graphs(self) -> int:
+        return self._drv.n_graphs
+
+    @property
+    def calls(self) -> int:
+        return self._drv.tiles_run
+
+
+class RealSREnhancer:
+    """The tensor part of the reference's ``RealESRGANer`` (RealSR/VmambaIR/utils.py:68-173): ``pre_process`` (reflect
+    pre-pad on the right / bottom, then reflect mod-pad to a multiple of 2 for scale 2 and of 4 for scale 1, :74-91),
+    ``tile_process`` / ``process`` (:93-160) and ``post_process`` (crop both pads off the enlarged image, :162-171).
+    ``half=True`` is the reference's ``model.half()`` inference: here fp16 autocast over fp32 master weights.  Colour
+    conversion / alpha handling of ``enhance`` (cv2) stay with the caller.  Pinned by tests/golden/g6_tiles.npz."""
+
+    def __init__(self, net: torch.nn.Module, scale: int, tile: int = 0, tile_pad: int = 10, pre_pad: int = 10,
+                 half: bool = False, use_graph: bool = True, device: Optional[torch.device] = None):
+        self.scale, self.tile_size, self.tile_pad, self.pre_pad, self.half = scale, tile, tile_pad, pre_pad, half
+        self.device = device if device is not None else next(net.parameters(), torch.zeros(())).device
+        acdt = torch.float16 if half else None
+        graph = use_graph and torch.device(self.device).type == "cuda"
+        self.tiled = TiledSR(net, scale, tile=max(tile, 1), tile_pad=tile_pad, autocast_dtype=acdt, use_graph=graph)
+        self.whole = GraphedForward(net, acdt, use_graph=graph)
+        self.mod_scale = None
+        self.mod_pad_h = self.mod_pad_w = 0
+
+    def pre_process(self, img) -> torch.Tensor:
+        """``img``: (H, W, C) array in [0, 1] (as ``enhance`` hands it over) or a (1, C, H, W) tensor"""
+        if isinstance(img, np.ndarray):
+            img = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (2, 0, 1)))).float().unsqueeze(0)
+        t = img.to(self.device)
+        if self.half:
+            t = t.half()
+        if self.pre_pad != 0:
+            t = F.pad(t, (0, self.pre_pad, 0, self.pre_pad), "reflect")
+        if self.scale == 2:
+            self.mod_scale = 2
+        elif self.scale == 1:
+            self.mod_scale = 4
+        self.mod_pad_h = self.mod_pad_w = 0
+        if self.mod_scale is not None:
+            _, _, h, w = t.shape
+            if h % self.mod_scale != 0:
+                self.mod_pad_h = self.mod_scale - h % self.mod_scale
+            if w % self.mod_scale != 0:
+                self.mod_pad_w = self.mod_scale - w % self.mod_scale
+            t = F.pad(t, (0, self.mod_pad_w, 0, self.mod_pad_h), "reflect")
+        self.img = t
+        return t
+
+    def process(self) -> torch.Tensor:
+        self.output = self.whole(self.img)
+        return self.output
+
+    def tile_process(self) -> torch.Tensor:
+        self.output = self.tiled(self.img)
+        return self.output
+
+    def post_process(self) -> torch.Tensor:
+        out = self.output
+        if self.mod_scale is not None:
+            _, _, h, w = out.shape
+            out = out[:, :, 0:h - self.mod_pad_h * self.scale, 0:w - self.mod_pad_w * self.scale]
+        if self.pre_pad != 0:
+            _, _, h, w = out.shape
+            out = out[:, :, 0:h - self.pre_pad * self.scale, 0:w - self.pre_pad * self.scale]
+        self.output = out
+        return out
+
+    @torch.no_grad()
+    def enhance_tensor(self, img) -> torch.Tensor:
+        self.pre_process(img)
+        if self.tile_size > 0:
+            self.tile_process()
+        else:
+            self.process()
+        return self.post_process()
+
+
+def split64_plan(h: int, w: int, split: int = 64) -> Tuple[int, int, int, int]:
+    """-> (mod_pad_h, mod_pad_w, rows, cols) of ``MambaSISRModel2.test`` (SRGAN/VmambaIR/models/MambaSISR2_model.py:99-117)"""
+    mod_pad_h = (h // split + 1) * split - h if h % split != 0 else 0
+    mod_pad_w = (w // split + 1) * split - w if w % split != 0 else 0
+    return mod_pad_h, mod_pad_w, (h + mod_pad_h) // split, (w + mod_pad_w) // split
+
+
+class Split64SR:
+    """Validation-time inference of the SRGAN tree (``MambaSISRModel2.test``, MambaSISR2_model.py:99-193): reflect-pad
+    the LQ image on the right / bottom to multiples of 64, run the net on every non-overlapping 64x64 cell, paste the
+    enlarged cells, crop the padding.  Every cell has ONE shape, so the forward is ONE hipGraph replayed per cell --
+    or per group of ``batch_tiles`` cells stacked on the batch axis (cells are independent: nothing in the nets mixes
+    batch entries), which is how a launch-bound 64x64 forward fills a 256-CU GPU.  The reference assembles the output
+    on the CPU in fp32 (``torch.zeros(1, C, H*scale, W*scale)``, :164); here it stays on the device."""
+
+    def __init__(self, net: torch.nn.Module, scale: int = 4, split: int = 64, autocast_dtype: Optional[torch.dtype] = None,
+                 use_graph: bool = True, batch_tiles: int = 1):
+        self.scale, self.split, self.batch_tiles = scale, split, max(1, int(batch_tiles))
+        self.fwd = GraphedForward(net, autocast_dtype, use_graph)
+        self.net = net
+
+    @torch.no_grad()
+    def __call__(self, lq: torch.Tensor) -> torch.Tensor:
+        _, C, h, w = lq.shape
+        s, sp = self.scale, self.split
+        mph, mpw, rows, cols = split64_plan(h, w, sp)
+        img = F.pad(lq, (0, mpw, 0, mph), "reflect") if (mph or mpw) else lq
+        cells = [(i, j) for i in range(rows) for j in range(cols)]
+        out = None
+        use_graph = self.fwd._drv.use_graph and img.is_cuda
+        for k in range(0, len(cells), self.batch_tiles):
+            grp = cells[k:k + self.batch_tiles]
+            chops = [img[..., i * sp:(i + 1) * sp, j * sp:(j + 1) * sp] for i, j in grp]
+            if use_graph and len(grp) < self.batch_tiles:      # keep ONE graph shape: pad the last group with repeats
+                chops = chops + [chops[-1]] * (self.batch_tiles - len(grp))
+            o = self.fwd(torch.cat(chops, 0).contiguous())
+            if out is None:
+                out = torch.zeros((1, o.shape[1], rows * sp * s, cols * sp * s), dtype=torch.float32, device=o.device)
+            for n, (i, j) in enumerate(grp):
+                out[..., i * sp * s:(i + 1) * sp * s, j * sp * s:(j + 1) * sp * s] = o[n:n + 1]
+        H, W = out.shape[-2:]
+        return out[:, :, 0:H - mph * s, 0:W - mpw * s]
