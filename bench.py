@@ -10,7 +10,15 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 Prints ONE JSON line on rank 0 with the metric, ``roofline`` (dominant scan kernel: algorithmic
 bytes / HIP-event kernel time, measured inside the timed region by the library's own events) and
 ``cpu_baseline`` (the same training step on the host cores with the CPU oracle as the scan, N = 1
-only, one batch-1 step).  Synthetic data, random-init weights (no network on the box).
+only, one batch-1 step; plus BASELINE.json configs[0] -- ONE OSS block on (2,48,48,48), forward and
+forward+backward, median of 3 -- as SURVEY.md section 8d defines it).  Synthetic data, random-init weights.
+
+Other workloads of BASELINE.json (not the driver's default line):
+  --global-batch 32      configs[2]: fixed global batch split over the ranks (32/16/8/4 per GPU), "scaling": "strong"
+  --config deraining     configs[3]: Mamber32 [3,5,7,9]+2, (4,3,128,128) per GPU, AdamW 3e-4 / decay 1e-4 + clip_grad_norm 0.01
+                         (Deraining/Deraining/Options/Deraining_mamber33.yml:52-103, image_restoration_model.py:144-173)
+  --config realsr-tiled  configs[4]: MambaRealSR11 [6,2,2,1]+6, fp16, 512x512 -> 2048x2048 by the RealESRGANer tile rule,
+                         one hipGraph per padded-tile shape (a "step" = one image); tiles/s in ``config``
 """
 import argparse
 import ctypes as C
@@ -32,6 +40,12 @@ sys.path.insert(0, ROOT)
 NET = dict(type="MambaSISR6", inp_channels=3, out_channels=3, dim=48, num_blocks=[15, 1, 1, 1],
            num_refinement_blocks=15, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
            LayerNorm_type="WithBias")
+NET_DERAIN = dict(type="Mamber32", inp_channels=3, out_channels=3, dim=48, num_blocks=[3, 5, 7, 9],
+                  num_refinement_blocks=2, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
+                  LayerNorm_type="WithBias", dual_pixel_task=False)
+NET_REALSR = dict(type="MambaRealSR11", inp_channels=3, out_channels=3, scale=4, dim=48, num_blocks=[6, 2, 2, 1],
+                  num_refinement_blocks=6, heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False,
+                  LayerNorm_type="WithBias")
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 _T0 = time.time()
 
@@ -70,6 +84,88 @@ def make_step(net, ema_params, opt, autocast_dtype, device_type):
     return step
 
 
+def make_eager(model, net, ema, derain, acdt):
+    """the same step op by op (``--graph 0`` and the roofline leg): Adam + EMA (SR) or AdamW + clip 0.01 (Deraining)"""
+    if not derain:
+        opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
+        return make_step(model, ema, opt, acdt, "cuda")
+    opt = torch.optim.AdamW(net.parameters(), lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-4, fused=True)
+
+    def step(lq, gt):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=acdt, enabled=acdt is not None):
+            out = model(lq)
+        loss = F.l1_loss(out.float(), gt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 0.01)
+        opt.step()
+        return loss
+
+    return step
+
+
+def bench_realsr_tiled(args):
+    """BASELINE.json configs[4]: RealSR inference 512x512 -> 2048x2048, tiled (RealESRGANer rule: tile 128 + halo 16, pre-pad
+    10), fp16, one hipGraph per padded-tile shape.  One "step" = one image.  Single GPU."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    dev = torch.device("cuda", 0)
+    from vmambair_amd import _capi
+    from vmambair_amd.archs import build_network
+    from vmambair_amd.infer import RealSREnhancer
+    lib = _capi.load()
+    torch.manual_seed(0)
+    net = build_network(NET_REALSR).to(dev)
+    img = torch.rand(1, 3, 512, 512, device=dev)
+    res = {}
+    for name, graph in (("eager", False), ("graph", True)):
+        drv = RealSREnhancer(net, 4, tile=128, tile_pad=16, pre_pad=10, half=True, use_graph=graph)
+        out = drv.enhance_tensor(img)   # capture / warm-up
+        for _ in range(max(0, args.warmup - 1)):
+            drv.enhance_tensor(img)
+        torch.cuda.synchronize()
+        n0 = drv.tiled.tiles_run
+        if graph:
+            lib.oss_prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = drv.enhance_tensor(img)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        tiles = (drv.tiled.tiles_run - n0) // args.steps
+        res[name] = {"s_per_image": round(dt, 4), "images_per_s": round(1.0 / dt, 3), "tiles_per_s": round(tiles / dt, 2),
+                     "tiles_per_image": tiles, "graphs": drv.tiled.n_graphs}
+        assert tuple(out.shape) == (1, 3, 2048, 2048) and torch.isfinite(out.float()).all()
+    # roofline of the dominant scan kernel: the same tiles once more, eager, with the library's events on
+    drv = RealSREnhancer(net, 4, tile=128, tile_pad=16, pre_pad=10, half=True, use_graph=False)
+    lib.oss_prof_reset()
+    lib.oss_prof_enable(1)
+    drv.enhance_tensor(img)
+    torch.cuda.synchronize()
+    lib.oss_prof_enable(0)
+    recs = collect_prof(lib)
+    roof = None
+    if recs:
+        dom = max(recs, key=lambda r: r["total_ms"])
+        ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "traffic": None, "kernel": f"{dom['kernel']} variant {dom['variant']} io {dom['io']}",
+                "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches": dom["launches"],
+                "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
+                "scan_ms_per_image": round(sum(r["total_ms"] for r in recs), 3),
+                "measured": "HIP events around every scan launch of one eager pass over the same tiles"}
+    g = res["graph"]
+    print(json.dumps({
+        "metric": "images/sec, x4 real-world SR inference 512x512 -> 2048x2048, tiled, fp16", "value": g["images_per_s"],
+        "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(g["s_per_image"] * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[4]: MambaRealSR11 [6,2,2,1]+6 dim48, fp16 autocast (scan arithmetic f32), "
+                               "no_grad, 512x512 LQ, RealESRGANer rule tile 128 + halo 16, pre_pad 10",
+                   "tiles_per_image": g["tiles_per_image"], "tiles_per_s": g["tiles_per_s"], "hipgraphs": g["graphs"],
+                   "eager": res["eager"], "graph": g},
+        "roofline": roof, "cpu_baseline": None}), flush=True)
+
+
 def collect_prof(lib):
     """all non-empty profiler buckets -> list of dicts"""
     recs = []
@@ -83,6 +179,39 @@ def collect_prof(lib):
                     recs.append(dict(kernel="oss_scan_fwd_kernel" if which == 0 else "oss_scan_bwd_kernel",
                                      variant=variant, io=name, launches=n.value, total_ms=ms.value, alg_bytes=by.value))
     return recs
+
+
+def cpu_config1(cores):
+    """BASELINE.json configs[0] / SURVEY.md 8d "Config 1": ``MamberBlock(dim=48)`` (x2 SR, 48x48 LQ, d_state 16, ONE OSS block),
+    ``torch.manual_seed(0); x = randn(2,48,48,48)``, fp32, forward and forward+backward, median of 3, on the host cores.
+    The reference's literal data flow (four flattenings, per-direction scans) with the sequential CPU scan = oracle/."""
+    import statistics
+    from vmambair_amd.oss_block import MamberBlock
+    torch.manual_seed(0)
+    blk = MamberBlock(48, variant="srgan")
+    for m in blk.modules():
+        if hasattr(m, "omni"):
+            m.omni = False
+    x = torch.randn(2, 48, 48, 48)
+    with torch.no_grad():
+        blk(x)                                   # untimed first call
+    fwd, both = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            blk(x)
+        fwd.append(time.perf_counter() - t0)
+    for _ in range(3):
+        xi = x.clone().requires_grad_()
+        blk.zero_grad()
+        t0 = time.perf_counter()
+        blk(xi).square().mean().backward()
+        both.append(time.perf_counter() - t0)
+    return {"workload": "BASELINE.json configs[0]: MamberBlock(48) on (2,48,48,48), fp32, d_state 16", "cores": cores,
+            "fwd_s": round(statistics.median(fwd), 4), "fwd_bwd_s": round(statistics.median(both), 4),
+            "images_per_s_fwd_bwd": round(2.0 / statistics.median(both), 3), "median_of": 3,
+            "reference_anchor_s": {"fwd": 2.3, "bwd": 46.4, "where": "reference MamberBlock through selective_scan_ref, 8 vCPU build "
+                                                                      "container (BASELINE.md section 3); unpublished"}}
 
 
 def cpu_baseline(seed=0):
@@ -114,7 +243,8 @@ def cpu_baseline(seed=0):
         dt = time.perf_counter() - t0
         if dt >= 10.0 or n >= 8:
             break
-    return {"value": round(n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+    cfg1 = cpu_config1(cores)
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port", "config1_block": cfg1,
             "sample": f"{n} training steps (fwd+bwd+Adam+EMA) after one untimed, batch 1, 64x64 LQ, fp32, whole MambaSISR6 net; "
                       "scan = oracle/oss_scan_oracle.c (OpenMP), rest = torch CPU", "seconds": round(dt, 2)}
 
@@ -124,7 +254,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 8 (sr) / 4 (deraining)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed GLOBAL batch split over the ranks (BASELINE.json configs[2]: 32 -> 32/16/8/4 per GPU); scaling = strong")
+    ap.add_argument("--config", choices=["sr", "deraining", "realsr-tiled"], default="sr")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro-streams", type=int, default=int(os.environ.get("VMAMBAIR_MICRO_STREAMS", "1")),
@@ -139,6 +272,8 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
         return
+    if args.config == "realsr-tiled":
+        return bench_realsr_tiled(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,12 +293,24 @@ def main():
     lib = _capi.load()
 
     torch.manual_seed(0)
-    net = build_network(NET).to(dev)
+    derain = args.config == "deraining"
+    net = build_network(NET_DERAIN if derain else NET).to(dev)
     acdt = torch.bfloat16 if args.dtype == "bf16" else None
-    B = args.batch_per_gpu
+    B = args.batch_per_gpu or (4 if derain else 8)
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not split over {world} ranks")
+        B, scaling = args.global_batch // world, "strong"
     g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank shard of the synthetic batch
-    lq = torch.rand(B, 3, 64, 64, device=dev, generator=g)
-    gt = torch.rand(B, 3, 256, 256, device=dev, generator=g)
+    if derain:
+        lq = torch.rand(B, 3, 128, 128, device=dev, generator=g)
+        gt = torch.rand(B, 3, 128, 128, device=dev, generator=g)
+    else:
+        lq = torch.rand(B, 3, 64, 64, device=dev, generator=g)
+        gt = torch.rand(B, 3, 256, 256, device=dev, generator=g)
+    opt_kw = dict(lr=3e-4, betas=(0.9, 0.999), ema_decay=0.0, weight_decay=1e-4, clip_grad_norm=0.01) if derain else \
+        dict(lr=2e-4, betas=(0.9, 0.99), ema_decay=0.999)
 
     def fence():
         torch.cuda.synchronize()
@@ -177,8 +324,7 @@ def main():
         if world > 1:  # same initial weights on every rank (DDP's constructor broadcast)
             for p_ in net.parameters():
                 dist.broadcast(p_.data, 0)
-        step = GraphedTrainStep(net, lr=2e-4, betas=(0.9, 0.99), ema_decay=0.999, autocast_dtype=acdt,
-                                micro_streams=args.micro_streams)
+        step = GraphedTrainStep(net, autocast_dtype=acdt, micro_streams=args.micro_streams, **opt_kw)
         log("capturing the training step")
         step.capture(lq, gt)
         log("captured")
@@ -188,8 +334,7 @@ def main():
         if world > 1:
             model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=50,
                                                               gradient_as_bucket_view=True)
-        opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
-        step = make_step(model, ema, opt, acdt, "cuda")
+        step = make_eager(model, net, ema, derain, acdt)
 
     log(f"model on {dev}, warmup {args.warmup} steps")
     for i in range(args.warmup):
@@ -197,6 +342,8 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
 
+    if args.graph and world > 1:
+        step.time_allreduce()
     lib.oss_prof_reset()
     lib.oss_prof_enable(0 if args.graph else 1)
     fence()
@@ -208,6 +355,7 @@ def main():
     lib.oss_prof_enable(0)
     log(f"timed {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.item())
+    allreduce_ms = step.collect_allreduce_ms() if (args.graph and world > 1) else None
     prof_note = "HIP events around every scan kernel launch inside the timed region"
     if args.graph and args.skip_roofline:
         prof_steps = 1
@@ -217,8 +365,7 @@ def main():
         ema2 = [p.detach().clone() for p in net.parameters()]
         for p_ in net.parameters():
             p_.grad = None
-        opt2 = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.99), fused=True)
-        eager = make_step(net, ema2, opt2, acdt, "cuda")
+        eager = make_eager(net, net, ema2, derain, acdt)
         eager(lq, gt)
         torch.cuda.synchronize()
         lib.oss_prof_reset()
@@ -248,13 +395,14 @@ def main():
             traffic, traffic_note = None, "no PMC record for this kernel build"
             valu_busy = None
             try:  # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
-                rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+                prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+                pmc = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof_dir, f)))
+                rec = json.load(open(os.path.join(prof_dir, pmc)))
                 if kkey in rec:
                     traffic = int(rec[kkey]["fetch_bytes"] + rec[kkey]["write_bytes"])
                     valu_busy = rec[kkey].get("valu_busy")
-                    traffic_note = ("FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch of this kernel at u:(8,384,4096), "
-                                    "profiles/r01_pmc_scan_traffic.txt; the excess over alg_bytes is the per-row-tile dB/dC "
-                                    "partials (written here, re-read by the finishing kernel) and B/C re-read per row tile")
+                    traffic_note = rec[kkey].get("note", "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch of this kernel at "
+                                                 "u:(8,384,4096), separate rocprofv3 --pmc passes") + f" [profiles/{pmc}]"
             except (OSError, ValueError, KeyError):
                 pass
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -302,15 +450,26 @@ def main():
 
         images = world * B * args.steps
         line = {
-            "metric": "images/sec, x4 SR 64->256 training step (fwd+bwd+Adam+EMA), full VmambaIR UNet",
+            "metric": ("images/sec, deraining 128x128 training step (fwd+bwd+clip+AdamW), Mamber32 [3,5,7,9]+2" if derain else
+                       "images/sec, x4 SR 64->256 training step (fwd+bwd+Adam+EMA), full VmambaIR UNet"),
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: x4 SR 64x64 LQ, MambaSISR6 dim48 [15,1,1,1]+15, "
-                                   f"{args.dtype} autocast (scan arithmetic f32), batch {B} per GPU",
-                       "global_batch": world * B, "per_gpu_batch": B, "lq": [64, 64], "gt": [256, 256],
-                       "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if args.graph else "eager", "optimizer": "Adam 2e-4 (0.9,0.99) + EMA 0.999", "loss": "L1"},
+            "config": {"workload": (f"BASELINE.json configs[3]: Deraining 128x128 patches, Mamber32 dim48 [3,5,7,9]+2, {args.dtype} "
+                                    f"autocast (scan arithmetic f32), batch {B} per GPU" if derain else
+                                    (f"BASELINE.json configs[2]: x4 SR 64x64 LQ, global batch {args.global_batch} over {world} GPU(s), "
+                                     if args.global_batch else "BASELINE.json configs[1]: x4 SR 64x64 LQ, ") +
+                                    f"MambaSISR6 dim48 [15,1,1,1]+15, {args.dtype} autocast (scan arithmetic f32), batch {B} per GPU"),
+                       "global_batch": world * B, "per_gpu_batch": B, "lq": list(lq.shape[-2:]), "gt": list(gt.shape[-2:]),
+                       "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if args.graph else "eager",
+                       "optimizer": ("AdamW 3e-4 (0.9,0.999) decay 1e-4 + clip_grad_norm 0.01, no EMA" if derain else
+                                     "Adam 2e-4 (0.9,0.99) + EMA 0.999"), "loss": "L1",
+                       # multi-GPU exchange: ONE flat fp32 all-reduce between the forward+backward graph and the optimizer graph
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
+                       "allreduce_overlapped": False,
+                       "allreduce_bytes": 4 * sum(p.numel() for p in net.parameters()) if world > 1 else 0},
             "final_loss": round(loss_val, 5), "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -281,6 +281,13 @@ typedef struct {
 } oss_adam_chunk;
 int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
                       float ema_decay, oss_stream_t stream);
+/* The Deraining tree's step (Deraining/basicsr/models/image_restoration_model.py:121-167): torch.optim.AdamW (decoupled
+ * decay: param *= 1 - lr * weight_decay before the Adam update) after clip_grad_norm_(params, 0.01).  grad_scale (device
+ * memory, one float, or NULL) multiplies every gradient inside the launch: the caller computes
+ * min(1, max_norm / (total_norm + 1e-6)) on the device, so nothing is read back and the step stays graph-capturable.
+ * ema_decay as above (entries with ema == NULL skip it: the Deraining YAML sets no EMA). */
+int oss_adamw_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float ema_decay, const float *grad_scale, oss_stream_t stream);
 
 /* Cross-merge of the four spatial directions (MambaSISR6_arch.py:427-430) on the omni scan's
  * un-flipped outputs: out (batch, 4, D, H*W) io dtype contiguous (directions 0/2 row-major, 1/3

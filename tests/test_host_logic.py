@@ -229,3 +229,25 @@ def test_deferred_gradient_adoption_contract():
             assert ops.orphaned_deferred_outputs([w]) == want_orphans
         finally:
             ops._DEFER_KEEP = ops._DEFER_OUTS = None
+
+
+@pytest.mark.parametrize("name,dim,variant", [("g3_block_srgan_mamber_d96.npz", 96, "srgan"),
+                                              ("g3_block_mamber32_d192.npz", 192, "mamber32"),
+                                              ("g3_block_realsr_fp16_d48.npz", 48, "realsr"),
+                                              ("g3_block_srgan_mamber_cfg1.npz", 48, "srgan")])
+def test_compact_block_fixtures_match_host_mirrors(name, dim, variant, oracle_cpu_kernel):
+    """round-2 fixtures (production widths, BASELINE config 1, fp16-exact RealSR block; float16 storage, strided y / dx /
+    gradients) through the host mirrors + CPU oracle twins: pins the twins the GPU tests of test_configs_gpu.py use"""
+    z = load_golden(name)
+    m = MamberBlock(dim, variant=variant)
+    m.load_state_dict({k[3:]: v.float() for k, v in z.items() if k.startswith("sd.")}, strict=True)
+    x = z["x"].float().requires_grad_()
+    y = m(x)
+    y.backward(z["dy"].float())
+    s, gs = int(z["io_stride"]), int(z["grad_stride"])
+    assert_close(y[..., ::s, ::s], z["y"], 1e-3, 1e-3 * max(1.0, float(z["y"].abs().max())), "y")
+    assert_close(x.grad[..., ::s, ::s], z["dx"], 3e-3, 3e-3 * max(1.0, float(z["dx"].abs().max())), "dx")
+    for k, p in m.named_parameters():
+        if k.endswith("conv_cout.bias"):
+            continue
+        assert_close(p.grad.reshape(-1)[::gs], z["grad." + k], 5e-3, 1e-3 * max(1.0, float(z["gradmax." + k])), k)

@@ -1,0 +1,168 @@
+"""The captured training step beyond the headline config (round 2): the Deraining step (AdamW + clip_grad_norm_ 0.01, no EMA:
+Deraining/basicsr/models/image_restoration_model.py:121-167), one graph per input shape for the progressive patch schedule
+(Deraining/basicsr/train.py:213-271), and the two-rank RCCL exchange (self-skips with fewer than two GPUs)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_net(seed=0, dim=8):
+    from vmambair_amd.archs import Mamber32
+    torch.manual_seed(seed)
+    return Mamber32(dim=dim, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+
+
+def eager_deraining_step(net, opt, lq, gt):
+    opt.zero_grad(set_to_none=True)
+    loss = F.l1_loss(net(lq), gt)
+    loss.backward()
+    norm = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.01)
+    opt.step()
+    return float(loss), float(norm)
+
+
+def test_adamw_clip_step_matches_torch():
+    """fused launch with weight decay + device-side clip coefficient vs torch.optim.AdamW after clip_grad_norm_"""
+    from vmambair_amd.optim import FusedAdamEMA
+    torch.manual_seed(0)
+    shapes = [(5,), (3, 7), (2049,), (48, 96, 1, 1), (1,), (4096,)]
+    pa = [torch.randn(s, device=DEV) for s in shapes]
+    pb = [p.clone().requires_grad_() for p in pa]
+    opt = torch.optim.AdamW(pb, lr=3e-2, betas=(0.9, 0.999), weight_decay=1e-2)
+    fo = FusedAdamEMA(pa, None, lr=3e-2, betas=(0.9, 0.999), ema_decay=0.0, weight_decay=1e-2, clip_grad_norm=0.5)
+    for step in range(4):
+        grads = [torch.randn(s, device=DEV) * (0.02 if step == 2 else 1.0) for s in shapes]   # step 2: below the clip norm
+        for p, q, g in zip(pa, pb, grads):
+            p.grad, q.grad = g.clone(), g.clone()
+        want_norm = float(torch.nn.utils.clip_grad_norm_(pb, 0.5))
+        fo.step()
+        opt.step()
+        assert float(fo.total_norm) == pytest.approx(want_norm, rel=1e-5)
+        assert float(fo.grad_scale) == pytest.approx(min(1.0, 0.5 / (want_norm + 1e-6)), rel=1e-5)
+    for p, q in zip(pa, pb):
+        assert torch.allclose(p, q.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_graphed_deraining_step_matches_eager():
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(3)
+    lq, gt = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 32, 32, device=DEV)
+    net_g, net_e = make_net(), make_net()
+    step = GraphedTrainStep(net_g, lr=3e-4, betas=(0.9, 0.999), ema_decay=0.0, autocast_dtype=None, warmup=1,
+                            loss_fn=F.l1_loss, weight_decay=1e-4, clip_grad_norm=0.01)
+    assert step.ema is None
+    opt = torch.optim.AdamW(net_e.parameters(), lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    for i in range(3):
+        lg = float(step(lq, gt))
+        le, norm = eager_deraining_step(net_e, opt, lq, gt)
+        assert lg == pytest.approx(le, rel=2e-3), i
+        assert float(step.fopt.total_norm) == pytest.approx(norm, rel=5e-3)
+    assert norm > 0.01, "the clip must be active for the test to mean anything"
+    for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
+        assert float((p - q).abs().max()) <= 2 * 3e-4 * 3 + 1e-5, k
+
+
+def test_one_graph_per_shape_progressive_schedule():
+    """patch size and batch change during Deraining training: the step keeps one forward+backward graph per shape and ONE
+    optimizer graph; alternating shapes gives the same trajectory as the eager loop"""
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(4)
+    batches = [(torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 32, 32, device=DEV)),
+               (torch.rand(1, 3, 48, 40, device=DEV), torch.rand(1, 3, 48, 40, device=DEV))]
+    net_g, net_e = make_net(1), make_net(1)
+    step = GraphedTrainStep(net_g, lr=3e-4, betas=(0.9, 0.999), ema_decay=0.0, autocast_dtype=None, warmup=1,
+                            weight_decay=1e-4, clip_grad_norm=0.01, multi_shape=True)
+    opt = torch.optim.AdamW(net_e.parameters(), lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    order = [0, 1, 0, 0, 1, 1, 0]
+    for i in order:
+        lg = float(step(*batches[i]))
+        le, _ = eager_deraining_step(net_e, opt, *batches[i])
+        assert lg == pytest.approx(le, rel=3e-3), i
+    assert step.n_graphs == 2 and step.graph_opt is not None
+    for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
+        assert float((p - q).abs().max()) <= 2 * 3e-4 * len(order) + 1e-5, k
+    # without multi_shape a second shape is an error, not a silent eager fallback
+    single = GraphedTrainStep(make_net(2), autocast_dtype=None, warmup=1)
+    single(*batches[0])
+    with pytest.raises(RuntimeError):
+        single(*batches[1])
+
+
+def test_warmup_leaves_no_trace():
+    """capture() warms up with real steps and restores parameters, EMA, moments and the step count"""
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    before = [p.detach().clone() for p in net.parameters()]
+    step = GraphedTrainStep(net, autocast_dtype=None, warmup=3)
+    step.capture(torch.rand(2, 3, 16, 16, device=DEV), torch.rand(2, 3, 64, 64, device=DEV))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
+    assert all(torch.equal(a, e) for a, e in zip(before, step.ema))
+    assert float(step.fopt.state[0]) == 0.0 and all(float(m.abs().max()) == 0.0 for m in step.fopt.exp_avg)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# two ranks over RCCL: the flat-buffer exchange between the two graphs
+# ---------------------------------------------------------------------------------------------------------------------
+def _nccl_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(dev)
+    g = torch.Generator().manual_seed(9)
+    lq_all, gt_all = torch.rand(4, 3, 16, 16, generator=g), torch.rand(4, 3, 64, 64, generator=g)
+    sl = slice(rank * 2, rank * 2 + 2)
+    step = GraphedTrainStep(net, autocast_dtype=None, warmup=1)
+    assert step.split and step.world == 2
+    step.time_allreduce()
+    for _ in range(2):
+        loss = step(lq_all[sl].to(dev), gt_all[sl].to(dev))
+    torch.cuda.synchronize()
+    ms = step.collect_allreduce_ms()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = bool(torch.equal(gathered[0], gathered[1]))
+    if rank == 0:
+        torch.save({"params": [p.detach().cpu() for p in net.parameters()], "same": same, "ms": ms, "lq": lq_all, "gt": gt_all},
+                   os.path.join(tmp, "r0.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rccl_step_equals_single_process_whole_batch():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's 8-GPU node); the exchange itself is covered by tests/test_ddp_gloo.py")
+    import tempfile
+    import torch.multiprocessing as mp
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    port = 29500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_nccl_worker, args=(2, port, tmp), nprocs=2, join=True)
+        blob = torch.load(os.path.join(tmp, "r0.pt"))
+    assert blob["same"], "both ranks must hold identical weights after the step"
+    assert blob["ms"] is not None and blob["ms"] > 0
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    step = GraphedTrainStep(net, autocast_dtype=None, warmup=1, split_graphs=True)
+    for _ in range(2):
+        step(blob["lq"].to(DEV), blob["gt"].to(DEV))     # whole batch of 4: mean loss = mean of the two rank means
+    for p, q in zip(net.parameters(), blob["params"]):
+        assert float((p.detach().cpu() - q).abs().max()) <= 2 * 2e-4 * 2 + 1e-5

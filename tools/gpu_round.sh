@@ -18,6 +18,10 @@ for leg in $LEGS; do
     benchmfma) VMAMBAIR_CONV1X1=mfma timeout ${BENCH_TIMEOUT:-700} python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_mfma.txt 2>gpurun_out/bench_mfma.err; echo "rc=$?"; tail -1 gpurun_out/bench_mfma.txt | cut -c1-260;;
     sweep)  timeout 600 python tools/scan_sweep.py ${SWEEP_ARGS:---quick} > gpurun_out/sweep.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/sweep.txt;;
     bench)  timeout ${BENCH_TIMEOUT:-700} python bench.py ${BENCH_ARGS:---steps 5 --warmup 2} > gpurun_out/bench.txt 2>gpurun_out/bench.err; echo "rc=$?"; tail -2 gpurun_out/bench.txt; tail -12 gpurun_out/bench.err;;
+    newtests) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_train_graph_gpu.py tests/test_checkpoint_psnr.py tests/test_infer.py -m gpu -q -s -p no:cacheprovider > gpurun_out/newtests.txt 2>&1; echo "rc=$?"; tail -5 gpurun_out/newtests.txt; grep -E "^\[(16bit|net)\]|^(FAILED|ERROR)" gpurun_out/newtests.txt | head -40;;
+    bench32) timeout 400 python bench.py --steps 10 --warmup 3 --global-batch 32 --no-cpu-baseline > gpurun_out/bench_gb32.txt 2>gpurun_out/bench_gb32.err; echo "rc=$?"; tail -1 gpurun_out/bench_gb32.txt | cut -c1-300;;
+    derain) timeout 600 python bench.py --steps 10 --warmup 3 --config deraining --no-cpu-baseline > gpurun_out/bench_derain.txt 2>gpurun_out/bench_derain.err; echo "rc=$?"; tail -1 gpurun_out/bench_derain.txt | cut -c1-300; tail -3 gpurun_out/bench_derain.err;;
+    realsr) timeout 600 python bench.py --steps 3 --warmup 1 --config realsr-tiled > gpurun_out/bench_realsr.txt 2>gpurun_out/bench_realsr.err; echo "rc=$?"; tail -1 gpurun_out/bench_realsr.txt | cut -c1-400; tail -3 gpurun_out/bench_realsr.err;;
     prof)   ( cd /tmp && export VMAMBAIR_CONV1X1=${PROF_CONV1X1:-vendor} && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --skip-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err" ); echo "rc=$?"; python tools/prof_summary.py gpurun_out/prof/bench_results.db gpurun_out/prof_summary.txt ${PROF_WINDOW_MS:-150}; rm -rf gpurun_out/prof; tail -1 gpurun_out/prof_bench.txt | cut -c1-200;;
   esac
 done

@@ -1,26 +1,54 @@
-"""In-tree build of the C-ABI library: hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+"""In-tree build of the C-ABI library: hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
+
+Every ``csrc/*.hip`` translation unit is compiled to an object file (in parallel; only those older than their source or
+than ANY header under ``csrc/`` / ``include/``) and linked into ``vmambair_amd/lib/libvmambair_oss.so``."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libvmambair_oss.so")
-SOURCES = ["oss_capi.hip", "oss_scan_fwd.hip", "oss_scan_bwd.hip", "oss_dwconv.hip", "oss_layernorm.hip", "oss_merge.hip", "oss_conv1x1.hip",
-           "oss_proj.hip", "oss_channel.hip", "oss_ffn.hip", "oss_optim.hip"]
-HEADERS = ["oss_device.h", "oss_host.h", "oss_mfma.h", os.path.join("..", "..", "include", "vmambair_oss.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+
+
+def _newest_header() -> float:
+    return max([os.path.getmtime(h) for h in headers()] + [os.path.getmtime(os.path.abspath(__file__))])
+
+
+def _stale_objects(force: bool = False):
+    th = _newest_header()
+    out = []
+    for s in sources():
+        o = _obj(s)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), th):
+            out.append(s)
+    return out
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in sources() + headers())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -30,14 +58,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libvmambair_oss.so")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    todo = _stale_objects(force)
+
+    def compile_one(src):
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", _obj(src) + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        os.replace(_obj(src) + ".tmp", _obj(src))
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", *[_obj(s) for s in sources()], "-o", LIB_PATH + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

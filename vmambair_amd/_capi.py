@@ -71,7 +71,7 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bw
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
-           "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
+           "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
            "oss_flush_finishes", "oss_hbm_copy", "oss_version"]
 
 _lib = None
@@ -167,6 +167,8 @@ def load():
     lib.oss_gelu_gate_bwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p]
     lib.oss_adam_ema_step.restype = C.c_int
     lib.oss_adam_ema_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p]
+    lib.oss_adamw_ema_step.restype = C.c_int
+    lib.oss_adamw_ema_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]
     lib.oss_set_defer_finish.restype = None
     lib.oss_set_defer_finish.argtypes = [C.c_int]
     lib.oss_deferred_chunks.restype = C.c_size_t

@@ -378,6 +378,14 @@ int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, 
     return adam_ema_step(chunks, n_chunks, state, lr, beta1, beta2, eps, ema_decay, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_adamw_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float ema_decay, const float *grad_scale, oss_stream_t stream) {
+    if (!chunks || !state) return OSS_ERR_NULL;
+    if (n_chunks <= 0 || weight_decay < 0.f) return OSS_ERR_SHAPE;
+    return adam_ema_step(chunks, n_chunks, state, lr, beta1, beta2, eps, ema_decay, reinterpret_cast<hipStream_t>(stream),
+                         weight_decay, grad_scale);
+}
+
 int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
     if (!out || !y) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;

@@ -65,6 +65,6 @@ bool defer_finish();
 void defer_sum(const float *src, int K, size_t stride, size_t V, float *dst0, size_t n0, float *dst1);
 int sum_partials_multi(const oss_sum_chunk *chunks, int n_chunks, hipStream_t s);
 int adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
-                  float ema_decay, hipStream_t s);
+                  float ema_decay, hipStream_t s, float weight_decay = 0.f, const float *grad_scale = nullptr);
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes);
 }  // namespace oss

@@ -5,7 +5,8 @@
 // table (one entry per <= 2048 elements of one tensor: pointers to param / grad / exp_avg / exp_avg_sq / ema)
 // built once by the host drives a single elementwise kernel; the step counter and the two bias corrections live
 // in device memory so that the launch can be replayed inside a hipGraph.  Same arithmetic as torch.optim.Adam
-// (no amsgrad, no weight decay, eps outside the sqrt of the bias-corrected second moment).
+// (no amsgrad, eps outside the sqrt of the bias-corrected second moment); optional decoupled weight decay = torch.optim.AdamW
+// and a gradient scale read from device memory = clip_grad_norm_ (the Deraining step: image_restoration_model.py:121-167).
 #include "oss_device.h"
 #include "oss_host.h"
 
@@ -21,9 +22,12 @@ __global__ void oss_adam_tick_kernel(float *state, float beta1, float beta2) {
 
 __global__ void __launch_bounds__(256)
 oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__restrict__ state, float lr, float beta1,
-                    float beta2, float eps, float ema_decay) {
+                    float beta2, float eps, float ema_decay, float decay_keep, const float *__restrict__ grad_scale) {
     const oss_adam_chunk c = chunks[blockIdx.x];
     const float step_size = lr / state[1], inv_bc2_sqrt = rsqrtf(state[2]);
+    // gs: gradient-clipping coefficient (clip_grad_norm_: grads *= min(1, max_norm / (total_norm + 1e-6))) read from
+    // device memory so that the launch can sit in a hipGraph; decay_keep = 1 - lr * weight_decay (AdamW, decoupled)
+    const float gs = grad_scale ? *grad_scale : 1.f;
     float *p = reinterpret_cast<float *>(c.param), *m = reinterpret_cast<float *>(c.exp_avg);
     float *v = reinterpret_cast<float *>(c.exp_avg_sq), *e = reinterpret_cast<float *>(c.ema);
     const float *g = reinterpret_cast<const float *>(c.grad);
@@ -40,6 +44,8 @@ oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__re
         if (e) load_items<4>(e + i, valid, vk, ev);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            gv[k] *= gs;
+            pv[k] *= decay_keep;                                              // torch.optim.AdamW: param.mul_(1 - lr * wd) first
             mv[k] = __builtin_fmaf(beta1, mv[k], (1.f - beta1) * gv[k]);      // exp_avg.lerp_(grad, 1 - beta1)
             vv[k] = __builtin_fmaf(beta2, vv[k], (1.f - beta2) * gv[k] * gv[k]);
             const float denom = sqrtf(vv[k]) * inv_bc2_sqrt + eps;
@@ -88,9 +94,10 @@ int sum_partials_multi(const oss_sum_chunk *chunks, int n_chunks, hipStream_t s)
 }
 
 int adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
-                  float ema_decay, hipStream_t s) {
+                  float ema_decay, hipStream_t s, float weight_decay, const float *grad_scale) {
     hipLaunchKernelGGL(oss_adam_tick_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2);
-    hipLaunchKernelGGL(oss_adam_ema_kernel, dim3(n_chunks), dim3(256), 0, s, chunks, state, lr, beta1, beta2, eps, ema_decay);
+    hipLaunchKernelGGL(oss_adam_ema_kernel, dim3(n_chunks), dim3(256), 0, s, chunks, state, lr, beta1, beta2, eps, ema_decay,
+                       1.f - lr * weight_decay, grad_scale);
     return (int)hipGetLastError();
 }
 

@@ -100,6 +100,7 @@ class FinishTable:
         nbytes = max(1, self.capacity) * _capi.SUM_CHUNK_BYTES
         self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.copied: Optional[torch.cuda.Event] = None   # the last eager host-to-device copy out of ``host``
 
 
 def pending_finish_chunks() -> int:
@@ -108,9 +109,17 @@ def pending_finish_chunks() -> int:
 
 def flush_finishes(table: FinishTable) -> None:
     lib = _capi.load()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if table.copied is not None and not capturing:
+        # oss_flush_finishes rewrites the pinned table and queues an asynchronous copy out of it: in eager mode the copy
+        # of the previous flush must have executed first (inside a capture the call runs once, at capture time)
+        table.copied.synchronize()
     with torch.cuda.device(table.dev.device):
         _capi.check(lib.oss_flush_finishes(table.host.data_ptr(), table.dev.data_ptr(), table.capacity,
                                            torch.cuda.current_stream().cuda_stream), "oss_flush_finishes")
+        if not capturing:
+            table.copied = torch.cuda.Event()
+            table.copied.record()
     if _DEFER_KEEP is not None:
         _DEFER_KEEP.clear()
         _DEFER_OUTS.clear()

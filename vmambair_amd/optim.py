@@ -17,13 +17,18 @@ from . import _capi
 
 class FusedAdamEMA:
     def __init__(self, params: Sequence[torch.Tensor], ema: Optional[Sequence[torch.Tensor]] = None, lr: float = 2e-4,
-                 betas=(0.9, 0.99), eps: float = 1e-8, ema_decay: float = 0.999):
+                 betas=(0.9, 0.99), eps: float = 1e-8, ema_decay: float = 0.999, weight_decay: float = 0.0,
+                 clip_grad_norm: Optional[float] = None):
+        """``weight_decay`` > 0: torch.optim.AdamW (decoupled); ``clip_grad_norm``: ``clip_grad_norm_(params, value)``
+        in front of the update -- the Deraining step (image_restoration_model.py:121-167; Options/Deraining_mamber33.yml:
+        AdamW 3e-4, decay 1e-4, betas (0.9, 0.999), use_grad_clip)."""
         self.params: List[torch.Tensor] = list(params)
         assert self.params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.params), \
             "FusedAdamEMA: contiguous fp32 GPU parameters only"
         self.ema = list(ema) if ema is not None else None
         assert self.ema is None or len(self.ema) == len(self.params)
         self.lr, self.betas, self.eps, self.ema_decay = lr, betas, eps, ema_decay
+        self.weight_decay, self.clip = float(weight_decay), clip_grad_norm
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         dev = self.params[0].device
@@ -35,6 +40,9 @@ class FusedAdamEMA:
         # captured host-to-device memcpy node re-reads it on every replay
         self._host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self._table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._copied: Optional[torch.cuda.Event] = None   # the last eager host-to-device copy of the table
+        self.grad_scale = torch.ones(1, dtype=torch.float32, device=dev)   # clip coefficient of the current step
+        self.total_norm = torch.zeros(1, dtype=torch.float32, device=dev)  # gradient norm before clipping (logging)
 
     def _build(self):
         rows = []
@@ -49,8 +57,17 @@ class FusedAdamEMA:
                              self.exp_avg_sq[i].data_ptr() + b, e + b if e else 0, n, 0))
         assert len(rows) == self._n
         arr = (_capi.AdamChunk * len(rows))(*[_capi.AdamChunk(*r) for r in rows])
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._copied is not None and not capturing:
+            # eager steps rebuild the table whenever autograd hands out new gradient tensors: the previous asynchronous
+            # copy out of the pinned buffer must have executed before the buffer is overwritten (a GPU running a step
+            # behind the host would otherwise read the NEXT step's pointers)
+            self._copied.synchronize()
         C.memmove(self._host.data_ptr(), C.addressof(arr), C.sizeof(arr))
         self._table.copy_(self._host, non_blocking=True)   # inside a stream capture this becomes a memcpy node of the graph
+        if not capturing:
+            self._copied = torch.cuda.Event()
+            self._copied.record()
 
     @torch.no_grad()
     def step(self) -> None:
@@ -59,7 +76,16 @@ class FusedAdamEMA:
             self._build()
             self._sig = sig
         lib = _capi.load()
+        scale = None
+        if self.clip is not None:
+            # clip_grad_norm_ (torch/nn/utils/clip_grad.py): total 2-norm of all gradients, coefficient clamped at 1 -- on
+            # the device, no read-back; the multiplication itself happens inside the optimizer launch
+            norms = torch._foreach_norm([p.grad for p in self.params])
+            total = torch.linalg.vector_norm(torch.stack(norms))
+            self.total_norm.copy_(total.reshape(1))
+            self.grad_scale.copy_((self.clip / (total + 1e-6)).clamp(max=1.0).reshape(1))
+            scale = self.grad_scale.data_ptr()
         with torch.cuda.device(self.params[0].device):
-            _capi.check(lib.oss_adam_ema_step(self._table.data_ptr(), self._n, self.state.data_ptr(), self.lr, self.betas[0],
-                                              self.betas[1], self.eps, self.ema_decay, torch.cuda.current_stream().cuda_stream),
-                        "oss_adam_ema_step")
+            _capi.check(lib.oss_adamw_ema_step(self._table.data_ptr(), self._n, self.state.data_ptr(), self.lr, self.betas[0],
+                                               self.betas[1], self.eps, self.weight_decay, self.ema_decay, scale,
+                                               torch.cuda.current_stream().cuda_stream), "oss_adamw_ema_step")

@@ -42,7 +42,13 @@ class GraphedTrainStep:
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16,
                  loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
                  fused_optimizer: bool = True, split_graphs: bool = False, overlap_wgrads: bool = False,
-                 defer_finishes: bool = True, micro_streams: int = 1):
+                 defer_finishes: bool = True, micro_streams: int = 1, weight_decay: float = 0.0,
+                 clip_grad_norm: Optional[float] = None, multi_shape: bool = False):
+        """``weight_decay`` / ``clip_grad_norm`` / ``ema_decay=0``: the Deraining step (AdamW + clip_grad_norm_(0.01), no
+        EMA: Deraining/basicsr/models/image_restoration_model.py:121-167).  ``multi_shape``: keep one forward+backward
+        graph per (lq, gt) shape -- the progressive patch schedule of that tree changes the patch size and the batch
+        six times (Deraining/basicsr/train.py:213-271) -- all sharing ONE optimizer graph (implies ``split_graphs``: the
+        gradients then always sit in the same flat buffer, so the optimizer's pointer table never changes)."""
         self.net = net
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.device = self.params[0].device
@@ -50,7 +56,8 @@ class GraphedTrainStep:
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         # two graphs (forward+backward | optimizer) with the gradient all-reduce between them: always for world > 1;
         # ``split_graphs`` forces the same structure on one GPU (tests)
-        self.split = self.world > 1 or split_graphs
+        self.multi_shape = multi_shape
+        self.split = self.world > 1 or split_graphs or multi_shape
         # split mode: the first graph ends by packing every gradient into ONE persistent fp32 buffer (a multi-tensor copy,
         # captured) and re-points ``p.grad`` at views of it, so that the only work between the two graphs is a single
         # all-reduce of that buffer -- no per-step host loop over the ~1450 gradient tensors, no unpack
@@ -81,15 +88,19 @@ class GraphedTrainStep:
         self._shadows = [s for _, s in self.shadow.values()]
         self._master_grads = [torch.zeros_like(m) for m in self._masters]
         self._shadow_map = {n: s for n, (_, s) in self.shadow.items()}
-        self.ema = [p.detach().clone() for p in self.params]
+        self.ema = [p.detach().clone() for p in self.params] if ema_decay > 0 else None
         # Adam + EMA: one HIP launch over a chunk table (vmambair_amd/optim.py) or torch's fused multi-tensor Adam + foreach EMA
         self.fopt = None
         self.opt = None
         if fused_optimizer and all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params):
             from .optim import FusedAdamEMA
-            self.fopt = FusedAdamEMA(self.params, self.ema, lr=lr, betas=betas, ema_decay=ema_decay)
+            self.fopt = FusedAdamEMA(self.params, self.ema, lr=lr, betas=betas, ema_decay=ema_decay,
+                                     weight_decay=weight_decay, clip_grad_norm=clip_grad_norm)
         else:
-            self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, fused=True, capturable=True)
+            assert clip_grad_norm is None, "gradient clipping is implemented in the fused optimizer launch only"
+            cls = torch.optim.AdamW if weight_decay > 0 else torch.optim.Adam
+            kw = dict(weight_decay=weight_decay) if weight_decay > 0 else {}
+            self.opt = cls(self.params, lr=lr, betas=betas, fused=True, capturable=True, **kw)
         # opt-in: weight gradients (needed only by the optimizer) on a second stream next to the input-gradient chain.
         # Measured SLOWER inside the hipGraph on this stack (138.5 vs 141.5 images/s: the cross-stream edges cost more
         # than the overlap of these 5-20 us kernels buys), hence off by default
@@ -117,6 +128,10 @@ class GraphedTrainStep:
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
+        # shape-keyed cache: (lq shape, gt shape) -> the per-shape part of the state above
+        self._shapes = {}
+        self._active = None
+        self.allreduce_ms = None   # set by time_allreduce(): events around the flat all-reduce (bench.py)
 
     # ---- pieces ------------------------------------------------------------------------------
     def _backward(self, loss, leaves, slot: int = 0):
@@ -227,18 +242,72 @@ class GraphedTrainStep:
             self.fopt.step()
             return
         self.opt.step()
-        with torch.no_grad():  # model_ema(decay) of the reference
-            torch._foreach_mul_(self.ema, self.ema_decay)
-            torch._foreach_add_(self.ema, [p.detach() for p in self.params], alpha=1.0 - self.ema_decay)
+        if self.ema is not None:
+            with torch.no_grad():  # model_ema(decay) of the reference
+                torch._foreach_mul_(self.ema, self.ema_decay)
+                torch._foreach_add_(self.ema, [p.detach() for p in self.params], alpha=1.0 - self.ema_decay)
 
     def _allreduce(self):
         if self.world > 1:   # gradients already sit in the flat buffer (see _pack_grads): one collective, mean over ranks
             self._flat.allreduce_mean()
 
     # ---- capture -----------------------------------------------------------------------------
+    def _snapshot(self):
+        """everything a training step changes: parameters, EMA, optimizer moments and step count"""
+        st = [p.detach().clone() for p in self.params]
+        if self.ema is not None:
+            st += [e.clone() for e in self.ema]
+        if self.fopt is not None:
+            st += [t.clone() for t in self.fopt.exp_avg + self.fopt.exp_avg_sq + [self.fopt.state]]
+        return st, None
+
+    def _restore(self, snap):
+        st, osd = snap
+        live = [p.detach() for p in self.params] + (list(self.ema) if self.ema is not None else [])
+        if self.fopt is not None:
+            live += self.fopt.exp_avg + self.fopt.exp_avg_sq + [self.fopt.state]
+        with torch.no_grad():
+            torch._foreach_copy_(live, st)
+        if self.opt is not None:   # torch optimizer: its state tensors were created by the warm-up; put them back to "no step yet"
+            with torch.no_grad():
+                for stt in self.opt.state.values():
+                    for v in stt.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+
+    def _key(self, lq, gt):
+        return (tuple(lq.shape), tuple(gt.shape))
+
+    def _stash(self):
+        if self._active is not None:
+            self._shapes[self._active] = (self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables)
+
+    def _activate(self, key):
+        if key == self._active:
+            return
+        self._stash()
+        self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables = self._shapes[key]
+        self._active = key
+
+    @property
+    def n_graphs(self) -> int:
+        return len(self._shapes) + (1 if self._active is not None and self._active not in self._shapes else 0)
+
     def capture(self, lq: torch.Tensor, gt: torch.Tensor) -> None:
+        """Capture the step for this (lq, gt) shape.  The eager warm-up steps (lazy initialisation, vendor solver search,
+        LDS attributes, table sizing) run real updates, so parameters, EMA and optimizer state are put back afterwards:
+        the first replay is the first update, as one ``optimize_parameters`` call per batch does in the reference."""
+        key = self._key(lq, gt)
+        if self._active is not None and key != self._active:
+            if not self.multi_shape:
+                raise RuntimeError("GraphedTrainStep was captured for another input shape; construct it with multi_shape=True "
+                                   "to keep one graph per shape (progressive patch schedule)")
+            self._stash()
+            self.graph_fb, self.ftables = None, [None] * self.nmicro
+        self._active = key
         self.static_lq = lq.clone()
         self.static_gt = gt.clone()
+        snap = self._snapshot()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up outside capture: lazy inits, MIOpen find, LDS attributes
@@ -246,26 +315,53 @@ class GraphedTrainStep:
                 self._fwd_bwd()
                 self._allreduce()
                 self._opt_ema()
+                torch.cuda.synchronize()   # the pointer tables of step k must not be rewritten while step k - 1 runs
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._restore(snap)
         torch.cuda.synchronize()
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb):
             self.static_loss = self._fwd_bwd()
             if not self.split:
                 self._opt_ema()
-        if self.split:
+        if self.split and self.graph_opt is None:   # one optimizer graph for every shape: it reads the flat gradient views
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt):
                 self._opt_ema()
+        self._stash()
+
+    def time_allreduce(self, on: bool = True) -> None:
+        """bench.py: bracket the flat all-reduce of every following step with events (``allreduce_ms`` = list of ms)"""
+        self.allreduce_ms = [] if on else None
+        self._ar_events = []
 
     # ---- replay ------------------------------------------------------------------------------
     def __call__(self, lq: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
-        if self.graph_fb is None:
+        key = self._key(lq, gt)
+        if key not in self._shapes:
             self.capture(lq, gt)
+        self._activate(key)
         self.static_lq.copy_(lq, non_blocking=True)
         self.static_gt.copy_(gt, non_blocking=True)
         self.graph_fb.replay()
         if self.split:
-            self._allreduce()
+            if self.allreduce_ms is not None and self.world > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._allreduce()
+                e1.record()
+                self._ar_events.append((e0, e1))
+            else:
+                self._allreduce()
             self.graph_opt.replay()
         return self.static_loss
+
+    def collect_allreduce_ms(self):
+        """-> mean milliseconds of the timed all-reduces (synchronises), or None"""
+        if not getattr(self, "_ar_events", None):
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._ar_events]
+        self._ar_events = []
+        return sum(ms) / len(ms)
