@@ -13,6 +13,9 @@ All fixtures hold fp16-exact weights / inputs (stored as float16) so that 16-bit
 16-bit tolerances (stated, measured margins in profiles/r02_*): against the fp32 reference, relative L2 error
   bf16 autocast: y <= 1.5e-2, dx <= 4e-2, parameter gradients <= 8e-2        (bf16 eps = 3.9e-3, ~20 rounded ops deep)
   fp16 autocast: y <= 2e-3,  dx <= 6e-3, parameter gradients <= 1.5e-2      (fp16 eps = 4.9e-4)
+A parameter gradient's error is taken relative to max(its own norm, 5 % of the largest gradient norm in the block): the
+channel branch's gradients are sums of large cancelling terms with norms 100-1000x below the conv weights', and the
+rounding noise of the activations they are formed from does not shrink with them.
 """
 import pytest
 import torch
@@ -82,11 +85,12 @@ def test_block_16bit_autocast_within_stated_tolerance(tag, dt, record_property):
     ly, ldx, lg = LIMITS[dt]
     ey, edx = rel_l2(y, z["y"]), rel_l2(dx, z["dx"])
     worst, wk = 0.0, ""
+    floor = 0.05 * max(float(z["grad." + k].norm()) for k in grads)
     for k, g in grads.items():
         ref = z["grad." + k]
-        if k.endswith("conv_cout.bias") or float(ref.norm()) < 1e-6:
+        if k.endswith("conv_cout.bias"):
             continue
-        e = rel_l2(g, ref)
+        e = float((g.detach().float().cpu() - ref).norm()) / max(float(ref.norm()), floor)
         if e > worst:
             worst, wk = e, k
     print(f"[16bit] {tag} {dt}: rel-L2 y {ey:.2e} dx {edx:.2e} worst parameter gradient {worst:.2e} ({wk})")

@@ -179,12 +179,13 @@ def test_realsr_enhancer_fp16_on_gpu_matches_cpu_twin():
     install_oracle_cpu_kernel()
     torch.manual_seed(3)
     net = MambaRealSR11(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
-    img = np.random.RandomState(0).rand(70, 52, 3).astype(np.float32)
+    # 54x38 + pre-pad 10 = 64x48: every padded window (40 / 24 wide) is a multiple of 8, which the 3-level UNet needs
+    img = np.random.RandomState(0).rand(54, 38, 3).astype(np.float32)
     want = RealSREnhancer(net, 4, tile=32, tile_pad=8, pre_pad=10, half=False, use_graph=False).enhance_tensor(img)
     net_g = MambaRealSR11(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
     net_g.load_state_dict(net.state_dict())
     net_g.to("cuda:0")
     drv = RealSREnhancer(net_g, 4, tile=32, tile_pad=8, pre_pad=10, half=True, use_graph=True)
     got = drv.enhance_tensor(img)
-    assert got.shape == (1, 3, 280, 208) and drv.tiled.n_graphs <= 9
+    assert got.shape == (1, 3, 216, 152) and drv.tiled.n_graphs <= 9
     assert_close(got, want, 3e-2, 3e-2, "tiled fp16 output")
