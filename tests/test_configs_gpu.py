@@ -11,8 +11,9 @@
 All fixtures hold fp16-exact weights / inputs (stored as float16) so that 16-bit runs start from the same numbers.
 
 16-bit tolerances (stated, measured margins in profiles/r02_*): against the fp32 reference, relative L2 error
-  bf16 autocast: y <= 1.5e-2, dx <= 4e-2, parameter gradients <= 8e-2        (bf16 eps = 3.9e-3, ~20 rounded ops deep)
-  fp16 autocast: y <= 2e-3,  dx <= 6e-3, parameter gradients <= 1.5e-2      (fp16 eps = 4.9e-4)
+  bf16 autocast: y <= 5e-3, dx <= 8e-3, parameter gradients <= 5e-2     (bf16 eps = 3.9e-3; measured 2.0e-3 / 2.9e-3 / 2.3e-2)
+  fp16 autocast: y <= 1e-3, dx <= 1e-3, parameter gradients <= 5e-3     (fp16 eps = 4.9e-4; measured 2.1e-4 / 2.9e-4 / 1.2e-3)
+  (worst case over the fixtures, profiles/r02_16bit_parity_margins.txt)
 A parameter gradient's error is taken relative to max(its own norm, 5 % of the largest gradient norm in the block): the
 channel branch's gradients are sums of large cancelling terms with norms 100-1000x below the conv weights', and the
 rounding noise of the activations they are formed from does not shrink with them.
@@ -73,7 +74,7 @@ def test_block_fp32_matches_reference(tag):
         assert_close(g, z["grad." + k], 5e-3, 1e-3 * max(1.0, float(z["gradmax." + k])), f"grad {k}")
 
 
-LIMITS = {torch.bfloat16: (1.5e-2, 4e-2, 8e-2), torch.float16: (2e-3, 6e-3, 1.5e-2)}
+LIMITS = {torch.bfloat16: (5e-3, 8e-3, 5e-2), torch.float16: (1e-3, 1e-3, 5e-3)}
 
 
 @pytest.mark.parametrize("tag,dt", [("d96", torch.bfloat16), ("d384", torch.bfloat16), ("m32_d192", torch.bfloat16),
@@ -172,10 +173,9 @@ def test_mamber32_block_at_128x128_matches_cpu_twin():
 # ------------------------------------------------------------------------------------------------------------------
 def test_whole_net_dim48_fp32_vs_cpu_twin_and_bf16_vs_fp32():
     """MambaSISR6 dim 48 [2,1,1,1]+2 (all four widths 48..384 and the x4 tail), batch 2, 64x64 LQ, L1 loss step:
-    (a) HIP fp32 vs CPU oracle twins: output 2e-3 of max|y|, every parameter gradient rel-L2 <= 2e-2;
-    (b) bf16 autocast (what bench.py times) vs HIP fp32: output rel-L2 <= 2e-2, loss within 1e-2 relative, gradient
-        of the whole parameter vector rel-L2 <= 0.12 and cosine >= 0.99 (stated; the r1 test only asked rel < 0.1 on dx
-        of one block)."""
+    (a) HIP fp32 vs CPU oracle twins: output 2e-3 of max|y|, every parameter gradient rel-L2 <= 2e-3 (measured 1e-4);
+    (b) bf16 autocast (what bench.py times) vs HIP fp32: output rel-L2 <= 1.5e-2 (measured 5.9e-3), loss within 5e-3
+        relative (2.5e-3), gradient of the whole parameter vector rel-L2 <= 4e-2 (1.1e-2) and cosine >= 0.999."""
     from conftest import install_oracle_cpu_kernel
     from vmambair_amd.archs import MambaSISR6
     import torch.nn.functional as F
@@ -200,11 +200,11 @@ def test_whole_net_dim48_fp32_vs_cpu_twin_and_bf16_vs_fp32():
     bad = [(k, rel_l2(g_f[k], g_c[k])) for k in g_c if not k.endswith("conv_cout.bias") and float(g_c[k].norm()) > 1e-7]
     worst = max(bad, key=lambda t: t[1])
     print(f"[net] fp32 HIP vs CPU twins: worst parameter-gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
-    assert worst[1] <= 2e-2, worst
+    assert worst[1] <= 2e-3, worst
     y_b, l_b, g_b = step(net, lq.to(DEV), gt.to(DEV), torch.bfloat16)
     ey = rel_l2(y_b, y_f)
     keys = [k for k in g_f if not k.endswith("conv_cout.bias")]
     vf, vb = torch.cat([g_f[k].reshape(-1) for k in keys]), torch.cat([g_b[k].reshape(-1) for k in keys])
     eg, cos = rel_l2(vb, vf), float(F.cosine_similarity(vb, vf, dim=0))
     print(f"[net] bf16 vs fp32: output rel-L2 {ey:.2e}, loss {l_b:.6f} vs {l_f:.6f}, gradient rel-L2 {eg:.2e}, cosine {cos:.5f}")
-    assert ey <= 2e-2 and abs(l_b - l_f) <= 1e-2 * abs(l_f) and eg <= 0.12 and cos >= 0.99, (ey, l_b, l_f, eg, cos)
+    assert ey <= 1.5e-2 and abs(l_b - l_f) <= 5e-3 * abs(l_f) and eg <= 4e-2 and cos >= 0.999, (ey, l_b, l_f, eg, cos)
