@@ -172,7 +172,7 @@ def collect_prof(lib):
     """all non-empty profiler buckets -> list of dicts"""
     recs = []
     for which in (0, 1):
-        for variant in range(12):
+        for variant in range(16):
             for io, name in ((0, "f32"), (1, "f16"), (2, "bf16")):
                 ms, n, by = C.c_double(), C.c_longlong(), C.c_double()
                 if lib.oss_prof_collect(which, variant, io, C.byref(ms), C.byref(n), C.byref(by)) != 0:

@@ -153,14 +153,32 @@ def test_every_forward_variant(fv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, fwd_variant=fv)
 
 
-@pytest.mark.parametrize("bv", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("bv", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_every_backward_variant(bv, itype):
     check_fwd_bwd(make_inputs(2, 32, 16, 2, 1100, itype), True, itype, bwd_variant=bv)
 
 
+@pytest.mark.parametrize("bv", [10, 11, 12, 13])
+@pytest.mark.parametrize("case", ["ragged_rows", "short", "odd_len_f16", "no_softplus_no_D", "wide_state"])
+def test_round2_backward_kernel_cases(bv, case):
+    """oss_scan_bwd_v2.h (lane-resident state scalars, register-prefetched tiles, one barrier per state): row tiles that do
+    not divide the group, sequences below one chunk, lengths that are not a multiple of 4 (scalar partial stores), the
+    optional inputs absent, and dstate > 64 (falls back to the round-1 kernel of the same row count)"""
+    if case == "ragged_rows":
+        check_fwd_bwd(make_inputs(2, 2 * 13, 16, 2, 700, torch.float32), True, torch.float32, bwd_variant=bv)
+    elif case == "short":
+        check_fwd_bwd(make_inputs(3, 16, 16, 4, 37, torch.float32), True, torch.float32, bwd_variant=bv)
+    elif case == "odd_len_f16":
+        check_fwd_bwd(make_inputs(1, 24, 16, 2, 1539, torch.float16), True, torch.float16, bwd_variant=bv)
+    elif case == "no_softplus_no_D":
+        check_fwd_bwd(make_inputs(2, 16, 16, 2, 530, torch.float32, has_D=False, has_bias=False), False, torch.float32, bwd_variant=bv)
+    else:
+        check_fwd_bwd(make_inputs(1, 8, 72, 2, 300, torch.float32), True, torch.float32, bwd_variant=bv)
+
+
 @pytest.mark.parametrize("dstate", [1, 5, 16, 19])
-@pytest.mark.parametrize("bv", [2, 8, 9])
+@pytest.mark.parametrize("bv", [2, 8, 9, 10, 13])
 def test_backward_two_states_at_a_time_with_odd_state_counts(dstate, bv):
     """variants 2, 8, 9 walk the states in pairs (8, 9: packed fp32 with a zero padding state); an odd count leaves a
     single state at the end of a tile, 19 > one staging tile of variant 9 and > two of variant 8"""
@@ -336,7 +354,7 @@ def test_full_size_properties(itype):
 @pytest.mark.parametrize("seqlen", [64, 100, 513, 1024, 2085])
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("rows", [8, 48])
-@pytest.mark.parametrize("bv", [-1, 8, 9], ids=["auto", "pair12", "pair8"])
+@pytest.mark.parametrize("bv", [-1, 8, 9, 10, 11], ids=["auto", "pair12", "pair8", "v2_12", "v2_8"])
 def test_omni_scan_matches_materialised_directions(seqlen, itype, rows, bv):
     if bv >= 0 and seqlen not in (100, 2085):
         pytest.skip("forced backward variants: shortest ragged and longest lengths only")

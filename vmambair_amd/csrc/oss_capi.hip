@@ -75,7 +75,7 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
 }
 
 // ---- per-launch event timing (oss_prof_*) -----------------------------------------------------
-constexpr int kProfVariants = 12;
+constexpr int kProfVariants = 16;
 struct ProfBucket {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0.0, bytes = 0.0;

@@ -367,6 +367,7 @@ oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*
 
 }  // namespace oss
 #include "oss_scan_bwd_pair.h"
+#include "oss_scan_bwd_v2.h"
 namespace oss {
 
 // workspace carving shared by the launchers; -> OSS_OK or OSS_ERR_WORKSPACE
@@ -452,6 +453,23 @@ static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, Lau
     return launch_finish<T>(p, ws, wdD, wdb, stream);
 }
 
+// round-2 kernel (oss_scan_bwd_v2.h): lane-resident per-state scalars, register-prefetched tiles, one barrier per state
+template <typename T, int WAVES, int NBB, int MINW>
+static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
+    constexpr int TC = 512;
+    const oss_scan_fwd_params &f = p.f;
+    BwdWs ws;
+    float *wdD, *wdb;
+    int rc = carve_ws(p, WAVES, ws, wdD, wdb);
+    if (rc != OSS_OK) return rc;
+    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC);
+    static size_t smem_enabled = 48 * 1024;
+    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW>, smem, smem_enabled,
+                     (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
+    if (rc != OSS_OK) return rc;
+    return launch_finish<T>(p, ws, wdD, wdb, stream);
+}
+
 // variant table: (lanes per row, items per lane = waves per workgroup, states per LDS tile)
 //   0: 64 x 8 x 8,  8 states  (TC 512, 8 rows/WG, 64 KiB LDS)
 //   1: 64 x 4 x 4, 16 states  (TC 256, 4 rows/WG, 40 KiB LDS)  short sequences / few rows per group
@@ -461,11 +479,16 @@ static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, Lau
 //   5: 64 x 8 x 6  (6 rows/WG, no spills): 48-row groups at batch 8 = exactly 256 workgroups
 //   8: two states per pass in packed fp32, 12 rows/WG (130 KiB LDS, 3 waves per SIMD)     oss_scan_bwd_pair.h
 //   9: likewise, 8 rows/WG, all 16 states staged at once (<= 256 VGPRs)
-static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8, 12, 8};
-int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 9) ? 1 : variant]; }
+//  10: round-2 kernel, 12 rows/WG (128 KiB LDS)   11: 8 rows/WG   12: 6 rows/WG   13: 4 rows/WG (two workgroups per CU)
+static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8, 12, 8, 12, 8, 6, 4};
+int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 13) ? 1 : variant]; }
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
+    if (variant >= 10 && p.f.dstate > 64) {   // the round-2 kernel keeps one lane per state: same-row-count round-1 kernel
+        static const int same_rows[] = {6, 3, 5, 1};
+        variant = same_rows[variant - 10];
+    }
     switch (variant) {
         case 0: return launch_bwd<T, 64, 8, 8, 8, 1, 4>(p, stream, timer);
         case 2: return launch_bwd<T, 64, 8, 8, 8, 2, 2>(p, stream, timer);
@@ -476,6 +499,10 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
         case 7: return launch_bwd<T, 64, 8, 8, 16, 1, 2>(p, stream, timer);    // variant 3 likewise
         case 8: return launch_bwd_pair<T, 8, 12, 8, 3>(p, stream, timer);
         case 9: return launch_bwd_pair<T, 8, 8, 16, 2>(p, stream, timer);
+        case 10: return launch_bwd2<T, 12, 8, 3>(p, stream, timer);
+        case 11: return launch_bwd2<T, 8, 8, 2>(p, stream, timer);
+        case 12: return launch_bwd2<T, 6, 8, 2>(p, stream, timer);
+        case 13: return launch_bwd2<T, 4, 8, 4>(p, stream, timer);
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }

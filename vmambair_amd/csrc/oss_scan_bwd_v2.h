@@ -1,0 +1,302 @@
+// oss_scan_bwd_v2.h -- round-2 selective-scan backward: the same algorithm, row ownership, workspace and finishing
+// kernel as oss_scan_bwd_kernel (oss_scan_bwd.hip; reference cus/selective_scan_bwd_kernel.cuh:66-273), restructured
+// around what the round-1 counters and ISA showed (profiles/r01_pmc_sq_scan.txt): that kernel
+// issues ~22 vector instructions per (element, state) but a wave spends half its time parked -- every state iteration
+// exposed five LDS round trips (three wave-uniform scalars read back from LDS, B/C tiles read right before use), one
+// global load (the saved forward state) and two workgroup barriers, with only 3 waves per SIMD to cover them.
+//
+//   * wave-uniform per-state scalars live in LANES of four registers (lane n = state n: A*log2e, the forward state
+//     entering the chunk, the reverse carry dh, the dA accumulator) and are fetched with v_readlane_b32 (an SGPR
+//     broadcast, no memory access); the saved forward states of a chunk are ONE global load per chunk (lane n loads
+//     state n);
+//   * B/C tiles of state n+1 are fetched from LDS into a second register set while state n computes (two sets
+//     alternate, so no copies), and stay in registers for all passes of a state (4 b128 reads per state instead of 8);
+//   * the cross-row dB/dC slabs are double-buffered: ONE barrier per state instead of two; the slab sum uses 16-byte
+//     reads, four waves per state, rotating over the workgroup so that the work is even across SIMDs;
+//   * u and softplus'(delta) are not held across the state loop (they are re-read / recomputed once per chunk), which
+//     pays for the second tile set in registers.
+// Needs dstate <= 64 (one lane per state); larger dstate takes the round-1 kernel.
+// Included by oss_scan_bwd.hip only (needs BwdWs).
+#pragma once
+#include "oss_device.h"
+
+namespace oss {
+
+__device__ __forceinline__ float lane_get(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// lane `lane` of vec := a wave-uniform value (a compare + select: v_writelane_b32 needs the value in an SGPR and the
+// lane select in M0 on this ISA family, and is not exposed as a builtin by this compiler)
+__device__ __forceinline__ float lane_set(float vec, int my_lane, int lane, float uniform_val) {
+    return (my_lane == lane) ? uniform_val : vec;
+}
+
+template <int I>
+__device__ __forceinline__ void read_tile(const float *t, float (&v)[I]) {
+#pragma unroll
+    for (int k = 0; k < I / 4; ++k) {
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(t + k * 256);   // tile_off<64, I>: quads of a lane are 64*4 floats apart
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+    }
+}
+
+template <typename T, int WAVES, int NBB, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW)
+oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
+    constexpr int LPR = 64, I = 8;
+    constexpr int ROWS = WAVES;
+    constexpr int TC = LPR * I;
+    constexpr int NT = WAVES * 64;
+    constexpr int RW = WAVES < 4 ? WAVES : 4;   // waves summing one state's slabs
+    static_assert(TC % kScanChunk == 0 && NBB % 2 == 0, "");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sB = smem;                    // [NBB][TC]  tile_off layout
+    float *sC = sB + NBB * TC;           // [NBB][TC]
+    float *slab = sC + NBB * TC;         // [2][ROWS][2][TC]  per-row dB / dC terms of one state, time order; two buffers
+
+    const oss_scan_fwd_params &f = p.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = lane;
+    const int wrow = wave;
+    const bool seg_first = (pos == 0), seg_last = (pos == LPR - 1);
+
+    const int L = f.seqlen, N = f.dstate, G = f.n_groups;
+    const int rows_per_group = f.dim / G;
+    const int tiles_per_group = ws.tiles;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
+    const int g = bid % G;
+    const int b = bid / G;
+    const int row_in_group = tile * ROWS + wrow;
+    const bool row_valid = row_in_group < rows_per_group;
+    const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
+    const bool rev = g >= f.rev_group_start;
+    const int d_u = f.u_row_mod > 0 ? d % f.u_row_mod : d;
+
+    const T *u_row = reinterpret_cast<const T *>(f.u) + b * f.u_batch_stride + d_u * f.u_d_stride;
+    const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride + d * f.delta_d_stride;
+    const int d_g = p.dout_row_mod > 0 ? d % p.dout_row_mod : d;
+    const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d_g * p.dout_d_stride;
+    T *du_row = reinterpret_cast<T *>(p.du) + b * p.du_batch_stride + d * p.du_d_stride;
+    T *dd_row = reinterpret_cast<T *>(p.ddelta) + b * p.ddelta_batch_stride + d * p.ddelta_d_stride;
+    const T *gB = reinterpret_cast<const T *>(f.B) + b * f.B_batch_stride + g * f.B_group_stride;
+    const T *gC = reinterpret_cast<const T *>(f.C) + b * f.C_batch_stride + g * f.C_group_stride;
+    const float Dd = f.D ? f.D[d] : 0.f;
+    const float bias = f.delta_bias ? f.delta_bias[d] : 0.f;
+    const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
+    const float *x_row = f.x ? f.x + ((size_t)b * f.dim + d) * n_xchunks * 2 * N : nullptr;
+    float *ws_bc = ws.bc + ((size_t)(b * G + g) * tiles_per_group + tile) * 2 * N * L;
+    const bool ws_vec = (L % 4) == 0;   // 16-byte stores of the partial rows
+
+    // lane n of these registers belongs to state n of this wave's row
+    float A2v = 0.f, dhcv = 0.f, dAv = 0.f, hcv = 0.f;
+    if (lane < N) {
+        const float av = f.A[d * f.A_d_stride + lane];
+        A2v = (f.a_log_form ? -__expf(av) : av) * kLog2e;
+    }
+    float dln_c = 0.f;  // delta of the first step of the later chunk (wave-uniform); 0 past the end
+
+    float dD_acc = 0.f, db_acc = 0.f;
+    const int n_chunks = (L + TC - 1) / TC;
+    int par = 0;  // slab buffer of the next state
+    for (int c = n_chunks - 1; c >= 0; --c) {
+        const int t0 = c * TC;
+        const int tl = t0 + pos * I;
+        const int valid = max(0, min(I, L - tl));
+        float dl[I], gg[I], w[I], Q[I], dd[I];
+        {
+            float uu[I];
+            load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+            load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+            load_items_dir<I>(g_row, tl, valid, L, rev, gg);
+            if (!row_valid) {  // a row slot past the end of the group must not contribute to dB/dC
+#pragma unroll
+                for (int i = 0; i < I; ++i) { uu[i] = 0.f; gg[i] = 0.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                float x = dl[i] + bias;
+                if (f.delta_softplus) { float e; x = softplus_thr(x, e); }
+                dl[i] = (i < valid) ? x : 0.f;
+                w[i] = dl[i] * uu[i];
+                Q[i] = 0.f;
+                dd[i] = 0.f;
+            }
+        }
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < I; ++i) S += dl[i];
+        const int xi = t0 / kScanChunk - 1;  // saved forward state entering this chunk (bwd_kernel.cuh:184)
+        hcv = (xi >= 0 && lane < N) ? x_row[(size_t)xi * 2 * N + 2 * lane + 1] : 0.f;
+        const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
+        const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
+
+        // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
+        auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I]) {
+            const float A2 = lane_get(A2v, n), hc = lane_get(hcv, n), dhc = lane_get(dhcv, n);
+            float a[I], hh[I];
+            // ---- forward recompute: local recurrence (hh holds b_t until the state pass)
+            float h = 0.f;
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                a[i] = exp2_hw(dl[i] * A2);
+                hh[i] = bt[i] * w[i];
+                h = (i == 0) ? hh[0] : __builtin_fmaf(a[i], h, hh[i]);
+            }
+            float P = exp2_hw(S * A2);
+            segment_scan<LPR>(P, h);
+            const float hfull = __builtin_fmaf(P, hc, h);
+            const float hin = shift_from_prev_lane(hfull, hc, seg_first);
+            {
+                float hp = hin;
+#pragma unroll
+                for (int i = 0; i < I; ++i) {
+                    hp = __builtin_fmaf(a[i], hp, hh[i]);
+                    hh[i] = hp;
+                }
+            }
+            // ---- reverse recurrence: element (a_{t+1}, C_t g_t)   (bwd_kernel.cuh:170-193)
+            const float a_edge = exp2_hw(dln_c * A2);
+            const float a_nl = shift_from_next_lane(a[0], a_edge, seg_last);
+            float dloc = 0.f;
+#pragma unroll
+            for (int i = I - 1; i >= 0; --i) {
+                const float an = (i == I - 1) ? a_nl : a[(i + 1) % I];
+                ct[i] *= gg[i];   // C_t g_t, used twice
+                dloc = (i == I - 1) ? ct[i] : __builtin_fmaf(an, dloc, ct[i]);
+            }
+            float Pm = segment_mirror<LPR>(exp2_hw(Sshift * A2), lane);
+            float dm = segment_mirror<LPR>(dloc, lane);
+            segment_scan<LPR>(Pm, dm);
+            const float dfull_m = __builtin_fmaf(Pm, dhc, dm);       // dh at the first step of mirrored lane
+            const float dex_m = shift_from_prev_lane(dfull_m, dhc, seg_first);
+            float dh = segment_mirror<LPR>(dex_m, lane);              // dh entering this lane from the right
+            dhcv = lane_set(dhcv, lane, n, lane_get(dfull_m, 63));          // mirrored-last lane = first lane in time
+            // ---- reverse pass with gradients (bwd_kernel.cuh:196-206); p_t = a_t h_{t-1}
+            float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;
+            float dA_acc = 0.f;
+#pragma unroll
+            for (int k = I / 4 - 1; k >= 0; --k) {
+                float vB[4], vC[4];
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    const int i = 4 * k + j;
+                    const float an = (i == I - 1) ? a_nl : a[(i + 1) % I];
+                    dh = __builtin_fmaf(an, dh, ct[i]);
+                    Q[i] = __builtin_fmaf(dh, bt[i], Q[i]);
+                    const float hprev = (i == 0) ? hin : hh[(i + I - 1) % I];
+                    const float r = dh * (a[i] * hprev);
+                    dd[i] = __builtin_fmaf(A2, r, dd[i]);
+                    dA_acc = __builtin_fmaf(dl[i], r, dA_acc);
+                    // rows past the end of the group carry u = dout = 0, so they contribute exact zeros
+                    vB[j] = dh * w[i];
+                    vC[j] = gg[i] * hh[i];
+                }
+                *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{vB[0], vB[1], vB[2], vB[3]};
+                *reinterpret_cast<f32x4 *>(sb + TC + 4 * k) = f32x4{vC[0], vC[1], vC[2], vC[3]};
+            }
+            const float dA_sum = segment_sum_to_last<LPR>(dA_acc) + lane_get(dAv, n);
+            dAv = lane_set(dAv, lane, n, lane_get(dA_sum, 63));
+        };
+        // sum the slabs of state n over the workgroup's rows (fixed order) and write the workgroup's partial
+        auto slab_sum = [&](int n, int buf) {
+            const int rw = (wave - (n * RW) % WAVES + WAVES) % WAVES;
+            if (rw >= RW) return;
+            for (int item = rw * 64 + lane; item < 2 * (TC / 4); item += RW * 64) {
+                const int arr = item / (TC / 4), q = item - arr * (TC / 4);
+                const float *src = slab + ((buf * ROWS) * 2 + arr) * TC + 4 * q;
+                f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+                for (int r = 1; r < ROWS; ++r) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * TC);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                const int t = t0 + 4 * q;  // scan position of acc.x; mirrored groups store at L-1-t
+                float *dst = ws_bc + (size_t)(arr * N + n) * L;
+                if (t + 3 < L && ws_vec) {
+                    if (!rev) *reinterpret_cast<f32x4 *>(dst + t) = acc;
+                    else *reinterpret_cast<f32x4 *>(dst + (L - 4 - t)) = f32x4{acc.w, acc.z, acc.y, acc.x};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t + j < L) dst[rev ? (L - 1 - t - j) : (t + j)] = acc[j];
+                }
+            }
+        };
+
+        for (int n0 = 0; n0 < N; n0 += NBB) {
+            const int nb = min(NBB, N - n0);
+            __syncthreads();   // the previous tile batch has been consumed (and the previous state's slab sums were read)
+            stage_bc_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * f.B_dstate_stride,
+                                          gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
+                                          f.C_dstate_stride, nb, t0, L, rev, tid);
+            __syncthreads();
+            const float *tb = sB + pos * 4, *tc = sC + pos * 4;
+            float b0[I], c0[I], b1[I], c1[I];
+            read_tile<I>(tb, b0);
+            read_tile<I>(tc, c0);
+            // every LDS read issued so far has landed before the loop starts: lgkmcnt counts in order, so without this the
+            // compiler must assume, at the top of every iteration, that the tiles of the CURRENT state may still be in
+            // flight behind the prefetch of the next one -- and waits for the prefetch (checked in the ISA)
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            for (int nn = 0; nn < nb; nn += 2) {
+                const bool has1 = nn + 1 < nb;
+                if (has1) { read_tile<I>(tb + (nn + 1) * TC, b1); read_tile<I>(tc + (nn + 1) * TC, c1); }
+                __builtin_amdgcn_sched_barrier(0);
+                state_pass(n0 + nn, b0, c0);
+                __syncthreads();                       // state n's slabs are complete; buffer par^1 is free again
+                slab_sum(n0 + nn, par);
+                par ^= 1;
+                if (has1) {
+                    if (nn + 2 < nb) { read_tile<I>(tb + (nn + 2) * TC, b0); read_tile<I>(tc + (nn + 2) * TC, c0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    state_pass(n0 + nn + 1, b1, c1);
+                    __syncthreads();
+                    slab_sum(n0 + nn + 1, par);
+                    par ^= 1;
+                }
+            }
+        }
+        // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245); u and softplus' re-derived here
+        {
+            float uu[I], raw[I], du[I], dv[I];
+            load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+            load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
+#pragma unroll
+            for (int i = 0; i < I; ++i) {
+                float s = 1.f;
+                if (f.delta_softplus) {
+                    const float r_ = raw[i] + bias;
+                    const float e = exp2_hw(r_ * kLog2e);
+                    // d softplus = sigmoid(raw) for raw <= 20, 1 above (bwd_kernel.cuh:228-241)
+                    s = (r_ <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                }
+                s = (i < valid) ? s : 0.f;
+                const float ui = row_valid ? uu[i] : 0.f;
+                du[i] = __builtin_fmaf(Q[i], dl[i], Dd * gg[i]);
+                const float ddel = __builtin_fmaf(Q[i], ui, dd[i] * kLn2);
+                dv[i] = ddel * s;
+                dD_acc = __builtin_fmaf(gg[i], ui, dD_acc);
+                db_acc += dv[i];
+            }
+            if (row_valid) {
+                store_items_dir<I>(du_row, tl, valid, L, rev, du);
+                store_items_dir<I>(dd_row, tl, valid, L, rev, dv);
+            }
+        }
+        dln_c = lane_get(dl[0], 0);
+    }
+    // ---- per-row partials over the sequence
+    const float dD_sum = segment_sum_to_last<LPR>(dD_acc);
+    const float db_sum = segment_sum_to_last<LPR>(db_acc);
+    if (row_valid) {
+        if (seg_last) {
+            if (ws.dD) ws.dD[(size_t)b * f.dim + d] = dD_sum;
+            if (ws.db) ws.db[(size_t)b * f.dim + d] = db_sum;
+        }
+        if (lane < N) ws.dA[((size_t)b * f.dim + d) * N + lane] = dAv;
+    }
+}
+
+}  // namespace oss
