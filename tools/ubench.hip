@@ -21,6 +21,38 @@ __global__ void __launch_bounds__(256) k_fma(float *out, float a, float b) {
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
 
+// plain v_fma_f32 pinned by inline asm: the C loop of k_fma above is turned into v_pk_fma_f32 by the SLP vectorizer
+// (checked in the ISA), so its "lane-instr/s" is really the packed rate -- round 1 read it as the scalar rate
+__global__ void __launch_bounds__(256) k_fma_asm(float *out, float a, float b) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                     "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+// one dependent chain per wave (what a recurrence looks like): issue-to-issue latency of v_fma_f32
+__global__ void __launch_bounds__(256) k_fma_chain(float *out, float a, float b) {
+    float x0 = threadIdx.x;
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(x0) : "v"(a), "v"(b));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0;
+}
+__global__ void __launch_bounds__(256) k_pkfma_chain(float *out, float a, float b) {
+    f32x2 A = {a, a}, B = {b, b};
+    f32x2 x0 = {(float)threadIdx.x, 1.f};
+    for (int i = 0; i < ITERS; ++i) {
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
+                     "v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
+                     : "+v"(x0) : "v"(A), "v"(B));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0.x + x0.y;
+}
+
 __global__ void __launch_bounds__(256) k_pkfma(float *out, float a, float b) {
     f32x2 A = {a, a}, B = {b, b};
     f32x2 x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f, x4 = x0 + 4.f, x5 = x0 + 5.f, x6 = x0 + 6.f, x7 = x0 + 7.f;
@@ -123,6 +155,19 @@ int main() {
     printf("v_fma_f32        : %8.2f T lane-instr/s  (%.1f TFLOP/s)\n", lanes * ITERS * 8 / ms / 1e9, lanes * ITERS * 8 * 2 / ms / 1e9);
     ms = time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); });
     printf("v_pk_fma_f32     : %8.2f T lane-instr/s  (%.1f TFLOP/s)\n", lanes * ITERS * 8 / ms / 1e9, lanes * ITERS * 8 * 4 / ms / 1e9);
+    for (int wps : {8, 3, 1}) {   // waves per SIMD: 8 (full), 3 (the scan backward's occupancy), 1
+        const int nb = prop.multiProcessorCount * wps;
+        const double ln = (double)nb * 256;
+        const double simd_cycles = 2.4e9 * prop.multiProcessorCount * 4;
+        float m1 = time_ms([&] { hipLaunchKernelGGL(k_fma_asm, dim3(nb), dim3(256), 0, 0, out, 1.0001f, 0.5f); });
+        float m2 = time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(nb), dim3(256), 0, 0, out, 1.0001f, 0.5f); });
+        float m3 = time_ms([&] { hipLaunchKernelGGL(k_fma_chain, dim3(nb), dim3(256), 0, 0, out, 1.0001f, 0.5f); });
+        float m4 = time_ms([&] { hipLaunchKernelGGL(k_pkfma_chain, dim3(nb), dim3(256), 0, 0, out, 1.0001f, 0.5f); });
+        float m5 = time_ms([&] { hipLaunchKernelGGL(k_exp, dim3(nb), dim3(256), 0, 0, out, 0.f); });
+        auto cyc = [&](float ms_) { return simd_cycles * (ms_ * 1e-3) / (ln / 64 * ITERS * 8); };   // SIMD cycles (at 2.4 GHz) per wave instruction
+        printf("%d waves/SIMD: v_fma_f32 (asm) %6.2f T lane-instr/s = %.2f cyc/instr | v_pk_fma_f32 %6.2f T = %.2f cyc | dependent chain: fma %.2f cyc, pk_fma %.2f cyc | v_exp_f32 %.2f cyc\n",
+               wps, ln * ITERS * 8 / m1 / 1e9, cyc(m1), ln * ITERS * 8 / m2 / 1e9, cyc(m2), cyc(m3), cyc(m4), cyc(m5));
+    }
     ms = time_ms([&] { hipLaunchKernelGGL(k_exp, dim3(blocks), dim3(256), 0, 0, out, 0.f); });
     printf("v_exp_f32        : %8.2f T lane-instr/s\n", lanes * ITERS * 8 / ms / 1e9);
     ms = time_ms([&] { hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); });

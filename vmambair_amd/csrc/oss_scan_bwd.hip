@@ -462,7 +462,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchT
     float *wdD, *wdb;
     int rc = carve_ws(p, WAVES, ws, wdD, wdb);
     if (rc != OSS_OK) return rc;
-    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC);
+    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC);   // two tile buffers, two slab buffers
     static size_t smem_enabled = 48 * 1024;
     rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW>, smem, smem_enabled,
                      (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
@@ -499,10 +499,10 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
         case 7: return launch_bwd<T, 64, 8, 8, 16, 1, 2>(p, stream, timer);    // variant 3 likewise
         case 8: return launch_bwd_pair<T, 8, 12, 8, 3>(p, stream, timer);
         case 9: return launch_bwd_pair<T, 8, 8, 16, 2>(p, stream, timer);
-        case 10: return launch_bwd2<T, 12, 8, 3>(p, stream, timer);
-        case 11: return launch_bwd2<T, 8, 8, 2>(p, stream, timer);
-        case 12: return launch_bwd2<T, 6, 8, 2>(p, stream, timer);
-        case 13: return launch_bwd2<T, 4, 8, 4>(p, stream, timer);
+        case 10: return launch_bwd2<T, 12, 4, 3>(p, stream, timer);
+        case 11: return launch_bwd2<T, 8, 4, 2>(p, stream, timer);
+        case 12: return launch_bwd2<T, 6, 4, 2>(p, stream, timer);
+        case 13: return launch_bwd2<T, 4, 4, 4>(p, stream, timer);
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }

@@ -14,7 +14,11 @@
 //   * the cross-row dB/dC slabs are double-buffered: ONE barrier per state instead of two; the slab sum uses 16-byte
 //     reads, four waves per state, rotating over the workgroup so that the work is even across SIMDs;
 //   * u and softplus'(delta) are not held across the state loop (they are re-read / recomputed once per chunk), which
-//     pays for the second tile set in registers.
+//     pays for the second tile set in registers;
+//   * the B/C tiles of the NEXT batch of states (or of the next chunk's first batch) are fetched from global memory into a
+//     few registers before the current batch's state loop and written to a second LDS tile buffer after it: the global
+//     latency and the two barriers of a synchronous refill (35 us of 268 at u:(8,384,4096), profiles/r02_scan_bwd_v2_
+//     experiments.txt) disappear behind the state loop.
 // Needs dstate <= 64 (one lane per state); larger dstate takes the round-1 kernel.
 // Included by oss_scan_bwd.hip only (needs BwdWs).
 #pragma once
@@ -40,6 +44,49 @@ __device__ __forceinline__ void read_tile(const float *t, float (&v)[I]) {
     }
 }
 
+// one 4-position group of a B or C row, as loaded (fp32: 4 words, 16-bit types: 2 words)
+template <typename T> struct RawQuad { uint32_t w[sizeof(T)]; };
+
+// memory elements m0 .. m0+3 of a row (zero outside [0, L)); `fast`: all four in range and the address is 8/16-byte aligned
+template <typename T>
+__device__ __forceinline__ RawQuad<T> load_quad(const T *row, int m0, int L, bool fast) {
+    RawQuad<T> r;
+    const T *p = row + m0;
+    if (fast) {
+        if constexpr (sizeof(T) == 4) {
+            const u32x4 q = *reinterpret_cast<const u32x4 *>(p);
+            r.w[0] = q.x; r.w[1] = q.y; r.w[2] = q.z; r.w[3] = q.w;
+        } else {
+            const u32x2 q = *reinterpret_cast<const u32x2 *>(p);
+            r.w[0] = q.x; r.w[1] = q.y;
+        }
+    } else {
+        uint32_t e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + j;
+            const bool ok = m >= 0 && m < L;
+            if constexpr (sizeof(T) == 4) e[j] = ok ? __float_as_uint(row[m]) : 0u;
+            else e[j] = ok ? (uint32_t)row[m].v : 0u;
+        }
+        if constexpr (sizeof(T) == 4) { r.w[0] = e[0]; r.w[1] = e[1]; r.w[2] = e[2]; r.w[3] = e[3]; }
+        else { r.w[0] = e[0] | (e[1] << 16); r.w[1] = e[2] | (e[3] << 16); }
+    }
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ f32x4 quad_to_f32(const RawQuad<T> &r, bool rev) {
+    float v[4];
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(r.w[j]);
+    } else {
+        unpack2<T>(r.w[0], v[0], v[1]);
+        unpack2<T>(r.w[1], v[2], v[3]);
+    }
+    return rev ? f32x4{v[3], v[2], v[1], v[0]} : f32x4{v[0], v[1], v[2], v[3]};
+}
+
 template <typename T, int WAVES, int NBB, int MINW>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
 oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
@@ -48,15 +95,17 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int TC = LPR * I;
     constexpr int NT = WAVES * 64;
     constexpr int RW = WAVES < 4 ? WAVES : 4;   // waves summing one state's slabs
-    static_assert(TC % kScanChunk == 0 && NBB % 2 == 0, "");
+    constexpr int Q = TC / 4;                    // 4-position groups per tile row
+    constexpr int QPT = (NBB * Q + NT - 1) / NT; // groups of one tile batch per thread
+    static_assert(TC % kScanChunk == 0 && NBB % 2 == 0 && TC == 512, "");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sB = smem;                    // [NBB][TC]  tile_off layout
-    float *sC = sB + NBB * TC;           // [NBB][TC]
-    float *slab = sC + NBB * TC;         // [2][ROWS][2][TC]  per-row dB / dC terms of one state, time order; two buffers
+    float *sT = smem;                          // [2 buffers][B | C][NBB][TC]  tile_off layout
+    float *slab = smem + 2 * 2 * NBB * TC;     // [2][ROWS][2][TC]  per-row dB / dC terms of one state, time order; two buffers
 
     const oss_scan_fwd_params &f = p.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the slab-sum rotation stays in scalar code
     const int pos = lane;
     const int wrow = wave;
     const bool seg_first = (pos == 0), seg_last = (pos == LPR - 1);
@@ -89,6 +138,43 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     float *ws_bc = ws.bc + ((size_t)(b * G + g) * tiles_per_group + tile) * 2 * N * L;
     const bool ws_vec = (L % 4) == 0;   // 16-byte stores of the partial rows
 
+    // ---- tile staging, split in two: global -> registers (issue), registers -> LDS (commit)
+    constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
+    RawQuad<T> pb[QPT], pc[QPT];
+    auto stage_issue = [&](int t0s, int n0s) {
+        const int nbs = min(NBB, N - n0s);
+        const bool fullchunk = (t0s + TC <= L);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int idx = tid + j * NT;
+            const int n = idx / Q, k = idx - n * Q;
+            if (idx < nbs * Q) {
+                const int s0 = t0s + 4 * k;                       // first scan position of the group
+                const int m0 = rev ? (L - 4 - s0) : s0;           // lowest memory index of the group
+                const T *rb = gB + (int64_t)(n0s + n) * f.B_dstate_stride;
+                const T *rc = gC + (int64_t)(n0s + n) * f.C_dstate_stride;
+                const bool fast = fullchunk &&
+                                  (((reinterpret_cast<uintptr_t>(rb + m0) | reinterpret_cast<uintptr_t>(rc + m0)) & amask) == 0);
+                pb[j] = load_quad<T>(rb, m0, L, fast);
+                pc[j] = load_quad<T>(rc, m0, L, fast);
+            }
+        }
+    };
+    auto stage_commit = [&](int buf, int n0s) {
+        const int nbs = min(NBB, N - n0s);
+        float *dB_ = sT + (size_t)buf * 2 * NBB * TC, *dC_ = dB_ + NBB * TC;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int idx = tid + j * NT;
+            const int n = idx / Q, k = idx - n * Q;
+            if (idx < nbs * Q) {
+                const int off = tile_off<LPR, I>(n, (4 * k) / I, (4 * k) % I);
+                *reinterpret_cast<f32x4 *>(dB_ + off) = quad_to_f32<T>(pb[j], rev);
+                *reinterpret_cast<f32x4 *>(dC_ + off) = quad_to_f32<T>(pc[j], rev);
+            }
+        }
+    };
+
     // lane n of these registers belongs to state n of this wave's row
     float A2v = 0.f, dhcv = 0.f, dAv = 0.f, hcv = 0.f;
     if (lane < N) {
@@ -99,12 +185,19 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 
     float dD_acc = 0.f, db_acc = 0.f;
     const int n_chunks = (L + TC - 1) / TC;
-    int par = 0;  // slab buffer of the next state
+    int par = 0;   // slab buffer of the next state
+    int tbuf = 0;  // tile buffer of the current batch
+    int rot = 0;   // first wave of the current state's slab sum (advances by RW per state, mod WAVES)
+    // tiles of the very first batch: synchronous
+    stage_issue((n_chunks - 1) * TC, 0);
+    stage_commit(0, 0);
+    __syncthreads();
     for (int c = n_chunks - 1; c >= 0; --c) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;
         const int valid = max(0, min(I, L - tl));
-        float dl[I], gg[I], w[I], Q[I], dd[I];
+        const bool chunk_full = (t0 + TC <= L);
+        float dl[I], gg[I], w[I], Q_[I], dd[I];
         {
             float uu[I];
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
@@ -120,7 +213,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 if (f.delta_softplus) { float e; x = softplus_thr(x, e); }
                 dl[i] = (i < valid) ? x : 0.f;
                 w[i] = dl[i] * uu[i];
-                Q[i] = 0.f;
+                Q_[i] = 0.f;
                 dd[i] = 0.f;
             }
         }
@@ -131,6 +224,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         hcv = (xi >= 0 && lane < N) ? x_row[(size_t)xi * 2 * N + 2 * lane + 1] : 0.f;
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
         const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
+        // lane-dependent parts of the slab-sum addresses (a reducing wave handles 4 scan positions of one array)
+        const float *sum_src = slab + 4 * lane;
+        float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * lane) : (t0 + 4 * lane));
 
         // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
         auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I]) {
@@ -172,7 +268,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             const float dfull_m = __builtin_fmaf(Pm, dhc, dm);       // dh at the first step of mirrored lane
             const float dex_m = shift_from_prev_lane(dfull_m, dhc, seg_first);
             float dh = segment_mirror<LPR>(dex_m, lane);              // dh entering this lane from the right
-            dhcv = lane_set(dhcv, lane, n, lane_get(dfull_m, 63));          // mirrored-last lane = first lane in time
+            dhcv = lane_set(dhcv, lane, n, lane_get(dfull_m, 63));    // mirrored-last lane = first lane in time
             // ---- reverse pass with gradients (bwd_kernel.cuh:196-206); p_t = a_t h_{t-1}
             float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;
             float dA_acc = 0.f;
@@ -184,7 +280,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                     const int i = 4 * k + j;
                     const float an = (i == I - 1) ? a_nl : a[(i + 1) % I];
                     dh = __builtin_fmaf(an, dh, ct[i]);
-                    Q[i] = __builtin_fmaf(dh, bt[i], Q[i]);
+                    Q_[i] = __builtin_fmaf(dh, bt[i], Q_[i]);
                     const float hprev = (i == 0) ? hin : hh[(i + I - 1) % I];
                     const float r = dh * (a[i] * hprev);
                     dd[i] = __builtin_fmaf(A2, r, dd[i]);
@@ -193,46 +289,57 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                     vB[j] = dh * w[i];
                     vC[j] = gg[i] * hh[i];
                 }
+#ifndef OSS_EXP_V2_NOSLAB   // (OSS_EXP_*: timing experiments only, tools/build_experiment.sh -- results are wrong)
                 *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{vB[0], vB[1], vB[2], vB[3]};
                 *reinterpret_cast<f32x4 *>(sb + TC + 4 * k) = f32x4{vC[0], vC[1], vC[2], vC[3]};
+#else
+                if (vB[0] + vC[3] == 12345.678f) sb[0] = vB[1] + vC[2];
+#endif
             }
             const float dA_sum = segment_sum_to_last<LPR>(dA_acc) + lane_get(dAv, n);
             dAv = lane_set(dAv, lane, n, lane_get(dA_sum, 63));
         };
-        // sum the slabs of state n over the workgroup's rows (fixed order) and write the workgroup's partial
+        // sum the slabs of state n over the workgroup's rows (fixed order) and write the workgroup's partial; four waves
+        // (rot .. rot+3, wrapping) take 128 positions of dB or dC each -- all of it but the loads / adds / store is scalar
         auto slab_sum = [&](int n, int buf) {
-            const int rw = (wave - (n * RW) % WAVES + WAVES) % WAVES;
-            if (rw >= RW) return;
-            for (int item = rw * 64 + lane; item < 2 * (TC / 4); item += RW * 64) {
-                const int arr = item / (TC / 4), q = item - arr * (TC / 4);
-                const float *src = slab + ((buf * ROWS) * 2 + arr) * TC + 4 * q;
-                f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
+#ifndef OSS_EXP_V2_NOSUM
+            int rw = wave - rot;
+            rw += (rw < 0) ? WAVES : 0;
+            if (rw < RW) {
+                for (int part = rw; part < 4; part += RW) {       // part = array * 2 + half of the chunk
+                    const float *src = sum_src + (size_t)buf * ROWS * 2 * TC + (part >> 1) * TC + (part & 1) * (TC / 2);
+                    f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
-                for (int r = 1; r < ROWS; ++r) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * TC);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                }
-                const int t = t0 + 4 * q;  // scan position of acc.x; mirrored groups store at L-1-t
-                float *dst = ws_bc + (size_t)(arr * N + n) * L;
-                if (t + 3 < L && ws_vec) {
-                    if (!rev) *reinterpret_cast<f32x4 *>(dst + t) = acc;
-                    else *reinterpret_cast<f32x4 *>(dst + (L - 4 - t)) = f32x4{acc.w, acc.z, acc.y, acc.x};
-                } else {
+                    for (int r = 1; r < ROWS; ++r) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * TC);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                    const int half = (part & 1) * (TC / 2);
+                    float *dst = sum_dst + (size_t)((part >> 1) * N + n) * L + (rev ? -half : half);
+                    if (chunk_full && ws_vec) {
+                        *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
+                    } else {
+                        const int t = t0 + half + 4 * lane;   // scan position of acc.x; mirrored groups store at L-1-t
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (t + j < L) dst[rev ? (L - 1 - t - j) : (t + j)] = acc[j];
+                        for (int j = 0; j < 4; ++j)
+                            if (t + j < L) dst[rev ? (3 - j) : j] = acc[j];
+                    }
                 }
             }
+#endif
+            rot += RW;
+            rot -= (rot >= WAVES) ? WAVES : 0;
         };
 
         for (int n0 = 0; n0 < N; n0 += NBB) {
             const int nb = min(NBB, N - n0);
-            __syncthreads();   // the previous tile batch has been consumed (and the previous state's slab sums were read)
-            stage_bc_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * f.B_dstate_stride,
-                                          gC + (int64_t)n0 * f.C_dstate_stride, f.B_dstate_stride,
-                                          f.C_dstate_stride, nb, t0, L, rev, tid);
-            __syncthreads();
-            const float *tb = sB + pos * 4, *tc = sC + pos * 4;
+            // the tiles this batch needs are in buffer tbuf (committed and fenced by the previous batch's last barrier);
+            // fetch the next batch's -- of this chunk, or the first of the next chunk -- from global memory now
+            const bool more_here = n0 + NBB < N;
+            const bool have_next = more_here || c > 0;
+            const int nt0 = more_here ? t0 : t0 - TC, nn0 = more_here ? n0 + NBB : 0;
+            if (have_next) stage_issue(nt0, nn0);
+            const float *tb = sT + (size_t)tbuf * 2 * NBB * TC + pos * 4, *tc = tb + NBB * TC;
             float b0[I], c0[I], b1[I], c1[I];
             read_tile<I>(tb, b0);
             read_tile<I>(tc, c0);
@@ -245,18 +352,26 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 if (has1) { read_tile<I>(tb + (nn + 1) * TC, b1); read_tile<I>(tc + (nn + 1) * TC, c1); }
                 __builtin_amdgcn_sched_barrier(0);
                 state_pass(n0 + nn, b0, c0);
+                if (!has1 && have_next) stage_commit(tbuf ^ 1, nn0);   // before the batch's last barrier, which then fences it
+#ifndef OSS_EXP_V2_NOBAR
                 __syncthreads();                       // state n's slabs are complete; buffer par^1 is free again
+#endif
                 slab_sum(n0 + nn, par);
                 par ^= 1;
                 if (has1) {
-                    if (nn + 2 < nb) { read_tile<I>(tb + (nn + 2) * TC, b0); read_tile<I>(tc + (nn + 2) * TC, c0); }
+                    const bool last = nn + 2 >= nb;
+                    if (!last) { read_tile<I>(tb + (nn + 2) * TC, b0); read_tile<I>(tc + (nn + 2) * TC, c0); }
                     __builtin_amdgcn_sched_barrier(0);
                     state_pass(n0 + nn + 1, b1, c1);
+                    if (last && have_next) stage_commit(tbuf ^ 1, nn0);
+#ifndef OSS_EXP_V2_NOBAR
                     __syncthreads();
+#endif
                     slab_sum(n0 + nn + 1, par);
                     par ^= 1;
                 }
             }
+            tbuf ^= 1;
         }
         // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245); u and softplus' re-derived here
         {
@@ -274,8 +389,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 }
                 s = (i < valid) ? s : 0.f;
                 const float ui = row_valid ? uu[i] : 0.f;
-                du[i] = __builtin_fmaf(Q[i], dl[i], Dd * gg[i]);
-                const float ddel = __builtin_fmaf(Q[i], ui, dd[i] * kLn2);
+                du[i] = __builtin_fmaf(Q_[i], dl[i], Dd * gg[i]);
+                const float ddel = __builtin_fmaf(Q_[i], ui, dd[i] * kLn2);
                 dv[i] = ddel * s;
                 dD_acc = __builtin_fmaf(gg[i], ui, dD_acc);
                 db_acc += dv[i];
