@@ -94,7 +94,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int ROWS = WAVES;
     constexpr int TC = LPR * I;
     constexpr int NT = WAVES * 64;
-    constexpr int RW = WAVES < 4 ? WAVES : 4;   // waves summing one state's slabs
+    constexpr int RW = WAVES < 8 ? WAVES : 8;   // waves summing one state's slabs (8 tasks: array x half chunk x quarter)
+    constexpr int HR = ROWS / 2;                 // a half wave sums the upper or the lower half of the rows
+    static_assert(ROWS % 2 == 0, "");
     constexpr int Q = TC / 4;                    // 4-position groups per tile row
     constexpr int QPT = (NBB * Q + NT - 1) / NT; // groups of one tile batch per thread
     static_assert(TC % kScanChunk == 0 && NBB % 2 == 0 && TC == 512, "");
@@ -224,9 +226,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         hcv = (xi >= 0 && lane < N) ? x_row[(size_t)xi * 2 * N + 2 * lane + 1] : 0.f;
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
         const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
-        // lane-dependent parts of the slab-sum addresses (a reducing wave handles 4 scan positions of one array)
-        const float *sum_src = slab + 4 * lane;
-        float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * lane) : (t0 + 4 * lane));
+        // lane-dependent parts of the slab-sum addresses: a half wave = 32 groups of 4 scan positions x one half of the rows
+        const float *sum_src = slab + 4 * (lane & 31) + (lane >> 5) * (HR * 2 * TC);
+        float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * (lane & 31)) : (t0 + 4 * (lane & 31)));
 
         // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
         auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I]) {
@@ -299,30 +301,41 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             const float dA_sum = segment_sum_to_last<LPR>(dA_acc) + lane_get(dAv, n);
             dAv = lane_set(dAv, lane, n, lane_get(dA_sum, 63));
         };
-        // sum the slabs of state n over the workgroup's rows (fixed order) and write the workgroup's partial; four waves
-        // (rot .. rot+3, wrapping) take 128 positions of dB or dC each -- all of it but the loads / adds / store is scalar
+        // sum the slabs of state n over the workgroup's rows (fixed order) and write the workgroup's partial.  Eight tasks
+        // (dB | dC) x (128-position quarter of the chunk), one per wave rot .. rot+7 (wrapping); inside a task the two half
+        // waves sum the lower / upper half of the rows for the same 32 position groups (16-byte reads, conflict-free) and
+        // are combined with v_permlane32_swap -- the latency of this sum sits on the critical path of every state (all
+        // waves wait for the summing ones at the next barrier), so it is spread as thin as the lanes allow.
         auto slab_sum = [&](int n, int buf) {
 #ifndef OSS_EXP_V2_NOSUM
             int rw = wave - rot;
             rw += (rw < 0) ? WAVES : 0;
             if (rw < RW) {
-                for (int part = rw; part < 4; part += RW) {       // part = array * 2 + half of the chunk
-                    const float *src = sum_src + (size_t)buf * ROWS * 2 * TC + (part >> 1) * TC + (part & 1) * (TC / 2);
+                for (int task = rw; task < 8; task += RW) {
+                    const int arr = task >> 2, off = (task & 3) * (TC / 4);
+                    const float *src = sum_src + (size_t)buf * ROWS * 2 * TC + arr * TC + off;
                     f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
-                    for (int r = 1; r < ROWS; ++r) {
+                    for (int r = 1; r < HR; ++r) {
                         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * TC);
                         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                     }
-                    const int half = (part & 1) * (TC / 2);
-                    float *dst = sum_dst + (size_t)((part >> 1) * N + n) * L + (rev ? -half : half);
-                    if (chunk_full && ws_vec) {
-                        *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
-                    } else {
-                        const int t = t0 + half + 4 * lane;   // scan position of acc.x; mirrored groups store at L-1-t
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (t + j < L) dst[rev ? (3 - j) : j] = acc[j];
+                    for (int k = 0; k < 4; ++k) {   // lower-rows sum + upper-rows sum, in every lane
+                        const int bits = __float_as_int(acc[k]);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                        acc[k] = __int_as_float(sw[0]) + __int_as_float(sw[1]);
+                    }
+                    float *dst = sum_dst + (size_t)(arr * N + n) * L + (rev ? -off : off);
+                    if (lane < 32) {
+                        if (chunk_full && ws_vec) {
+                            *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
+                        } else {
+                            const int t = t0 + off + 4 * lane;   // scan position of acc.x; mirrored groups store at L-1-t
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (t + j < L) dst[rev ? (3 - j) : j] = acc[j];
+                        }
                     }
                 }
             }
