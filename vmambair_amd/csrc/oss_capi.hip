@@ -66,11 +66,13 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     // <= one 8-row workgroup per CU: nothing is gained by leaving register room for a second one, so take the
     // build without spills (u:(8,192,4096): 0.196 ms against 0.229, profiles/r01_sweep_v4_bwd_variants.txt)
     const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
-    if (wgs <= 256) return pair ? 9 : 3;
+    const bool v2 = dstate <= 64 && !pair;   // round-2 kernel (oss_scan_bwd_v2.h): u:(8,192,4096) 0.172 ms against 0.203,
+                                             // u:(8,384,4096) 0.235 against 0.284 (profiles/r02_scan_bwd_v2_experiments.txt)
+    if (wgs <= 256) return pair ? 9 : (v2 ? 11 : 3);
     // more rows per workgroup: fewer dB / dC partial tiles and an even load (u:(8,384,4096) bf16: 0.271 ms against
     // 0.355; u:(32,384,4096): 1.07 against 1.14)
     // (variant 6 = 4 with all 16 states staged at once: 0.2655 against 0.275 ms)
-    if (rows_per_group >= 12) return pair ? 8 : (dstate <= 16 ? 6 : 4);
+    if (rows_per_group >= 12) return pair ? 8 : (v2 ? 10 : (dstate <= 16 ? 6 : 4));
     return pair ? 9 : 0;
 }
 

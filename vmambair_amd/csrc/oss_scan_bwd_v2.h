@@ -94,8 +94,12 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int ROWS = WAVES;
     constexpr int TC = LPR * I;
     constexpr int NT = WAVES * 64;
-    constexpr int RW = WAVES < 8 ? WAVES : 8;   // waves summing one state's slabs (8 tasks: array x half chunk x quarter)
-    constexpr int HR = ROWS / 2;                 // a half wave sums the upper or the lower half of the rows
+    // slab sums: 12-wave workgroups spread one state's sum over 8 waves (half waves take half of the rows each); smaller
+    // workgroups use 4 waves with whole-row sums (all 8 waves summing every state measured slower: 0.185 vs 0.172 ms)
+    constexpr bool SPLIT = WAVES > 8;
+    constexpr int NTASK = SPLIT ? 8 : 4;         // (dB | dC) x (quarters | halves) of the chunk
+    constexpr int RW = WAVES < NTASK ? WAVES : NTASK;
+    constexpr int HR = SPLIT ? ROWS / 2 : ROWS;  // rows summed by one lane
     static_assert(ROWS % 2 == 0, "");
     constexpr int Q = TC / 4;                    // 4-position groups per tile row
     constexpr int QPT = (NBB * Q + NT - 1) / NT; // groups of one tile batch per thread
@@ -227,8 +231,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
         const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
         // lane-dependent parts of the slab-sum addresses: a half wave = 32 groups of 4 scan positions x one half of the rows
-        const float *sum_src = slab + 4 * (lane & 31) + (lane >> 5) * (HR * 2 * TC);
-        float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * (lane & 31)) : (t0 + 4 * (lane & 31)));
+        const int sl = SPLIT ? (lane & 31) : lane;
+        const float *sum_src = slab + 4 * sl + (SPLIT ? (lane >> 5) * (HR * 2 * TC) : 0);
+        float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * sl) : (t0 + 4 * sl));
 
         // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
         auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I]) {
@@ -311,8 +316,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             int rw = wave - rot;
             rw += (rw < 0) ? WAVES : 0;
             if (rw < RW) {
-                for (int task = rw; task < 8; task += RW) {
-                    const int arr = task >> 2, off = (task & 3) * (TC / 4);
+                for (int task = rw; task < NTASK; task += RW) {
+                    const int arr = task / (NTASK / 2), off = (task % (NTASK / 2)) * (TC / (NTASK / 2));
                     const float *src = sum_src + (size_t)buf * ROWS * 2 * TC + arr * TC + off;
                     f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
@@ -320,18 +325,20 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * TC);
                         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                     }
+                    if constexpr (SPLIT) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {   // lower-rows sum + upper-rows sum, in every lane
-                        const int bits = __float_as_int(acc[k]);
-                        const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
-                        acc[k] = __int_as_float(sw[0]) + __int_as_float(sw[1]);
+                        for (int k = 0; k < 4; ++k) {   // lower-rows sum + upper-rows sum, in every lane
+                            const int bits = __float_as_int(acc[k]);
+                            const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                            acc[k] = __int_as_float(sw[0]) + __int_as_float(sw[1]);
+                        }
                     }
                     float *dst = sum_dst + (size_t)(arr * N + n) * L + (rev ? -off : off);
-                    if (lane < 32) {
+                    if (!SPLIT || lane < 32) {
                         if (chunk_full && ws_vec) {
                             *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
                         } else {
-                            const int t = t0 + off + 4 * lane;   // scan position of acc.x; mirrored groups store at L-1-t
+                            const int t = t0 + off + 4 * sl;   // scan position of acc.x; mirrored groups store at L-1-t
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (t + j < L) dst[rev ? (3 - j) : j] = acc[j];
