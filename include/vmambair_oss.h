@@ -79,6 +79,17 @@ typedef struct {
     const float *delta_bias;/* (dim) or NULL                                                   */
     void *out;              /* (batch, dim, seqlen) io dtype                                   */
     float *x;               /* (batch, dim, oss_scan_num_chunks(seqlen), 2*dstate) contiguous  */
+    /* Delta computed INSIDE the scan (the archs' `dts = einsum(dts, dt_projs_weight)` followed by
+     * the scan, SRGAN/VmambaIR/archs/MambaSISR6_arch.py:409-424): with dt_weight != NULL the `delta` pointer holds the
+     * rank-dt_rank factor z: (batch, n_groups, >= dt_rank rows, seqlen) io dtype -- the first rows of x_dbl -- with element
+     * strides (delta_batch_stride, dt_group_stride, dt_rank_stride), time contiguous (mirrored like B / C for groups >=
+     * rev_group_start), and the kernels evaluate
+     *     delta[b, d, t] = sum_r dt_weight[d * dt_rank + r] * z[b, group(d), r, t]        (fp32, r ascending)
+     * so the (batch, dim, seqlen) delta tensor never exists.  delta_d_stride is ignored then.  dt_rank <= 8 (every
+     * reference config where the fused form is used: D <= 128). */
+    const float *dt_weight; /* (dim, dt_rank) float contiguous, or NULL = `delta` is the (batch, dim, seqlen) tensor */
+    int dt_rank, reserved1_;
+    int64_t dt_group_stride, dt_rank_stride;
 } oss_scan_fwd_params;
 
 /* Mirrors SSMParamsBwd (selective_scan.h:68-90). */
@@ -104,6 +115,14 @@ typedef struct {
     int64_t dBC_group_stride; /* element stride between (batch, group) blocks of dB and of dC; the batch
                                  stride is n_groups times it.  0 = dstate * seqlen (contiguous).  Lets
                                  the caller have dB / dC written into the rows of a wider buffer.  */
+    /* f.dt_weight != NULL (delta computed inside the scan): ddelta is not written; instead
+     *   ddt[b, g, r, t]  = sum over the rows d of group g of dt_weight[d, r] * ddelta[b, d, t]   (io dtype; the dt rows of the
+     *                      gradient of x_dbl -- with dBC_group_stride the kernel fills ALL rows of that gradient)
+     *   ddt_weight[d, r] = sum over b, t of ddelta[b, d, t] * z[b, g, r, t]                       (float, (dim, dt_rank))
+     * Only the round-2 kernels do this: dstate <= 64, 16-bit or float I/O, dt_rank <= 8. */
+    void *ddt;
+    float *ddt_weight;
+    int64_t ddt_batch_stride, ddt_group_stride, ddt_rank_stride;
 } oss_scan_bwd_params;
 
 /* Time steps between two saved states in `x` (the reference's is 2048,
@@ -116,11 +135,18 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
 
 /* Replaces selective_scan_bwd_cuda<1, input_t, float> (cus/selective_scan_bwd_kernel.cuh:275-310)
  * plus the zero-fills and casts around it (cus/selective_scan.cpp:319-327,347). */
+/* (the workspace size covers the fused-delta form with dt_rank <= 8 as well) */
 size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups);
 int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream);
 
-/* Kernel-variant override for tuning / A-B benches: -1 = heuristic (default).  Forward variants 0..7, backward variants 0..9
- * (tables in oss_scan_fwd.hip / oss_scan_bwd.hip; 8 and 9 = two states per pass in packed fp32, oss_scan_bwd_pair.h).  An
+/* 1 when the fused-delta form (oss_scan_fwd_params.dt_weight) covers this SS2D_1 shape: 16-bit I/O on the matrix-core
+ * projection kernels (which may then be called with dts / ddts == NULL), dt_rank <= 8, dstate <= 64, seqlen >= 512
+ * (shorter sequences take the small-shape kernels, which read delta). */
+int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstate, int seqlen);
+
+/* Kernel-variant override for tuning / A-B benches: -1 = heuristic (default).  Forward variants 0..7, backward variants 0..13
+ * (tables in oss_scan_fwd.hip / oss_scan_bwd.hip; 8 and 9 = two states per pass in packed fp32, oss_scan_bwd_pair.h; 10..13 =
+ * the round-2 kernel, oss_scan_bwd_v2.h).  An
  * unknown number falls back to the small-shape variant. */
 void oss_scan_set_variant(int fwd_variant, int bwd_variant);
 int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);

@@ -45,6 +45,9 @@ def test_struct_layout_matches_header():
 #include <stddef.h>
 #include "vmambair_oss.h"
 int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu ", offsetof(oss_scan_fwd_params, dt_weight), offsetof(oss_scan_fwd_params, dt_rank),
+         offsetof(oss_scan_fwd_params, dt_rank_stride), offsetof(oss_scan_bwd_params, ddt), offsetof(oss_scan_bwd_params, ddt_weight),
+         offsetof(oss_scan_bwd_params, ddt_rank_stride));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(oss_scan_fwd_params), offsetof(oss_scan_fwd_params, u_batch_stride),
          offsetof(oss_scan_fwd_params, u), offsetof(oss_scan_fwd_params, x), sizeof(oss_scan_bwd_params),
          offsetof(oss_scan_bwd_params, dout_batch_stride), offsetof(oss_scan_bwd_params, dout),
@@ -59,7 +62,8 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     F, B, Ch = _capi.ScanFwdParams, _capi.ScanBwdParams, _capi.ChanParams
-    want = [ctypes.sizeof(F), F.u_batch_stride.offset, F.u.offset, F.x.offset, ctypes.sizeof(B),
+    want = [F.dt_weight.offset, F.dt_rank.offset, F.dt_rank_stride.offset, B.ddt.offset, B.ddt_weight.offset, B.ddt_rank_stride.offset,
+            ctypes.sizeof(F), F.u_batch_stride.offset, F.u.offset, F.x.offset, ctypes.sizeof(B),
             B.dout_batch_stride.offset, B.dout.offset, B.workspace_bytes.offset, B.dBC_group_stride.offset,
             ctypes.sizeof(Ch), Ch.pooled.offset, Ch.zt.offset, Ch.c.offset]
     assert got == want
@@ -69,7 +73,8 @@ def test_workspace_query_is_pure():
     lib = _capi.load()
     n = lib.oss_scan_bwd_workspace_bytes(2, 8, 100, 16, 4)
     tiles = (2 + 3) // 4  # 2 rows per group, 4 rows per workgroup in the smallest variant (bwd variant 1)
-    assert n == 4 * (2 * 4 * tiles * 2 * 16 * 100 + 2 * 8 * 18)
+    # per row tile: dB / dC partial rows (2 * dstate) + 8 rows for the fused-delta form; per (batch, row): dA, dD, dbias, 8 dt weights
+    assert n == 4 * (2 * 4 * tiles * (2 * 16 + 8) * 100 + 2 * 8 * (18 + 8))
     assert lib.oss_scan_bwd_workspace_bytes(2, 7, 100, 16, 4) == 0  # dim % n_groups != 0
 
 

@@ -438,3 +438,93 @@ def test_omni_block_path_equals_reference_data_flow_on_gpu():
     assert_close(res[0][1], res[1][1], 1e-3, 1e-3, "dx")
     for k in res[1][2]:
         assert_close(res[0][2][k], res[1][2][k], 2e-3, 2e-4 * max(1.0, float(res[1][2][k].abs().max())), k)
+
+
+# ------------------------------------------------------------------------------------------------
+# f1: delta computed inside the scan from the rank-R factor
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("L,rows,R,bv", [(1024, 48, 3, -1), (1539, 13, 6, -1), (4096, 96, 6, -1), (700, 24, 8, 13), (2085, 12, 5, 11)])
+def test_fused_delta_scan_matches_materialised_delta(itype, L, rows, R, bv):
+    """``dt_weight`` form (include/vmambair_oss.h): delta = W_dt . z inside the kernels, gradient of z and of W_dt out of the
+    backward -- against the same kernels fed the materialised delta (the archs' ``dts = einsum(dts, dt_projs_weight)``,
+    MambaSISR6_arch.py:409-411) with the projection and its adjoint done by torch in fp32.  Omni form (4 groups, two mirrored,
+    shared u rows) as SS2D_1 issues it."""
+    K, N, Bsz = 4, 16, 2
+    Cc = R + 2 * N
+    g = torch.Generator().manual_seed(5)
+    x2 = torch.randn(Bsz, 2 * rows, L, generator=g).to(itype).to(DEV)
+    xdbl = torch.randn(Bsz, K, Cc, L, generator=g).to(itype).to(DEV)
+    xdbl[:, :, :R] *= 0.3
+    W = (torch.randn(K * rows, R, generator=g) * 0.5).to(DEV)
+    A_log = torch.log(0.5 + torch.rand(K * rows, N, generator=g)).to(DEV)
+    D, bias = torch.randn(K * rows, generator=g).to(DEV), (0.5 * torch.rand(K * rows, generator=g)).to(DEV)
+    dout = torch.randn(Bsz, 2 * rows, L, generator=g).to(itype).to(DEV)
+    Bm, Cm = xdbl[:, :, R:R + N], xdbl[:, :, R + N:]
+    z = xdbl[:, :, :R].float()
+    delta = torch.einsum("kdr,bkrl->bkdl", W.view(K, rows, R), z).reshape(Bsz, K * rows, L)
+    lib = _capi.load()
+    lib.oss_scan_set_variant(-1, bv)
+    try:
+        kw = dict(rev_group_start=2, u_row_mod=2 * rows, a_log_form=True)
+        out_f, x_f = vmambair_amd.selective_scan_fwd(x2, xdbl, A_log, Bm, Cm, D, bias, True, 1, dt_weight=W, **kw)
+        out_u, x_u = vmambair_amd.selective_scan_fwd(x2, delta.to(itype), A_log, Bm, Cm, D, bias, True, 1, **kw)
+        dxf = torch.full_like(xdbl, float("nan"))
+        dxu = torch.zeros_like(xdbl)
+        gf = vmambair_amd.selective_scan_bwd(x2, xdbl, A_log, Bm, Cm, D, bias, dout, x_f, True, 1, dout_row_mod=2 * rows,
+                                             dbc_into=dxf, dt_weight=W, **kw)
+        gu = vmambair_amd.selective_scan_bwd(x2, delta.to(itype), A_log, Bm, Cm, D, bias, dout, x_u, True, 1,
+                                             dout_row_mod=2 * rows, dbc_into=dxu, **kw)
+    finally:
+        lib.oss_scan_set_variant(-1, -1)
+    assert len(gf) == 8 and gf[1] is None and len(gu) == 7
+    # the materialised delta is rounded to the I/O type on its way into the kernel, the fused one is not
+    rtol, atol = TOL[itype]
+    assert_close(out_f, out_u, rtol, atol, "out")
+    assert_close(x_f[..., 1::2], x_u[..., 1::2], rtol, atol, "saved states")
+    assert_close(gf[0], gu[0], rtol * 2, atol * 2, "du")
+    ddelta = gu[1].float().view(Bsz, K, rows, L)
+    dz_ref = torch.einsum("kdr,bkdl->bkrl", W.view(K, rows, R), ddelta)
+    dW_ref = torch.einsum("bkdl,bkrl->kdr", ddelta, z).reshape(K * rows, R)
+    sc = float(dz_ref.abs().max())
+    assert torch.isfinite(dxf).all(), "every row of the x_dbl gradient is written"
+    assert_close(dxf[:, :, :R], dz_ref, rtol * 5, atol * 10 + (2e-5 if itype == torch.float32 else 8e-3) * sc, "gradient of the dt factor")
+    assert_close(dxf[:, :, R:], dxu[:, :, R:], rtol, atol, "dB / dC rows")
+    wa = (2e-5 if itype == torch.float32 else 4e-3)
+    assert_close(gf[7], dW_ref, RTOLW * 5, max(ATOLW * 5, wa * float(dW_ref.abs().max())), "gradient of dt_weight")
+    for i, n in ((2, "dA_log"), (5, "dD"), (6, "dbias")):
+        assert_close(gf[i], gu[i], RTOLW * 5, max(ATOLW * 5, wa * float(gu[i].abs().max())), n)
+    # bit-stable reruns of the fused form as well
+    dxf2 = torch.empty_like(xdbl)
+    gf2 = vmambair_amd.selective_scan_bwd(x2, xdbl, A_log, Bm, Cm, D, bias, dout, x_f, True, 1, dout_row_mod=2 * rows,
+                                          dbc_into=dxf2, dt_weight=W, **kw) if bv < 0 else None
+    if gf2 is not None:
+        assert torch.equal(dxf2, dxf) and torch.equal(gf2[7], gf[7]) and torch.equal(gf2[0], gf[0])
+
+
+@pytest.mark.parametrize("dim,hw", [(48, (32, 32)), (96, (24, 40))])
+def test_fused_delta_core_matches_materialised_core(dim, hw):
+    """SS2DCoreFn with and without the fused delta (ops.FUSED_DT) under bf16: same output and gradients to bf16 rounding"""
+    from vmambair_amd import ops
+    from vmambair_amd.oss_block import SS2D_1
+    torch.manual_seed(0)
+    m = SS2D_1(d_model=dim, ssm_ratio=1, variant="srgan").to(DEV)
+    x = torch.randn(2, dim, *hw, device=DEV).to(torch.bfloat16)
+    assert ops.fused_dt_supported(torch.bfloat16, 2, dim, m.dt_rank + 32, m.dt_rank, 16, hw[0] * hw[1])
+    res = []
+    for fused in (True, False):
+        ops.FUSED_DT = fused
+        try:
+            m.zero_grad()
+            xi = x.clone().requires_grad_()
+            y = m.forward_core(xi)
+            y.float().square().mean().backward()
+        finally:
+            ops.FUSED_DT = True
+        res.append((y.detach().float(), xi.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    assert rel(res[0][0], res[1][0]) < 1e-2 and rel(res[0][1], res[1][1]) < 2e-2
+    for k in res[1][2]:
+        assert rel(res[0][2][k], res[1][2][k]) < 3e-2, k

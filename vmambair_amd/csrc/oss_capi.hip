@@ -131,6 +131,7 @@ static double bwd_alg_bytes(const oss_scan_fwd_params &p, int s) {
 
 static int check_fwd(const oss_scan_fwd_params *p) {
     if (!p || !p->u || !p->delta || !p->A || !p->B || !p->C) return OSS_ERR_NULL;
+    if (p->dt_weight && (p->dt_rank < 1 || p->dt_rank > kMaxDtRank)) return OSS_ERR_SHAPE;
     if (p->batch < 0 || p->dim <= 0 || p->seqlen < 0 || p->dstate <= 0 || p->n_groups <= 0) return OSS_ERR_SHAPE;
     if (p->dim % p->n_groups != 0) return OSS_ERR_SHAPE;  // selective_scan.cpp:190
     if (p->dstate > OSS_MAX_DSTATE) return OSS_ERR_DSTATE;  // selective_scan.cpp:191
@@ -181,7 +182,9 @@ size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, 
     const int rows_per_group = dim / n_groups;
     const int rows = scan_bwd_rows_per_wg(1);
     const size_t tiles = (size_t)(rows_per_group + rows - 1) / rows;
-    const size_t floats = (size_t)batch * n_groups * tiles * 2 * dstate * seqlen + (size_t)batch * dim * (dstate + 2);
+    // + kMaxDtRank partial rows per tile and kMaxDtRank dt-weight partials per (batch, row): the fused-delta form
+    const size_t floats = (size_t)batch * n_groups * tiles * (2 * dstate + kMaxDtRank) * seqlen +
+                          (size_t)batch * dim * (dstate + 2 + kMaxDtRank);
     return floats * sizeof(float);
 }
 
@@ -189,7 +192,9 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     if (!p) return OSS_ERR_NULL;
     int rc = check_fwd(&p->f);
     if (rc != OSS_OK) return rc;
-    if (!p->dout || !p->du || !p->ddelta || !p->dA || !p->dB || !p->dC) return OSS_ERR_NULL;
+    if (!p->dout || !p->du || !p->dA || !p->dB || !p->dC) return OSS_ERR_NULL;
+    if (!p->f.dt_weight && !p->ddelta) return OSS_ERR_NULL;
+    if (p->f.dt_weight && (!p->ddt || !p->ddt_weight)) return OSS_ERR_NULL;
     const oss_scan_fwd_params &f = p->f;
     if (f.batch == 0 || f.seqlen == 0) return OSS_OK;
     if (!f.x && oss_scan_num_chunks(f.seqlen) > 1) return OSS_ERR_NULL;  // selective_scan.cpp:310
@@ -263,32 +268,36 @@ size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen)
 
 int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const float *dt_projs_weight, void *xdbl, void *dts,
                  int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
-    if (!x2 || !x_proj_weight || !dt_projs_weight || !xdbl || !dts) return OSS_ERR_NULL;
+    if (!x2 || !x_proj_weight || !dt_projs_weight || !xdbl) return OSS_ERR_NULL;   // dts == NULL: fused-delta form
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
     return proj_fwd(io, x2, x_proj_weight, dt_projs_weight, xdbl, dts, batch, D, C, R, seqlen, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *x_proj_weight,
                    const float *dt_projs_weight, void *dx2, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
-    if (!ddts || !dxdbl || !x_proj_weight || !dt_projs_weight || !dx2) return OSS_ERR_NULL;
+    if (!dxdbl || !x_proj_weight || !dt_projs_weight || !dx2) return OSS_ERR_NULL;   // ddts == NULL: fused-delta form
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
     return proj_dgrad(io, ddts, dxdbl, du, x_proj_weight, dt_projs_weight, dx2, batch, D, C, R, seqlen,
                       reinterpret_cast<hipStream_t>(stream));
 }
 
 void oss_proj_set_path(int force_vector_alu) { proj_force_valu(force_vector_alu); }
+int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstate, int seqlen) {
+    return proj_mfma_ok(io, batch, D, C, R, seqlen) && R >= 1 && R <= kMaxDtRank && dstate <= 64 && seqlen >= 512;
+}
 void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
 
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
-    if (!x2 || !xdbl || !dxdbl || !ddts || !dx_proj_weight || !ddt_projs_weight || !partials) return OSS_ERR_NULL;
+    if (!x2 || !xdbl || !dxdbl || !dx_proj_weight || !partials) return OSS_ERR_NULL;
+    if (ddts && !ddt_projs_weight) return OSS_ERR_NULL;   // ddts == NULL: the scan backward produced ddt_projs_weight itself
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t L = seqlen;
     // x_proj_weight: one problem per flattening j; its 2C rows are the rows of directions j and j + 2 of dxdbl
     int e = conv1x1_wgrad(io, dxdbl, x2, dx_proj_weight, partials, batch, 2 * C, D, seqlen, 4 * C * L, L, 2 * D * L, L, s,
                           /*G*/ 2, /*gsg*/ C * L, /*xsg*/ D * L, /*Mh*/ C, /*gs_hi*/ 2 * C * L);
-    if (e) return e;
+    if (e || !ddts) return e;
     // dt_projs_weight: one problem per direction k: ddts[:, k] (D rows) x the dt rows of xdbl[:, k] (R rows)
     float *part2 = partials + (size_t)batch * conv1x1_wgrad_slabs(seqlen) * 2 * (2 * (size_t)C) * D;
     return conv1x1_wgrad(io, ddts, xdbl, ddt_projs_weight, part2, batch, D, R, seqlen, 4 * D * L, L, 4 * C * L, L, s,

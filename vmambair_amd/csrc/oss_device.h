@@ -223,6 +223,23 @@ __device__ __forceinline__ void store_items_dir(T *row, int tl, int valid, int L
     }
 }
 
+// delta computed where it is consumed (include/vmambair_oss.h: dt_weight): acc[i] = sum_r w[r] * z[r][scan position tl + i],
+// r ascending, fp32 -- the dt projection of the archs (MambaSISR6_arch.py:409-411) without its (batch, dim, seqlen) output
+constexpr int kMaxDtRank = 8;
+template <int I, typename T>
+__device__ __forceinline__ void dt_project(const T *z0, int64_t rank_stride, const float *w, int R, int tl, int valid, int L,
+                                           bool rev, float (&acc)[I]) {
+#pragma unroll
+    for (int i = 0; i < I; ++i) acc[i] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        float zz[I];
+        load_items_dir<I>(z0 + r * rank_stride, tl, valid, L, rev, zz);
+        const float wr = w[r];
+#pragma unroll
+        for (int i = 0; i < I; ++i) acc[i] = __builtin_fmaf(wr, zz[i], acc[i]);
+    }
+}
+
 // Stage nb state rows x TC scan positions of one (batch, group) of B and C into the LDS tiles as
 // fp32 (tile_off image).  `rev`: scan position s reads memory L-1-s.
 template <typename T, int LPR, int I, int NT>

@@ -46,6 +46,7 @@ int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, vo
 int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,
                int D, int C, int R, int L, hipStream_t s);
 void proj_force_valu(int on);
+bool proj_mfma_ok(oss_dtype io, int B, int D, int C, int R, int L);
 int cross_scan2(oss_dtype it, oss_dtype ot, const void *x, void *x2, int B, int D, int H, int W, int64_t xsb, int64_t xsc,
                 hipStream_t s);
 int cross_merge2(oss_dtype io, const void *g2, void *dx, int B, int D, int H, int W, hipStream_t s);

@@ -681,6 +681,7 @@ static int proj_fwd_mfma_t(const void *x2, const float *Wx, const float *Wdt, vo
     else if (ks <= 12) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 12>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else if (ks <= 24) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 24>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else               hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 48>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
+    if (!dts) return (int)hipGetLastError();   // delta is evaluated inside the scan (oss_scan_fwd_params.dt_weight)
     const int nw = dt_waves(B, L, D);
     dim3 g2((L + 127) / 128, 4, B);  // L is even here: two time steps per lane
     if (R <= 8) hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 8, 2>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
@@ -697,8 +698,9 @@ static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, cons
     while (nw > 1 && sizeof(float) * 128 * (size_t)nw * R > 48 * 1024) nw >>= 1;  // cross-wave reduction buffer <= 48 KiB
     dim3 g1((L + 127) / 128, 4, B);
     const size_t smem = sizeof(float) * 128 * (size_t)nw * R;
-    if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
-    else        hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
+    if (!ddts) {}   // the scan backward already filled the dt rows of dxdbl (oss_scan_bwd_params.ddt)
+    else if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
+    else             hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
     const int mt = (D + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
     dim3 grid((L + 255) / 256, 2 * splits, B);
     const int ks = (2 * C + 15) / 16;
@@ -709,12 +711,13 @@ static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, cons
 }
 
 // 16-bit I/O and shapes the register-resident operands cover -> matrix-core path
-static bool proj_mfma_ok(oss_dtype io, int B, int D, int C, int R, int L) {
+bool proj_mfma_ok(oss_dtype io, int B, int D, int C, int R, int L) {
     return io != OSS_F32 && L % 2 == 0 && D <= 16 * 48 && 2 * C <= 16 * 16 && R <= 32 && B <= 65535 && g_proj_force_valu == 0;
 }
 
 int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
              int L, hipStream_t s) {
+    if (!dts && !proj_mfma_ok(io, B, D, C, R, L)) return OSS_ERR_NULL;   // dts may be omitted on the matrix-core path only
     if (proj_mfma_ok(io, B, D, C, R, L))
         return io == OSS_BF16 ? proj_fwd_mfma_t<bf16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s)
                               : proj_fwd_mfma_t<f16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
@@ -728,6 +731,7 @@ int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, vo
 
 int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *Wx, const float *Wdt, void *dx2, int B,
                int D, int C, int R, int L, hipStream_t s) {
+    if (!ddts && !proj_mfma_ok(io, B, D, C, R, L)) return OSS_ERR_NULL;
     if (proj_mfma_ok(io, B, D, C, R, L))
         return io == OSS_BF16 ? proj_dgrad_mfma_t<bf16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s)
                               : proj_dgrad_mfma_t<f16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);

@@ -27,15 +27,16 @@
 namespace oss {
 
 // workspace layout (floats):
-//   [0, nBC)                 dB/dC partials  [batch][group][tile][2][N][L]
+//   [0, nBC)                 dB/dC (+ d dt-factor) partials  [batch][group][tile][2 N + RP][L]
 //   [nBC, nBC + batch*dim*N) dA partials     [batch][dim][N]
-//   then dD partials [batch][dim], then ddelta_bias partials [batch][dim]
+//   then dD partials [batch][dim], then ddelta_bias partials [batch][dim], then dt-weight partials [batch][dim][kMaxDtRank]
+// RP = rows of the gradient of the dt factor z (fused-delta form: dt_rank rounded up to even), else 0.
 struct BwdWs {
-    float *bc, *dA, *dD, *db;
-    int tiles;
+    float *bc, *dA, *dD, *db, *dW;
+    int tiles, rp;
 };
-__host__ __device__ inline size_t ws_bc_floats(int batch, int G, int tiles, int N, int L) {
-    return (size_t)batch * G * tiles * 2 * N * L;
+__host__ __device__ inline size_t ws_bc_floats(int batch, int G, int tiles, int N, int L, int RP = 0) {
+    return (size_t)batch * G * tiles * (2 * N + RP) * L;
 }
 
 // SPS: states walked together between two barriers (2: two independent dependency chains per wave for the
@@ -318,8 +319,18 @@ oss_scan_bwd_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 // of the finishing launch)
 __device__ __forceinline__ void finish_w(int i, const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA,
                                          float *dD, float *db, int batch, int dim, int N, const float *A_log,
-                                         int64_t A_d_stride) {
+                                         int64_t A_d_stride, const float *ws_dW, float *dW, int R) {
     const int nA = dim * N;
+    if (dW && i >= nA + dim) {   // dt-weight gradient of the fused-delta form: sum over batch in batch order
+        const int j = i - nA - dim;
+        if (j < dim * R) {
+            const int d = j / R, r = j - d * R;
+            float s = 0.f;
+            for (int b = 0; b < batch; ++b) s += ws_dW[((size_t)b * dim + d) * kMaxDtRank + r];
+            dW[j] = s;
+        }
+        return;
+    }
     if (i < nA) {
         float s = 0.f;
         for (int b = 0; b < batch; ++b) s += ws_dA[(size_t)b * nA + i];
@@ -340,29 +351,45 @@ __device__ __forceinline__ void finish_w(int i, const float *ws_dA, const float 
     }
 }
 
-// ONE finishing launch: blocks [0, nblk_bc) add the row-tile partials of dB/dC in tile order and
-// cast to the I/O type; the remaining blocks reduce the weight-gradient partials over batch.
+// ONE finishing launch: blocks [0, nblk_bc) add the row-tile partials of dB / dC (and of the dt-factor gradient in the
+// fused-delta form) in tile order and cast to the I/O type; the remaining blocks reduce the weight-gradient partials over batch.
+struct FinishArgs {
+    const float *ws_bc;
+    void *dB, *dC, *dZ;
+    int tiles, N, RP, R, G;
+    size_t L, total;            // total = batch * G * (2 N + R) * L outputs
+    unsigned nblk_bc;
+    const float *ws_dA, *ws_dD, *ws_db, *ws_dW;
+    float *dA, *dD, *db, *dW;
+    int batch, dim;
+    const float *A_log;
+    int64_t A_d_stride;
+    size_t out_group_stride;    // (batch, group) block stride of dB and of dC
+    int64_t dz_batch_stride, dz_group_stride, dz_rank_stride;
+};
 template <typename T>
 __global__ void __launch_bounds__(256)
-oss_scan_bwd_finish(const float *ws_bc, T *dB, T *dC, int tiles, size_t nl /* N*L */, size_t total /* batch*G*N*L */,
-                    unsigned nblk_bc, const float *ws_dA, const float *ws_dD, const float *ws_db, float *dA, float *dD,
-                    float *db, int batch, int dim, int N, const float *A_log, int64_t A_d_stride, size_t out_group_stride) {
-    if (blockIdx.x >= nblk_bc) {
-        finish_w((int)((blockIdx.x - nblk_bc) * 256 + threadIdx.x), ws_dA, ws_dD, ws_db, dA, dD, db, batch, dim, N, A_log,
-                 A_d_stride);
+oss_scan_bwd_finish(const FinishArgs a) {
+    if (blockIdx.x >= a.nblk_bc) {
+        finish_w((int)((blockIdx.x - a.nblk_bc) * 256 + threadIdx.x), a.ws_dA, a.ws_dD, a.ws_db, a.dA, a.dD, a.db, a.batch, a.dim,
+                 a.N, a.A_log, a.A_d_stride, a.ws_dW, a.dW, a.R);
         return;
     }
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const size_t bg = i / nl, r = i - bg * nl;
-    const float *base = ws_bc + bg * tiles * 2 * nl + r;
-    float sb = 0.f, sc = 0.f;
-    for (int t = 0; t < tiles; ++t) {
-        sb += base[(size_t)t * 2 * nl];
-        sc += base[(size_t)t * 2 * nl + nl];
+    if (i >= a.total) return;
+    const size_t rows_out = 2 * (size_t)a.N + a.R, pt = (2 * (size_t)a.N + a.RP) * a.L;   // outputs / partial floats per (b, g)
+    const size_t bg = i / (rows_out * a.L), rem = i - bg * rows_out * a.L;
+    const size_t row = rem / a.L, t = rem - row * a.L;
+    const float *base = a.ws_bc + bg * a.tiles * pt + row * a.L + t;
+    float s = 0.f;
+    for (int k = 0; k < a.tiles; ++k) s += base[(size_t)k * pt];
+    const T v = from_f32<T>(s);
+    if (row < (size_t)a.N) reinterpret_cast<T *>(a.dB)[bg * a.out_group_stride + row * a.L + t] = v;
+    else if (row < 2 * (size_t)a.N) reinterpret_cast<T *>(a.dC)[bg * a.out_group_stride + (row - a.N) * a.L + t] = v;
+    else {
+        const size_t b = bg / a.G, g = bg - b * a.G;
+        reinterpret_cast<T *>(a.dZ)[b * a.dz_batch_stride + g * a.dz_group_stride + (row - 2 * a.N) * a.dz_rank_stride + t] = v;
     }
-    dB[bg * out_group_stride + r] = from_f32<T>(sb);
-    dC[bg * out_group_stride + r] = from_f32<T>(sc);
 }
 
 }  // namespace oss
@@ -375,14 +402,17 @@ static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, fl
     const oss_scan_fwd_params &f = p.f;
     const int rows_per_group = f.dim / f.n_groups;
     const int tiles = (rows_per_group + rows_per_wg - 1) / rows_per_wg;
-    const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen);
-    const size_t need = sizeof(float) * (n_bc + (size_t)f.batch * f.dim * (f.dstate + 2));
+    const int rp = f.dt_weight ? ((f.dt_rank + 1) & ~1) : 0;
+    const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen, rp);
+    const size_t need = sizeof(float) * (n_bc + (size_t)f.batch * f.dim * (f.dstate + 2 + (rp ? kMaxDtRank : 0)));
     if (!p.workspace || p.workspace_bytes < need) return OSS_ERR_WORKSPACE;
     ws.bc = reinterpret_cast<float *>(p.workspace);
     ws.dA = ws.bc + n_bc;
     ws.dD = ws.dA + (size_t)f.batch * f.dim * f.dstate;
     ws.db = ws.dD + (size_t)f.batch * f.dim;
+    ws.dW = rp ? ws.db + (size_t)f.batch * f.dim : nullptr;
     ws.tiles = tiles;
+    ws.rp = rp;
     wdD = ws.dD; wdb = ws.db;
     if (!p.dD) ws.dD = nullptr;
     if (!p.ddelta_bias) ws.db = nullptr;
@@ -392,14 +422,20 @@ static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, fl
 template <typename T>
 static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *wdD, float *wdb, hipStream_t stream) {
     const oss_scan_fwd_params &f = p.f;
-    const size_t nl = (size_t)f.dstate * f.seqlen;
-    const size_t total = (size_t)f.batch * f.n_groups * nl;
-    const unsigned nblk_bc = (unsigned)((total + 255) / 256);
-    const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + 255) / 256);
-    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(nblk_bc + nblk_w), dim3(256), 0, stream, ws.bc,
-                       reinterpret_cast<T *>(p.dB), reinterpret_cast<T *>(p.dC), ws.tiles, nl, total, nblk_bc, ws.dA, wdD, wdb,
-                       p.dA, p.dD, p.ddelta_bias, f.batch, f.dim, f.dstate, f.a_log_form ? f.A : nullptr, f.A_d_stride,
-                       p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : nl);
+    FinishArgs a;
+    a.ws_bc = ws.bc; a.dB = p.dB; a.dC = p.dC; a.dZ = p.ddt;
+    a.tiles = ws.tiles; a.N = f.dstate; a.RP = ws.rp; a.R = ws.rp ? f.dt_rank : 0; a.G = f.n_groups;
+    a.L = (size_t)f.seqlen;
+    a.total = (size_t)f.batch * f.n_groups * (2 * (size_t)f.dstate + a.R) * f.seqlen;
+    a.nblk_bc = (unsigned)((a.total + 255) / 256);
+    a.ws_dA = ws.dA; a.ws_dD = wdD; a.ws_db = wdb; a.ws_dW = ws.dW;
+    a.dA = p.dA; a.dD = p.dD; a.db = p.ddelta_bias; a.dW = ws.rp ? p.ddt_weight : nullptr;
+    a.batch = f.batch; a.dim = f.dim;
+    a.A_log = f.a_log_form ? f.A : nullptr; a.A_d_stride = f.A_d_stride;
+    a.out_group_stride = p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : (size_t)f.dstate * f.seqlen;
+    a.dz_batch_stride = p.ddt_batch_stride; a.dz_group_stride = p.ddt_group_stride; a.dz_rank_stride = p.ddt_rank_stride;
+    const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + f.dim * a.R + 255) / 256);
+    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(a.nblk_bc + nblk_w), dim3(256), 0, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -454,8 +490,11 @@ static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, Lau
 }
 
 // round-2 kernel (oss_scan_bwd_v2.h): lane-resident per-state scalars, register-prefetched tiles, one barrier per state
-template <typename T, int WAVES, int NBB, int MINW>
+template <typename T, int WAVES, int NBB, int MINW, bool FD = false>
 static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
+    if constexpr (!FD) {
+        if (p.f.dt_weight) return launch_bwd2<T, WAVES, NBB, MINW, true>(p, stream, timer);
+    }
     constexpr int TC = 512;
     const oss_scan_fwd_params &f = p.f;
     BwdWs ws;
@@ -464,7 +503,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchT
     if (rc != OSS_OK) return rc;
     const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC);   // two tile buffers, two slab buffers
     static size_t smem_enabled = 48 * 1024;
-    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW>, smem, smem_enabled,
+    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD>, smem, smem_enabled,
                      (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);
@@ -485,6 +524,10 @@ int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant 
 
 template <typename T>
 int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
+    if (p.f.dt_weight) {   // delta computed inside the scan: round-2 kernels only
+        if (p.f.dstate > 64 || p.f.dt_rank < 1 || p.f.dt_rank > kMaxDtRank || !p.ddt || !p.ddt_weight) return OSS_ERR_SHAPE;
+        if (variant < 10) variant = 13;
+    }
     if (variant >= 10 && p.f.dstate > 64) {   // the round-2 kernel keeps one lane per state: same-row-count round-1 kernel
         static const int same_rows[] = {6, 3, 5, 1};
         variant = same_rows[variant - 10];

@@ -87,7 +87,10 @@ __device__ __forceinline__ f32x4 quad_to_f32(const RawQuad<T> &r, bool rev) {
     return rev ? f32x4{v[3], v[2], v[1], v[0]} : f32x4{v[0], v[1], v[2], v[3]};
 }
 
-template <typename T, int WAVES, int NBB, int MINW>
+// FD: delta computed inside the scan from the rank-R factor z (include/vmambair_oss.h: dt_weight); the kernel then emits the
+// gradient of z (summed over the rows of the group: slab rounds like dB / dC, two rank rows per round) and the per-row
+// gradient of dt_weight instead of ddelta.
+template <typename T, int WAVES, int NBB, int MINW, bool FD>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
 oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     constexpr int LPR = 64, I = 8;
@@ -130,7 +133,10 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     const int d_u = f.u_row_mod > 0 ? d % f.u_row_mod : d;
 
     const T *u_row = reinterpret_cast<const T *>(f.u) + b * f.u_batch_stride + d_u * f.u_d_stride;
-    const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride + d * f.delta_d_stride;
+    const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride +
+                      (FD ? g * f.dt_group_stride : d * f.delta_d_stride);   // FD: rank row 0 of the (batch, group) block of z
+    const float *dt_w = FD ? f.dt_weight + (size_t)d * f.dt_rank : nullptr;
+    const int R = FD ? f.dt_rank : 0;
     const int d_g = p.dout_row_mod > 0 ? d % p.dout_row_mod : d;
     const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d_g * p.dout_d_stride;
     T *du_row = reinterpret_cast<T *>(p.du) + b * p.du_batch_stride + d * p.du_d_stride;
@@ -141,7 +147,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     const float bias = f.delta_bias ? f.delta_bias[d] : 0.f;
     const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
     const float *x_row = f.x ? f.x + ((size_t)b * f.dim + d) * n_xchunks * 2 * N : nullptr;
-    float *ws_bc = ws.bc + ((size_t)(b * G + g) * tiles_per_group + tile) * 2 * N * L;
+    float *ws_bc = ws.bc + ((size_t)(b * G + g) * tiles_per_group + tile) * (2 * N + ws.rp) * L;
     const bool ws_vec = (L % 4) == 0;   // 16-byte stores of the partial rows
 
     // ---- tile staging, split in two: global -> registers (issue), registers -> LDS (commit)
@@ -190,6 +196,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     float dln_c = 0.f;  // delta of the first step of the later chunk (wave-uniform); 0 past the end
 
     float dD_acc = 0.f, db_acc = 0.f;
+    float dWv = 0.f;   // FD: lane r = gradient of dt_weight[d, r]
     const int n_chunks = (L + TC - 1) / TC;
     int par = 0;   // slab buffer of the next state
     int tbuf = 0;  // tile buffer of the current batch
@@ -207,7 +214,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         {
             float uu[I];
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
-            load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+            if constexpr (FD) dt_project<I>(dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, dl);
+            else load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
             load_items_dir<I>(g_row, tl, valid, L, rev, gg);
             if (!row_valid) {  // a row slot past the end of the group must not contribute to dB/dC
 #pragma unroll
@@ -311,7 +319,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         // waves sum the lower / upper half of the rows for the same 32 position groups (16-byte reads, conflict-free) and
         // are combined with v_permlane32_swap -- the latency of this sum sits on the critical path of every state (all
         // waves wait for the summing ones at the next barrier), so it is spread as thin as the lanes allow.
-        auto slab_sum = [&](int n, int buf) {
+        auto slab_sum = [&](int prow0, int prow1, int buf) {   // partial rows of the slab's first / second array
 #ifndef OSS_EXP_V2_NOSUM
             int rw = wave - rot;
             rw += (rw < 0) ? WAVES : 0;
@@ -333,7 +341,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                             acc[k] = __int_as_float(sw[0]) + __int_as_float(sw[1]);
                         }
                     }
-                    float *dst = sum_dst + (size_t)(arr * N + n) * L + (rev ? -off : off);
+                    float *dst = sum_dst + (size_t)(arr ? prow1 : prow0) * L + (rev ? -off : off);
                     if (!SPLIT || lane < 32) {
                         if (chunk_full && ws_vec) {
                             *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
@@ -376,7 +384,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 #ifndef OSS_EXP_V2_NOBAR
                 __syncthreads();                       // state n's slabs are complete; buffer par^1 is free again
 #endif
-                slab_sum(n0 + nn, par);
+                slab_sum(n0 + nn, N + n0 + nn, par);
                 par ^= 1;
                 if (has1) {
                     const bool last = nn + 2 >= nb;
@@ -387,7 +395,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 #ifndef OSS_EXP_V2_NOBAR
                     __syncthreads();
 #endif
-                    slab_sum(n0 + nn + 1, par);
+                    slab_sum(n0 + nn + 1, N + n0 + nn + 1, par);
                     par ^= 1;
                 }
             }
@@ -397,7 +405,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         {
             float uu[I], raw[I], du[I], dv[I];
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
-            load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
+            if constexpr (FD) dt_project<I>(dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, raw);
+            else load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
 #pragma unroll
             for (int i = 0; i < I; ++i) {
                 float s = 1.f;
@@ -417,7 +426,42 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             }
             if (row_valid) {
                 store_items_dir<I>(du_row, tl, valid, L, rev, du);
-                store_items_dir<I>(dd_row, tl, valid, L, rev, dv);
+                if constexpr (!FD) store_items_dir<I>(dd_row, tl, valid, L, rev, dv);
+            }
+            if constexpr (FD) {
+                // gradient of the dt factor z and of dt_weight (bwd of the archs' dt einsum, MambaSISR6_arch.py:411):
+                //   dz[r, t] = sum over the group's rows of w[d, r] * ddelta[d, t]   -> slab rounds, rank rows 2 rr, 2 rr + 1
+                //   dw[d, r] = sum over t of ddelta[d, t] * z[r, t]                   -> per-lane partial, reduced at the end
+                if (!row_valid) {
+#pragma unroll
+                    for (int i = 0; i < I; ++i) dv[i] = 0.f;
+                }
+                for (int rr = 0; 2 * rr < R; ++rr) {
+                    float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int r = 2 * rr + h2;
+                        const bool on = r < R;
+                        float zz[I];
+                        float wr = 0.f;
+                        if (on) {
+                            load_items_dir<I>(dt_row + r * f.dt_rank_stride, tl, valid, L, rev, zz);
+                            wr = dt_w[r];
+                            float acc = 0.f;
+#pragma unroll
+                            for (int i = 0; i < I; ++i) acc = __builtin_fmaf(dv[i], zz[i], acc);
+                            const float tot = segment_sum_to_last<LPR>(acc) + lane_get(dWv, r);
+                            dWv = lane_set(dWv, lane, r, lane_get(tot, 63));
+                        }
+#pragma unroll
+                        for (int k = 0; k < I / 4; ++k)
+                            *reinterpret_cast<f32x4 *>(sb + h2 * TC + 4 * k) =
+                                f32x4{wr * dv[4 * k], wr * dv[4 * k + 1], wr * dv[4 * k + 2], wr * dv[4 * k + 3]};
+                    }
+                    __syncthreads();
+                    slab_sum(2 * N + 2 * rr, 2 * N + 2 * rr + 1, par);
+                    par ^= 1;
+                }
             }
         }
         dln_c = lane_get(dl[0], 0);
@@ -431,6 +475,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             if (ws.db) ws.db[(size_t)b * f.dim + d] = db_sum;
         }
         if (lane < N) ws.dA[((size_t)b * f.dim + d) * N + lane] = dAv;
+    }
+    if constexpr (FD) {
+        if (row_valid && lane < R) ws.dW[((size_t)b * f.dim + d) * kMaxDtRank + lane] = dWv;
     }
 }
 

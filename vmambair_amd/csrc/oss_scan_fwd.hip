@@ -56,7 +56,10 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
     const int d_u = p.u_row_mod > 0 ? d % p.u_row_mod : d;          // directions sharing one copy of u
 
     const T *u_row = reinterpret_cast<const T *>(p.u) + b * p.u_batch_stride + d_u * p.u_d_stride;
-    const T *dt_row = reinterpret_cast<const T *>(p.delta) + b * p.delta_batch_stride + d * p.delta_d_stride;
+    const bool fused_dt = p.dt_weight != nullptr;   // delta = dt_weight[d, :] . z[b, g, :, t] evaluated here
+    const T *dt_row = reinterpret_cast<const T *>(p.delta) + b * p.delta_batch_stride +
+                      (fused_dt ? g * p.dt_group_stride : d * p.delta_d_stride);
+    const float *dt_w = fused_dt ? p.dt_weight + (size_t)d * p.dt_rank : nullptr;
     T *out_row = reinterpret_cast<T *>(p.out) + b * p.out_batch_stride + d * p.out_d_stride;
     const T *gB = reinterpret_cast<const T *>(p.B) + b * p.B_batch_stride + g * p.B_group_stride;
     const T *gC = reinterpret_cast<const T *>(p.C) + b * p.C_batch_stride + g * p.C_group_stride;
@@ -85,7 +88,8 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         {
             float uu[I];
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
-            load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+            if (fused_dt) dt_project<I>(dt_row, p.dt_rank_stride, dt_w, p.dt_rank, tl, valid, L, rev, dl);
+            else load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
 #pragma unroll
             for (int i = 0; i < I; ++i) {
                 float x = dl[i] + bias;

@@ -11,6 +11,8 @@ all invisible to callers:
     (the reference zero-fills five tensors and casts two, :319-327,347);
   * ``nrows`` is accepted and ignored (the reference archs always end up with 1,
     SRGAN/VmambaIR/archs/MambaSISR6_arch.py:57,69).
+Beyond the reference's signature (keyword-only, used by the fused spatial core): ``dt_weight`` -- delta computed INSIDE the
+scan from the rank-R rows of x_dbl (include/vmambair_oss.h), so the (batch, 4 D, L) delta / ddelta tensors never exist.
 
 No CPU implementation exists: CPU tensors are rejected exactly as the reference rejects them
 (``TORCH_CHECK(u.is_cuda())``, :174).
@@ -150,7 +152,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0):
+def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0, dt_weight=None):
     # selective_scan.cpp:165-215
     _check(u.dtype in _DT, "u must be float32, float16 or bfloat16")
     _check(A.dtype == torch.float32, "A must be float32")
@@ -169,7 +171,13 @@ def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0):
     n_groups = B.shape[1]
     _check(n_groups > 0 and dim % n_groups == 0, "dims should be dividable by n_groups")
     _check(dstate <= 256, "selective_scan only supports state dimension <= 256")
-    _check(tuple(delta.shape) == (batch, dim, seqlen), "delta must have u's shape")
+    if dt_weight is None:
+        _check(tuple(delta.shape) == (batch, dim, seqlen), "delta must have u's shape")
+    else:   # delta = the rank-R factor z: (batch, n_groups, rows >= R, seqlen); dt_weight: (dim, R) float
+        _check(dt_weight.dtype == torch.float32 and dt_weight.is_cuda and dt_weight.dim() == 2 and dt_weight.shape[0] == dim and
+               dt_weight.is_contiguous() and 1 <= dt_weight.shape[1] <= 8, "dt_weight must be a contiguous (dim, R <= 8) float tensor")
+        _check(delta.dim() == 4 and delta.shape[0] == batch and delta.shape[1] == n_groups and delta.shape[2] >= dt_weight.shape[1]
+               and delta.shape[3] == seqlen, "with dt_weight, delta must be the (batch, n_groups, >= R, seqlen) factor")
     _check(tuple(B.shape) == (batch, n_groups, dstate, seqlen), "B has the wrong shape")
     _check(tuple(C.shape) == (batch, n_groups, dstate, seqlen), "C has the wrong shape")
     for name, t in (("u", u), ("delta", delta), ("B", B), ("C", C)):
@@ -187,7 +195,7 @@ def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0):
 
 
 def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start=None, u_row_mod=0,
-              a_log_form=False):
+              a_log_form=False, dt_weight=None):
     batch, dim, seqlen, dstate, n_groups = dims
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, seqlen, dstate, n_groups
     P.delta_softplus = 1 if delta_softplus else 0
@@ -196,6 +204,9 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
     P.a_log_form = 1 if a_log_form else 0
     P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
     P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
+    if dt_weight is not None:
+        P.dt_weight, P.dt_rank = dt_weight.data_ptr(), dt_weight.shape[1]
+        P.dt_group_stride, P.dt_rank_stride = delta.stride(1), delta.stride(2)
     if out is not None:
         P.out_batch_stride, P.out_d_stride = out.stride(0), out.stride(1)
     P.A_d_stride = A.stride(0)
@@ -209,21 +220,25 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], delta_softplus: bool,
                        nrows: int = 1, rev_group_start: Optional[int] = None, u_row_mod: int = 0,
-                       a_log_form: bool = False) -> List[torch.Tensor]:
+                       a_log_form: bool = False, dt_weight: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``.
-    ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling, see include/vmambair_oss.h."""
-    dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod)
+    ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling; ``dt_weight``: ``delta`` is the rank-R factor and the
+    kernels evaluate delta themselves -- see include/vmambair_oss.h."""
+    dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight)
     batch, dim, seqlen, dstate, _ = dims
     lib = _capi.load()
     n_chunks = int(lib.oss_scan_num_chunks(seqlen))
-    out = torch.empty_like(delta)
-    if out.stride(-1) != 1 and out.size(-1) != 1:
-        out = torch.empty(delta.shape, dtype=delta.dtype, device=delta.device)
+    if dt_weight is None:
+        out = torch.empty_like(delta)
+        if out.stride(-1) != 1 and out.size(-1) != 1:
+            out = torch.empty(delta.shape, dtype=delta.dtype, device=delta.device)
+    else:
+        out = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
     x = torch.empty((batch, dim, n_chunks, 2 * dstate), dtype=torch.float32, device=u.device)
     if batch == 0 or seqlen == 0:  # nothing to launch (empty tensors have no device pointer)
         return [out, x]
     P = _capi.ScanFwdParams()
-    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form)
+    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight)
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_fwd(P, _DT[u.dtype], stream), "oss_scan_fwd")
@@ -235,11 +250,14 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
                        x: Optional[torch.Tensor], delta_softplus: bool, nrows: int = 1,
                        rev_group_start: Optional[int] = None, u_row_mod: int = 0,
                        dout_row_mod: int = 0, a_log_form: bool = False,
-                       dbc_into: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+                       dbc_into: Optional[torch.Tensor] = None,
+                       dt_weight: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
-    form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``."""
-    dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod)
+    form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``.
+    With ``dt_weight`` (delta computed inside the scan; needs ``dbc_into``): ``ddelta`` is ``None``, the gradient of the rank
+    factor lands in the first R rows of ``dbc_into`` and an eighth entry, the (dim, R) gradient of ``dt_weight``, is returned."""
+    dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight)
     batch, dim, seqlen, dstate, n_groups = dims
     _check(dout.dtype == u.dtype and dout.is_cuda, "dout must be a CUDA/HIP tensor of u's dtype")
     _check(tuple(dout.shape) == (batch, dout_row_mod or dim, seqlen), "dout must have u's shape")
@@ -251,8 +269,11 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     if x is not None:
         _check(x.dtype == torch.float32 and x.is_cuda and x.is_contiguous(), "x must be a contiguous float32 tensor")
         _check(tuple(x.shape) == (batch, dim, n_chunks, 2 * dstate), "x has the wrong shape")
+    fused = dt_weight is not None
+    _check(not fused or dbc_into is not None, "dt_weight needs dbc_into (the gradient of x_dbl the kernel fills)")
     du = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
-    ddelta = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
+    ddelta = None if fused else torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
+    ddtw = torch.empty((dim, dt_weight.shape[1]), dtype=torch.float32, device=u.device) if fused else None
     dA = torch.empty((dim, dstate), dtype=torch.float32, device=u.device)
     if dbc_into is not None:
         # (batch, n_groups, R + 2 dstate, seqlen): dB / dC land in its last 2 dstate rows (oss_proj_dgrad fills the rest)
@@ -267,18 +288,22 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     dD = torch.empty((dim,), dtype=torch.float32, device=u.device) if D is not None else None
     dbias = torch.empty((dim,), dtype=torch.float32, device=u.device) if delta_bias is not None else None
     if batch == 0 or seqlen == 0:
-        for t in (dA, dD, dbias):
+        for t in (dA, dD, dbias, ddtw):
             if t is not None:
                 t.zero_()
-        return [du, ddelta, dA, dB, dC, dD, dbias]
+        return [du, ddelta, dA, dB, dC, dD, dbias] + ([ddtw] if fused else [])
     ws_bytes = int(lib.oss_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, n_groups))
     ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.float32, device=u.device)
     P = _capi.ScanBwdParams()
-    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form)
+    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight)
     P.dout_batch_stride, P.dout_d_stride = dout.stride(0), dout.stride(1)
     P.du_batch_stride, P.du_d_stride = du.stride(0), du.stride(1)
-    P.ddelta_batch_stride, P.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
-    P.dout, P.du, P.ddelta, P.dA = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), dA.data_ptr()
+    if fused:
+        P.ddt, P.ddt_weight = dbc_into.data_ptr(), ddtw.data_ptr()
+        P.ddt_batch_stride, P.ddt_group_stride, P.ddt_rank_stride = dbc_into.stride(0), dbc_into.stride(1), dbc_into.stride(2)
+    else:
+        P.ddelta_batch_stride, P.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
+    P.dout, P.du, P.ddelta, P.dA = dout.data_ptr(), du.data_ptr(), _ptr(ddelta), dA.data_ptr()
     P.dB, P.dC, P.dD, P.ddelta_bias = dB.data_ptr(), dC.data_ptr(), _ptr(dD), _ptr(dbias)
     P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     P.dout_row_mod = int(dout_row_mod)
@@ -286,7 +311,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
-    return [du, ddelta, dA, dB, dC, dD, dbias]
+    return [du, ddelta, dA, dB, dC, dD, dbias] + ([ddtw] if fused else [])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -359,6 +384,15 @@ def core_supported(D: int, R: int, N: int) -> bool:
     return R <= 32 and (2 * (R + 2 * N) + nw - 1) // nw <= 32 and (((D + nwd - 1) // nwd + 7) & ~7) <= 64
 
 
+#: ``VMAMBAIR_FUSED_DT=0`` keeps delta materialised (A-B timing / parity of the two forms)
+FUSED_DT = os.environ.get("VMAMBAIR_FUSED_DT", "1") != "0"
+
+
+def fused_dt_supported(dtype: torch.dtype, B: int, D: int, Cc: int, R: int, N: int, L: int) -> bool:
+    """delta computed inside the scan kernels: 16-bit I/O, dt_rank <= 8, L >= 512 (include/vmambair_oss.h)"""
+    return FUSED_DT and bool(_capi.load().oss_scan_fused_dt_ok(_DT[dtype], B, D, Cc, R, N, L))
+
+
 def _dims_core(x, x_proj_weight, dt_projs_weight, A_logs):
     _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "ss2d_core: x must be a (B, D, H, W) GPU tensor")
     B, D, H, W = x.shape
@@ -410,41 +444,44 @@ def _proj_weights(x_proj_weight, dt_projs_weight):
     return x_proj_weight.detach().float().contiguous(), dt_projs_weight.detach().float().contiguous()
 
 
-def proj_fwd(x2: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor) -> List[torch.Tensor]:
-    """x2 (B, 2, D, L) -> [xdbl (B, 4, R + 2N, L), dts (B, 4 D, L)] (MambaSISR6_arch.py:406-411, omni form)"""
+def proj_fwd(x2: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor, want_dts: bool = True) -> List[torch.Tensor]:
+    """x2 (B, 2, D, L) -> [xdbl (B, 4, R + 2N, L), dts (B, 4 D, L)] (MambaSISR6_arch.py:406-411, omni form).
+    ``want_dts=False`` (fused-delta form): the dt projection is left to the scan kernels, ``dts`` comes back empty."""
     B, _, D, L = x2.shape
     Cc, R = x_proj_weight.shape[1], dt_projs_weight.shape[2]
     wx, wdt = _proj_weights(x_proj_weight, dt_projs_weight)
     x2 = x2.contiguous()
     xdbl = torch.empty((B, 4, Cc, L), dtype=x2.dtype, device=x2.device)
-    dts = torch.empty((B, 4 * D, L), dtype=x2.dtype, device=x2.device)
+    dts = torch.empty((B, 4 * D, L) if want_dts else (0,), dtype=x2.dtype, device=x2.device)
     if x2.numel():
         with torch.cuda.device(x2.device):
             _capi.check(_capi.load().oss_proj_fwd(_DT[x2.dtype], x2.data_ptr(), wx.data_ptr(), wdt.data_ptr(), xdbl.data_ptr(),
-                                                  dts.data_ptr(), B, D, Cc, R, L, torch.cuda.current_stream().cuda_stream),
-                        "oss_proj_fwd")
+                                                  dts.data_ptr() if want_dts else None, B, D, Cc, R, L,
+                                                  torch.cuda.current_stream().cuda_stream), "oss_proj_fwd")
     return [xdbl, dts]
 
 
-def proj_dgrad(ddts: torch.Tensor, dxdbl: torch.Tensor, du: Optional[torch.Tensor], x_proj_weight: torch.Tensor,
+def proj_dgrad(ddts: Optional[torch.Tensor], dxdbl: torch.Tensor, du: Optional[torch.Tensor], x_proj_weight: torch.Tensor,
                dt_projs_weight: torch.Tensor) -> torch.Tensor:
     """fills the dt rows of ``dxdbl`` (B, 4, C, L) in place (its B / C rows hold dB / dC on entry) and returns
     dx2 (B, 2, D, L) = x_proj^T dxdbl (+ du) summed over the two directions of each flattening."""
     B, _, Cc, L = dxdbl.shape
     D, R = dt_projs_weight.shape[1], dt_projs_weight.shape[2]
     wx, wdt = _proj_weights(x_proj_weight, dt_projs_weight)
-    _check(dxdbl.is_contiguous() and ddts.is_contiguous() and (du is None or du.is_contiguous()), "proj_dgrad: contiguous inputs")
+    _check(dxdbl.is_contiguous() and (ddts is None or ddts.is_contiguous()) and (du is None or du.is_contiguous()),
+           "proj_dgrad: contiguous inputs")   # ddts None: the dt rows of dxdbl are already filled (fused-delta scan backward)
     dx2 = torch.empty((B, 2, D, L), dtype=dxdbl.dtype, device=dxdbl.device)
     if dx2.numel():
         with torch.cuda.device(dxdbl.device):
-            _capi.check(_capi.load().oss_proj_dgrad(_DT[dxdbl.dtype], ddts.data_ptr(), dxdbl.data_ptr(), _ptr(du), wx.data_ptr(),
+            _capi.check(_capi.load().oss_proj_dgrad(_DT[dxdbl.dtype], _ptr(ddts), dxdbl.data_ptr(), _ptr(du), wx.data_ptr(),
                                                     wdt.data_ptr(), dx2.data_ptr(), B, D, Cc, R, L,
                                                     torch.cuda.current_stream().cuda_stream), "oss_proj_dgrad")
     return dx2
 
 
-def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: torch.Tensor, R: int) -> List[torch.Tensor]:
-    """-> [dx_proj_weight (4, C, D), ddt_projs_weight (4, D, R)] fp32"""
+def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: Optional[torch.Tensor], R: int) -> List[torch.Tensor]:
+    """-> [dx_proj_weight (4, C, D), ddt_projs_weight (4, D, R)] fp32 (the second ``None`` when ``ddts`` is: the fused-delta
+    scan backward produces it)"""
     B, _, D, L = x2.shape
     Cc = xdbl.shape[2]
     dev = x2.device
@@ -458,10 +495,10 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
     with torch.cuda.device(dev):
         with _fork_for_wgrad(x2, xdbl, dxdbl, ddts):
             dwx = torch.empty((4, Cc, D), dtype=torch.float32, device=dev)
-            dwdt = torch.empty((4, D, R), dtype=torch.float32, device=dev)
+            dwdt = torch.empty((4, D, R), dtype=torch.float32, device=dev) if ddts is not None else None
             part = torch.empty((max(1, lib.oss_proj_wgrad_partial_floats(B, D, Cc, R, L)),), dtype=torch.float32, device=dev)
-            _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), ddts.data_ptr(),
-                                           dwx.data_ptr(), dwdt.data_ptr(), part.data_ptr(), B, D, Cc, R, L,
+            _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), _ptr(ddts),
+                                           dwx.data_ptr(), _ptr(dwdt), part.data_ptr(), B, D, Cc, R, L,
                                            torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
             _keep(part, dwx, dwdt)
     return [dwx, dwdt]
@@ -477,9 +514,12 @@ def ss2d_core_fwd(x: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight:
         e = x.new_empty
         return [e((B, D, H, W), dtype=torch.float32), e((B, 2, D, L)), e((B, 4, Cc, L)), e((B, 4 * D, L)), e(0, dtype=torch.float32)]
     x2 = cross_scan2(x)
-    xdbl, dts = proj_fwd(x2, x_proj_weight, dt_projs_weight)
-    out, states = selective_scan_fwd(x2.view(B, 2 * D, L), dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:],
-                                     Ds.detach().float(), dt_bias.detach().float().reshape(-1), True, 1, 2, 2 * D, True)
+    fused = fused_dt_supported(x2.dtype, B, D, Cc, R, N, L)
+    xdbl, dts = proj_fwd(x2, x_proj_weight, dt_projs_weight, want_dts=not fused)
+    # fused: delta = dt_projs_weight . xdbl[:, :, :R] is evaluated inside the scan kernels (dts stays empty)
+    out, states = selective_scan_fwd(x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N],
+                                     xdbl[:, :, R + N:], Ds.detach().float(), dt_bias.detach().float().reshape(-1), True, 1, 2,
+                                     2 * D, True, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None)
     y = merge4(out.view(B, 4, D, L), H, W)
     return [y, x2, xdbl, dts, states]
 
@@ -494,12 +534,17 @@ def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: t
     # the merge hands the same gradient to directions k and k + 2: two flattenings of dy, read with dout_row_mod
     g2 = cross_scan2(dy, x2.dtype)
     dxdbl = torch.empty((B, 4, Cc, L), dtype=x2.dtype, device=x2.device)
-    du, ddts, dA, _, _, dD, dbias = selective_scan_bwd(
-        x2.view(B, 2 * D, L), dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:], Ds.detach().float(),
-        dt_bias.detach().float().reshape(-1), g2.view(B, 2 * D, L), states, True, 1, 2, 2 * D, 2 * D, True, dbc_into=dxdbl)
-    dx2 = proj_dgrad(ddts, dxdbl, du, x_proj_weight, dt_projs_weight)
+    fused = dts.numel() == 0 and x2.numel() > 0   # the forward ran the fused-delta form
+    res = selective_scan_bwd(
+        x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:],
+        Ds.detach().float(), dt_bias.detach().float().reshape(-1), g2.view(B, 2 * D, L), states, True, 1, 2, 2 * D, 2 * D, True,
+        dbc_into=dxdbl, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None)
+    du, ddts, dA, _, _, dD, dbias = res[:7]
+    dx2 = proj_dgrad(ddts, dxdbl, du, x_proj_weight, dt_projs_weight)   # fused: every row of dxdbl is already in place
     dx = cross_merge2(dx2, H, W)
     dwx, dwdt = proj_wgrad(x2, xdbl, dxdbl, ddts, R)
+    if fused:
+        dwdt = res[7].view(4, D, R)
     return [dx, dwx, dwdt, dA, dD, dbias.view(4, D)]
 
 
