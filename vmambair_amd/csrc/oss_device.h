@@ -223,20 +223,79 @@ __device__ __forceinline__ void store_items_dir(T *row, int tl, int valid, int L
     }
 }
 
+// I items of one lane as loaded (not yet converted): 16-bit types I/2 words, float I words
+template <typename T, int I> struct RawItems { uint32_t w[I * sizeof(T) / 4]; };
+
+// scan positions tl .. tl+I-1 of a row (memory L-1-t for time-reversed rows); positions >= L read as 0
+template <int I, typename T>
+__device__ __forceinline__ RawItems<T, I> load_raw_dir(const T *row, int tl, int valid, int L, bool rev) {
+    RawItems<T, I> r;
+    constexpr int W = I * sizeof(T) / 4;
+    const T *p = rev ? row + (L - tl - I) : row + tl;
+    if (valid == I && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) {
+            const u32x4 q = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(p) + 4 * k);
+            r.w[4 * k] = q.x; r.w[4 * k + 1] = q.y; r.w[4 * k + 2] = q.z; r.w[4 * k + 3] = q.w;
+        }
+    } else {   // element by element, stored in MEMORY order of the block [tl, tl+I) (or its mirror image)
+#pragma unroll
+        for (int k = 0; k < W; ++k) r.w[k] = 0u;
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            const int s_ = rev ? (I - 1 - i) : i;   // scan offset held at memory slot i
+            if (s_ < valid) {
+                const T e = row[rev ? (L - 1 - tl - s_) : (tl + s_)];
+                if constexpr (sizeof(T) == 4) r.w[i] = __float_as_uint(e);
+                else r.w[i / 2] |= (uint32_t)e.v << (16 * (i & 1));
+            }
+        }
+    }
+    return r;
+}
+template <int I, typename T>
+__device__ __forceinline__ void unpack_raw_dir(const RawItems<T, I> &r, bool rev, float (&v)[I]) {
+    float m[I];
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < I; ++i) m[i] = __uint_as_float(r.w[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < I / 2; ++i) unpack2<T>(r.w[i], m[2 * i], m[2 * i + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < I; ++i) v[i] = rev ? m[I - 1 - i] : m[i];
+}
+
 // delta computed where it is consumed (include/vmambair_oss.h: dt_weight): acc[i] = sum_r w[r] * z[r][scan position tl + i],
-// r ascending, fp32 -- the dt projection of the archs (MambaSISR6_arch.py:409-411) without its (batch, dim, seqlen) output
+// r ascending, fp32 -- the dt projection of the archs (MambaSISR6_arch.py:409-411) without its (batch, dim, seqlen) output.
+// The rows are fetched four at a time so that their global loads are in flight together (a rolled loop over r serialises
+// them: one L2 round trip per rank row, measured +70 us on the u:(8,384,4096) backward).
 constexpr int kMaxDtRank = 8;
 template <int I, typename T>
 __device__ __forceinline__ void dt_project(const T *z0, int64_t rank_stride, const float *w, int R, int tl, int valid, int L,
                                            bool rev, float (&acc)[I]) {
 #pragma unroll
     for (int i = 0; i < I; ++i) acc[i] = 0.f;
-    for (int r = 0; r < R; ++r) {
-        float zz[I];
-        load_items_dir<I>(z0 + r * rank_stride, tl, valid, L, rev, zz);
-        const float wr = w[r];
 #pragma unroll
-        for (int i = 0; i < I; ++i) acc[i] = __builtin_fmaf(wr, zz[i], acc[i]);
+    for (int r0 = 0; r0 < kMaxDtRank; r0 += 4) {
+        if (r0 < R) {
+            RawItems<T, I> rz[4];
+            float wr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = min(r0 + q, R - 1);   // rows past the rank re-read the last one with weight 0
+                rz[q] = load_raw_dir<I>(z0 + r * rank_stride, tl, valid, L, rev);
+                wr[q] = (r0 + q < R) ? w[r] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zz[I];
+                unpack_raw_dir<I>(rz[q], rev, zz);
+#pragma unroll
+                for (int i = 0; i < I; ++i) acc[i] = __builtin_fmaf(wr[q], zz[i], acc[i]);
+            }
+        }
     }
 }
 

@@ -30,7 +30,7 @@ namespace oss {
 //   [0, nBC)                 dB/dC (+ d dt-factor) partials  [batch][group][tile][2 N + RP][L]
 //   [nBC, nBC + batch*dim*N) dA partials     [batch][dim][N]
 //   then dD partials [batch][dim], then ddelta_bias partials [batch][dim], then dt-weight partials [batch][dim][kMaxDtRank]
-// RP = rows of the gradient of the dt factor z (fused-delta form: dt_rank rounded up to even), else 0.
+// RP = rows of the gradient of the dt factor z (fused-delta form: dt_rank), else 0.
 struct BwdWs {
     float *bc, *dA, *dD, *db, *dW;
     int tiles, rp;
@@ -402,7 +402,7 @@ static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, fl
     const oss_scan_fwd_params &f = p.f;
     const int rows_per_group = f.dim / f.n_groups;
     const int tiles = (rows_per_group + rows_per_wg - 1) / rows_per_wg;
-    const int rp = f.dt_weight ? ((f.dt_rank + 1) & ~1) : 0;
+    const int rp = f.dt_weight ? f.dt_rank : 0;
     const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen, rp);
     const size_t need = sizeof(float) * (n_bc + (size_t)f.batch * f.dim * (f.dstate + 2 + (rp ? kMaxDtRank : 0)));
     if (!p.workspace || p.workspace_bytes < need) return OSS_ERR_WORKSPACE;

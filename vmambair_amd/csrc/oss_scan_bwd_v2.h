@@ -211,6 +211,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         const int valid = max(0, min(I, L - tl));
         const bool chunk_full = (t0 + TC <= L);
         float dl[I], gg[I], w[I], Q_[I], dd[I];
+        // FD: softplus'(delta) of the chunk is kept from here to the per-element outputs (16-bit I/O: packed pairs in the I/O
+        // type -- the materialised-delta form rounds delta itself to that type), instead of evaluating the projection twice
+        uint32_t sigp[FD ? (sizeof(T) == 4 ? I : I / 2) : 1];
         {
             float uu[I];
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
@@ -221,14 +224,30 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 #pragma unroll
                 for (int i = 0; i < I; ++i) { uu[i] = 0.f; gg[i] = 0.f; }
             }
+            float sg[I];
 #pragma unroll
             for (int i = 0; i < I; ++i) {
-                float x = dl[i] + bias;
-                if (f.delta_softplus) { float e; x = softplus_thr(x, e); }
+                const float raw_ = dl[i] + bias;
+                float x = raw_, s_ = 1.f;
+                if (f.delta_softplus) {
+                    float e;
+                    x = softplus_thr(raw_, e);
+                    if constexpr (FD) s_ = (raw_ <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;   // bwd_kernel.cuh:228-241
+                }
+                if constexpr (FD) sg[i] = (i < valid) ? s_ : 0.f;
                 dl[i] = (i < valid) ? x : 0.f;
                 w[i] = dl[i] * uu[i];
                 Q_[i] = 0.f;
                 dd[i] = 0.f;
+            }
+            if constexpr (FD) {
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int i = 0; i < I; ++i) sigp[i] = __float_as_uint(sg[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < I / 2; ++i) sigp[i] = pack2<T>(sg[2 * i], sg[2 * i + 1]);
+                }
             }
         }
         float S = 0.f;
@@ -401,26 +420,39 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             }
             tbuf ^= 1;
         }
-        // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245); u and softplus' re-derived here
+        // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245); u (and softplus' unless FD) re-derived here
         {
-            float uu[I], raw[I], du[I], dv[I];
+            float uu[I], sg[I], du[I], dv[I];
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
-            if constexpr (FD) dt_project<I>(dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, raw);
-            else load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
+            if constexpr (FD) {
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int i = 0; i < I; ++i) sg[i] = __uint_as_float(sigp[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < I / 2; ++i) unpack2<T>(sigp[i], sg[2 * i], sg[2 * i + 1]);
+                }
+            } else {
+                float raw[I];
+                load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
+#pragma unroll
+                for (int i = 0; i < I; ++i) {
+                    float s = 1.f;
+                    if (f.delta_softplus) {
+                        const float r_ = raw[i] + bias;
+                        const float e = exp2_hw(r_ * kLog2e);
+                        // d softplus = sigmoid(raw) for raw <= 20, 1 above (bwd_kernel.cuh:228-241)
+                        s = (r_ <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                    }
+                    sg[i] = (i < valid) ? s : 0.f;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < I; ++i) {
-                float s = 1.f;
-                if (f.delta_softplus) {
-                    const float r_ = raw[i] + bias;
-                    const float e = exp2_hw(r_ * kLog2e);
-                    // d softplus = sigmoid(raw) for raw <= 20, 1 above (bwd_kernel.cuh:228-241)
-                    s = (r_ <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
-                }
-                s = (i < valid) ? s : 0.f;
                 const float ui = row_valid ? uu[i] : 0.f;
                 du[i] = __builtin_fmaf(Q_[i], dl[i], Dd * gg[i]);
                 const float ddel = __builtin_fmaf(Q_[i], ui, dd[i] * kLn2);
-                dv[i] = ddel * s;
+                dv[i] = ddel * sg[i];
                 dD_acc = __builtin_fmaf(gg[i], ui, dD_acc);
                 db_acc += dv[i];
             }
@@ -429,39 +461,72 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 if constexpr (!FD) store_items_dir<I>(dd_row, tl, valid, L, rev, dv);
             }
             if constexpr (FD) {
-                // gradient of the dt factor z and of dt_weight (bwd of the archs' dt einsum, MambaSISR6_arch.py:411):
-                //   dz[r, t] = sum over the group's rows of w[d, r] * ddelta[d, t]   -> slab rounds, rank rows 2 rr, 2 rr + 1
-                //   dw[d, r] = sum over t of ddelta[d, t] * z[r, t]                   -> per-lane partial, reduced at the end
+                // backward of the archs' dt einsum (MambaSISR6_arch.py:411) on the chunk:
+                //   dw[d, r]  = sum over t of ddelta[d, t] * z[r, t]                  per row: lane r of dWv
+                //   dz[r, t]  = sum over the group's rows of w[d, r] * ddelta[d, t]   ONE slab round: every wave leaves its row of
+                //               ddelta in the slab, eight waves form the rank-R combinations for one scan position per lane
                 if (!row_valid) {
 #pragma unroll
                     for (int i = 0; i < I; ++i) dv[i] = 0.f;
                 }
-                for (int rr = 0; 2 * rr < R; ++rr) {
-                    float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;
 #pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int r = 2 * rr + h2;
-                        const bool on = r < R;
-                        float zz[I];
-                        float wr = 0.f;
-                        if (on) {
-                            load_items_dir<I>(dt_row + r * f.dt_rank_stride, tl, valid, L, rev, zz);
-                            wr = dt_w[r];
-                            float acc = 0.f;
+                for (int r0 = 0; r0 < kMaxDtRank; r0 += 4) {
+                    if (r0 < R) {
+                        RawItems<T, I> rz[4];
 #pragma unroll
-                            for (int i = 0; i < I; ++i) acc = __builtin_fmaf(dv[i], zz[i], acc);
-                            const float tot = segment_sum_to_last<LPR>(acc) + lane_get(dWv, r);
-                            dWv = lane_set(dWv, lane, r, lane_get(tot, 63));
+                        for (int q = 0; q < 4; ++q)
+                            rz[q] = load_raw_dir<I>(dt_row + min(r0 + q, R - 1) * f.dt_rank_stride, tl, valid, L, rev);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (r0 + q < R) {
+                                float zz[I], acc = 0.f;
+                                unpack_raw_dir<I>(rz[q], rev, zz);
+#pragma unroll
+                                for (int i = 0; i < I; ++i) acc = __builtin_fmaf(dv[i], zz[i], acc);
+                                const float tot = segment_sum_to_last<LPR>(acc) + lane_get(dWv, r0 + q);
+                                dWv = lane_set(dWv, lane, r0 + q, lane_get(tot, 63));
+                            }
                         }
-#pragma unroll
-                        for (int k = 0; k < I / 4; ++k)
-                            *reinterpret_cast<f32x4 *>(sb + h2 * TC + 4 * k) =
-                                f32x4{wr * dv[4 * k], wr * dv[4 * k + 1], wr * dv[4 * k + 2], wr * dv[4 * k + 3]};
                     }
-                    __syncthreads();
-                    slab_sum(2 * N + 2 * rr, 2 * N + 2 * rr + 1, par);
-                    par ^= 1;
                 }
+                float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;
+#pragma unroll
+                for (int k = 0; k < I / 4; ++k)
+                    *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{dv[4 * k], dv[4 * k + 1], dv[4 * k + 2], dv[4 * k + 3]};
+                __syncthreads();
+                {   // waves rot .. rot+7: lane = one scan position; acc[r] = sum over rows of w[row, r] * ddelta[row, t]
+                    constexpr int RZ = WAVES < 8 ? WAVES : 8;
+                    int rw = wave - rot;
+                    rw += (rw < 0) ? WAVES : 0;
+                    if (rw < RZ) {
+                        const int row0 = g * rows_per_group + tile * ROWS;   // first row of this workgroup (uniform)
+                        for (int e = rw * 64 + lane; e < TC; e += RZ * 64) {
+                            const float *src = slab + (size_t)par * ROWS * 2 * TC + e;
+                            float acc[kMaxDtRank];
+#pragma unroll
+                            for (int r = 0; r < kMaxDtRank; ++r) acc[r] = 0.f;
+#pragma unroll
+                            for (int rr = 0; rr < ROWS; ++rr) {
+                                const float v = src[rr * 2 * TC];
+                                const int drow = min(row0 + rr, g * rows_per_group + rows_per_group - 1);   // slots past the group hold zeros
+                                const float *wrow_ = f.dt_weight + (size_t)drow * R;
+#pragma unroll
+                                for (int r = 0; r < kMaxDtRank; ++r)
+                                    if (r < R) acc[r] = __builtin_fmaf(wrow_[r], v, acc[r]);
+                            }
+                            const int t = t0 + e;
+                            if (t < L) {
+                                float *dst = ws_bc + (size_t)(2 * N) * L + (rev ? (L - 1 - t) : t);
+#pragma unroll
+                                for (int r = 0; r < kMaxDtRank; ++r)
+                                    if (r < R) dst[(size_t)r * L] = acc[r];
+                            }
+                        }
+                    }
+                    rot += RZ;
+                    rot -= (rot >= WAVES) ? WAVES : 0;
+                }
+                par ^= 1;
             }
         }
         dln_c = lane_get(dl[0], 0);
