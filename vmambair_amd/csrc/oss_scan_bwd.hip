@@ -501,7 +501,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchT
     float *wdD, *wdb;
     int rc = carve_ws(p, WAVES, ws, wdD, wdb);
     if (rc != OSS_OK) return rc;
-    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC);   // two tile buffers, two slab buffers
+    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + (FD ? WAVES * kMaxDtRank : 0));   // two tile buffers, two slab buffers (+ dt weights)
     static size_t smem_enabled = 48 * 1024;
     rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD>, smem, smem_enabled,
                      (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);

@@ -111,6 +111,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sT = smem;                          // [2 buffers][B | C][NBB][TC]  tile_off layout
     float *slab = smem + 2 * 2 * NBB * TC;     // [2][ROWS][2][TC]  per-row dB / dC terms of one state, time order; two buffers
+    float *sW = slab + 2 * ROWS * 2 * TC;      // FD: [ROWS][kMaxDtRank] dt weights of the workgroup's rows (zero-padded)
 
     const oss_scan_fwd_params &f = p.f;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -201,6 +202,13 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     int par = 0;   // slab buffer of the next state
     int tbuf = 0;  // tile buffer of the current batch
     int rot = 0;   // first wave of the current state's slab sum (advances by RW per state, mod WAVES)
+    if constexpr (FD) {
+        if (tid < ROWS * kMaxDtRank) {
+            const int rr = tid / kMaxDtRank, r = tid - rr * kMaxDtRank;
+            const bool ok = tile * ROWS + rr < rows_per_group && r < R;
+            sW[tid] = ok ? f.dt_weight[(size_t)(g * rows_per_group + tile * ROWS + rr) * R + r] : 0.f;
+        }
+    }
     // tiles of the very first batch: synchronous
     stage_issue((n_chunks - 1) * TC, 0);
     stage_commit(0, 0);
@@ -499,7 +507,6 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                     int rw = wave - rot;
                     rw += (rw < 0) ? WAVES : 0;
                     if (rw < RZ) {
-                        const int row0 = g * rows_per_group + tile * ROWS;   // first row of this workgroup (uniform)
                         for (int e = rw * 64 + lane; e < TC; e += RZ * 64) {
                             const float *src = slab + (size_t)par * ROWS * 2 * TC + e;
                             float acc[kMaxDtRank];
@@ -508,11 +515,14 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 #pragma unroll
                             for (int rr = 0; rr < ROWS; ++rr) {
                                 const float v = src[rr * 2 * TC];
-                                const int drow = min(row0 + rr, g * rows_per_group + rows_per_group - 1);   // slots past the group hold zeros
-                                const float *wrow_ = f.dt_weight + (size_t)drow * R;
-#pragma unroll
-                                for (int r = 0; r < kMaxDtRank; ++r)
-                                    if (r < R) acc[r] = __builtin_fmaf(wrow_[r], v, acc[r]);
+                                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + rr * kMaxDtRank);       // LDS broadcast reads
+                                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + rr * kMaxDtRank + 4);   // (zeros past the rank)
+                                acc[0] = __builtin_fmaf(w0.x, v, acc[0]); acc[1] = __builtin_fmaf(w0.y, v, acc[1]);
+                                acc[2] = __builtin_fmaf(w0.z, v, acc[2]); acc[3] = __builtin_fmaf(w0.w, v, acc[3]);
+                                if (R > 4) {
+                                    acc[4] = __builtin_fmaf(w1.x, v, acc[4]); acc[5] = __builtin_fmaf(w1.y, v, acc[5]);
+                                    acc[6] = __builtin_fmaf(w1.z, v, acc[6]); acc[7] = __builtin_fmaf(w1.w, v, acc[7]);
+                                }
                             }
                             const int t = t0 + e;
                             if (t < L) {
