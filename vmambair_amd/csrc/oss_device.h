@@ -269,32 +269,37 @@ __device__ __forceinline__ void unpack_raw_dir(const RawItems<T, I> &r, bool rev
 
 // delta computed where it is consumed (include/vmambair_oss.h: dt_weight): acc[i] = sum_r w[r] * z[r][scan position tl + i],
 // r ascending, fp32 -- the dt projection of the archs (MambaSISR6_arch.py:409-411) without its (batch, dim, seqlen) output.
-// The rows are fetched four at a time so that their global loads are in flight together (a rolled loop over r serialises
-// them: one L2 round trip per rank row, measured +70 us on the u:(8,384,4096) backward).
+// Split in two so that a kernel can put the loads of ALL rank rows in flight together with its other chunk loads (u, dout):
+// every dependent global load is a full memory round trip (~1 us measured for rows another XCD has just written), and a loop
+// that loads, converts and accumulates row by row pays it once per row (+70 us on the u:(8,384,4096) backward).
 constexpr int kMaxDtRank = 8;
+template <typename T, int I> struct DtRows {
+    RawItems<T, I> z[kMaxDtRank];
+    float w[kMaxDtRank];
+};
 template <int I, typename T>
-__device__ __forceinline__ void dt_project(const T *z0, int64_t rank_stride, const float *w, int R, int tl, int valid, int L,
-                                           bool rev, float (&acc)[I]) {
+__device__ __forceinline__ void dt_rows_load(DtRows<T, I> &d, const T *z0, int64_t rank_stride, const float *w, int R, int tl,
+                                             int valid, int L, bool rev) {
+    // every slot is filled (slots past the rank re-read the last row with weight 0): straight-line code whose loads all issue
+    // before the first wait, and an aggregate the compiler keeps in registers
+#pragma unroll
+    for (int r = 0; r < kMaxDtRank; ++r) {
+        const int rr = min(r, R - 1);
+        d.z[r] = load_raw_dir<I>(z0 + rr * rank_stride, tl, valid, L, rev);
+        d.w[r] = (r < R) ? w[rr] : 0.f;
+    }
+}
+template <int I, typename T>
+__device__ __forceinline__ void dt_rows_apply(const DtRows<T, I> &d, int R, bool rev, float (&acc)[I]) {
 #pragma unroll
     for (int i = 0; i < I; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int r0 = 0; r0 < kMaxDtRank; r0 += 4) {
-        if (r0 < R) {
-            RawItems<T, I> rz[4];
-            float wr[4];
+    for (int r = 0; r < kMaxDtRank; ++r) {
+        if (r < R) {   // wave-uniform
+            float zz[I];
+            unpack_raw_dir<I>(d.z[r], rev, zz);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = min(r0 + q, R - 1);   // rows past the rank re-read the last one with weight 0
-                rz[q] = load_raw_dir<I>(z0 + r * rank_stride, tl, valid, L, rev);
-                wr[q] = (r0 + q < R) ? w[r] : 0.f;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float zz[I];
-                unpack_raw_dir<I>(rz[q], rev, zz);
-#pragma unroll
-                for (int i = 0; i < I; ++i) acc[i] = __builtin_fmaf(wr[q], zz[i], acc[i]);
-            }
+            for (int i = 0; i < I; ++i) acc[i] = __builtin_fmaf(d.w[r], zz[i], acc[i]);
         }
     }
 }

@@ -224,10 +224,19 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         uint32_t sigp[FD ? (sizeof(T) == 4 ? I : I / 2) : 1];
         {
             float uu[I];
-            load_items_dir<I>(u_row, tl, valid, L, rev, uu);
-            if constexpr (FD) dt_project<I>(dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, dl);
-            else load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
-            load_items_dir<I>(g_row, tl, valid, L, rev, gg);
+            if constexpr (FD) {   // every load of the chunk in flight before the first use
+                DtRows<T, I> zr;
+                dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev);
+                const RawItems<T, I> ru = load_raw_dir<I>(u_row, tl, valid, L, rev);
+                const RawItems<T, I> rg = load_raw_dir<I>(g_row, tl, valid, L, rev);
+                dt_rows_apply<I>(zr, R, rev, dl);
+                unpack_raw_dir<I>(ru, rev, uu);
+                unpack_raw_dir<I>(rg, rev, gg);
+            } else {
+                load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+                load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+                load_items_dir<I>(g_row, tl, valid, L, rev, gg);
+            }
             if (!row_valid) {  // a row slot past the end of the group must not contribute to dB/dC
 #pragma unroll
                 for (int i = 0; i < I; ++i) { uu[i] = 0.f; gg[i] = 0.f; }
@@ -431,6 +440,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         // ---- per-element outputs (bwd_kernel.cuh:151,200-203,228-245); u (and softplus' unless FD) re-derived here
         {
             float uu[I], sg[I], du[I], dv[I];
+            DtRows<T, FD ? I : 4> zr;   // FD: the rank rows again (for the dt_weight gradient), in flight together with u
+            if constexpr (FD) dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev);
             load_items_dir<I>(u_row, tl, valid, L, rev, uu);
             if constexpr (FD) {
                 if constexpr (sizeof(T) == 4) {
@@ -478,23 +489,14 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                     for (int i = 0; i < I; ++i) dv[i] = 0.f;
                 }
 #pragma unroll
-                for (int r0 = 0; r0 < kMaxDtRank; r0 += 4) {
-                    if (r0 < R) {
-                        RawItems<T, I> rz[4];
+                for (int r = 0; r < kMaxDtRank; ++r) {
+                    if (r < R) {
+                        float zz[I], acc = 0.f;
+                        unpack_raw_dir<I>(zr.z[r], rev, zz);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            rz[q] = load_raw_dir<I>(dt_row + min(r0 + q, R - 1) * f.dt_rank_stride, tl, valid, L, rev);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (r0 + q < R) {
-                                float zz[I], acc = 0.f;
-                                unpack_raw_dir<I>(rz[q], rev, zz);
-#pragma unroll
-                                for (int i = 0; i < I; ++i) acc = __builtin_fmaf(dv[i], zz[i], acc);
-                                const float tot = segment_sum_to_last<LPR>(acc) + lane_get(dWv, r0 + q);
-                                dWv = lane_set(dWv, lane, r0 + q, lane_get(tot, 63));
-                            }
-                        }
+                        for (int i = 0; i < I; ++i) acc = __builtin_fmaf(dv[i], zz[i], acc);
+                        const float tot = segment_sum_to_last<LPR>(acc) + lane_get(dWv, r);
+                        dWv = lane_set(dWv, lane, r, lane_get(tot, 63));
                     }
                 }
                 float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;

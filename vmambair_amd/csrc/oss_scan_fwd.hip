@@ -87,9 +87,15 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         float dl[I], w[I], y[I];
         {
             float uu[I];
-            load_items_dir<I>(u_row, tl, valid, L, rev, uu);
-            if (fused_dt) dt_project<I>(dt_row, p.dt_rank_stride, dt_w, p.dt_rank, tl, valid, L, rev, dl);
-            else load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+            if (fused_dt) {   // all rank rows and u in flight together, then the projection
+                DtRows<T, I> zr;
+                dt_rows_load<I>(zr, dt_row, p.dt_rank_stride, dt_w, p.dt_rank, tl, valid, L, rev);
+                load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+                dt_rows_apply<I>(zr, p.dt_rank, rev, dl);
+            } else {
+                load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+                load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
+            }
 #pragma unroll
             for (int i = 0; i < I; ++i) {
                 float x = dl[i] + bias;
