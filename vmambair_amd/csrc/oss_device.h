@@ -226,32 +226,51 @@ __device__ __forceinline__ void store_items_dir(T *row, int tl, int valid, int L
 // I items of one lane as loaded (not yet converted): 16-bit types I/2 words, float I words
 template <typename T, int I> struct RawItems { uint32_t w[I * sizeof(T) / 4]; };
 
-// scan positions tl .. tl+I-1 of a row (memory L-1-t for time-reversed rows); positions >= L read as 0
+// scan positions tl .. tl+I-1 of a row (memory L-1-t for time-reversed rows); positions >= L read as 0.
+// The vector form and the element-wise form are separate functions on purpose: a caller that fetches several rows decides
+// ONCE (raw_fast_ok for every pointer) and keeps all the vector loads in one basic block -- a per-load branch makes hipcc
+// end every branch with s_waitcnt vmcnt(0), which serialises the loads (one memory round trip each).
 template <int I, typename T>
-__device__ __forceinline__ RawItems<T, I> load_raw_dir(const T *row, int tl, int valid, int L, bool rev) {
+__device__ __forceinline__ const T *raw_block_ptr(const T *row, int tl, int L, bool rev) {
+    return rev ? row + (L - tl - I) : row + tl;
+}
+template <int I, typename T>
+__device__ __forceinline__ bool raw_fast_ok(const T *row, int tl, int valid, int L, bool rev) {
+    return valid == I && (reinterpret_cast<uintptr_t>(raw_block_ptr<I>(row, tl, L, rev)) & 15u) == 0;
+}
+template <int I, typename T>
+__device__ __forceinline__ RawItems<T, I> load_raw_fast(const T *row, int tl, int L, bool rev) {
     RawItems<T, I> r;
     constexpr int W = I * sizeof(T) / 4;
-    const T *p = rev ? row + (L - tl - I) : row + tl;
-    if (valid == I && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(raw_block_ptr<I>(row, tl, L, rev));
 #pragma unroll
-        for (int k = 0; k < W / 4; ++k) {
-            const u32x4 q = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(p) + 4 * k);
-            r.w[4 * k] = q.x; r.w[4 * k + 1] = q.y; r.w[4 * k + 2] = q.z; r.w[4 * k + 3] = q.w;
-        }
-    } else {   // element by element, stored in MEMORY order of the block [tl, tl+I) (or its mirror image)
+    for (int k = 0; k < W / 4; ++k) {
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(p + 4 * k);
+        r.w[4 * k] = q.x; r.w[4 * k + 1] = q.y; r.w[4 * k + 2] = q.z; r.w[4 * k + 3] = q.w;
+    }
+    return r;
+}
+template <int I, typename T>
+__device__ __forceinline__ RawItems<T, I> load_raw_slow(const T *row, int tl, int valid, int L, bool rev) {
+    RawItems<T, I> r;
+    constexpr int W = I * sizeof(T) / 4;
 #pragma unroll
-        for (int k = 0; k < W; ++k) r.w[k] = 0u;
+    for (int k = 0; k < W; ++k) r.w[k] = 0u;
 #pragma unroll
-        for (int i = 0; i < I; ++i) {
-            const int s_ = rev ? (I - 1 - i) : i;   // scan offset held at memory slot i
-            if (s_ < valid) {
-                const T e = row[rev ? (L - 1 - tl - s_) : (tl + s_)];
-                if constexpr (sizeof(T) == 4) r.w[i] = __float_as_uint(e);
-                else r.w[i / 2] |= (uint32_t)e.v << (16 * (i & 1));
-            }
+    for (int i = 0; i < I; ++i) {   // stored in MEMORY order of the block [tl, tl+I) (or its mirror image)
+        const int s_ = rev ? (I - 1 - i) : i;   // scan offset held at memory slot i
+        if (s_ < valid) {
+            const T e = row[rev ? (L - 1 - tl - s_) : (tl + s_)];
+            if constexpr (sizeof(T) == 4) r.w[i] = __float_as_uint(e);
+            else r.w[i / 2] |= (uint32_t)e.v << (16 * (i & 1));
         }
     }
     return r;
+}
+template <int I, typename T>
+__device__ __forceinline__ RawItems<T, I> load_raw_dir(const T *row, int tl, int valid, int L, bool rev) {
+    if (raw_fast_ok<I>(row, tl, valid, L, rev)) return load_raw_fast<I>(row, tl, L, rev);
+    return load_raw_slow<I>(row, tl, valid, L, rev);
 }
 template <int I, typename T>
 __device__ __forceinline__ void unpack_raw_dir(const RawItems<T, I> &r, bool rev, float (&v)[I]) {
@@ -277,15 +296,21 @@ template <typename T, int I> struct DtRows {
     RawItems<T, I> z[kMaxDtRank];
     float w[kMaxDtRank];
 };
+// all rank rows aligned for the vector form?
+template <int I, typename T>
+__device__ __forceinline__ bool dt_rows_fast_ok(const T *z0, int64_t rank_stride, int tl, int valid, int L, bool rev) {
+    return raw_fast_ok<I>(z0, tl, valid, L, rev) && ((rank_stride * (int64_t)sizeof(T)) & 15) == 0;
+}
+// every slot is filled (slots past the rank re-read the last row with weight 0): straight-line code whose loads all issue
+// before the first wait, and an aggregate the compiler keeps in registers.  `fast` = dt_rows_fast_ok(...), decided by the
+// caller together with its other rows.
 template <int I, typename T>
 __device__ __forceinline__ void dt_rows_load(DtRows<T, I> &d, const T *z0, int64_t rank_stride, const float *w, int R, int tl,
-                                             int valid, int L, bool rev) {
-    // every slot is filled (slots past the rank re-read the last row with weight 0): straight-line code whose loads all issue
-    // before the first wait, and an aggregate the compiler keeps in registers
+                                             int valid, int L, bool rev, bool fast) {
 #pragma unroll
     for (int r = 0; r < kMaxDtRank; ++r) {
         const int rr = min(r, R - 1);
-        d.z[r] = load_raw_dir<I>(z0 + rr * rank_stride, tl, valid, L, rev);
+        d.z[r] = fast ? load_raw_fast<I>(z0 + rr * rank_stride, tl, L, rev) : load_raw_slow<I>(z0 + rr * rank_stride, tl, valid, L, rev);
         d.w[r] = (r < R) ? w[rr] : 0.f;
     }
 }

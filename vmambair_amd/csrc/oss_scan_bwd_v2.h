@@ -226,9 +226,17 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             float uu[I];
             if constexpr (FD) {   // every load of the chunk in flight before the first use
                 DtRows<T, I> zr;
-                dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev);
-                const RawItems<T, I> ru = load_raw_dir<I>(u_row, tl, valid, L, rev);
-                const RawItems<T, I> rg = load_raw_dir<I>(g_row, tl, valid, L, rev);
+                RawItems<T, I> ru, rg;
+                if (dt_rows_fast_ok<I>(dt_row, f.dt_rank_stride, tl, valid, L, rev) && raw_fast_ok<I>(u_row, tl, valid, L, rev) &&
+                    raw_fast_ok<I>(g_row, tl, valid, L, rev)) {
+                    dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, true);
+                    ru = load_raw_fast<I>(u_row, tl, L, rev);
+                    rg = load_raw_fast<I>(g_row, tl, L, rev);
+                } else {
+                    dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, false);
+                    ru = load_raw_slow<I>(u_row, tl, valid, L, rev);
+                    rg = load_raw_slow<I>(g_row, tl, valid, L, rev);
+                }
                 dt_rows_apply<I>(zr, R, rev, dl);
                 unpack_raw_dir<I>(ru, rev, uu);
                 unpack_raw_dir<I>(rg, rev, gg);
@@ -441,8 +449,19 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         {
             float uu[I], sg[I], du[I], dv[I];
             DtRows<T, FD ? I : 4> zr;   // FD: the rank rows again (for the dt_weight gradient), in flight together with u
-            if constexpr (FD) dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev);
-            load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+            if constexpr (FD) {
+                RawItems<T, I> ru;
+                if (dt_rows_fast_ok<I>(dt_row, f.dt_rank_stride, tl, valid, L, rev) && raw_fast_ok<I>(u_row, tl, valid, L, rev)) {
+                    dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, true);
+                    ru = load_raw_fast<I>(u_row, tl, L, rev);
+                } else {
+                    dt_rows_load<I>(zr, dt_row, f.dt_rank_stride, dt_w, R, tl, valid, L, rev, false);
+                    ru = load_raw_slow<I>(u_row, tl, valid, L, rev);
+                }
+                unpack_raw_dir<I>(ru, rev, uu);
+            } else {
+                load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+            }
             if constexpr (FD) {
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll

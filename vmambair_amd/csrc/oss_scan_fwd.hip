@@ -89,9 +89,16 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
             float uu[I];
             if (fused_dt) {   // all rank rows and u in flight together, then the projection
                 DtRows<T, I> zr;
-                dt_rows_load<I>(zr, dt_row, p.dt_rank_stride, dt_w, p.dt_rank, tl, valid, L, rev);
-                load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+                RawItems<T, I> ru;
+                if (dt_rows_fast_ok<I>(dt_row, p.dt_rank_stride, tl, valid, L, rev) && raw_fast_ok<I>(u_row, tl, valid, L, rev)) {
+                    dt_rows_load<I>(zr, dt_row, p.dt_rank_stride, dt_w, p.dt_rank, tl, valid, L, rev, true);
+                    ru = load_raw_fast<I>(u_row, tl, L, rev);
+                } else {
+                    dt_rows_load<I>(zr, dt_row, p.dt_rank_stride, dt_w, p.dt_rank, tl, valid, L, rev, false);
+                    ru = load_raw_slow<I>(u_row, tl, valid, L, rev);
+                }
                 dt_rows_apply<I>(zr, p.dt_rank, rev, dl);
+                unpack_raw_dir<I>(ru, rev, uu);
             } else {
                 load_items_dir<I>(u_row, tl, valid, L, rev, uu);
                 load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
