@@ -510,19 +510,19 @@ def test_fused_delta_core_matches_materialised_core(dim, hw):
     torch.manual_seed(0)
     m = SS2D_1(d_model=dim, ssm_ratio=1, variant="srgan").to(DEV)
     x = torch.randn(2, dim, *hw, device=DEV).to(torch.bfloat16)
-    assert ops.fused_dt_supported(torch.bfloat16, 2, dim, m.dt_rank + 32, m.dt_rank, 16, hw[0] * hw[1])
     res = []
     # a fixed random cotangent: mean(LayerNorm(.)^2) is constant up to the affine part, so its gradient is rounding noise
     gw = torch.randn(2, dim, *hw, device=DEV)
     for fused in (True, False):
-        ops.FUSED_DT = fused
+        keep, ops.FUSED_DT = ops.FUSED_DT, fused
         try:
+            assert ops.fused_dt_supported(torch.bfloat16, 2, dim, m.dt_rank + 32, m.dt_rank, 16, hw[0] * hw[1]) == fused
             m.zero_grad()
             xi = x.clone().requires_grad_()
             y = m.forward_core(xi)
             (y.float() * gw).sum().backward()
         finally:
-            ops.FUSED_DT = True
+            ops.FUSED_DT = keep
         res.append((y.detach().float(), xi.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
 
     def rel(a, b):

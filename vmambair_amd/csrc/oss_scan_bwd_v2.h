@@ -249,17 +249,18 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
 #pragma unroll
                 for (int i = 0; i < I; ++i) { uu[i] = 0.f; gg[i] = 0.f; }
             }
-            float sg[I];
+            float sg[FD ? I : 1];
 #pragma unroll
             for (int i = 0; i < I; ++i) {
-                const float raw_ = dl[i] + bias;
-                float x = raw_, s_ = 1.f;
+                float x = dl[i] + bias;
                 if (f.delta_softplus) {
+                    const float raw_ = x;
                     float e;
                     x = softplus_thr(raw_, e);
-                    if constexpr (FD) s_ = (raw_ <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;   // bwd_kernel.cuh:228-241
+                    if constexpr (FD) sg[i] = (i < valid) ? ((raw_ <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f) : 0.f;   // bwd_kernel.cuh:228-241
+                } else if constexpr (FD) {
+                    sg[i] = (i < valid) ? 1.f : 0.f;
                 }
-                if constexpr (FD) sg[i] = (i < valid) ? s_ : 0.f;
                 dl[i] = (i < valid) ? x : 0.f;
                 w[i] = dl[i] * uu[i];
                 Q_[i] = 0.f;

@@ -20,7 +20,9 @@
 
 namespace oss {
 
-template <typename T, int LPR, int I, int WAVES>
+// FD: delta evaluated here from the rank-R factor (include/vmambair_oss.h: dt_weight) -- its own instantiation, so that the
+// plain form keeps the register allocation it was tuned with
+template <typename T, int LPR, int I, int WAVES, bool FD = false>
 __global__ void __launch_bounds__(WAVES * 64)
 oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
     constexpr int RPW = 64 / LPR;      // rows per wave
@@ -56,7 +58,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
     const int d_u = p.u_row_mod > 0 ? d % p.u_row_mod : d;          // directions sharing one copy of u
 
     const T *u_row = reinterpret_cast<const T *>(p.u) + b * p.u_batch_stride + d_u * p.u_d_stride;
-    const bool fused_dt = p.dt_weight != nullptr;   // delta = dt_weight[d, :] . z[b, g, :, t] evaluated here
+    constexpr bool fused_dt = FD;   // delta = dt_weight[d, :] . z[b, g, :, t] evaluated here
     const T *dt_row = reinterpret_cast<const T *>(p.delta) + b * p.delta_batch_stride +
                       (fused_dt ? g * p.dt_group_stride : d * p.delta_d_stride);
     const float *dt_w = fused_dt ? p.dt_weight + (size_t)d * p.dt_rank : nullptr;
@@ -87,7 +89,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         float dl[I], w[I], y[I];
         {
             float uu[I];
-            if (fused_dt) {   // all rank rows and u in flight together, then the projection
+            if constexpr (FD) {   // all rank rows and u in flight together, then the projection
                 DtRows<T, I> zr;
                 RawItems<T, I> ru;
                 if (dt_rows_fast_ok<I>(dt_row, p.dt_rank_stride, tl, valid, L, rev) && raw_fast_ok<I>(u_row, tl, valid, L, rev)) {
@@ -177,14 +179,17 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
     }
 }
 
-template <typename T, int LPR, int I, int WAVES>
+template <typename T, int LPR, int I, int WAVES, bool FD = false>
 static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
+    if constexpr (!FD) {
+        if (p.dt_weight) return launch_fwd<T, LPR, I, WAVES, true>(p, stream);
+    }
     constexpr int ROWS = WAVES * (64 / LPR);
     constexpr int TC = LPR * I;
     const int rows_per_group = p.dim / p.n_groups;
     const int tiles = (rows_per_group + ROWS - 1) / ROWS;
     const size_t smem = sizeof(float) * (2 * (size_t)kNB * TC + 3 * (size_t)p.dstate * ROWS);
-    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES>;
+    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD>;
     static size_t smem_enabled = 48 * 1024;  // per instantiation; raised once when a launch needs more
     if (smem > smem_enabled) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

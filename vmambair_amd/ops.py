@@ -384,8 +384,12 @@ def core_supported(D: int, R: int, N: int) -> bool:
     return R <= 32 and (2 * (R + 2 * N) + nw - 1) // nw <= 32 and (((D + nwd - 1) // nwd + 7) & ~7) <= 64
 
 
-#: ``VMAMBAIR_FUSED_DT=0`` keeps delta materialised (A-B timing / parity of the two forms)
-FUSED_DT = os.environ.get("VMAMBAIR_FUSED_DT", "1") != "0"
+#: ``VMAMBAIR_FUSED_DT=1`` evaluates delta inside the scan kernels.  OPT-IN: parity-green, but measured
+#: SLOWER on the MI355X at the headline shapes (148 vs 161 images/s; scan backward 0.367 vs 0.229 ms, forward 0.096 vs 0.081 ms at
+#: u:(8,384,4096) bf16, profiles/r02_ab_fused_delta.txt): the scans are bound by vector-ALU issue and load latency, not by HBM,
+#: so the delta / ddelta traffic the fusion removes was free, while the projection, its adjoint and the extra cross-row sum
+#: it moves into them are not; the two kernels it retires (oss_dt_fwd / oss_dt_dgrad, 13 us each) run at the HBM roof.
+FUSED_DT = os.environ.get("VMAMBAIR_FUSED_DT", "0") == "1"
 
 
 def fused_dt_supported(dtype: torch.dtype, B: int, D: int, Cc: int, R: int, N: int, L: int) -> bool:
