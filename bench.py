@@ -171,15 +171,16 @@ def bench_realsr_tiled(args):
 def collect_prof(lib):
     """all non-empty profiler buckets -> list of dicts"""
     recs = []
-    for which in (0, 1):
+    names = {0: "oss_scan_fwd_kernel", 1: "oss_scan_bwd_kernel", 2: "oss_scan_bwd_finish"}
+    for which in (0, 1, 2):
         for variant in range(16):
             for io, name in ((0, "f32"), (1, "f16"), (2, "bf16")):
-                ms, n, by = C.c_double(), C.c_longlong(), C.c_double()
-                if lib.oss_prof_collect(which, variant, io, C.byref(ms), C.byref(n), C.byref(by)) != 0:
+                ms, n, by, own = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+                if lib.oss_prof_collect2(which, variant, io, C.byref(ms), C.byref(n), C.byref(by), C.byref(own)) != 0:
                     continue
                 if n.value:
-                    recs.append(dict(kernel="oss_scan_fwd_kernel" if which == 0 else "oss_scan_bwd_kernel",
-                                     variant=variant, io=name, launches=n.value, total_ms=ms.value, alg_bytes=by.value))
+                    recs.append(dict(kernel=names[which], variant=variant, io=name, launches=n.value, total_ms=ms.value,
+                                     alg_bytes=by.value, own_bytes=own.value))
     return recs
 
 
@@ -389,11 +390,15 @@ def main():
     if rank == 0:
         recs = collect_prof(lib)
         roof = None
+        fin = {(r["variant"], r["io"]): r for r in recs if r["kernel"] == "oss_scan_bwd_finish"}
+        recs = [r for r in recs if r["kernel"] != "oss_scan_bwd_finish"]
         if recs:
             dom = max(recs, key=lambda r: r["total_ms"])
             avg_ms = dom["total_ms"] / dom["launches"]
             achieved = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
             kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}"
+            fdom = fin.get((dom["variant"], dom["io"])) if dom["kernel"] == "oss_scan_bwd_kernel" else None
+            with_fin_ms = dom["total_ms"] + (fdom["total_ms"] if fdom else 0.0)
             traffic, traffic_note = None, "no PMC record for this kernel build"
             valu_busy = None
             try:  # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
@@ -416,6 +421,13 @@ def main():
                     "valu_busy": valu_busy,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
+                    # SURVEY.md 8d asks for both: `achieved` prices the unfused-equivalent bytes (every direction its own
+                    # u / dout rows); the omni kernel's own algorithmic bytes share them between directions k, k + 2
+                    "own_alg_bytes_per_launch": round(dom["own_bytes"] / dom["launches"]),
+                    "achieved_own_GBps": round(dom["own_bytes"] / (dom["total_ms"] * 1e-3) / 1e9, 1),
+                    # the backward's finishing kernel (adds the row-tile dB/dC partials, casts; one per call) priced in
+                    "finish_avg_ms": round(fdom["total_ms"] / fdom["launches"], 4) if fdom else None,
+                    "frac_with_finish": round(dom["alg_bytes"] / (with_fin_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "all_scan_kernels": [
                         {"kernel": r["kernel"], "variant": r["variant"], "io": r["io"], "launches": r["launches"],
                          "avg_ms": round(r["total_ms"] / r["launches"], 4),

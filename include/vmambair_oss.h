@@ -345,13 +345,17 @@ int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const flo
 /* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every
  * main forward / backward kernel launch is bracketed by HIP events recorded on the launch stream.
  * oss_prof_collect synchronises those events and returns, for one bucket (which: 0 = forward
- * kernel, 1 = backward kernel; variant; io dtype), the summed kernel time, the number of launches
+ * kernel, 1 = backward main kernel, 2 = backward finishing kernel; variant; io dtype), the summed kernel time, the number of launches
  * and the summed ALGORITHMIC bytes (SURVEY.md section 8d formulas).
  * Returns 0, or OSS_ERR_SHAPE for a bucket out of range. */
 void oss_prof_enable(int on);
 void oss_prof_reset(void);
 int oss_prof_collect(int which, int variant, oss_dtype io, double *total_ms, long long *launches,
                      double *algorithmic_bytes);
+/* ... plus the kernel's OWN algorithmic bytes (tensors the omni form shares between directions counted once); which = 2
+ * selects the backward's finishing kernel (time only). */
+int oss_prof_collect2(int which, int variant, oss_dtype io, double *total_ms, long long *launches, double *algorithmic_bytes,
+                      double *own_bytes);
 
 /* HBM copy-kernel (float4 read+write) used by bench.py to measure the achievable bandwidth in
  * the same run as the scan kernels; copies n_bytes (multiple of 16) from src to dst. */

@@ -530,3 +530,10 @@ def test_fused_delta_core_matches_materialised_core(dim, hw):
     assert rel(res[0][0], res[1][0]) < 1e-2 and rel(res[0][1], res[1][1]) < 2e-2
     for k in res[1][2]:
         assert rel(res[0][2][k], res[1][2][k]) < 3e-2, k
+
+
+def test_large_dstate_falls_back_when_the_tiles_do_not_fit_lds():
+    """dstate = 250 with the 12-row / 1024-step forward variant needs 167 KiB of LDS (> 160 KiB on gfx950): the launcher takes the
+    small-shape variant instead of failing; the reference admits dstate <= 256 (selective_scan.cpp:191)"""
+    check_fwd_bwd(make_inputs(1, 24, 250, 2, 1100, torch.float32), True, torch.float32, fwd_variant=6, bwd_variant=6)
+    check_fwd_bwd(make_inputs(1, 24, 250, 2, 1100, torch.float32), True, torch.float32, fwd_variant=3, bwd_variant=10)

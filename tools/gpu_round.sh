@@ -23,6 +23,7 @@ for leg in $LEGS; do
     derain) timeout 600 python bench.py --steps 10 --warmup 3 --config deraining --no-cpu-baseline > gpurun_out/bench_derain.txt 2>gpurun_out/bench_derain.err; echo "rc=$?"; tail -1 gpurun_out/bench_derain.txt | cut -c1-300; tail -3 gpurun_out/bench_derain.err;;
     realsr) timeout 600 python bench.py --steps 3 --warmup 1 --config realsr-tiled > gpurun_out/bench_realsr.txt 2>gpurun_out/bench_realsr.err; echo "rc=$?"; tail -1 gpurun_out/bench_realsr.txt | cut -c1-400; tail -3 gpurun_out/bench_realsr.err;;
     wgradab) for t in 0 12 21 22; do VMAMBAIR_WGRAD_TILE=$t timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_wgt$t.txt 2>gpurun_out/bench_wgt$t.err; echo "wgrad tile=$t rc=$? $(tail -1 gpurun_out/bench_wgt$t.txt | cut -c1-140)"; done;;
+    pmc)    bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; echo "rc=$?"; grep -E "oss_scan" gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt | cut -c1-160;;
     prof)   ( cd /tmp && export VMAMBAIR_CONV1X1=${PROF_CONV1X1:-mfma} && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --skip-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err" ); echo "rc=$?"; python tools/prof_summary.py gpurun_out/prof/bench_results.db gpurun_out/prof_summary.txt ${PROF_WINDOW_MS:-150}; rm -rf gpurun_out/prof; tail -1 gpurun_out/prof_bench.txt | cut -c1-200;;
   esac
 done

@@ -71,7 +71,7 @@ SUM_CHUNK_BYTES = 40   # sizeof(oss_sum_chunk)
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_prof_enable", "oss_prof_reset",
-           "oss_prof_collect", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
+           "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
@@ -118,6 +118,9 @@ def load():
     lib.oss_prof_collect.restype = C.c_int
     lib.oss_prof_collect.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                      C.POINTER(C.c_double)]
+    lib.oss_prof_collect2.restype = C.c_int
+    lib.oss_prof_collect2.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.oss_dwconv3x3_fwd.restype = C.c_int
     lib.oss_dwconv3x3_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + \
         [C.c_int64] * 4 + [C.c_int, C.c_void_p]

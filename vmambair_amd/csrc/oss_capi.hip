@@ -80,12 +80,12 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
 constexpr int kProfVariants = 16;
 struct ProfBucket {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    double ms = 0.0, bytes = 0.0;
+    double ms = 0.0, bytes = 0.0, own = 0.0;
     long long launches = 0;
 };
 static std::mutex g_prof_mu;
 static std::atomic<int> g_prof_on{0};
-static ProfBucket g_prof[2][kProfVariants][3];
+static ProfBucket g_prof[3][kProfVariants][3];   // forward kernel, backward main kernel, backward finishing kernel
 static std::vector<hipEvent_t> g_event_pool;
 
 static hipEvent_t prof_event() {
@@ -94,10 +94,10 @@ static hipEvent_t prof_event() {
 }
 
 struct ProfTimer : LaunchTimer {  // begin/end bracket exactly one kernel launch
-    bool on; int which, variant, io; double bytes; hipEvent_t e0{}, e1{};
-    ProfTimer(int which_, int variant_, int io_, double bytes_)
+    bool on; int which, variant, io; double bytes, own; hipEvent_t e0{}, e1{};
+    ProfTimer(int which_, int variant_, int io_, double bytes_, double own_ = 0.0)
         : on(g_prof_on.load() != 0 && variant_ >= 0 && variant_ < kProfVariants), which(which_), variant(variant_),
-          io(io_), bytes(bytes_) {}
+          io(io_), bytes(bytes_), own(own_) {}
     void begin(hipStream_t s) override {
         if (!on) return;
         {
@@ -113,6 +113,7 @@ struct ProfTimer : LaunchTimer {  // begin/end bracket exactly one kernel launch
         ProfBucket &b = g_prof[which][variant][io];
         b.pending.emplace_back(e0, e1);
         b.bytes += bytes;
+        b.own += own;
         b.launches += 1;
     }
 };
@@ -127,6 +128,21 @@ static double bwd_alg_bytes(const oss_scan_fwd_params &p, int s) {
     const double BKL = (double)p.batch * p.dim * p.seqlen, BGNL = (double)p.batch * p.n_groups * p.dstate * p.seqlen;
     const double xb = 4.0 * p.batch * p.dim * oss_scan_num_chunks(p.seqlen) * 2 * p.dstate;
     return s * (5.0 * BKL + 4.0 * BGNL) + 4.0 * (2.0 * p.dim * p.dstate + 4.0 * p.dim) + xb;
+}
+
+// the kernel's OWN algorithmic bytes: in the omni form directions k and k + K/2 share the rows of u (u_row_mod) and of dout
+// (dout_row_mod), so those tensors are counted once (SURVEY.md 8d "fused-op accounting": both figures are reported)
+static double fwd_own_bytes(const oss_scan_fwd_params &p, int s) {
+    const double full = fwd_alg_bytes(p, s);
+    if (p.u_row_mod <= 0) return full;
+    return full - (double)s * p.batch * (p.dim - p.u_row_mod) * p.seqlen;
+}
+static double bwd_own_bytes(const oss_scan_bwd_params &q, int s) {
+    const oss_scan_fwd_params &p = q.f;
+    double v = bwd_alg_bytes(p, s);
+    if (p.u_row_mod > 0) v -= (double)s * p.batch * (p.dim - p.u_row_mod) * p.seqlen;
+    if (q.dout_row_mod > 0) v -= (double)s * p.batch * (p.dim - q.dout_row_mod) * p.seqlen;
+    return v;
 }
 
 static int check_fwd(const oss_scan_fwd_params *p) {
@@ -158,7 +174,7 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
     if (v < 0) v = scan_fwd_pick_variant(p->batch, p->dim, p->seqlen, p->dstate, p->n_groups, eb);
     g_last_fwd.store(v);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    ProfTimer prof(0, v, (int)io, fwd_alg_bytes(*p, eb));
+    ProfTimer prof(0, v, (int)io, fwd_alg_bytes(*p, eb), fwd_own_bytes(*p, eb));
     prof.begin(s);
     switch (io) {
         case OSS_F32: rc = scan_fwd_dispatch<float>(*p, v, s); break;
@@ -202,11 +218,13 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     const int v = bwd_variant_for(f.batch, f.dim, f.seqlen, f.dstate, f.n_groups);
     g_last_bwd.store(v);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    ProfTimer prof(1, v, (int)io, bwd_alg_bytes(f, io == OSS_F32 ? 4 : 2));
+    const int eb = io == OSS_F32 ? 4 : 2;
+    ProfTimer prof(1, v, (int)io, bwd_alg_bytes(f, eb), bwd_own_bytes(*p, eb));
+    ProfTimer fprof(2, v, (int)io, 0.0);   // the finishing kernel of the same call
     switch (io) {
-        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, s, &prof);
-        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, s, &prof);
-        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, s, &prof);
+        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, s, &prof, &fprof);
+        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, s, &prof, &fprof);
+        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, s, &prof, &fprof);
     }
     return OSS_ERR_SHAPE;
 }
@@ -434,12 +452,22 @@ void oss_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &k : g_prof) for (auto &v : k) for (auto &b : v) {
         for (auto &pr : b.pending) { (void)hipEventSynchronize(pr.second); g_event_pool.push_back(pr.first); g_event_pool.push_back(pr.second); }
-        b.pending.clear(); b.ms = 0.0; b.bytes = 0.0; b.launches = 0;
+        b.pending.clear(); b.ms = 0.0; b.bytes = 0.0; b.own = 0.0; b.launches = 0;
     }
 }
 
+int oss_prof_collect2(int which, int variant, oss_dtype io, double *total_ms, long long *launches, double *algorithmic_bytes,
+                      double *own_bytes) {
+    const int rc = oss_prof_collect(which, variant, io, total_ms, launches, algorithmic_bytes);
+    if (rc == OSS_OK && own_bytes) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        *own_bytes = g_prof[which][variant][(int)io].own;
+    }
+    return rc;
+}
+
 int oss_prof_collect(int which, int variant, oss_dtype io, double *total_ms, long long *launches, double *algorithmic_bytes) {
-    if (which < 0 || which > 1 || variant < 0 || variant >= kProfVariants || (int)io < 0 || (int)io > 2) return OSS_ERR_SHAPE;
+    if (which < 0 || which > 2 || variant < 0 || variant >= kProfVariants || (int)io < 0 || (int)io > 2) return OSS_ERR_SHAPE;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfBucket &b = g_prof[which][variant][(int)io];
     for (auto &pr : b.pending) {

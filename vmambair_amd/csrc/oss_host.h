@@ -3,19 +3,43 @@
 #include <hip/hip_runtime.h>
 #include "../../include/vmambair_oss.h"
 
+#include <atomic>
+
 namespace oss {
 struct bf16_t;
 struct f16_t;
 
+// Dynamic LDS above the 48 KiB default has to be enabled per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize).
+// One gate per kernel instantiation: what has been enabled so far, one lock-free slot per device, so that a process driving
+// several GPUs (or several host threads) never launches with a stale assumption.
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // gfx950: 160 KiB per workgroup
+struct LdsGate {
+    std::atomic<size_t> enabled[16] = {};
+    int ensure(const void *kern, size_t bytes) {
+        if (bytes <= 48 * 1024) return 0;
+        if (bytes > kMaxLdsBytes) return OSS_ERR_SHAPE;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t> &slot = enabled[dev & 15];
+        if (bytes <= slot.load(std::memory_order_acquire)) return 0;
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        size_t cur = slot.load(std::memory_order_relaxed);
+        while (cur < bytes && !slot.compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+        return 0;
+    }
+};
+
 template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t stream);
-// brackets the MAIN backward kernel only (not the two finishing kernels) for oss_prof_*
+// one timer brackets the MAIN backward kernel, a second one the finishing kernel (oss_prof_* buckets 1 and 2)
 struct LaunchTimer {
     virtual void begin(hipStream_t) = 0;
     virtual void end(hipStream_t) = 0;
     virtual ~LaunchTimer() = default;
 };
 template <typename T>
-int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer);
+int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer,
+                      LaunchTimer *finish_timer = nullptr);
 
 // number of row tiles the backward splits a group into for `variant` (workspace sizing)
 int scan_bwd_rows_per_wg(int variant);

@@ -577,12 +577,7 @@ static int proj_fwd_dc(int D) {
     return (((D + parts - 1) / parts) + 7) & ~7;
 }
 
-template <typename K>
-static int enable_lds(K kern, size_t bytes) {
-    if (bytes <= 48 * 1024) return 0;
-    if (bytes > 160 * 1024) return OSS_ERR_SHAPE;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
+
 
 template <typename T>
 static int proj_fwd_t(const void *x2, const float *Wx, const float *Wdt, void *xdbl, void *dts, int B, int D, int C, int R,
@@ -598,12 +593,8 @@ static int proj_fwd_t(const void *x2, const float *Wx, const float *Wdt, void *x
 #define OSS_PROJ_FWD(NQ_, RM_)                                                                              \
     do {                                                                                                    \
         auto kern = oss_proj_fwd_kernel<T, NQ_, RM_>;                                                       \
-        static size_t enabled = 48 * 1024;                                                                  \
-        if (smem > enabled) {                                                                               \
-            const int e = enable_lds(kern, smem);                                                           \
-            if (e) return e;                                                                                \
-            enabled = smem;                                                                                 \
-        }                                                                                                   \
+        static LdsGate gate;                                                                                \
+        if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;                \
         hipLaunchKernelGGL(kern, grid, block, smem, s, xp, Wx, Wdt, zp, dp, D, C, R, L, dc);               \
     } while (0)
     if (R <= 8) {
@@ -620,12 +611,8 @@ static int proj_dgrad_launch(const T *ddts, T *dxdbl, const T *du, const float *
                              int R, int L, int nw, int slice, hipStream_t s) {
     const size_t smem = proj_dgrad_lds_bytes(D, C, R);
     auto kern = oss_proj_dgrad_kernel<T, DS, RMAX, MAXT>;
-    static size_t enabled = 48 * 1024;
-    if (smem > enabled) {
-        const int e = enable_lds(kern, smem);
-        if (e) return e;
-        enabled = smem;
-    }
+    static LdsGate gate;
+    if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
     dim3 grid((L + 63) / 64, 2, B), block(64 * nw);
     hipLaunchKernelGGL(kern, grid, block, smem, s, ddts, dxdbl, du, Wx, Wdt, dx2, D, C, R, L, slice, proj_dgrad_qc(D, C));
     return (int)hipGetLastError();

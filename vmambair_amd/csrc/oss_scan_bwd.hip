@@ -397,6 +397,8 @@ oss_scan_bwd_finish(const FinishArgs a) {
 #include "oss_scan_bwd_v2.h"
 namespace oss {
 
+static thread_local LaunchTimer *g_finish_timer = nullptr;   // set by scan_bwd_dispatch around the launchers
+
 // workspace carving shared by the launchers; -> OSS_OK or OSS_ERR_WORKSPACE
 static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, float *&wdD, float *&wdb) {
     const oss_scan_fwd_params &f = p.f;
@@ -435,19 +437,16 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
     a.out_group_stride = p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : (size_t)f.dstate * f.seqlen;
     a.dz_batch_stride = p.ddt_batch_stride; a.dz_group_stride = p.ddt_group_stride; a.dz_rank_stride = p.ddt_rank_stride;
     const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + f.dim * a.R + 255) / 256);
+    if (g_finish_timer) g_finish_timer->begin(stream);
     hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(a.nblk_bc + nblk_w), dim3(256), 0, stream, a);
+    if (g_finish_timer) g_finish_timer->end(stream);
     return (int)hipGetLastError();
 }
 
 template <typename K>
-static int launch_main(K kern, size_t smem, size_t &smem_enabled, unsigned nblocks, int nthreads,
+static int launch_main(K kern, size_t smem, LdsGate &gate, unsigned nblocks, int nthreads,
                        const oss_scan_bwd_params &p, const BwdWs &ws, hipStream_t stream, LaunchTimer *timer) {
-    if (smem > smem_enabled) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        smem_enabled = smem;
-    }
+    if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
     if (timer) timer->begin(stream);
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nthreads), smem, stream, p, ws);
     if (timer) timer->end(stream);
@@ -464,8 +463,13 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     int rc = carve_ws(p, ROWS, ws, wdD, wdb);
     if (rc != OSS_OK) return rc;
     const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 2 * (size_t)SPS * ROWS * TC + 3 * (size_t)f.dstate * ROWS + ROWS);
-    static size_t smem_enabled = 48 * 1024;
-    rc = launch_main(oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB, SPS, MINW>, smem, smem_enabled,
+    if constexpr (!(I == 4 && WAVES == 4)) {
+        // large dstate: the per-row state tables no longer fit next to the tiles and slabs -> the small-shape variant.  The
+        // workspace was carved for THIS variant's row tiles, so it is carved again there (the query sizes for 4-row tiles)
+        if (smem > kMaxLdsBytes) return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
+    }
+    static LdsGate gate;
+    rc = launch_main(oss_scan_bwd_kernel<T, LPR, I, WAVES, NBB, SPS, MINW>, smem, gate,
                      (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);
@@ -482,8 +486,8 @@ static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, Lau
     if (rc != OSS_OK) return rc;
     const size_t np = (size_t)((f.dstate + 1) & ~1);
     const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + 3 * np * WAVES + WAVES);
-    static size_t smem_enabled = 48 * 1024;
-    rc = launch_main(oss_scan_bwd_pair_kernel<T, I, WAVES, NBB, MINW>, smem, smem_enabled,
+    static LdsGate gate;
+    rc = launch_main(oss_scan_bwd_pair_kernel<T, I, WAVES, NBB, MINW>, smem, gate,
                      (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);
@@ -502,8 +506,8 @@ static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchT
     int rc = carve_ws(p, WAVES, ws, wdD, wdb);
     if (rc != OSS_OK) return rc;
     const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + (FD ? WAVES * kMaxDtRank : 0));   // two tile buffers, two slab buffers (+ dt weights)
-    static size_t smem_enabled = 48 * 1024;
-    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD>, smem, smem_enabled,
+    static LdsGate gate;
+    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD>, smem, gate,
                      (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);
@@ -523,7 +527,16 @@ static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8, 12, 8, 12, 8, 6, 4};
 int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 13) ? 1 : variant]; }
 
 template <typename T>
-int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
+static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer);
+template <typename T>
+int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer, LaunchTimer *finish_timer) {
+    g_finish_timer = finish_timer;
+    const int rc = scan_bwd_dispatch_<T>(p, variant, stream, timer);
+    g_finish_timer = nullptr;
+    return rc;
+}
+template <typename T>
+static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
     if (p.f.dt_weight) {   // delta computed inside the scan: round-2 kernels only
         if (p.f.dstate > 64 || p.f.dt_rank < 1 || p.f.dt_rank > kMaxDtRank || !p.ddt || !p.ddt_weight) return OSS_ERR_SHAPE;
         if (variant < 10) variant = 13;
@@ -550,8 +563,8 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t str
     }
 }
 
-template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *);
-template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *);
-template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *);
+template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *, LaunchTimer *);
+template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *, LaunchTimer *);
+template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *, LaunchTimer *);
 
 }  // namespace oss

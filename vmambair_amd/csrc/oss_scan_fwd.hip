@@ -189,14 +189,13 @@ static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
     const int rows_per_group = p.dim / p.n_groups;
     const int tiles = (rows_per_group + ROWS - 1) / ROWS;
     const size_t smem = sizeof(float) * (2 * (size_t)kNB * TC + 3 * (size_t)p.dstate * ROWS);
-    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD>;
-    static size_t smem_enabled = 48 * 1024;  // per instantiation; raised once when a launch needs more
-    if (smem > smem_enabled) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        smem_enabled = smem;
+    if constexpr (!(LPR == 64 && I == 4 && WAVES == 4)) {
+        // large dstate: tiles + per-row carries no longer fit 160 KiB -> the small-shape variant (4 rows, 256-step chunks)
+        if (smem > kMaxLdsBytes) return launch_fwd<T, 64, 4, 4, FD>(p, stream);
     }
+    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD>;
+    static LdsGate gate;
+    if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
     const dim3 grid((unsigned)(p.batch * p.n_groups * tiles));
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
     return (int)hipGetLastError();

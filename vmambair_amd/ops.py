@@ -78,20 +78,31 @@ def deferred_finishes():
 
 def _keep(scratch: torch.Tensor, *outs) -> None:
     """keep the storages of a deferred reduction (its partials and its outputs) alive until the flush"""
+    _readers_on_main(scratch, *outs)
     if _DEFER_KEEP is not None:
         _DEFER_KEEP.append(scratch)
         for t in outs:
             if t is not None:
                 _DEFER_KEEP.append(t.detach())   # an alias: the returned tensor itself must stay unshared (see CONTRACT)
-                _DEFER_OUTS.append(t.untyped_storage().data_ptr())
+                _DEFER_OUTS.append((t.data_ptr(), t.numel()))
+
+
+def _keep_views(flat: torch.Tensor, views) -> None:
+    """a deferred output handed to autograd as several views (ChannelGateFn): every view must be adopted, so each one is
+    registered by its own address instead of the flat buffer's"""
+    if _DEFER_OUTS is not None:
+        key = (flat.data_ptr(), flat.numel())
+        if key in _DEFER_OUTS:
+            _DEFER_OUTS.remove(key)
+        _DEFER_OUTS.extend((v.data_ptr(), v.numel()) for v in views if v is not None)
 
 
 def orphaned_deferred_outputs(leaves) -> int:
     """-> how many outputs deferred so far (since the last flush) are NOT the storage of some leaf's ``.grad``: those were
     copied (cast / accumulated / cloned) before they held data, i.e. the CONTRACT above is broken for them.  Call after the
     backward, before ``flush_finishes``."""
-    owned = {p.grad.untyped_storage().data_ptr() for p in leaves if p.grad is not None}
-    return sum(1 for ptr in (_DEFER_OUTS or ()) if ptr not in owned)
+    owned = {(p.grad.data_ptr(), p.grad.numel()) for p in leaves if p.grad is not None}
+    return sum(1 for key in (_DEFER_OUTS or ()) if key not in owned)
 
 
 class FinishTable:
@@ -127,15 +138,29 @@ def flush_finishes(table: FinishTable) -> None:
         _DEFER_OUTS.clear()
 
 
+_WGRAD_MAIN: Optional[torch.cuda.Stream] = None   # the stream the current side-stream section was forked from
+
+
 def _fork_for_wgrad(*inputs: torch.Tensor):
     """-> a context under which to allocate the weight-gradient outputs and launch their kernels"""
+    global _WGRAD_MAIN
     side = _WGRAD_SIDE
     if side is None:
         return contextlib.nullcontext()
-    side.wait_stream(torch.cuda.current_stream())
+    _WGRAD_MAIN = torch.cuda.current_stream()
+    side.wait_stream(_WGRAD_MAIN)
     for t in inputs:
         t.record_stream(side)   # the allocator must not hand these blocks out again before the side stream is done
     return torch.cuda.stream(side)
+
+
+def _readers_on_main(*tensors) -> None:
+    """tensors allocated inside a ``_fork_for_wgrad`` section belong to the side stream's pool but are read on the main stream
+    (flush, casts, optimizer): tell the allocator, or a freed block could be reused on the side stream under those readers"""
+    if _WGRAD_SIDE is not None and _WGRAD_MAIN is not None and torch.cuda.current_stream() == _WGRAD_SIDE:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(_WGRAD_MAIN)
 
 
 def scan_chunk() -> int:
@@ -864,6 +889,7 @@ class ChannelGateFn(torch.autograd.Function):
         d_A, d_D, d_bias = take(2 * dc * 16, A_logs), take(2 * dc, Dsc), take(2 * dc, dt_bias)
         d_wdtc, d_wxc = take(2 * dc * Rc, Wdtc), take(2 * Cc * dc, Wxc)
         d_cinw, d_cinb = take(dc, cin_w), take(dc, cin_b)
+        _keep_views(gr, (d_cnw, d_cnb, d_coutw, d_coutb, d_A, d_D, d_bias, d_wdtc, d_wxc, d_cinw, d_cinb))
         return dy2, d_cinw, d_cinb, d_wxc, d_wdtc, d_bias, d_A, d_D, d_coutw, d_coutb, d_cnw, d_cnb, None
 
 
