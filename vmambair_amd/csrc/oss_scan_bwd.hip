@@ -367,19 +367,23 @@ struct FinishArgs {
     size_t out_group_stride;    // (batch, group) block stride of dB and of dC
     int64_t dz_batch_stride, dz_group_stride, dz_rank_stride;
 };
+// grid = (ceil(L / 256), 2 N + R output rows, batch * G + 1): no index arithmetic beyond one multiply-add per pointer; the
+// last z-slab runs the weight-gradient sums (grid-stride)
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_scan_bwd_finish(const FinishArgs a) {
-    if (blockIdx.x >= a.nblk_bc) {
-        finish_w((int)((blockIdx.x - a.nblk_bc) * 256 + threadIdx.x), a.ws_dA, a.ws_dD, a.ws_db, a.dA, a.dD, a.db, a.batch, a.dim,
-                 a.N, a.A_log, a.A_d_stride, a.ws_dW, a.dW, a.R);
+    const size_t n_bg = (size_t)a.batch * a.G;
+    if (blockIdx.z >= n_bg) {
+        const int total_w = a.dim * a.N + a.dim + a.dim * a.R;
+        const int stride = (int)(gridDim.x * gridDim.y) * 256;
+        for (int i = (int)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x; i < total_w; i += stride)
+            finish_w(i, a.ws_dA, a.ws_dD, a.ws_db, a.dA, a.dD, a.db, a.batch, a.dim, a.N, a.A_log, a.A_d_stride, a.ws_dW, a.dW, a.R);
         return;
     }
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.total) return;
-    const size_t rows_out = 2 * (size_t)a.N + a.R, pt = (2 * (size_t)a.N + a.RP) * a.L;   // outputs / partial floats per (b, g)
-    const size_t bg = i / (rows_out * a.L), rem = i - bg * rows_out * a.L;
-    const size_t row = rem / a.L, t = rem - row * a.L;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.L) return;
+    const size_t row = blockIdx.y, bg = blockIdx.z;
+    const size_t pt = (2 * (size_t)a.N + a.RP) * a.L;   // partial floats per (b, g, tile)
     const float *base = a.ws_bc + bg * a.tiles * pt + row * a.L + t;
     float s = 0.f;
     for (int k = 0; k < a.tiles; ++k) s += base[(size_t)k * pt];
@@ -436,9 +440,10 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
     a.A_log = f.a_log_form ? f.A : nullptr; a.A_d_stride = f.A_d_stride;
     a.out_group_stride = p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : (size_t)f.dstate * f.seqlen;
     a.dz_batch_stride = p.ddt_batch_stride; a.dz_group_stride = p.ddt_group_stride; a.dz_rank_stride = p.ddt_rank_stride;
-    const unsigned nblk_w = (unsigned)((f.dim * f.dstate + f.dim + f.dim * a.R + 255) / 256);
+    if ((size_t)f.batch * f.n_groups + 1 > 65535 || 2 * f.dstate + a.R > 65535) return OSS_ERR_SHAPE;
+    const dim3 grid((unsigned)((f.seqlen + 255) / 256), (unsigned)(2 * f.dstate + a.R), (unsigned)(f.batch * f.n_groups + 1));
     if (g_finish_timer) g_finish_timer->begin(stream);
-    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, dim3(a.nblk_bc + nblk_w), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(oss_scan_bwd_finish<T>, grid, dim3(256), 0, stream, a);
     if (g_finish_timer) g_finish_timer->end(stream);
     return (int)hipGetLastError();
 }

@@ -123,10 +123,21 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     const int L = f.seqlen, N = f.dstate, G = f.n_groups;
     const int rows_per_group = f.dim / G;
     const int tiles_per_group = ws.tiles;
-    int bid = blockIdx.x;
-    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
-    const int g = bid % G;
-    const int b = bid / G;
+    // workgroup -> (batch, group, row tile).  The row tiles of one (batch, group) read the same B / C rows; consecutive
+    // workgroup ids go round-robin over the 8 XCDs (each with its own L2), so when the (batch, group) count divides by 8 the
+    // tiles of a group are given ids with the same residue mod 8: they then share one L2's copy of B / C instead of fetching
+    // it eight times (speed only -- nothing depends on where a workgroup runs).
+    int bid = blockIdx.x, tile, bg;
+    if ((f.batch * G) % 8 == 0) {
+        const int xcd = bid & 7, s_ = bid >> 3;
+        bg = (s_ / tiles_per_group) * 8 + xcd;
+        tile = s_ % tiles_per_group;
+    } else {
+        tile = bid % tiles_per_group;
+        bg = bid / tiles_per_group;
+    }
+    const int g = bg % G;
+    const int b = bg / G;
     const int row_in_group = tile * ROWS + wrow;
     const bool row_valid = row_in_group < rows_per_group;
     const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
