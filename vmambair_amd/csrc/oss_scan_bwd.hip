@@ -386,7 +386,13 @@ oss_scan_bwd_finish(const FinishArgs a) {
     const size_t pt = (2 * (size_t)a.N + a.RP) * a.L;   // partial floats per (b, g, tile)
     const float *base = a.ws_bc + bg * a.tiles * pt + row * a.L + t;
     float s = 0.f;
-    for (int k = 0; k < a.tiles; ++k) s += base[(size_t)k * pt];
+    for (int k0 = 0; k0 < a.tiles; k0 += 8) {   // eight loads in flight, added in tile order (same sum as a rolled loop)
+        float v8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v8[k] = (k0 + k < a.tiles) ? base[(size_t)(k0 + k) * pt] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v8[k];
+    }
     const T v = from_f32<T>(s);
     if (row < (size_t)a.N) reinterpret_cast<T *>(a.dB)[bg * a.out_group_stride + row * a.L + t] = v;
     else if (row < 2 * (size_t)a.N) reinterpret_cast<T *>(a.dC)[bg * a.out_group_stride + (row - a.N) * a.L + t] = v;
