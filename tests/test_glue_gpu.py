@@ -171,7 +171,7 @@ def test_conv1x1_wgrad_tiles_per_wave(mode, B, Cin, Cout, H, W):
 
 
 def test_conv1x1_on_strided_views_and_autocast(monkeypatch):
-    monkeypatch.setattr(ops, "CONV1X1_IMPL", "mfma")
+    monkeypatch.setattr(ops.pointwise, "CONV1X1_IMPL", "mfma")
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(32, 48, 1).to(DEV)
     big = torch.randn(2, 64, 16, 16, device=DEV)

@@ -192,6 +192,35 @@ def test_whole_module_omni_equals_reference_data_flow(variant, oracle_cpu_kernel
         assert_close(res[0][2][k], res[1][2][k], 2e-3, 2e-4 * max(1.0, float(res[1][2][k].abs().max())), k)
 
 
+def test_deferred_views_are_checked_one_by_one():
+    """a deferred flat gradient buffer handed to autograd as several views (ChannelGateFn): each view has to be adopted -- one
+    adopted view must not hide a copied one"""
+    import torch
+    from vmambair_amd import ops
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, a, b):
+            return x * (a.sum() + b.sum())
+
+        @staticmethod
+        def backward(ctx, g):
+            flat = torch.arange(6.0)
+            ops._keep(torch.zeros(2), flat)
+            va, vb = flat[:4], flat[4:]
+            ops._keep_views(flat, (va, vb))
+            return g, va, (vb.clone() if CLONE_B else vb)
+
+    for CLONE_B, want in ((False, 0), (True, 1)):
+        a, b = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(2))
+        ops._common._DEFER_KEEP, ops._common._DEFER_OUTS = [], []
+        try:
+            Fn.apply(torch.ones(3, requires_grad=True), a, b).sum().backward()
+            assert ops.orphaned_deferred_outputs([a, b]) == want
+        finally:
+            ops._common._DEFER_KEEP = ops._common._DEFER_OUTS = None
+
+
 def test_deferred_gradient_adoption_contract():
     """ops.deferred_finishes(): an unfinished gradient must be ADOPTED as the leaf's .grad (same storage), never cloned
     -- autograd clones when anybody else still references the returned tensor object, which is why ops._keep stores
@@ -213,8 +242,8 @@ def test_deferred_gradient_adoption_contract():
             if MODE == "alias":
                 ops._keep(scratch, dw)                       # what the real ops do
             else:
-                ops._DEFER_KEEP.extend([scratch, dw])        # the bug this guards against: a second owner of `dw`
-                ops._DEFER_OUTS.append(dw.untyped_storage().data_ptr())
+                ops._common._DEFER_KEEP.extend([scratch, dw])        # the bug this guards against: a second owner of `dw`
+                ops._common._DEFER_OUTS.append((dw.data_ptr(), dw.numel()))
             made.append(dw.data_ptr())
             return g, dw
 
@@ -222,13 +251,13 @@ def test_deferred_gradient_adoption_contract():
         made.clear()
         w = torch.nn.Parameter(torch.ones(4))
         x = torch.ones(3, requires_grad=True)
-        ops._DEFER_KEEP, ops._DEFER_OUTS = [], []
+        ops._common._DEFER_KEEP, ops._common._DEFER_OUTS = [], []
         try:
             Fn.apply(x, w).sum().backward()
             assert (w.grad.data_ptr() == made[0]) == (want_orphans == 0)
             assert ops.orphaned_deferred_outputs([w]) == want_orphans
         finally:
-            ops._DEFER_KEEP = ops._DEFER_OUTS = None
+            ops._common._DEFER_KEEP = ops._common._DEFER_OUTS = None
 
 
 @pytest.mark.parametrize("name,dim,variant", [("g3_block_srgan_mamber_d96.npz", 96, "srgan"),

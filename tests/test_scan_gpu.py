@@ -504,7 +504,7 @@ def test_fused_delta_scan_matches_materialised_delta(itype, L, rows, R, bv):
 
 @pytest.mark.parametrize("dim,hw", [(48, (32, 32)), (96, (24, 40))])
 def test_fused_delta_core_matches_materialised_core(dim, hw):
-    """SS2DCoreFn with and without the fused delta (ops.FUSED_DT) under bf16: same output and gradients to bf16 rounding"""
+    """SS2DCoreFn with and without the fused delta (ops.core.FUSED_DT) under bf16: same output and gradients to bf16 rounding"""
     from vmambair_amd import ops
     from vmambair_amd.oss_block import SS2D_1
     torch.manual_seed(0)
@@ -514,7 +514,7 @@ def test_fused_delta_core_matches_materialised_core(dim, hw):
     # a fixed random cotangent: mean(LayerNorm(.)^2) is constant up to the affine part, so its gradient is rounding noise
     gw = torch.randn(2, dim, *hw, device=DEV)
     for fused in (True, False):
-        keep, ops.FUSED_DT = ops.FUSED_DT, fused
+        keep, ops.core.FUSED_DT = ops.core.FUSED_DT, fused
         try:
             assert ops.fused_dt_supported(torch.bfloat16, 2, dim, m.dt_rank + 32, m.dt_rank, 16, hw[0] * hw[1]) == fused
             m.zero_grad()
@@ -522,7 +522,7 @@ def test_fused_delta_core_matches_materialised_core(dim, hw):
             y = m.forward_core(xi)
             (y.float() * gw).sum().backward()
         finally:
-            ops.FUSED_DT = keep
+            ops.core.FUSED_DT = keep
         res.append((y.detach().float(), xi.grad.float(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
 
     def rel(a, b):

@@ -1,0 +1,179 @@
+"""Shared plumbing of the ``torch.ops.vmambair`` operators: the I/O-dtype table, the operator library handle, argument
+checks, the deferred-finishing registry (one launch for all partial-sum reductions of a backward pass) and the optional
+side stream for weight gradients.  Split out of the round-1 ``ops.py``; see ``vmambair_amd/ops/__init__.py``."""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import List, Optional
+
+import torch
+
+from .. import _capi
+
+_DT = {torch.float32: _capi.OSS_F32, torch.float16: _capi.OSS_F16, torch.bfloat16: _capi.OSS_BF16}
+
+
+# Weight gradients are needed by nobody before the optimizer: a training step may hand them a second stream so that
+# they overlap the input-gradient chain (vmambair_amd/train_graph.py joins the stream before the optimizer runs).
+_WGRAD_SIDE: Optional[torch.cuda.Stream] = None
+
+
+@contextlib.contextmanager
+def wgrad_side_stream(stream: Optional[torch.cuda.Stream]):
+    """Inside this context the weight-gradient launches of the in-tree backward ops go to ``stream`` (forked from the
+    current stream).  The caller must make the current stream wait for ``stream`` before reading any weight gradient."""
+    global _WGRAD_SIDE
+    prev, _WGRAD_SIDE = _WGRAD_SIDE, stream
+    try:
+        yield
+    finally:
+        _WGRAD_SIDE = prev
+
+
+# Deferred finishing (include/vmambair_oss.h: oss_set_defer_finish / oss_flush_finishes): inside ``deferred_finishes()`` the
+# backward ops skip their small finishing launches; ``flush_finishes`` runs them all as one launch.  The scratch buffers
+# (and outputs) of the deferred reductions are kept alive here until then.
+#
+# CONTRACT: a deferred output (a weight / bias gradient) holds no valid data until the flush, so nothing may READ it
+# before: it has to reach its leaf's ``.grad`` by being adopted, not copied.  autograd's AccumulateGrad adopts an incoming
+# gradient only when the leaf has no ``.grad`` yet (set ``p.grad = None`` before the backward), dtype and layout match
+# the leaf, and nobody else references the tensor object -- hence ``_keep`` stores storage ALIASES (``detach()``), never
+# the returned tensors themselves.  ``orphaned_deferred_outputs`` checks the contract after a backward.
+_DEFER_KEEP: Optional[list] = None
+_DEFER_OUTS: Optional[list] = None
+
+
+@contextlib.contextmanager
+def deferred_finishes():
+    """Defer every partial-sum finishing launch issued inside the context; the caller MUST call ``flush_finishes`` (with the
+    context still open) before any weight gradient is read."""
+    global _DEFER_KEEP, _DEFER_OUTS
+    lib = _capi.load()
+    assert _DEFER_KEEP is None, "deferred_finishes() does not nest"
+    _DEFER_KEEP, _DEFER_OUTS = [], []
+    lib.oss_set_defer_finish(1)
+    try:
+        yield
+    finally:
+        lib.oss_set_defer_finish(0)
+        _DEFER_KEEP = _DEFER_OUTS = None
+
+
+def _keep(scratch: torch.Tensor, *outs) -> None:
+    """keep the storages of a deferred reduction (its partials and its outputs) alive until the flush"""
+    _readers_on_main(scratch, *outs)
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.append(scratch)
+        for t in outs:
+            if t is not None:
+                _DEFER_KEEP.append(t.detach())   # an alias: the returned tensor itself must stay unshared (see CONTRACT)
+                _DEFER_OUTS.append((t.data_ptr(), t.numel()))
+
+
+def _keep_views(flat: torch.Tensor, views) -> None:
+    """a deferred output handed to autograd as several views (ChannelGateFn): every view must be adopted, so each one is
+    registered by its own address instead of the flat buffer's"""
+    if _DEFER_OUTS is not None:
+        key = (flat.data_ptr(), flat.numel())
+        if key in _DEFER_OUTS:
+            _DEFER_OUTS.remove(key)
+        _DEFER_OUTS.extend((v.data_ptr(), v.numel()) for v in views if v is not None)
+
+
+def orphaned_deferred_outputs(leaves) -> int:
+    """-> how many outputs deferred so far (since the last flush) are NOT the storage of some leaf's ``.grad``: those were
+    copied (cast / accumulated / cloned) before they held data, i.e. the CONTRACT above is broken for them.  Call after the
+    backward, before ``flush_finishes``."""
+    owned = {(p.grad.data_ptr(), p.grad.numel()) for p in leaves if p.grad is not None}
+    return sum(1 for key in (_DEFER_OUTS or ()) if key not in owned)
+
+
+class FinishTable:
+    """pinned host + device buffers for the chunk table of ``oss_flush_finishes`` (allocated outside any stream capture)"""
+
+    def __init__(self, device, capacity_chunks: int):
+        self.capacity = int(capacity_chunks)
+        nbytes = max(1, self.capacity) * _capi.SUM_CHUNK_BYTES
+        self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.copied: Optional[torch.cuda.Event] = None   # the last eager host-to-device copy out of ``host``
+
+
+def pending_finish_chunks() -> int:
+    return int(_capi.load().oss_deferred_chunks())
+
+
+def flush_finishes(table: FinishTable) -> None:
+    lib = _capi.load()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if table.copied is not None and not capturing:
+        # oss_flush_finishes rewrites the pinned table and queues an asynchronous copy out of it: in eager mode the copy
+        # of the previous flush must have executed first (inside a capture the call runs once, at capture time)
+        table.copied.synchronize()
+    with torch.cuda.device(table.dev.device):
+        _capi.check(lib.oss_flush_finishes(table.host.data_ptr(), table.dev.data_ptr(), table.capacity,
+                                           torch.cuda.current_stream().cuda_stream), "oss_flush_finishes")
+        if not capturing:
+            table.copied = torch.cuda.Event()
+            table.copied.record()
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.clear()
+        _DEFER_OUTS.clear()
+
+
+_WGRAD_MAIN: Optional[torch.cuda.Stream] = None   # the stream the current side-stream section was forked from
+
+
+def _fork_for_wgrad(*inputs: torch.Tensor):
+    """-> a context under which to allocate the weight-gradient outputs and launch their kernels"""
+    global _WGRAD_MAIN
+    side = _WGRAD_SIDE
+    if side is None:
+        return contextlib.nullcontext()
+    _WGRAD_MAIN = torch.cuda.current_stream()
+    side.wait_stream(_WGRAD_MAIN)
+    for t in inputs:
+        t.record_stream(side)   # the allocator must not hand these blocks out again before the side stream is done
+    return torch.cuda.stream(side)
+
+
+def _readers_on_main(*tensors) -> None:
+    """tensors allocated inside a ``_fork_for_wgrad`` section belong to the side stream's pool but are read on the main stream
+    (flush, casts, optimizer): tell the allocator, or a freed block could be reused on the side stream under those readers"""
+    if _WGRAD_SIDE is not None and _WGRAD_MAIN is not None and torch.cuda.current_stream() == _WGRAD_SIDE:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(_WGRAD_MAIN)
+
+
+def scan_chunk() -> int:
+    """Time steps between two saved states in ``x``."""
+    return int(_capi.load().oss_scan_chunk())
+
+
+def _check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+
+def _planes(t: torch.Tensor) -> torch.Tensor:
+    """(B, C, H, W) with contiguous H*W planes (arbitrary batch / channel strides), else a copy."""
+    if t.stride(3) == 1 and t.stride(2) == t.size(3):
+        return t
+    return t.contiguous()
+
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.detach().float().contiguous()
+
+
+
+#: operator library (GPU dispatch key only -- there is deliberately no CPU kernel in the product)
+_LIB = torch.library.Library("vmambair", "DEF")

@@ -1,0 +1,97 @@
+"""Depth-wise 3x3 convolution of the OSS block (SS2D_1.conv2d, FeedForward.dwconv; MambaSISR6_arch.py:209,286-294), optionally
+with the silu that follows it fused.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import List, Optional
+
+import torch
+
+from .. import _capi
+from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
+
+
+def dwconv3x3_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: bool = False) -> List[torch.Tensor]:
+    """``F.conv2d(x, weight, bias, padding=1, groups=C)`` for a (C, 1, 3, 3) weight, HIP only -> [y, pre].
+    ``x`` fp32 / fp16 / bf16, weight and bias fp32 (master precision), fp32 accumulation.  ``act``: y = silu(conv) and
+    ``pre`` = the convolution itself (kept for the backward); otherwise ``pre`` is empty."""
+    _check(x.is_cuda and weight.is_cuda, "dwconv3x3: tensors must be on the GPU")
+    _check(x.dim() == 4 and x.dtype in _DT, "dwconv3x3: x must be (B, C, H, W) float32/float16/bfloat16")
+    B, Cc, H, W = x.shape
+    _check(tuple(weight.shape) == (Cc, 1, 3, 3), "dwconv3x3: weight must be (C, 1, 3, 3)")
+    w = weight.detach().to(torch.float32).reshape(Cc, 9).contiguous()
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    x = _planes(x)
+    y = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    pre = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device) if act else x.new_empty(0)
+    if x.numel() == 0:
+        return [y, pre]
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_dwconv3x3_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), pre.data_ptr() if act else None,
+                                          B, Cc, H, W, x.stride(0), x.stride(1), y.stride(0), y.stride(1), 0, st), "oss_dwconv3x3_fwd")
+    return [y, pre]
+
+
+def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bias: bool,
+                  pre: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """-> [dx (x dtype), dweight (C,1,3,3) fp32, dbias (C) fp32 or empty].  ``pre``: the forward ran with the fused silu;
+    dy is then the gradient of silu(conv) and ``dy * silu'(pre)`` is formed inside the weight-gradient kernel."""
+    B, Cc, H, W = x.shape
+    w = weight.detach().to(torch.float32).reshape(Cc, 9).contiguous()
+    x, dy = _planes(x), _planes(dy)
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    act = pre is not None and pre.numel() > 0
+    dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    dpre = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device) if act else None
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        # weight gradient: with the fused activation it also produces the gradient the input-gradient pass convolves
+        # (so it stays on the main stream); without it, it may overlap the input gradient on the side stream
+        with (contextlib.nullcontext() if act else _fork_for_wgrad(x, dy)):
+            dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+            db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if has_bias else None
+            part = torch.empty((B, Cc, 10), dtype=torch.float32, device=x.device)
+            _capi.check(lib.oss_dwconv3x3_wgrad(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(),
+                                                pre.data_ptr() if act else None, _ptr(dpre), B, Cc, H, W, x.stride(0), x.stride(1),
+                                                dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream),
+                        "oss_dwconv3x3_wgrad")
+            _keep(part, dw, db)
+        g = dpre if act else dy
+        _capi.check(lib.oss_dwconv3x3_fwd(_DT[x.dtype], g.data_ptr(), w.data_ptr(), None, dx.data_ptr(), None, B, Cc, H, W,
+                                          g.stride(0), g.stride(1), dx.stride(0), dx.stride(1), 1,
+                                          torch.cuda.current_stream().cuda_stream), "oss_dwconv3x3_fwd(flip)")
+    return [dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
+
+
+_LIB.define("dwconv3x3_fwd(Tensor x, Tensor weight, Tensor? bias, bool act) -> Tensor[]")
+_LIB.define("dwconv3x3_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias, Tensor? pre) -> Tensor[]")
+_LIB.impl("dwconv3x3_fwd", dwconv3x3_fwd, "CUDA")
+_LIB.impl("dwconv3x3_bwd", dwconv3x3_bwd, "CUDA")
+
+
+class DWConv3x3Fn(torch.autograd.Function):
+    """autograd node of the depth-wise conv (optionally with the silu that follows it in SS2D_1, :486)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act=False):
+        ctx.has_bias = bias is not None
+        y, pre = torch.ops.vmambair.dwconv3x3_fwd(x, weight, bias, act)
+        ctx.save_for_backward(x, weight, pre if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, pre = ctx.saved_tensors
+        dx, dw, db = torch.ops.vmambair.dwconv3x3_bwd(x, weight, dy, ctx.has_bias, pre)
+        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), None
+
+
+def dwconv3x3(x: torch.Tensor, conv: torch.nn.Conv2d, act: bool = False) -> torch.Tensor:
+    """Run a ``nn.Conv2d(C, C, 3, padding=1, groups=C)`` module's parameters through the HIP kernels
+    (``act``: followed by silu, fused)."""
+    return DWConv3x3Fn.apply(x, conv.weight, conv.bias, act)

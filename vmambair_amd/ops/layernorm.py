@@ -1,0 +1,120 @@
+"""Per-pixel LayerNorm over channels, NCHW in / NCHW out, optional fused * silu(gate) (MambaSISR6_arch.py:144-195,488-493).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import List, Optional
+
+import torch
+
+from .. import _capi
+from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
+
+
+_CODE_DT = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}
+_LN_PAIRS = {(torch.float32, torch.float32), (torch.float32, torch.float16), (torch.float32, torch.bfloat16),
+             (torch.float16, torch.float32), (torch.float16, torch.float16), (torch.bfloat16, torch.float32),
+             (torch.bfloat16, torch.bfloat16)}
+
+
+def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
+                out_code: int) -> List[torch.Tensor]:
+    """-> [y (B, C, H, W) of dtype ``out_code``, mean (B, H*W), rstd (B, H*W)]; eps = 1e-5."""
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "ln_nchw: x must be a (B, C, H, W) GPU tensor")
+    out_dtype = _CODE_DT[int(out_code)]
+    _check((x.dtype, out_dtype) in _LN_PAIRS, f"ln_nchw: unsupported dtype pair {x.dtype} -> {out_dtype}")
+    B, Cc, H, W = x.shape
+    P = H * W
+    x = _planes(x)
+    w = weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    if gate is not None:
+        gate = _planes(gate)
+        if gate.dtype != out_dtype:
+            gate = gate.to(out_dtype)
+    y = torch.empty((B, Cc, H, W), dtype=out_dtype, device=x.device)
+    mean = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        return [y, mean, rstd]
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_ln_nchw_fwd(_DT[x.dtype], _DT[out_dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
+                                        y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, Cc, P, x.stride(0), x.stride(1),
+                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1),
+                                        1e-5, st), "oss_ln_nchw_fwd")
+    return [y, mean, rstd]
+
+
+def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
+                dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, skip_grad: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """-> [dx (x dtype) (+ skip_grad), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty]"""
+    B, Cc, H, W = x.shape
+    P = H * W
+    x = _planes(x)
+    dy = dy.contiguous()
+    w = weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    if gate is not None:
+        gate = _planes(gate)
+        if gate.dtype != dy.dtype:
+            gate = gate.to(dy.dtype)
+    if skip_grad is not None:
+        skip_grad = skip_grad.to(x.dtype).contiguous()
+    dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device) if gate is not None else None
+    dw = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if bias is not None else None
+    lib = _capi.load()
+    part = torch.empty((max(1, lib.oss_ln_nchw_bwd_partial_floats(B, Cc, P)),), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = torch.cuda.current_stream().cuda_stream
+        _capi.check(lib.oss_ln_nchw_bwd(_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
+                                        dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dgate),
+                                        dw.data_ptr(), _ptr(db), part.data_ptr(), _ptr(skip_grad), B, Cc, P, x.stride(0), x.stride(1),
+                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1), st),
+                    "oss_ln_nchw_bwd")
+    _keep(part, dw, db)
+    e = x.new_empty(0, dtype=torch.float32)
+    return [dx, dgate if dgate is not None else e, dw, db if db is not None else e]
+
+
+_LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
+_LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd, "
+            "Tensor? skip_grad) -> Tensor[]")
+_LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
+_LIB.impl("ln_nchw_bwd", ln_nchw_bwd, "CUDA")
+_DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+class LayerNormNCHWFn(torch.autograd.Function):
+    """``passthrough``: also return ``x`` itself (an alias) as a second output.  A block that computes
+    ``x + f(norm(x))`` feeds that alias into the sum, so the gradient of the skip connection arrives HERE and is
+    added to dx inside the backward kernel instead of by a separate accumulation kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gate, out_dtype, passthrough=False):
+        y, mean, rstd = torch.ops.vmambair.ln_nchw_fwd(x, weight, bias, gate, _DT_CODE[out_dtype])
+        ctx.has_bias, ctx.has_gate = bias is not None, gate is not None
+        ctx.save_for_backward(x, weight, bias, gate, mean, rstd)
+        return (y, x.view_as(x)) if passthrough else y
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        x, weight, bias, gate, mean, rstd = ctx.saved_tensors
+        if dy is None:  # only the alias was used
+            return dskip, None, None, None, None, None
+        dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd, dskip)
+        return (dx, dw.to(weight.dtype), db.to(bias.dtype) if ctx.has_bias else None,
+                dgate.to(gate.dtype) if ctx.has_gate else None, None, None)
+
+
+def layer_norm_nchw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                    gate: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, passthrough: bool = False):
+    """LN over channels of an NCHW tensor (optionally times silu(gate)).  ``out_dtype`` defaults to the
+    autocast dtype when autocast is on (what the consumer conv would cast to anyway), else x.dtype."""
+    if out_dtype is None:
+        out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+    return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype, passthrough)

@@ -1,0 +1,104 @@
+"""1x1 convolutions of the OSS block as MFMA GEMMs on NCHW: bf16 / fp16 I/O, fp32 master weights (MambaSISR6_arch.py:205,211,281,329).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from typing import List, Optional
+
+import torch
+
+from .. import _capi
+from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
+
+
+def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.conv2d(x, weight, bias) [+ residual]`` for a (Cout, Cin, 1, 1) weight; x bf16/fp16 (B, Cin, H, W)."""
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "conv1x1: x must be bf16/fp16 on the GPU")
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    _check(tuple(weight.shape) == (Cout, Cin, 1, 1), "conv1x1: weight must be (Cout, Cin, 1, 1)")
+    x = _planes(x)
+    w = weight.detach().float().reshape(Cout, Cin).contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    if residual is not None:
+        _check(tuple(residual.shape) == (B, Cout, H, W), "conv1x1: residual must have the output's shape")
+        residual = residual.to(x.dtype).contiguous()
+    y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+    if x.numel() == 0:
+        return y
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        _capi.check(lib.oss_conv1x1_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(residual), y.data_ptr(), B, Cout, Cin,
+                                        H * W, x.stride(0), x.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_fwd")
+    return y
+
+
+def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bias: bool = False) -> List[torch.Tensor]:
+    """-> [dx (x dtype), dweight (Cout, Cin, 1, 1) fp32, dbias (Cout) fp32 or empty]"""
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    P = H * W
+    x, dy = _planes(x), _planes(dy)
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    w = weight.detach().float().reshape(Cout, Cin).contiguous()
+    dx = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
+    lib = _capi.load()
+    with torch.cuda.device(x.device):
+        with _fork_for_wgrad(x, dy):
+            dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
+            db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
+            part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
+            _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
+                                              Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
+                                              torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
+            _keep(part, dw, db)
+        _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
+                                          dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
+    return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]
+
+
+_LIB.define("conv1x1_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? residual) -> Tensor")
+_LIB.define("conv1x1_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias) -> Tensor[]")
+_LIB.impl("conv1x1_fwd", conv1x1_fwd, "CUDA")
+_LIB.impl("conv1x1_bwd", conv1x1_bwd, "CUDA")
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual=None):
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(x, weight)
+        return torch.ops.vmambair.conv1x1_fwd(x, weight, bias, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = torch.ops.vmambair.conv1x1_bwd(x, weight, dy, ctx.has_bias)
+        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), (dy if ctx.has_res else None)
+
+
+#: "mfma" (default) or "vendor".  16-bit activations go to the in-tree MFMA kernels (pixel-pair tiles: 4-byte
+#: activation loads and result stores, fp32 master weights narrowed in the loader, split-K weight gradient):
+#: 1 launch forward, 3 backward, against ~4 + ~8 of the vendor path (NCHW<->NHWC transposes, casts, tensor-ops
+#: around one implicit-GEMM kernel) and faster per call (profiles/r01_opbench_v14.txt).  float32 activations
+#: always take the vendor conv.  ``VMAMBAIR_CONV1X1=vendor`` keeps everything on the vendor path (A-B timing).
+CONV1X1_IMPL = os.environ.get("VMAMBAIR_CONV1X1", "mfma")
+
+
+def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The 1x1 projections of the block (in_conv / out_conv / project_in / project_out,
+    MambaSISR6_arch.py:205,211,281,329): in-tree MFMA kernels for 16-bit activations (under autocast fp32
+    inputs are narrowed first, as autocast would), vendor conv otherwise.  ``residual``: the block's skip
+    connection, added in the kernel's epilogue (``x + attn(norm1(x))``, :515-516)."""
+    if CONV1X1_IMPL == "mfma" and x.is_cuda:
+        if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        if x.dtype in (torch.bfloat16, torch.float16):
+            if residual is not None and residual.dtype != x.dtype:  # e.g. an fp32 stream: keep torch's type promotion
+                return residual + Conv1x1Fn.apply(x, conv.weight, conv.bias, None)
+            return Conv1x1Fn.apply(x, conv.weight, conv.bias, residual)
+    y = conv(x)
+    return y if residual is None else residual + y

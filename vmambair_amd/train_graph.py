@@ -77,7 +77,7 @@ class GraphedTrainStep:
                 if ".conv_cin." in name or ".conv_cout." in name:
                     continue  # consumed in fp32 by the channel branch
                 dense_conv = isinstance(m, torch.nn.Conv2d) and m.groups == 1  # depth-wise convs run on our fp32-weight kernel
-                if dense_conv and m.kernel_size == (1, 1) and _ops.CONV1X1_IMPL == "mfma" and owner.rsplit(".", 1)[-1] in (
+                if dense_conv and m.kernel_size == (1, 1) and _ops.pointwise.CONV1X1_IMPL == "mfma" and owner.rsplit(".", 1)[-1] in (
                         "in_conv", "out_conv", "project_in", "project_out", "reduce_chan_level2", "reduce_chan_level3"):
                     continue  # the MFMA 1x1 kernels read the fp32 masters and narrow them in their loader
                 # x_proj_weight / dt_projs_weight: the fused spatial core (SS2DCoreFn) reads the fp32 masters
