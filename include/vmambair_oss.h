@@ -330,7 +330,9 @@ int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int he
  * (SS2D_1: y1 * act(z), :488-493).  mean / rstd: (batch, pixels) float, written by fwd, read by bwd.
  * bwd: partials = oss_ln_nchw_bwd_partial_floats(batch, channels, pixels) floats of scratch
  * (per-workgroup dweight / dbias sums, combined in a fixed order by a finishing kernel).  skip_grad (x_type,
- * contiguous like dx, or NULL) is added to dx: the gradient arriving over the block's skip connection. */
+ * contiguous like dx, or NULL) is added to dx: the gradient arriving over the block's skip connection.
+ * dgate_batch_stride: element stride between the images of dgate (0 = channels * pixels): SS2D_1 splits one tensor into x | z
+ * (MambaSISR6_arch.py:487), and the gradient of the gate z is written straight into its half of that tensor's gradient. */
 size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels);
 int oss_ln_nchw_fwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
                     const void *gate, void *y, float *mean, float *rstd, int batch, int channels, int pixels,
@@ -340,7 +342,7 @@ int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const flo
                     const void *gate, const void *dy, const float *mean, const float *rstd, void *dx, void *dgate,
                     float *dweight, float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels,
                     int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
-                    int64_t gate_channel_stride, oss_stream_t stream);
+                    int64_t gate_channel_stride, int64_t dgate_batch_stride, oss_stream_t stream);
 
 /* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every
  * main forward / backward kernel launch is bracketed by HIP events recorded on the launch stream.

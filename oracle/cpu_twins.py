@@ -34,7 +34,7 @@ def install():
         pre = F.conv2d(x.float(), weight.float(), None if bias is None else bias.float(), padding=1, groups=x.shape[1])
         return [(F.silu(pre) if act else pre).to(x.dtype), pre.to(x.dtype) if act else torch.empty(0)]
 
-    def dw_bwd(x, weight, dy, has_bias, pre=None):
+    def dw_bwd(x, weight, dy, has_bias, pre=None, dx_into=None):
         xx = x.detach().float().requires_grad_()
         ww = weight.detach().float().requires_grad_()
         g = dy.float()
@@ -47,7 +47,11 @@ def install():
             y = F.conv2d(xx, ww, None, padding=1, groups=x.shape[1])
         dx, dw = torch.autograd.grad(y, (xx, ww), g)
         db = g.sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)
-        return [dx.to(x.dtype), dw, db]
+        dx = dx.to(x.dtype)
+        if dx_into is not None and dx_into.dtype == dx.dtype:   # one half of the gradient of a split tensor (ops.PairGrad)
+            dx_into.copy_(dx)
+            dx = dx_into
+        return [dx, dw, db]
 
     def _mirror(t, G_or_rows, start, per):  # flip time of groups >= start (per rows each)
         t = t.clone()
@@ -107,7 +111,7 @@ def install():
         B, C, H, W = x.shape
         return [y.to(codes[out_code]), mu.reshape(B, H * W), rstd.reshape(B, H * W)]
 
-    def ln_bwd(x, weight, bias, gate, dy, mean, rstd, skip_grad=None):
+    def ln_bwd(x, weight, bias, gate, dy, mean, rstd, skip_grad=None, dgate_into=None):
         leaves = [x.detach().float().requires_grad_(), weight.detach().float().requires_grad_()]
         bb = bias.detach().float().requires_grad_() if bias is not None else None
         gg = gate.detach().float().requires_grad_() if gate is not None else None
@@ -120,6 +124,9 @@ def install():
         dg = gr.pop(0).to(dy.dtype) if gg is not None else torch.empty(0)
         if skip_grad is not None:
             dx = dx + skip_grad.float()
+        if dgate_into is not None and gg is not None and dgate_into.dtype == dg.dtype:
+            dgate_into.copy_(dg)
+            dg = dgate_into
         return [dx.to(x.dtype), dg, dw, db]
 
     def _core_ref(x, wx, wdt, A_logs, Ds, dt_bias):

@@ -280,3 +280,48 @@ def test_compact_block_fixtures_match_host_mirrors(name, dim, variant, oracle_cp
         if k.endswith("conv_cout.bias"):
             continue
         assert_close(p.grad.reshape(-1)[::gs], z["grad." + k], 5e-3, 1e-3 * max(1.0, float(z["gradmax." + k])), k)
+
+
+def test_split_halves_gradients_land_in_one_buffer(oracle_cpu_kernel):
+    """x, z = xz.chunk(2, 1) of SS2D_1 (MambaSISR6_arch.py:487): the depth-wise conv and the gated LayerNorm write d x and d z
+    into the halves of ONE buffer (ops.PairGrad) and the split's backward hands that buffer on without a cat; a producer that
+    ignores the offer still gives the right gradient through the cat fallback"""
+    import torch
+    from vmambair_amd import ops
+    torch.manual_seed(0)
+    xz = torch.randn(2, 8, 5, 6, requires_grad=True)
+    a, b, pair = ops.split_halves(xz)
+    assert pair is not None and torch.equal(a, xz[:, :4]) and torch.equal(b, xz[:, 4:])
+    ga, gb = pair.half(0, a), pair.half(1, b)
+    ga.copy_(torch.full_like(a, 2.0))
+    gb.copy_(torch.full_like(b, 3.0))
+    base = pair.buf.data_ptr()
+    torch.autograd.backward([a, b], [ga, gb])
+    assert xz.grad.data_ptr() == base, "the buffer itself became the gradient"
+    assert torch.equal(xz.grad[:, :4], torch.full_like(a, 2.0)) and torch.equal(xz.grad[:, 4:], torch.full_like(b, 3.0))
+    # fallback: gradients that are NOT the offered halves
+    xz2 = torch.randn(2, 8, 5, 6, requires_grad=True)
+    a2, b2, pair2 = ops.split_halves(xz2)
+    pair2.half(0, a2)
+    torch.autograd.backward([a2, b2], [torch.ones_like(a2), 2 * torch.ones_like(b2)])
+    assert torch.equal(xz2.grad, torch.cat([torch.ones_like(a2), 2 * torch.ones_like(b2)], 1))
+    # no gradient recording: plain views, no buffer
+    with torch.no_grad():
+        assert ops.split_halves(xz)[2] is None
+    # whole module: same input gradient as with a plain chunk
+    from vmambair_amd.oss_block import SS2D_1
+    m = SS2D_1(d_model=16, ssm_ratio=1, variant="srgan")
+    x = torch.randn(1, 16, 6, 5)
+    g = torch.randn(1, 16, 6, 5)
+    x1 = x.clone().requires_grad_()
+    m(x1).backward(g)
+    ref = x1.grad.clone()
+    keep = ops.split_halves
+    import vmambair_amd.oss_block as blk
+    blk.split_halves = lambda t: (*t.chunk(2, dim=1), None)
+    try:
+        x2 = x.clone().requires_grad_()
+        m(x2).backward(g)
+    finally:
+        blk.split_halves = keep
+    assert torch.allclose(x2.grad, ref, rtol=1e-6, atol=1e-7)

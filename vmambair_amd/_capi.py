@@ -131,7 +131,7 @@ def load():
     lib.oss_ln_nchw_bwd_partial_floats.restype = C.c_size_t
     lib.oss_ln_nchw_bwd_partial_floats.argtypes = [C.c_int] * 3
     lib.oss_ln_nchw_bwd.restype = C.c_int
-    lib.oss_ln_nchw_bwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 13 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_void_p]
+    lib.oss_ln_nchw_bwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 13 + [C.c_int] * 3 + [C.c_int64] * 5 + [C.c_void_p]
     lib.oss_merge4.restype = C.c_int
     lib.oss_merge4.argtypes = [C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     lib.oss_conv1x1_fwd.restype = C.c_int

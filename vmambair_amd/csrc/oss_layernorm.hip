@@ -145,7 +145,8 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
                        const TY *__restrict__ gate, const TY *__restrict__ dy, const float *__restrict__ mean_in,
                        const float *__restrict__ rstd_in, TX *__restrict__ dx, TY *__restrict__ dgate,
                        float *__restrict__ part /*[nblk][2][C]*/, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb,
-                       int64_t gsc, const TX *__restrict__ res /* (B, C, P) or NULL: added to dx (gradient of a skip connection) */) {
+                       int64_t gsc, const TX *__restrict__ res /* (B, C, P) or NULL: added to dx (gradient of a skip connection) */,
+                       int64_t dgsb /* batch stride of dgate (channel stride P): lets it land in one half of a wider buffer */) {
     __shared__ float red[2][kLnMaxWaves * 64 * V];
     constexpr int NI = CPW > 0 ? CPW : 1;
     const int b = blockIdx.y;
@@ -213,7 +214,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     for (int u = 0; u < V; ++u) { m1[u] = s1[u] / (float)C; m2[u] = s2[u] / (float)C; }
     TX *dxp = dx + (size_t)b * C * P + pc;
     const TX *rsp = res ? res + (size_t)b * C * P + pc : nullptr;
-    TY *dgp = GATE ? dgate + (size_t)b * C * P + pc : nullptr;
+    TY *dgp = GATE ? dgate + (size_t)b * dgsb + pc : nullptr;
     auto second = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
         const float wc = w[c], bc = with_bias ? bias[c] : 0.f;
         float d[V], dg[V];
@@ -329,9 +330,10 @@ static int ln_fwd_t(const void *x, const float *w, const float *bias, const void
 template <typename TX, typename TY>
 static int ln_bwd_t(const void *x, const float *w, const float *bias, const void *gate, const void *dy, const float *mean,
                     const float *rstd, void *dx, void *dgate, float *dw, float *db, float *part, int B, int C, int P,
-                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res) {
+                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res, int64_t dgsb) {
+    if (dgsb <= 0) dgsb = (int64_t)C * P;
     const int nw = ln_waves(B, C, P);
-    const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, dy, dx) &&
+    const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, dy, dx) && dgsb % 2 == 0 &&
                        ((reinterpret_cast<uintptr_t>(dgate) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd) |
                          reinterpret_cast<uintptr_t>(res)) & 7u) == 0;
     const TX *rp = reinterpret_cast<const TX *>(res);
@@ -343,8 +345,8 @@ static int ln_bwd_t(const void *x, const float *w, const float *bias, const void
     const TY *dyp = reinterpret_cast<const TY *>(dy);
     TX *dxp = reinterpret_cast<TX *>(dx);
     TY *dgp = reinterpret_cast<TY *>(dgate);
-    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, true, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp);
-    else      OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, false, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp);
+    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, true, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp, dgsb);
+    else      OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, false, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp, dgsb);
     if (defer_finish())
         defer_sum(part, nblk, (size_t)2 * C, (size_t)(db ? 2 : 1) * C, dw, (size_t)C, db);
     else
@@ -372,8 +374,9 @@ int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const
 
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
-                float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res) {
-    OSS_LN_DISPATCH(ln_bwd_t, x, w, bias, gate, dy, mean, rstd, dx, dgate, dw, db, part, B, C, P, xsb, xsc, gsb, gsc, s, res)
+                float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res,
+                int64_t dgsb) {
+    OSS_LN_DISPATCH(ln_bwd_t, x, w, bias, gate, dy, mean, rstd, dx, dgate, dw, db, part, B, C, P, xsb, xsc, gsb, gsc, s, res, dgsb)
 }
 
 }  // namespace oss

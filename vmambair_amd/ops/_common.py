@@ -177,3 +177,54 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 #: operator library (GPU dispatch key only -- there is deliberately no CPU kernel in the product)
 _LIB = torch.library.Library("vmambair", "DEF")
+
+
+# ---------------------------------------------------------------------------------------------
+# a tensor split into two channel halves whose gradients are produced by two different kernels
+# ---------------------------------------------------------------------------------------------
+class PairGrad:
+    """Gradient buffer of ``xz`` for ``x, z = split_halves(xz)`` (SS2D_1: ``x, z = xz.chunk(2, dim=1)``, MambaSISR6_arch.py:487).
+    The backward kernels that produce d x and d z (depth-wise conv, gated LayerNorm) write into the two halves of ONE
+    (B, 2 C, H, W) buffer, so autograd's ``cat`` of the two gradients (14 us per block) disappears."""
+
+    def __init__(self):
+        self.buf = None
+
+    def half(self, idx: int, like: torch.Tensor) -> torch.Tensor:
+        B, Cc, H, W = like.shape
+        if self.buf is None:
+            self.buf = torch.empty((B, 2 * Cc, H, W), dtype=like.dtype, device=like.device)
+        return self.buf[:, idx * Cc:(idx + 1) * Cc]
+
+
+class _SplitHalvesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xz):
+        ctx.pair = PairGrad()
+        a, b = xz.chunk(2, dim=1)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        buf = ctx.pair.buf
+        ctx.pair.buf = None
+        if buf is not None and ga is not None and gb is not None:
+            Cc = buf.shape[1] // 2
+            if ga.data_ptr() == buf.data_ptr() and gb.data_ptr() == buf[:, Cc:].data_ptr() and \
+                    ga.stride() == buf.stride() and gb.stride() == buf.stride() and ga.dtype == buf.dtype == gb.dtype:
+                return buf   # both halves were written in place
+        if ga is None or gb is None:
+            ref = ga if ga is not None else gb
+            ga = torch.zeros_like(ref) if ga is None else ga
+            gb = torch.zeros_like(ref) if gb is None else gb
+        return torch.cat([ga, gb], dim=1)
+
+
+def split_halves(xz: torch.Tensor):
+    """-> (x, z, pair): the two channel halves of ``xz`` and the ``PairGrad`` their gradient producers may write into
+    (``None`` when no gradient is being recorded)"""
+    if not (torch.is_grad_enabled() and xz.requires_grad):
+        a, b = xz.chunk(2, dim=1)
+        return a, b, None
+    a, b = _SplitHalvesFn.apply(xz)
+    return a, b, getattr(a.grad_fn, "pair", None)

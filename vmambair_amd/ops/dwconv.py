@@ -37,16 +37,21 @@ def dwconv3x3_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
 
 
 def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bias: bool,
-                  pre: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                  pre: Optional[torch.Tensor] = None, dx_into: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """-> [dx (x dtype), dweight (C,1,3,3) fp32, dbias (C) fp32 or empty].  ``pre``: the forward ran with the fused silu;
-    dy is then the gradient of silu(conv) and ``dy * silu'(pre)`` is formed inside the weight-gradient kernel."""
+    dy is then the gradient of silu(conv) and ``dy * silu'(pre)`` is formed inside the weight-gradient kernel.
+    ``dx_into``: a (B, C, H, W) view with contiguous planes (e.g. one half of a wider buffer) that receives dx."""
     B, Cc, H, W = x.shape
     w = weight.detach().to(torch.float32).reshape(Cc, 9).contiguous()
     x, dy = _planes(x), _planes(dy)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)
     act = pre is not None and pre.numel() > 0
-    dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    if dx_into is not None and dx_into.dtype == x.dtype and tuple(dx_into.shape) == (B, Cc, H, W) and \
+            dx_into.stride(3) == 1 and dx_into.stride(2) == W:
+        dx = dx_into
+    else:
+        dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
     dpre = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device) if act else None
     lib = _capi.load()
     with torch.cuda.device(x.device):
@@ -69,7 +74,7 @@ def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_b
 
 
 _LIB.define("dwconv3x3_fwd(Tensor x, Tensor weight, Tensor? bias, bool act) -> Tensor[]")
-_LIB.define("dwconv3x3_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias, Tensor? pre) -> Tensor[]")
+_LIB.define("dwconv3x3_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias, Tensor? pre, Tensor? dx_into) -> Tensor[]")
 _LIB.impl("dwconv3x3_fwd", dwconv3x3_fwd, "CUDA")
 _LIB.impl("dwconv3x3_bwd", dwconv3x3_bwd, "CUDA")
 
@@ -78,8 +83,9 @@ class DWConv3x3Fn(torch.autograd.Function):
     """autograd node of the depth-wise conv (optionally with the silu that follows it in SS2D_1, :486)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act=False):
+    def forward(ctx, x, weight, bias, act=False, grad_into=None):
         ctx.has_bias = bias is not None
+        ctx.grad_into = grad_into   # (PairGrad, half index) or None: where the input gradient should land
         y, pre = torch.ops.vmambair.dwconv3x3_fwd(x, weight, bias, act)
         ctx.save_for_backward(x, weight, pre if act else None)
         return y
@@ -87,11 +93,12 @@ class DWConv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, pre = ctx.saved_tensors
-        dx, dw, db = torch.ops.vmambair.dwconv3x3_bwd(x, weight, dy, ctx.has_bias, pre)
-        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), None
+        into = ctx.grad_into[0].half(ctx.grad_into[1], x) if ctx.grad_into is not None else None
+        dx, dw, db = torch.ops.vmambair.dwconv3x3_bwd(x, weight, dy, ctx.has_bias, pre, into)
+        return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), None, None
 
 
-def dwconv3x3(x: torch.Tensor, conv: torch.nn.Conv2d, act: bool = False) -> torch.Tensor:
+def dwconv3x3(x: torch.Tensor, conv: torch.nn.Conv2d, act: bool = False, grad_into=None) -> torch.Tensor:
     """Run a ``nn.Conv2d(C, C, 3, padding=1, groups=C)`` module's parameters through the HIP kernels
-    (``act``: followed by silu, fused)."""
-    return DWConv3x3Fn.apply(x, conv.weight, conv.bias, act)
+    (``act``: followed by silu, fused; ``grad_into``: ``(PairGrad, half)`` from ``split_halves``)."""
+    return DWConv3x3Fn.apply(x, conv.weight, conv.bias, act, grad_into)

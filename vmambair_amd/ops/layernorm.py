@@ -49,8 +49,10 @@ def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
-                dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, skip_grad: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
-    """-> [dx (x dtype) (+ skip_grad), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty]"""
+                dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, skip_grad: Optional[torch.Tensor] = None,
+                dgate_into: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """-> [dx (x dtype) (+ skip_grad), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty].  ``dgate_into``: a
+    (B, C, H, W) view with channel stride H*W (one half of a wider buffer) that receives dgate."""
     B, Cc, H, W = x.shape
     P = H * W
     x = _planes(x)
@@ -64,7 +66,13 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if skip_grad is not None:
         skip_grad = skip_grad.to(x.dtype).contiguous()
     dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
-    dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device) if gate is not None else None
+    dgate = None
+    if gate is not None:
+        if dgate_into is not None and dgate_into.dtype == dy.dtype and tuple(dgate_into.shape) == (B, Cc, H, W) and \
+                dgate_into.stride(3) == 1 and dgate_into.stride(2) == W and dgate_into.stride(1) == P:
+            dgate = dgate_into
+        else:
+            dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device)
     dw = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if bias is not None else None
     lib = _capi.load()
@@ -74,8 +82,8 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         _capi.check(lib.oss_ln_nchw_bwd(_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
                                         dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dgate),
                                         dw.data_ptr(), _ptr(db), part.data_ptr(), _ptr(skip_grad), B, Cc, P, x.stride(0), x.stride(1),
-                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1), st),
-                    "oss_ln_nchw_bwd")
+                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1),
+                                        0 if dgate is None else dgate.stride(0), st), "oss_ln_nchw_bwd")
     _keep(part, dw, db)
     e = x.new_empty(0, dtype=torch.float32)
     return [dx, dgate if dgate is not None else e, dw, db if db is not None else e]
@@ -83,7 +91,7 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 _LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
 _LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd, "
-            "Tensor? skip_grad) -> Tensor[]")
+            "Tensor? skip_grad, Tensor? dgate_into) -> Tensor[]")
 _LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
 _LIB.impl("ln_nchw_bwd", ln_nchw_bwd, "CUDA")
 _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -95,9 +103,10 @@ class LayerNormNCHWFn(torch.autograd.Function):
     added to dx inside the backward kernel instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gate, out_dtype, passthrough=False):
+    def forward(ctx, x, weight, bias, gate, out_dtype, passthrough=False, gate_grad_into=None):
         y, mean, rstd = torch.ops.vmambair.ln_nchw_fwd(x, weight, bias, gate, _DT_CODE[out_dtype])
         ctx.has_bias, ctx.has_gate = bias is not None, gate is not None
+        ctx.gate_grad_into = gate_grad_into   # (PairGrad, half index) or None
         ctx.save_for_backward(x, weight, bias, gate, mean, rstd)
         return (y, x.view_as(x)) if passthrough else y
 
@@ -105,16 +114,20 @@ class LayerNormNCHWFn(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         x, weight, bias, gate, mean, rstd = ctx.saved_tensors
         if dy is None:  # only the alias was used
-            return dskip, None, None, None, None, None
-        dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd, dskip)
+            return dskip, None, None, None, None, None, None
+        into = None
+        if ctx.has_gate and ctx.gate_grad_into is not None and gate.dtype == dy.dtype:
+            into = ctx.gate_grad_into[0].half(ctx.gate_grad_into[1], gate)
+        dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd, dskip, into)
         return (dx, dw.to(weight.dtype), db.to(bias.dtype) if ctx.has_bias else None,
-                dgate.to(gate.dtype) if ctx.has_gate else None, None, None)
+                dgate.to(gate.dtype) if ctx.has_gate else None, None, None, None)
 
 
 def layer_norm_nchw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                    gate: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, passthrough: bool = False):
+                    gate: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, passthrough: bool = False,
+                    gate_grad_into=None):
     """LN over channels of an NCHW tensor (optionally times silu(gate)).  ``out_dtype`` defaults to the
     autocast dtype when autocast is on (what the consumer conv would cast to anyway), else x.dtype."""
     if out_dtype is None:
         out_dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
-    return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype, passthrough)
+    return LayerNormNCHWFn.apply(x, weight, bias, gate, out_dtype, passthrough, gate_grad_into)

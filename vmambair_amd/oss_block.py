@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, gelu_gate, layer_norm_nchw
+from .ops import (ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, gelu_gate, layer_norm_nchw,
+                  split_halves)
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
@@ -52,9 +53,10 @@ class LayerNorm(nn.Module):
         self.with_bias = LayerNorm_type != "BiasFree"
         self.body = _LNBody(dim, self.with_bias)
 
-    def forward(self, x: torch.Tensor, gate: torch.Tensor = None, out_dtype: torch.dtype = None, passthrough: bool = False):
+    def forward(self, x: torch.Tensor, gate: torch.Tensor = None, out_dtype: torch.dtype = None, passthrough: bool = False,
+                gate_grad_into=None):
         """NCHW in, NCHW out, no permutes (HIP kernel).  ``gate``: fused ``* silu(gate)`` epilogue."""
-        return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype, passthrough)
+        return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype, passthrough, gate_grad_into)
 
 
 class FeedForward(nn.Module):
@@ -153,7 +155,7 @@ class SS2D_1(nn.Module):
             self.Dsc._no_weight_decay = True
 
     # -- four spatial directions (MambaSISR6_arch.py:395-436; index maps: SURVEY.md Appendix B) --
-    def forward_core(self, x: torch.Tensor, gate: torch.Tensor = None) -> torch.Tensor:
+    def forward_core(self, x: torch.Tensor, gate: torch.Tensor = None, gate_grad_into=None) -> torch.Tensor:
         """Omni form: two flattenings of x instead of the four of ``cross_scan_2d``; the projections of
         directions 2/3 are computed on the un-flipped rows (a column of a matmul does not depend on
         its position) and the scan kernels walk those directions backwards.  Same values as
@@ -163,7 +165,7 @@ class SS2D_1(nn.Module):
         if self.fused_core and core_supported(self.d_inner, self.dt_rank, self.d_state):
             # flattenings + both projections + scan + merge as one autograd node on the HIP kernels
             y = SS2DCoreFn.apply(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
-            return self._out_norm(y, x.dtype, gate)
+            return self._out_norm(y, x.dtype, gate, gate_grad_into)
         B, Cc, H, W = x.shape
         L = H * W
         R, N = self.dt_rank, self.d_state
@@ -185,10 +187,10 @@ class SS2D_1(nn.Module):
             y = y + out[:, 3].reshape(B, -1, W, H).transpose(2, 3).reshape(B, -1, L).float()
         return self._out_norm(y.view(B, Cc, H, W), x.dtype, gate)
 
-    def _out_norm(self, y, dtype, gate):
+    def _out_norm(self, y, dtype, gate, gate_grad_into=None):
         """out_norm(y).to(x.dtype) [* silu(gate)]  (MambaSISR6_arch.py:433-434,488-493)"""
         if isinstance(self.out_norm, LayerNorm):
-            return self.out_norm(y, gate=gate, out_dtype=dtype)
+            return self.out_norm(y, gate=gate, out_dtype=dtype, gate_grad_into=gate_grad_into)
         y = self.out_norm(y).to(dtype)  # tests swap in an Identity to look at the merge alone
         return y if gate is None else y * F.silu(gate)
 
@@ -282,9 +284,11 @@ class SS2D_1(nn.Module):
     def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
         """``residual``: the block's skip connection, added in the epilogue of the out_conv kernel"""
         xz = conv1x1(x, self.in_conv)
-        x, z = xz.chunk(2, dim=1)
-        x = dwconv3x3(x, self.conv2d, act=True)  # act(conv2d(x)), silu in the conv's epilogue
-        y2 = self.forward_core(x, gate=z)  # out_norm(merge) * silu(z), fused in the LayerNorm kernel
+        # x, z = xz.chunk(2, dim=1): the gradients of the halves are written by their producers into ONE buffer (no cat)
+        x, z, pair = split_halves(xz)
+        x = dwconv3x3(x, self.conv2d, act=True, grad_into=None if pair is None else (pair, 0))  # silu in the conv's epilogue
+        # out_norm(merge) * silu(z), fused in the LayerNorm kernel
+        y2 = self.forward_core(x, gate=z, gate_grad_into=None if pair is None else (pair, 1))
         if self.omni and self.fused_channel and y2.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
                 chan_supported(self.dc_inner or 1, self.dc_state, self.d_inner):
             # pooling + channel scans + LayerNorm + gate as one autograd node (oss_channel.hip)
