@@ -289,16 +289,34 @@ def test_split_halves_gradients_land_in_one_buffer(oracle_cpu_kernel):
     import torch
     from vmambair_amd import ops
     torch.manual_seed(0)
-    xz = torch.randn(2, 8, 5, 6, requires_grad=True)
+    leaf = torch.randn(2, 8, 5, 6, requires_grad=True)
+    xz = leaf * 1.0
+    seen = []
+    xz.register_hook(lambda g_: seen.append(g_.data_ptr()))
     a, b, pair = ops.split_halves(xz)
     assert pair is not None and torch.equal(a, xz[:, :4]) and torch.equal(b, xz[:, 4:])
-    ga, gb = pair.half(0, a), pair.half(1, b)
-    ga.copy_(torch.full_like(a, 2.0))
-    gb.copy_(torch.full_like(b, 3.0))
-    base = pair.buf.data_ptr()
-    torch.autograd.backward([a, b], [ga, gb])
-    assert xz.grad.data_ptr() == base, "the buffer itself became the gradient"
-    assert torch.equal(xz.grad[:, :4], torch.full_like(a, 2.0)) and torch.equal(xz.grad[:, 4:], torch.full_like(b, 3.0))
+
+    bufptr = []
+
+    class Producer(torch.autograd.Function):   # stands for the kernels that write their input gradient into the offered half
+        @staticmethod
+        def forward(ctx, t, idx, val):
+            ctx.idx, ctx.val = idx, val
+            ctx.save_for_backward(t)
+            return t.sum()
+
+        @staticmethod
+        def backward(ctx, g_):
+            (t,) = ctx.saved_tensors
+            out = pair.half(ctx.idx, t)
+            bufptr.append(pair.buf.data_ptr())
+            out.fill_(ctx.val)
+            return out, None, None
+
+    (Producer.apply(a, 0, 2.0) + Producer.apply(b, 1, 3.0)).backward()
+    assert seen[0] == bufptr[0] == bufptr[1], "the gradient of xz IS the shared buffer: no cat, no copy"
+    assert leaf.grad is not None and torch.equal(leaf.grad[:, :4], torch.full_like(a, 2.0)) and torch.equal(leaf.grad[:, 4:], torch.full_like(b, 3.0))
+    assert pair.buf is None, "the split's backward consumed the buffer (handed on without a cat)"
     # fallback: gradients that are NOT the offered halves
     xz2 = torch.randn(2, 8, 5, 6, requires_grad=True)
     a2, b2, pair2 = ops.split_halves(xz2)
