@@ -19,6 +19,8 @@ Other workloads of BASELINE.json (not the driver's default line):
                          (Deraining/Deraining/Options/Deraining_mamber33.yml:52-103, image_restoration_model.py:144-173)
   --config realsr-tiled  configs[4]: MambaRealSR11 [6,2,2,1]+6, fp16, 512x512 -> 2048x2048 by the RealESRGANer tile rule,
                          one hipGraph per padded-tile shape (a "step" = one image); tiles/s in ``config``
+  --config srgan-split64 validation-time inference of the SRGAN tree (MambaSISRModel2.test: 64x64 cells, no overlap) on a
+                         256x256 LQ image: eager cells / ONE hipGraph replayed per cell / the same graph on 16 stacked cells
 """
 import argparse
 import ctypes as C
@@ -168,6 +170,45 @@ def bench_realsr_tiled(args):
         "roofline": roof, "cpu_baseline": None}), flush=True)
 
 
+def bench_srgan_split64(args):
+    """``MambaSISRModel2.test`` (SRGAN/VmambaIR/models/MambaSISR2_model.py:99-193): the LQ image in 64x64 cells, one forward per
+    cell.  Every cell has the same shape, so the forward is one hipGraph; cells are independent, so they can also share ONE
+    forward on the batch axis.  MambaSISR6 [15,1,1,1]+15, 256x256 LQ -> 1024x1024 (16 cells), bf16 autocast."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    dev = torch.device("cuda", 0)
+    from vmambair_amd.archs import build_network
+    from vmambair_amd.infer import Split64SR
+    torch.manual_seed(0)
+    net = build_network(NET).to(dev)
+    lq = torch.rand(1, 3, 256, 256, device=dev)
+    res, ref = {}, None
+    for name, graph, bt in (("eager_cell_by_cell", False, 1), ("graph_cell_by_cell", True, 1), ("graph_16_cells_stacked", True, 16)):
+        drv = Split64SR(net, 4, autocast_dtype=torch.bfloat16, use_graph=graph, batch_tiles=bt)
+        out = drv(lq)
+        for _ in range(max(0, args.warmup - 1)):
+            drv(lq)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = drv(lq)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        assert tuple(out.shape) == (1, 3, 1024, 1024) and torch.isfinite(out).all()
+        if ref is None:
+            ref = out.clone()
+        res[name] = {"s_per_image": round(dt, 4), "images_per_s": round(1.0 / dt, 3), "cells_per_s": round(16 / dt, 1),
+                     "forwards_per_image": 16 // bt, "max_abs_diff_vs_eager": float((out - ref).abs().max())}
+    best = max(res.values(), key=lambda r: r["images_per_s"])
+    print(json.dumps({
+        "metric": "images/sec, x4 SR validation inference in 64x64 cells (MambaSISRModel2.test), 256x256 LQ", "value": best["images_per_s"],
+        "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(best["s_per_image"] * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "SRGAN-tree validation path: MambaSISR6 dim48 [15,1,1,1]+15, bf16 autocast, no_grad, 256x256 LQ in 16 "
+                               "cells of 64x64 (SURVEY.md 8f row 3)", **res},
+        "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def collect_prof(lib):
     """all non-empty profiler buckets -> list of dicts"""
     recs = []
@@ -260,7 +301,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 8 (sr) / 4 (deraining)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed GLOBAL batch split over the ranks (BASELINE.json configs[2]: 32 -> 32/16/8/4 per GPU); scaling = strong")
-    ap.add_argument("--config", choices=["sr", "deraining", "realsr-tiled"], default="sr")
+    ap.add_argument("--config", choices=["sr", "deraining", "realsr-tiled", "srgan-split64"], default="sr")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--micro-streams", type=int, default=int(os.environ.get("VMAMBAIR_MICRO_STREAMS", "1")),
@@ -277,6 +318,8 @@ def main():
         return
     if args.config == "realsr-tiled":
         return bench_realsr_tiled(args)
+    if args.config == "srgan-split64":
+        return bench_srgan_split64(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -21,6 +21,7 @@ for leg in $LEGS; do
     newtests) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_train_graph_gpu.py tests/test_checkpoint_psnr.py tests/test_infer.py -m gpu -q -s -p no:cacheprovider > gpurun_out/newtests.txt 2>&1; echo "rc=$?"; tail -5 gpurun_out/newtests.txt; grep -E "^\[(16bit|net)\]|^(FAILED|ERROR)" gpurun_out/newtests.txt | head -40;;
     bench32) timeout 400 python bench.py --steps 10 --warmup 3 --global-batch 32 --no-cpu-baseline > gpurun_out/bench_gb32.txt 2>gpurun_out/bench_gb32.err; echo "rc=$?"; tail -1 gpurun_out/bench_gb32.txt | cut -c1-300;;
     derain) timeout 600 python bench.py --steps 10 --warmup 3 --config deraining --no-cpu-baseline > gpurun_out/bench_derain.txt 2>gpurun_out/bench_derain.err; echo "rc=$?"; tail -1 gpurun_out/bench_derain.txt | cut -c1-300; tail -3 gpurun_out/bench_derain.err;;
+    split64) timeout 600 python bench.py --steps 3 --warmup 1 --config srgan-split64 > gpurun_out/bench_split64.txt 2>gpurun_out/bench_split64.err; echo "rc=$?"; tail -1 gpurun_out/bench_split64.txt | cut -c1-900; tail -3 gpurun_out/bench_split64.err;;
     realsr) timeout 600 python bench.py --steps 3 --warmup 1 --config realsr-tiled > gpurun_out/bench_realsr.txt 2>gpurun_out/bench_realsr.err; echo "rc=$?"; tail -1 gpurun_out/bench_realsr.txt | cut -c1-400; tail -3 gpurun_out/bench_realsr.err;;
     wgradab) for t in 0 12 21 22; do VMAMBAIR_WGRAD_TILE=$t timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_wgt$t.txt 2>gpurun_out/bench_wgt$t.err; echo "wgrad tile=$t rc=$? $(tail -1 gpurun_out/bench_wgt$t.txt | cut -c1-140)"; done;;
     pmc)    bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; echo "rc=$?"; grep -E "oss_scan" gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt | cut -c1-160;;
