@@ -207,9 +207,10 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
         torch.cuda.synchronize()
         got[M] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
     assert got[2][0] == pytest.approx(got[1][0], rel=1e-5 if acdt is None else 1e-2)
-    # fp32: the vendor library may pick different solvers for the 3x3 convolutions at batch 4 and batch 2 (measured: up to
-    # 4e-4 of a gradient's scale between runs); a lost or doubled micro-batch would be an error of 0.5
-    tol = 2e-3 if acdt is None else 5e-2
+    # fp32: the vendor library may pick different solvers for the 3x3 convolutions at batch 4 and batch 2, and our own kernels
+    # pick workgroup shapes (i.e. summation orders) by batch size; on the smallest gradients (scale 1e-5, sums with cancellation)
+    # that was measured at up to 5e-3 of the tensor's own scale.  A lost or doubled micro-batch would be an error of 0.5.
+    tol = 1e-2 if acdt is None else 5e-2
     # bf16: noise floor of the small channel-branch gradients, see test_deferred_finishing_gives_the_same_gradients
     floor = 1e-9 if acdt is None else 2e-3 * max(float(v.abs().max()) for v in got[1][1].values())
     wrong = []

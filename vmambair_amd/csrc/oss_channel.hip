@@ -11,9 +11,14 @@
 // whole thing in one launch per direction of autograd, plus row reductions / row-affine passes over the
 // (B, d, H, W) tensor at both ends.  fp32 throughout (the RealSR tree forces fp32 here even under AMP).
 //
-// Scan layout inside the workgroup: wave k = direction k, lane = (row i of the direction) * 16 + state n; the
-// time loop is serial (L <= 768 steps), sums over the 16 states are DPP row reductions, sums over the rows of
-// a direction cross the 16-lane rows with ds_bpermute.  The states h[row, l, n] of every step are kept in HBM
+// Scan layout inside the workgroup: lane = (row i of the direction) * 16 + state n; sums over the 16 states are DPP row
+// reductions, sums over the rows of a direction cross the 16-lane rows with ds_bpermute.  A direction's L steps are cut
+// into S = NT / 128 time segments, one WAVE per (direction, segment): a single wave on a SIMD issues one vector
+// instruction per ~5.6 cycles (profiles/r02_ubench_issue_rates.txt), which -- not the dependent FMA -- is what the
+// one-wave-per-direction scan of round 1 ran at (~290 cycles per step).  Every segment first runs the bare recurrence
+// from a zero state (a, B u and one FMA per step) to get its (product of a, end state) pair, the pairs are chained
+// through LDS (the scan monoid of oss_device.h, S - 1 FMAs), then every segment runs the full step (outputs, saved
+// states / gradients) from its true incoming state.  The states h[row, l, n] of every step are kept in HBM
 // for the backward recurrence (it needs h_{t-1}; 8 x 768 x 16 floats per image at most).
 #include "oss_device.h"
 #include "oss_host.h"
@@ -21,14 +26,20 @@
 namespace oss {
 
 constexpr int kChN = 16;  // dc_state of every reference config
-constexpr int kChU = 16;  // scan steps whose operands are fetched together
+constexpr int kChU = 8;   // scan steps whose operands are fetched together
+constexpr int kChNT = 512;  // threads per workgroup: 8 waves = 2 directions x 4 time segments
+constexpr int kChRed = 8;   // floats of the block-sum scratch
 
-__device__ __forceinline__ float block_sum_256(float v, float *red /*[4]*/, int tid) {
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float *red /*[kChRed]*/, int tid) {
+    static_assert(NT == 256 || NT == 512, "block_sum: 4 or 8 waves");
     const float w = segment_sum_to_last<64>(v);
     __syncthreads();  // red may still be read from a previous call
     if ((tid & 63) == 63) red[tid >> 6] = w;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = (red[0] + red[1]) + (red[2] + red[3]);
+    if constexpr (NT == 512) t += (red[4] + red[5]) + (red[6] + red[7]);
+    return t;
 }
 
 // sum over the rows i of a direction (lanes n, 16 + n, 32 + n, 48 + n); every lane gets the total
@@ -42,8 +53,8 @@ __device__ __forceinline__ float sum_over_rows(float v, int lane) {
 // backward either way); without it every phase pays a round trip through L2
 // (a template parameter, not a runtime pointer select: generic-address loads would tie the LDS and vector-memory
 // wait counters together inside the serial scan loop)
-template <bool use_lds>
-__global__ void __launch_bounds__(256)
+template <bool use_lds, int NT>
+__global__ void __launch_bounds__(NT)
 oss_chan_fwd_kernel(oss_chan_params p) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, L = p.L, dc = p.dc, Cc = p.Cc, Rc = p.Rc;
@@ -58,8 +69,10 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *seq = sm;                 // [dc][L]
     float *ybuf = seq + dc * L;      // [2 dc][L]
     float *ycs = ybuf + 2 * dc * L;  // [L]
-    float *red = ycs + L;            // [4]
-    for (int l = tid; l < L; l += 256) {
+    float *red = ycs + L;            // [kChRed]
+    float *segP = red + kChRed;      // [NT]: product of a over a wave's time segment, per lane
+    float *segH = segP + NT;         // [NT]: the segment's end state from a zero start
+    for (int l = tid; l < L; l += NT) {
         const float pl = p.pooled[(size_t)b * L + l];
         for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
     }
@@ -68,15 +81,15 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *zg = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
     float *dg = p.dts + (size_t)b * 2 * dc * L;
     float *zb, *db, *dlsF = nullptr;   // dlsF [2 dc][L]: softplus(dts + bias), computed once per (row, l) for the 16 state lanes
-    if constexpr (use_lds) { zb = red + 4; db = zb + 2 * L * Cc; dlsF = db + 2 * dc * L; } else { zb = zg; db = dg; }
+    if constexpr (use_lds) { zb = segH + NT; db = zb + 2 * L * Cc; dlsF = db + 2 * dc * L; } else { zb = zg; db = dg; }
     // z[k][l][c] = sum_i Wxc[k][c][i] seq[i][l]: a thread keeps the dc weights of its column (k, c) in registers and walks l
     // (one output per iteration with its index arithmetic and dc dependent L2 loads measured 13 of the kernel's 32 us at
     // L = 96, profiles/r01_chan_phase_timing.txt)
     {
         const int ncol = 2 * Cc;
-        const int tpc = ncol >= 256 ? 1 : 256 / ncol;          // threads per column
-        for (int col = tid % (ncol < 256 ? ncol : 256); col < ncol; col += 256) {
-            const int sub = ncol < 256 ? tid / ncol : 0;
+        const int tpc = ncol >= NT ? 1 : NT / ncol;          // threads per column
+        for (int col = tid % (ncol < NT ? ncol : NT); col < ncol; col += NT) {
+            const int sub = ncol < NT ? tid / ncol : 0;
             if (sub >= tpc) break;
             float wv[4];
 #pragma unroll
@@ -95,9 +108,9 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     }
     __syncthreads();
     OSS_STAMP();
-    // dts[row][l] = sum_r Wdtc[row][r] z[k][l][r]: 256 / (2 dc) threads per row, the row's first 8 weights in registers
+    // dts[row][l] = sum_r Wdtc[row][r] z[k][l][r]: NT / (2 dc) threads per row, the row's first 8 weights in registers
     {
-        const int nrow = 2 * dc, tpr = 256 / nrow;      // dc <= 4: >= 32 threads per row
+        const int nrow = 2 * dc, tpr = NT / nrow;      // dc <= 4: >= 32 threads per row
         const int row = tid / tpr, sub = tid - row * tpr;
         if (row < nrow) {
             const int k = row / dc;
@@ -124,26 +137,53 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     }
     __syncthreads();
     OSS_STAMP();
-    const int wave = tid >> 6, lane = tid & 63;
-    if (wave < 2) {
-        const int k = wave, i = lane >> 4, n = lane & 15;
+    constexpr int S = NT / 128;   // time segments per direction
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    {
+        const int k = wave / S, seg = wave - k * S, i = lane >> 4, n = lane & 15;
         const bool act = i < dc;
         const int row = k * dc + (act ? i : 0);
         const float A2 = -__expf(p.A_logs[row * kChN + n]) * kLog2e;
         const float Dv = p.Dsc[row], bias = p.dt_bias[row];
         const float *dr = (use_lds ? dlsF : db) + row * L, *ur = seq + (act ? i : 0) * L;
         float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
-        float h = 0.f;
-        // per chunk of kChU steps: (1) fetch + everything that does not depend on the recurrence (softplus, exp, B u),
+        const int Ls = ((L + S - 1) / S + kChU - 1) / kChU * kChU;   // steps per segment, whole fetch chunks
+        const int tb = min(seg * Ls, L), te = min(tb + Ls, L);
+        auto delta_at = [&](int l) {
+            if constexpr (use_lds) { return dr[l]; } else { float e; return softplus_thr(dr[l] + bias, e); }
+        };
+        // pass A: the recurrence alone from a zero state -> (product of a, end state) of this segment.  A step past the
+        // segment's end takes delta = 0: a = 1, B u delta = 0, i.e. the identity.
+        float hl = 0.f, sdl = 0.f;
+        for (int t0 = tb; t0 < te; t0 += kChU) {
+            float dlv[kChU], buv[kChU];
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = min(t0 + j, te - 1), l = k ? L - 1 - t : t;
+                const float dl = t0 + j < te ? delta_at(l) : 0.f;
+                dlv[j] = dl;
+                buv[j] = dl * zb[(k * L + l) * Cc + Rc + n] * ur[l];
+            }
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                hl = __builtin_fmaf(exp2_hw(dlv[j] * A2), hl, buv[j]);
+                sdl += dlv[j];
+            }
+        }
+        segP[tid] = exp2_hw(sdl * A2);
+        segH[tid] = hl;
+        __syncthreads();
+        float h = 0.f;   // the state entering this segment: segments 0 .. seg-1 of the direction, in order
+        for (int q = 0; q < seg; ++q) h = __builtin_fmaf(segP[(k * S + q) * 64 + lane], h, segH[(k * S + q) * 64 + lane]);
+        // pass B, per chunk of kChU steps: (1) fetch + everything that does not depend on the recurrence (exp, B u),
         // (2) the recurrence itself -- one dependent FMA per step, (3) the outputs (independent reductions)
-        for (int t0 = 0; t0 < L; t0 += kChU) {
+        for (int t0 = tb; t0 < te; t0 += kChU) {
             float av[kChU], bu[kChU], us[kChU], Cs[kChU], hv[kChU];
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
-                const int t = min(t0 + j, L - 1), l = k ? L - 1 - t : t;
+                const int t = min(t0 + j, te - 1), l = k ? L - 1 - t : t;
                 const float *zr = zb + (k * L + l) * Cc + Rc;
-                float dl;
-                if constexpr (use_lds) { dl = dr[l]; } else { float e; dl = softplus_thr(dr[l] + bias, e); }
+                const float dl = delta_at(l);
                 us[j] = ur[l];
                 av[j] = exp2_hw(dl * A2);
                 bu[j] = dl * zr[n] * us[j];
@@ -157,7 +197,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = t0 + j;
-                if (t < L) {
+                if (t < te) {
                     const int l = k ? L - 1 - t : t;
                     if (act) hr[l * kChN + n] = hv[j];
                     const float tot = segment_sum_to_last<16>(Cs[j] * hv[j]);
@@ -169,18 +209,18 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     __syncthreads();
     OSS_STAMP();
     float part = 0.f;
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += NT) {
         float s = lift ? p.cout_b[0] : 0.f;
         for (int i = 0; i < dc; ++i) s = __builtin_fmaf(lift ? p.cout_w[i] : 1.f, ybuf[i * L + l] + ybuf[(dc + i) * L + l], s);
         ycs[l] = s;
         part += s;
     }
-    for (int idx = tid; idx < 2 * dc * L; idx += 256) p.y[(size_t)b * 2 * dc * L + idx] = ybuf[idx];
-    const float mu = block_sum_256(part, red, tid) / (float)L;
+    for (int idx = tid; idx < 2 * dc * L; idx += NT) p.y[(size_t)b * 2 * dc * L + idx] = ybuf[idx];
+    const float mu = block_sum<NT>(part, red, tid) / (float)L;
     float q = 0.f;
-    for (int l = tid; l < L; l += 256) { const float d = ycs[l] - mu; q = __builtin_fmaf(d, d, q); }
-    const float rstd = 1.0f / sqrtf(block_sum_256(q, red, tid) / (float)L + 1e-5f);
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += NT) { const float d = ycs[l] - mu; q = __builtin_fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(block_sum<NT>(q, red, tid) / (float)L + 1e-5f);
+    for (int l = tid; l < L; l += NT) {
         p.yc[(size_t)b * L + l] = ycs[l];
         p.c[(size_t)b * L + l] = __builtin_fmaf((ycs[l] - mu) * rstd, p.cn_w[l], p.cn_b[l]);
     }
@@ -203,8 +243,8 @@ struct ChanSlots {
     }
 };
 
-template <bool use_lds /* the three scratch arrays live in LDS instead of HBM */>
-__global__ void __launch_bounds__(256)
+template <bool use_lds /* the three scratch arrays live in LDS instead of HBM */, int NT>
+__global__ void __launch_bounds__(NT)
 oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): grad of c*/, float *__restrict__ dpool,
                     float *__restrict__ gpart, float *__restrict__ dzt, float *__restrict__ ddts, float *__restrict__ dug,
                     int stage_zdt /* the dt columns of z fit in LDS next to everything else */) {
@@ -222,15 +262,15 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     float *seq = sm;              // [dc][L]
     float *dys = seq + dc * L;    // [L]   grad of yc
     float *dsq = dys + L;         // [dc][L] grad of seq
-    float *red = dsq + dc * L;    // [4]
-    float *sWx = red + 4;         // [2][Cc][dc]  xc_proj weights (read 2 Cc times per output of the dseq pass)
+    float *red = dsq + dc * L;    // [kChRed], then [5][NT] scratch of the time segments (pairs to chain, partial sums)
+    float *sWx = red + kChRed + 5 * NT;   // [2][Cc][dc]  xc_proj weights (read 2 Cc times per output of the dseq pass)
     float *zdt = sWx + 2 * Cc * dc;   // [2][L][Rc]  the dt columns of z (operands of the dtc_projs weight gradient)
     float *lds_end = zdt + (stage_zdt ? 2 * L * Rc : 0);
     float *gp = gpart + (size_t)b * sl.total;
-    for (int idx = tid; idx < 2 * Cc * dc; idx += 256) sWx[idx] = p.Wxc[idx];
+    for (int idx = tid; idx < 2 * Cc * dc; idx += NT) sWx[idx] = p.Wxc[idx];
     if (stage_zdt) {
         const float *zsrc = p.zt + (size_t)b * 2 * L * Cc;
-        for (int kl = tid; kl < 2 * L; kl += 256)
+        for (int kl = tid; kl < 2 * L; kl += NT)
             for (int r = 0; r < Rc; ++r) zdt[kl * Rc + r] = zsrc[kl * Cc + r];
     }
     const float *db = p.dts + (size_t)b * 2 * dc * L;
@@ -240,7 +280,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         dlsL = dub + 2 * dc * L; sgsL = dlsL + 2 * dc * L;
         // softplus(dts + bias) and its derivative once per (row, l) instead of once per state lane inside the serial scan
 #pragma unroll 4
-        for (int idx = tid; idx < 2 * dc * L; idx += 256) {
+        for (int idx = tid; idx < 2 * dc * L; idx += NT) {
             const float x = db[idx] + p.dt_bias[idx / L];
             float e;
             dlsL[idx] = softplus_thr(x, e);
@@ -251,7 +291,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     }
     const float mu = p.stat[b * 2], rstd = p.stat[b * 2 + 1];
     float s1 = 0.f, s2 = 0.f;
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += NT) {
         const float pl = p.pooled[(size_t)b * L + l];
         for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
         const float g0 = gc[(size_t)b * L + l], xh = (p.yc[(size_t)b * L + l] - mu) * rstd, g = g0 * p.cn_w[l];
@@ -260,20 +300,20 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         s1 += g;
         s2 = __builtin_fmaf(g, xh, s2);
     }
-    const float m1 = block_sum_256(s1, red, tid) / (float)L;
-    const float m2 = block_sum_256(s2, red, tid) / (float)L;
-    for (int l = tid; l < L; l += 256) {
+    const float m1 = block_sum<NT>(s1, red, tid) / (float)L;
+    const float m2 = block_sum<NT>(s2, red, tid) / (float)L;
+    for (int l = tid; l < L; l += NT) {
         const float xh = (p.yc[(size_t)b * L + l] - mu) * rstd, g = gc[(size_t)b * L + l] * p.cn_w[l];
         dys[l] = rstd * (g - m1 - xh * m2);
     }
     __syncthreads();
     OSS_STAMP();
     const float *yb = p.y + (size_t)b * 2 * dc * L;
-    // (the conv_cout gradients are wave-level sums done by waves 2 and 3 while waves 0 and 1 run the scans, below)
     const float *zb = p.zt + (size_t)b * 2 * L * Cc;
-    const int wave = tid >> 6, lane = tid & 63;
-    if (wave < 2) {
-        const int k = wave, i = lane >> 4, n = lane & 15;
+    constexpr int S = NT / 128;   // time segments per direction (see the header comment)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    {
+        const int k = wave / S, seg = wave - k * S, i = lane >> 4, n = lane & 15;
         const bool act = i < dc;
         const int row = k * dc + (act ? i : 0);
         const float A = -__expf(p.A_logs[row * kChN + n]), A2 = A * kLog2e;
@@ -282,7 +322,9 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         const float *dr = (use_lds ? dlsL : db) + row * L, *ur = seq + (act ? i : 0) * L;
         const float *sgr = use_lds ? sgsL + row * L : nullptr;
         const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
-        float carry = 0.f, dA = 0.f, dD = 0.f, dbs = 0.f;
+        const int Ls = ((L + S - 1) / S + kChU - 1) / kChU * kChU;
+        const int tb = min(seg * Ls, L), te = min(tb + Ls, L);   // this wave walks t = te-1 ... tb
+        float dA = 0.f, dD = 0.f, dbs = 0.f;
         // raw operands of the steps t0, t0 - 1, ...: fetched one chunk ahead of the arithmetic
         auto fetch = [&](int t0, float (&xs)[kChU], float (&Bs)[kChU], float (&Cs)[kChU], float (&hv)[kChU + 1]) {
 #pragma unroll
@@ -299,10 +341,35 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
             hv[kChU] = t >= 0 ? hr[l * kChN + n] : 0.f;
         };
         float xs[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1];
-        fetch(L - 1, xs, Bs, Cs, hv);
-        for (int t0 = L - 1; t0 >= 0; t0 -= kChU) {
+        if (te > tb) fetch(te - 1, xs, Bs, Cs, hv);   // in flight across pass A
+        // pass A: the reverse recurrence alone from a zero carry -> (product of a, carry leaving the segment at tb)
+        float cl = 0.f, sdl = 0.f;
+        for (int t0 = te - 1; t0 >= tb; t0 -= kChU) {
+            float dlv[kChU], gv[kChU];
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {
+                const int t = max(t0 - j, tb), l = k ? L - 1 - t : t;
+                const bool on = t0 - j >= tb;
+                float dl;
+                if constexpr (use_lds) { dl = dr[l]; } else { float e; dl = softplus_thr(dr[l] + bias, e); }
+                dlv[j] = on ? dl : 0.f;
+                gv[j] = on ? cw * dys[l] * zb[(k * L + l) * Cc + Rc + kChN + n] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < kChU; ++j) {   // off steps: a = 1, g = 0 -- the identity
+                cl = exp2_hw(dlv[j] * A2) * (gv[j] + cl);
+                sdl += dlv[j];
+            }
+        }
+        float *segP = red + kChRed, *segC = segP + NT;
+        segP[tid] = exp2_hw(sdl * A2);
+        segC[tid] = cl;
+        __syncthreads();
+        float carry = 0.f;   // a_{t+1} dh_{t+1} entering this segment from the later ones, latest first
+        for (int q = S - 1; q > seg; --q) carry = __builtin_fmaf(segP[(k * S + q) * 64 + lane], carry, segC[(k * S + q) * 64 + lane]);
+        for (int t0 = te - 1; t0 >= tb; t0 -= kChU) {
             float nxs[kChU], nBs[kChU], nCs[kChU], nhv[kChU + 1];
-            if (t0 - kChU >= 0) fetch(t0 - kChU, nxs, nBs, nCs, nhv);
+            if (t0 - kChU >= tb) fetch(t0 - kChU, nxs, nBs, nCs, nhv);
             // (1) recurrence-independent terms, (2) the reverse recurrence (two dependent FMAs per step),
             // (3) the gradients of the step (independent of each other)
             float us[kChU], dyv[kChU], dls[kChU], sg[kChU], av[kChU], dhv[kChU];
@@ -320,11 +387,11 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
                 }
                 av[j] = exp2_hw(dls[j] * A2);
                 us[j] = ur[l];
-                dyv[j] = t0 - j >= 0 ? cw * dys[l] : 0.f;
+                dyv[j] = t0 - j >= tb ? cw * dys[l] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
-                const bool on = t0 - j >= 0;
+                const bool on = t0 - j >= tb;
                 const float dh = __builtin_fmaf(dyv[j], Cs[j], carry);
                 dhv[j] = dh;
                 carry = on ? av[j] * dh : carry;
@@ -332,7 +399,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
 #pragma unroll
             for (int j = 0; j < kChU; ++j) {
                 const int t = t0 - j;
-                if (t >= 0) {
+                if (t >= tb) {
                     const int l = k ? L - 1 - t : t;
                     const float dl = dls[j], u = us[j], Bv = Bs[j], a = av[j], dh = dhv[j];
                     const float h = hv[j], hp = t > 0 ? hv[j + 1] : 0.f;
@@ -355,28 +422,35 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
                     }
                 }
             }
-            if (t0 - kChU >= 0) {
+            if (t0 - kChU >= tb) {
 #pragma unroll
                 for (int j = 0; j < kChU; ++j) { xs[j] = nxs[j]; Bs[j] = nBs[j]; Cs[j] = nCs[j]; hv[j] = nhv[j]; }
                 hv[kChU] = nhv[kChU];
             }
         }
-        if (act) {
-            gp[sl.dA + row * kChN + n] = dA * A;  // d/dA_log: A = -exp(A_log)
-            if (n == 15) { gp[sl.dD + row] = dD; gp[sl.dbias + row] = dbs; }
+        // the segments' partial sums of dA / dD / dbias, combined in segment order by the wave of segment 0
+        float *accA = segC + NT, *accD = accA + NT, *accB = accD + NT;
+        accA[tid] = dA; accD[tid] = dD; accB[tid] = dbs;
+        __syncthreads();
+        if (seg == 0 && act) {
+            float tA = 0.f, tD = 0.f, tB = 0.f;
+            for (int q = 0; q < S; ++q) {
+                const int o = (k * S + q) * 64 + lane;
+                tA += accA[o]; tD += accD[o]; tB += accB[o];
+            }
+            gp[sl.dA + row * kChN + n] = tA * A;  // d/dA_log: A = -exp(A_log)
+            if (n == 15) { gp[sl.dD + row] = tD; gp[sl.dbias + row] = tB; }
         }
-    }
-    else {
-        // waves 2, 3: gradients of conv_cout (sums over l of dyc * (y0 + y1), and of dyc), no workgroup barrier needed
-        const int wl = tid - 128;  // 0 .. 127
-        for (int o = wl >> 6; o < dc + 1; o += 2) {   // wave 2: outputs 0, 2, 4; wave 3: outputs 1, 3
+        // gradients of conv_cout (sums over l of dyc * (y0 + y1), and of dyc): wave o does output o; slot dc = the bias
+        if (wave <= dc) {
+            const int o = wave;
             float a = 0.f;
             if (lift) {
-                for (int l = wl & 63; l < L; l += 64)
+                for (int l = lane; l < L; l += 64)
                     a = o < dc ? __builtin_fmaf(dys[l], yb[o * L + l] + yb[(dc + o) * L + l], a) : a + dys[l];
             }
             const float t = segment_sum_to_last<64>(a);
-            if ((wl & 63) == 63) gp[sl.coutw + o] = t;   // slot dc = conv_cout.bias
+            if (lane == 63) gp[sl.coutw + o] = t;
         }
     }
     __syncthreads();
@@ -384,9 +458,9 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     // dt rows of dz
     {   // a thread keeps the dc weights of its column (k, r) in registers and walks l
         const int ncol = 2 * Rc;
-        const int tpc = ncol >= 256 ? 1 : 256 / ncol;
-        for (int col = tid % (ncol < 256 ? ncol : 256); col < ncol; col += 256) {
-            const int sub = ncol < 256 ? tid / ncol : 0;
+        const int tpc = ncol >= NT ? 1 : NT / ncol;
+        for (int col = tid % (ncol < NT ? ncol : NT); col < ncol; col += NT) {
+            const int sub = ncol < NT ? tid / ncol : 0;
             if (sub >= tpc) break;
             const int k = col / Rc, r = col - k * Rc;
             float wv[4];
@@ -403,7 +477,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < dc * L; idx += 256) {
+    for (int idx = tid; idx < dc * L; idx += NT) {
         const int i = idx / L, l = idx - i * L;
         float s = dub[i * L + l] + dub[(dc + i) * L + l];
         for (int k = 0; k < 2; ++k) {
@@ -416,7 +490,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     }
     __syncthreads();
     OSS_STAMP();
-    for (int l = tid; l < L; l += 256) {
+    for (int l = tid; l < L; l += NT) {
         float s = 0.f;
         for (int i = 0; i < dc; ++i) s = lift ? __builtin_fmaf(p.cin_w[i], dsq[i * L + l], s) : s + dsq[i * L + l];
         dpool[(size_t)b * L + l] = s;
@@ -424,7 +498,7 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     OSS_STAMP();
     // parameter gradients that are sums over l: one output per thread
     const int n_wdtc = 2 * dc * Rc, n_wxc = 2 * Cc * dc;
-    for (int o = tid; o < n_wdtc + n_wxc + 2 * dc; o += 256) {
+    for (int o = tid; o < n_wdtc + n_wxc + 2 * dc; o += NT) {
         float s = 0.f;
         if (o < n_wdtc) {
             const int row = o / Rc, r = o - row * Rc, k = row / dc;
@@ -491,7 +565,7 @@ oss_rowsum_kernel(const T *__restrict__ a, const T *__restrict__ bmul, float *__
     } else {
         for (int p = tid; p < P; p += 256) s = bp ? __builtin_fmaf(to_f32(ap[p]), to_f32(bp[p]), s) : s + to_f32(ap[p]);
     }
-    const float t = block_sum_256(s, red, tid);
+    const float t = block_sum<256>(s, red, tid);
     if (tid == 0) out[row] = t * alpha;
 }
 
@@ -538,16 +612,16 @@ static int chan_check(const oss_chan_params &p) {
 
 int chan_fwd(const oss_chan_params &p, hipStream_t s) {
     if (int e = chan_check(p)) return e;
-    size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + 4);
+    size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + kChRed + 2 * kChNT);
     if (smem > 48 * 1024) return OSS_ERR_SHAPE;
     const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 4 * (size_t)p.dc * p.L);
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
     if (use_lds) {
-        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel<true>), smem)) return e;
-        hipLaunchKernelGGL(oss_chan_fwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p);
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel<true, kChNT>), smem)) return e;
+        hipLaunchKernelGGL((oss_chan_fwd_kernel<true, kChNT>), dim3(p.B), dim3(kChNT), smem, s, p);
     } else {
-        hipLaunchKernelGGL(oss_chan_fwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p);
+        hipLaunchKernelGGL((oss_chan_fwd_kernel<false, kChNT>), dim3(p.B), dim3(kChNT), smem, s, p);
     }
     return (int)hipGetLastError();
 }
@@ -555,7 +629,7 @@ int chan_fwd(const oss_chan_params &p, hipStream_t s) {
 int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsum, float *scratch, hipStream_t s) {
     if (int e = chan_check(p)) return e;
     if (!gc || !dpool || !gsum || !scratch) return OSS_ERR_NULL;
-    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + 4 + 2 * (size_t)p.Cc * p.dc);
+    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + kChRed + 5 * kChNT + 2 * (size_t)p.Cc * p.dc);
     if (smem > kChanLdsMax) return OSS_ERR_SHAPE;
     const size_t zdt_bytes = sizeof(float) * 2 * (size_t)p.L * p.Rc;
     const int stage_zdt = smem + zdt_bytes <= kChanLdsMax ? 1 : 0;
@@ -564,17 +638,17 @@ int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsu
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
     if (use_lds) {
-        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<true>), smem)) return e;
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<true, kChNT>), smem)) return e;
     } else {
-        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<false>), smem)) return e;
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_bwd_kernel<false, kChNT>), smem)) return e;
     }
     const size_t np = chan_grad_floats(p.L, p.dc, p.Rc, p.Cc);
     float *gpart = scratch;
     float *dzt = gpart + (size_t)p.B * np;
     float *ddts = dzt + (size_t)p.B * 2 * p.L * p.Cc;
     float *dug = ddts + (size_t)p.B * 2 * p.dc * p.L;
-    if (use_lds) hipLaunchKernelGGL(oss_chan_bwd_kernel<true>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, stage_zdt);
-    else         hipLaunchKernelGGL(oss_chan_bwd_kernel<false>, dim3(p.B), dim3(256), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, stage_zdt);
+    if (use_lds) hipLaunchKernelGGL((oss_chan_bwd_kernel<true, kChNT>), dim3(p.B), dim3(kChNT), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, stage_zdt);
+    else         hipLaunchKernelGGL((oss_chan_bwd_kernel<false, kChNT>), dim3(p.B), dim3(kChNT), smem, s, p, gc, dpool, gpart, dzt, ddts, dug, stage_zdt);
     if (defer_finish())
         defer_sum(gpart, p.B, np, np, gsum, np, nullptr);
     else
