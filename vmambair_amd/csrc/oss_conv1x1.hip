@@ -181,15 +181,136 @@ oss_conv1x1_reuse_kernel(const T *__restrict__ x, const float *__restrict__ w, c
     }
 }
 
+// Weight fragment of one MFMA k-step: the 8 consecutive k of row `mrow` starting at k0, narrowed to T; zero outside the
+// (M x K) matrix.  Addresses are always valid, so the loads carry no condition.  WT: W(m, k) = w[k * M + m] (input gradient),
+// else w[m * K + k]; WVEC: two 16-byte loads (K % 8 == 0, aligned).
+template <typename T, bool WT, bool WVEC>
+__device__ __forceinline__ s16x8 load_wfrag(const float *__restrict__ w, int mrow, int M, int K, int k0) {
+    const bool mok = mrow < M;
+    const int mc = mok ? mrow : 0;
+    if constexpr (!WT && WVEC) {
+        const bool kok = k0 + 8 <= K;
+        const float *wp = w + mc * K + (kok ? k0 : 0);
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+        const s16x8 f = cvt8<T>(w0, w1);
+        return (mok && kok) ? f : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    } else {
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            const bool kok = k < K;
+            const int kc = kok ? k : K - 1;
+            const float w1 = WT ? w[kc * M + mc] : w[mc * K + kc];
+            wv[e] = (mok && kok) ? w1 : 0.f;
+        }
+        return cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+    }
+}
+
+// Epilogue of the pixel-pair kernels: the 16 accumulator rows of a lane (+ bias, + residual) -> one 4-byte store per row.
+// The bias values and the residual words of ALL rows are fetched first (clamped addresses, no per-row condition) and the
+// stores follow back to back.  The first version loaded bias[row] and res[row] inside `if (row < M && pok)` row by row:
+// hipcc then ends every row with s_waitcnt vmcnt(0), which on gfx9 also waits for the previous row's STORE -- 16
+// serialised memory round trips, ~2/3 of the kernel's time (profiles/r02_conv1x1_epilogue.txt).
+template <typename T>
+__device__ __forceinline__ void pair_epilogue(const f32x16 &acca, const f32x16 &accb, const float *__restrict__ bias,
+                                              const T *__restrict__ resp /* this lane's pixel pair, row 0; or NULL */,
+                                              T *__restrict__ yp /* same for the output */, int m0, int kg, int M, int P, bool pok) {
+    const int psw = P >> 1;
+    float bv[16];
+    uint32_t rw[16];
+    if (bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = bias[min(m0 + (r & 3) + 8 * (r >> 2) + 4 * kg, M - 1)];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+    }
+    if (resp) {
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(resp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rw[r] = rp[(size_t)min(m0 + (r & 3) + 8 * (r >> 2) + 4 * kg, M - 1) * psw];
+    }
+    uint32_t *yw = reinterpret_cast<uint32_t *>(yp);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        float va = acca[r] + bv[r], vb = accb[r] + bv[r];
+        if (resp) {
+            float r0, r1;
+            unpack2<T>(rw[r], r0, r1);
+            va += r0;
+            vb += r1;
+        }
+        if (row < M && pok) yw[(size_t)row * psw] = pack2<T>(va, vb);
+    }
+}
+
+// Raw (fp32) weight fragments of one row tile, all KS k-steps: in flight as a group, narrowed when they are needed.
+template <int KS>
+struct WRaw { f32x4 lo[KS], hi[KS]; };
+
+// issue the loads of row `mrow`'s fragments (addresses clamped into the matrix: no condition on any load)
+template <int KS, bool WT, bool WVEC>
+__device__ __forceinline__ void wraw_issue(WRaw<KS> &r, const float *__restrict__ w, int mrow, int M, int K, int kg) {
+    const int mc = mrow < M ? mrow : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = ks * 16 + kg * 8;
+        if constexpr (!WT && WVEC) {
+            const float *wp = w + mc * K + (k0 + 8 <= K ? k0 : 0);
+            r.lo[ks] = *reinterpret_cast<const f32x4 *>(wp);
+            r.hi[ks] = *reinterpret_cast<const f32x4 *>(wp + 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e, kc = k < K ? k : K - 1;
+                const float v = WT ? w[kc * M + mc] : w[mc * K + kc];
+                if (e < 4) r.lo[ks][e] = v; else r.hi[ks][e - 4] = v;
+            }
+        }
+    }
+}
+
+// ... and narrow them to T, zero outside the (M x K) matrix
+template <typename T, int KS, bool WT, bool WVEC>
+__device__ __forceinline__ void wraw_narrow(const WRaw<KS> &r, s16x8 (&af)[KS], int mrow, int M, int K, int kg) {
+    const bool mok = mrow < M;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = ks * 16 + kg * 8;
+        if constexpr (!WT && WVEC) {
+            const s16x8 f = cvt8<T>(r.lo[ks], r.hi[ks]);
+            af[ks] = (mok && k0 + 8 <= K) ? f : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        } else {
+            f32x4 lo = r.lo[ks], hi = r.hi[ks];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = (mok && k0 + e < K) ? lo[e] : 0.f;
+                hi[e] = (mok && k0 + 4 + e < K) ? hi[e] : 0.f;
+            }
+            af[ks] = cvt8<T>(lo, hi);
+        }
+    }
+}
+
 // Pixel-pair form of the kernel above (P even, 4-byte aligned rows): one wave = 64 pixels as TWO MFMA column
 // tiles that interleave -- tile A holds the even pixels p0 + 2c, tile B the odd ones p0 + 2c + 1 (c = lane & 31).
 // One 4-byte load per lane and channel feeds both tiles (128-byte row segments instead of 64), one weight
 // fragment feeds two MFMAs, and the epilogue packs the two tiles' results into one 4-byte store per lane and
 // row (the 2-byte stores of the single-tile form were ~40% of its time: profiles/r01_conv_ablation.txt).
 // wvec: weights readable as two 16-byte loads per fragment (K % 8 == 0, aligned); else element-wise.
-// Pixel-pair form, whole K in registers (K <= 16 KS): the row tiles are produced one after the other
-// (low register pressure, high occupancy); `mt_per_wave` of them per workgroup.
-template <typename T, int KS, bool WT, bool WVEC>
+// Whole K in registers (K <= 16 KS); a wave produces `mt_per_wave` row tiles one after the other.
+//
+// Round 2: the kernel is a chain of memory round trips (~1 us each under load), not a stream, so the order of the loads is
+// the design.  (1) A tile's operands -- weight fragments, one bias value per lane (redistributed with ds_bpermute), the 16
+// residual words -- are issued as ONE group with clamped addresses and no per-load condition; (2) PF: the NEXT tile's group
+// is issued before the current tile's MFMAs and stores, so a wave with several tiles pays the latency once; (3) the first
+// group is issued before the activation loads.  The first version fetched weights k-step by k-step and bias / residual row
+// by row, each behind its own s_waitcnt vmcnt(0) (which on gfx9 also waits for the previous row's store): 12 row tiles on
+// one wave took 36 us (profiles/r02_conv1x1_pipeline.txt).
+template <typename T, int KS, bool WT, bool WVEC, bool RES, bool PF>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                         T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, int mt_per_wave, const T *__restrict__ res) {
@@ -200,10 +321,32 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
     const int col = lane & 31, kg = lane >> 5;
     const int p = p0 + 2 * col;  // even pixel of this lane's pair
     const bool pok = p < P;      // P is even: the odd pixel is in range too
-    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x + b * xsb + (pok ? p : 0));
+    const int pc = pok ? p : 0;
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x + b * xsb + pc);
     const int xsw = xsk >> 1;    // row stride in 4-byte words
-    T *yb = y + (size_t)b * M * P;
+    const int psw = P >> 1;
+    uint32_t *yw = reinterpret_cast<uint32_t *>(y + (size_t)b * M * P + pc);
+    const uint32_t *rp = RES ? reinterpret_cast<const uint32_t *>(res + (size_t)b * M * P + pc) : nullptr;
+    const float *bp = bias ? bias : w;   // always a readable address: the bias load carries no branch
     const int ksteps = (K + 15) >> 4;
+    const int mt_total = (M + 31) >> 5;
+    const int mt_begin = blockIdx.z * mt_per_wave, mt_end = min(mt_total, mt_begin + mt_per_wave);
+    if (mt_begin >= mt_end) return;
+
+    WRaw<KS> wr;
+    float bl;
+    uint32_t rw[16];
+    auto issue = [&](int mt) {   // one tile's operand group
+        const int m0 = mt * 32;
+        wraw_issue<KS, WT, WVEC>(wr, w, m0 + col, M, K, kg);
+        bl = bp[min(m0 + col, M - 1)];
+        if constexpr (RES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rw[r] = rp[(size_t)min(m0 + (r & 3) + 8 * (r >> 2) + 4 * kg, M - 1) * psw];
+        }
+    };
+    issue(mt_begin);
+
     s16x8 bfa[KS], bfb[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -211,63 +354,50 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
         for (int e = 0; e < 8; ++e) {
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < K;
-            const uint32_t v = (pok && kok) ? xw[(kok ? k : K - 1) * xsw] : 0u;
+            // always-valid address, value masked afterwards: a load under a per-lane condition costs a branch each
+            const uint32_t raw = xw[(kok ? k : K - 1) * xsw];
+            const uint32_t v = (pok && kok) ? raw : 0u;
             bfa[ks][e] = (short)(v & 0xffffu);
             bfb[ks][e] = (short)(v >> 16);
         }
     }
-    const int mt_total = (M + 31) >> 5;
-    const int mt_end = min(mt_total, (int)(blockIdx.z + 1) * mt_per_wave);
-    for (int mt = blockIdx.z * mt_per_wave; mt < mt_end; ++mt) {
+
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
         const int m0 = mt * 32;
-        const int mrow = m0 + col;
-        const bool mok = mrow < M;
-        const int mc = mok ? mrow : 0;
+        s16x8 af[KS];
+        wraw_narrow<T, KS, WT, WVEC>(wr, af, m0 + col, M, K, kg);
+        const float bcur = bias ? bl : 0.f;
+        uint32_t rcur[16];
+        if constexpr (RES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rcur[r] = rw[r];
+        }
+        if constexpr (PF) issue(min(mt + 1, mt_total - 1));   // unconditional: the last one is wasted, a branch would cost a wait
         f32x16 acca, accb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
-                const int k0 = ks * 16 + kg * 8;
-                s16x8 af;
-                if constexpr (!WT && WVEC) {
-                    const bool kok = k0 + 8 <= K;
-                    const float *wp = w + mc * K + (kok ? k0 : 0);
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
-                    af = (mok && kok) ? cvt8<T>(w0, w1) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                } else {
-                    float wv[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int k = k0 + e;
-                        const bool kok = k < K;
-                        const int kc = kok ? k : K - 1;
-                        const float w1 = WT ? w[kc * M + mc] : w[mc * K + kc];
-                        wv[e] = (mok && kok) ? w1 : 0.f;
-                    }
-                    af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
-                }
-                acca = Mfma<T>::run(af, bfa[ks], acca);
-                accb = Mfma<T>::run(af, bfb[ks], accb);
+                acca = Mfma<T>::run(af[ks], bfa[ks], acca);
+                accb = Mfma<T>::run(af[ks], bfb[ks], accb);
             }
         }
-        uint32_t *yw = reinterpret_cast<uint32_t *>(yb + p);
-        const int psw = P >> 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (row < M && pok) {
-                const float bv = bias ? bias[row] : 0.f;
-                float va = acca[r] + bv, vb = accb[r] + bv;
-                if (res) {
-                    float r0, r1;
-                    unpack2<T>(reinterpret_cast<const uint32_t *>(res + (size_t)b * M * P + p)[(size_t)row * psw], r0, r1);
-                    va += r0;
-                    vb += r1;
-                }
-                yw[(size_t)row * psw] = pack2<T>(va, vb);
+            const int rin = (r & 3) + 8 * (r >> 2) + 4 * kg, row = m0 + rin;
+            const float bv = __int_as_float(__builtin_amdgcn_ds_bpermute(rin << 2, __float_as_int(bcur)));
+            float va = acca[r] + bv, vb = accb[r] + bv;
+            if constexpr (RES) {
+                float r0, r1;
+                unpack2<T>(rcur[r], r0, r1);
+                va += r0;
+                vb += r1;
             }
+            if (row < M && pok) yw[(size_t)row * psw] = pack2<T>(va, vb);
+        }
+        if constexpr (!PF) {
+            if (mt + 1 < mt_end) issue(mt + 1);
         }
     }
 }
@@ -304,66 +434,31 @@ oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, c
             for (int e = 0; e < 8; ++e) {
                 const int k = kc + ks * 16 + kg * 8 + e;
                 const bool kok = k < K;
-                const uint32_t v = (pok && kok) ? xw[(kok ? k : K - 1) * xsw] : 0u;
+                const uint32_t raw = xw[(kok ? k : K - 1) * xsw];
+                const uint32_t v = (pok && kok) ? raw : 0u;
                 bfa[ks][e] = (short)(v & 0xffffu);
                 bfb[ks][e] = (short)(v >> 16);
             }
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const int mrow = (mt0 + t) * 32 + col;
-            const bool mok = mrow < M;
-            const int mc = mok ? mrow : 0;
+            s16x8 af[KS];   // the tile's weight fragments of this chunk, fetched together (rows / columns outside the matrix: zeros)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[ks] = load_wfrag<T, WT, WVEC>(w, (mt0 + t) * 32 + col, M, K, kc + ks * 16 + kg * 8);
             if ((mt0 + t) * 32 < M) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const int k0 = kc + ks * 16 + kg * 8;
                     if (kc + ks * 16 < K) {
-                        s16x8 af;
-                        if constexpr (!WT && WVEC) {
-                            const bool kok = k0 + 8 <= K;
-                            const float *wp = w + mc * K + (kok ? k0 : 0);
-                            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
-                            af = (mok && kok) ? cvt8<T>(w0, w1) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                        } else {
-                            float wv[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const int k = k0 + e;
-                                const bool kok = k < K;
-                                const int kcl = kok ? k : K - 1;
-                                const float w1 = WT ? w[kcl * M + mc] : w[mc * K + kcl];
-                                wv[e] = (mok && kok) ? w1 : 0.f;
-                            }
-                            af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
-                        }
-                        acca[t] = Mfma<T>::run(af, bfa[ks], acca[t]);
-                        accb[t] = Mfma<T>::run(af, bfb[ks], accb[t]);
+                        acca[t] = Mfma<T>::run(af[ks], bfa[ks], acca[t]);
+                        accb[t] = Mfma<T>::run(af[ks], bfb[ks], accb[t]);
                     }
                 }
             }
         }
     }
-    uint32_t *yw = reinterpret_cast<uint32_t *>(yb + p);
-    const int psw = P >> 1;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (mt0 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (row < M && pok) {
-                const float bv = bias ? bias[row] : 0.f;
-                float va = acca[t][r] + bv, vb = accb[t][r] + bv;
-                if (res) {
-                    float r0, r1;
-                    unpack2<T>(reinterpret_cast<const uint32_t *>(res + (size_t)b * M * P + p)[(size_t)row * psw], r0, r1);
-                    va += r0;
-                    vb += r1;
-                }
-                yw[(size_t)row * psw] = pack2<T>(va, vb);
-            }
-        }
-    }
+    for (int t = 0; t < MT; ++t)
+        pair_epilogue<T>(acca[t], accb[t], bias, res ? res + (size_t)b * M * P + (pok ? p : 0) : nullptr, yb + p, (mt0 + t) * 32, kg, M, P, pok);
 }
 
 // partial[slab][g][m][n] = sum over the slab's pixels of dy_g[b, m, p] x_g[b, n, p];  slabs = B * ceil(P / SLAB).
@@ -487,6 +582,17 @@ oss_conv1x1_wgrad_finish(const float *__restrict__ part, float *__restrict__ dw,
     }
 }
 
+// how many waves a launch of the whole-K kernels aims for (row tiles are dealt to more workgroups until it is reached);
+// VMAMBAIR_CONV1X1_WAVES overrides for A-B timing
+static long conv1x1_target_waves() {
+    static const long v = [] {
+        const char *e = getenv("VMAMBAIR_CONV1X1_WAVES");
+        const long t = e ? atol(e) : 0;
+        return t > 0 ? t : 1024L;   // 1024 / 2048 / 4096: 177.0 / 176.2 / 175.0 images/s (profiles/r02_conv1x1_pipeline.txt)
+    }();
+    return v;
+}
+
 template <typename T>
 static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, int B, int M, int K, int P, int64_t xsb,
                            int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const T *res) {
@@ -503,16 +609,19 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
         const int xk = (int)xsk;
         if (K <= 16 * 12) {
             // whole K in registers: enough workgroups to fill the chip twice, otherwise as few activation re-loads as possible
-            int split = (int)((4096 + waves_p - 1) / waves_p);
+            int split = (int)((conv1x1_target_waves() + waves_p - 1) / waves_p);
             if (split < 1) split = 1;
             if (split > mt) split = mt;
             const int per = (mt + split - 1) / split;
             dim3 grid(pb, B, (mt + per - 1) / per);
-#define OSS_PAIR1(KS_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pair_kernel<T, KS_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res)
-#define OSS_PAIR(KS_) do { if (wt) OSS_PAIR1(KS_, true, false); else if (wvec) OSS_PAIR1(KS_, false, true); else OSS_PAIR1(KS_, false, false); } while (0)
-            if (K <= 16 * 3)      OSS_PAIR(3);
-            else if (K <= 16 * 6) OSS_PAIR(6);
-            else                  OSS_PAIR(12);
+#define OSS_PAIR2(KS_, WT_, WV_, PF_) do { if (res) hipLaunchKernelGGL((oss_conv1x1_pair_kernel<T, KS_, WT_, WV_, true, PF_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res); \
+                                           else     hipLaunchKernelGGL((oss_conv1x1_pair_kernel<T, KS_, WT_, WV_, false, PF_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, per, res); } while (0)
+#define OSS_PAIR(KS_, PF_) do { if (wt) OSS_PAIR2(KS_, true, false, PF_); else if (wvec) OSS_PAIR2(KS_, false, true, PF_); else OSS_PAIR2(KS_, false, false, PF_); } while (0)
+            // PF (next tile's operands in flight during the current tile): the raw fp32 fragments of two tiles fit up to 6 k-steps
+            if (K <= 16 * 3)      OSS_PAIR(3, true);
+            else if (K <= 16 * 6) OSS_PAIR(6, true);
+            else                  OSS_PAIR(12, false);
+#undef OSS_PAIR2
 #undef OSS_PAIR
 #undef OSS_PAIR1
         } else {
