@@ -148,6 +148,10 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
                        int64_t gsc, const TX *__restrict__ res /* (B, C, P) or NULL: added to dx (gradient of a skip connection) */,
                        int64_t dgsb /* batch stride of dgate (channel stride P): lets it land in one half of a wider buffer */) {
     __shared__ float red[2][kLnMaxWaves * 64 * V];
+    // per-channel dweight / dbias partials of this workgroup, staged here and written out in one coalesced pass: stored
+    // to global memory channel by channel inside the first pass, every store dragged an s_waitcnt vmcnt behind it that
+    // also waited for the store of the channel before (gfx9 counts stores in vmcnt)
+    __shared__ float pws[CPW > 0 ? 2 * kLnMaxWaves * CPW : 1];
     constexpr int NI = CPW > 0 ? CPW : 1;
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -156,6 +160,11 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     const bool ok = p < P;
     const int pc = ok ? p : 0;
     const TX *xp = x + b * xsb + pc;
+    // the skip connection's gradient (added to dx).  Loaded without a branch: with res == NULL the loads read dx itself (same
+    // shape and type, values discarded).  A wave-uniform `if (res)` around the loads makes hipcc treat every later use of the
+    // loaded registers as "maybe still in flight": s_waitcnt vmcnt(0) before each -- which then waits for the previous STORE.
+    const bool has_res = res != nullptr;
+    const TX *rsp = (has_res ? res : dx) + (size_t)b * C * P + pc;
     const TY *gyp = dy + (size_t)b * C * P + pc;
     const TY *gp = GATE ? gate + b * gsb + pc : nullptr;
     const bool with_bias = bias != nullptr;
@@ -164,7 +173,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     load_v<float, V>(rstd_in + (size_t)b * P + pc, rstd);
     const float okf = ok ? 1.f : 0.f;
     float *pw_out = part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
-    float xv[NI][V], gv[NI][V], zv[NI][V];  // x, dy, gate
+    float xv[NI][V], gv[NI][V], zv[NI][V], rv[NI][V];  // x, dy, gate, res
     float s1[V], s2[V];
 #pragma unroll
     for (int u = 0; u < V; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
@@ -184,7 +193,10 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
         }
         const float pw = segment_sum_to_last<64>(aw);
         const float pb = segment_sum_to_last<64>(ab);
-        if (lane == 63) { pw_out[c] = pw; pw_out[C + c] = pb; }
+        if (lane == 63) {
+            if constexpr (CPW > 0) { pws[c] = pw; pws[C + c] = pb; }
+            else                   { pw_out[c] = pw; pw_out[C + c] = pb; }
+        }
     };
     if constexpr (CPW > 0) {
 #pragma unroll
@@ -193,6 +205,20 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
             load_v<TX, V>(xp + cc * xsc, xv[i]);
             load_v<TY, V>(gyp + (size_t)cc * P, gv[i]);
             if constexpr (GATE) load_v<TY, V>(gp + cc * gsc, zv[i]);
+        }
+        // needed last, in flight with everything else.  (The gated form -- out_norm, which has no skip connection in any of
+        // the nets -- keeps a branch: unconditional dummy loads would double its traffic.)
+        if (!GATE || has_res) {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                const int c = wave + i * nw, cc = c < C ? c : C - 1;
+                load_v<TX, V>(rsp + (size_t)cc * P, rv[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i)
+#pragma unroll
+                for (int u = 0; u < V; ++u) rv[i][u] = 0.f;
         }
 #pragma unroll
         for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) first(c, xv[i], gv[i], zv[i]); }
@@ -209,13 +235,15 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     }
     ln_cross_wave_sum<V>(red[0], s1, wave, lane, nw);
     ln_cross_wave_sum<V>(red[1], s2, wave, lane, nw);
+    if constexpr (CPW > 0) {   // (the barriers above ordered the pws writes)
+        for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) pw_out[t] = pws[t];
+    }
     float m1[V], m2[V];
 #pragma unroll
     for (int u = 0; u < V; ++u) { m1[u] = s1[u] / (float)C; m2[u] = s2[u] / (float)C; }
     TX *dxp = dx + (size_t)b * C * P + pc;
-    const TX *rsp = res ? res + (size_t)b * C * P + pc : nullptr;
     TY *dgp = GATE ? dgate + (size_t)b * dgsb + pc : nullptr;
-    auto second = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
+    auto second = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V], const float (&rval)[V]) {
         const float wc = w[c], bc = with_bias ? bias[c] : 0.f;
         float d[V], dg[V];
 #pragma unroll
@@ -232,29 +260,26 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
             const float gw = g * wc;
             d[u] = with_bias ? rstd[u] * (gw - m1[u] - xh * m2[u]) : rstd[u] * gw - xh * rstd[u] * rstd[u] * m2[u];
         }
-        if (ok) {
-            if (rsp) {
-                float rv[V];
-                load_v<TX, V>(rsp + (size_t)c * P, rv);
 #pragma unroll
-                for (int u = 0; u < V; ++u) d[u] += rv[u];
-            }
+        for (int u = 0; u < V; ++u) d[u] += has_res ? rval[u] : 0.f;
+        if (ok) {
             store_v<TX, V>(dxp + (size_t)c * P, d);
             if constexpr (GATE) store_v<TY, V>(dgp + (size_t)c * P, dg);
         }
     };
     if constexpr (CPW > 0) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) second(c, xv[i], gv[i], zv[i]); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) second(c, xv[i], gv[i], zv[i], rv[i]); }
     } else {
         for (int c = wave; c < C; c += nw) {
-            float t[V], g[V], z[V];
+            float t[V], g[V], z[V], r[V];
             load_v<TX, V>(xp + c * xsc, t);
             load_v<TY, V>(gyp + (size_t)c * P, g);
 #pragma unroll
-            for (int u = 0; u < V; ++u) z[u] = 0.f;
+            for (int u = 0; u < V; ++u) { z[u] = 0.f; r[u] = 0.f; }
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
-            second(c, t, g, z);
+            load_v<TX, V>(rsp + (size_t)c * P, r);
+            second(c, t, g, z, r);
         }
     }
 }

@@ -24,14 +24,26 @@ oss_merge4_kernel(const T *__restrict__ out, float *__restrict__ y, int D, int H
     const T *o3 = out + ((size_t)(b * 4 + 3) * D + d) * L;
     const int h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    // column-major planes: element (h, w) lives at w*H + h; read with h fastest
+    // column-major planes: element (h, w) lives at w*H + h; read with h fastest.  All sixteen loads of a thread are issued
+    // first, with clamped addresses (a load under `ok ? :` / `if` is its own round trip: branch + s_waitcnt vmcnt(0))
+    float a1[4], a3[4], a0[4], a2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int wl = ty + 8 * r;  // local w
-        const int w = w0 + wl, h = h0 + tx;
-        const bool ok = (w < W) && (h < H);
-        t1[wl][tx] = ok ? to_f32(o1[(size_t)w * H + h]) : 0.f;
-        t3[wl][tx] = ok ? to_f32(o3[(size_t)w * H + h]) : 0.f;
+        const int w = min(w0 + ty + 8 * r, W - 1), h = min(h0 + tx, H - 1);
+        a1[r] = to_f32(o1[(size_t)w * H + h]);
+        a3[r] = to_f32(o3[(size_t)w * H + h]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = min(h0 + ty + 8 * r, H - 1), w = min(w0 + tx, W - 1);
+        const size_t i = (size_t)h * W + w;
+        a0[r] = to_f32(o0[i]);
+        a2[r] = to_f32(o2[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t1[ty + 8 * r][tx] = a1[r];
+        t3[ty + 8 * r][tx] = a3[r];
     }
     __syncthreads();
 #pragma unroll
@@ -40,7 +52,7 @@ oss_merge4_kernel(const T *__restrict__ out, float *__restrict__ y, int D, int H
         const int h = h0 + hl, w = w0 + tx;
         if (h < H && w < W) {
             const size_t i = (size_t)h * W + w;
-            const float a = to_f32(o0[i]) + to_f32(o2[i]);
+            const float a = a0[r] + a2[r];
             const float c = a + t1[tx][hl];
             y[(size_t)plane * L + i] = c + t3[tx][hl];
         }

@@ -288,7 +288,8 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
         for (int e = 0; e < 8; ++e) {
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < D;
-            const uint32_t v = (pok && kok) ? xw[(size_t)(kok ? k : D - 1) * lw] : 0u;
+            const uint32_t raw = xw[(size_t)(kok ? k : D - 1) * lw];   // always-valid address, masked afterwards (no branch per load)
+            const uint32_t v = (pok && kok) ? raw : 0u;
             bfa[ks][e] = (short)(v & 0xffffu);
             bfb[ks][e] = (short)(v >> 16);
         }
@@ -301,28 +302,41 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
         const bool qok = q < M;
         const int qc = qok ? q : 0, kk = qc >= C ? 1 : 0;
         const float *wrow = Wx + ((size_t)((j + 2 * kk) * C + (qc - kk * C))) * D;
+        // the tile's weight fragments as ONE group of loads (clamped addresses), then the MFMAs: fetched inside the
+        // `ks < ksteps` branch every k-step waited for its own loads (a round trip per k-step)
+        s16x8 af[KS];
+        if (wvec) {
+            f32x4 w0[KS], w1[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k0 = ks * 16 + kg * 8;
+                const float *wp = wrow + (k0 + 8 <= D ? k0 : 0);
+                w0[ks] = *reinterpret_cast<const f32x4 *>(wp);
+                w1[ks] = *reinterpret_cast<const f32x4 *>(wp + 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 f = cvt8<T>(w0[ks], w1[ks]);
+                af[ks] = (qok && ks * 16 + kg * 8 + 8 <= D) ? f : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = ks * 16 + kg * 8 + e;
+                    const float wv = wrow[k < D ? k : 0];
+                    af[ks][e] = (qok && k < D) ? to_bits<T>(wv) : (short)0;
+                }
+        }
         f32x16 acca, accb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
-                const int k0 = ks * 16 + kg * 8;
-                s16x8 af;
-                if (wvec) {
-                    const bool kok = k0 + 8 <= D;
-                    const float *wp = wrow + (kok ? k0 : 0);
-                    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
-                    af = (qok && kok) ? cvt8<T>(w0, w1) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const bool kok = k0 + e < D;
-                        af[e] = (qok && kok) ? to_bits<T>(wrow[kok ? k0 + e : 0]) : (short)0;
-                    }
-                }
-                acca = Mfma<T>::run(af, bfa[ks], acca);
-                accb = Mfma<T>::run(af, bfb[ks], accb);
+                acca = Mfma<T>::run(af[ks], bfa[ks], acca);
+                accb = Mfma<T>::run(af[ks], bfb[ks], accb);
             }
         }
 #pragma unroll
@@ -361,7 +375,8 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < K;
             const uint32_t q = kok ? k : 0;
-            const uint32_t v = (pok && kok) ? zw[q * lw + (q >= (uint32_t)C ? CLw : 0u)] : 0u;  // row q (+ C L: direction j + 2)
+            const uint32_t raw = zw[q * lw + (q >= (uint32_t)C ? CLw : 0u)];  // row q (+ C L: direction j + 2); always valid
+            const uint32_t v = (pok && kok) ? raw : 0u;
             bfa[ks][e] = (short)(v & 0xffffu);
             bfb[ks][e] = (short)(v >> 16);
         }
@@ -373,43 +388,55 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
         const int d = mt * 32 + col;  // A-operand row (a row of dx2) of this lane
         const bool dok = d < D;
         const uint32_t dc = dok ? d : 0;
+        // operand loads of the tile in two groups, no per-load condition (see oss_conv1x1.hip: fetched k-step by k-step and,
+        // in the epilogue, row by row inside `if (row < D && pok)`, every one of them was its own memory round trip):
+        // (1) the du words of the 16 output rows, needed last, issued first; (2) all weight fragments
+        uint32_t ua[16], ub[16];
+        if (du) {
+            const uint32_t *du0 = reinterpret_cast<const uint32_t *>(du + ((size_t)(b * 4 + j) * D) * L + (pok ? p : 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = (size_t)min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg, D - 1) * lw;
+                ua[r] = du0[o];
+                ub[r] = du0[(size_t)D * lw * 2 + o];  // direction j + 2: 2 D rows further
+            }
+        }
+        float wv[KS][8];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {  // W^T: 32 consecutive d per k -> 128-byte rows
+                const int k = ks * 16 + kg * 8 + e;
+                const uint32_t q = k < K ? k : 0;
+                wv[ks][e] = wb[q * (uint32_t)D + (q >= (uint32_t)C ? CD : 0u) + dc];
+            }
         f32x16 acca, accb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
-                float wv[8];
+                float m[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {  // W^T: 32 consecutive d per k -> 128-byte rows
-                    const int k = ks * 16 + kg * 8 + e;
-                    const bool kok = k < K;
-                    const uint32_t q = kok ? k : 0;
-                    const float w1 = wb[q * (uint32_t)D + (q >= (uint32_t)C ? CD : 0u) + dc];
-                    wv[e] = (dok && kok) ? w1 : 0.f;
-                }
-                const s16x8 af = cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
+                for (int e = 0; e < 8; ++e) m[e] = (dok && ks * 16 + kg * 8 + e < K) ? wv[ks][e] : 0.f;
+                const s16x8 af = cvt8<T>(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]});
                 acca = Mfma<T>::run(af, bfa[ks], acca);
                 accb = Mfma<T>::run(af, bfb[ks], accb);
             }
         }
-        const uint32_t *du0 = du ? reinterpret_cast<const uint32_t *>(du + ((size_t)(b * 4 + j) * D) * L + p) : nullptr;
-        uint32_t *ob = reinterpret_cast<uint32_t *>(dx2 + ((size_t)(b * 2 + j) * D) * L + p);
+        uint32_t *ob = reinterpret_cast<uint32_t *>(dx2 + ((size_t)(b * 2 + j) * D) * L + (pok ? p : 0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (row < D && pok) {
-                float va = acca[r], vb = accb[r];
-                const size_t o = (size_t)row * lw;
-                if (du) {
-                    float a0, a1, b0, b1;
-                    unpack2<T>(du0[o], a0, a1);
-                    unpack2<T>(du0[(size_t)D * L + o], b0, b1);  // direction j + 2: 2 D rows further
-                    va += a0 + b0;
-                    vb += a1 + b1;
-                }
-                ob[o] = pack2<T>(va, vb);
+            float va = acca[r], vb = accb[r];
+            if (du) {
+                float a0, a1, b0, b1;
+                unpack2<T>(ua[r], a0, a1);
+                unpack2<T>(ub[r], b0, b1);
+                va += a0 + b0;
+                vb += a1 + b1;
             }
+            if (row < D && pok) ob[(size_t)row * lw] = pack2<T>(va, vb);
         }
     }
 }
@@ -427,12 +454,14 @@ oss_dt_fwd_kernel(const T *__restrict__ xdbl, const float *__restrict__ Wdt, T *
     const bool ok = p < L;  // V == 2 only with L even: the pair is in range as a whole
     const int pc = ok ? p : 0;
     float zr[RMAX][V];
+    // clamped row index, value masked afterwards: `if (r < R) load` is a wave-uniform branch per load, and hipcc closes
+    // each with s_waitcnt vmcnt(0) -- R serialised round trips before the first output (rule 2)
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
+    for (int r = 0; r < RMAX; ++r) load_v<T, V>(xdbl + ((size_t)(b * 4 + k) * C + min(r, R - 1)) * L + pc, zr[r]);
 #pragma unroll
-        for (int i = 0; i < V; ++i) zr[r][i] = 0.f;
-        if (r < R) load_v<T, V>(xdbl + ((size_t)(b * 4 + k) * C + r) * L + pc, zr[r]);
-    }
+    for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+        for (int i = 0; i < V; ++i) zr[r][i] = r < R ? zr[r][i] : 0.f;
     for (int d = wave; d < D; d += nw) {
         const float *wr = Wdt + ((size_t)k * D + d) * R;
         float s[V];
@@ -466,17 +495,26 @@ oss_dt_dgrad_kernel(const T *__restrict__ ddts, const float *__restrict__ Wdt, T
     for (int r = 0; r < RMAX; ++r)
 #pragma unroll
         for (int i = 0; i < V; ++i) pa[r][i] = 0.f;
-    for (int d = wave; d < D; d += nw) {
-        float g[V];
-        load_v<T, V>(ddts + ((size_t)(b * 4 + k) * D + d) * L + pc, g);
-        const float *wr = Wdt + ((size_t)k * D + d) * R;
+    // four rows of ddts in flight per pass (one load, one wait per row was a round trip per row); rows past D: clamped
+    // address, zero weight
+    constexpr int DU = 4;
+    for (int d0 = wave; d0 < D; d0 += DU * nw) {
+        float g[DU][V];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r)
-            if (r < R) {
-                const float wv = wr[r];
+        for (int u = 0; u < DU; ++u) load_v<T, V>(ddts + ((size_t)(b * 4 + k) * D + min(d0 + u * nw, D - 1)) * L + pc, g[u]);
 #pragma unroll
-                for (int i = 0; i < V; ++i) pa[r][i] = __builtin_fmaf(wv, g[i], pa[r][i]);
-            }
+        for (int u = 0; u < DU; ++u) {
+            const int d = d0 + u * nw;
+            const bool dok = d < D;
+            const float *wr = Wdt + ((size_t)k * D + (dok ? d : D - 1)) * R;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R) {
+                    const float wv = dok ? wr[r] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) pa[r][i] = __builtin_fmaf(wv, g[u][i], pa[r][i]);
+                }
+        }
     }
 #pragma unroll
     for (int r = 0; r < RMAX; ++r)
@@ -515,13 +553,18 @@ oss_cross_scan2_kernel(const TI *__restrict__ x, TO *__restrict__ x2, int D, int
     const size_t L = (size_t)H * W;
     TO *o0 = x2 + ((size_t)(b * 2 + 0) * D + d) * L;
     TO *o1 = x2 + ((size_t)(b * 2 + 1) * D + d) * L;
+    float val[4];   // the four loads first (clamped addresses): load / store pairs under `if` were four serial round trips
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = min(th * 32 + ty + 8 * r, H - 1), w = min(tw * 32 + tx, W - 1);
+        val[r] = to_f32(xp[(size_t)h * W + w]);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int h = th * 32 + ty + 8 * r, w = tw * 32 + tx;
         if (h < H && w < W) {
-            const float val = to_f32(xp[(size_t)h * W + w]);
-            o0[(size_t)h * W + w] = from_f32<TO>(val);
-            tile[ty + 8 * r][tx] = val;
+            o0[(size_t)h * W + w] = from_f32<TO>(val[r]);
+            tile[ty + 8 * r][tx] = val[r];
         }
     }
     __syncthreads();
@@ -544,16 +587,24 @@ oss_cross_merge2_kernel(const T *__restrict__ g2, T *__restrict__ dx, int D, int
     const T *g0 = g2 + ((size_t)(b * 2 + 0) * D + d) * L;
     const T *g1 = g2 + ((size_t)(b * 2 + 1) * D + d) * L;
     T *o = dx + ((size_t)b * D + d) * L;
+    float v1[4], v0[4];   // all eight loads first (clamped addresses), see oss_cross_scan2_kernel
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int w = tw * 32 + ty + 8 * r, h = th * 32 + tx;
-        if (h < H && w < W) tile[tx][ty + 8 * r] = to_f32(g1[(size_t)w * H + h]);
+        const int w = min(tw * 32 + ty + 8 * r, W - 1), h = min(th * 32 + tx, H - 1);
+        v1[r] = to_f32(g1[(size_t)w * H + h]);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = min(th * 32 + ty + 8 * r, H - 1), w = min(tw * 32 + tx, W - 1);
+        v0[r] = to_f32(g0[(size_t)h * W + w]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[tx][ty + 8 * r] = v1[r];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int h = th * 32 + ty + 8 * r, w = tw * 32 + tx;
-        if (h < H && w < W) o[(size_t)h * W + w] = from_f32<T>(to_f32(g0[(size_t)h * W + w]) + tile[ty + 8 * r][tx]);
+        if (h < H && w < W) o[(size_t)h * W + w] = from_f32<T>(v0[r] + tile[ty + 8 * r][tx]);
     }
 }
 
