@@ -465,7 +465,7 @@ oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, c
 // G independent problems per launch (group g: dy + g gsg, x + g xsg); row m of dy sits at
 // (m / Mh) gs_hi + (m % Mh) gsm, so that one problem can take its rows from two places (the two scan
 // directions that share a flattening, oss_proj.hip).
-constexpr int kWgradSlab = 512;
+constexpr int kWgradSlab = 256;   // pixels per partial product (512 until round 2: see the full-slab path of the kernel)
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
@@ -499,9 +499,31 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
         int pk = pbeg;
-        if (aligned) {
+        if (aligned && pend - pbeg == kWgradSlab) {
+            // a full slab: ALL its operand loads (2 x 16 bytes per k-step and lane) are issued before the first MFMA.
+            // A k-step is one MFMA (64 cycles) but a load is a ~1 us round trip: walked 64 pixels at a time (8 loads,
+            // wait, 4 MFMAs) the kernel was a chain of 8 round trips at 1.5 waves per SIMD.
+            constexpr int IT = kWgradSlab / 16;
+            u32x4 qa[IT], qb[IT];
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+#ifdef OSS_EXP_WGRAD_NOLOAD   // timing experiment: operands without memory traffic
+                qa[u] = u32x4{(uint32_t)lane, (uint32_t)u, 1u, 2u};
+                qb[u] = u32x4{(uint32_t)lane, (uint32_t)u, 3u, 4u};
+#else
+                qa[u] = *reinterpret_cast<const u32x4 *>(ga + pbeg + u * 16 + kg * 8);
+                qb[u] = *reinterpret_cast<const u32x4 *>(xa + pbeg + u * 16 + kg * 8);
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const s16x8 af = mok ? __builtin_bit_cast(s16x8, qa[u]) : zero8;
+                const s16x8 bf = nok ? __builtin_bit_cast(s16x8, qb[u]) : (one ? ones8 : zero8);
+                acc = Mfma<T>::run(af, bf, acc);
+            }
+            pk = pend;
+        } else if (aligned) {
             // 4 k-steps (64 pixels) per iteration: all eight 16-byte loads are issued before the first MFMA needs them
-            // (explicit double-buffering of the next iteration's loads measured no better: 13.0 vs 12.3 us)
             for (; pk + 64 <= pend; pk += 64) {
                 u32x4 qa[4], qb[4];
 #pragma unroll
@@ -541,7 +563,11 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
             const int cn = n0 + col;
+#ifdef OSS_EXP_WGRAD_NOSTORE   // timing experiment: results not written
+            if (row < M && cn < NB && acc[r] == 123456.789f) {
+#else
             if (row < M && cn < NB) {
+#endif
                 const size_t drow = ((size_t)(row / Mh) * G + g) * Mh + row % Mh;  // destination row of (group g, row)
                 if (cn < N) pb[drow * N + cn] = acc[r];
                 else pb[(size_t)G * M * N + row] = acc[r];   // dbias (only ever with G == 1)
@@ -746,7 +772,29 @@ oss_conv1x1_wgrad_tiles_kernel(const T *__restrict__ dy, const T *__restrict__ x
         return f;
     };
     int pk = pbeg;
-    if (aligned) {
+    if (aligned && pend - pbeg == kWgradSlab) {
+        // a full slab: every operand load first, then the MFMAs (see oss_conv1x1_wgrad_kernel)
+        constexpr int IT = kWgradSlab / 16;
+        u32x4 qa[IT][TM], qb[IT][TN];
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) qa[u][i] = *reinterpret_cast<const u32x4 *>(ga[i] + pbeg + u * 16 + kg * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) qb[u][j] = *reinterpret_cast<const u32x4 *>(xa[j] + pbeg + u * 16 + kg * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < IT; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const s16x8 af = mok[i] ? __builtin_bit_cast(s16x8, qa[u][i]) : zero8;
+                    const s16x8 bf = nok[j] ? __builtin_bit_cast(s16x8, qb[u][j]) : (one[j] ? ones8 : zero8);
+                    acc[i][j] = Mfma<T>::run(af, bf, acc[i][j]);
+                }
+        pk = pend;
+    } else if (aligned) {
         for (; pk + 32 <= pend; pk += 32) {   // 2 k-steps per iteration: 2 (TM + TN) 16-byte loads in flight
             s16x8 af[2][TM], bf[2][TN];
 #pragma unroll
