@@ -90,6 +90,21 @@ __device__ __forceinline__ f32x4 quad_to_f32(const RawQuad<T> &r, bool rev) {
 // FD: delta computed inside the scan from the rank-R factor z (include/vmambair_oss.h: dt_weight); the kernel then emits the
 // gradient of z (summed over the rows of the group: slab rounds like dB / dC, two rank rows per round) and the per-row
 // gradient of dt_weight instead of ddelta.
+#ifdef OSS_EXP_V2_GROUP_PRO
+constexpr bool kV2GroupPro = true;
+#else
+constexpr bool kV2GroupPro = false;
+#endif
+#ifdef OSS_EXP_V2_GROUP_EPI
+constexpr bool kV2GroupEpi = true;
+#else
+constexpr bool kV2GroupEpi = false;
+#endif
+#ifdef OSS_EXP_V2_HCV_EARLY
+constexpr bool kV2HcvEarly = true;
+#else
+constexpr bool kV2HcvEarly = false;
+#endif
 template <typename T, int WAVES, int NBB, int MINW, bool FD>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
 oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
@@ -251,10 +266,30 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 dt_rows_apply<I>(zr, R, rev, dl);
                 unpack_raw_dir<I>(ru, rev, uu);
                 unpack_raw_dir<I>(rg, rev, gg);
-            } else {
+            } else if constexpr (!kV2GroupPro) {
                 load_items_dir<I>(u_row, tl, valid, L, rev, uu);
                 load_items_dir<I>(dt_row, tl, valid, L, rev, dl);
                 load_items_dir<I>(g_row, tl, valid, L, rev, gg);
+            } else {
+                // u, delta, dout of the chunk and the saved forward state as ONE group of loads behind one fast / slow decision:
+                // three load_items_dir calls each end in their own s_waitcnt vmcnt(0) (a branch per call), i.e. three
+                // serial round trips per chunk and wave before any arithmetic (and a fourth for the state)
+                RawItems<T, I> ru, rd, rg;
+                if (raw_fast_ok<I>(u_row, tl, valid, L, rev) && raw_fast_ok<I>(dt_row, tl, valid, L, rev) &&
+                    raw_fast_ok<I>(g_row, tl, valid, L, rev)) {
+                    ru = load_raw_fast<I>(u_row, tl, L, rev);
+                    rd = load_raw_fast<I>(dt_row, tl, L, rev);
+                    rg = load_raw_fast<I>(g_row, tl, L, rev);
+                } else {
+                    ru = load_raw_slow<I>(u_row, tl, valid, L, rev);
+                    rd = load_raw_slow<I>(dt_row, tl, valid, L, rev);
+                    rg = load_raw_slow<I>(g_row, tl, valid, L, rev);
+                }
+                if constexpr (kV2HcvEarly)
+                    hcv = (t0 >= kScanChunk && lane < N) ? x_row[(size_t)(t0 / kScanChunk - 1) * 2 * N + 2 * lane + 1] : 0.f;
+                unpack_raw_dir<I>(ru, rev, uu);
+                unpack_raw_dir<I>(rd, rev, dl);
+                unpack_raw_dir<I>(rg, rev, gg);
             }
             if (!row_valid) {  // a row slot past the end of the group must not contribute to dB/dC
 #pragma unroll
@@ -290,8 +325,10 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         float S = 0.f;
 #pragma unroll
         for (int i = 0; i < I; ++i) S += dl[i];
-        const int xi = t0 / kScanChunk - 1;  // saved forward state entering this chunk (bwd_kernel.cuh:184)
-        hcv = (xi >= 0 && lane < N) ? x_row[(size_t)xi * 2 * N + 2 * lane + 1] : 0.f;
+        if constexpr (FD || !(kV2GroupPro && kV2HcvEarly)) {   // saved forward state entering this chunk (bwd_kernel.cuh:184); otherwise fetched with the chunk's rows
+            const int xi = t0 / kScanChunk - 1;
+            hcv = (xi >= 0 && lane < N) ? x_row[(size_t)xi * 2 * N + 2 * lane + 1] : 0.f;
+        }
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
         const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
         // lane-dependent parts of the slab-sum addresses: a half wave = 32 groups of 4 scan positions x one half of the rows
@@ -471,8 +508,6 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                     ru = load_raw_slow<I>(u_row, tl, valid, L, rev);
                 }
                 unpack_raw_dir<I>(ru, rev, uu);
-            } else {
-                load_items_dir<I>(u_row, tl, valid, L, rev, uu);
             }
             if constexpr (FD) {
                 if constexpr (sizeof(T) == 4) {
@@ -484,7 +519,21 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
                 }
             } else {
                 float raw[I];
-                load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
+                if constexpr (!kV2GroupEpi) {
+                    load_items_dir<I>(u_row, tl, valid, L, rev, uu);
+                    load_items_dir<I>(dt_row, tl, valid, L, rev, raw);
+                } else {   // u and delta again (not kept across the state loop: registers), as one group of loads
+                    RawItems<T, I> ru, rd;
+                    if (raw_fast_ok<I>(u_row, tl, valid, L, rev) && raw_fast_ok<I>(dt_row, tl, valid, L, rev)) {
+                        ru = load_raw_fast<I>(u_row, tl, L, rev);
+                        rd = load_raw_fast<I>(dt_row, tl, L, rev);
+                    } else {
+                        ru = load_raw_slow<I>(u_row, tl, valid, L, rev);
+                        rd = load_raw_slow<I>(dt_row, tl, valid, L, rev);
+                    }
+                    unpack_raw_dir<I>(ru, rev, uu);
+                    unpack_raw_dir<I>(rd, rev, raw);
+                }
 #pragma unroll
                 for (int i = 0; i < I; ++i) {
                     float s = 1.f;
