@@ -329,11 +329,16 @@ static int ln_tile(bool pairs) { return pairs ? 128 : 64; }
 
 size_t ln_nchw_bwd_partial_floats(int B, int C, int P) { return (size_t)((P + 63) / 64) * B * 2 * C; }
 
+// (kLnCPW / 2 channel slots per wave when they suffice -- C = 96 on 8 waves, C = 48 on 4: a slot past C re-loads channel
+// C - 1, so the full-width instantiation spent half of its load instructions, and of the vmcnt range, on duplicates)
 #define OSS_LN_LAUNCH(KERN, GATE_, ...)                                                                         \
     do {                                                                                                        \
+        const bool half = C <= nw * (kLnCPW / 2);                                                               \
         if (!ln_cached(C))   hipLaunchKernelGGL((KERN<TX, TY, GATE_, 0, 1, 1024>), grid, block, 0, s, __VA_ARGS__);      \
         else if (!pairs)     hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW, 1, 1024>), grid, block, 0, s, __VA_ARGS__); \
+        else if (nw == 4 && half) hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW / 2, 2, 256>), grid, block, 0, s, __VA_ARGS__);  \
         else if (nw == 4)    hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW, 2, 256>), grid, block, 0, s, __VA_ARGS__);  \
+        else if (half)       hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW / 2, 2, 512>), grid, block, 0, s, __VA_ARGS__);  \
         else                 hipLaunchKernelGGL((KERN<TX, TY, GATE_, kLnCPW, 2, 512>), grid, block, 0, s, __VA_ARGS__);  \
     } while (0)
 
