@@ -646,6 +646,7 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
             // PF (next tile's operands in flight during the current tile): the raw fp32 fragments of two tiles fit up to 6 k-steps
             if (K <= 16 * 3)      OSS_PAIR(3, true);
             else if (K <= 16 * 6) OSS_PAIR(6, true);
+            else if (K <= 16 * 8) OSS_PAIR(8, false);    // K = 127 (EFFN hidden width at dim 48): no duplicate k-steps
             else                  OSS_PAIR(12, false);
 #undef OSS_PAIR2
 #undef OSS_PAIR

@@ -715,7 +715,8 @@ static int proj_fwd_mfma_t(const void *x2, const float *Wx, const float *Wdt, vo
     const int mt = (2 * C + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
     dim3 grid((L + 255) / 256, 2 * splits, B);
     const int ks = (D + 15) / 16;
-    if (ks <= 6)       hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 6>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
+    if (ks <= 3)       hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 3>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);   // d_inner 48: no duplicate k-steps
+    else if (ks <= 6)  hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 6>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else if (ks <= 12) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 12>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else if (ks <= 24) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 24>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else               hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 48>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
