@@ -499,6 +499,59 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
         int pk = pbeg;
+#ifndef OSS_EXP_WGRAD_DIRECT
+        if (aligned && pend - pbeg == kWgradSlab) {
+            // A full slab, operands through LDS.  The MFMA fragment of a lane is 8 consecutive pixels of ITS OWN row (row =
+            // lane & 31): loaded straight from memory, one 16-byte load instruction touches 32 rows -- 64 separate cache
+            // lines of which it uses 16 bytes each -- and the texture addresser, which takes a cycle per line, was busy for
+            // the whole kernel (TA_BUSY 41.5 K of 43 K cycles, profiles/r02_pmc_wgrad_ta_bound.txt).  Here a load instruction
+            // covers 8 rows x 128 contiguous bytes (lane = (row % 8, 16-byte chunk)), the wave parks the 32 x 64-pixel pieces
+            // of both operands in its own LDS region (rows padded to 144 bytes: conflict-free 16-byte reads) and reads the
+            // fragments back.  Wave-private, so no barrier: LDS operations of one wave execute in order.
+            constexpr int PIECES = kWgradSlab / 64, RS = 72;   // row stride in elements (64 + 8 pad)
+            __shared__ __attribute__((aligned(16))) T stage[4][2][32 * RS];
+            T *sa = stage[wave][0], *sb = stage[wave][1];
+            const int r8 = lane >> 3, q = lane & 7;
+            const T *pa[4], *px[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mr2 = min(m0 + r8 + 8 * j, M - 1), nr2 = min(n0 + r8 + 8 * j, N - 1);
+                pa[j] = gb + (mr2 / Mh) * gs_hi + (mr2 % Mh) * gsm + pbeg + q * 8;
+                px[j] = xb + nr2 * xsn + pbeg + q * 8;
+            }
+            u32x4 qa[PIECES][4], qb[PIECES][4];
+#pragma unroll
+            for (int pc = 0; pc < PIECES; ++pc)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    qa[pc][j] = *reinterpret_cast<const u32x4 *>(pa[j] + pc * 64);
+                    qb[pc][j] = *reinterpret_cast<const u32x4 *>(px[j] + pc * 64);
+                }
+#pragma unroll
+            for (int pc = 0; pc < PIECES; ++pc) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<u32x4 *>(sa + (r8 + 8 * j) * RS + q * 8) = qa[pc][j];
+                    *reinterpret_cast<u32x4 *>(sb + (r8 + 8 * j) * RS + q * 8) = qb[pc][j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                u32x4 fa[4], fb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fa[u] = *reinterpret_cast<const u32x4 *>(sa + col * RS + u * 16 + kg * 8);
+                    fb[u] = *reinterpret_cast<const u32x4 *>(sb + col * RS + u * 16 + kg * 8);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const s16x8 af = mok ? __builtin_bit_cast(s16x8, fa[u]) : zero8;
+                    const s16x8 bf = nok ? __builtin_bit_cast(s16x8, fb[u]) : (one ? ones8 : zero8);
+                    acc = Mfma<T>::run(af, bf, acc);
+                }
+            }
+            pk = pend;
+        } else
+#endif
         if (aligned && pend - pbeg == kWgradSlab) {
             // a full slab: ALL its operand loads (2 x 16 bytes per k-step and lane) are issued before the first MFMA.
             // A k-step is one MFMA (64 cycles) but a load is a ~1 us round trip: walked 64 pixels at a time (8 loads,
