@@ -465,7 +465,7 @@ oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, c
 // G independent problems per launch (group g: dy + g gsg, x + g xsg); row m of dy sits at
 // (m / Mh) gs_hi + (m % Mh) gsm, so that one problem can take its rows from two places (the two scan
 // directions that share a flattening, oss_proj.hip).
-constexpr int kWgradSlab = 256;   // pixels per partial product (512 until round 2: see the full-slab path of the kernel)
+constexpr int kWgradSlab = 512;   // pixels per partial product
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
@@ -519,9 +519,11 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
                 pa[j] = gb + (mr2 / Mh) * gs_hi + (mr2 % Mh) * gsm + pbeg + q * 8;
                 px[j] = xb + nr2 * xsn + pbeg + q * 8;
             }
-            u32x4 qa[PIECES][4], qb[PIECES][4];
+            // a window of WIN pieces in flight: piece pc + WIN is requested as soon as piece pc has left its registers
+            constexpr int WIN = PIECES < 4 ? PIECES : 4;
+            u32x4 qa[WIN][4], qb[WIN][4];
 #pragma unroll
-            for (int pc = 0; pc < PIECES; ++pc)
+            for (int pc = 0; pc < WIN; ++pc)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     qa[pc][j] = *reinterpret_cast<const u32x4 *>(pa[j] + pc * 64);
@@ -531,8 +533,15 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
             for (int pc = 0; pc < PIECES; ++pc) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    *reinterpret_cast<u32x4 *>(sa + (r8 + 8 * j) * RS + q * 8) = qa[pc][j];
-                    *reinterpret_cast<u32x4 *>(sb + (r8 + 8 * j) * RS + q * 8) = qb[pc][j];
+                    *reinterpret_cast<u32x4 *>(sa + (r8 + 8 * j) * RS + q * 8) = qa[pc % WIN][j];
+                    *reinterpret_cast<u32x4 *>(sb + (r8 + 8 * j) * RS + q * 8) = qb[pc % WIN][j];
+                }
+                if (pc + WIN < PIECES) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        qa[pc % WIN][j] = *reinterpret_cast<const u32x4 *>(pa[j] + (pc + WIN) * 64);
+                        qb[pc % WIN][j] = *reinterpret_cast<const u32x4 *>(px[j] + (pc + WIN) * 64);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 u32x4 fa[4], fb[4];
