@@ -73,8 +73,15 @@ template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi
 // V consecutive elements per lane as one access (V = 2: 4-byte accesses for the 16-bit types -- a wave's 2-byte
 // accesses move 128 bytes per instruction and were what bounded these kernels)
 template <typename T, int V> __device__ __forceinline__ void load_v(const T *p, float (&v)[V]) {
+    static_assert(V == 1 || V == 2 || V == 8, "load_v: 1, 2 or 8 elements");
     if constexpr (V == 1) {
         v[0] = to_f32(*p);
+    } else if constexpr (V == 8 && sizeof(T) == 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else if constexpr (V == 8) {   // one 16-byte access
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(p);
+        unpack2<T>(q.x, v[0], v[1]); unpack2<T>(q.y, v[2], v[3]); unpack2<T>(q.z, v[4], v[5]); unpack2<T>(q.w, v[6], v[7]);
     } else if constexpr (sizeof(T) == 4) {
         const f32x2 q = *reinterpret_cast<const f32x2 *>(p);
         v[0] = q.x; v[1] = q.y;
@@ -85,6 +92,11 @@ template <typename T, int V> __device__ __forceinline__ void load_v(const T *p, 
 template <typename T, int V> __device__ __forceinline__ void store_v(T *p, const float (&v)[V]) {
     if constexpr (V == 1) {
         *p = from_f32<T>(v[0]);
+    } else if constexpr (V == 8 && sizeof(T) == 4) {
+        *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4 *>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else if constexpr (V == 8) {
+        *reinterpret_cast<u32x4 *>(p) = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
     } else if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<f32x2 *>(p) = f32x2{v[0], v[1]};
     } else {

@@ -721,6 +721,14 @@ static int proj_fwd_mfma_t(const void *x2, const float *Wx, const float *Wdt, vo
     else if (ks <= 24) hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 24>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     else               hipLaunchKernelGGL((oss_proj_fwd_mfma_kernel<T, 48>), grid, dim3(256), 0, s, xp, Wx, zp, D, C, L, per);
     if (!dts) return (int)hipGetLastError();   // delta is evaluated inside the scan (oss_scan_fwd_params.dt_weight)
+    // eight time steps per lane (16-byte accesses: dts, the (B, 4D, L) result, is what this kernel moves) where rows allow it
+    const bool wide = R <= 8 && L % 8 == 0 && L >= 2048 && ((reinterpret_cast<uintptr_t>(zp) | reinterpret_cast<uintptr_t>(dp)) & 15u) == 0;
+    if (wide) {
+        const int nw = dt_waves(B, L / 4, D);
+        dim3 g8((L + 511) / 512, 4, B);
+        hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 8, 8>), g8, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
+        return (int)hipGetLastError();
+    }
     const int nw = dt_waves(B, L, D);
     dim3 g2((L + 127) / 128, 4, B);  // L is even here: two time steps per lane
     if (R <= 8) hipLaunchKernelGGL((oss_dt_fwd_kernel<T, 8, 2>), g2, dim3(64 * nw), 0, s, zp, Wdt, dp, D, C, R, L);
@@ -738,6 +746,13 @@ static int proj_dgrad_mfma_t(const void *ddts, void *dxdbl, const void *du, cons
     dim3 g1((L + 127) / 128, 4, B);
     const size_t smem = sizeof(float) * 128 * (size_t)nw * R;
     if (!ddts) {}   // the scan backward already filled the dt rows of dxdbl (oss_scan_bwd_params.ddt)
+    else if (R <= 8 && L % 8 == 0 && L >= 2048 && ((reinterpret_cast<uintptr_t>(gp) | reinterpret_cast<uintptr_t>(zp)) & 15u) == 0) {
+        // eight time steps per lane (16-byte loads of ddts)
+        int nw8 = dt_waves(B, L / 4, D);
+        while (nw8 > 1 && sizeof(float) * 512 * (size_t)nw8 * R > 48 * 1024) nw8 >>= 1;
+        const size_t smem8 = sizeof(float) * 512 * (size_t)nw8 * R;
+        hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8, 8>), dim3((L + 511) / 512, 4, B), dim3(64 * nw8), smem8, s, gp, Wdt, zp, D, C, R, L);
+    }
     else if (R <= 8) hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 8, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
     else             hipLaunchKernelGGL((oss_dt_dgrad_kernel<T, 32, 2>), g1, dim3(64 * nw), smem, s, gp, Wdt, zp, D, C, R, L);
     const int mt = (D + 31) / 32, per = mfma_tiles_per_wg(B, L, mt), splits = (mt + per - 1) / per;
