@@ -490,8 +490,17 @@ void oss_scan_set_variant(int fwd_variant, int bwd_variant) {
 int oss_scan_last_variant(int which) { return which == 0 ? g_last_fwd.load() : g_last_bwd.load(); }
 
 __global__ void __launch_bounds__(256) oss_copy_kernel(const f32x4 *src, f32x4 *dst, size_t n) {
+    // eight 16-byte loads in flight per lane before the first store (one load per iteration left the memory system idle
+    // between a wave's round trips)
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+    }
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
