@@ -288,8 +288,13 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
         for (int e = 0; e < 8; ++e) {
             const int k = ks * 16 + kg * 8 + e;
             const bool kok = k < D;
-            const uint32_t raw = xw[(size_t)(kok ? k : D - 1) * lw];   // always-valid address, masked afterwards (no branch per load)
-            const uint32_t v = (pok && kok) ? raw : 0u;
+            uint32_t v;
+            if constexpr (KS <= 12) {   // always-valid address, masked afterwards (no branch per load)
+                const uint32_t raw = xw[(size_t)(kok ? k : D - 1) * lw];
+                v = (pok && kok) ? raw : 0u;
+            } else {                    // the deep-level instantiations (hundreds of loads): branchy form, compiles 5x faster
+                v = (pok && kok) ? xw[(size_t)(kok ? k : D - 1) * lw] : 0u;
+            }
             bfa[ks][e] = (short)(v & 0xffffu);
             bfb[ks][e] = (short)(v >> 16);
         }
@@ -302,41 +307,45 @@ oss_proj_fwd_mfma_kernel(const T *__restrict__ x2, const float *__restrict__ Wx,
         const bool qok = q < M;
         const int qc = qok ? q : 0, kk = qc >= C ? 1 : 0;
         const float *wrow = Wx + ((size_t)((j + 2 * kk) * C + (qc - kk * C))) * D;
-        // the tile's weight fragments as ONE group of loads (clamped addresses), then the MFMAs: fetched inside the
-        // `ks < ksteps` branch every k-step waited for its own loads (a round trip per k-step)
-        s16x8 af[KS];
-        if (wvec) {
-            f32x4 w0[KS], w1[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int k0 = ks * 16 + kg * 8;
-                const float *wp = wrow + (k0 + 8 <= D ? k0 : 0);
-                w0[ks] = *reinterpret_cast<const f32x4 *>(wp);
-                w1[ks] = *reinterpret_cast<const f32x4 *>(wp + 4);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 f = cvt8<T>(w0[ks], w1[ks]);
-                af[ks] = (qok && ks * 16 + kg * 8 + 8 <= D) ? f : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = ks * 16 + kg * 8 + e;
-                    const float wv = wrow[k < D ? k : 0];
-                    af[ks][e] = (qok && k < D) ? to_bits<T>(wv) : (short)0;
-                }
-        }
+        // the tile's weight fragments in groups of GS k-steps -- ONE batch of loads (clamped addresses), then the MFMAs:
+        // fetched inside the `ks < ksteps` branch every k-step waited for its own loads (a round trip per k-step)
+        constexpr int GS = KS < 12 ? KS : 12;
         f32x16 acca, accb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks < ksteps) {
-                acca = Mfma<T>::run(af[ks], bfa[ks], acca);
-                accb = Mfma<T>::run(af[ks], bfb[ks], accb);
+        for (int g0 = 0; g0 < KS; g0 += GS) {
+            s16x8 af[GS];
+            if (wvec) {
+                f32x4 w0[GS], w1[GS];
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {
+                    const int k0 = (g0 + u) * 16 + kg * 8;
+                    const float *wp = wrow + (k0 + 8 <= D ? k0 : 0);
+                    w0[u] = *reinterpret_cast<const f32x4 *>(wp);
+                    w1[u] = *reinterpret_cast<const f32x4 *>(wp + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {
+                    const s16x8 f = cvt8<T>(w0[u], w1[u]);
+                    af[u] = (qok && (g0 + u) * 16 + kg * 8 + 8 <= D) ? f : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < GS; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = (g0 + u) * 16 + kg * 8 + e;
+                        const float wv = wrow[k < D ? k : 0];
+                        af[u][e] = (qok && k < D) ? to_bits<T>(wv) : (short)0;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                if (g0 + u < ksteps) {
+                    acca = Mfma<T>::run(af[u], bfa[g0 + u], acca);
+                    accb = Mfma<T>::run(af[u], bfb[g0 + u], accb);
+                }
             }
         }
 #pragma unroll
@@ -401,27 +410,31 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
                 ub[r] = du0[(size_t)D * lw * 2 + o];  // direction j + 2: 2 D rows further
             }
         }
-        float wv[KS][8];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {  // W^T: 32 consecutive d per k -> 128-byte rows
-                const int k = ks * 16 + kg * 8 + e;
-                const uint32_t q = k < K ? k : 0;
-                wv[ks][e] = wb[q * (uint32_t)D + (q >= (uint32_t)C ? CD : 0u) + dc];
-            }
         f32x16 acca, accb;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
+        constexpr int GS = KS < 8 ? KS : 8;   // k-steps whose weight loads form one batch
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks < ksteps) {
-                float m[8];
+        for (int g0 = 0; g0 < KS; g0 += GS) {
+            float wv[GS][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = (dok && ks * 16 + kg * 8 + e < K) ? wv[ks][e] : 0.f;
-                const s16x8 af = cvt8<T>(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]});
-                acca = Mfma<T>::run(af, bfa[ks], acca);
-                accb = Mfma<T>::run(af, bfb[ks], accb);
+            for (int u = 0; u < GS; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {  // W^T: 32 consecutive d per k -> 128-byte rows
+                    const int k = (g0 + u) * 16 + kg * 8 + e;
+                    const uint32_t q = k < K ? k : 0;
+                    wv[u][e] = wb[q * (uint32_t)D + (q >= (uint32_t)C ? CD : 0u) + dc];
+                }
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                if (g0 + u < ksteps) {
+                    float m[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) m[e] = (dok && (g0 + u) * 16 + kg * 8 + e < K) ? wv[u][e] : 0.f;
+                    const s16x8 af = cvt8<T>(f32x4{m[0], m[1], m[2], m[3]}, f32x4{m[4], m[5], m[6], m[7]});
+                    acca = Mfma<T>::run(af, bfa[g0 + u], acca);
+                    accb = Mfma<T>::run(af, bfb[g0 + u], accb);
+                }
             }
         }
         uint32_t *ob = reinterpret_cast<uint32_t *>(dx2 + ((size_t)(b * 2 + j) * D) * L + (pok ? p : 0));
