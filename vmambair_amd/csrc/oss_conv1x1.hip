@@ -254,6 +254,11 @@ struct WRaw { f32x4 lo[KS], hi[KS]; };
 // issue the loads of row `mrow`'s fragments (addresses clamped into the matrix: no condition on any load)
 template <int KS, bool WT, bool WVEC>
 __device__ __forceinline__ void wraw_issue(WRaw<KS> &r, const float *__restrict__ w, int mrow, int M, int K, int kg) {
+#ifdef OSS_EXP_CONV_NOW   // timing experiment: weight fragments without memory traffic
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { r.lo[ks] = f32x4{1.f, 2.f, (float)mrow, (float)kg}; r.hi[ks] = r.lo[ks]; }
+    return;
+#endif
     const int mc = mrow < M ? mrow : 0;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -295,6 +300,46 @@ __device__ __forceinline__ void wraw_narrow(const WRaw<KS> &r, s16x8 (&af)[KS], 
     }
 }
 
+// Forward weights (W(m, k) = w[m * K + k], K % 8 == 0) through wave-private LDS.  The MFMA fragment of a lane is 8 consecutive
+// k of ITS OWN row: loaded straight from memory, one 16-byte load instruction touches 32 rows = 64 cache lines and the
+// texture addresser spends a cycle on each (the weight loads were 6 of the 18.6 us of in_conv at d = 96 -- experiment build
+// CONV_NOW, profiles/r02_conv1x1_pipeline.txt).  A row tile is ONE contiguous block of 32 K floats: lane l fetches the 16-byte
+// chunks l, l + 64, ... (fully coalesced), narrows them and parks them as [32][16 KS + 8] T (padded rows: conflict-free
+// 16-byte reads); the fragments are read back from there.  No barrier: LDS operations of one wave execute in order.
+template <int KS>
+__device__ __forceinline__ void wflat_issue(WRaw<KS> &r, const float *__restrict__ w, int m0, int M, int K, int lane) {
+    const int lim = min(M - m0, 32) * K - 4;          // last chunk inside the matrix
+    const float *base = w + (size_t)m0 * K;
+#pragma unroll
+    for (int i = 0; i < 2 * KS; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(base + min(256 * i + 4 * lane, lim));
+        if (i < KS) r.lo[i] = q; else r.hi[i - KS] = q;
+    }
+}
+template <typename T, int KS>
+__device__ __forceinline__ void wflat_frags(const WRaw<KS> &r, T *__restrict__ myl, s16x8 (&af)[KS], int m0, int M, int K,
+                                            int col, int kg, int row0, int k0, int sr, int sk) {
+    constexpr int RS = 16 * KS + 8;
+    const int nl = K >> 3;            // chunks per lane: 32 K floats / 4 / 64
+    int rr = row0, kk = k0;
+#pragma unroll
+    for (int i = 0; i < 2 * KS; ++i) {
+        const f32x4 q = i < KS ? r.lo[i] : r.hi[i < KS ? 0 : i - KS];
+        if (i < nl) *reinterpret_cast<u32x2 *>(myl + rr * RS + kk) = u32x2{pack2<T>(q.x, q.y), pack2<T>(q.z, q.w)};
+        kk += sk;
+        rr += sr;
+        if (kk >= K) { kk -= K; ++rr; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool mok = m0 + col < M;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 f = *reinterpret_cast<const u32x4 *>(myl + col * RS + ks * 16 + kg * 8);
+        af[ks] = (mok && ks * 16 + kg * 8 + 8 <= K) ? __builtin_bit_cast(s16x8, f) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Pixel-pair form of the kernel above (P even, 4-byte aligned rows): one wave = 64 pixels as TWO MFMA column
 // tiles that interleave -- tile A holds the even pixels p0 + 2c, tile B the odd ones p0 + 2c + 1 (c = lane & 31).
 // One 4-byte load per lane and channel feeds both tiles (128-byte row segments instead of 64), one weight
@@ -333,12 +378,17 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
     const int mt_begin = blockIdx.z * mt_per_wave, mt_end = min(mt_total, mt_begin + mt_per_wave);
     if (mt_begin >= mt_end) return;
 
+    constexpr bool WLDS = !WT && WVEC;   // forward weights through LDS (see wflat_issue)
+    __shared__ __attribute__((aligned(16))) T wlds[WLDS ? 4 * 32 * (16 * KS + 8) : 8];
+    T *myl = wlds + (WLDS ? wave * 32 * (16 * KS + 8) : 0);
+    const int wf_row0 = WLDS ? (4 * lane) / K : 0, wf_k0 = WLDS ? (4 * lane) % K : 0, wf_sr = WLDS ? 256 / K : 0, wf_sk = WLDS ? 256 % K : 0;
     WRaw<KS> wr;
     float bl;
     uint32_t rw[16];
     auto issue = [&](int mt) {   // one tile's operand group
         const int m0 = mt * 32;
-        wraw_issue<KS, WT, WVEC>(wr, w, m0 + col, M, K, kg);
+        if constexpr (WLDS) wflat_issue<KS>(wr, w, m0, M, K, lane);
+        else                wraw_issue<KS, WT, WVEC>(wr, w, m0 + col, M, K, kg);
         bl = bp[min(m0 + col, M - 1)];
         if constexpr (RES) {
 #pragma unroll
@@ -365,7 +415,8 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
     for (int mt = mt_begin; mt < mt_end; ++mt) {
         const int m0 = mt * 32;
         s16x8 af[KS];
-        wraw_narrow<T, KS, WT, WVEC>(wr, af, m0 + col, M, K, kg);
+        if constexpr (WLDS) wflat_frags<T, KS>(wr, myl, af, m0, M, K, col, kg, wf_row0, wf_k0, wf_sr, wf_sk);
+        else                wraw_narrow<T, KS, WT, WVEC>(wr, af, m0 + col, M, K, kg);
         const float bcur = bias ? bl : 0.f;
         uint32_t rcur[16];
         if constexpr (RES) {
