@@ -115,7 +115,12 @@ def test_fused_scan_merge_node_equals_separate_ops():
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 192, 64, 64), (1, 48, 96, 16, 24), (2, 127, 48, 8, 8), (1, 96, 254, 12, 10),
-                                            (3, 5, 7, 3, 5), (1, 255, 96, 16, 16), (2, 384, 384, 8, 8)])
+                                            (3, 5, 7, 3, 5), (1, 255, 96, 16, 16), (2, 384, 384, 8, 8),
+                                            # round 2: weight tiles staged through LDS (K % 8 == 0) with a ragged last row tile and
+                                            # fewer chunks than slots; several row tiles per wave (prefetch); K = 128 / 192 widths;
+                                            # weight-gradient slabs: full (512 pixels), rolling window, ragged tail
+                                            (1, 80, 100, 16, 16), (1, 40, 33, 8, 16), (2, 192, 96, 32, 32), (1, 128, 64, 16, 32),
+                                            (1, 96, 510, 64, 64), (1, 48, 192, 32, 48), (1, 96, 97, 24, 24)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_conv1x1_mfma(dt, B, Cin, Cout, H, W, has_bias):
     """MFMA 1x1 convolution (fwd, input grad, weight grad) against F.conv2d in fp32 on the same
