@@ -26,7 +26,7 @@ def ln_ref(x, w, b, gate):
 
 
 @pytest.mark.parametrize("shape", [(2, 48, 16, 24), (1, 96, 64, 64), (3, 384, 8, 8), (2, 7, 5, 3), (4, 48, 1, 1),
-                                   (2, 768, 8, 8), (1, 400, 3, 5), (2, 192, 9, 11)])
+                                   (2, 768, 8, 8), (1, 400, 3, 5), (2, 192, 9, 11), (1, 100, 16, 16), (2, 24, 8, 8)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)],
                          ids=["f32-f32", "f32-bf16", "bf16-bf16"])
 @pytest.mark.parametrize("with_bias", [True, False])
@@ -218,7 +218,7 @@ def test_gelu_gate_on_batch_strided_input():
     assert_close(ops.gelu_gate(h), F.gelu(x1) * x2, 1e-5, 1e-5, "strided")
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 96, 7, 5), (2, 400, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 96, 7, 5), (2, 400, 4, 4), (1, 96, 32, 32), (2, 100, 16, 16), (1, 192, 16, 16)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_layernorm_passthrough_adds_the_skip_gradient(shape, dt):
     """x + f(norm(x)): the skip connection's gradient enters the LayerNorm node and is added inside its kernel"""
