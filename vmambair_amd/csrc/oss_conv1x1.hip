@@ -453,6 +453,119 @@ oss_conv1x1_pair_kernel(const T *__restrict__ x, const float *__restrict__ w, co
     }
 }
 
+// Forward 1x1 convolution with 192 < K <= 512 and ANY K (the EFFN's project_out: K = hidden width 255 / 127 x 2), one row tile
+// per workgroup.  W(m, k) = w[m * K + k] with odd K has no 16-byte-aligned rows, so the K-chunked kernel below fetched its
+// weight fragments element by element: 4-byte loads whose 32 lanes-of-a-row touch 32 different rows -- 64 cache lines per load
+// instruction, 64 such instructions per chunk and tile, the texture addresser busy half of the kernel (TA_BUSY 31 K of ~63 K
+// cycles at 255 -> 96, 26 us for a 23 MB problem).  But the 32 rows of a tile are ONE contiguous, 16-byte-aligned block of 32 K
+// floats (m0 is a multiple of 32): the workgroup copies it with coalesced 16-byte loads, narrows it and scatters it into an LDS
+// image [32][K8 + 8] of T once; all four waves then read their fragments with ds_read_b128.
+// WT (input gradient, W(m, k) = w[k * M + m], M % 4 == 0): the tile is 32 contiguous floats of every row k; a 16-byte chunk holds
+// 4 consecutive m of one k and is scattered down a column of the image.
+template <typename T, bool WT>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_pairw_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                         T *__restrict__ y, int M, int K, int P, int64_t xsb, int xsk, const T *__restrict__ res) {
+    constexpr int KS = 8, CH = KS * 16, KMAX = 512, NI = 32 * KMAX / 4 / 256;   // 16 chunks of 16 bytes per thread at most
+    __shared__ __attribute__((aligned(16))) T wl[32 * (KMAX + 8)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    const bool active = p0 < P;      // (no early return: the staging below has a workgroup barrier)
+    const int col = lane & 31, kg = lane >> 5;
+    const int p = p0 + 2 * col;
+    const bool pok = active && p < P;
+    const uint32_t *xw = reinterpret_cast<const uint32_t *>(x + b * xsb + (pok ? p : 0));
+    const int xsw = xsk >> 1;
+    const int m0 = blockIdx.z * 32;
+    const int RS = ((K + 7) & ~7) + 8;
+
+    auto load_x = [&](int kc, s16x8 (&fa)[KS], s16x8 (&fb)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kc + ks * 16 + kg * 8 + e;
+                const bool kok = k < K;
+                const uint32_t raw = xw[(kok ? k : K - 1) * xsw];
+                const uint32_t v = (pok && kok) ? raw : 0u;
+                fa[ks][e] = (short)(v & 0xffffu);
+                fb[ks][e] = (short)(v >> 16);
+            }
+        }
+    };
+    s16x8 fa[KS], fb[KS];
+    load_x(0, fa, fb);   // in flight across the staging
+
+    if constexpr (WT) {   // ---- the tile's weights -> LDS (transposing)
+        const int kr = tid >> 3, m4 = (tid & 7) * 4;          // 32 rows k per pass, 8 chunks of 4 columns m each
+        const int mcl = min(m0 + m4, M - 4);                   // (M % 4 == 0: a chunk is inside the matrix or wholly outside)
+        f32x4 q[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4 *>(w + (size_t)min(kr + 32 * i, K - 1) * M + mcl);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int k = kr + 32 * i;
+            if (k < K) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wl[(m4 + e) * RS + k] = from_f32<T>(q[i][e]);
+            }
+        }
+    } else {   // ---- the tile's weights -> LDS
+        const int total = 32 * K, lim = min(M - m0, 32) * K - 4;
+        const float *base = w + (size_t)m0 * K;
+        f32x4 q[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4 *>(base + min(4 * (i * 256 + tid), lim));
+        int r = (4 * tid) / K, k = (4 * tid) - r * K;
+        const int sr = 1024 / K, sk = 1024 - sr * K;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (4 * (i * 256 + tid) < total) {
+                int rr = r, kk = k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (rr < 32) wl[rr * RS + kk] = from_f32<T>(q[i][e]);
+                    if (++kk == K) { kk = 0; ++rr; }
+                }
+            }
+            k += sk;
+            r += sr;
+            if (k >= K) { k -= K; ++r; }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    f32x16 acca, accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acca[r] = 0.f; accb[r] = 0.f; }
+    const bool mok = m0 + col < M;
+    for (int kc = 0; kc < K; kc += CH) {
+        if (kc) load_x(kc, fa, fb);
+        s16x8 af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = kc + ks * 16 + kg * 8;
+            // (a fragment wholly past K may lie beyond the row's pad: clamp the address, the mask below zeroes it)
+            const u32x4 f = *reinterpret_cast<const u32x4 *>(wl + col * RS + min(k0, RS - 8));
+            s16x8 v = __builtin_bit_cast(s16x8, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (mok && k0 + e < K) ? v[e] : (short)0;
+            af[ks] = v;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (kc + ks * 16 < K) {
+                acca = Mfma<T>::run(af[ks], fa[ks], acca);
+                accb = Mfma<T>::run(af[ks], fb[ks], accb);
+            }
+        }
+    }
+    T *yb = y + (size_t)b * M * P;
+    pair_epilogue<T>(acca, accb, bias, res ? res + (size_t)b * M * P + (pok ? p : 0) : nullptr, yb + p, m0, kg, M, P, pok);
+}
+
 // K is walked in chunks of KS k-steps (KS * 16 channels) whose activation fragments live in registers; up to MT
 // output row tiles per workgroup are accumulated across the chunks, so any K and M are covered by one kernel
 // (grid.z splits M into groups of <= MT tiles).
@@ -769,6 +882,15 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
             int per = 3;
             while (per > 1 && waves_p * ((mt + per - 1) / per) < 4096) --per;
             if (per > mt) per = mt;
+            // forward: weights through LDS.  (The same for the input gradient -- template WT, parity-green -- measured SLOWER,
+            // 188.0 against 191.0 images/s: its element-wise loads are coalesced already (32 consecutive m per k) and the
+            // transposing LDS scatter plus the barrier cost more than they save.  Kept for A-B runs: VMAMBAIR_CONV1X1_WT_LDS=1.)
+            static const bool wt_lds = getenv("VMAMBAIR_CONV1X1_WT_LDS") != nullptr;
+            if (per == 1 && K <= 512 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0 && (plain || (wt && wt_lds && M % 4 == 0))) {
+                if (plain) hipLaunchKernelGGL((oss_conv1x1_pairw_kernel<T, false>), dim3(pb, B, mt), dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, res);
+                else       hipLaunchKernelGGL((oss_conv1x1_pairw_kernel<T, true>), dim3(pb, B, mt), dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, res);
+                return;
+            }
             dim3 grid(pb, B, (mt + per - 1) / per);
 #define OSS_PAIR1(MT_, WT_, WV_) hipLaunchKernelGGL((oss_conv1x1_pairk_kernel<T, 8, MT_, WT_, WV_>), grid, dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, res)
 #define OSS_PAIR(MT_) do { if (wt) OSS_PAIR1(MT_, true, false); else if (wvec) OSS_PAIR1(MT_, false, true); else OSS_PAIR1(MT_, false, false); } while (0)
