@@ -859,6 +859,11 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
         const int pb = (P + 255) / 256;
         const long waves_p = (long)B * ((P + 63) / 64);
         const int xk = (int)xsk;
+        if (plain && !wvec && K > 16 * 3 && K <= 512 && (reinterpret_cast<uintptr_t>(w) & 15u) == 0) {
+            // forward with rows that are not 16-byte aligned (K = 127, the EFFN hidden width at dim 48): weight tile through LDS
+            hipLaunchKernelGGL((oss_conv1x1_pairw_kernel<T, false>), dim3(pb, B, mt), dim3(256), 0, s, x, w, bias, y, M, K, P, xsb, xk, res);
+            return;
+        }
         if (K <= 16 * 12) {
             // whole K in registers: enough workgroups to fill the chip twice, otherwise as few activation re-loads as possible
             int split = (int)((conv1x1_target_waves() + waves_p - 1) / waves_p);
