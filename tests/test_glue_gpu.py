@@ -77,7 +77,7 @@ def test_layernorm_on_channel_strided_views():
     assert_close(y, ln_ref(x.cpu(), w.cpu(), b.cpu(), gate.cpu()), 1e-4, 1e-4, "strided")
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 64, 64), (1, 5, 3, 7), (2, 8, 33, 70), (1, 96, 16, 8)])
+@pytest.mark.parametrize("shape", [(2, 48, 64, 64), (1, 5, 3, 7), (2, 8, 33, 70), (1, 96, 16, 8), (1, 3, 128, 128), (2, 4, 66, 130), (1, 2, 190, 64)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_merge4_bit_exact(shape, dt):
     """((y0 + flip y2) + T y1) + T flip y3 of the reference (MambaSISR6_arch.py:427-430) on the omni

@@ -13,7 +13,8 @@ DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 IDS = ["f32", "bf16", "f16"]
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 3, 7), (1, 48, 64, 64), (2, 8, 33, 70), (3, 96, 16, 8), (1, 4, 1, 9)])
+@pytest.mark.parametrize("shape", [(2, 5, 3, 7), (1, 48, 64, 64), (2, 8, 33, 70), (3, 96, 16, 8), (1, 4, 1, 9),
+                                   (1, 3, 128, 128), (2, 4, 66, 130), (1, 2, 64, 200), (1, 2, 190, 64)])   # 64 x 64 pair tiles, ragged edges
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_cross_scan2_and_merge2_bit_exact(shape, dt):
     torch.manual_seed(0)

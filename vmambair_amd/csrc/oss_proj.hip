@@ -812,8 +812,86 @@ int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, cons
 
 void proj_force_valu(int on) { g_proj_force_valu = on ? 1 : 0; }
 
+// 16-bit output, even H and W >= 64: the same two kernels on 64 x 64 tiles with TWO adjacent elements per lane on the contiguous
+// axis of every access (4-byte accesses; a wave's 2-byte accesses move 128 bytes per instruction -- DESIGN.md 4.4 rule 1).
+// The transposed side pairs two consecutive h: lane hx reads tile rows 2 hx and 2 hx + 1 (row stride 65 floats: conflict-free).
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+oss_cross_scan2_pair_kernel(const TI *__restrict__ x, TO *__restrict__ x2, int D, int H, int W, int64_t xsb, int64_t xsc) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 pairs x 8
+    const int tiles_w = (W + 63) >> 6;
+    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    const int d = blockIdx.y, b = blockIdx.z;
+    const TI *xp = x + b * xsb + d * xsc;
+    const size_t L = (size_t)H * W;
+    TO *o0 = x2 + ((size_t)(b * 2 + 0) * D + d) * L;
+    TO *o1 = x2 + ((size_t)(b * 2 + 1) * D + d) * L;
+    float val[8][2];
+    const int w = tw * 64 + 2 * tx, wc = min(w, W - 2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_v<TI, 2>(xp + (size_t)min(th * 64 + ty + 8 * r, H - 1) * W + wc, val[r]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int h = th * 64 + ty + 8 * r;
+        tile[ty + 8 * r][2 * tx] = val[r][0];
+        tile[ty + 8 * r][2 * tx + 1] = val[r][1];
+        if (h < H && w < W) store_v<TO, 2>(o0 + (size_t)h * W + w, val[r]);
+    }
+    __syncthreads();
+    const int h2 = th * 64 + 2 * tx;   // this lane's pair of rows
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int wl = ty + 8 * r, wg = tw * 64 + wl;
+        const float v[2] = {tile[2 * tx][wl], tile[2 * tx + 1][wl]};
+        if (wg < W && h2 < H) store_v<TO, 2>(o1 + (size_t)wg * H + h2, v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_cross_merge2_pair_kernel(const T *__restrict__ g2, T *__restrict__ dx, int D, int H, int W) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles_w = (W + 63) >> 6;
+    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+    const int d = blockIdx.y, b = blockIdx.z;
+    const size_t L = (size_t)H * W;
+    const T *g0 = g2 + ((size_t)(b * 2 + 0) * D + d) * L;
+    const T *g1 = g2 + ((size_t)(b * 2 + 1) * D + d) * L;
+    T *o = dx + ((size_t)b * D + d) * L;
+    float v1[8][2], v0[8][2];
+    const int h2 = th * 64 + 2 * tx, h2c = min(h2, H - 2);
+    const int w = tw * 64 + 2 * tx, wc = min(w, W - 2);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_v<T, 2>(g1 + (size_t)min(tw * 64 + ty + 8 * r, W - 1) * H + h2c, v1[r]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_v<T, 2>(g0 + (size_t)min(th * 64 + ty + 8 * r, H - 1) * W + wc, v0[r]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        tile[2 * tx][ty + 8 * r] = v1[r][0];
+        tile[2 * tx + 1][ty + 8 * r] = v1[r][1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int hl = ty + 8 * r, h = th * 64 + hl;
+        const float v[2] = {v0[r][0] + tile[hl][2 * tx], v0[r][1] + tile[hl][2 * tx + 1]};
+        if (h < H && w < W) store_v<T, 2>(o + (size_t)h * W + w, v);
+    }
+}
+
 template <typename TI, typename TO>
 static int cross_scan2_t(const void *x, void *x2, int B, int D, int H, int W, int64_t xsb, int64_t xsc, hipStream_t s) {
+    if constexpr (sizeof(TO) == 2) {
+        const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2);
+        if (H >= 64 && W >= 64 && H % 2 == 0 && W % 2 == 0 && xsb % 2 == 0 && xsc % 2 == 0 && (al & (sizeof(TI) == 4 ? 7u : 3u)) == 0) {
+            dim3 grid64(((H + 63) / 64) * ((W + 63) / 64), D, B);
+            hipLaunchKernelGGL((oss_cross_scan2_pair_kernel<TI, TO>), grid64, dim3(256), 0, s, reinterpret_cast<const TI *>(x),
+                               reinterpret_cast<TO *>(x2), D, H, W, xsb, xsc);
+            return (int)hipGetLastError();
+        }
+    }
     dim3 grid(((H + 31) / 32) * ((W + 31) / 32), D, B);
     hipLaunchKernelGGL((oss_cross_scan2_kernel<TI, TO>), grid, dim3(256), 0, s, reinterpret_cast<const TI *>(x),
                        reinterpret_cast<TO *>(x2), D, H, W, xsb, xsc);
@@ -835,6 +913,13 @@ int cross_scan2(oss_dtype it, oss_dtype ot, const void *x, void *x2, int B, int 
 
 int cross_merge2(oss_dtype io, const void *g2, void *dx, int B, int D, int H, int W, hipStream_t s) {
     if (B > 65535 || D > 65535) return OSS_ERR_SHAPE;
+    if (io != OSS_F32 && H >= 64 && W >= 64 && H % 2 == 0 && W % 2 == 0 &&
+        ((reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(dx)) & 3u) == 0) {
+        dim3 grid64(((H + 63) / 64) * ((W + 63) / 64), D, B);
+        if (io == OSS_F16) hipLaunchKernelGGL(oss_cross_merge2_pair_kernel<f16_t>, grid64, dim3(256), 0, s, reinterpret_cast<const f16_t *>(g2), reinterpret_cast<f16_t *>(dx), D, H, W);
+        else               hipLaunchKernelGGL(oss_cross_merge2_pair_kernel<bf16_t>, grid64, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g2), reinterpret_cast<bf16_t *>(dx), D, H, W);
+        return (int)hipGetLastError();
+    }
     dim3 grid(((H + 31) / 32) * ((W + 31) / 32), D, B);
     switch (io) {
         case OSS_F32:
