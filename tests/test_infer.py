@@ -189,3 +189,31 @@ def test_realsr_enhancer_fp16_on_gpu_matches_cpu_twin():
     got = drv.enhance_tensor(img)
     assert got.shape == (1, 3, 216, 152) and drv.tiled.n_graphs <= 9
     assert_close(got, want, 3e-2, 3e-2, "tiled fp16 output")
+    # the tiles of one padded shape stacked on the batch axis: the same image (and fewer forwards)
+    drv4 = RealSREnhancer(net_g, 4, tile=32, tile_pad=8, pre_pad=10, half=True, use_graph=True, batch_tiles=4)
+    got4 = drv4.enhance_tensor(img)
+    assert_close(got4, want, 3e-2, 3e-2, "tiled fp16 output, tiles stacked")
+    assert_close(got4, got, 2e-2, 2e-2, "stacked against tile by tile")
+    assert drv4.tiled.tiles_run == drv.tiled.tiles_run
+
+
+def test_tiles_stacked_on_the_batch_axis_give_the_same_image():
+    """TiledSR(batch_tiles=4): tiles of one padded shape go through the net together -- same output as one by one (CPU, a
+    net with per-sample statistics like the real one: instance-normalised 3x3 conv)"""
+    from vmambair_amd.infer import TiledSR
+    torch.manual_seed(0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Conv2d(3, 12, 3, padding=1)
+        def forward(self, x):
+            y = self.c(x)
+            y = y - y.mean(dim=(2, 3), keepdim=True)       # depends on the whole tile, never on other batch entries
+            return torch.nn.functional.pixel_shuffle(y, 2)
+    net = Net()
+    img = torch.rand(1, 3, 72, 88)
+    one = TiledSR(net, 2, tile=32, tile_pad=4, autocast_dtype=None, use_graph=False)(img)
+    for bt in (2, 4, 7):
+        many = TiledSR(net, 2, tile=32, tile_pad=4, autocast_dtype=None, use_graph=False, batch_tiles=bt)(img)
+        assert torch.allclose(many, one, atol=1e-6), bt
