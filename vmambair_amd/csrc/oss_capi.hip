@@ -68,6 +68,9 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
     const bool v2 = dstate <= 64 && !pair;   // round-2 kernel (oss_scan_bwd_v2.h): u:(8,192,4096) 0.172 ms against 0.203,
                                              // u:(8,384,4096) 0.235 against 0.284 (profiles/r02_scan_bwd_v2_experiments.txt)
+    // very few rows (Deraining level 0 at batch 4: 96 8-row workgroups for 256 CUs): 4-row workgroups spread the same waves over
+    // twice the CUs, one wave per SIMD instead of two (u:(4,192,16384): 0.585 ms against 0.684)
+    if (wgs <= 128 && v2 && rows_per_group % 4 == 0) return 13;
     if (wgs <= 256) return pair ? 9 : (v2 ? 11 : 3);
     // more rows per workgroup: fewer dB / dC partial tiles and an even load (u:(8,384,4096) bf16: 0.271 ms against
     // 0.355; u:(32,384,4096): 1.07 against 1.14)

@@ -569,7 +569,7 @@ static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, hipStre
         case 10: return launch_bwd2<T, 12, 4, 3>(p, stream, timer);
         case 11: return launch_bwd2<T, 8, 4, 2>(p, stream, timer);
         case 12: return launch_bwd2<T, 6, 4, 2>(p, stream, timer);
-        case 13: return launch_bwd2<T, 4, 4, 4>(p, stream, timer);
+        case 13: return launch_bwd2<T, 4, 4, 2>(p, stream, timer);   // 4-row workgroups for calls with few rows (one wave per SIMD, no spills)
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }
