@@ -454,6 +454,11 @@ oss_proj_dgrad_mfma_kernel(const T *__restrict__ dxdbl, const T *__restrict__ du
     }
 }
 
+// value of lane `src` (a compile-time index after unrolling) in every lane: v_readlane_b32, no memory traffic
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 // dts[b, k, d, p] = sum_r Wdt[k, d, r] xdbl[b, k, r, p]   (dt_proj on the ROUNDED dt rows; write-bound: the
 // (B, 4D, L) result is the largest tensor of the block).  grid (ceil(L / (64 V)), 4, B); lane = V consecutive time
 // steps; wave w owns d = w, w + nw, ...
@@ -475,18 +480,24 @@ oss_dt_fwd_kernel(const T *__restrict__ xdbl, const float *__restrict__ Wdt, T *
     for (int r = 0; r < RMAX; ++r)
 #pragma unroll
         for (int i = 0; i < V; ++i) zr[r][i] = r < R ? zr[r][i] : 0.f;
+    // a channel's R weights: ONE vector load (lane r holds w[r], zero past R), the next channel's row in flight during the
+    // current one; the values come out with v_readlane.  (R scalar loads per channel, each waited for, made the R = 24
+    // instantiation latency-bound: 27 us for a 13 MB problem.)
+    const int rl = min(lane, R - 1);
+    auto wrow = [&](int d) { return lane < R ? Wdt[((size_t)k * D + min(d, D - 1)) * R + rl] : 0.f; };
+    float wnext = wrow(wave);
     for (int d = wave; d < D; d += nw) {
-        const float *wr = Wdt + ((size_t)k * D + d) * R;
+        const float wl = wnext;
+        wnext = wrow(d + nw);
         float s[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) s[i] = 0.f;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r)
-            if (r < R) {
-                const float wv = wr[r];
+        for (int r = 0; r < RMAX; ++r) {
+            const float wv = lane_bcast(wl, r);
 #pragma unroll
-                for (int i = 0; i < V; ++i) s[i] = __builtin_fmaf(wv, zr[r][i], s[i]);
-            }
+            for (int i = 0; i < V; ++i) s[i] = __builtin_fmaf(wv, zr[r][i], s[i]);
+        }
         if (ok) store_v<T, V>(dts + ((size_t)(b * 4 + k) * D + d) * L + p, s);
     }
 }
@@ -515,18 +526,20 @@ oss_dt_dgrad_kernel(const T *__restrict__ ddts, const float *__restrict__ Wdt, T
         float g[DU][V];
 #pragma unroll
         for (int u = 0; u < DU; ++u) load_v<T, V>(ddts + ((size_t)(b * 4 + k) * D + min(d0 + u * nw, D - 1)) * L + pc, g[u]);
+        float wl[DU];   // the rows' weight vectors (lane r holds w[r]; zero past R and for rows past D), see oss_dt_fwd_kernel
 #pragma unroll
         for (int u = 0; u < DU; ++u) {
             const int d = d0 + u * nw;
-            const bool dok = d < D;
-            const float *wr = Wdt + ((size_t)k * D + (dok ? d : D - 1)) * R;
+            wl[u] = (lane < R && d < D) ? Wdt[((size_t)k * D + min(d, D - 1)) * R + min(lane, R - 1)] : 0.f;
+        }
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r)
-                if (r < R) {
-                    const float wv = dok ? wr[r] : 0.f;
+        for (int u = 0; u < DU; ++u) {
 #pragma unroll
-                    for (int i = 0; i < V; ++i) pa[r][i] = __builtin_fmaf(wv, g[u][i], pa[r][i]);
-                }
+            for (int r = 0; r < RMAX; ++r) {
+                const float wv = lane_bcast(wl[u], r);
+#pragma unroll
+                for (int i = 0; i < V; ++i) pa[r][i] = __builtin_fmaf(wv, g[u][i], pa[r][i]);
+            }
         }
     }
 #pragma unroll
