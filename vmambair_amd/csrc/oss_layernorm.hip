@@ -23,6 +23,11 @@ __device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_r
 
 constexpr int kLnMaxWaves = 16;
 
+// value of lane `src` (compile-time after unrolling) in every lane
+__device__ __forceinline__ float ln_lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 // sum over the workgroup's waves of V values per lane; fixed order.  red: [kLnMaxWaves][V][64]
 template <int V>
 __device__ __forceinline__ void ln_cross_wave_sum(float *red, float (&v)[V], int wave, int lane, int nw) {
@@ -177,8 +182,15 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     float s1[V], s2[V];
 #pragma unroll
     for (int u = 0; u < V; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
-    auto first = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
-        const float wc = w[c];
+    // the wave's weights and biases as ONE vector load each (lane i = channel slot i): a scalar load per channel, waited for
+    // inside the pass, was a round trip per channel
+    float wvec = 0.f, bvec = 0.f;
+    if constexpr (CPW > 0) {
+        const int cs = min(wave + min(lane, CPW - 1) * nw, C - 1);
+        wvec = w[cs];
+        bvec = with_bias ? bias[cs] : 0.f;
+    }
+    auto first = [&](int c, float wc, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
         float aw = 0.f, ab = 0.f;
 #pragma unroll
         for (int u = 0; u < V; ++u) {
@@ -221,7 +233,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
                 for (int u = 0; u < V; ++u) rv[i][u] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) first(c, xv[i], gv[i], zv[i]); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) first(c, ln_lane_bcast(wvec, i), xv[i], gv[i], zv[i]); }
     } else {
         for (int c = wave; c < C; c += nw) {
             float t[V], g[V], z[V];
@@ -230,7 +242,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 #pragma unroll
             for (int u = 0; u < V; ++u) z[u] = 0.f;
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
-            first(c, t, g, z);
+            first(c, w[c], t, g, z);
         }
     }
     ln_cross_wave_sum<V>(red[0], s1, wave, lane, nw);
@@ -243,8 +255,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     for (int u = 0; u < V; ++u) { m1[u] = s1[u] / (float)C; m2[u] = s2[u] / (float)C; }
     TX *dxp = dx + (size_t)b * C * P + pc;
     TY *dgp = GATE ? dgate + (size_t)b * dgsb + pc : nullptr;
-    auto second = [&](int c, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V], const float (&rval)[V]) {
-        const float wc = w[c], bc = with_bias ? bias[c] : 0.f;
+    auto second = [&](int c, float wc, float bc, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V], const float (&rval)[V]) {
         float d[V], dg[V];
 #pragma unroll
         for (int u = 0; u < V; ++u) {
@@ -269,7 +280,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     };
     if constexpr (CPW > 0) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) second(c, xv[i], gv[i], zv[i], rv[i]); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) second(c, ln_lane_bcast(wvec, i), ln_lane_bcast(bvec, i), xv[i], gv[i], zv[i], rv[i]); }
     } else {
         for (int c = wave; c < C; c += nw) {
             float t[V], g[V], z[V], r[V];
@@ -279,7 +290,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
             for (int u = 0; u < V; ++u) { z[u] = 0.f; r[u] = 0.f; }
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
             load_v<TX, V>(rsp + (size_t)c * P, r);
-            second(c, t, g, z, r);
+            second(c, w[c], with_bias ? bias[c] : 0.f, t, g, z, r);
         }
     }
 }
