@@ -112,8 +112,13 @@ oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
         store_v<float, V>(rstd_out + (size_t)b * P + p, rstd);
     }
     TY *yp = y + (size_t)b * C * P + pc;
-    auto emit = [&](int c, const float (&xval)[V], const float (&zval)[V]) {
-        const float wc = w[c], bc = with_bias ? bias[c] : 0.f;
+    float wvec = 0.f, bvec = 0.f;   // the wave's weights / biases: lane i = channel slot i (see the backward kernel)
+    if constexpr (CPW > 0) {
+        const int cs = min(wave + min(lane, CPW - 1) * nw, C - 1);
+        wvec = w[cs];
+        bvec = with_bias ? bias[cs] : 0.f;
+    }
+    auto emit = [&](int c, float wc, float bc, const float (&xval)[V], const float (&zval)[V]) {
         float o[V];
 #pragma unroll
         for (int u = 0; u < V; ++u) {
@@ -125,7 +130,7 @@ oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     };
     if constexpr (CPW > 0) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) emit(c, xv[i], zv[i]); }
+        for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) emit(c, ln_lane_bcast(wvec, i), ln_lane_bcast(bvec, i), xv[i], zv[i]); }
     } else {
         for (int c = wave; c < C; c += nw) {
             float t[V], z[V];
@@ -133,7 +138,7 @@ oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 #pragma unroll
             for (int u = 0; u < V; ++u) z[u] = 0.f;
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
-            emit(c, t, z);
+            emit(c, w[c], with_bias ? bias[c] : 0.f, t, z);
         }
     }
 }
