@@ -212,7 +212,9 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
     # that was measured at up to 5e-3 of the tensor's own scale.  A lost or doubled micro-batch would be an error of 0.5.
     tol = 1e-2 if acdt is None else 5e-2
     # bf16: noise floor of the small channel-branch gradients, see test_deferred_finishing_gives_the_same_gradients
-    floor = 1e-9 if acdt is None else 2e-3 * max(float(v.abs().max()) for v in got[1][1].values())
+    # ... and an absolute floor relative to the LARGEST gradient of the net: a tensor whose gradient is ~1e-7 of that (Dsc of
+    # the latent block) is summation-order noise in fp32 as well
+    floor = (1e-6 if acdt is None else 2e-3) * max(float(v.abs().max()) for v in got[1][1].values())
     wrong = []
     for k, ref in got[1][1].items():
         if k.endswith("conv_cout.bias"):
