@@ -90,6 +90,13 @@ typedef struct {
     const float *dt_weight; /* (dim, dt_rank) float contiguous, or NULL = `delta` is the (batch, dim, seqlen) tensor */
     int dt_rank, reserved1_;
     int64_t dt_group_stride, dt_rank_stride;
+    /* Optional scratch of oss_scan_fwd_workspace_bytes() bytes (no init needed) for oss_scan_fwd.  With it, calls whose
+     * (batch, group, row tile) grid cannot fill the GPU (batch-1 inference tiles, few-row levels) are cut into time
+     * segments that run as separate workgroups (two launches: segment-local pass, then the real pass from the folded
+     * carries; oss_scan_set_segments).  NULL / too small = every row is walked by one workgroup, as the reference does
+     * (cus/selective_scan_fwd_kernel.cuh:101-102).  Ignored by oss_scan_bwd (which has its own workspace). */
+    void *workspace;
+    size_t workspace_bytes;
 } oss_scan_fwd_params;
 
 /* Mirrors SSMParamsBwd (selective_scan.h:68-90). */
@@ -131,6 +138,7 @@ int oss_scan_chunk(void);
 int oss_scan_num_chunks(int seqlen);
 
 /* Replaces selective_scan_fwd_cuda<1, input_t, float> (cus/selective_scan_fwd_kernel.cuh:174-207). */
+size_t oss_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups);   /* 0 when seqlen <= 256 */
 int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream);
 
 /* Replaces selective_scan_bwd_cuda<1, input_t, float> (cus/selective_scan_bwd_kernel.cuh:275-310)
@@ -150,6 +158,12 @@ int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstat
  * unknown number falls back to the small-shape variant. */
 void oss_scan_set_variant(int fwd_variant, int bwd_variant);
 int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
+/* Time segments per row of the next launches (tuning / tests): -1 = heuristic (segments only when the launch would leave
+ * most CUs without a workgroup), 0 or 1 = never, n > 1 = n segments (clamped to the number of chunks of the kernel variant;
+ * the backward segments only its round-2 kernels, variants 10..13, dstate <= 64, and never the fused-delta form).
+ * oss_scan_last_segments: what the last call used (1 = unsegmented). */
+void oss_scan_set_segments(int fwd_segments, int bwd_segments);
+int oss_scan_last_segments(int which /* 0 fwd, 1 bwd */);
 
 /* Depth-wise 3x3 convolution, stride 1, zero padding 1, of the OSS block: SS2D_1.conv2d
  * (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:286-294) and the EFFN dwconv (:209); both are

@@ -45,6 +45,7 @@ def test_struct_layout_matches_header():
 #include <stddef.h>
 #include "vmambair_oss.h"
 int main(void) {
+  printf("%zu %zu ", offsetof(oss_scan_fwd_params, workspace), offsetof(oss_scan_fwd_params, workspace_bytes));
   printf("%zu %zu %zu %zu %zu %zu ", offsetof(oss_scan_fwd_params, dt_weight), offsetof(oss_scan_fwd_params, dt_rank),
          offsetof(oss_scan_fwd_params, dt_rank_stride), offsetof(oss_scan_bwd_params, ddt), offsetof(oss_scan_bwd_params, ddt_weight),
          offsetof(oss_scan_bwd_params, ddt_rank_stride));
@@ -62,7 +63,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     F, B, Ch = _capi.ScanFwdParams, _capi.ScanBwdParams, _capi.ChanParams
-    want = [F.dt_weight.offset, F.dt_rank.offset, F.dt_rank_stride.offset, B.ddt.offset, B.ddt_weight.offset, B.ddt_rank_stride.offset,
+    want = [F.workspace.offset, F.workspace_bytes.offset, F.dt_weight.offset, F.dt_rank.offset, F.dt_rank_stride.offset, B.ddt.offset, B.ddt_weight.offset, B.ddt_rank_stride.offset,
             ctypes.sizeof(F), F.u_batch_stride.offset, F.u.offset, F.x.offset, ctypes.sizeof(B),
             B.dout_batch_stride.offset, B.dout.offset, B.workspace_bytes.offset, B.dBC_group_stride.offset,
             ctypes.sizeof(Ch), Ch.pooled.offset, Ch.zt.offset, Ch.c.offset]
@@ -76,6 +77,21 @@ def test_workspace_query_is_pure():
     # per row tile: dB / dC partial rows (2 * dstate) + 8 rows for the fused-delta form; per (batch, row): dA, dD, dbias, 8 dt weights
     assert n == 4 * (2 * 4 * tiles * (2 * 16 + 8) * 100 + 2 * 8 * (18 + 8))
     assert lib.oss_scan_bwd_workspace_bytes(2, 7, 100, 16, 4) == 0  # dim % n_groups != 0
+    # long sequences: room for time-segmented launches -- one weight-gradient partial per (batch, segment, row) and the
+    # reverse-carry pairs; segments are counted in 512-step chunks, at most 64
+    n = lib.oss_scan_bwd_workspace_bytes(1, 8, 2048, 16, 4)
+    assert n == 4 * (1 * 4 * 1 * (2 * 16 + 8) * 2048 + 1 * 4 * 8 * (18 + 8) + 2 * 1 * 8 * 16 * 4)
+    # forward: (prod a, h) per (batch, row, segment, state); segments counted in 256-step chunks, at most 64; none needed below
+    assert lib.oss_scan_fwd_workspace_bytes(2, 8, 256, 16, 4) == 0
+    assert lib.oss_scan_fwd_workspace_bytes(2, 8, 1000, 16, 4) == 4 * 2 * 2 * 8 * 16 * 4
+    assert lib.oss_scan_fwd_workspace_bytes(1, 384, 160 * 160, 16, 4) == 4 * 2 * 384 * 16 * 64
+
+
+def test_segment_override_round_trips_without_a_gpu():
+    lib = _capi.load()
+    lib.oss_scan_set_segments(3, 5)
+    lib.oss_scan_set_segments(-1, -1)
+    assert lib.oss_scan_last_segments(0) >= 1 and lib.oss_scan_last_segments(1) >= 1
 
 
 def test_cpu_tensors_are_rejected_not_silently_computed():

@@ -537,3 +537,137 @@ def test_large_dstate_falls_back_when_the_tiles_do_not_fit_lds():
     small-shape variant instead of failing; the reference admits dstate <= 256 (selective_scan.cpp:191)"""
     check_fwd_bwd(make_inputs(1, 24, 250, 2, 1100, torch.float32), True, torch.float32, fwd_variant=6, bwd_variant=6)
     check_fwd_bwd(make_inputs(1, 24, 250, 2, 1100, torch.float32), True, torch.float32, fwd_variant=3, bwd_variant=10)
+
+
+# ------------------------------------------------------------------------------------------------
+# time-segmented launches (round 3): workgroup = (batch, group, row tile, SEGMENT); the reference walks a row's chunks
+# sequentially in one block (cus/selective_scan_fwd_kernel.cuh:101-102,147-158, cus/selective_scan_bwd_kernel.cuh:120-125,184)
+# ------------------------------------------------------------------------------------------------
+def _with_segments(fs, bs, fn):
+    lib = _capi.load()
+    lib.oss_scan_set_segments(fs, bs)
+    try:
+        return fn(lib)
+    finally:
+        lib.oss_scan_set_segments(-1, -1)
+        lib.oss_scan_set_variant(-1, -1)
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("seqlen", [1024, 2048 + 37, 4096 + 3, 5000])
+@pytest.mark.parametrize("segs", [2, 3, 5, 64])
+def test_time_segmented_scans_match_oracle(itype, seqlen, segs):
+    """every segment count (64 = one chunk per segment) at full, ragged and non-multiple-of-4 lengths, all seven gradients"""
+    if itype != torch.float32 and segs == 5:
+        pytest.skip("16-bit types: 2, 3 and max segments")
+
+    def run(lib):
+        check_fwd_bwd(make_inputs(2, 24, 16, 2, seqlen, itype), True, itype)
+        assert lib.oss_scan_last_segments(0) > 1 and lib.oss_scan_last_segments(1) > 1, "the segmented kernels did not run"
+    _with_segments(segs, segs, run)
+
+
+@pytest.mark.parametrize("fv,bv", [(0, 10), (3, 11), (6, 12), (5, 13), (7, 10), (4, 11), (1, 13), (2, 10)])
+def test_time_segments_on_every_kernel_variant(fv, bv):
+    """forward variants differ in chunk length (256 / 512 / 1024) and rows per wave; backward: the four round-2 row-tile sizes.
+    Ragged row tiles (13 rows per group), no softplus / D / bias on one leg."""
+    def run(lib):
+        lib.oss_scan_set_variant(fv, bv)
+        # check_fwd_bwd resets the variant override at its end, so force it inside via its arguments
+        check_fwd_bwd(make_inputs(2, 26, 16, 2, 3000, torch.float32), True, torch.float32, fwd_variant=fv, bwd_variant=bv)
+        assert lib.oss_scan_last_segments(0) > 1 and lib.oss_scan_last_segments(1) > 1
+        check_fwd_bwd(make_inputs(1, 16, 5, 4, 2100, torch.float32, has_D=False, has_bias=False), False, torch.float32,
+                      fwd_variant=fv, bwd_variant=bv)
+    _with_segments(3, 4, run)
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("segs", [2, 7])
+def test_time_segments_in_the_omni_form(itype, segs):
+    """time-mirrored groups (rev_group_start), shared u / dout rows, A_log form: the calls the blocks make"""
+    _with_segments(segs, segs, lambda lib: (_omni_scan_case(2085, itype, 8), _omni_scan_case(3000, itype, 48)))
+
+
+def test_time_segments_large_dstate_and_fallbacks():
+    """dstate 40 (three 16-state tiles), dstate 72 (> 64: the backward takes the unsegmented round-1 kernel, the forward still
+    segments), a forward workspace that is too small (falls back to the unsegmented launch, same results)"""
+    def run(lib):
+        check_fwd_bwd(make_inputs(1, 8, 40, 2, 2500, torch.float32), True, torch.float32)
+        assert lib.oss_scan_last_segments(0) > 1 and lib.oss_scan_last_segments(1) > 1
+        check_fwd_bwd(make_inputs(1, 8, 72, 2, 1500, torch.float32), True, torch.float32, bwd_variant=10)
+        assert lib.oss_scan_last_segments(1) == 1
+    _with_segments(4, 4, run)
+
+
+def test_segmented_and_unsegmented_launches_agree_and_are_stable():
+    """same inputs with 1 and with 4 segments: equal to fp32 round-off (a segment's entering state is the fold of
+    segment-local states, a different association of the same products); reruns of the segmented launch are bit-identical"""
+    ins = to_dev(make_inputs(2, 48, 16, 4, 4096, torch.float32))
+    u, delta, A, B, C, D, bias, dout = ins
+
+    def both(lib):
+        o, x = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1)
+        g = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x, True, 1)
+        return o, x, g, lib.oss_scan_last_segments(0), lib.oss_scan_last_segments(1)
+    o1, x1, g1, sf1, sb1 = _with_segments(1, 1, both)
+    o4, x4, g4, sf4, sb4 = _with_segments(4, 4, both)
+    o4b, x4b, g4b, _, _ = _with_segments(4, 4, both)
+    assert (sf1, sb1) == (1, 1) and sf4 == 4 and sb4 == 4
+    assert torch.equal(o4, o4b) and torch.equal(x4, x4b) and all(torch.equal(a, b) for a, b in zip(g4, g4b))
+    assert_close(o4, o1, 1e-5, 1e-5 * float(o1.abs().max()), "out: 4 segments vs 1")
+    assert_close(x4[..., 1::2], x1[..., 1::2], 1e-5, 1e-5 * float(x1[..., 1::2].abs().max()), "saved states")
+    for n, a, b in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], g4, g1):
+        assert_close(a, b, 1e-4, 2e-5 * float(b.abs().max()), n + ": 4 segments vs 1")
+
+
+def test_segment_heuristic_fills_idle_cus_only():
+    """the default picks segments for under-filled launches (RealSR tiles at batch 1, Deraining level 0 at batch 4) and leaves
+    the headline launches (one workgroup per CU already) alone"""
+    lib = _capi.load()
+
+    def segs(Bsz, KD, G, L, itype=torch.bfloat16):
+        ins = to_dev(make_inputs(Bsz, KD, 16, G, L, itype))
+        u, delta, A, B, C, D, bias, dout = ins
+        o, x = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1)
+        vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x, True, 1)
+        torch.cuda.synchronize()
+        return lib.oss_scan_last_segments(0), lib.oss_scan_last_segments(1)
+    assert segs(8, 384, 4, 4096) == (1, 1)
+    f, b = segs(1, 384, 4, 128 * 128)
+    assert f > 1 and b > 1
+    f, b = segs(4, 192, 4, 128 * 128)
+    assert f > 1 and b > 1
+
+
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_segmented_scan_at_inference_tile_length(itype):
+    """RealSR tile: batch 1, u (1, 384, 160*160) -- sampled rows of out / du / ddelta against the oracle, dB / dC of one
+    group against the oracle on that group's rows"""
+    torch.manual_seed(3)
+    Bsz, KD, N, G, L = 1, 384, 16, 4, 160 * 160
+    u = torch.randn(Bsz, KD, L, device=DEV).to(itype)
+    delta = (0.5 * torch.rand(Bsz, KD, L, device=DEV)).to(itype)
+    A = -0.5 * torch.rand(KD, N, device=DEV)
+    Bm = torch.randn(Bsz, G, N, L, device=DEV).to(itype)
+    Cm = torch.randn(Bsz, G, N, L, device=DEV).to(itype)
+    D = torch.randn(KD, device=DEV)
+    bias = 0.5 * torch.rand(KD, device=DEV)
+    dout = torch.randn(Bsz, KD, L, device=DEV).to(itype)
+    lib = _capi.load()
+    out, x = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+    assert lib.oss_scan_last_segments(0) > 1
+    g = vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
+    assert lib.oss_scan_last_segments(1) > 1
+    rtol, atol = TOL[itype]
+    g0 = 1
+    rows = slice(g0 * (KD // G), (g0 + 1) * (KD // G))      # every row of group 1: dB / dC need all of them
+    sub = [t.cpu() for t in (u[:, rows], delta[:, rows], A[rows], Bm[:, g0:g0 + 1], Cm[:, g0:g0 + 1], D[rows], bias[rows])]
+    ref_out, ref_x = oss_oracle.scan_fwd(*sub, True, chunk=256)
+    ref = oss_oracle.scan_bwd(*sub, dout[:, rows].cpu(), None, True)
+    assert_close(out[:, rows], ref_out, rtol, atol, "out")
+    assert_close(x[:, rows][..., 1::2], ref_x[..., 1::2], 6e-4, 2e-3, "states")
+    assert_close(g[0][:, rows], ref[0], rtol * 2, atol * 2, "du")
+    assert_close(g[1][:, rows], ref[1], rtol * 5, atol * 10, "ddelta")
+    assert_close(g[3][:, g0:g0 + 1], ref[3], rtol, atol * 4, "dB (96-row sums)")
+    assert_close(g[4][:, g0:g0 + 1], ref[4], rtol, atol * 4, "dC (96-row sums)")
+    assert_close(g[2][rows], ref[2], RTOLW, max(ATOLW * 5, 2e-3 * float(ref[2].abs().max())), "dA")

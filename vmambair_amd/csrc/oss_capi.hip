@@ -12,6 +12,29 @@ namespace oss {
 
 static std::atomic<int> g_force_fwd{-1}, g_force_bwd{-1};
 static std::atomic<int> g_last_fwd{-1}, g_last_bwd{-1};
+static std::atomic<int> g_force_fwd_seg{-1}, g_force_bwd_seg{-1};
+std::atomic<int> g_last_fwd_segments{1}, g_last_bwd_segments{1};
+
+// Segments of a launch that has `wgs` workgroups (one per CU at a time for the wide variants) over `n_chunks` chunks when
+// it is not cut in time.  Cost model in units of one chunk of one workgroup: rounds over the 256 CUs x chunks per segment x
+// (1 + ovh), where ovh is the extra sweep a segmented launch pays (forward: the B side of the step again, ~0.55 of a pass;
+// backward: the reverse recurrence alone, ~0.3).  Launches that already put a workgroup on every CU are left alone, and a
+// larger segment count has to win by 5 % to be taken.
+int scan_pick_segments(long wgs, int n_chunks, int seg_req, double ovh) {
+    if (seg_req == 0 || seg_req == 1 || n_chunks < 2 || wgs <= 0) return 1;
+    if (seg_req > 1) return std::min(std::min(seg_req, n_chunks), kMaxSegments);
+    if (wgs >= 256) return 1;
+    int best = 1;
+    double best_cost = (double)n_chunks;
+    for (int s = 2; s <= std::min(n_chunks, 16); ++s) {
+        const int cps = (n_chunks + s - 1) / s;
+        if ((n_chunks + cps - 1) / cps != s) continue;   // not a segment count this chunk count can have
+        const double rounds = (double)((wgs * s + 255) / 256);
+        const double cost = rounds * cps * (1.0 + ovh);
+        if (cost < 0.95 * best_cost) { best = s; best_cost = cost; }
+    }
+    return best;
+}
 
 // ---- variant heuristics -----------------------------------------------------------------------
 // The forward/backward kernels are VALU-bound, so the cheapest variant in instructions per
@@ -176,13 +199,15 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
     int v = g_force_fwd.load();
     if (v < 0) v = scan_fwd_pick_variant(p->batch, p->dim, p->seqlen, p->dstate, p->n_groups, eb);
     g_last_fwd.store(v);
+    g_last_fwd_segments.store(1);
+    const int sr = g_force_fwd_seg.load();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfTimer prof(0, v, (int)io, fwd_alg_bytes(*p, eb), fwd_own_bytes(*p, eb));
     prof.begin(s);
     switch (io) {
-        case OSS_F32: rc = scan_fwd_dispatch<float>(*p, v, s); break;
-        case OSS_F16: rc = scan_fwd_dispatch<f16_t>(*p, v, s); break;
-        case OSS_BF16: rc = scan_fwd_dispatch<bf16_t>(*p, v, s); break;
+        case OSS_F32: rc = scan_fwd_dispatch<float>(*p, v, sr, s); break;
+        case OSS_F16: rc = scan_fwd_dispatch<f16_t>(*p, v, sr, s); break;
+        case OSS_BF16: rc = scan_fwd_dispatch<bf16_t>(*p, v, sr, s); break;
         default: rc = OSS_ERR_SHAPE;
     }
     prof.end(s);
@@ -201,10 +226,19 @@ size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, 
     const int rows_per_group = dim / n_groups;
     const int rows = scan_bwd_rows_per_wg(1);
     const size_t tiles = (size_t)(rows_per_group + rows - 1) / rows;
-    // + kMaxDtRank partial rows per tile and kMaxDtRank dt-weight partials per (batch, row): the fused-delta form
+    // + kMaxDtRank partial rows per tile and kMaxDtRank dt-weight partials per (batch, row): the fused-delta form;
+    // time-segmented launches: one weight-gradient partial per (batch, segment, row) + the reverse-carry pairs
+    const size_t segs = (size_t)std::min(kMaxSegments, std::max(1, (seqlen + 511) / 512));
     const size_t floats = (size_t)batch * n_groups * tiles * (2 * dstate + kMaxDtRank) * seqlen +
-                          (size_t)batch * dim * (dstate + 2 + kMaxDtRank);
+                          (size_t)batch * segs * dim * (dstate + 2 + kMaxDtRank) +
+                          (segs > 1 ? 2 * (size_t)batch * dim * dstate * segs : 0);
     return floats * sizeof(float);
+}
+
+size_t oss_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups) {
+    if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups) return 0;
+    const int segs = std::min(kMaxSegments, (seqlen + kScanChunk - 1) / kScanChunk);   // the shortest chunk any variant has
+    return segs > 1 ? scan_carry_bytes(batch, dim, dstate, segs) : 0;
 }
 
 int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream) {
@@ -224,10 +258,11 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     const int eb = io == OSS_F32 ? 4 : 2;
     ProfTimer prof(1, v, (int)io, bwd_alg_bytes(f, eb), bwd_own_bytes(*p, eb));
     ProfTimer fprof(2, v, (int)io, 0.0);   // the finishing kernel of the same call
+    const int sr = g_force_bwd_seg.load();
     switch (io) {
-        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, s, &prof, &fprof);
-        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, s, &prof, &fprof);
-        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, s, &prof, &fprof);
+        case OSS_F32: return scan_bwd_dispatch<float>(*p, v, sr, s, &prof, &fprof);
+        case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, sr, s, &prof, &fprof);
+        case OSS_BF16: return scan_bwd_dispatch<bf16_t>(*p, v, sr, s, &prof, &fprof);
     }
     return OSS_ERR_SHAPE;
 }
@@ -491,6 +526,11 @@ void oss_scan_set_variant(int fwd_variant, int bwd_variant) {
     g_force_bwd.store(bwd_variant);
 }
 int oss_scan_last_variant(int which) { return which == 0 ? g_last_fwd.load() : g_last_bwd.load(); }
+void oss_scan_set_segments(int fwd_segments, int bwd_segments) {
+    g_force_fwd_seg.store(fwd_segments);
+    g_force_bwd_seg.store(bwd_segments);
+}
+int oss_scan_last_segments(int which) { return which == 0 ? g_last_fwd_segments.load() : g_last_bwd_segments.load(); }
 
 __global__ void __launch_bounds__(256) oss_copy_kernel(const f32x4 *src, f32x4 *dst, size_t n) {
     // eight 16-byte loads in flight per lane before the first store (one load per iteration left the memory system idle

@@ -342,8 +342,9 @@ __device__ __forceinline__ void dt_rows_apply(const DtRows<T, I> &d, int R, bool
 }
 
 // Stage nb state rows x TC scan positions of one (batch, group) of B and C into the LDS tiles as
-// fp32 (tile_off image).  `rev`: scan position s reads memory L-1-s.
-template <typename T, int LPR, int I, int NT>
+// fp32 (tile_off image).  `rev`: scan position s reads memory L-1-s.  WITH_C = false stages B only (the local pass of
+// the time-segmented forward never touches C).
+template <typename T, int LPR, int I, int NT, bool WITH_C = true>
 __device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB, const T *gC, int64_t strideB,
                                                int64_t strideC, int nb, int t0, int L, bool rev, int tid) {
     constexpr int TC = LPR * I;
@@ -355,17 +356,25 @@ __device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB
         const int s0 = t0 + 4 * k;                       // first scan position of the group
         const int m0 = rev ? (L - 4 - s0) : s0;          // lowest memory index of the group
         const T *pb = gB + n * strideB + m0;
-        const T *pc = gC + n * strideC + m0;
-        float b4[4], c4[4];
+        const T *pc = WITH_C ? gC + n * strideC + m0 : pb;
+        float b4[4], c4[4] = {0.f, 0.f, 0.f, 0.f};
         if (fullchunk && ((reinterpret_cast<uintptr_t>(pb) | reinterpret_cast<uintptr_t>(pc)) & amask) == 0) {
             if constexpr (sizeof(T) == 4) {
-                f32x4 qb = *reinterpret_cast<const f32x4 *>(pb), qc = *reinterpret_cast<const f32x4 *>(pc);
+                f32x4 qb = *reinterpret_cast<const f32x4 *>(pb);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { b4[j] = qb[j]; c4[j] = qc[j]; }
+                for (int j = 0; j < 4; ++j) b4[j] = qb[j];
+                if constexpr (WITH_C) {
+                    f32x4 qc = *reinterpret_cast<const f32x4 *>(pc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c4[j] = qc[j];
+                }
             } else {
-                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb), qc = *reinterpret_cast<const u32x2 *>(pc);
+                u32x2 qb = *reinterpret_cast<const u32x2 *>(pb);
                 unpack2<T>(qb.x, b4[0], b4[1]); unpack2<T>(qb.y, b4[2], b4[3]);
-                unpack2<T>(qc.x, c4[0], c4[1]); unpack2<T>(qc.y, c4[2], c4[3]);
+                if constexpr (WITH_C) {
+                    u32x2 qc = *reinterpret_cast<const u32x2 *>(pc);
+                    unpack2<T>(qc.x, c4[0], c4[1]); unpack2<T>(qc.y, c4[2], c4[3]);
+                }
             }
         } else {
 #pragma unroll
@@ -373,7 +382,7 @@ __device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB
                 const int m = m0 + j;
                 const bool ok = m >= 0 && m < L;
                 b4[j] = ok ? to_f32(gB[n * strideB + m]) : 0.f;
-                c4[j] = ok ? to_f32(gC[n * strideC + m]) : 0.f;
+                if constexpr (WITH_C) c4[j] = ok ? to_f32(gC[n * strideC + m]) : 0.f;
             }
         }
         f32x4 vb, vc;
@@ -382,7 +391,7 @@ __device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB
         const int pos = (4 * k) / I, i0 = (4 * k) % I;
         const int off = tile_off<LPR, I>(n, pos, i0);
         *reinterpret_cast<f32x4 *>(sB + off) = vb;
-        *reinterpret_cast<f32x4 *>(sC + off) = vc;
+        if constexpr (WITH_C) *reinterpret_cast<f32x4 *>(sC + off) = vc;
     }
 }
 

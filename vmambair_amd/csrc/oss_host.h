@@ -30,7 +30,15 @@ struct LdsGate {
     }
 };
 
-template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t stream);
+// Time-segmented launches (oss_scan_fwd.hip: FwdSeg, oss_scan_bwd_v2.h: BwdSeg).  seg_req: -1 = heuristic, 0 / 1 = never,
+// n > 1 = n segments (clamped to the number of chunks).
+constexpr int kMaxSegments = 64;
+int scan_pick_segments(long wgs, int n_chunks, int seg_req, double ovh);
+inline size_t scan_carry_bytes(int batch, int dim, int dstate, int n_seg) {
+    return sizeof(float) * 2 * (size_t)batch * dim * dstate * n_seg;
+}
+extern std::atomic<int> g_last_fwd_segments, g_last_bwd_segments;
+template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream);
 // one timer brackets the MAIN backward kernel, a second one the finishing kernel (oss_prof_* buckets 1 and 2)
 struct LaunchTimer {
     virtual void begin(hipStream_t) = 0;
@@ -38,7 +46,7 @@ struct LaunchTimer {
     virtual ~LaunchTimer() = default;
 };
 template <typename T>
-int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer,
+int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, int seg_req, hipStream_t stream, LaunchTimer *timer,
                       LaunchTimer *finish_timer = nullptr);
 
 // number of row tiles the backward splits a group into for `variant` (workspace sizing)

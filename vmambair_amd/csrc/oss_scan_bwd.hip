@@ -362,6 +362,7 @@ struct FinishArgs {
     const float *ws_dA, *ws_dD, *ws_db, *ws_dW;
     float *dA, *dD, *db, *dW;
     int batch, dim;
+    int wbatch;                 // weight-gradient partials per row: batch * time segments
     const float *A_log;
     int64_t A_d_stride;
     size_t out_group_stride;    // (batch, group) block stride of dB and of dC
@@ -377,7 +378,7 @@ oss_scan_bwd_finish(const FinishArgs a) {
         const int total_w = a.dim * a.N + a.dim + a.dim * a.R;
         const int stride = (int)(gridDim.x * gridDim.y) * 256;
         for (int i = (int)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x; i < total_w; i += stride)
-            finish_w(i, a.ws_dA, a.ws_dD, a.ws_db, a.dA, a.dD, a.db, a.batch, a.dim, a.N, a.A_log, a.A_d_stride, a.ws_dW, a.dW, a.R);
+            finish_w(i, a.ws_dA, a.ws_dD, a.ws_db, a.dA, a.dD, a.db, a.wbatch, a.dim, a.N, a.A_log, a.A_d_stride, a.ws_dW, a.dW, a.R);
         return;
     }
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -409,20 +410,26 @@ namespace oss {
 
 static thread_local LaunchTimer *g_finish_timer = nullptr;   // set by scan_bwd_dispatch around the launchers
 
-// workspace carving shared by the launchers; -> OSS_OK or OSS_ERR_WORKSPACE
-static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, float *&wdD, float *&wdb) {
+// workspace carving shared by the launchers; -> OSS_OK or OSS_ERR_WORKSPACE.  n_seg > 1 (time-segmented launch): one
+// weight-gradient partial per (batch, segment, row) and, behind them, the reverse-carry pairs (*carry).
+static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, float *&wdD, float *&wdb, int n_seg = 1,
+                    float **carry = nullptr) {
     const oss_scan_fwd_params &f = p.f;
     const int rows_per_group = f.dim / f.n_groups;
     const int tiles = (rows_per_group + rows_per_wg - 1) / rows_per_wg;
     const int rp = f.dt_weight ? f.dt_rank : 0;
     const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen, rp);
-    const size_t need = sizeof(float) * (n_bc + (size_t)f.batch * f.dim * (f.dstate + 2 + (rp ? kMaxDtRank : 0)));
+    const size_t wb = (size_t)f.batch * n_seg;
+    const size_t n_w = wb * f.dim * (f.dstate + 2 + (rp ? kMaxDtRank : 0));
+    const size_t n_carry = n_seg > 1 ? scan_carry_bytes(f.batch, f.dim, f.dstate, n_seg) / sizeof(float) : 0;
+    const size_t need = sizeof(float) * (n_bc + n_w + n_carry);
     if (!p.workspace || p.workspace_bytes < need) return OSS_ERR_WORKSPACE;
     ws.bc = reinterpret_cast<float *>(p.workspace);
     ws.dA = ws.bc + n_bc;
-    ws.dD = ws.dA + (size_t)f.batch * f.dim * f.dstate;
-    ws.db = ws.dD + (size_t)f.batch * f.dim;
-    ws.dW = rp ? ws.db + (size_t)f.batch * f.dim : nullptr;
+    ws.dD = ws.dA + wb * f.dim * f.dstate;
+    ws.db = ws.dD + wb * f.dim;
+    ws.dW = rp ? ws.db + wb * f.dim : nullptr;
+    if (carry) *carry = ws.bc + n_bc + n_w;
     ws.tiles = tiles;
     ws.rp = rp;
     wdD = ws.dD; wdb = ws.db;
@@ -432,9 +439,10 @@ static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, fl
 }
 
 template <typename T>
-static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *wdD, float *wdb, hipStream_t stream) {
+static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *wdD, float *wdb, hipStream_t stream, int n_seg = 1) {
     const oss_scan_fwd_params &f = p.f;
     FinishArgs a;
+    a.wbatch = f.batch * n_seg;
     a.ws_bc = ws.bc; a.dB = p.dB; a.dC = p.dC; a.dZ = p.ddt;
     a.tiles = ws.tiles; a.N = f.dstate; a.RP = ws.rp; a.R = ws.rp ? f.dt_rank : 0; a.G = f.n_groups;
     a.L = (size_t)f.seqlen;
@@ -454,12 +462,12 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
     return (int)hipGetLastError();
 }
 
-template <typename K>
+template <typename K, typename... Extra>
 static int launch_main(K kern, size_t smem, LdsGate &gate, unsigned nblocks, int nthreads,
-                       const oss_scan_bwd_params &p, const BwdWs &ws, hipStream_t stream, LaunchTimer *timer) {
+                       const oss_scan_bwd_params &p, const BwdWs &ws, hipStream_t stream, LaunchTimer *timer, Extra... extra) {
     if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
     if (timer) timer->begin(stream);
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nthreads), smem, stream, p, ws);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nthreads), smem, stream, p, ws, extra...);
     if (timer) timer->end(stream);
     return (int)hipGetLastError();
 }
@@ -506,20 +514,48 @@ static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, Lau
 
 // round-2 kernel (oss_scan_bwd_v2.h): lane-resident per-state scalars, register-prefetched tiles, one barrier per state
 template <typename T, int WAVES, int NBB, int MINW, bool FD = false>
-static int launch_bwd2(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
+static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t stream, LaunchTimer *timer) {
     if constexpr (!FD) {
-        if (p.f.dt_weight) return launch_bwd2<T, WAVES, NBB, MINW, true>(p, stream, timer);
+        if (p.f.dt_weight) return launch_bwd2<T, WAVES, NBB, MINW, true>(p, seg_req, stream, timer);
     }
     constexpr int TC = 512;
     const oss_scan_fwd_params &f = p.f;
+    const int rows_per_group = f.dim / f.n_groups;
+    const int tiles = (rows_per_group + WAVES - 1) / WAVES;
+    const unsigned wgs = (unsigned)(f.batch * f.n_groups * tiles);
+    const int n_chunks = (f.seqlen + TC - 1) / TC;
+    int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.3);
+    int cps = n_chunks;
+    if (n_seg > 1) { cps = (n_chunks + n_seg - 1) / n_seg; n_seg = (n_chunks + cps - 1) / cps; }
     BwdWs ws;
-    float *wdD, *wdb;
-    int rc = carve_ws(p, WAVES, ws, wdD, wdb);
+    float *wdD, *wdb, *carry = nullptr;
+    int rc = carve_ws(p, WAVES, ws, wdD, wdb, n_seg, &carry);
+    if (rc != OSS_OK && n_seg > 1) {   // a caller that sized the workspace for the unsegmented form
+        n_seg = 1; cps = n_chunks;
+        rc = carve_ws(p, WAVES, ws, wdD, wdb);
+    }
     if (rc != OSS_OK) return rc;
+    g_last_bwd_segments.store(n_seg);
     const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + (FD ? WAVES * kMaxDtRank : 0));   // two tile buffers, two slab buffers (+ dt weights)
+    if constexpr (!FD) {
+        if (n_seg > 1) {
+            const BwdSeg sg{carry, n_seg, cps};
+            auto kc = oss_scan_bwd_carry_kernel<T, WAVES>;
+            if (timer) timer->begin(stream);
+            hipLaunchKernelGGL(kc, dim3(wgs * (unsigned)(n_seg - 1)), dim3(WAVES * 64), sizeof(float) * kNB * TC, stream, p, sg, tiles);
+            auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true>;
+            static LdsGate gate_s;
+            if (const int e = gate_s.ensure(reinterpret_cast<const void *>(km), smem)) return e;
+            hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
+            if (timer) timer->end(stream);
+            rc = (int)hipGetLastError();
+            if (rc != OSS_OK) return rc;
+            return launch_finish<T>(p, ws, wdD, wdb, stream, n_seg);
+        }
+    }
     static LdsGate gate;
-    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD>, smem, gate,
-                     (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
+    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
+                     BwdSeg{nullptr, 1, n_chunks});
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);
 }
@@ -538,16 +574,18 @@ static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8, 12, 8, 12, 8, 6, 4};
 int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 13) ? 1 : variant]; }
 
 template <typename T>
-static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer);
+static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, int seg_req, hipStream_t stream, LaunchTimer *timer);
 template <typename T>
-int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer, LaunchTimer *finish_timer) {
+int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, int seg_req, hipStream_t stream, LaunchTimer *timer,
+                      LaunchTimer *finish_timer) {
     g_finish_timer = finish_timer;
-    const int rc = scan_bwd_dispatch_<T>(p, variant, stream, timer);
+    g_last_bwd_segments.store(1);
+    const int rc = scan_bwd_dispatch_<T>(p, variant, seg_req, stream, timer);
     g_finish_timer = nullptr;
     return rc;
 }
 template <typename T>
-static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, hipStream_t stream, LaunchTimer *timer) {
+static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, int seg_req, hipStream_t stream, LaunchTimer *timer) {
     if (p.f.dt_weight) {   // delta computed inside the scan: round-2 kernels only
         if (p.f.dstate > 64 || p.f.dt_rank < 1 || p.f.dt_rank > kMaxDtRank || !p.ddt || !p.ddt_weight) return OSS_ERR_SHAPE;
         if (variant < 10) variant = 13;
@@ -566,16 +604,16 @@ static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, hipStre
         case 7: return launch_bwd<T, 64, 8, 8, 16, 1, 2>(p, stream, timer);    // variant 3 likewise
         case 8: return launch_bwd_pair<T, 8, 12, 8, 3>(p, stream, timer);
         case 9: return launch_bwd_pair<T, 8, 8, 16, 2>(p, stream, timer);
-        case 10: return launch_bwd2<T, 12, 4, 3>(p, stream, timer);
-        case 11: return launch_bwd2<T, 8, 4, 2>(p, stream, timer);
-        case 12: return launch_bwd2<T, 6, 4, 2>(p, stream, timer);
-        case 13: return launch_bwd2<T, 4, 4, 2>(p, stream, timer);   // 4-row workgroups for calls with few rows (one wave per SIMD, no spills)
+        case 10: return launch_bwd2<T, 12, 4, 3>(p, seg_req, stream, timer);
+        case 11: return launch_bwd2<T, 8, 4, 2>(p, seg_req, stream, timer);
+        case 12: return launch_bwd2<T, 6, 4, 2>(p, seg_req, stream, timer);
+        case 13: return launch_bwd2<T, 4, 4, 2>(p, seg_req, stream, timer);   // 4-row workgroups for calls with few rows (one wave per SIMD, no spills)
         default: return launch_bwd<T, 64, 4, 4, 16, 1, 3>(p, stream, timer);
     }
 }
 
-template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *, LaunchTimer *);
-template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *, LaunchTimer *);
-template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, hipStream_t, LaunchTimer *, LaunchTimer *);
+template int scan_bwd_dispatch<float>(const oss_scan_bwd_params &, int, int, hipStream_t, LaunchTimer *, LaunchTimer *);
+template int scan_bwd_dispatch<bf16_t>(const oss_scan_bwd_params &, int, int, hipStream_t, LaunchTimer *, LaunchTimer *);
+template int scan_bwd_dispatch<f16_t>(const oss_scan_bwd_params &, int, int, hipStream_t, LaunchTimer *, LaunchTimer *);
 
 }  // namespace oss

@@ -105,9 +105,20 @@ constexpr bool kV2HcvEarly = true;
 #else
 constexpr bool kV2HcvEarly = false;
 #endif
-template <typename T, int WAVES, int NBB, int MINW, bool FD>
+// SEG: time-segmented launch (workgroup = (batch, group, row tile, SEGMENT of cps chunks)) for calls whose row-tile grid
+// leaves CUs idle.  The reference walks a row's chunks last to first inside one block (cus/selective_scan_bwd_kernel.cuh:
+// 120-125,184); here a segment starts from (a) the forward state saved in x -- free, x holds one every 256 steps -- and
+// (b) the reverse carry dh entering from the later segments, folded from the per-segment pairs that
+// oss_scan_bwd_carry_kernel (below) leaves in sg.carry.  Per-(batch, row) partials of dA / dD / dbias get one slot per
+// segment (summed by the finishing kernel in segment order).
+struct BwdSeg {
+    float *carry;   // [batch][dim][n_seg][dstate][2]: (prod of a_{t+1} over the segment, dh at its first step from a zero carry)
+    int n_seg, cps; // segments per row, 512-step chunks per segment
+};
+template <typename T, int WAVES, int NBB, int MINW, bool FD, bool SEG = false>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
-oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
+oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg sg) {
+    static_assert(!(FD && SEG), "the fused-delta form is not segmented");
     constexpr int LPR = 64, I = 8;
     constexpr int ROWS = WAVES;
     constexpr int TC = LPR * I;
@@ -143,7 +154,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     // tiles of a group are given ids with the same residue mod 8: they then share one L2's copy of B / C instead of fetching
     // it eight times (speed only -- nothing depends on where a workgroup runs).
     int bid = blockIdx.x, tile, bg;
-    if ((f.batch * G) % 8 == 0) {
+    const int n_seg = SEG ? sg.n_seg : 1;
+    if ((f.batch * G * n_seg) % 8 == 0) {
         const int xcd = bid & 7, s_ = bid >> 3;
         bg = (s_ / tiles_per_group) * 8 + xcd;
         tile = s_ % tiles_per_group;
@@ -151,6 +163,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         tile = bid % tiles_per_group;
         bg = bid / tiles_per_group;
     }
+    int seg = 0;
+    if constexpr (SEG) { seg = bg % n_seg; bg /= n_seg; }   // the tiles of one (batch, group, segment) share B / C
     const int g = bg % G;
     const int b = bg / G;
     const int row_in_group = tile * ROWS + wrow;
@@ -225,6 +239,26 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     float dD_acc = 0.f, db_acc = 0.f;
     float dWv = 0.f;   // FD: lane r = gradient of dt_weight[d, r]
     const int n_chunks = (L + TC - 1) / TC;
+    const int c_begin = SEG ? seg * sg.cps : 0;
+    const int c_end = SEG ? min(n_chunks, c_begin + sg.cps) : n_chunks;
+    if constexpr (SEG) {
+        // dh entering from the later segments: fold their pairs, last segment first
+        if (lane < N) {
+            const float2 *cr = reinterpret_cast<const float2 *>(sg.carry) + (((size_t)b * f.dim + d) * n_seg) * N + lane;
+            float dh = 0.f;
+            for (int j = n_seg - 1; j > seg; --j) {
+                const float2 pr = cr[(size_t)j * N];
+                dh = __builtin_fmaf(pr.x, dh, pr.y);
+            }
+            dhcv = dh;
+        }
+        const int t1 = c_end * TC;   // first step of the next segment
+        if (t1 < L) {
+            float x = to_f32(dt_row[rev ? (L - 1 - t1) : t1]) + bias;
+            if (f.delta_softplus) { float e; x = softplus_thr(x, e); }
+            dln_c = x;
+        }
+    }
     int par = 0;   // slab buffer of the next state
     int tbuf = 0;  // tile buffer of the current batch
     int rot = 0;   // first wave of the current state's slab sum (advances by RW per state, mod WAVES)
@@ -236,10 +270,10 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
         }
     }
     // tiles of the very first batch: synchronous
-    stage_issue((n_chunks - 1) * TC, 0);
+    stage_issue((c_end - 1) * TC, 0);
     stage_commit(0, 0);
     __syncthreads();
-    for (int c = n_chunks - 1; c >= 0; --c) {
+    for (int c = c_end - 1; c >= c_begin; --c) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;
         const int valid = max(0, min(I, L - tl));
@@ -457,7 +491,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
             // the tiles this batch needs are in buffer tbuf (committed and fenced by the previous batch's last barrier);
             // fetch the next batch's -- of this chunk, or the first of the next chunk -- from global memory now
             const bool more_here = n0 + NBB < N;
-            const bool have_next = more_here || c > 0;
+            const bool have_next = more_here || c > c_begin;
             const int nt0 = more_here ? t0 : t0 - TC, nn0 = more_here ? n0 + NBB : 0;
             if (have_next) stage_issue(nt0, nn0);
             const float *tb = sT + (size_t)tbuf * 2 * NBB * TC + pos * 4, *tc = tb + NBB * TC;
@@ -626,15 +660,130 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws) {
     // ---- per-row partials over the sequence
     const float dD_sum = segment_sum_to_last<LPR>(dD_acc);
     const float db_sum = segment_sum_to_last<LPR>(db_acc);
+    const size_t slot = (size_t)(b * n_seg + seg) * f.dim + d;   // one partial per (batch, segment, row)
     if (row_valid) {
         if (seg_last) {
-            if (ws.dD) ws.dD[(size_t)b * f.dim + d] = dD_sum;
-            if (ws.db) ws.db[(size_t)b * f.dim + d] = db_sum;
+            if (ws.dD) ws.dD[slot] = dD_sum;
+            if (ws.db) ws.db[slot] = db_sum;
         }
-        if (lane < N) ws.dA[((size_t)b * f.dim + d) * N + lane] = dAv;
+        if (lane < N) ws.dA[slot * N + lane] = dAv;
     }
     if constexpr (FD) {
-        if (row_valid && lane < R) ws.dW[((size_t)b * f.dim + d) * kMaxDtRank + lane] = dWv;
+        if (row_valid && lane < R) ws.dW[slot * kMaxDtRank + lane] = dWv;
+    }
+}
+
+// Reverse-carry pass of the time-segmented backward (launched before oss_scan_bwd2_kernel<..., SEG = true>): for every
+// segment s >= 1 of every row the pair
+//     ( prod_{t0 < t <= t1} a_t ,  dh_{t0} evaluated with dh_{t1} = 0 )
+// of the reverse recurrence dh_t = C_t g_t + a_{t+1} dh_{t+1} (cus/selective_scan_bwd_kernel.cuh:170-193) over the
+// segment's steps [t0, t1).  Only the recurrence itself: delta (+ softplus), dout, C -- 4 vector instructions and one
+// v_exp_f32 per (element, state) against the main kernel's ~28.  Same lane / chunk decomposition as the main kernel
+// (row = one wave, 64 lanes x 8 steps), all of a chunk's C rows staged at once.
+template <typename T, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tiles_per_group) {
+    constexpr int LPR = 64, I = 8, TC = LPR * I, NT = WAVES * 64, ROWS = WAVES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [kNB][TC] C tile, tile_off image
+    const oss_scan_fwd_params &f = p.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool seg_first = (lane == 0), seg_last = (lane == LPR - 1);
+    const int L = f.seqlen, N = f.dstate, G = f.n_groups;
+    const int rows_per_group = f.dim / G;
+    int bid = blockIdx.x;
+    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
+    const int seg = 1 + bid % (sg.n_seg - 1); bid /= (sg.n_seg - 1);   // segment 0 has no predecessor to hand a carry to
+    const int g = bid % G;
+    const int b = bid / G;
+    const int row_in_group = tile * ROWS + wave;
+    const bool row_valid = row_in_group < rows_per_group;
+    const int d = g * rows_per_group + (row_valid ? row_in_group : 0);
+    const bool rev = g >= f.rev_group_start;
+    const T *dt_row = reinterpret_cast<const T *>(f.delta) + b * f.delta_batch_stride + d * f.delta_d_stride;
+    const int d_g = p.dout_row_mod > 0 ? d % p.dout_row_mod : d;
+    const T *g_row = reinterpret_cast<const T *>(p.dout) + b * p.dout_batch_stride + d_g * p.dout_d_stride;
+    const T *gC = reinterpret_cast<const T *>(f.C) + b * f.C_batch_stride + g * f.C_group_stride;
+    const float bias = f.delta_bias ? f.delta_bias[d] : 0.f;
+
+    float A2v = 0.f, dhcv = 0.f, Pv = 1.f;   // lane n = state n (dstate <= 64)
+    if (lane < N) {
+        const float av = f.A[d * f.A_d_stride + lane];
+        A2v = (f.a_log_form ? -__expf(av) : av) * kLog2e;
+    }
+    const int n_chunks = (L + TC - 1) / TC;
+    const int c_begin = seg * sg.cps, c_end = min(n_chunks, c_begin + sg.cps);
+    float dln_c = 0.f;
+    {
+        const int t1 = c_end * TC;
+        if (t1 < L) {
+            float x = to_f32(dt_row[rev ? (L - 1 - t1) : t1]) + bias;
+            if (f.delta_softplus) { float e; x = softplus_thr(x, e); }
+            dln_c = x;
+        }
+    }
+    for (int c = c_end - 1; c >= c_begin; --c) {
+        const int t0 = c * TC;
+        const int tl = t0 + lane * I;
+        const int valid = max(0, min(I, L - tl));
+        float dl[I], gg[I];
+        {
+            RawItems<T, I> rd, rg;
+            if (raw_fast_ok<I>(dt_row, tl, valid, L, rev) && raw_fast_ok<I>(g_row, tl, valid, L, rev)) {
+                rd = load_raw_fast<I>(dt_row, tl, L, rev);
+                rg = load_raw_fast<I>(g_row, tl, L, rev);
+            } else {
+                rd = load_raw_slow<I>(dt_row, tl, valid, L, rev);
+                rg = load_raw_slow<I>(g_row, tl, valid, L, rev);
+            }
+            unpack_raw_dir<I>(rd, rev, dl);
+            unpack_raw_dir<I>(rg, rev, gg);
+        }
+        float S = 0.f;
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            float x = dl[i] + bias;
+            if (f.delta_softplus) { float e; x = softplus_thr(x, e); }
+            dl[i] = (i < valid) ? x : 0.f;
+            S += dl[i];
+        }
+        const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
+        const float Sshift = S - dl[0] + dln_lane;
+        for (int n0 = 0; n0 < N; n0 += kNB) {
+            const int nb = min(kNB, N - n0);
+            __syncthreads();   // the previous tile has been read by everyone
+            stage_bc_tiles<T, LPR, I, NT, false>(smem, nullptr, gC + (int64_t)n0 * f.C_dstate_stride, gC, f.C_dstate_stride,
+                                                 f.C_dstate_stride, nb, t0, L, rev, tid);
+            __syncthreads();
+            for (int nn = 0; nn < nb; ++nn) {
+                const int n = n0 + nn;
+                const float A2 = lane_get(A2v, n), dhc = lane_get(dhcv, n);
+                float ct[I];
+                read_tile<I>(smem + nn * TC + lane * 4, ct);
+                float a[I];
+#pragma unroll
+                for (int i = 0; i < I; ++i) a[i] = exp2_hw(dl[i] * A2);
+                const float a_nl = shift_from_next_lane(a[0], exp2_hw(dln_c * A2), seg_last);
+                float dloc = 0.f;
+#pragma unroll
+                for (int i = I - 1; i >= 0; --i) {
+                    const float an = (i == I - 1) ? a_nl : a[(i + 1) % I];
+                    const float cg = ct[i] * gg[i];
+                    dloc = (i == I - 1) ? cg : __builtin_fmaf(an, dloc, cg);
+                }
+                float Pm = segment_mirror<LPR>(exp2_hw(Sshift * A2), lane);
+                float dm = segment_mirror<LPR>(dloc, lane);
+                segment_scan<LPR>(Pm, dm);
+                const float dfull_m = __builtin_fmaf(Pm, dhc, dm);   // mirrored-last lane: dh at the chunk's first step
+                dhcv = lane_set(dhcv, lane, n, lane_get(dfull_m, 63));
+                Pv = lane_set(Pv, lane, n, lane_get(Pv, n) * lane_get(Pm, 63));
+            }
+        }
+        dln_c = lane_get(dl[0], 0);
+    }
+    if (row_valid && lane < N) {
+        float2 *cr = reinterpret_cast<float2 *>(sg.carry) + (((size_t)b * f.dim + d) * sg.n_seg + seg) * N + lane;
+        *cr = make_float2(Pv, dhcv);
     }
 }
 

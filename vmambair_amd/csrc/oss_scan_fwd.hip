@@ -22,9 +22,25 @@ namespace oss {
 
 // FD: delta evaluated here from the rank-R factor (include/vmambair_oss.h: dt_weight) -- its own instantiation, so that the
 // plain form keeps the register allocation it was tuned with
-template <typename T, int LPR, int I, int WAVES, bool FD = false>
+//
+// SEG: time-segmented launches for calls whose (batch, group, row tile) grid leaves CUs idle (RealSR tiles at batch 1,
+// the Deraining tree's level 0).  The reference walks the chunks of a row sequentially inside one block
+// (cus/selective_scan_fwd_kernel.cuh:101-102,147-158) and so does SEG = 0 here.  With SEG the sequence is cut into
+// n_seg segments of cps chunks, one workgroup per (batch, group, row tile, segment), two launches:
+//   SEG = 1 (local pass, segments 0 .. n_seg-2): the recurrence from a ZERO state over the segment, nothing but the
+//            B side of the step (no C, no y, no stores) -> carry[b, d, s, n] = (prod of a over the segment, h at its end);
+//   SEG = 2 (real pass, every segment): the state entering segment s is the fold of the pairs of segments 0 .. s-1 in
+//            the scan monoid (selective_scan_common.h:89-96) -- s fused multiply-adds per (row, state) -- then the plain
+//            step over the segment's chunks.
+// Same arithmetic per step as the unsegmented kernel; the state entering a segment is associated differently
+// (segment-local partial states folded instead of one running chain), i.e. equal up to fp32 round-off.
+struct FwdSeg {
+    float *carry;   // [batch][dim][n_seg][dstate][2] floats
+    int n_seg, cps; // segments per row, chunks (of TC steps) per segment
+};
+template <typename T, int LPR, int I, int WAVES, bool FD = false, int SEG = 0>
 __global__ void __launch_bounds__(WAVES * 64)
-oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
+oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     constexpr int RPW = 64 / LPR;      // rows per wave
     constexpr int ROWS = WAVES * RPW;  // rows per workgroup
     constexpr int TC = LPR * I;        // time steps per chunk
@@ -49,6 +65,11 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
     const int tiles_per_group = (rows_per_group + ROWS - 1) / ROWS;
     int bid = blockIdx.x;
     const int tile = bid % tiles_per_group; bid /= tiles_per_group;
+    int seg = 0;
+    if constexpr (SEG != 0) {
+        const int ns = SEG == 1 ? sg.n_seg - 1 : sg.n_seg;   // the last segment has no successor: no local pass
+        seg = bid % ns; bid /= ns;
+    }
     const int g = bid % p.n_groups;
     const int b = bid / p.n_groups;
     const int row_in_group = tile * ROWS + wrow;
@@ -75,14 +96,25 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         const int n = idx / ROWS, r = idx - n * ROWS;
         const int rg = tile * ROWS + r;
         const int dd = g * rows_per_group + (rg < rows_per_group ? rg : 0);
-        carH[idx] = 0.f;
-        carP[idx] = 1.f;
+        float h0 = 0.f, P0 = 1.f;
+        if constexpr (SEG == 2) {   // fold the local pairs of the earlier segments, in time order
+            const float2 *cr = reinterpret_cast<const float2 *>(sg.carry) + (((size_t)b * p.dim + dd) * sg.n_seg) * N + n;
+            for (int j = 0; j < seg; ++j) {
+                const float2 pr = cr[(size_t)j * N];
+                h0 = __builtin_fmaf(pr.x, h0, pr.y);
+                P0 *= pr.x;
+            }
+        }
+        carH[idx] = h0;
+        carP[idx] = P0;
         const float av = p.A[dd * p.A_d_stride + n];
         sA2[idx] = (p.a_log_form ? -__expf(av) : av) * kLog2e;
     }
 
     const int n_chunks = (L + TC - 1) / TC;
-    for (int c = 0; c < n_chunks; ++c) {
+    const int c_begin = SEG != 0 ? seg * sg.cps : 0;
+    const int c_end = SEG != 0 ? min(n_chunks, c_begin + sg.cps) : n_chunks;
+    for (int c = c_begin; c < c_end; ++c) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;  // first time step of this lane
         const int valid = max(0, min(I, L - tl));
@@ -127,7 +159,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
         for (int n0 = 0; n0 < N; n0 += kNB) {
             const int nb = min(kNB, N - n0);
             __syncthreads();  // everyone is done with the previous tile (and the carry init)
-            stage_bc_tiles<T, LPR, I, NT>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
+            stage_bc_tiles<T, LPR, I, NT, SEG != 1>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
                                           gC + (int64_t)n0 * p.C_dstate_stride, p.B_dstate_stride,
                                           p.C_dstate_stride, nb, t0, L, rev, tid);
             __syncthreads();
@@ -157,32 +189,48 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p) {
                 const float Pfull = P * Pc;
                 float hin = shift_from_prev_lane(hfull, hc, seg_first);
                 if (seg_last) { carH[n * ROWS + wrow] = hfull; carP[n * ROWS + wrow] = Pfull; }
-                if (writes_x) {
-                    float2 st = make_float2(Pfull, hfull);
-                    *reinterpret_cast<float2 *>(x_row + (size_t)xc * 2 * N + 2 * n) = st;
-                }
-                const float *tc = sC + tile_off<LPR, I>(nn, pos, 0);
-                h = hin;
+                if constexpr (SEG != 1) {
+                    if (writes_x) {
+                        float2 st = make_float2(Pfull, hfull);
+                        *reinterpret_cast<float2 *>(x_row + (size_t)xc * 2 * N + 2 * n) = st;
+                    }
+                    const float *tc = sC + tile_off<LPR, I>(nn, pos, 0);
+                    h = hin;
 #pragma unroll
-                for (int k = 0; k < I / 4; ++k) {
-                    const f32x4 cv = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
+                    for (int k = 0; k < I / 4; ++k) {
+                        const f32x4 cv = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * k + j;
-                        h = __builtin_fmaf(a[i], h, bb[i]);
-                        y[i] = __builtin_fmaf(cv[j], h, y[i]);
+                        for (int j = 0; j < 4; ++j) {
+                            const int i = 4 * k + j;
+                            h = __builtin_fmaf(a[i], h, bb[i]);
+                            y[i] = __builtin_fmaf(cv[j], h, y[i]);
+                        }
                     }
                 }
             }
         }
-        if (row_valid) store_items_dir<I>(out_row, tl, valid, L, rev, y);
+        if constexpr (SEG != 1) {
+            if (row_valid) store_items_dir<I>(out_row, tl, valid, L, rev, y);
+        }
+    }
+    if constexpr (SEG == 1) {   // the segment's pair: what the later segments fold
+        __syncthreads();
+        for (int idx = tid; idx < N * ROWS; idx += NT) {
+            const int n = idx / ROWS, r = idx - n * ROWS;
+            const int rg = tile * ROWS + r;
+            if (rg < rows_per_group) {
+                const int dd = g * rows_per_group + rg;
+                float2 *cr = reinterpret_cast<float2 *>(sg.carry) + (((size_t)b * p.dim + dd) * sg.n_seg + seg) * N + n;
+                *cr = make_float2(carP[idx], carH[idx]);
+            }
+        }
     }
 }
 
 template <typename T, int LPR, int I, int WAVES, bool FD = false>
-static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
+static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t stream) {
     if constexpr (!FD) {
-        if (p.dt_weight) return launch_fwd<T, LPR, I, WAVES, true>(p, stream);
+        if (p.dt_weight) return launch_fwd<T, LPR, I, WAVES, true>(p, seg_req, stream);
     }
     constexpr int ROWS = WAVES * (64 / LPR);
     constexpr int TC = LPR * I;
@@ -191,13 +239,33 @@ static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
     const size_t smem = sizeof(float) * (2 * (size_t)kNB * TC + 3 * (size_t)p.dstate * ROWS);
     if constexpr (!(LPR == 64 && I == 4 && WAVES == 4)) {
         // large dstate: tiles + per-row carries no longer fit 160 KiB -> the small-shape variant (4 rows, 256-step chunks)
-        if (smem > kMaxLdsBytes) return launch_fwd<T, 64, 4, 4, FD>(p, stream);
+        if (smem > kMaxLdsBytes) return launch_fwd<T, 64, 4, 4, FD>(p, seg_req, stream);
     }
-    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD>;
+    const unsigned wgs = (unsigned)(p.batch * p.n_groups * tiles);
+    const int n_chunks = (p.seqlen + TC - 1) / TC;
+    int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.55);
+    if (n_seg > 1 && (!p.workspace || p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, n_seg))) n_seg = 1;
+    g_last_fwd_segments.store(n_seg);
+    if constexpr (!FD) {
+        if (n_seg > 1) {
+            FwdSeg sg;
+            sg.carry = reinterpret_cast<float *>(p.workspace);
+            sg.cps = (n_chunks + n_seg - 1) / n_seg;
+            sg.n_seg = (n_chunks + sg.cps - 1) / sg.cps;
+            auto k1 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 1>;
+            auto k2 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 2>;
+            static LdsGate gate1, gate2;
+            if (const int e = gate1.ensure(reinterpret_cast<const void *>(k1), smem)) return e;
+            if (const int e = gate2.ensure(reinterpret_cast<const void *>(k2), smem)) return e;
+            hipLaunchKernelGGL(k1, dim3(wgs * (unsigned)(sg.n_seg - 1)), dim3(WAVES * 64), smem, stream, p, sg);
+            hipLaunchKernelGGL(k2, dim3(wgs * (unsigned)sg.n_seg), dim3(WAVES * 64), smem, stream, p, sg);
+            return (int)hipGetLastError();
+        }
+    }
+    auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD, 0>;
     static LdsGate gate;
     if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
-    const dim3 grid((unsigned)(p.batch * p.n_groups * tiles));
-    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(WAVES * 64), smem, stream, p, FwdSeg{nullptr, 1, n_chunks});
     return (int)hipGetLastError();
 }
 
@@ -209,21 +277,21 @@ static int launch_fwd(const oss_scan_fwd_params &p, hipStream_t stream) {
 //   4: 64 x 4  x 4   (TC  256,  4 rows/WG)   short sequences / few rows per group
 //   5: 64 x 8  x 12  (TC  512, 12 rows/WG), 6: 64 x 16 x 12 (TC 1024, 12 rows/WG): row counts that give <= 256 such workgroups
 template <typename T>
-int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, hipStream_t stream) {
+int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream) {
     switch (variant) {
-        case 0: return launch_fwd<T, 64, 8, 8>(p, stream);
-        case 1: return launch_fwd<T, 32, 16, 8>(p, stream);
-        case 2: return launch_fwd<T, 16, 16, 4>(p, stream);
-        case 3: return launch_fwd<T, 64, 16, 8>(p, stream);
-        case 5: return launch_fwd<T, 64, 8, 12>(p, stream);   // 12 rows per workgroup: one workgroup per CU at 3072 rows
-        case 6: return launch_fwd<T, 64, 16, 12>(p, stream);
-        case 7: return launch_fwd<T, 64, 16, 6>(p, stream);
-        default: return launch_fwd<T, 64, 4, 4>(p, stream);
+        case 0: return launch_fwd<T, 64, 8, 8>(p, seg_req, stream);
+        case 1: return launch_fwd<T, 32, 16, 8>(p, seg_req, stream);
+        case 2: return launch_fwd<T, 16, 16, 4>(p, seg_req, stream);
+        case 3: return launch_fwd<T, 64, 16, 8>(p, seg_req, stream);
+        case 5: return launch_fwd<T, 64, 8, 12>(p, seg_req, stream);   // 12 rows per workgroup: one workgroup per CU at 3072 rows
+        case 6: return launch_fwd<T, 64, 16, 12>(p, seg_req, stream);
+        case 7: return launch_fwd<T, 64, 16, 6>(p, seg_req, stream);
+        default: return launch_fwd<T, 64, 4, 4>(p, seg_req, stream);
     }
 }
 
-template int scan_fwd_dispatch<float>(const oss_scan_fwd_params &, int, hipStream_t);
-template int scan_fwd_dispatch<bf16_t>(const oss_scan_fwd_params &, int, hipStream_t);
-template int scan_fwd_dispatch<f16_t>(const oss_scan_fwd_params &, int, hipStream_t);
+template int scan_fwd_dispatch<float>(const oss_scan_fwd_params &, int, int, hipStream_t);
+template int scan_fwd_dispatch<bf16_t>(const oss_scan_fwd_params &, int, int, hipStream_t);
+template int scan_fwd_dispatch<f16_t>(const oss_scan_fwd_params &, int, int, hipStream_t);
 
 }  // namespace oss

@@ -116,6 +116,11 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
         return [out, x]
     P = _capi.ScanFwdParams()
     _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight)
+    # scratch for the time-segmented launch (under-filled grids: batch-1 tiles, few-row levels); a few hundred KB
+    ws_bytes = int(lib.oss_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate, dims[4]))
+    if ws_bytes:
+        ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=u.device)
+        P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_fwd(P, _DT[u.dtype], stream), "oss_scan_fwd")
