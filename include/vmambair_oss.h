@@ -310,8 +310,11 @@ int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chu
 /* Adam + EMA of the training step (MambaSISR_model.py:120-147: torch.optim.Adam without amsgrad / weight decay,
  * then ema = decay * ema + (1 - decay) * param) as one elementwise launch over a chunk table in device memory:
  * one entry per <= OSS_ADAM_CHUNK consecutive elements of one parameter tensor (all float; ema may be NULL).
- * state: 3 floats in device memory {step count, 1 - beta1^t, 1 - beta2^t}; the call advances the step count
- * first (so the launch pair can be replayed inside a hipGraph). */
+ * state: 4 floats in device memory {step count, 1 - beta1^t, 1 - beta2^t, learning rate}; the call advances the step
+ * count first (so the launch pair can be replayed inside a hipGraph).  lr >= 0: the learning rate of this call (baked into
+ * a captured launch); lr < 0: the kernel reads state[3], which the host may rewrite between replays -- the reference
+ * trainings change the rate during a run (MultiStepLR, SRGAN/options/MambaSISR15_x4.yml:84-87;
+ * CosineAnnealingRestartCyclicLR every iteration, Deraining/Deraining/Options/Deraining_mamber33.yml:81-85). */
 #define OSS_ADAM_CHUNK 2048
 typedef struct {
     void *param;

@@ -49,8 +49,8 @@ def install():
         db = g.sum(dim=(0, 2, 3)) if has_bias else torch.empty(0)
         dx = dx.to(x.dtype)
         if dx_into is not None and dx_into.dtype == dx.dtype:   # one half of the gradient of a split tensor (ops.PairGrad)
-            dx_into.copy_(dx)
-            dx = dx_into
+            dx_into.copy_(dx)        # mutated argument, empty return (the operator's contract: ops/dwconv.py)
+            dx = x.new_empty(0)
         return [dx, dw, db]
 
     def _mirror(t, G_or_rows, start, per):  # flip time of groups >= start (per rows each)
@@ -125,8 +125,8 @@ def install():
         if skip_grad is not None:
             dx = dx + skip_grad.float()
         if dgate_into is not None and gg is not None and dgate_into.dtype == dg.dtype:
-            dgate_into.copy_(dg)
-            dg = dgate_into
+            dgate_into.copy_(dg)      # mutated argument, empty return (the operator's contract: ops/layernorm.py)
+            dg = torch.empty(0)
         return [dx.to(x.dtype), dg, dw, db]
 
     def _core_ref(x, wx, wdt, A_logs, Ds, dt_bias):

@@ -24,6 +24,8 @@ Fixture families:
   g5_psnr.npz, g5_ckpt_*.pth, g5_net_psnr.npz    (round 2) the reference's calculate_psnr / tensor2img / save_network
   g6_tiles_*.npz    (round 2) RealESRGANer.pre_process/tile_process/post_process and MambaSISRModel2.test run on
                     position-coded images with a recording stand-in for the network
+  g7_lr.npz         (round 3) learning rates of the reference's CosineAnnealingRestartCyclicLR / torch MultiStepLR stepped the
+                    way update_learning_rate steps them
 """
 import ast
 import importlib.util
@@ -495,9 +497,43 @@ def make_g6():
     print("wrote g6_tiles.npz", os.path.getsize(os.path.join(OUT, "g6_tiles.npz")) // 1024, "KiB")
 
 
+def make_g7():
+    """learning rates of the reference's schedulers at sampled iterations, driven the way ``update_learning_rate`` drives
+    them (Deraining/basicsr/models/base_model.py:183-193: one scheduler.step() before every iteration but the first)"""
+    sched = load_by_path("ref_lr_scheduler", f"{REF}/Deraining/basicsr/models/lr_scheduler.py")
+    out = {}
+
+    def run(tag, make, n_iter, sample):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=make["lr"])
+        s_ = make["cls"](opt, **make["kw"])
+        its, lrs = [], []
+        for it in range(1, n_iter + 1):
+            if it > 1:
+                opt.step()
+                s_.step()
+            if it in sample:
+                its.append(it)
+                lrs.append(opt.param_groups[0]["lr"])
+        out[tag + "_iter"] = np.asarray(its, dtype=np.int64)
+        out[tag + "_lr"] = np.asarray(lrs, dtype=np.float64)
+
+    # the Deraining YAML's schedule, shrunk 1000x in time so that it can be stepped through (same shape of curve)
+    pts = set(range(1, 12)) | {71, 72, 143, 144, 145, 146, 147, 200, 288, 300, 431, 432}
+    run("cyclic", dict(lr=3e-4, cls=sched.CosineAnnealingRestartCyclicLR,
+                       kw=dict(periods=[144, 288], restart_weights=[1, 1], eta_mins=[3e-4, 1e-6])), 432, pts)
+    run("cyclic_w", dict(lr=2e-4, cls=sched.CosineAnnealingRestartCyclicLR,
+                         kw=dict(periods=[10, 20, 30], restart_weights=[1, 0.5, 0.25], eta_mins=[1e-6, 1e-5, 0.0])), 60,
+        set(range(1, 61)))
+    run("multistep", dict(lr=2e-4, cls=torch.optim.lr_scheduler.MultiStepLR, kw=dict(milestones=[50, 70], gamma=0.5)), 100,
+        {1, 2, 49, 50, 51, 52, 70, 71, 72, 100})
+    np.savez_compressed(os.path.join(OUT, "g7_lr.npz"), **out)
+    print("g7_lr.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g3w", "g3c1", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g3w", "g3c1", "g5", "g6", "g7"]
     if "g1" in which:
         make_g1()
     if "g2" in which:
@@ -506,6 +542,6 @@ if __name__ == "__main__":
         make_g3()
     if "g4" in which:
         make_g4()
-    for k, fn in (("g3w", make_g3w), ("g3c1", make_g3c1), ("g5", make_g5), ("g6", make_g6)):
+    for k, fn in (("g3w", make_g3w), ("g3c1", make_g3c1), ("g5", make_g5), ("g6", make_g6), ("g7", make_g7)):
         if k in which:
             fn()

@@ -332,7 +332,10 @@ def test_split_halves_gradients_land_in_one_buffer(oracle_cpu_kernel):
     x = torch.randn(1, 16, 6, 5)
     g = torch.randn(1, 16, 6, 5)
     x1 = x.clone().requires_grad_()
+    from vmambair_amd.ops import _common
+    before = _common.CAT_FALLBACKS
     m(x1).backward(g)
+    assert _common.CAT_FALLBACKS == before, "dwconv3x3_bwd / ln_nchw_bwd wrote their halves in place: the split did not cat"
     ref = x1.grad.clone()
     keep = ops.split_halves
     import vmambair_amd.oss_block as blk

@@ -562,8 +562,11 @@ def test_time_segmented_scans_match_oracle(itype, seqlen, segs):
         pytest.skip("16-bit types: 2, 3 and max segments")
 
     def run(lib):
-        check_fwd_bwd(make_inputs(2, 24, 16, 2, seqlen, itype), True, itype)
-        assert lib.oss_scan_last_segments(0) > 1 and lib.oss_scan_last_segments(1) > 1, "the segmented kernels did not run"
+        # forward variant 0 / backward variant 13: 512-step chunks both ways, so that every length here has >= 2 chunks
+        check_fwd_bwd(make_inputs(2, 24, 16, 2, seqlen, itype), True, itype, fwd_variant=0, bwd_variant=13)
+        want = min(segs, (seqlen + 511) // 512)
+        assert lib.oss_scan_last_segments(0) == want and lib.oss_scan_last_segments(1) == want, "the segmented kernels did not run"
+        check_fwd_bwd(make_inputs(2, 24, 16, 2, seqlen, itype), True, itype)   # whatever variants the heuristics pick
     _with_segments(segs, segs, run)
 
 
@@ -592,7 +595,7 @@ def test_time_segments_large_dstate_and_fallbacks():
     """dstate 40 (three 16-state tiles), dstate 72 (> 64: the backward takes the unsegmented round-1 kernel, the forward still
     segments), a forward workspace that is too small (falls back to the unsegmented launch, same results)"""
     def run(lib):
-        check_fwd_bwd(make_inputs(1, 8, 40, 2, 2500, torch.float32), True, torch.float32)
+        check_fwd_bwd(make_inputs(1, 8, 40, 2, 2500, torch.float32), True, torch.float32, bwd_variant=13)
         assert lib.oss_scan_last_segments(0) > 1 and lib.oss_scan_last_segments(1) > 1
         check_fwd_bwd(make_inputs(1, 8, 72, 2, 1500, torch.float32), True, torch.float32, bwd_variant=10)
         assert lib.oss_scan_last_segments(1) == 1

@@ -111,6 +111,144 @@ def test_warmup_leaves_no_trace():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# learning-rate schedule under graph replay, training-state save / resume
+# ---------------------------------------------------------------------------------------------------------------------
+def test_set_lr_reaches_the_captured_optimizer_launch():
+    """the reference changes the rate during a run (update_learning_rate, Deraining/basicsr/models/base_model.py:183-205); the
+    fused launch reads it from device memory, so a replayed graph follows ``set_lr``: trajectory = eager AdamW driven by the
+    reference's own scheduler object"""
+    from vmambair_amd import lr_schedule
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(5)
+    lq, gt = torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 32, 32, device=DEV)
+    net_g, net_e = make_net(7), make_net(7)
+    kw = dict(periods=[3, 5], restart_weights=[1, 0.5], eta_mins=[3e-4, 1e-5])
+    step = GraphedTrainStep(net_g, lr=3e-4, betas=(0.9, 0.999), ema_decay=0.0, autocast_dtype=None, warmup=1,
+                            weight_decay=1e-4, clip_grad_norm=0.01)
+    opt = torch.optim.AdamW(net_e.parameters(), lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    lrs = []
+    for it in range(1, 8):
+        lr = lr_schedule.cosine_restart_cyclic(it, 3e-4, **kw)
+        lrs.append(lr)
+        step.set_lr(lr)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        lg = float(step(lq, gt))
+        le, _ = eager_deraining_step(net_e, opt, lq, gt)
+        assert lg == pytest.approx(le, rel=3e-3), it
+    assert len(set(lrs)) > 3 and step.iteration == 7 and float(step.fopt.state[3]) == pytest.approx(lrs[-1])
+    for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
+        assert float((p - q).abs().max()) <= 2 * 3e-4 * 7 + 1e-5, k
+    # a constant-rate twin must end somewhere else: the schedule really acted
+    net_c = make_net(7)
+    const = GraphedTrainStep(net_c, lr=3e-4, betas=(0.9, 0.999), ema_decay=0.0, autocast_dtype=None, warmup=1,
+                             weight_decay=1e-4, clip_grad_norm=0.01)
+    for _ in range(7):
+        const(lq, gt)
+    assert max(float((p - q).abs().max()) for p, q in zip(net_c.parameters(), net_g.parameters())) > 1e-5
+
+
+def test_fused_adam_state_dict_round_trips_with_torch_adam():
+    """``FusedAdamEMA.state_dict()`` has torch.optim.Adam's layout: a torch optimizer loads it and continues identically, and
+    the fused optimizer loads a torch state (what the reference's .state files hold, base_model.py:312-351)"""
+    from vmambair_amd.optim import FusedAdamEMA
+    torch.manual_seed(1)
+    shapes = [(7,), (3, 5), (2050,), (1,)]
+    pa = [torch.randn(s, device=DEV) for s in shapes]
+    fo = FusedAdamEMA(pa, None, lr=1e-2, betas=(0.9, 0.99), ema_decay=0.0)
+    grads = [[torch.randn(s, device=DEV) for s in shapes] for _ in range(6)]
+    for k in range(3):
+        for p, g in zip(pa, grads[k]):
+            p.grad = g.clone()
+        fo.step()
+    sd = fo.state_dict()
+    assert float(sd["state"][0]["step"]) == 3.0 and sd["param_groups"][0]["lr"] == 1e-2
+    # torch continues from the fused state
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    topt = torch.optim.Adam(pb, lr=123.0, betas=(0.5, 0.5))
+    topt.load_state_dict(sd)
+    # ... and a fresh fused optimizer continues from torch's state
+    pc = [p.detach().clone() for p in pa]
+    fo2 = FusedAdamEMA(pc, None, lr=5.0, betas=(0.9, 0.99), ema_decay=0.0)
+    fo2.load_state_dict(topt.state_dict())
+    assert fo2.lr == 1e-2 and float(fo2.state[0]) == 3.0
+    for k in range(3, 6):
+        for p, q, r, g in zip(pa, pb, pc, grads[k]):
+            p.grad, q.grad, r.grad = g.clone(), g.clone(), g.clone()
+        fo.step(); topt.step(); fo2.step()
+    for p, q, r in zip(pa, pb, pc):
+        assert torch.allclose(p, q.detach(), rtol=1e-5, atol=1e-6) and torch.equal(p, r)
+
+
+def test_training_state_save_and_resume(tmp_path):
+    """save_training_state / resume_training (base_model.py:312-351): a run interrupted after 2 steps and resumed in a NEW
+    process-like object (fresh net from the saved weights, fresh graphs) ends where the uninterrupted run ends"""
+    from vmambair_amd import checkpoint
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(2)
+    lq, gt = torch.rand(2, 3, 16, 16, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+
+    def fresh():
+        torch.manual_seed(11)
+        return MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    net_a = fresh()
+    a = GraphedTrainStep(net_a, autocast_dtype=None, warmup=1)
+    for _ in range(4):
+        a(lq, gt)
+    net_b = fresh()
+    b = GraphedTrainStep(net_b, autocast_dtype=None, warmup=1)
+    for _ in range(2):
+        b(lq, gt)
+    path = checkpoint.save_training_state(b, str(tmp_path / "training_states"), epoch=0, current_iter=2)
+    assert path.endswith("2.state") and checkpoint.save_training_state(b, str(tmp_path), 0, -1) is None
+    wpath = checkpoint.save_network(net_b, str(tmp_path / "net_g_2.pth"))
+    net_c = fresh()
+    with torch.no_grad():
+        for p in net_c.parameters():
+            p.add_(1.0)                       # definitely not the saved weights
+    checkpoint.load_network(net_c, wpath, strict=True)
+    c = GraphedTrainStep(net_c, autocast_dtype=None, warmup=1)
+    c.capture(lq, gt)                         # graphs exist BEFORE the resume: tensors are restored in place
+    where = checkpoint.resume_training(c, path)
+    assert where == {"epoch": 0, "iter": 2} and c.iteration == 2
+    for _ in range(2):
+        c(lq, gt)
+    for (k, p), q in zip(net_a.named_parameters(), net_c.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), k
+    for e1, e2 in zip(a.ema, c.ema):
+        assert torch.allclose(e1, e2, rtol=1e-5, atol=1e-6)
+
+
+def test_second_shape_capture_keeps_the_torch_optimizer_state():
+    """with the torch fallback optimizer (fused_optimizer=False) a second input shape captured in the middle of a
+    run must not reset the Adam moments / step count"""
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(6)
+    batches = [(torch.rand(2, 3, 32, 32, device=DEV), torch.rand(2, 3, 32, 32, device=DEV)),
+               (torch.rand(1, 3, 48, 40, device=DEV), torch.rand(1, 3, 48, 40, device=DEV))]
+    net_g, net_e = make_net(3), make_net(3)
+    step = GraphedTrainStep(net_g, lr=3e-4, betas=(0.9, 0.999), ema_decay=0.0, autocast_dtype=None, warmup=2,
+                            weight_decay=1e-4, multi_shape=True, fused_optimizer=False)
+    assert step.opt is not None and step.fopt is None
+    opt = torch.optim.AdamW(net_e.parameters(), lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-4)
+    order = [0, 0, 0, 1, 0, 1]
+    for n, i in enumerate(order):
+        lg = float(step(*batches[i]))
+        opt.zero_grad(set_to_none=True)
+        loss = F.l1_loss(net_e(batches[i][0]), batches[i][1])
+        loss.backward()
+        opt.step()
+        assert lg == pytest.approx(float(loss), rel=3e-3), n
+    steps = {float(st["step"]) for st in step.opt.state.values()}
+    assert steps == {float(len(order))}, steps
+    for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
+        assert float((p - q).abs().max()) <= 2 * 3e-4 * len(order) + 1e-5, k
+    step.set_lr(1e-5)
+    assert float(step.opt.param_groups[0]["lr"]) == pytest.approx(1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # two ranks over RCCL: the flat-buffer exchange between the two graphs
 # ---------------------------------------------------------------------------------------------------------------------
 def _nccl_worker(rank, world, port, tmp):

@@ -16,6 +16,15 @@ for leg in $LEGS; do
     libab)  for lib in "" "$GRAFT_REPO_ROOT/vmambair_amd/lib/libvmambair_oss_exp_${EXP_LIB:-NOSLP}.so"; do tag=$([ -z "$lib" ] && echo base || echo exp); VMAMBAIR_LIB=$lib timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_lib_$tag.txt 2>gpurun_out/bench_lib_$tag.err; echo "lib=$tag rc=$?"; tail -1 gpurun_out/bench_lib_$tag.txt | cut -c1-200; VMAMBAIR_LIB=$lib timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench_$tag.txt 2>&1; echo "opbench rc=$?"; done;;
     opbench) timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/opbench.txt;;
     benchmfma) VMAMBAIR_CONV1X1=mfma timeout ${BENCH_TIMEOUT:-700} python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_mfma.txt 2>gpurun_out/bench_mfma.err; echo "rc=$?"; tail -1 gpurun_out/bench_mfma.txt | cut -c1-260;;
+    segtest) timeout 600 python -m pytest tests/test_scan_gpu.py -m gpu -q -p no:cacheprovider --maxfail=60 -k "segment or reruns_are_stable or every_backward_variant or round2_backward" > gpurun_out/segtest.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/segtest.txt; grep -E "^(FAILED|ERROR)" gpurun_out/segtest.txt | head -40;;
+    segsweep) # time-segmented launches on the under-filled shapes (Deraining level 0, RealSR tiles) + the finishing kernel at the headline shape
+            timeout 300 python tools/scan_sweep.py --shapes "4,192,16384,4" --dtypes bf16 --fwd-variants 0,3,5,6 --bwd-variants 10,11,13 --segs 1,2,4,8,16 > gpurun_out/segsweep_derain.txt 2>&1; echo "rc=$?";
+            timeout 300 python tools/scan_sweep.py --shapes "1,384,25600,4;1,192,25600,4" --dtypes f16 --fwd-variants 0,3,5,6 --bwd-variants 10 --segs 1,4,7,9,13,16 > gpurun_out/segsweep_realsr.txt 2>&1; echo "rc=$?";
+            timeout 300 python tools/scan_sweep.py --shapes "8,384,4096,4;8,192,4096,4;4,768,4096,4" --dtypes bf16 --fwd-variants=-1 --bwd-variants=-1 --segs=-1,1,2 > gpurun_out/segsweep_headline.txt 2>&1; echo "rc=$?"; tail -30 gpurun_out/segsweep_headline.txt | cut -c1-220;;
+    copyab) for m in 0 1 2 3 4; do VMAMBAIR_COPY_MODE=$m timeout 120 python tools/scan_sweep.py --shapes "1,8,256,2" --dtypes bf16 --fwd-variants "" --bwd-variants "" 2>/dev/null | head -1 | sed "s/^/mode $m: /"; done > gpurun_out/copyab.txt; cat gpurun_out/copyab.txt;;
+    segsweep2) timeout 400 python tools/scan_sweep.py --shapes "8,192,4096,4;4,384,4096,4;4,768,1024,4" --dtypes bf16 --fwd-variants 0,3,5,6 --bwd-variants 10,11 --segs 1,2,4 > gpurun_out/segsweep_mid.txt 2>/dev/null; echo "rc=$?";
+            timeout 300 python tools/scan_sweep.py --shapes "1,768,6400,4;1,1536,1600,4;1,384,20736,4" --dtypes f16 --fwd-variants 0,3,5,6 --bwd-variants "" --segs 1,2,4,7 > gpurun_out/segsweep_realsr_levels.txt 2>/dev/null; echo "rc=$?";
+            timeout 300 python tools/scan_sweep.py --shapes "4,192,16384,4;1,384,25600,4;8,384,4096,4;8,192,4096,4" --dtypes bf16 --fwd-variants=-1 --bwd-variants=-1 --segs=-1 > gpurun_out/segsweep_auto.txt 2>/dev/null; echo "rc=$?"; cut -c1-200 gpurun_out/segsweep_auto.txt;;
     sweep)  timeout 600 python tools/scan_sweep.py ${SWEEP_ARGS:---quick} > gpurun_out/sweep.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/sweep.txt;;
     bench)  timeout ${BENCH_TIMEOUT:-700} python bench.py ${BENCH_ARGS:---steps 5 --warmup 2} > gpurun_out/bench.txt 2>gpurun_out/bench.err; echo "rc=$?"; tail -2 gpurun_out/bench.txt; tail -12 gpurun_out/bench.err;;
     newtests) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_train_graph_gpu.py tests/test_checkpoint_psnr.py tests/test_infer.py -m gpu -q -s -p no:cacheprovider > gpurun_out/newtests.txt 2>&1; echo "rc=$?"; tail -5 gpurun_out/newtests.txt; grep -E "^\[(16bit|net)\]|^(FAILED|ERROR)" gpurun_out/newtests.txt | head -40;;

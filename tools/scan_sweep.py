@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--fwd-variants", default="0,6")
     ap.add_argument("--bwd-variants", default="3,7")
     ap.add_argument("--shapes", default="", help="B,KD,L,G;... (default: the headline shapes)")
+    ap.add_argument("--segs", default="-1", help="time segments per row to sweep (oss_scan_set_segments): -1 heuristic, 1 off, n")
+    ap.add_argument("--dtypes", default="", help="f32,bf16,f16 (default f32,bf16; --quick: bf16)")
     args = ap.parse_args()
     lib = _capi.load()
     dev = "cuda:0"
@@ -62,7 +64,7 @@ def main():
     fvs = tuple(int(v) for v in args.fwd_variants.split(",") if v != "")
     bvs = tuple(int(v) for v in args.bwd_variants.split(",") if v != "")
     for (B, KD, L, G) in shapes:
-        for dname in (["f32", "bf16"] if not args.quick else ["bf16"]):
+        for dname in (args.dtypes.split(",") if args.dtypes else (["f32", "bf16"] if not args.quick else ["bf16"])):
             dt, io = DT[dname]
             torch.manual_seed(0)
             u = torch.randn(B, KD, L, device=dev).to(dt)
@@ -74,8 +76,10 @@ def main():
             bias = 0.5 * torch.rand(KD, device=dev)
             dout = torch.randn(B, KD, L, device=dev).to(dt)
             for which, variants in ((0, fvs), (1, bvs)):
-                for v in variants:
+              for v in variants:
+                for sg in [int(t) for t in args.segs.split(",")]:
                     lib.oss_scan_set_variant(v if which == 0 else -1, v if which == 1 else -1)
+                    lib.oss_scan_set_segments(sg if which == 0 else -1, sg if which == 1 else -1)
                     try:
                         out, x = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
                         if which == 1:
@@ -90,11 +94,12 @@ def main():
                                 vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
                         torch.cuda.synchronize()
                         lib.oss_prof_enable(0)
-                        ms, cnt, by = collect(lib, which, v, io)
-                        if which == 1:  # fwd launches inside the loop are none; but the warm fwd is excluded by reset
-                            pass
+                        vv = lib.oss_scan_last_variant(which)   # -1 = heuristic: the bucket of what it picked
+                        ms, cnt, by = collect(lib, which, vv, io)
+                        fms = collect(lib, 2, vv, io)[0] if which == 1 else 0.0
                         rec = {"kernel": "fwd" if which == 0 else "bwd", "shape": [B, KD, L, G], "dtype": dname,
-                               "variant": v, "launches": cnt, "ms": round(ms / max(cnt, 1), 4),
+                               "variant": vv, "segments": lib.oss_scan_last_segments(which), "launches": cnt,
+                               "ms": round(ms / max(cnt, 1), 4), "finish_ms": round(fms / max(cnt, 1), 4),
                                "alg_GBps": round(by / max(ms, 1e-9) / 1e6, 1),
                                "Melem_per_s": round(B * KD * L * cnt / max(ms, 1e-9) / 1e3, 1)}
                     except Exception as e:  # keep sweeping
@@ -102,6 +107,7 @@ def main():
                                "variant": v, "error": str(e)[:200]}
                     print(json.dumps(rec), flush=True)
             lib.oss_scan_set_variant(-1, -1)
+            lib.oss_scan_set_segments(-1, -1)
             del u, delta, Bm, Cm, dout
             torch.cuda.empty_cache()
 

@@ -111,3 +111,37 @@ def load_for_inference(net: torch.nn.Module, load_path: str) -> str:
     bare_model(net).load_state_dict(_strip_module(blob[key]), strict=True)
     net.eval()
     return key
+
+
+# ---- training state (resume) ---------------------------------------------------------------------
+def save_training_state(step, states_dir: str, epoch: int, current_iter: int) -> Optional[str]:
+    """``BaseModel.save_training_state`` (Deraining/basicsr/models/base_model.py:312-334): ``{current_iter}.state`` holding
+    ``{'epoch', 'iter', 'optimizers': [optimizer.state_dict()], 'schedulers': [...]}``; nothing is written for
+    ``current_iter == -1`` (the "latest" save at the end of training).  ``step``: a ``GraphedTrainStep`` (or anything with
+    ``state_dict()`` returning ``{'iter', 'optimizers', 'ema'}``).  The optimizer entry has ``torch.optim.Adam(W)``'s layout
+    (vmambair_amd/optim.py), so the reference's ``resume_training`` can load it into its torch optimizer and this module can
+    load a ``.state`` file the reference wrote.  ``schedulers`` holds the one thing a closed-form schedule needs -- the
+    iteration -- in ``_LRScheduler.state_dict()``'s field name (``last_epoch`` = iterations stepped so far = iter - 1 + 1)."""
+    if current_iter == -1:
+        return None
+    sd = step.state_dict()
+    state = {"epoch": int(epoch), "iter": int(current_iter), "optimizers": sd["optimizers"],
+             "schedulers": [{"last_epoch": max(int(current_iter) - 1, 0)}], "ema": sd.get("ema")}
+    os.makedirs(states_dir, exist_ok=True)
+    path = os.path.join(states_dir, f"{current_iter}.state")
+    tmp = path + ".tmp"
+    torch.save(state, tmp)
+    os.replace(tmp, path)
+    return path
+
+
+def resume_training(step, resume_state: Union[str, dict]) -> dict:
+    """``BaseModel.resume_training`` (base_model.py:336-351) + the iteration bookkeeping of ``train.py`` (:176-190): puts the
+    optimizer moments, step count, learning rate (and EMA weights when the file has them) back -> ``{'epoch', 'iter'}``
+    to continue from.  ``resume_state``: a path or the loaded dict."""
+    if isinstance(resume_state, str):
+        resume_state = torch.load(resume_state, map_location="cpu", weights_only=False)
+    opts = resume_state["optimizers"]
+    assert len(opts) == 1, "Wrong lengths of optimizers"   # the reference's own assertion (base_model.py:344-345)
+    step.load_state_dict({"iter": resume_state["iter"], "optimizers": opts, "ema": resume_state.get("ema")})
+    return {"epoch": int(resume_state["epoch"]), "iter": int(resume_state["iter"])}

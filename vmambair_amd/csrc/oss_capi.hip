@@ -65,6 +65,12 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     // 16 lanes per row (4 rows per wave): fewest scan steps, but only rows/4 waves
     if (rows_per_group % 16 == 0 && rows / 4 >= 2048) return 2;
     if (rows_per_group % 16 == 0 && rows / 2 >= 2048) return 1;
+    // long sequences whose 12-row tiles leave CUs idle (RealSR tiles at batch 1: u:(1,384,25600) is 32 workgroups; Deraining
+    // level 0 at batch 4: 64): the widest workgroup, cut into time segments by scan_pick_segments until the CUs are covered
+    // (u:(1,384,25600) f16 0.129 ms in 9 segments against 0.354 ms for one 8-row workgroup per tile; u:(4,192,16384) bf16
+    // 0.139 in 4 segments against 0.222 -- profiles/r03_segment_sweep.txt)
+    // (u:(1,768,6400) f16: 0.070 ms in 4 segments against 0.093; at 128 such workgroups -- u:(8,192,4096) -- variant 3 stays ahead)
+    if (seqlen >= 4096 && rows_per_group % 12 == 0 && (long)batch * n_groups * (rows_per_group / 12) < 128) return 6;
     // <= one 8-row workgroup per CU and a long sequence: 16 items per lane (half the chunk hand-overs; u:(8,192,4096)
     // bf16 0.065 ms against 0.077, profiles/r01_sweep_v4_bwd_variants.txt)
     if (seqlen >= 1024 && (long)batch * n_groups * ((rows_per_group + 7) / 8) <= 256) return 3;
@@ -91,6 +97,12 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
     const bool v2 = dstate <= 64 && !pair;   // round-2 kernel (oss_scan_bwd_v2.h): u:(8,192,4096) 0.172 ms against 0.203,
                                              // u:(8,384,4096) 0.235 against 0.284 (profiles/r02_scan_bwd_v2_experiments.txt)
+    // long sequences whose 12-row tiles leave CUs idle: 12-row workgroups cut into time segments (scan_pick_segments) instead
+    // of ever smaller row tiles -- a third of the dB / dC partial tiles of the 4-row form and three waves per SIMD
+    // (u:(4,192,16384) bf16: 0.328 + 0.029 ms in 4 segments against 0.590 + 0.087 for variant 13; u:(1,384,25600) f16:
+    // 0.293 + 0.022 in 9 segments against 1.316 -- profiles/r03_segment_sweep.txt)
+    // (u:(8,192,4096) bf16, 128 such workgroups: 0.166 + 0.015 ms in 2 segments against 0.168 + 0.020 for variant 11)
+    if (v2 && seqlen >= 2048 && rows_per_group % 12 == 0 && (long)batch * n_groups * (rows_per_group / 12) < 192) return 10;
     // very few rows (Deraining level 0 at batch 4: 96 8-row workgroups for 256 CUs): 4-row workgroups spread the same waves over
     // twice the CUs, one wave per SIMD instead of two (u:(4,192,16384): 0.585 ms against 0.684)
     if (wgs <= 128 && v2 && rows_per_group % 4 == 0) return 13;
@@ -532,9 +544,47 @@ void oss_scan_set_segments(int fwd_segments, int bwd_segments) {
 }
 int oss_scan_last_segments(int which) { return which == 0 ? g_last_fwd_segments.load() : g_last_bwd_segments.load(); }
 
+// copy kernels of oss_hbm_copy.  Default (mode 2): one 16-byte element per lane and a grid as large as the buffer -- the
+// dispatcher streams short workgroups faster than any loop keeps loads in flight: 6.12 TB/s on 1 GiB, against 5.58 for
+// contiguous 32 KiB pieces per workgroup with eight loads in flight (mode 0), 5.55 for one such piece per workgroup (mode 3),
+// 5.23 for sixteen loads in flight (mode 4) and 4.75 for the round-2 kernel (mode 1: grid-stride, nontemporal) --
+// profiles/r03_copy_modes.txt; the guide's measured float4 copy is 6.29.  VMAMBAIR_COPY_MODE selects (A-B runs).
+__global__ void __launch_bounds__(256) oss_copy_pieces_kernel(const f32x4 *src, f32x4 *dst, size_t n_pieces) {
+    constexpr size_t PIECE = 2048;   // 16-byte elements per piece
+    for (size_t pc = blockIdx.x; pc < n_pieces; pc += gridDim.x) {
+        const f32x4 *s = src + pc * PIECE + threadIdx.x;
+        f32x4 *d = dst + pc * PIECE + threadIdx.x;
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = s[k * 256];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k * 256] = v[k];
+    }
+}
+// mode 3: one 32 KiB piece per workgroup, grid = number of pieces (no loop: the dispatcher streams workgroups); mode 4: sixteen
+// loads in flight per lane (64 KiB pieces)
+__global__ void __launch_bounds__(256) oss_copy_piece_per_wg_kernel(const f32x4 *src, f32x4 *dst) {
+    const f32x4 *s = src + (size_t)blockIdx.x * 2048 + threadIdx.x;
+    f32x4 *d = dst + (size_t)blockIdx.x * 2048 + threadIdx.x;
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = s[k * 256];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k * 256] = v[k];
+}
+__global__ void __launch_bounds__(256) oss_copy_pieces16_kernel(const f32x4 *src, f32x4 *dst, size_t n_pieces) {
+    constexpr size_t PIECE = 4096;
+    for (size_t pc = blockIdx.x; pc < n_pieces; pc += gridDim.x) {
+        const f32x4 *s = src + pc * PIECE + threadIdx.x;
+        f32x4 *d = dst + pc * PIECE + threadIdx.x;
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = s[k * 256];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k * 256] = v[k];
+    }
+}
 __global__ void __launch_bounds__(256) oss_copy_kernel(const f32x4 *src, f32x4 *dst, size_t n) {
-    // eight 16-byte loads in flight per lane before the first store (one load per iteration left the memory system idle
-    // between a wave's round trips)
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i + 7 * stride < n; i += 8 * stride) {
@@ -546,15 +596,39 @@ __global__ void __launch_bounds__(256) oss_copy_kernel(const f32x4 *src, f32x4 *
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
+__global__ void __launch_bounds__(256) oss_copy_flat_kernel(const f32x4 *src, f32x4 *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
 
 int oss_hbm_copy(const void *src, void *dst, size_t n_bytes, oss_stream_t stream) {
     if (!src || !dst) return OSS_ERR_NULL;
     const size_t n = n_bytes / 16;
     if (n == 0) return OSS_OK;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(oss_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n);
+    static const int mode = [] { const char *e = std::getenv("VMAMBAIR_COPY_MODE"); return e ? std::atoi(e) : 2; }();
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const f32x4 *sp = reinterpret_cast<const f32x4 *>(src);
+    f32x4 *dp = reinterpret_cast<f32x4 *>(dst);
+    if (mode == 1) {
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(oss_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, sp, dp, n);
+    } else if (mode == 2 && (n + 255) / 256 <= 0x7fffffffu) {
+        hipLaunchKernelGGL(oss_copy_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sp, dp, n);
+    } else if (mode == 3 && n % 2048 == 0) {
+        hipLaunchKernelGGL(oss_copy_piece_per_wg_kernel, dim3((unsigned)(n / 2048)), dim3(256), 0, s, sp, dp);
+    } else if (mode == 4 && n % 4096 == 0) {
+        hipLaunchKernelGGL(oss_copy_pieces16_kernel, dim3((unsigned)std::min<size_t>(n / 4096, 256 * 4)), dim3(256), 0, s, sp, dp, n / 4096);
+    } else {
+        const size_t pieces = n / 2048, tail = n - pieces * 2048;
+        if (pieces) {
+            const unsigned blocks = (unsigned)std::min<size_t>(pieces, 256 * 8);
+            hipLaunchKernelGGL(oss_copy_pieces_kernel, dim3(blocks), dim3(256), 0, s, sp, dp, pieces);
+        }
+        if (tail)
+            hipLaunchKernelGGL(oss_copy_flat_kernel, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, s, sp + pieces * 2048,
+                               dp + pieces * 2048, tail);
+    }
     return (int)hipGetLastError();
 }
 

@@ -12,7 +12,11 @@
 
 namespace oss {
 
-// state[0] = step count (float), state[1] = 1 - beta1^t, state[2] = 1 - beta2^t
+// state[0] = step count (float), state[1] = 1 - beta1^t, state[2] = 1 - beta2^t, state[3] = learning rate (read when the
+// host passes lr < 0: both reference trainings change it during the run -- MultiStepLR at 50k / 70k iterations,
+// SRGAN/options/MambaSISR15_x4.yml:84-87; CosineAnnealingRestartCyclicLR stepped every iteration,
+// Deraining/Deraining/Options/Deraining_mamber33.yml:81-85 through update_learning_rate, Deraining/basicsr/models/base_model.py:
+// 183-193 -- and a value baked into a captured launch could not follow)
 __global__ void oss_adam_tick_kernel(float *state, float beta1, float beta2) {
     const float t = state[0] + 1.f;
     state[0] = t;
@@ -21,9 +25,11 @@ __global__ void oss_adam_tick_kernel(float *state, float beta1, float beta2) {
 }
 
 __global__ void __launch_bounds__(256)
-oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__restrict__ state, float lr, float beta1,
-                    float beta2, float eps, float ema_decay, float decay_keep, const float *__restrict__ grad_scale) {
+oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__restrict__ state, float lr_arg, float beta1,
+                    float beta2, float eps, float ema_decay, float weight_decay, const float *__restrict__ grad_scale) {
     const oss_adam_chunk c = chunks[blockIdx.x];
+    const float lr = lr_arg < 0.f ? state[3] : lr_arg;
+    const float decay_keep = 1.f - lr * weight_decay;
     const float step_size = lr / state[1], inv_bc2_sqrt = rsqrtf(state[2]);
     // gs: gradient-clipping coefficient (clip_grad_norm_: grads *= min(1, max_norm / (total_norm + 1e-6))) read from
     // device memory so that the launch can sit in a hipGraph; decay_keep = 1 - lr * weight_decay (AdamW, decoupled)
@@ -97,7 +103,7 @@ int adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, floa
                   float ema_decay, hipStream_t s, float weight_decay, const float *grad_scale) {
     hipLaunchKernelGGL(oss_adam_tick_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2);
     hipLaunchKernelGGL(oss_adam_ema_kernel, dim3(n_chunks), dim3(256), 0, s, chunks, state, lr, beta1, beta2, eps, ema_decay,
-                       1.f - lr * weight_decay, grad_scale);
+                       weight_decay, grad_scale);
     return (int)hipGetLastError();
 }
 

@@ -245,13 +245,14 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
     const int n_chunks = (p.seqlen + TC - 1) / TC;
     int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.55);
     if (n_seg > 1 && (!p.workspace || p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, n_seg))) n_seg = 1;
-    g_last_fwd_segments.store(n_seg);
+    g_last_fwd_segments.store(1);
     if constexpr (!FD) {
         if (n_seg > 1) {
             FwdSeg sg;
             sg.carry = reinterpret_cast<float *>(p.workspace);
             sg.cps = (n_chunks + n_seg - 1) / n_seg;
             sg.n_seg = (n_chunks + sg.cps - 1) / sg.cps;
+            g_last_fwd_segments.store(sg.n_seg);
             auto k1 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 1>;
             auto k2 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 2>;
             static LdsGate gate1, gate2;

@@ -197,6 +197,10 @@ class PairGrad:
         return self.buf[:, idx * Cc:(idx + 1) * Cc]
 
 
+#: how often the split's backward had to fall back to ``cat`` (a producer ignored the offered half): tests assert it stays put
+CAT_FALLBACKS = 0
+
+
 class _SplitHalvesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xz):
@@ -213,6 +217,8 @@ class _SplitHalvesFn(torch.autograd.Function):
             if ga.data_ptr() == buf.data_ptr() and gb.data_ptr() == buf[:, Cc:].data_ptr() and \
                     ga.stride() == buf.stride() and gb.stride() == buf.stride() and ga.dtype == buf.dtype == gb.dtype:
                 return buf   # both halves were written in place
+        global CAT_FALLBACKS
+        CAT_FALLBACKS += 1
         if ga is None or gb is None:
             ref = ga if ga is not None else gb
             ga = torch.zeros_like(ref) if ga is None else ga

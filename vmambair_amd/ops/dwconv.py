@@ -40,18 +40,18 @@ def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_b
                   pre: Optional[torch.Tensor] = None, dx_into: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """-> [dx (x dtype), dweight (C,1,3,3) fp32, dbias (C) fp32 or empty].  ``pre``: the forward ran with the fused silu;
     dy is then the gradient of silu(conv) and ``dy * silu'(pre)`` is formed inside the weight-gradient kernel.
-    ``dx_into``: a (B, C, H, W) view with contiguous planes (e.g. one half of a wider buffer) that receives dx."""
+    ``dx_into``: a (B, C, H, W) view with contiguous planes (e.g. one half of a wider buffer) that receives dx -- the operator
+    MUTATES it (schema ``Tensor(a!)?``) and then returns an EMPTY dx: the caller reads the buffer it handed in (an operator must
+    not return one of its inputs)."""
     B, Cc, H, W = x.shape
     w = weight.detach().to(torch.float32).reshape(Cc, 9).contiguous()
     x, dy = _planes(x), _planes(dy)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)
     act = pre is not None and pre.numel() > 0
-    if dx_into is not None and dx_into.dtype == x.dtype and tuple(dx_into.shape) == (B, Cc, H, W) and \
-            dx_into.stride(3) == 1 and dx_into.stride(2) == W:
-        dx = dx_into
-    else:
-        dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    in_place = dx_into is not None and dx_into.dtype == x.dtype and tuple(dx_into.shape) == (B, Cc, H, W) and \
+        dx_into.stride(3) == 1 and dx_into.stride(2) == W
+    dx = dx_into if in_place else torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
     dpre = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device) if act else None
     lib = _capi.load()
     with torch.cuda.device(x.device):
@@ -70,11 +70,11 @@ def dwconv3x3_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_b
         _capi.check(lib.oss_dwconv3x3_fwd(_DT[x.dtype], g.data_ptr(), w.data_ptr(), None, dx.data_ptr(), None, B, Cc, H, W,
                                           g.stride(0), g.stride(1), dx.stride(0), dx.stride(1), 1,
                                           torch.cuda.current_stream().cuda_stream), "oss_dwconv3x3_fwd(flip)")
-    return [dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
+    return [x.new_empty(0) if in_place else dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 
 _LIB.define("dwconv3x3_fwd(Tensor x, Tensor weight, Tensor? bias, bool act) -> Tensor[]")
-_LIB.define("dwconv3x3_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias, Tensor? pre, Tensor? dx_into) -> Tensor[]")
+_LIB.define("dwconv3x3_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias, Tensor? pre, Tensor(a!)? dx_into) -> Tensor[]")
 _LIB.impl("dwconv3x3_fwd", dwconv3x3_fwd, "CUDA")
 _LIB.impl("dwconv3x3_bwd", dwconv3x3_bwd, "CUDA")
 
@@ -95,6 +95,8 @@ class DWConv3x3Fn(torch.autograd.Function):
         x, weight, pre = ctx.saved_tensors
         into = ctx.grad_into[0].half(ctx.grad_into[1], x) if ctx.grad_into is not None else None
         dx, dw, db = torch.ops.vmambair.dwconv3x3_bwd(x, weight, dy, ctx.has_bias, pre, into)
+        if into is not None and dx.numel() == 0 and x.numel() != 0:
+            dx = into   # written in place: the half of the PairGrad buffer IS the gradient (_SplitHalvesFn then skips its cat)
         return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), None, None
 
 

@@ -67,12 +67,11 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
         skip_grad = skip_grad.to(x.dtype).contiguous()
     dx = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
     dgate = None
-    if gate is not None:
-        if dgate_into is not None and dgate_into.dtype == dy.dtype and tuple(dgate_into.shape) == (B, Cc, H, W) and \
-                dgate_into.stride(3) == 1 and dgate_into.stride(2) == W and dgate_into.stride(1) == P:
-            dgate = dgate_into
-        else:
-            dgate = torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device)
+    in_place = False   # dgate_into is MUTATED (schema ``Tensor(a!)?``) and an EMPTY dgate is returned: an operator must not
+    if gate is not None:   # return one of its inputs; the caller reads the buffer it handed in
+        in_place = dgate_into is not None and dgate_into.dtype == dy.dtype and tuple(dgate_into.shape) == (B, Cc, H, W) and \
+            dgate_into.stride(3) == 1 and dgate_into.stride(2) == W and dgate_into.stride(1) == P
+        dgate = dgate_into if in_place else torch.empty((B, Cc, H, W), dtype=dy.dtype, device=x.device)
     dw = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if bias is not None else None
     lib = _capi.load()
@@ -86,12 +85,12 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
                                         0 if dgate is None else dgate.stride(0), st), "oss_ln_nchw_bwd")
     _keep(part, dw, db)
     e = x.new_empty(0, dtype=torch.float32)
-    return [dx, dgate if dgate is not None else e, dw, db if db is not None else e]
+    return [dx, dgate if (dgate is not None and not in_place) else e, dw, db if db is not None else e]
 
 
 _LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
 _LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd, "
-            "Tensor? skip_grad, Tensor? dgate_into) -> Tensor[]")
+            "Tensor? skip_grad, Tensor(a!)? dgate_into) -> Tensor[]")
 _LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
 _LIB.impl("ln_nchw_bwd", ln_nchw_bwd, "CUDA")
 _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
@@ -119,6 +118,8 @@ class LayerNormNCHWFn(torch.autograd.Function):
         if ctx.has_gate and ctx.gate_grad_into is not None and gate.dtype == dy.dtype:
             into = ctx.gate_grad_into[0].half(ctx.gate_grad_into[1], gate)
         dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, weight, bias, gate, dy, mean, rstd, dskip, into)
+        if ctx.has_gate and into is not None and dgate.numel() == 0 and gate.numel() != 0:
+            dgate = into   # written in place: the half of the PairGrad buffer IS the gradient
         return (dx, dw.to(weight.dtype), db.to(bias.dtype) if ctx.has_bias else None,
                 dgate.to(gate.dtype) if ctx.has_gate else None, None, None, None)
 

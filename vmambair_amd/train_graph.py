@@ -100,7 +100,11 @@ class GraphedTrainStep:
             assert clip_grad_norm is None, "gradient clipping is implemented in the fused optimizer launch only"
             cls = torch.optim.AdamW if weight_decay > 0 else torch.optim.Adam
             kw = dict(weight_decay=weight_decay) if weight_decay > 0 else {}
-            self.opt = cls(self.params, lr=lr, betas=betas, fused=True, capturable=True, **kw)
+            # the rate as a device tensor: a captured torch step then follows ``set_lr`` too
+            self.opt = cls(self.params, lr=torch.tensor(float(lr), dtype=torch.float32, device=self.device), betas=betas,
+                           fused=True, capturable=True, **kw)
+        self.lr = float(lr)
+        self.iteration = 0   # optimizer steps taken through __call__ (``current_iter`` of the reference's training loop)
         # opt-in: weight gradients (needed only by the optimizer) on a second stream next to the input-gradient chain.
         # Measured SLOWER inside the hipGraph on this stack (138.5 vs 141.5 images/s: the cross-stream edges cost more
         # than the overlap of these 5-20 us kernels buys), hence off by default
@@ -259,7 +263,14 @@ class GraphedTrainStep:
             st += [e.clone() for e in self.ema]
         if self.fopt is not None:
             st += [t.clone() for t in self.fopt.exp_avg + self.fopt.exp_avg_sq + [self.fopt.state]]
-        return st, None
+        osd = None
+        if self.opt is not None:
+            # torch optimizer: clone every state tensor that exists NOW.  A second shape captured in the middle of a run
+            # (multi_shape: the progressive patch schedule does that six times) must get the trained moments and step
+            # count back after its warm-up steps, not zeros
+            osd = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in stt.items()}
+                   for p, stt in self.opt.state.items()}
+        return st, osd
 
     def _restore(self, snap):
         st, osd = snap
@@ -268,12 +279,63 @@ class GraphedTrainStep:
             live += self.fopt.exp_avg + self.fopt.exp_avg_sq + [self.fopt.state]
         with torch.no_grad():
             torch._foreach_copy_(live, st)
-        if self.opt is not None:   # torch optimizer: its state tensors were created by the warm-up; put them back to "no step yet"
+        if self.opt is not None:
             with torch.no_grad():
-                for stt in self.opt.state.values():
-                    for v in stt.values():
+                for p, stt in self.opt.state.items():
+                    saved = (osd or {}).get(id(p))
+                    for k, v in stt.items():
+                        if not torch.is_tensor(v):
+                            continue
+                        if saved is not None and k in saved:
+                            v.copy_(saved[k])   # in place: a graph captured earlier keeps reading these tensors
+                        else:
+                            v.zero_()           # created by this (the first) warm-up: back to "no step yet"
+
+    # ---- learning rate, training state ---------------------------------------------------------
+    def set_lr(self, lr: float) -> None:
+        """learning rate of the following steps (graph replays included): what the reference's
+        ``update_learning_rate(current_iter)`` does through its scheduler before every ``optimize_parameters``
+        (Deraining/basicsr/train.py:238, basicsr/models/base_model.py:183-205)."""
+        if self.fopt is not None:
+            self.fopt.set_lr(lr)
+        else:
+            with torch.no_grad():
+                for g in self.opt.param_groups:
+                    g["lr"].fill_(float(lr))
+        self.lr = float(lr)
+
+    def state_dict(self) -> dict:
+        """what ``save_training_state`` keeps (base_model.py:312-334: iteration, optimizer state) plus the EMA weights
+        (a second network in the reference, saved by ``save_network`` under ``params_ema``)"""
+        osd = self.fopt.state_dict() if self.fopt is not None else self.opt.state_dict()
+        return {"iter": self.iteration, "optimizers": [osd],
+                "ema": [e.detach().clone() for e in self.ema] if self.ema is not None else None}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """resume (``resume_training``, base_model.py:336-351).  Tensors are written IN PLACE, so graphs captured before
+        the call keep working; hyper-parameters other than the learning rate are baked into captured launches and must
+        match the ones this object was built with."""
+        osd = sd["optimizers"][0]
+        if self.fopt is not None:
+            self.fopt.load_state_dict(osd)
+            self.lr = self.fopt.lr
+        else:
+            lr_t = self.opt.param_groups[0]["lr"]
+            cur = self.opt.state_dict()
+            for k, ent in osd["state"].items():
+                if k in cur["state"]:        # existing tensors (possibly captured): copy in place
+                    for name, v in ent.items():
                         if torch.is_tensor(v):
-                            v.zero_()
+                            cur["state"][k][name].copy_(v)
+                else:
+                    self.opt.state[self.params[k]] = {n: (v.to(self.device).clone() if torch.is_tensor(v) else v) for n, v in ent.items()}
+            with torch.no_grad():
+                lr_t.fill_(float(osd["param_groups"][0]["lr"]))
+            self.lr = float(osd["param_groups"][0]["lr"])
+        if self.ema is not None and sd.get("ema") is not None:
+            with torch.no_grad():
+                torch._foreach_copy_(self.ema, [e.to(self.device) for e in sd["ema"]])
+        self.iteration = int(sd.get("iter", 0))
 
     def _key(self, lq, gt):
         return (tuple(lq.shape), tuple(gt.shape))
@@ -355,6 +417,7 @@ class GraphedTrainStep:
             else:
                 self._allreduce()
             self.graph_opt.replay()
+        self.iteration += 1
         return self.static_loss
 
     def collect_allreduce_ms(self):
