@@ -161,6 +161,10 @@ def bench_realsr_tiled(args):
                 "traffic": None, "kernel": f"{dom['kernel']} variant {dom['variant']} io {dom['io']}",
                 "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches": dom["launches"],
                 "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
+                "segments": {"fwd_last_call": int(lib.oss_scan_last_segments(0))},
+                "all_scan_kernels": [{"kernel": r["kernel"], "variant": r["variant"], "io": r["io"], "launches": r["launches"],
+                                      "avg_ms": round(r["total_ms"] / r["launches"], 4),
+                                      "alg_GBps": round(r["alg_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in recs],
                 "scan_ms_per_image": round(sum(r["total_ms"] for r in recs), 3),
                 "measured": "HIP events around every scan launch of one eager pass over the same tiles"}
     g = max(res.values(), key=lambda r: r["images_per_s"])
@@ -212,6 +216,30 @@ def bench_srgan_split64(args):
         "config": {"workload": "SRGAN-tree validation path: MambaSISR6 dim48 [15,1,1,1]+15, bf16 autocast, no_grad, 256x256 LQ in 16 "
                                "cells of 64x64 (SURVEY.md 8f row 3)", **res},
         "roofline": None, "cpu_baseline": None}), flush=True)
+
+
+def pmc_lookup(lib, kkey):
+    """HBM bytes per launch of kernel ``kkey`` from the PMC record under profiles/ (separate rocprofv3 --pmc passes,
+    tools/pmc_traffic.sh + tools/pmc_record.py) -- only when the record was measured on THIS build of the scan kernels
+    (``oss_scan_build_id()``); a record of another build is reported as stale, never silently (VERDICT r2 #10)."""
+    prof_dir = os.path.join(ROOT, "profiles")
+    build = lib.oss_scan_build_id().decode()
+    try:
+        names = sorted((f for f in os.listdir(prof_dir) if f.endswith("pmc_traffic.json")), reverse=True)
+        for f in names:
+            rec = json.load(open(os.path.join(prof_dir, f)))
+            if kkey not in rec:
+                continue
+            if rec.get("_build_id") != build:
+                return None, (f"stale: profiles/{f} was measured on scan-kernel build {rec.get('_build_id', '(unrecorded)')}, "
+                              f"this library is {build}"), None
+            e = rec[kkey]
+            return int(e["fetch_bytes"] + e["write_bytes"]), \
+                f"FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes, build {build} [profiles/{f}]", \
+                e.get("valu_busy", e.get("valu_active_share_of_wave_cycles"))
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, "no PMC record for this kernel", None
 
 
 def collect_prof(lib):
@@ -298,6 +326,34 @@ def cpu_baseline(seed=0):
                       "scan = oracle/oss_scan_oracle.c (OpenMP), rest = torch CPU", "seconds": round(dt, 2)}
 
 
+def secondary_workloads():
+    """BASELINE.json configs[3] and configs[4] in front of the driver: a few Deraining training steps and one
+    RealSR tiled image, each in its own process after the headline's timed region, each with its dominant scan kernel's
+    roofline fraction.  Bounded: 5 + 2 steps; a failure of this leg never touches the headline line."""
+    import subprocess
+    me = os.path.abspath(__file__)
+    out = {}
+    for name, extra in (("deraining", ["--config", "deraining", "--steps", "5", "--warmup", "2"]),
+                        ("realsr_tiled", ["--config", "realsr-tiled", "--steps", "2", "--warmup", "1"])):
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, me, *extra, "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True,
+                               timeout=240)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            roof = j.get("roofline") or {}
+            out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                         "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "workload": j["config"]["workload"],
+                         "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                                "launches", "alg_bytes_per_launch", "frac_with_finish", "segments")},
+                         "seconds": round(time.time() - t0, 1)}
+            if name == "realsr_tiled":
+                out[name]["tiles_per_s"] = j["config"].get("tiles_per_s")
+                out[name]["tiles_per_forward"] = j["config"].get("tiles_per_forward")
+        except Exception as e:   # noqa: BLE001
+            out[name] = {"error": str(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,6 +365,8 @@ def main():
     ap.add_argument("--config", choices=["sr", "deraining", "realsr-tiled", "srgan-split64"], default="sr")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the trailing Deraining / RealSR legs of the default single-GPU run (the `secondary` block)")
     ap.add_argument("--micro-streams", type=int, default=int(os.environ.get("VMAMBAIR_MICRO_STREAMS", "1")),
                     help="micro-batches of the per-GPU batch run as parallel branches of the step's graph (train_graph.py)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("VMAMBAIR_BENCH_GRAPH", "1")),
@@ -397,12 +455,15 @@ def main():
         step.time_allreduce()
     lib.oss_prof_reset()
     lib.oss_prof_enable(0 if args.graph else 1)
+    st_ = torch.cuda.current_stream().cuda_stream
+    lib.oss_prof_marker(1, st_)   # kernel-trace markers around the timed region (tools/prof_summary.py), outside the clock
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(lq, gt)
     fence()
     dt = time.perf_counter() - t0
+    lib.oss_prof_marker(2, st_)
     lib.oss_prof_enable(0)
     log(f"timed {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.item())
@@ -447,19 +508,7 @@ def main():
             kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}"
             fdom = fin.get((dom["variant"], dom["io"])) if dom["kernel"] == "oss_scan_bwd_kernel" else None
             with_fin_ms = dom["total_ms"] + (fdom["total_ms"] if fdom else 0.0)
-            traffic, traffic_note = None, "no PMC record for this kernel build"
-            valu_busy = None
-            try:  # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)
-                prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-                pmc = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof_dir, f)))
-                rec = json.load(open(os.path.join(prof_dir, pmc)))
-                if kkey in rec:
-                    traffic = int(rec[kkey]["fetch_bytes"] + rec[kkey]["write_bytes"])
-                    valu_busy = rec[kkey].get("valu_busy")
-                    traffic_note = rec[kkey].get("note", "FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch of this kernel at "
-                                                 "u:(8,384,4096), separate rocprofv3 --pmc passes") + f" [profiles/{pmc}]"
-            except (OSError, ValueError, KeyError):
-                pass
+            traffic, traffic_note, valu_busy = pmc_lookup(lib, kkey)
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": kkey,
@@ -469,6 +518,8 @@ def main():
                     "valu_busy": valu_busy,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
+                    # time segments per row of the LAST scan call (1 = one workgroup walks the whole row, as the reference does)
+                    "segments": {"fwd": int(lib.oss_scan_last_segments(0)), "bwd": int(lib.oss_scan_last_segments(1))},
                     # SURVEY.md 8d asks for both: `achieved` prices the unfused-equivalent bytes (every direction its own
                     # u / dout rows); the omni kernel's own algorithmic bytes share them between directions k, k + 2
                     "own_alg_bytes_per_launch": round(dom["own_bytes"] / dom["launches"]),
@@ -510,6 +561,11 @@ def main():
             except Exception as e:  # the headline number must survive a broken baseline leg
                 cpu = {"error": str(e)[:200]}
 
+        second = None
+        if world == 1 and args.config == "sr" and not args.global_batch and not args.no_secondary:
+            log("secondary workloads (configs[3], configs[4]; subprocesses, 240 s limit each)")
+            second = secondary_workloads()
+
         images = world * B * args.steps
         line = {
             "metric": ("images/sec, deraining 128x128 training step (fwd+bwd+clip+AdamW), Mamber32 [3,5,7,9]+2" if derain else
@@ -532,7 +588,7 @@ def main():
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "allreduce_overlapped": False,
                        "allreduce_bytes": 4 * sum(p.numel() for p in net.parameters()) if world > 1 else 0},
-            "final_loss": round(loss_val, 5), "roofline": roof, "cpu_baseline": cpu,
+            "final_loss": round(loss_val, 5), "roofline": roof, "cpu_baseline": cpu, "secondary": second,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

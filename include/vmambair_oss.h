@@ -380,6 +380,16 @@ int oss_prof_collect2(int which, int variant, oss_dtype io, double *total_ms, lo
  * the same run as the scan kernels; copies n_bytes (multiple of 16) from src to dst. */
 int oss_hbm_copy(const void *src, void *dst, size_t n_bytes, oss_stream_t stream);
 
+/* Launches an empty kernel named oss_prof_marker_begin (which = 1) / oss_prof_marker_end (2) on `stream`: bench.py brackets
+ * its timed region with them so that tools/prof_summary.py can cut a rocprofv3 kernel trace down to the steady-state
+ * replays (no warm-up, capture or vendor solver search). */
+int oss_prof_marker(int which, oss_stream_t stream);
+
+/* Hash of the sources the scan kernels are compiled from (oss_scan_*.hip/.h, oss_device.h), fixed at build time.  PMC
+ * counter records under profiles/ carry the id of the build they were measured on; bench.py reports counters only when it
+ * matches the loaded library ("stale" otherwise). */
+const char *oss_scan_build_id(void);
+
 const char *oss_version(void);
 
 #ifdef __cplusplus

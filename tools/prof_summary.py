@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace rocpd database into text (runs on the GPU box: the .db itself
-is too large to ship back).  Usage: prof_summary.py <results.db> <out.txt> [window_ms]"""
+is too large to ship back).  Usage: prof_summary.py <results.db> <out.txt> [window_ms]
+
+Round 3: when the trace holds the library's marker kernels (oss_prof_marker_begin / _end, launched by bench.py around its
+timed region) the FIRST table is the steady-state window between them -- graph replays only, no eager warm-up, no capture,
+no vendor solver search -- normalised per training step (steps = launches of oss_adam_tick_kernel in the window, one per
+optimizer step).  The whole-run table follows for reference."""
 import sqlite3
 import sys
 
@@ -10,6 +15,22 @@ def main():
     window_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 150.0
     cur = sqlite3.connect(db_path).cursor()
     lines = []
+    mb = cur.execute("select max(end) from kernels where name like '%oss_prof_marker_begin%'").fetchone()[0]
+    me = cur.execute("select min(start) from kernels where name like '%oss_prof_marker_end%' and start > ?", (mb or 0,)).fetchone()[0]
+    if mb and me:
+        rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
+                                "from kernels where start>=? and end<=? group by name order by 3 desc", (mb, me)))
+        steps = sum(r[1] for r in rows if "oss_adam_tick_kernel" in r[0]) or 1
+        tot = sum(r[2] for r in rows)
+        n = sum(r[1] for r in rows)
+        wall = (me - mb) / 1e6
+        lines.append(f"# STEADY STATE (between the bench's marker kernels = its timed region): {steps} steps, {wall:.2f} ms wall = "
+                     f"{wall / steps:.3f} ms/step; {n} kernel launches = {n / steps:.0f} per step; {tot / steps:.3f} ms of kernel time "
+                     f"per step ({100 * tot / wall:.1f} % of the wall time: the rest is gaps between dependent kernels)")
+        lines.append("# ms/step  share  launches/step  avg_us  min_us  max_us  kernel")
+        for r in rows:
+            lines.append(f"{r[2] / steps:9.4f} {100 * r[2] / tot:5.1f}% {r[1] / steps:9.1f} {r[3]:9.1f} {r[4]:9.1f} {r[5]:9.1f}  {r[0]}")
+        lines.append("")
     rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
                             "from kernels group by name order by 3 desc"))
     tot = sum(r[2] for r in rows)

@@ -18,6 +18,18 @@ LIB_PATH = os.path.join(LIB_DIR, "libvmambair_oss.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 
+#: the files the scan kernels are compiled from: their hash is the library's oss_scan_build_id()
+SCAN_FILES = ("oss_scan_fwd.hip", "oss_scan_bwd.hip", "oss_scan_bwd_v2.h", "oss_scan_bwd_pair.h", "oss_device.h")
+
+
+def scan_build_id() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in SCAN_FILES:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -53,7 +65,9 @@ def _stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP translation unit into vmambair_amd/lib/libvmambair_oss.so."""
-    if not force and not _stale():
+    idfile0 = os.path.join(OBJ_DIR, "scan_build_id.txt")
+    same_id = os.path.exists(idfile0) and open(idfile0).read() == scan_build_id()
+    if not force and not _stale() and same_id:
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -61,8 +75,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     todo = _stale_objects(force)
 
+    bid = scan_build_id()
+    idfile = os.path.join(OBJ_DIR, "scan_build_id.txt")
+    if not (os.path.exists(idfile) and open(idfile).read() == bid):   # the id is compiled into oss_capi.o
+        open(idfile, "w").write(bid)
+        capi = os.path.join(CSRC, "oss_capi.hip")
+        if capi not in todo:
+            todo.append(capi)
+
     def compile_one(src):
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", _obj(src) + ".tmp"]
+        cmd = [hipcc, *FLAGS, f'-DOSS_SCAN_BUILD_ID="{bid}"', "-c", src, "-o", _obj(src) + ".tmp"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

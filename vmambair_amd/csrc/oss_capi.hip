@@ -632,6 +632,22 @@ int oss_hbm_copy(const void *src, void *dst, size_t n_bytes, oss_stream_t stream
     return (int)hipGetLastError();
 }
 
-const char *oss_version(void) { return "vmambair_oss 0.1 (gfx950)"; }
+// a one-lane kernel whose only purpose is its NAME in a kernel trace: tools/prof_summary.py keeps the launches between
+// marker 1 and marker 2 (bench.py puts them around the timed region), so that a summary holds steady-state graph replays only
+__global__ void oss_prof_marker_begin() {}
+__global__ void oss_prof_marker_end() {}
+int oss_prof_marker(int which, oss_stream_t stream) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (which == 1) hipLaunchKernelGGL(oss_prof_marker_begin, dim3(1), dim3(1), 0, s);
+    else hipLaunchKernelGGL(oss_prof_marker_end, dim3(1), dim3(1), 0, s);
+    return (int)hipGetLastError();
+}
+
+#ifndef OSS_SCAN_BUILD_ID
+#define OSS_SCAN_BUILD_ID "unknown"
+#endif
+const char *oss_scan_build_id(void) { return OSS_SCAN_BUILD_ID; }
+
+const char *oss_version(void) { return "vmambair_oss 0.3 (gfx950)"; }
 
 }  // extern "C"

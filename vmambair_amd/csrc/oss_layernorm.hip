@@ -170,11 +170,13 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     const bool ok = p < P;
     const int pc = ok ? p : 0;
     const TX *xp = x + b * xsb + pc;
-    // the skip connection's gradient (added to dx).  Loaded without a branch: with res == NULL the loads read dx itself (same
-    // shape and type, values discarded).  A wave-uniform `if (res)` around the loads makes hipcc treat every later use of the
-    // loaded registers as "maybe still in flight": s_waitcnt vmcnt(0) before each -- which then waits for the previous STORE.
+    // the skip connection's gradient (added to dx).  Loaded without a branch: with res == NULL the loads re-read x at the very
+    // addresses the pass has just fetched (cache hits, values discarded) -- never dx, the output other lanes are writing
+    // (ADVICE r2).  A wave-uniform `if (res)` around the loads makes hipcc treat every later use of the loaded registers as
+    // "maybe still in flight": s_waitcnt vmcnt(0) before each -- which then waits for the previous STORE.
     const bool has_res = res != nullptr;
-    const TX *rsp = (has_res ? res : dx) + (size_t)b * C * P + pc;
+    const TX *rsp = has_res ? res + (size_t)b * C * P + pc : xp;
+    const int64_t rsc = has_res ? (int64_t)P : xsc;
     const TY *gyp = dy + (size_t)b * C * P + pc;
     const TY *gp = GATE ? gate + b * gsb + pc : nullptr;
     const bool with_bias = bias != nullptr;
@@ -229,7 +231,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 #pragma unroll
             for (int i = 0; i < CPW; ++i) {
                 const int c = wave + i * nw, cc = c < C ? c : C - 1;
-                load_v<TX, V>(rsp + (size_t)cc * P, rv[i]);
+                load_v<TX, V>(rsp + cc * rsc, rv[i]);
             }
         } else {
 #pragma unroll
@@ -294,7 +296,7 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 #pragma unroll
             for (int u = 0; u < V; ++u) { z[u] = 0.f; r[u] = 0.f; }
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
-            load_v<TX, V>(rsp + (size_t)c * P, r);
+            load_v<TX, V>(rsp + c * rsc, r);
             second(c, w[c], with_bias ? bias[c] : 0.f, t, g, z, r);
         }
     }
