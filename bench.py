@@ -158,12 +158,12 @@ def bench_realsr_tiled(args):
         dom = max(recs, key=lambda r: r["total_ms"])
         ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": None, "kernel": f"{dom['kernel']} variant {dom['variant']} io {dom['io']}",
+                "traffic": None, "kernel": f"{dom['kernel']} variant {dom['variant']} io {dom['io']}" + (" segmented" if dom["segmented"] else ""),
                 "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches": dom["launches"],
                 "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
                 "segments": {"fwd_last_call": int(lib.oss_scan_last_segments(0))},
-                "all_scan_kernels": [{"kernel": r["kernel"], "variant": r["variant"], "io": r["io"], "launches": r["launches"],
-                                      "avg_ms": round(r["total_ms"] / r["launches"], 4),
+                "all_scan_kernels": [{"kernel": r["kernel"], "variant": r["variant"], "segmented": r["segmented"], "io": r["io"],
+                                      "launches": r["launches"], "avg_ms": round(r["total_ms"] / r["launches"], 4),
                                       "alg_GBps": round(r["alg_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in recs],
                 "scan_ms_per_image": round(sum(r["total_ms"] for r in recs), 3),
                 "measured": "HIP events around every scan launch of one eager pass over the same tiles"}
@@ -247,14 +247,14 @@ def collect_prof(lib):
     recs = []
     names = {0: "oss_scan_fwd_kernel", 1: "oss_scan_bwd_kernel", 2: "oss_scan_bwd_finish"}
     for which in (0, 1, 2):
-        for variant in range(16):
+        for variant in range(32):   # 16 + v: time-segmented launches of variant v (their own bucket)
             for io, name in ((0, "f32"), (1, "f16"), (2, "bf16")):
                 ms, n, by, own = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
                 if lib.oss_prof_collect2(which, variant, io, C.byref(ms), C.byref(n), C.byref(by), C.byref(own)) != 0:
                     continue
                 if n.value:
-                    recs.append(dict(kernel=names[which], variant=variant, io=name, launches=n.value, total_ms=ms.value,
-                                     alg_bytes=by.value, own_bytes=own.value))
+                    recs.append(dict(kernel=names[which], variant=variant % 16, segmented=variant >= 16, io=name, launches=n.value,
+                                     total_ms=ms.value, alg_bytes=by.value, own_bytes=own.value))
     return recs
 
 
@@ -499,14 +499,14 @@ def main():
     if rank == 0:
         recs = collect_prof(lib)
         roof = None
-        fin = {(r["variant"], r["io"]): r for r in recs if r["kernel"] == "oss_scan_bwd_finish"}
+        fin = {(r["variant"], r["io"], r["segmented"]): r for r in recs if r["kernel"] == "oss_scan_bwd_finish"}
         recs = [r for r in recs if r["kernel"] != "oss_scan_bwd_finish"]
         if recs:
             dom = max(recs, key=lambda r: r["total_ms"])
             avg_ms = dom["total_ms"] / dom["launches"]
             achieved = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
-            kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}"
-            fdom = fin.get((dom["variant"], dom["io"])) if dom["kernel"] == "oss_scan_bwd_kernel" else None
+            kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}" + (" segmented" if dom["segmented"] else "")
+            fdom = fin.get((dom["variant"], dom["io"], dom["segmented"])) if dom["kernel"] == "oss_scan_bwd_kernel" else None
             with_fin_ms = dom["total_ms"] + (fdom["total_ms"] if fdom else 0.0)
             traffic, traffic_note, valu_busy = pmc_lookup(lib, kkey)
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -528,8 +528,8 @@ def main():
                     "finish_avg_ms": round(fdom["total_ms"] / fdom["launches"], 4) if fdom else None,
                     "frac_with_finish": round(dom["alg_bytes"] / (with_fin_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "all_scan_kernels": [
-                        {"kernel": r["kernel"], "variant": r["variant"], "io": r["io"], "launches": r["launches"],
-                         "avg_ms": round(r["total_ms"] / r["launches"], 4),
+                        {"kernel": r["kernel"], "variant": r["variant"], "segmented": r["segmented"], "io": r["io"],
+                         "launches": r["launches"], "avg_ms": round(r["total_ms"] / r["launches"], 4),
                          "alg_GBps": round(r["alg_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in recs],
                     "scan_ms_per_step": round(sum(r["total_ms"] for r in recs) / prof_steps, 3),
                     "measured": prof_note}

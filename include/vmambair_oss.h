@@ -369,6 +369,7 @@ int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const flo
  * Returns 0, or OSS_ERR_SHAPE for a bucket out of range. */
 void oss_prof_enable(int on);
 void oss_prof_reset(void);
+/* variant 16 + v: the time-segmented launches of kernel variant v (carry / local pass included in the call's time) */
 int oss_prof_collect(int which, int variant, oss_dtype io, double *total_ms, long long *launches,
                      double *algorithmic_bytes);
 /* ... plus the kernel's OWN algorithmic bytes (tensors the omni form shares between directions counted once); which = 2

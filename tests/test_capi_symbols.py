@@ -109,3 +109,19 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
 def test_drop_in_module_surface():
     import selective_scan_cuda_core as m
     assert callable(m.fwd) and callable(m.bwd)
+
+
+def test_compiled_torch_boundary_is_built_and_registers_its_ops():
+    """lib/libvmambair_torch.so (csrc_host/oss_torch_host.cpp) loads without a GPU and defines the two operators with the
+    mutated-argument annotation; no compute call here"""
+    from vmambair_amd import _host
+    assert os.path.exists(_build.HOST_LIB), "run __graft_entry__.build() first"
+    assert _host.mode() == "c++"
+    ops = _host.ops()
+    s = str(ops.scan_bwd.default._schema)
+    assert "Tensor(a!)? dbc_into" in s and str(ops.scan_fwd.default._schema).endswith("-> Tensor[]")
+    _host.use("ctypes")
+    try:
+        assert _host.mode() == "ctypes" and _host.ops() is None
+    finally:
+        _host.use(None)

@@ -123,11 +123,27 @@ def test_scan_long_sequence_properties():
     A = -0.5 * torch.rand(KD, N, device=DEV)
     Bm, Cm = torch.randn(Bsz, G, N, L, device=DEV), torch.randn(Bsz, G, N, L, device=DEV)
     D, bias = torch.randn(KD, device=DEV), 0.5 * torch.rand(KD, device=DEV)
-    out, x = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
     h = 256 * 23
-    out_h, x_h = vmambair_amd.selective_scan_fwd(u[..., :h].contiguous(), delta[..., :h].contiguous(), A, Bm[..., :h].contiguous(),
+    lib = _capi.load()
+
+    def both():
+        o, xs = vmambair_amd.selective_scan_fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+        oh, xh = vmambair_amd.selective_scan_fwd(u[..., :h].contiguous(), delta[..., :h].contiguous(), A, Bm[..., :h].contiguous(),
                                                   Cm[..., :h].contiguous(), D, bias, True, 1)
-    assert torch.equal(out[..., :h], out_h) and torch.equal(x[:, :, :23], x_h)
+        return o, xs, oh, xh
+    # one workgroup per row tile walking the whole row (the reference's order of operations): the prefix is bit-identical
+    lib.oss_scan_set_segments(1, 1)
+    try:
+        out, x, out_h, x_h = both()
+        assert torch.equal(out[..., :h], out_h) and torch.equal(x[:, :, :23], x_h)
+    finally:
+        lib.oss_scan_set_segments(-1, -1)
+    # default launch: this call is cut into time segments (768 rows leave CUs idle) and the two lengths are cut differently;
+    # a segment's entering state is a fold of segment-local states, so causality holds to fp32 round-off instead of bit for bit
+    out, x, out_h, x_h = both()
+    assert lib.oss_scan_last_segments(0) >= 1
+    assert_close(out[..., :h], out_h, 1e-5, 1e-5 * float(out_h.abs().max()), "causality (segmented launch)")
+    assert_close(x[:, :, :23, 1::2], x_h[..., 1::2], 1e-5, 1e-5 * float(x_h[..., 1::2].abs().max()), "saved states")
     dout = torch.randn(Bsz, KD, L, device=DEV)
     g1 = vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)
     g1b = vmambair_amd.selective_scan_bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1)

@@ -532,6 +532,106 @@ def test_fused_delta_core_matches_materialised_core(dim, hw):
         assert rel(res[0][2][k], res[1][2][k]) < 3e-2, k
 
 
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("L,rows,R,bv", [(1024, 48, 3, -1), (1539, 13, 6, -1), (2085, 12, 8, 11), (700, 24, 5, 13)])
+def test_fused_delta_scan_against_oracle(itype, L, rows, R, bv):
+    """f1 against the ORACLE, not against our own unfused kernels: the four materialised directions
+    (reference data flow, MambaSISR6_arch.py:401-428) with delta = W_dt . z evaluated on the CPU WITHOUT rounding to the I/O
+    type (what the fused kernels do in fp32), forward through oracle/oss_scan_oracle.c, backward through its float64 twin; the
+    gradients of z and W_dt follow from the oracle's ddelta by the einsum's own adjoint."""
+    K, N, Bsz = 4, 16, 2
+    Cc = R + 2 * N
+    g = torch.Generator().manual_seed(17)
+    x2 = torch.randn(Bsz, 2 * rows, L, generator=g).to(itype)
+    xdbl = torch.randn(Bsz, K, Cc, L, generator=g)
+    xdbl[:, :, :R] *= 0.3
+    xdbl = xdbl.to(itype)
+    W = torch.randn(K * rows, R, generator=g) * 0.5
+    A_log = torch.log(0.5 + torch.rand(K * rows, N, generator=g))
+    D, bias = torch.randn(K * rows, generator=g), 0.5 * torch.rand(K * rows, generator=g)
+    dout = torch.randn(Bsz, 2 * rows, L, generator=g).to(itype)
+
+    def mirror(t, per):
+        t = t.clone()
+        t[:, 2 * per:] = t[:, 2 * per:].flip(-1)
+        return t
+    # ---- oracle on the materialised directions
+    A = -torch.exp(A_log)
+    z4 = mirror(xdbl[:, :, :R].double(), 1)
+    delta4 = torch.einsum("kdr,bkrl->bkdl", W.view(K, rows, R).double(), z4).reshape(Bsz, K * rows, L)
+    u4, g4 = mirror(x2.repeat(1, 2, 1), rows), mirror(dout.repeat(1, 2, 1), rows)
+    B4, C4 = mirror(xdbl[:, :, R:R + N], 1), mirror(xdbl[:, :, R + N:], 1)
+    ref_out, ref_x = oss_oracle.scan_fwd(u4, delta4.float(), A, B4, C4, D, bias, True, chunk=256)
+    r64 = oss_oracle.scan_bwd(u4, delta4, A, B4, C4, D, bias, g4, None, True, real="f64")
+    dd4 = r64[1].view(Bsz, K, rows, L)
+    dz_ref = mirror(torch.einsum("kdr,bkdl->bkrl", W.view(K, rows, R).double(), dd4), 1)
+    dW_ref = torch.einsum("bkdl,bkrl->kdr", dd4, z4).reshape(K * rows, R)
+    # ---- fused HIP kernels, omni form
+    lib = _capi.load()
+    lib.oss_scan_set_variant(-1, bv)
+    try:
+        dv = [t.to(DEV) for t in (x2, xdbl, A_log)]
+        Bm, Cm = dv[1][:, :, R:R + N], dv[1][:, :, R + N:]
+        kw = dict(rev_group_start=2, u_row_mod=2 * rows, a_log_form=True)
+        out_f, x_f = vmambair_amd.selective_scan_fwd(dv[0], dv[1], dv[2], Bm, Cm, D.to(DEV), bias.to(DEV), True, 1,
+                                                      dt_weight=W.to(DEV), **kw)
+        dxf = torch.full_like(dv[1], float("nan"))
+        gf = vmambair_amd.selective_scan_bwd(dv[0], dv[1], dv[2], Bm, Cm, D.to(DEV), bias.to(DEV), dout.to(DEV), x_f, True, 1,
+                                             dout_row_mod=2 * rows, dbc_into=dxf, dt_weight=W.to(DEV), **kw)
+    finally:
+        lib.oss_scan_set_variant(-1, -1)
+    rtol, atol = TOL[itype]
+    lo = itype == torch.float32
+    assert_close(out_f, mirror(ref_out, rows), rtol, atol, "out")
+    assert_close(x_f[..., 1::2], ref_x[..., 1::2], 6e-4, 2e-3, "saved states")
+    assert_close(gf[0], mirror(r64[0], rows), rtol * 2, atol * 2, "du")
+    assert torch.isfinite(dxf).all(), "every row of the x_dbl gradient is written"
+    sc = float(dz_ref.abs().max())
+    assert_close(dxf[:, :, :R], dz_ref, rtol * 5, atol * 10 + (2e-5 if lo else 8e-3) * sc, "gradient of the dt factor z")
+    assert_close(dxf[:, :, R:R + N], mirror(r64[3], 1), rtol, atol, "dB")
+    assert_close(dxf[:, :, R + N:], mirror(r64[4], 1), rtol, atol, "dC")
+    wa = 2e-5 if lo else 4e-3
+    assert_close(gf[7], dW_ref, RTOLW * 5, max(ATOLW * 5, wa * float(dW_ref.abs().max())), "gradient of dt_weight")
+    dAlog_ref = r64[2] * A.double()                         # A = -exp(A_log)  =>  d/dA_log = dA * A
+    assert_close(gf[2], dAlog_ref, RTOLW * 5, max(ATOLW * 5, wa * float(dAlog_ref.abs().max())), "dA_log")
+    assert_close(gf[5], r64[5], RTOLW * 5, max(ATOLW * 5, wa * float(r64[5].abs().max())), "dD")
+    assert_close(gf[6], r64[6], RTOLW * 5, max(ATOLW * 5, wa * float(r64[6].abs().max())), "dbias")
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_fused_delta_core_against_oracle_twin(itype, oracle_cpu_kernel):
+    """SS2DCoreFn with delta evaluated inside the scans (ops.core.FUSED_DT) vs the literal reference data flow of
+    SS2D_1.forward_core on the CPU oracle (oracle/cpu_twins.py: ss2d_core), same tensors"""
+    from vmambair_amd import ops
+    from vmambair_amd.oss_block import SS2D_1
+    torch.manual_seed(8)
+    m = SS2D_1(d_model=48, ssm_ratio=1, variant="srgan")
+    x = torch.randn(2, m.d_inner, 32, 24).to(itype).float()      # values representable in the I/O type
+    gw = torch.randn(2, m.d_inner, 32, 24)
+    xc = x.clone().requires_grad_()
+    yc = ops.SS2DCoreFn.apply(xc, m.x_proj_weight, m.dt_projs_weight, m.A_logs, m.Ds, m.dt_projs_bias)   # CPU twin, fp32
+    (yc * gw).sum().backward()
+    want = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    md = m.to(DEV)
+    keep, ops.core.FUSED_DT = ops.core.FUSED_DT, True
+    try:
+        if itype != torch.float32:   # the fused form is 16-bit only (oss_scan_fused_dt_ok); fp32 runs the plain core: same check
+            assert ops.fused_dt_supported(itype, 2, m.d_inner, m.dt_rank + 32, m.dt_rank, 16, 32 * 24)
+        xg = x.to(DEV).to(itype).requires_grad_()
+        yg = ops.SS2DCoreFn.apply(xg, md.x_proj_weight, md.dt_projs_weight, md.A_logs, md.Ds, md.dt_projs_bias)
+        (yg.float() * gw.to(DEV)).sum().backward()
+    finally:
+        ops.core.FUSED_DT = keep
+
+    def rel(a, b):
+        return float((a.float().cpu() - b).norm() / b.norm().clamp_min(1e-20))
+    lim = 2e-4 if itype == torch.float32 else 2e-2      # bf16: x_dbl, B, C, out are rounded to bf16 between the kernels
+    assert rel(yg, yc.detach()) < lim and rel(xg.grad, xc.grad) < 2 * lim
+    for k, gref in want.items():
+        assert rel(dict(md.named_parameters())[k].grad, gref) < 3 * lim, k
+
+
 def test_large_dstate_falls_back_when_the_tiles_do_not_fit_lds():
     """dstate = 250 with the 12-row / 1024-step forward variant needs 167 KiB of LDS (> 160 KiB on gfx950): the launcher takes the
     small-shape variant instead of failing; the reference admits dstate <= 256 (selective_scan.cpp:191)"""
@@ -674,3 +774,55 @@ def test_segmented_scan_at_inference_tile_length(itype):
     assert_close(g[3][:, g0:g0 + 1], ref[3], rtol, atol * 4, "dB (96-row sums)")
     assert_close(g[4][:, g0:g0 + 1], ref[4], rtol, atol * 4, "dC (96-row sums)")
     assert_close(g[2][rows], ref[2], RTOLW, max(ATOLW * 5, 2e-3 * float(ref[2].abs().max())), "dA")
+
+
+# ------------------------------------------------------------------------------------------------
+# the two host boundaries over the same C ABI: compiled TORCH_LIBRARY layer (default) and ctypes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_compiled_and_ctypes_boundaries_agree(itype):
+    """csrc_host/oss_torch_host.cpp (what cus/selective_scan.cpp:157-349 is to the reference) and the ctypes marshalling in
+    ops/scan.py fill the same parameter struct: bit-identical tensors, same None pattern, same errors; strided B / C views,
+    omni arguments and the in-place dB / dC rows included"""
+    from vmambair_amd import _host
+    assert _host.mode() == "c++", "the compiled boundary must be the default on a GPU box (build() makes it)"
+    torch.manual_seed(0)
+    Bsz, K, rows, L, R, N = 2, 4, 12, 1300, 3, 16
+    xdbl = torch.randn(Bsz, K, R + 2 * N, L, device=DEV).to(itype)
+    x2 = torch.randn(Bsz, 2 * rows, L, device=DEV).to(itype)
+    delta = (0.5 * torch.rand(Bsz, K * rows, L, device=DEV)).to(itype)
+    A_log = torch.log(0.5 + torch.rand(K * rows, N, device=DEV))
+    D, bias = torch.randn(K * rows, device=DEV), 0.5 * torch.rand(K * rows, device=DEV)
+    dout = torch.randn(Bsz, 2 * rows, L, device=DEV).to(itype)
+    Bm, Cm = xdbl[:, :, R:R + N], xdbl[:, :, R + N:]
+    kw = dict(rev_group_start=2, u_row_mod=2 * rows, a_log_form=True)
+    res = {}
+    for mode in ("c++", "ctypes"):
+        _host.use(mode)
+        try:
+            out, x = vmambair_amd.selective_scan_fwd(x2, delta, A_log, Bm, Cm, D, bias, True, 1, **kw)
+            into = torch.zeros_like(xdbl)
+            g = vmambair_amd.selective_scan_bwd(x2, delta, A_log, Bm, Cm, D, bias, dout, x, True, 1, dout_row_mod=2 * rows,
+                                                dbc_into=into, **kw)
+            plain = vmambair_amd.selective_scan_bwd(x2.repeat(1, 2, 1), delta, -torch.exp(A_log), Bm.contiguous(), Cm.contiguous(),
+                                                    None, None, dout.repeat(1, 2, 1), None if L <= 256 else x, False, 1)
+            with pytest.raises(RuntimeError, match="delta, B, C must have u's dtype"):
+                vmambair_amd.selective_scan_fwd(x2, delta.float() if itype != torch.float32 else delta.half(), A_log, Bm, Cm, D, bias, True, 1, **kw)
+            with pytest.raises(RuntimeError, match="dout must have u's shape"):
+                vmambair_amd.selective_scan_bwd(x2, delta, A_log, Bm, Cm, D, bias, dout[:, :5], x, True, 1, dout_row_mod=2 * rows, **kw)
+            e_out, e_x = vmambair_amd.selective_scan_fwd(x2[:0], delta[:0], A_log, Bm[:0], Cm[:0], D, bias, True, 1, **kw)
+            assert e_out.shape == (0, K * rows, L) and e_x.shape[0] == 0
+        finally:
+            _host.use(None)
+        res[mode] = (out, x, g, into, plain)
+    a, b = res["c++"], res["ctypes"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    for ga, gb in ((a[2], b[2]), (a[4], b[4])):
+        assert len(ga) == len(gb) == 7
+        for t1, t2 in zip(ga, gb):
+            assert (t1 is None) == (t2 is None)
+            if t1 is not None:
+                assert t1.dtype == t2.dtype and t1.shape == t2.shape and torch.equal(t1, t2)
+    assert a[4][5] is None and a[4][6] is None, "absent D / delta_bias come back as None through both boundaries"
+    # dB / dC of the in-place form are views of dbc_into's last rows in both
+    assert a[2][3].data_ptr() == a[3][:, :, R:R + N].data_ptr() and a[2][4].data_ptr() == a[3][:, :, R + N:].data_ptr()

@@ -16,6 +16,9 @@ for leg in $LEGS; do
     libab)  for lib in "" "$GRAFT_REPO_ROOT/vmambair_amd/lib/libvmambair_oss_exp_${EXP_LIB:-NOSLP}.so"; do tag=$([ -z "$lib" ] && echo base || echo exp); VMAMBAIR_LIB=$lib timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_lib_$tag.txt 2>gpurun_out/bench_lib_$tag.err; echo "lib=$tag rc=$?"; tail -1 gpurun_out/bench_lib_$tag.txt | cut -c1-200; VMAMBAIR_LIB=$lib timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench_$tag.txt 2>&1; echo "opbench rc=$?"; done;;
     opbench) timeout 300 python tools/op_bench.py ${OPBENCH_ARGS:-} > gpurun_out/opbench.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/opbench.txt;;
     benchmfma) VMAMBAIR_CONV1X1=mfma timeout ${BENCH_TIMEOUT:-700} python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_mfma.txt 2>gpurun_out/bench_mfma.err; echo "rc=$?"; tail -1 gpurun_out/bench_mfma.txt | cut -c1-260;;
+    newtests3) timeout 900 python -m pytest tests/test_scan_gpu.py tests/test_train_graph_gpu.py tests/test_configs_gpu.py tests/test_block_gpu.py -m gpu -q -p no:cacheprovider --maxfail=30 -k "fused_delta or train_graph or long_sequence or set_lr or state or second_shape or block_matches" > gpurun_out/newtests3.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/newtests3.txt; grep -E "^(FAILED|ERROR)" gpurun_out/newtests3.txt | head -30;;
+    hostab) timeout 300 python tools/host_overhead.py > gpurun_out/host_overhead.txt 2>/dev/null; echo "rc=$?"; cat gpurun_out/host_overhead.txt;
+            for m in "c++" ctypes; do VMAMBAIR_HOST=$m timeout 300 python bench.py --steps 3 --warmup 1 --config srgan-split64 > gpurun_out/bench_split64_$m.txt 2>/dev/null; echo "host=$m rc=$?"; tail -1 gpurun_out/bench_split64_$m.txt | cut -c1-700; done;;
     segtest) timeout 600 python -m pytest tests/test_scan_gpu.py -m gpu -q -p no:cacheprovider --maxfail=60 -k "segment or reruns_are_stable or every_backward_variant or round2_backward" > gpurun_out/segtest.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/segtest.txt; grep -E "^(FAILED|ERROR)" gpurun_out/segtest.txt | head -40;;
     segsweep) # time-segmented launches on the under-filled shapes (Deraining level 0, RealSR tiles) + the finishing kernel at the headline shape
             timeout 300 python tools/scan_sweep.py --shapes "4,192,16384,4" --dtypes bf16 --fwd-variants 0,3,5,6 --bwd-variants 10,11,13 --segs 1,2,4,8,16 > gpurun_out/segsweep_derain.txt 2>&1; echo "rc=$?";
@@ -26,14 +29,16 @@ for leg in $LEGS; do
             timeout 300 python tools/scan_sweep.py --shapes "1,768,6400,4;1,1536,1600,4;1,384,20736,4" --dtypes f16 --fwd-variants 0,3,5,6 --bwd-variants "" --segs 1,2,4,7 > gpurun_out/segsweep_realsr_levels.txt 2>/dev/null; echo "rc=$?";
             timeout 300 python tools/scan_sweep.py --shapes "4,192,16384,4;1,384,25600,4;8,384,4096,4;8,192,4096,4" --dtypes bf16 --fwd-variants=-1 --bwd-variants=-1 --segs=-1 > gpurun_out/segsweep_auto.txt 2>/dev/null; echo "rc=$?"; cut -c1-200 gpurun_out/segsweep_auto.txt;;
     sweep)  timeout 600 python tools/scan_sweep.py ${SWEEP_ARGS:---quick} > gpurun_out/sweep.txt 2>&1; echo "rc=$?"; tail -3 gpurun_out/sweep.txt;;
-    bench)  timeout ${BENCH_TIMEOUT:-700} python bench.py ${BENCH_ARGS:---steps 5 --warmup 2} > gpurun_out/bench.txt 2>gpurun_out/bench.err; echo "rc=$?"; tail -2 gpurun_out/bench.txt; tail -12 gpurun_out/bench.err;;
+    bench)  SECONDS=0; timeout ${BENCH_TIMEOUT:-700} python bench.py ${BENCH_ARGS:-} > gpurun_out/bench.txt 2>gpurun_out/bench.err; echo "rc=$? wall ${SECONDS}s"; tail -2 gpurun_out/bench.txt; tail -12 gpurun_out/bench.err;;
     newtests) timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_train_graph_gpu.py tests/test_checkpoint_psnr.py tests/test_infer.py -m gpu -q -s -p no:cacheprovider > gpurun_out/newtests.txt 2>&1; echo "rc=$?"; tail -5 gpurun_out/newtests.txt; grep -E "^\[(16bit|net)\]|^(FAILED|ERROR)" gpurun_out/newtests.txt | head -40;;
     bench32) timeout 400 python bench.py --steps 10 --warmup 3 --global-batch 32 --no-cpu-baseline > gpurun_out/bench_gb32.txt 2>gpurun_out/bench_gb32.err; echo "rc=$?"; tail -1 gpurun_out/bench_gb32.txt | cut -c1-300;;
-    derain) timeout 600 python bench.py --steps 10 --warmup 3 --config deraining --no-cpu-baseline > gpurun_out/bench_derain.txt 2>gpurun_out/bench_derain.err; echo "rc=$?"; tail -1 gpurun_out/bench_derain.txt | cut -c1-300; tail -3 gpurun_out/bench_derain.err;;
+    derain) timeout 600 python bench.py --steps 10 --warmup 3 --config deraining --no-cpu-baseline --no-secondary > gpurun_out/bench_derain.txt 2>gpurun_out/bench_derain.err; echo "rc=$?"; tail -1 gpurun_out/bench_derain.txt | cut -c1-300; tail -3 gpurun_out/bench_derain.err;;
     split64) timeout 600 python bench.py --steps 3 --warmup 1 --config srgan-split64 > gpurun_out/bench_split64.txt 2>gpurun_out/bench_split64.err; echo "rc=$?"; tail -1 gpurun_out/bench_split64.txt | cut -c1-900; tail -3 gpurun_out/bench_split64.err;;
     realsr) timeout 600 python bench.py --steps 3 --warmup 1 --config realsr-tiled > gpurun_out/bench_realsr.txt 2>gpurun_out/bench_realsr.err; echo "rc=$?"; tail -1 gpurun_out/bench_realsr.txt | cut -c1-400; tail -3 gpurun_out/bench_realsr.err;;
     wgradab) for t in 0 12 21 22; do VMAMBAIR_WGRAD_TILE=$t timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --skip-roofline > gpurun_out/bench_wgt$t.txt 2>gpurun_out/bench_wgt$t.err; echo "wgrad tile=$t rc=$? $(tail -1 gpurun_out/bench_wgt$t.txt | cut -c1-140)"; done;;
     pmc)    bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; echo "rc=$?"; grep -E "oss_scan" gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt | cut -c1-160;;
-    prof)   ( cd /tmp && export VMAMBAIR_CONV1X1=${PROF_CONV1X1:-mfma} && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --skip-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err" ); echo "rc=$?"; python tools/prof_summary.py gpurun_out/prof/bench_results.db gpurun_out/prof_summary.txt ${PROF_WINDOW_MS:-150}; rm -rf gpurun_out/prof; tail -1 gpurun_out/prof_bench.txt | cut -c1-200;;
+    pmcrec) bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; REPS=3 bash tools/pmc_sq.sh > gpurun_out/pmc_sq.log 2>&1; python tools/pmc_record.py gpurun_out/r03_pmc_traffic.json > gpurun_out/pmc_record.log 2>&1; echo "rc=$?"; cut -c1-400 gpurun_out/pmc_record.log;;
+    benchfp32) timeout 600 python bench.py --steps 10 --warmup 3 --dtype fp32 --no-cpu-baseline --no-secondary > gpurun_out/bench_fp32.txt 2>gpurun_out/bench_fp32.err; echo "rc=$?"; tail -1 gpurun_out/bench_fp32.txt | cut -c1-300;;
+    prof)   ( cd /tmp && export VMAMBAIR_CONV1X1=${PROF_CONV1X1:-mfma} && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --skip-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.txt" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.err" ); echo "rc=$?"; python tools/prof_summary.py gpurun_out/prof/bench_results.db gpurun_out/prof_summary.txt ${PROF_WINDOW_MS:-150}; rm -rf gpurun_out/prof; tail -1 gpurun_out/prof_bench.txt | cut -c1-200;;
   esac
 done

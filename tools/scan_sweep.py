@@ -95,8 +95,9 @@ def main():
                         torch.cuda.synchronize()
                         lib.oss_prof_enable(0)
                         vv = lib.oss_scan_last_variant(which)   # -1 = heuristic: the bucket of what it picked
-                        ms, cnt, by = collect(lib, which, vv, io)
-                        fms = collect(lib, 2, vv, io)[0] if which == 1 else 0.0
+                        bucket = vv + (16 if lib.oss_scan_last_segments(which) > 1 else 0)   # segmented launches: own bucket
+                        ms, cnt, by = collect(lib, which, bucket, io)
+                        fms = collect(lib, 2, bucket, io)[0] if which == 1 else 0.0
                         rec = {"kernel": "fwd" if which == 0 else "bwd", "shape": [B, KD, L, G], "dtype": dname,
                                "variant": vv, "segments": lib.oss_scan_last_segments(which), "launches": cnt,
                                "ms": round(ms / max(cnt, 1), 4), "finish_ms": round(fms / max(cnt, 1), 4),

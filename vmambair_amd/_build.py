@@ -100,6 +100,42 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+# ---- compiled torch boundary (csrc_host/oss_torch_host.cpp -> lib/libvmambair_torch.so) ------------------------------------
+HOST_SRC = os.path.join(HERE, "csrc_host", "oss_torch_host.cpp")
+HOST_LIB = os.path.join(LIB_DIR, "libvmambair_torch.so")
+
+
+def host_stale() -> bool:
+    if not os.path.exists(HOST_LIB):
+        return True
+    t = os.path.getmtime(HOST_LIB)
+    deps = [HOST_SRC, os.path.join(HERE, "..", "include", "vmambair_oss.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """Compile the C++ ``TORCH_LIBRARY`` layer of the scan ops (host code only: argument checks, allocation, struct fill) and link
+    it against libtorch and the in-tree C-ABI library (``$ORIGIN`` rpath: both .so files travel together)."""
+    if not force and not host_stale():
+        return HOST_LIB
+    import torch
+    from torch.utils import cpp_extension as ce
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    build(force=False)   # the library it links against
+    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}", "-Wno-unused-result",
+           *[f"-I{d}" for d in ce.include_paths()], "-I/opt/rocm/include", f"-I{os.path.join(HERE, '..', 'include')}",
+           HOST_SRC, "-o", HOST_LIB + ".tmp", f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           f"-L{LIB_DIR}", "-lvmambair_oss", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(HOST_LIB + ".tmp", HOST_LIB)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     import sys
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -115,7 +115,7 @@ int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
 }
 
 // ---- per-launch event timing (oss_prof_*) -----------------------------------------------------
-constexpr int kProfVariants = 16;
+constexpr int kProfVariants = 32;   // 0..15: the kernel variants; 16 + v: time-segmented launches of variant v
 struct ProfBucket {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0.0, bytes = 0.0, own = 0.0;
@@ -134,8 +134,9 @@ static hipEvent_t prof_event() {
 struct ProfTimer : LaunchTimer {  // begin/end bracket exactly one kernel launch
     bool on; int which, variant, io; double bytes, own; hipEvent_t e0{}, e1{};
     ProfTimer(int which_, int variant_, int io_, double bytes_, double own_ = 0.0)
-        : on(g_prof_on.load() != 0 && variant_ >= 0 && variant_ < kProfVariants), which(which_), variant(variant_),
+        : on(g_prof_on.load() != 0 && variant_ >= 0 && variant_ < 16), which(which_), variant(variant_),
           io(io_), bytes(bytes_), own(own_) {}
+    void segmented() override { if (variant < 16) variant += 16; }
     void begin(hipStream_t s) override {
         if (!on) return;
         {
@@ -222,6 +223,7 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
         case OSS_BF16: rc = scan_fwd_dispatch<bf16_t>(*p, v, sr, s); break;
         default: rc = OSS_ERR_SHAPE;
     }
+    if (g_last_fwd_segments.load() > 1) prof.segmented();   // local pass + real pass: timed as one call, in its own bucket
     prof.end(s);
     return rc;
 }

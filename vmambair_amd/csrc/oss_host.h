@@ -43,6 +43,7 @@ template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int va
 struct LaunchTimer {
     virtual void begin(hipStream_t) = 0;
     virtual void end(hipStream_t) = 0;
+    virtual void segmented() {}   // the launch about to be timed is a time-segmented one (its own profiler bucket)
     virtual ~LaunchTimer() = default;
 };
 template <typename T>

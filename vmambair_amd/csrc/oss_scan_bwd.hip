@@ -576,7 +576,8 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
         if (n_seg > 1) {
             const BwdSeg sg{carry, n_seg, cps};
             auto kc = oss_scan_bwd_carry_kernel<T, WAVES>;
-            if (timer) timer->begin(stream);
+            if (timer) { timer->segmented(); timer->begin(stream); }
+            if (g_finish_timer) g_finish_timer->segmented();
             hipLaunchKernelGGL(kc, dim3(wgs * (unsigned)(n_seg - 1)), dim3(WAVES * 64), sizeof(float) * kNB * TC, stream, p, sg, tiles);
             auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true>;
             static LdsGate gate_s;

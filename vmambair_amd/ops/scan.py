@@ -25,7 +25,7 @@ from typing import List, Optional
 
 import torch
 
-from .. import _capi
+from .. import _capi, _host
 from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
 
 
@@ -101,6 +101,10 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``.
     ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling; ``dt_weight``: ``delta`` is the rank-R factor and the
     kernels evaluate delta themselves -- see include/vmambair_oss.h."""
+    host = _host.ops()
+    if host is not None and u.is_cuda:   # compiled boundary (csrc_host/oss_torch_host.cpp): same checks, same C ABI
+        return list(host.scan_fwd(u, delta, A, B, C, D, delta_bias, bool(delta_softplus),
+                                  -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), bool(a_log_form), dt_weight))
     dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight)
     batch, dim, seqlen, dstate, _ = dims
     lib = _capi.load()
@@ -139,6 +143,18 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``.
     With ``dt_weight`` (delta computed inside the scan; needs ``dbc_into``): ``ddelta`` is ``None``, the gradient of the rank
     factor lands in the first R rows of ``dbc_into`` and an eighth entry, the (dim, R) gradient of ``dt_weight``, is returned."""
+    host = _host.ops()
+    if host is not None and u.is_cuda:   # compiled boundary: [du, ddelta, dA, dB, dC, dD, dbias, ddt_weight], empty = absent
+        r = host.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, bool(delta_softplus),
+                          -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), int(dout_row_mod), bool(a_log_form),
+                          dbc_into, dt_weight)
+        du, ddelta, dA, dB, dC, dD, dbias, ddtw = r
+        if dbc_into is not None:   # written in place (a mutated argument is not returned): the views are made here
+            rows, N = dbc_into.shape[2], A.shape[1]
+            dB, dC = dbc_into[:, :, rows - 2 * N:rows - N], dbc_into[:, :, rows - N:]
+        fused = dt_weight is not None
+        return [du, None if fused else ddelta, dA, dB, dC, dD if D is not None else None,
+                dbias if delta_bias is not None else None] + ([ddtw] if fused else [])
     dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight)
     batch, dim, seqlen, dstate, n_groups = dims
     _check(dout.dtype == u.dtype and dout.is_cuda, "dout must be a CUDA/HIP tensor of u's dtype")
