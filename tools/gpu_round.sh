@@ -19,6 +19,7 @@ for leg in $LEGS; do
     newtests3) timeout 900 python -m pytest tests/test_scan_gpu.py tests/test_train_graph_gpu.py tests/test_configs_gpu.py tests/test_block_gpu.py -m gpu -q -p no:cacheprovider --maxfail=30 -k "fused_delta or train_graph or long_sequence or set_lr or state or second_shape or block_matches" > gpurun_out/newtests3.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/newtests3.txt; grep -E "^(FAILED|ERROR)" gpurun_out/newtests3.txt | head -30;;
     hostab) timeout 300 python tools/host_overhead.py > gpurun_out/host_overhead.txt 2>/dev/null; echo "rc=$?"; cat gpurun_out/host_overhead.txt;
             for m in "c++" ctypes; do VMAMBAIR_HOST=$m timeout 300 python bench.py --steps 3 --warmup 1 --config srgan-split64 > gpurun_out/bench_split64_$m.txt 2>/dev/null; echo "host=$m rc=$?"; tail -1 gpurun_out/bench_split64_$m.txt | cut -c1-700; done;;
+    wgradovl) for v in 0 1; do VMAMBAIR_OVERLAP_WGRADS=$v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --skip-roofline > gpurun_out/bench_ovl$v.txt 2>/dev/null; echo "overlap_wgrads=$v rc=$? $(tail -1 gpurun_out/bench_ovl$v.txt | cut -c1-140)"; done;;
     segtest) timeout 600 python -m pytest tests/test_scan_gpu.py -m gpu -q -p no:cacheprovider --maxfail=60 -k "segment or reruns_are_stable or every_backward_variant or round2_backward" > gpurun_out/segtest.txt 2>&1; echo "rc=$?"; tail -4 gpurun_out/segtest.txt; grep -E "^(FAILED|ERROR)" gpurun_out/segtest.txt | head -40;;
     segsweep) # time-segmented launches on the under-filled shapes (Deraining level 0, RealSR tiles) + the finishing kernel at the headline shape
             timeout 300 python tools/scan_sweep.py --shapes "4,192,16384,4" --dtypes bf16 --fwd-variants 0,3,5,6 --bwd-variants 10,11,13 --segs 1,2,4,8,16 > gpurun_out/segsweep_derain.txt 2>&1; echo "rc=$?";

@@ -70,6 +70,15 @@ def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, ratio: in
     return (idx % n_items)[rank:total:world]
 
 
+def split_global_batch(global_batch: int, world: int) -> int:
+    """per-rank batch of a FIXED global batch (BASELINE.json configs[2]: 32 images over 1 / 2 / 4 / 8 GPUs = 32 / 16 / 8 / 4
+    each; the reference fixes ``batch_size_per_gpu`` instead, Deraining/basicsr/data/__init__.py:80-95).  The shards must
+    be equal: the gradient mean over ranks equals the whole-batch gradient only then."""
+    if global_batch <= 0 or world <= 0 or global_batch % world:
+        raise ValueError(f"global batch {global_batch} does not split evenly over {world} ranks")
+    return global_batch // world
+
+
 def reduce_loss_dict(losses: dict) -> dict:
     """``reduce_loss_dict`` (base_model.py:353-378): reduce to rank 0 and average there."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
