@@ -307,6 +307,18 @@ void oss_set_defer_finish(int on);
 size_t oss_deferred_chunks(void);
 int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chunks, oss_stream_t stream);
 
+/* Deferred weight gradients.  After oss_set_defer_wgrad(1), oss_conv1x1_wgrad and the x_proj / dt_proj products of oss_proj_wgrad
+ * (16-bit I/O) do not launch: each call records its problem (operands, partial buffer and outputs must stay alive and unread)
+ * and -- with oss_set_defer_finish(1) -- its finishing sum; oss_flush_wgrads then runs EVERY recorded product as one grouped
+ * launch (the descriptor table, oss_deferred_wgrad_table_bytes() bytes, goes through host_table -- pinned, kept alive when
+ * the call is captured into a hipGraph -- to device_table).  Call it before oss_flush_finishes.  Results are bit-identical to
+ * the one-launch-per-product form: same tiles, same partial layout, same summation order.
+ * oss_set_defer_wgrad(0/1) also drops whatever was recorded and not flushed. */
+void oss_set_defer_wgrad(int on);
+size_t oss_deferred_wgrads(void);
+size_t oss_deferred_wgrad_table_bytes(void);
+int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes, oss_stream_t stream);
+
 /* Adam + EMA of the training step (MambaSISR_model.py:120-147: torch.optim.Adam without amsgrad / weight decay,
  * then ema = decay * ema + (1 - decay) * param) as one elementwise launch over a chunk table in device memory:
  * one entry per <= OSS_ADAM_CHUNK consecutive elements of one parameter tensor (all float; ema may be NULL).

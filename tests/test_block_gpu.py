@@ -100,3 +100,39 @@ def test_fused_adam_ema_matches_torch_adam():
     for p, q, e, f in zip(pa, pb, ema_a, ema_b):
         assert_close(p, q, 1e-5, 1e-6, "param")
         assert_close(e, f, 1e-5, 1e-6, "ema")
+
+
+@pytest.mark.parametrize("dim,hw", [(48, (32, 24)), (96, (64, 64))])
+def test_grouped_weight_gradient_launch_is_bit_identical(dim, hw):
+    """weight-gradient products recorded during the backward and run as ONE grouped launch (oss_flush_wgrads) vs one launch per
+    product: same tiles, same partials, same finishing sums -> torch.equal on every parameter gradient and on dx"""
+    from vmambair_amd import _capi, ops
+    torch.manual_seed(0)
+    m = MamberBlock(dim, variant="srgan").to(DEV)
+    x = torch.randn(2, dim, *hw, device=DEV)
+    gy = torch.randn(2, dim, *hw, device=DEV)
+    lib = _capi.load()
+    res = []
+    for grouped in (False, True, True):
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        with ops.deferred_finishes(wgrads=grouped):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(xi)
+            y.backward(gy)
+            n_rec = ops.pending_wgrads()
+            assert (n_rec > 0) == grouped, "the 1x1 / projection weight-gradient products are recorded only in grouped mode"
+            if grouped:
+                wt = ops.WgradTable(DEV, ops.pending_wgrad_table_bytes())
+                ops.flush_wgrads(wt)
+                assert ops.pending_wgrads() == 0
+            ft = ops.FinishTable(DEV, ops.pending_finish_chunks())
+            ops.flush_finishes(ft)
+        torch.cuda.synchronize()
+        res.append((xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, n_rec))
+    assert res[1][2] >= 5, "in_conv, out_conv, project_in, project_out and the two projection products of one block"
+    for other in (res[1], res[2]):
+        assert torch.equal(res[0][0], other[0])
+        for k, g in res[0][1].items():
+            assert torch.equal(g, other[1][k]), k
+    assert lib.oss_deferred_wgrads() == 0

@@ -78,7 +78,8 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
            "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
-           "oss_flush_finishes", "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version"]
+           "oss_flush_finishes", "oss_set_defer_wgrad", "oss_deferred_wgrads", "oss_deferred_wgrad_table_bytes", "oss_flush_wgrads",
+           "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version"]
 
 _lib = None
 
@@ -191,6 +192,12 @@ def load():
     lib.oss_deferred_chunks.restype = C.c_size_t
     lib.oss_flush_finishes.restype = C.c_int
     lib.oss_flush_finishes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.oss_set_defer_wgrad.restype = None
+    lib.oss_set_defer_wgrad.argtypes = [C.c_int]
+    lib.oss_deferred_wgrads.restype = C.c_size_t
+    lib.oss_deferred_wgrad_table_bytes.restype = C.c_size_t
+    lib.oss_flush_wgrads.restype = C.c_int
+    lib.oss_flush_wgrads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_prof_marker.restype = C.c_int

@@ -57,6 +57,18 @@ void defer_sum(const float *src, int K, size_t stride, size_t V, float *dst0, si
         j += n;
     }
 }
+// ---- deferred weight gradients (grouped launch) -------------------------------------------------------------------------
+static std::atomic<int> g_defer_wgrad{0};
+static std::vector<unsigned char> g_wgrad_descs;   // recorded descriptors, wgrad_desc_bytes() each
+static std::vector<unsigned> g_wgrad_blocks;       // workgroups of each
+bool defer_wgrad() { return g_defer_wgrad.load() != 0; }
+void defer_wgrad_push(const void *desc, size_t bytes, unsigned blocks) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(desc);
+    g_wgrad_descs.insert(g_wgrad_descs.end(), p, p + bytes);
+    g_wgrad_blocks.push_back(blocks);
+}
+
 int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups, int elem_bytes) {
     (void)dstate; (void)elem_bytes;
     const int rows_per_group = dim / n_groups;
@@ -427,6 +439,53 @@ int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, i
     if (!h || !dout || !dh) return OSS_ERR_NULL;
     if (batch <= 0 || half_elems == 0) return OSS_ERR_SHAPE;
     return gelu_gate_bwd(io, h, dout, dh, batch, half_elems, h_batch_stride, dout_batch_stride, reinterpret_cast<hipStream_t>(stream));
+}
+
+void oss_set_defer_wgrad(int on) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_defer_wgrad.store(on ? 1 : 0);
+    g_wgrad_descs.clear();
+    g_wgrad_blocks.clear();
+}
+size_t oss_deferred_wgrads(void) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    return g_wgrad_blocks.size();
+}
+size_t oss_deferred_wgrad_table_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    size_t blocks = 0;
+    for (unsigned b : g_wgrad_blocks) blocks += b;
+    // descriptors (padded to 256 bytes) + one 16-bit problem index per workgroup
+    return ((g_wgrad_descs.size() + 255) & ~(size_t)255) + 2 * blocks;
+}
+int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes, oss_stream_t stream) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    const size_t n = g_wgrad_blocks.size();
+    if (n == 0) return 0;
+    if (!host_table || !device_table) return OSS_ERR_NULL;
+    if (n > 65535) return OSS_ERR_SHAPE;
+    const size_t db = wgrad_desc_bytes();
+    const size_t desc_bytes = (g_wgrad_descs.size() + 255) & ~(size_t)255;
+    size_t total = 0;
+    for (unsigned b : g_wgrad_blocks) total += b;
+    if (desc_bytes + 2 * total > capacity_bytes) return OSS_ERR_WORKSPACE;
+    if (total > 0x7fffffffu) return OSS_ERR_SHAPE;
+    const int io = wgrad_desc_io(g_wgrad_descs.data());
+    unsigned first = 0;
+    uint16_t *map = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(host_table) + desc_bytes);
+    for (size_t i = 0; i < n; ++i) {
+        if (wgrad_desc_io(g_wgrad_descs.data() + i * db) != io) return OSS_ERR_SHAPE;   // one I/O type per flush
+        wgrad_desc_set_first_block(g_wgrad_descs.data() + i * db, first);
+        for (unsigned k = 0; k < g_wgrad_blocks[i]; ++k) map[first + k] = (uint16_t)i;
+        first += g_wgrad_blocks[i];
+    }
+    std::memcpy(host_table, g_wgrad_descs.data(), g_wgrad_descs.size());
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const hipError_t e = hipMemcpyAsync(device_table, host_table, desc_bytes + 2 * total, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    g_wgrad_descs.clear();
+    g_wgrad_blocks.clear();
+    return wgrad_grouped_launch(io, device_table, reinterpret_cast<unsigned char *>(device_table) + desc_bytes, (unsigned)total, s);
 }
 
 void oss_set_defer_finish(int on) {

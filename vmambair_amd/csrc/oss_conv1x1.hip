@@ -630,13 +630,16 @@ oss_conv1x1_pairk_kernel(const T *__restrict__ x, const float *__restrict__ w, c
 // (m / Mh) gs_hi + (m % Mh) gsm, so that one problem can take its rows from two places (the two scan
 // directions that share a flattening, oss_proj.hip).
 constexpr int kWgradSlab = 512;   // pixels per partial product
+// The body is shared by the one-problem launch and the grouped launch (oss_conv1x1_wgrad_grouped_kernel): `slab` of `nslabs`,
+// `by` = batch * G + group, `bz` = group of four 32 x 32 tiles -- the launch coordinates of the one-problem grid.
 template <typename T>
-__global__ void __launch_bounds__(256)
-oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
-                         int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
-                         int64_t gs_hi, int NB /* N, or N + 1: a virtual all-ones row of x whose column of dW is dbias */) {
+__device__ __forceinline__ void
+wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
+           int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
+           int64_t gs_hi, int NB /* N, or N + 1: a virtual all-ones row of x whose column of dW is dbias */,
+           int slab, int nslabs, int by, int bz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y / G, g = blockIdx.y - b * G, slab = blockIdx.x;
+    const int b = by / G, g = by - b * G;
     const int pbeg = slab * kWgradSlab, pend = min(P, pbeg + kWgradSlab);
     const int col = lane & 31, kg = lane >> 5;
     const int mt = (M + 31) >> 5, nt = (NB + 31) >> 5;
@@ -644,13 +647,13 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
     const T *xb = x + b * xsb + g * xsg;
     // one partial vector per (batch, slab): [G * M rows in DESTINATION order][N], then (NB > N) the M dbias sums
     const size_t pvec = (size_t)G * M * N + (NB > N ? M : 0);
-    float *pb = part + (size_t)(b * gridDim.x + slab) * pvec;
+    float *pb = part + (size_t)(b * nslabs + slab) * pvec;
     const short kOne = (short)from_f32<T>(1.0f).v;  // 1.0 in the I/O type
     const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0}, ones8 = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
     const bool aligned = (((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(xb)) & 15u) == 0) &&
                          (gsm % 8 == 0) && (xsn % 8 == 0) && (pbeg % 8 == 0) && (gs_hi % 8 == 0);
     {
-        const int tile = blockIdx.z * 4 + wave;  // one 32 x 32 tile of dW per wave
+        const int tile = bz * 4 + wave;  // one 32 x 32 tile of dW per wave
         if (tile >= mt * nt) return;
         const int m0 = (tile / nt) * 32, n0 = (tile % nt) * 32;
         const int mrow = m0 + col, nrow = n0 + col;
@@ -800,6 +803,42 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
             }
         }
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
+                         int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
+                         int64_t gs_hi, int NB) {
+    wgrad_body<T>(dy, x, part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y,
+                  (int)blockIdx.z);
+}
+
+// Grouped launch: ALL weight-gradient products of a backward pass as one kernel.  Nobody needs a weight gradient before the
+// optimizer, yet each one-problem launch is a single under-filled round of <= ~200 workgroups whose 10 us are latency, not
+// work (302 launches = 3.2 ms of a 40 ms step, profiles/r03_rocprof_bench_steady_state_v1.txt).  With oss_set_defer_wgrad(1)
+// conv1x1_wgrad() only records its problem; oss_flush_wgrads() copies the descriptor table to the device and runs this
+// kernel over every recorded problem's workgroups back to back (block -> problem through a 16-bit table), so the chip is
+// full for the whole launch and the operands stream at memory speed.  Same per-problem arithmetic, same partial layout, same
+// finishing sums: bit-identical weight gradients.
+struct WgradDesc {
+    const void *dy, *x;
+    float *part;
+    int64_t gsb, gsm, xsb, xsn, gsg, xsg, gs_hi;
+    int M, N, P, G, Mh, NB, slabs, bgs /* batch * G */;
+    unsigned first_block;
+    int io;
+};
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint16_t *__restrict__ block_problem) {
+    const WgradDesc d = descs[block_problem[blockIdx.x]];
+    const unsigned local = blockIdx.x - d.first_block;
+    const int slab = (int)(local % (unsigned)d.slabs);
+    const unsigned r = local / (unsigned)d.slabs;
+    const int by = (int)(r % (unsigned)d.bgs), bz = (int)(r / (unsigned)d.bgs);
+    wgrad_body<T>(reinterpret_cast<const T *>(d.dy), reinterpret_cast<const T *>(d.x), d.part, d.M, d.N, d.P, d.gsb, d.gsm, d.xsb,
+                  d.xsn, d.G, d.gsg, d.xsg, d.Mh, d.gs_hi, d.NB, slab, d.slabs, by, bz);
 }
 
 // out[j] = sum over the nslab partial vectors (fixed order), j < nw -> dw[j], else db[j - nw].
@@ -1122,6 +1161,14 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
     const int tiles = ((M + 31) / 32) * ((NB + 31) / 32);
     dim3 grid(slabs, B * G, (tiles + 3) / 4);
     const int tmode = wgrad_tile_mode();
+    if (defer_wgrad() && !tmode && (io == OSS_BF16 || io == OSS_F16) && (size_t)slabs * B * G * ((tiles + 3) / 4) < (1u << 24)) {
+        WgradDesc d;
+        d.dy = dy; d.x = x; d.part = part;
+        d.gsb = gsb; d.gsm = gsm; d.xsb = xsb; d.xsn = xsn; d.gsg = gsg; d.xsg = xsg; d.gs_hi = gs_hi;
+        d.M = M; d.N = N; d.P = P; d.G = G; d.Mh = Mh; d.NB = NB; d.slabs = slabs; d.bgs = B * G;
+        d.first_block = 0; d.io = (int)io;
+        defer_wgrad_push(&d, sizeof(d), (unsigned)(slabs * B * G * ((tiles + 3) / 4)));
+    } else
     if (tmode && (io == OSS_BF16 || io == OSS_F16)) {
         if (io == OSS_BF16)
             wgrad_tiles_launch<bf16_t>(tmode, reinterpret_cast<const bf16_t *>(dy), reinterpret_cast<const bf16_t *>(x), part, B, M, N, P,
@@ -1150,5 +1197,23 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
                            pvec, nw);
     return (int)hipGetLastError();
 }
+
+// ---- grouped weight gradients: flush (oss_capi.hip keeps the recorded descriptors as raw bytes + block counts) -----------------
+size_t wgrad_desc_bytes() { return sizeof(WgradDesc); }
+// descs: n descriptors in host memory with first_block filled; d_descs / d_map: their device copies (already queued on s)
+int wgrad_grouped_launch(int io, const void *d_descs, const void *d_map, unsigned total_blocks, hipStream_t s) {
+    if (total_blocks == 0) return 0;
+    if (io == OSS_BF16)
+        hipLaunchKernelGGL(oss_conv1x1_wgrad_grouped_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, s,
+                           reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map));
+    else if (io == OSS_F16)
+        hipLaunchKernelGGL(oss_conv1x1_wgrad_grouped_kernel<f16_t>, dim3(total_blocks), dim3(256), 0, s,
+                           reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map));
+    else
+        return OSS_ERR_SHAPE;
+    return (int)hipGetLastError();
+}
+void wgrad_desc_set_first_block(void *desc, unsigned first) { reinterpret_cast<WgradDesc *>(desc)->first_block = first; }
+int wgrad_desc_io(const void *desc) { return reinterpret_cast<const WgradDesc *>(desc)->io; }
 
 }  // namespace oss

@@ -95,6 +95,14 @@ int gelu_gate_fwd(oss_dtype io, const void *h, void *out, int B, size_t n, int64
 int gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int B, size_t n, int64_t hsb, int64_t gsb, hipStream_t s);
 // oss_set_defer_finish(1): the launchers do not run their finishing kernels; they register the reduction instead
 // (out[j] = sum_{k<K} src[k * stride + j], j < n0 -> dst0[j], else dst1[j - n0]) and oss_flush_finishes runs them all
+// oss_set_defer_wgrad(1): conv1x1_wgrad() records its problem instead of launching; oss_flush_wgrads runs them all as ONE
+// grouped launch (oss_conv1x1.hip: oss_conv1x1_wgrad_grouped_kernel)
+bool defer_wgrad();
+void defer_wgrad_push(const void *desc, size_t bytes, unsigned blocks);
+size_t wgrad_desc_bytes();
+int wgrad_grouped_launch(int io, const void *d_descs, const void *d_map, unsigned total_blocks, hipStream_t s);
+void wgrad_desc_set_first_block(void *desc, unsigned first);
+int wgrad_desc_io(const void *desc);
 bool defer_finish();
 void defer_sum(const float *src, int K, size_t stride, size_t V, float *dst0, size_t n0, float *dst1);
 int sum_partials_multi(const oss_sum_chunk *chunks, int n_chunks, hipStream_t s);

@@ -44,20 +44,35 @@ _DEFER_KEEP: Optional[list] = None
 _DEFER_OUTS: Optional[list] = None
 
 
+#: ``VMAMBAIR_DEFER_WGRAD=0`` keeps one launch per weight-gradient product (A-B timing).  Default: inside ``deferred_finishes()``
+#: the 1x1-conv / projection weight-gradient products are only RECORDED by the library and ``flush_wgrads`` runs all of them as
+#: one grouped launch at the end of the backward (include/vmambair_oss.h: oss_set_defer_wgrad).
+DEFER_WGRADS = os.environ.get("VMAMBAIR_DEFER_WGRAD", "1") == "1"
+
+
 @contextlib.contextmanager
-def deferred_finishes():
-    """Defer every partial-sum finishing launch issued inside the context; the caller MUST call ``flush_finishes`` (with the
-    context still open) before any weight gradient is read."""
+def deferred_finishes(wgrads: Optional[bool] = None):
+    """Defer every partial-sum finishing launch issued inside the context -- and (``wgrads``, default ``DEFER_WGRADS``) the
+    weight-gradient products themselves; the caller MUST call ``flush_wgrads`` and then ``flush_finishes`` (with the context
+    still open) before any weight gradient is read."""
     global _DEFER_KEEP, _DEFER_OUTS
     lib = _capi.load()
     assert _DEFER_KEEP is None, "deferred_finishes() does not nest"
     _DEFER_KEEP, _DEFER_OUTS = [], []
     lib.oss_set_defer_finish(1)
+    lib.oss_set_defer_wgrad(1 if (DEFER_WGRADS if wgrads is None else wgrads) else 0)
     try:
         yield
     finally:
         lib.oss_set_defer_finish(0)
+        lib.oss_set_defer_wgrad(0)
         _DEFER_KEEP = _DEFER_OUTS = None
+
+
+def _keep_operands(*tensors) -> None:
+    """operands of a RECORDED (not yet launched) weight-gradient product: alive until ``flush_wgrads`` has queued the launch"""
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.extend(t for t in tensors if t is not None)
 
 
 def _keep(scratch: torch.Tensor, *outs) -> None:
@@ -98,6 +113,39 @@ class FinishTable:
         self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.copied: Optional[torch.cuda.Event] = None   # the last eager host-to-device copy out of ``host``
+
+
+class WgradTable:
+    """pinned host + device buffers for the descriptor table of ``oss_flush_wgrads`` (allocated outside any stream capture)"""
+
+    def __init__(self, device, nbytes: int):
+        self.capacity = max(256, int(nbytes))
+        self.host = torch.empty(self.capacity, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(self.capacity, dtype=torch.uint8, device=device)
+        self.copied: Optional[torch.cuda.Event] = None
+
+
+def pending_wgrad_table_bytes() -> int:
+    return int(_capi.load().oss_deferred_wgrad_table_bytes())
+
+
+def pending_wgrads() -> int:
+    return int(_capi.load().oss_deferred_wgrads())
+
+
+def flush_wgrads(table: WgradTable) -> None:
+    """run every recorded weight-gradient product as ONE grouped launch on the current stream (before ``flush_finishes``:
+    the finishing sums read the partials this launch writes)"""
+    lib = _capi.load()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if table.copied is not None and not capturing:
+        table.copied.synchronize()   # the previous copy out of the pinned table has executed (cf. flush_finishes)
+    with torch.cuda.device(table.dev.device):
+        _capi.check(lib.oss_flush_wgrads(table.host.data_ptr(), table.dev.data_ptr(), table.capacity,
+                                         torch.cuda.current_stream().cuda_stream), "oss_flush_wgrads")
+        if not capturing:
+            table.copied = torch.cuda.Event()
+            table.copied.record()
 
 
 def pending_finish_chunks() -> int:

@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from .. import _capi
-from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
+from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_operands, _keep_views, _planes, _ptr)  # noqa: F401
 from .scan import merge4, selective_scan_bwd, selective_scan_fwd
 
 
@@ -144,6 +144,7 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
                                            dwx.data_ptr(), _ptr(dwdt), part.data_ptr(), B, D, Cc, R, L,
                                            torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
             _keep(part, dwx, dwdt)
+            _keep_operands(x2, xdbl, dxdbl, ddts)
     return [dwx, dwdt]
 
 

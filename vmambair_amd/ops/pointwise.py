@@ -9,7 +9,8 @@ from typing import List, Optional
 import torch
 
 from .. import _capi
-from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
+from ._common import (_keep_operands,
+                      _DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
 
 
 def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -55,6 +56,7 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
                                               Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
                                               torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
             _keep(part, dw, db)
+            _keep_operands(dy, x)
         _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
                                           dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
     return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]

@@ -129,6 +129,7 @@ class GraphedTrainStep:
                 self._leaf_sets.append({n: self._shadow_map.get(n, named[n]).detach().requires_grad_() for n in self._names})
             self._shadow_tmp = [torch.zeros_like(m) for m in self._masters]
         self.ftables = [None] * self.nmicro
+        self.wtables = [None] * self.nmicro
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
@@ -153,6 +154,12 @@ class GraphedTrainStep:
                 lost = _ops.orphaned_deferred_outputs(leaves)
                 if lost:
                     raise RuntimeError(f"{lost} deferred weight gradients were copied before the flush (see ops.py CONTRACT)")
+            if _ops.pending_wgrads():   # the recorded weight-gradient products, as ONE grouped launch (ops/_common.py)
+                nb = _ops.pending_wgrad_table_bytes()
+                if self.wtables[slot] is None or self.wtables[slot].capacity < nb:
+                    assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient table must exist before the capture"
+                    self.wtables[slot] = _ops.WgradTable(self.device, nb)
+                _ops.flush_wgrads(self.wtables[slot])
             n = _ops.pending_finish_chunks()
             if self.ftables[slot] is None or self.ftables[slot].capacity < n:   # first (eager, warm-up) step: sizes the table
                 assert not torch.cuda.is_current_stream_capturing(), "the finish table must exist before the capture"
@@ -342,13 +349,13 @@ class GraphedTrainStep:
 
     def _stash(self):
         if self._active is not None:
-            self._shapes[self._active] = (self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables)
+            self._shapes[self._active] = (self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables, self.wtables)
 
     def _activate(self, key):
         if key == self._active:
             return
         self._stash()
-        self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables = self._shapes[key]
+        self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables, self.wtables = self._shapes[key]
         self._active = key
 
     @property
@@ -365,7 +372,7 @@ class GraphedTrainStep:
                 raise RuntimeError("GraphedTrainStep was captured for another input shape; construct it with multi_shape=True "
                                    "to keep one graph per shape (progressive patch schedule)")
             self._stash()
-            self.graph_fb, self.ftables = None, [None] * self.nmicro
+            self.graph_fb, self.ftables, self.wtables = None, [None] * self.nmicro, [None] * self.nmicro
         self._active = key
         self.static_lq = lq.clone()
         self.static_gt = gt.clone()
