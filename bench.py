@@ -133,11 +133,16 @@ def bench_realsr_tiled(args):
         n0 = drv.tiled.tiles_run
         if graph:
             lib.oss_prof_reset()
+        mark = graph and bt == 1   # kernel-trace markers around the tile-by-tile graph leg (tools/prof_summary.py)
+        if mark:
+            lib.oss_prof_marker(1, torch.cuda.current_stream().cuda_stream)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = drv.enhance_tensor(img)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
+        if mark:
+            lib.oss_prof_marker(2, torch.cuda.current_stream().cuda_stream)
         tiles = (drv.tiled.tiles_run - n0) // args.steps
         assert tuple(out.shape) == (1, 3, 2048, 2048) and torch.isfinite(out.float()).all()
         if ref is None:

@@ -20,7 +20,7 @@ def main():
     if mb and me:
         rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
                                 "from kernels where start>=? and end<=? group by name order by 3 desc", (mb, me)))
-        steps = sum(r[1] for r in rows if "oss_adam_tick_kernel" in r[0]) or 1
+        steps = sum(r[1] for r in rows if "oss_adam_tick_kernel" in r[0]) or (int(sys.argv[4]) if len(sys.argv) > 4 else 1)
         tot = sum(r[2] for r in rows)
         n = sum(r[1] for r in rows)
         wall = (me - mb) / 1e6

@@ -154,6 +154,9 @@ def pending_finish_chunks() -> int:
 
 def flush_finishes(table: FinishTable) -> None:
     lib = _capi.load()
+    if int(lib.oss_deferred_wgrads()):
+        raise RuntimeError("weight-gradient products are still recorded: call flush_wgrads before flush_finishes "
+                           "(the finishing sums read the partials the grouped launch writes)")
     capturing = torch.cuda.is_current_stream_capturing()
     if table.copied is not None and not capturing:
         # oss_flush_finishes rewrites the pinned table and queues an asynchronous copy out of it: in eager mode the copy
