@@ -547,6 +547,11 @@ static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, Lau
     return launch_finish<T>(p, ws, wdD, wdb, stream);
 }
 
+#ifndef OSS_CARRY_WAVES
+#define OSS_CARRY_WAVES 0   // 0 = the main kernel's row tile
+#endif
+constexpr int kCarryWaves = OSS_CARRY_WAVES;
+
 // round-2 kernel (oss_scan_bwd_v2.h): lane-resident per-state scalars, register-prefetched tiles, one barrier per state
 template <typename T, int WAVES, int NBB, int MINW, bool FD = false>
 static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t stream, LaunchTimer *timer) {
@@ -575,10 +580,16 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     if constexpr (!FD) {
         if (n_seg > 1) {
             const BwdSeg sg{carry, n_seg, cps};
-            auto kc = oss_scan_bwd_carry_kernel<T, WAVES>;
+            // the carry pass is per ROW (nothing is summed over rows), so its row tile is free: 4-row workgroups (three times the
+            // workgroups, several per CU) measured SLOWER than the main kernel's tile -- u:(4,192,16384) 0.355 against 0.340 ms for
+            // the whole call -- because every workgroup stages the group's C rows again
+            constexpr int CW = kCarryWaves > 0 ? kCarryWaves : WAVES;
+            const int ctiles = (rows_per_group + CW - 1) / CW;
+            auto kc = oss_scan_bwd_carry_kernel<T, CW>;
             if (timer) { timer->segmented(); timer->begin(stream); }
             if (g_finish_timer) g_finish_timer->segmented();
-            hipLaunchKernelGGL(kc, dim3(wgs * (unsigned)(n_seg - 1)), dim3(WAVES * 64), sizeof(float) * kNB * TC, stream, p, sg, tiles);
+            hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_seg - 1))), dim3(CW * 64), sizeof(float) * kNB * TC,
+                               stream, p, sg, ctiles);
             auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true>;
             static LdsGate gate_s;
             if (const int e = gate_s.ensure(reinterpret_cast<const void *>(km), smem)) return e;
