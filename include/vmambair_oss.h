@@ -97,6 +97,14 @@ typedef struct {
      * (cus/selective_scan_fwd_kernel.cuh:101-102).  Ignored by oss_scan_bwd (which has its own workspace). */
     void *workspace;
     size_t workspace_bytes;
+    /* Optional lane states (round 3): oss_scan_lane_state_floats() floats, layout [batch][dim][dstate][L8] with
+     * L8 = round_up(ceil(seqlen / 8), 64): entry k of a (batch, row, state) line is the state h ENTERING scan steps 8k .. 8k+7
+     * (h after step 8k - 1; 0 for k = 0).  oss_scan_fwd writes them when hs != NULL (a by-product of its second pass);
+     * oss_scan_bwd given the same buffer in f.hs reads them instead of re-running the forward recurrence and one lane scan per
+     * state (round-2 kernels, dstate <= 64, not the fused-delta form) -- same gradients to fp32 round-off.  NULL = recompute
+     * from `x`, as the reference's backward does (cus/selective_scan_bwd_kernel.cuh:184-186).  The torch layers keep the
+     * buffer in the tail of the opaque `x` tensor's storage, so no caller-visible signature changes. */
+    float *hs;
 } oss_scan_fwd_params;
 
 /* Mirrors SSMParamsBwd (selective_scan.h:68-90). */
@@ -139,6 +147,7 @@ int oss_scan_num_chunks(int seqlen);
 
 /* Replaces selective_scan_fwd_cuda<1, input_t, float> (cus/selective_scan_fwd_kernel.cuh:174-207). */
 size_t oss_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups);   /* 0 when seqlen <= 256 */
+size_t oss_scan_lane_state_floats(int batch, int dim, int seqlen, int dstate);                    /* size of `hs` */
 int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream);
 
 /* Replaces selective_scan_bwd_cuda<1, input_t, float> (cus/selective_scan_bwd_kernel.cuh:275-310)
@@ -164,6 +173,8 @@ int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
  * oss_scan_last_segments: what the last call used (1 = unsegmented). */
 void oss_scan_set_segments(int fwd_segments, int bwd_segments);
 int oss_scan_last_segments(int which /* 0 fwd, 1 bwd */);
+/* 1 when the last oss_scan_bwd call ran the kernels that load the forward pass's lane states (f.hs), else 0 */
+int oss_scan_last_lane_states(void);
 
 /* Depth-wise 3x3 convolution, stride 1, zero padding 1, of the OSS block: SS2D_1.conv2d
  * (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:286-294) and the EFFN dwconv (:209); both are

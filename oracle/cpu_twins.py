@@ -149,7 +149,7 @@ def install():
         invwh_y = inv[:, 1].reshape(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
         return (out[:, 0] + inv[:, 0] + wh_y + invwh_y).view(B, D, H, W)
 
-    def core_fwd(x, wx, wdt, A_logs, Ds, dt_bias):
+    def core_fwd(x, wx, wdt, A_logs, Ds, dt_bias, want_hs=False):
         B, D, H, W = x.shape
         R = wdt.shape[2]
         xf = x.float()
@@ -159,9 +159,9 @@ def install():
             xdbl = torch.cat([torch.einsum("bjdl,jcd->bjcl", x2, wx[0:2].float()),
                               torch.einsum("bjdl,jcd->bjcl", x2, wx[2:4].float())], dim=1)
             dts = torch.einsum("bkrl,kdr->bkdl", xdbl[:, :, :R], wdt.float()).reshape(B, 4 * D, H * W)
-        return [y, x2.to(x.dtype), xdbl.to(x.dtype), dts.to(x.dtype), torch.empty(0)]
+        return [y, x2.to(x.dtype), xdbl.to(x.dtype), dts.to(x.dtype), torch.empty(0), torch.empty(0)]
 
-    def core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias):
+    def core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias, lane_states=None):
         B, _, D, L = x2.shape
         H, W = dy.shape[2], dy.shape[3]
         leaves = [t.detach().float().requires_grad_() for t in (x2[:, 0].reshape(B, D, H, W), wx, wdt, A_logs, Ds, dt_bias)]

@@ -826,3 +826,107 @@ def test_compiled_and_ctypes_boundaries_agree(itype):
     assert a[4][5] is None and a[4][6] is None, "absent D / delta_bias come back as None through both boundaries"
     # dB / dC of the in-place form are views of dbc_into's last rows in both
     assert a[2][3].data_ptr() == a[3][:, :, R:R + N].data_ptr() and a[2][4].data_ptr() == a[3][:, :, R + N:].data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# lane states (round 3): the forward pass saves the state entering every 8-step block, the backward loads it instead of
+# re-running the forward recurrence (the reference recomputes from the chunk state, cus/selective_scan_bwd_kernel.cuh:184-202)
+# ------------------------------------------------------------------------------------------------
+def _fwd_bwd_with_lane_states(cpu_inputs, softplus, fv=-1, bv=-1, segs=(-1, -1), **kw):
+    lib = _capi.load()
+    lib.oss_scan_set_variant(fv, bv)
+    lib.oss_scan_set_segments(*segs)
+    try:
+        dv = to_dev(cpu_inputs)
+        u, delta, A, B, C, D, bias, dout = dv
+        fkw = {k: v for k, v in kw.items() if k != "dout_row_mod"}
+        if "dout_row_mod" in kw:
+            dout = dout[:, :kw["dout_row_mod"]].contiguous()
+        out, x, hs = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, softplus, 1, want_hs=True, **fkw)
+        g_hs = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x, softplus, 1, hs=hs, **kw)
+        used = lib.oss_scan_last_lane_states()
+        g_re = vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x, softplus, 1, **kw)
+        assert lib.oss_scan_last_lane_states() == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.oss_scan_set_variant(-1, -1)
+        lib.oss_scan_set_segments(-1, -1)
+    return out, x, hs, g_hs, g_re, used
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("seqlen", [300, 1024, 2085, 4096 + 3])
+@pytest.mark.parametrize("fv,bv", [(-1, -1), (0, 10), (3, 11), (6, 12), (5, 13), (1, 10), (2, 11), (4, 13)])
+def test_backward_from_saved_lane_states_matches_oracle(itype, seqlen, fv, bv):
+    """every forward variant writes the lane states (chunk lengths 256 / 512 / 1024, 4 / 8 / 16 steps per lane, several rows per
+    wave), every round-2 backward variant reads them: all seven gradients against the oracle at the reference's tolerances, and
+    against the recomputing kernels to fp32 round-off"""
+    if (fv, bv) != (-1, -1) and (itype == torch.float16 or seqlen == 1024):
+        pytest.skip("forced variants: f32 / bf16 at the ragged lengths")
+    cpu = make_inputs(2, 26, 16, 2, seqlen, itype)
+    out, x, hs, g_hs, g_re, used = _fwd_bwd_with_lane_states(cpu, True, fv, bv)
+    u, delta, A, B, C, D, bias, dout = cpu
+    assert used == 1, "the lane-state kernels did not run"
+    assert hs.numel() == 2 * 26 * 16 * (((seqlen + 7) // 8 + 63) // 64 * 64)
+    # the saved entries themselves: h entering block k = the oracle's state after step 8k - 1 (chunk = 8 -> one state per block)
+    _, ref_x8 = oss_oracle.scan_fwd(u, delta, A, B, C, D, bias, True, chunk=8)
+    L8 = (seqlen + 7) // 8
+    stride = hs.numel() // (2 * 26 * 16)
+    got = hs.view(2, 26, 16, stride)[..., 1:L8].cpu()                       # entries 1 .. L8-1 = states after blocks 0 .. L8-2
+    want = ref_x8[:, :, :L8 - 1, 1::2].permute(0, 1, 3, 2)
+    assert_close(got, want, 6e-4, 2e-3, "lane states")
+    assert float(hs.view(2, 26, 16, stride)[..., 0].abs().max()) == 0.0, "the state entering step 0 is 0"
+    ref = oss_oracle.scan_bwd(u, delta, A, B, C, D, bias, dout, None, True)
+    rtol, atol = TOL[itype]
+    tols = [(rtol * 2, atol * 2), (rtol * 5, atol * 10), (RTOLW, ATOLW * 5), (rtol, atol), (rtol, atol), (RTOLW, ATOLW), (RTOLW, ATOLW)]
+    for n, got_, re_, want_, (rt, at) in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"], g_hs, g_re, ref, tols):
+        if n in ("dA", "dD", "ddelta_bias"):
+            at = max(at, (2e-5 if itype == torch.float32 else 2e-3) * float(want_.abs().max()))
+        assert_close(got_, want_, rt, at, n)
+        sc = float(re_.float().abs().max())
+        assert_close(got_, re_, 1e-4 if itype == torch.float32 else 2e-2, (2e-5 if itype == torch.float32 else 8e-3) * sc + 1e-7,
+                     n + ": saved vs recomputed forward states")
+
+
+@pytest.mark.parametrize("segs", [(1, 1), (3, 4), (64, 64)])
+def test_lane_states_with_time_segments_and_the_omni_form(segs):
+    """segmented forward (real pass) writes them, segmented backward reads them; time-mirrored groups index them by SCAN position"""
+    K, N, Bsz, rows, L = 4, 16, 2, 12, 3000
+    g = torch.Generator().manual_seed(21)
+    x2 = torch.randn(Bsz, 2 * rows, L, generator=g)
+    delta = 0.5 * torch.rand(Bsz, K * rows, L, generator=g)
+    A = -0.5 * torch.rand(K * rows, N, generator=g)
+    Bm, Cm = torch.randn(Bsz, K, N, L, generator=g), torch.randn(Bsz, K, N, L, generator=g)
+    D, bias = torch.randn(K * rows, generator=g), 0.5 * torch.rand(K * rows, generator=g)
+    dout = torch.randn(Bsz, 2 * rows, L, generator=g)
+
+    def mirror(t, per):
+        t = t.clone()
+        t[:, 2 * per:] = t[:, 2 * per:].flip(-1)
+        return t
+    out, x, hs, g_hs, g_re, used = _fwd_bwd_with_lane_states((x2, delta, A, Bm, Cm, D, bias, dout), True, segs=segs,
+                                                             rev_group_start=2, u_row_mod=2 * rows, dout_row_mod=2 * rows)
+    assert _capi.load().oss_scan_last_segments(1) >= 1
+    assert used == 1
+    u4, g4 = mirror(x2.repeat(1, 2, 1), rows), mirror(dout.repeat(1, 2, 1), rows)
+    ref_out, _ = oss_oracle.scan_fwd(u4, mirror(delta, rows), A, mirror(Bm, 1), mirror(Cm, 1), D, bias, True, chunk=256)
+    ref = oss_oracle.scan_bwd(u4, mirror(delta, rows), A, mirror(Bm, 1), mirror(Cm, 1), D, bias, g4, None, True)
+    assert_close(out, mirror(ref_out, rows), 6e-4, 2e-3, "out")
+    assert_close(g_hs[0], mirror(ref[0], rows), 1.2e-3, 4e-3, "du")
+    assert_close(g_hs[1], mirror(ref[1], rows), 3e-3, 2e-2, "ddelta")
+    assert_close(g_hs[3], mirror(ref[3], 1), 6e-4, 2e-3, "dB")
+    assert_close(g_hs[4], mirror(ref[4], 1), 6e-4, 2e-3, "dC")
+    assert_close(g_hs[2], ref[2], RTOLW, max(ATOLW * 5, 2e-5 * float(ref[2].abs().max())), "dA")
+
+
+def test_lane_states_fall_back_where_they_do_not_apply():
+    """dstate > 64 (round-1 backward kernel) and the fused-delta form ignore the buffer; a wrong-sized buffer is an error"""
+    cpu = make_inputs(1, 8, 72, 2, 700, torch.float32)
+    out, x, hs, g_hs, g_re, used = _fwd_bwd_with_lane_states(cpu, True)
+    assert used == 0
+    for a, b in zip(g_hs, g_re):
+        assert torch.equal(a, b)
+    u, delta, A, B, C, D, bias, dout = to_dev(make_inputs(1, 8, 16, 2, 700, torch.float32))
+    o, x, hs = vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1, want_hs=True)
+    with pytest.raises(RuntimeError, match="lane-state tensor"):
+        vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x, True, 1, hs=hs[:-64])

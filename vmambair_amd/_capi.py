@@ -35,7 +35,7 @@ class ScanFwdParams(C.Structure):
         ("D", C.c_void_p), ("delta_bias", C.c_void_p), ("out", C.c_void_p), ("x", C.c_void_p),
         ("dt_weight", C.c_void_p), ("dt_rank", C.c_int), ("reserved1_", C.c_int),
         ("dt_group_stride", C.c_int64), ("dt_rank_stride", C.c_int64),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("hs", C.c_void_p),
     ]
 
 
@@ -70,9 +70,9 @@ ADAM_CHUNK = 2048
 SUM_CHUNK_BYTES = 40   # sizeof(oss_sum_chunk)
 
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fwd_workspace_bytes", "oss_scan_bwd_workspace_bytes",
+SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fwd_workspace_bytes", "oss_scan_lane_state_floats", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments",
-           "oss_scan_last_segments", "oss_prof_enable", "oss_prof_reset",
+           "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
@@ -109,6 +109,9 @@ def load():
     lib.oss_scan_bwd_workspace_bytes.argtypes = [C.c_int] * 5
     lib.oss_scan_fwd_workspace_bytes.restype = C.c_size_t
     lib.oss_scan_fwd_workspace_bytes.argtypes = [C.c_int] * 5
+    lib.oss_scan_last_lane_states.restype = C.c_int
+    lib.oss_scan_lane_state_floats.restype = C.c_size_t
+    lib.oss_scan_lane_state_floats.argtypes = [C.c_int] * 4
     lib.oss_scan_set_segments.restype = None
     lib.oss_scan_set_segments.argtypes = [C.c_int, C.c_int]
     lib.oss_scan_last_segments.restype = C.c_int

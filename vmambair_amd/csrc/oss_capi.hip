@@ -13,7 +13,7 @@ namespace oss {
 static std::atomic<int> g_force_fwd{-1}, g_force_bwd{-1};
 static std::atomic<int> g_last_fwd{-1}, g_last_bwd{-1};
 static std::atomic<int> g_force_fwd_seg{-1}, g_force_bwd_seg{-1};
-std::atomic<int> g_last_fwd_segments{1}, g_last_bwd_segments{1};
+std::atomic<int> g_last_fwd_segments{1}, g_last_bwd_segments{1}, g_last_bwd_lane_states{0};
 
 // Segments of a launch that has `wgs` workgroups (one per CU at a time for the wide variants) over `n_chunks` chunks when
 // it is not cut in time.  Cost model in units of one chunk of one workgroup: rounds over the 256 CUs x chunks per segment x
@@ -261,6 +261,11 @@ size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, 
     return floats * sizeof(float);
 }
 
+size_t oss_scan_lane_state_floats(int batch, int dim, int seqlen, int dstate) {
+    if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0) return 0;
+    return (size_t)batch * dim * dstate * lane_state_stride(seqlen);
+}
+
 size_t oss_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups) {
     if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0 || n_groups <= 0 || dim % n_groups) return 0;
     const int segs = std::min(kMaxSegments, (seqlen + kScanChunk - 1) / kScanChunk);   // the shortest chunk any variant has
@@ -285,6 +290,7 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     ProfTimer prof(1, v, (int)io, bwd_alg_bytes(f, eb), bwd_own_bytes(*p, eb));
     ProfTimer fprof(2, v, (int)io, 0.0);   // the finishing kernel of the same call
     const int sr = g_force_bwd_seg.load();
+    g_last_bwd_lane_states.store(0);
     switch (io) {
         case OSS_F32: return scan_bwd_dispatch<float>(*p, v, sr, s, &prof, &fprof);
         case OSS_F16: return scan_bwd_dispatch<f16_t>(*p, v, sr, s, &prof, &fprof);
@@ -604,6 +610,7 @@ void oss_scan_set_segments(int fwd_segments, int bwd_segments) {
     g_force_bwd_seg.store(bwd_segments);
 }
 int oss_scan_last_segments(int which) { return which == 0 ? g_last_fwd_segments.load() : g_last_bwd_segments.load(); }
+int oss_scan_last_lane_states(void) { return g_last_bwd_lane_states.load(); }
 
 // copy kernels of oss_hbm_copy.  Default (mode 2): one 16-byte element per lane and a grid as large as the buffer -- the
 // dispatcher streams short workgroups faster than any loop keeps loads in flight: 6.12 TB/s on 1 GiB, against 5.58 for

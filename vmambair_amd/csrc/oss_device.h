@@ -13,6 +13,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kScanChunk = 256;  // time steps between saved states in x (oss_scan_chunk())
 constexpr int kNB = 16;          // states per LDS tile
+// lane states (include/vmambair_oss.h: hs): entries per (batch, row, state) line, one per 8 scan steps, padded to whole 512-step chunks
+__host__ __device__ inline size_t lane_state_stride(int seqlen) { return (size_t)(((seqlen + 7) / 8 + 63) & ~63); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -37,7 +37,7 @@ int scan_pick_segments(long wgs, int n_chunks, int seg_req, double ovh);
 inline size_t scan_carry_bytes(int batch, int dim, int dstate, int n_seg) {
     return sizeof(float) * 2 * (size_t)batch * dim * dstate * n_seg;
 }
-extern std::atomic<int> g_last_fwd_segments, g_last_bwd_segments;
+extern std::atomic<int> g_last_fwd_segments, g_last_bwd_segments, g_last_bwd_lane_states;
 template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream);
 // one timer brackets the MAIN backward kernel, a second one the finishing kernel (oss_prof_* buckets 1 and 2)
 struct LaunchTimer {

@@ -576,7 +576,12 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     }
     if (rc != OSS_OK) return rc;
     g_last_bwd_segments.store(n_seg);
-    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + (FD ? WAVES * kMaxDtRank : 0));   // two tile buffers, two slab buffers (+ dt weights)
+    // lane states saved by the forward pass (f.hs): the kernels that load them instead of re-running the forward recurrence
+    const bool hs = !FD && f.hs != nullptr;
+    // two tile buffers, two slab buffers (+ dt weights | + two buffers of this wave's lane states)
+    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + (FD ? WAVES * kMaxDtRank : 0) +
+                                         (hs ? 2 * (size_t)WAVES * NBB * 64 : 0));
+    g_last_bwd_lane_states.store(hs ? 1 : 0);
     if constexpr (!FD) {
         if (n_seg > 1) {
             const BwdSeg sg{carry, n_seg, cps};
@@ -590,18 +595,31 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             if (g_finish_timer) g_finish_timer->segmented();
             hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_seg - 1))), dim3(CW * 64), sizeof(float) * kNB * TC,
                                stream, p, sg, ctiles);
-            auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true>;
-            static LdsGate gate_s;
-            if (const int e = gate_s.ensure(reinterpret_cast<const void *>(km), smem)) return e;
-            hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
+            static LdsGate gate_s, gate_sh;
+            if (hs) {
+                auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, true>;
+                if (const int e = gate_sh.ensure(reinterpret_cast<const void *>(km), smem)) return e;
+                hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
+            } else {
+                auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, false>;
+                if (const int e = gate_s.ensure(reinterpret_cast<const void *>(km), smem)) return e;
+                hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
+            }
             if (timer) timer->end(stream);
             rc = (int)hipGetLastError();
             if (rc != OSS_OK) return rc;
             return launch_finish<T>(p, ws, wdD, wdb, stream, n_seg);
         }
+        if (hs) {
+            static LdsGate gate_h;
+            rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, false, true>, smem, gate_h, wgs, WAVES * 64, p, ws, stream,
+                             timer, BwdSeg{nullptr, 1, n_chunks});
+            if (rc != OSS_OK) return rc;
+            return launch_finish<T>(p, ws, wdD, wdb, stream);
+        }
     }
     static LdsGate gate;
-    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
+    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false, false>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
                      BwdSeg{nullptr, 1, n_chunks});
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);

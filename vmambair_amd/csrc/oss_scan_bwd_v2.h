@@ -115,10 +115,15 @@ struct BwdSeg {
     float *carry;   // [batch][dim][n_seg][dstate][2]: (prod of a_{t+1} over the segment, dh at its first step from a zero carry)
     int n_seg, cps; // segments per row, 512-step chunks per segment
 };
-template <typename T, int WAVES, int NBB, int MINW, bool FD, bool SEG = false>
+// HS: the forward pass left the state entering every 8-step block in f.hs (include/vmambair_oss.h: lane states).  A lane's
+// 8 steps then start from a LOADED state: the local forward recurrence, the product of a over the lane and one of the two lane
+// scans per state drop out of the state pass (28 of its 165 vector instructions); the loads go global -> LDS directly
+// (global_load_lds_dword: no registers) one staging batch ahead, into a wave-private region next to the B / C tiles.
+template <typename T, int WAVES, int NBB, int MINW, bool FD, bool SEG = false, bool HS = false>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
 oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg sg) {
     static_assert(!(FD && SEG), "the fused-delta form is not segmented");
+    static_assert(!(FD && HS), "the fused-delta form recomputes the forward states");
     constexpr int LPR = 64, I = 8;
     constexpr int ROWS = WAVES;
     constexpr int TC = LPR * I;
@@ -138,6 +143,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     float *sT = smem;                          // [2 buffers][B | C][NBB][TC]  tile_off layout
     float *slab = smem + 2 * 2 * NBB * TC;     // [2][ROWS][2][TC]  per-row dB / dC terms of one state, time order; two buffers
     float *sW = slab + 2 * ROWS * 2 * TC;      // FD: [ROWS][kMaxDtRank] dt weights of the workgroup's rows (zero-padded)
+    float *sH = sW;                            // HS: [2 buffers][WAVES][NBB][64] lane states of this wave's row (never with FD)
 
     const oss_scan_fwd_params &f = p.f;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -194,9 +200,18 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     // ---- tile staging, split in two: global -> registers (issue), registers -> LDS (commit)
     constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
     RawQuad<T> pb[QPT], pc[QPT];
-    auto stage_issue = [&](int t0s, int n0s) {
+    const size_t hs_stride = lane_state_stride(L);
+    const float *hs_row = HS ? f.hs + ((size_t)b * f.dim + d) * N * hs_stride + lane : nullptr;
+    auto stage_issue = [&](int t0s, int n0s, int buf) {
         const int nbs = min(NBB, N - n0s);
         const bool fullchunk = (t0s + TC <= L);
+        if constexpr (HS) {   // this wave's lane states of the batch: global -> LDS, complete by the time stage_commit has waited
+            float *dst = sH + (size_t)((buf * WAVES + wave) * NBB) * 64;
+            const float *src = hs_row + (size_t)n0s * hs_stride + (t0s >> 3);
+#pragma unroll
+            for (int k = 0; k < NBB; ++k)
+                if (k < nbs) __builtin_amdgcn_global_load_lds(src + (size_t)k * hs_stride, dst + k * 64, 4, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
             const int idx = tid + j * NT;
@@ -215,6 +230,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     };
     auto stage_commit = [&](int buf, int n0s) {
         const int nbs = min(NBB, N - n0s);
+        if constexpr (HS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the lane-state loads into LDS have landed
         float *dB_ = sT + (size_t)buf * 2 * NBB * TC, *dC_ = dB_ + NBB * TC;
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
@@ -270,7 +286,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
         }
     }
     // tiles of the very first batch: synchronous
-    stage_issue((c_end - 1) * TC, 0);
+    stage_issue((c_end - 1) * TC, 0, 0);
     stage_commit(0, 0);
     __syncthreads();
     for (int c = c_end - 1; c >= c_begin; --c) {
@@ -359,7 +375,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
         float S = 0.f;
 #pragma unroll
         for (int i = 0; i < I; ++i) S += dl[i];
-        if constexpr (FD || !(kV2GroupPro && kV2HcvEarly)) {   // saved forward state entering this chunk (bwd_kernel.cuh:184); otherwise fetched with the chunk's rows
+        if constexpr (!HS && (FD || !(kV2GroupPro && kV2HcvEarly))) {   // saved forward state entering this chunk (bwd_kernel.cuh:184); otherwise fetched with the chunk's rows
             const int xi = t0 / kScanChunk - 1;
             hcv = (xi >= 0 && lane < N) ? x_row[(size_t)xi * 2 * N + 2 * lane + 1] : 0.f;
         }
@@ -371,21 +387,33 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
         float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * sl) : (t0 + 4 * sl));
 
         // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
-        auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I]) {
-            const float A2 = lane_get(A2v, n), hc = lane_get(hcv, n), dhc = lane_get(dhcv, n);
+        auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I], float hin_saved) {
+            const float A2 = lane_get(A2v, n), dhc = lane_get(dhcv, n);
             float a[I], hh[I];
-            // ---- forward recompute: local recurrence (hh holds b_t until the state pass)
-            float h = 0.f;
+            float hin;
+            if constexpr (HS) {
+                // ---- forward states: the state entering this lane's steps was saved by the forward pass
 #pragma unroll
-            for (int i = 0; i < I; ++i) {
-                a[i] = exp2_hw(dl[i] * A2);
-                hh[i] = bt[i] * w[i];
-                h = (i == 0) ? hh[0] : __builtin_fmaf(a[i], h, hh[i]);
+                for (int i = 0; i < I; ++i) {
+                    a[i] = exp2_hw(dl[i] * A2);
+                    hh[i] = bt[i] * w[i];
+                }
+                hin = (valid > 0) ? hin_saved : 0.f;   // entries past the end of the sequence are never written
+            } else {
+                // ---- forward recompute: local recurrence (hh holds b_t until the state pass)
+                const float hc = lane_get(hcv, n);
+                float h = 0.f;
+#pragma unroll
+                for (int i = 0; i < I; ++i) {
+                    a[i] = exp2_hw(dl[i] * A2);
+                    hh[i] = bt[i] * w[i];
+                    h = (i == 0) ? hh[0] : __builtin_fmaf(a[i], h, hh[i]);
+                }
+                float P = exp2_hw(S * A2);
+                segment_scan<LPR>(P, h);
+                const float hfull = __builtin_fmaf(P, hc, h);
+                hin = shift_from_prev_lane(hfull, hc, seg_first);
             }
-            float P = exp2_hw(S * A2);
-            segment_scan<LPR>(P, h);
-            const float hfull = __builtin_fmaf(P, hc, h);
-            const float hin = shift_from_prev_lane(hfull, hc, seg_first);
             {
                 float hp = hin;
 #pragma unroll
@@ -493,20 +521,26 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
             const bool more_here = n0 + NBB < N;
             const bool have_next = more_here || c > c_begin;
             const int nt0 = more_here ? t0 : t0 - TC, nn0 = more_here ? n0 + NBB : 0;
-            if (have_next) stage_issue(nt0, nn0);
+            if (have_next) stage_issue(nt0, nn0, tbuf ^ 1);
             const float *tb = sT + (size_t)tbuf * 2 * NBB * TC + pos * 4, *tc = tb + NBB * TC;
             float b0[I], c0[I], b1[I], c1[I];
+            float h0s = 0.f, h1s = 0.f;   // HS: the saved state entering this lane's steps, per state of the register double set
+            const float *th = HS ? sH + (size_t)((tbuf * WAVES + wave) * NBB) * 64 + lane : nullptr;
             read_tile<I>(tb, b0);
             read_tile<I>(tc, c0);
+            if constexpr (HS) h0s = th[0];
             // every LDS read issued so far has landed before the loop starts: lgkmcnt counts in order, so without this the
             // compiler must assume, at the top of every iteration, that the tiles of the CURRENT state may still be in
             // flight behind the prefetch of the next one -- and waits for the prefetch (checked in the ISA)
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
             for (int nn = 0; nn < nb; nn += 2) {
                 const bool has1 = nn + 1 < nb;
-                if (has1) { read_tile<I>(tb + (nn + 1) * TC, b1); read_tile<I>(tc + (nn + 1) * TC, c1); }
+                if (has1) {
+                    read_tile<I>(tb + (nn + 1) * TC, b1); read_tile<I>(tc + (nn + 1) * TC, c1);
+                    if constexpr (HS) h1s = th[(nn + 1) * 64];
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                state_pass(n0 + nn, b0, c0);
+                state_pass(n0 + nn, b0, c0, h0s);
                 if (!has1 && have_next) stage_commit(tbuf ^ 1, nn0);   // before the batch's last barrier, which then fences it
 #ifndef OSS_EXP_V2_NOBAR
                 __syncthreads();                       // state n's slabs are complete; buffer par^1 is free again
@@ -515,9 +549,12 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
                 par ^= 1;
                 if (has1) {
                     const bool last = nn + 2 >= nb;
-                    if (!last) { read_tile<I>(tb + (nn + 2) * TC, b0); read_tile<I>(tc + (nn + 2) * TC, c0); }
+                    if (!last) {
+                        read_tile<I>(tb + (nn + 2) * TC, b0); read_tile<I>(tc + (nn + 2) * TC, c0);
+                        if constexpr (HS) h0s = th[(nn + 2) * 64];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-                    state_pass(n0 + nn + 1, b1, c1);
+                    state_pass(n0 + nn + 1, b1, c1, h1s);
                     if (last && have_next) stage_commit(tbuf ^ 1, nn0);
 #ifndef OSS_EXP_V2_NOBAR
                     __syncthreads();

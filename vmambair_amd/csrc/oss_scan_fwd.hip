@@ -90,6 +90,8 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     const float bias = p.delta_bias ? p.delta_bias[d] : 0.f;
     const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
     float *x_row = p.x + ((size_t)b * p.dim + d) * n_xchunks * 2 * N;
+    const size_t hs_stride = lane_state_stride(L);
+    float *hs_line = (SEG != 1 && p.hs) ? p.hs + ((size_t)b * p.dim + d) * N * hs_stride : nullptr;
 
     // carries start at (h, P) = (0, 1); A is pre-scaled once (fwd_kernel.cuh:125-127)
     for (int idx = tid; idx < N * ROWS; idx += NT) {
@@ -196,6 +198,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
                     }
                     const float *tc = sC + tile_off<LPR, I>(nn, pos, 0);
                     h = hin;
+                    float h_mid = 0.f;   // I = 16: the state after this lane's 8th step
 #pragma unroll
                     for (int k = 0; k < I / 4; ++k) {
                         const f32x4 cv = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
@@ -203,7 +206,21 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
                         for (int j = 0; j < 4; ++j) {
                             const int i = 4 * k + j;
                             h = __builtin_fmaf(a[i], h, bb[i]);
+                            if (I == 16 && i == 7) h_mid = h;
                             y[i] = __builtin_fmaf(cv[j], h, y[i]);
+                        }
+                    }
+                    // lane states for the backward (include/vmambair_oss.h: hs): the state ENTERING every 8-step block whose
+                    // first step lies inside the sequence -- a by-product of this pass
+                    if (hs_line && row_valid && valid > 0) {
+                        float *hl = hs_line + (size_t)n * hs_stride + (tl >> 3);
+                        if constexpr (I == 16) {
+                            if (valid > 8) *reinterpret_cast<float2 *>(hl) = make_float2(hin, h_mid);
+                            else hl[0] = hin;
+                        } else if constexpr (I == 8) {
+                            hl[0] = hin;
+                        } else {   // I = 4: every other lane starts a block
+                            if ((tl & 7) == 0) hl[0] = hin;
                         }
                     }
                 }

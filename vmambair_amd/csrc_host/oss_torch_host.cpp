@@ -115,7 +115,7 @@ Dims common_checks(const Tensor &u, const Tensor &delta, const Tensor &A, const 
 
 void fill_fwd(oss_scan_fwd_params &P, const Tensor &u, const Tensor &delta, const Tensor &A, const Tensor &B, const Tensor &C,
               const OptTensor &D, const OptTensor &delta_bias, const Tensor *out, const OptTensor &x, const Dims &d, bool softplus,
-              int64_t rev_group_start, int64_t u_row_mod, bool a_log_form, const OptTensor &dt_weight) {
+              int64_t rev_group_start, int64_t u_row_mod, bool a_log_form, const OptTensor &dt_weight, const OptTensor &hs = std::nullopt) {
     std::memset(&P, 0, sizeof(P));
     P.batch = (int)d.batch; P.dim = (int)d.dim; P.seqlen = (int)d.seqlen; P.dstate = (int)d.dstate; P.n_groups = (int)d.n_groups;
     P.delta_softplus = softplus ? 1 : 0;
@@ -137,12 +137,14 @@ void fill_fwd(oss_scan_fwd_params &P, const Tensor &u, const Tensor &delta, cons
     P.D = reinterpret_cast<const float *>(ptr(D));
     P.delta_bias = reinterpret_cast<const float *>(ptr(delta_bias));
     P.x = reinterpret_cast<float *>(const_cast<void *>(ptr(x)));
+    P.hs = reinterpret_cast<float *>(const_cast<void *>(ptr(hs)));
 }
 
 // cus/selective_scan.cpp:157-239
+// want_hs: also return the lane states (include/vmambair_oss.h: hs) as a third tensor, for scan_bwd's `hs` argument
 std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor &A, const Tensor &B, const Tensor &C,
                              const OptTensor &D, const OptTensor &delta_bias, bool delta_softplus, int64_t rev_group_start,
-                             int64_t u_row_mod, bool a_log_form, const OptTensor &dt_weight) {
+                             int64_t u_row_mod, bool a_log_form, const OptTensor &dt_weight, bool want_hs) {
     const Dims d = common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight);
     const at::hip::OptionalHIPGuardMasqueradingAsCUDA guard(u.device());
     const int n_chunks = oss_scan_num_chunks((int)d.seqlen);
@@ -155,9 +157,16 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
         out = at::empty({d.batch, d.dim, d.seqlen}, u.options());
     }
     Tensor x = at::empty({d.batch, d.dim, (int64_t)n_chunks, 2 * d.dstate}, u.options().dtype(at::kFloat));
-    if (d.batch == 0 || d.seqlen == 0) return {out, x};   // nothing to launch
+    OptTensor hs;
+    if (want_hs)
+        hs = at::empty({(int64_t)oss_scan_lane_state_floats((int)d.batch, (int)d.dim, (int)d.seqlen, (int)d.dstate)},
+                       u.options().dtype(at::kFloat));
+    if (d.batch == 0 || d.seqlen == 0) {   // nothing to launch
+        if (want_hs) return {out, x, *hs};
+        return {out, x};
+    }
     oss_scan_fwd_params P;
-    fill_fwd(P, u, delta, A, B, C, D, delta_bias, &out, x, d, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight);
+    fill_fwd(P, u, delta, A, B, C, D, delta_bias, &out, x, d, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight, hs);
     Tensor ws;   // scratch of the time-segmented launch (under-filled grids); a few hundred KB
     const size_t ws_bytes = oss_scan_fwd_workspace_bytes((int)d.batch, (int)d.dim, (int)d.seqlen, (int)d.dstate, (int)d.n_groups);
     if (ws_bytes) {
@@ -167,6 +176,7 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
     }
     hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     check_rc(oss_scan_fwd(&P, io_of(u), reinterpret_cast<oss_stream_t>(stream)), "oss_scan_fwd");
+    if (want_hs) return {out, x, *hs};
     return {out, x};
 }
 
@@ -176,7 +186,7 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
 std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor &A, const Tensor &B, const Tensor &C,
                              const OptTensor &D, const OptTensor &delta_bias, const Tensor &dout, const OptTensor &x,
                              bool delta_softplus, int64_t rev_group_start, int64_t u_row_mod, int64_t dout_row_mod, bool a_log_form,
-                             const OptTensor &dbc_into, const OptTensor &dt_weight) {
+                             const OptTensor &dbc_into, const OptTensor &dt_weight, const OptTensor &hs) {
     const Dims d = common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight);
     TORCH_CHECK(dout.scalar_type() == u.scalar_type() && dout.is_cuda(), "dout must be a CUDA/HIP tensor of u's dtype");
     TORCH_CHECK(dout.dim() == 3 && dout.size(0) == d.batch && dout.size(1) == (dout_row_mod ? dout_row_mod : d.dim) &&
@@ -194,6 +204,10 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
     const bool fused = dt_weight.has_value() && dt_weight->defined();
     const bool into = dbc_into.has_value() && dbc_into->defined();
     TORCH_CHECK(!fused || into, "dt_weight needs dbc_into (the gradient of x_dbl the kernel fills)");
+    if (hs.has_value() && hs->defined())
+        TORCH_CHECK(hs->scalar_type() == at::ScalarType::Float && hs->is_cuda() && hs->is_contiguous() &&
+                        (size_t)hs->numel() == oss_scan_lane_state_floats((int)d.batch, (int)d.dim, (int)d.seqlen, (int)d.dstate),
+                    "hs must be the lane-state tensor the forward call returned");
     const auto io = u.options();
     const auto f32 = u.options().dtype(at::kFloat);
     Tensor du = at::empty({d.batch, d.dim, d.seqlen}, io);
@@ -233,7 +247,7 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
     Tensor ws = at::empty({(int64_t)((std::max<size_t>(ws_bytes, 16) + 3) / 4)}, f32);
     oss_scan_bwd_params P;
     std::memset(&P, 0, sizeof(P));
-    fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, nullptr, x, d, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight);
+    fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, nullptr, x, d, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight, hs);
     P.dout_batch_stride = dout.stride(0); P.dout_d_stride = dout.stride(1);
     P.du_batch_stride = du.stride(0); P.du_d_stride = du.stride(1);
     if (fused) {
@@ -260,10 +274,10 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
 
 TORCH_LIBRARY(vmambair_host, m) {
     m.def("scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, bool delta_softplus, "
-          "int rev_group_start, int u_row_mod, bool a_log_form, Tensor? dt_weight) -> Tensor[]");
+          "int rev_group_start, int u_row_mod, bool a_log_form, Tensor? dt_weight, bool want_hs) -> Tensor[]");
     m.def("scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, Tensor dout, Tensor? x, "
           "bool delta_softplus, int rev_group_start, int u_row_mod, int dout_row_mod, bool a_log_form, Tensor(a!)? dbc_into, "
-          "Tensor? dt_weight) -> Tensor[]");
+          "Tensor? dt_weight, Tensor? hs) -> Tensor[]");
 }
 
 TORCH_LIBRARY_IMPL(vmambair_host, CUDA, m) {

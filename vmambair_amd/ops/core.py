@@ -12,6 +12,7 @@ import torch
 
 from .. import _capi
 from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_operands, _keep_views, _planes, _ptr)  # noqa: F401
+from . import scan as _scan
 from .scan import merge4, selective_scan_bwd, selective_scan_fwd
 
 
@@ -149,28 +150,34 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
 
 
 def ss2d_core_fwd(x: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor, A_logs: torch.Tensor,
-                  Ds: torch.Tensor, dt_bias: torch.Tensor) -> List[torch.Tensor]:
+                  Ds: torch.Tensor, dt_bias: torch.Tensor, want_hs: bool = False) -> List[torch.Tensor]:
     """``SS2D_1.forward_core`` up to (not including) ``out_norm`` (MambaSISR6_arch.py:395-431), omni form ->
-    ``[y (B, D, H, W) fp32, x2, xdbl, dts, states]`` (the last four are what the backward needs)."""
+    ``[y (B, D, H, W) fp32, x2, xdbl, dts, states, lane_states]`` (the last five are what the backward needs; ``lane_states``
+    -- the state entering every 8-step block, a by-product of the forward scan -- is empty when it was not asked for)."""
     B, D, H, W, Cc, R, N = _dims_core(x, x_proj_weight, dt_projs_weight, A_logs)
     L = H * W
     if x.numel() == 0:
         e = x.new_empty
-        return [e((B, D, H, W), dtype=torch.float32), e((B, 2, D, L)), e((B, 4, Cc, L)), e((B, 4 * D, L)), e(0, dtype=torch.float32)]
+        return [e((B, D, H, W), dtype=torch.float32), e((B, 2, D, L)), e((B, 4, Cc, L)), e((B, 4 * D, L)), e(0, dtype=torch.float32),
+                e(0, dtype=torch.float32)]
     x2 = cross_scan2(x)
     fused = fused_dt_supported(x2.dtype, B, D, Cc, R, N, L)
     xdbl, dts = proj_fwd(x2, x_proj_weight, dt_projs_weight, want_dts=not fused)
     # fused: delta = dt_projs_weight . xdbl[:, :, :R] is evaluated inside the scan kernels (dts stays empty)
-    out, states = selective_scan_fwd(x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N],
-                                     xdbl[:, :, R + N:], Ds.detach().float(), dt_bias.detach().float().reshape(-1), True, 1, 2,
-                                     2 * D, True, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None)
+    # lane states only when a backward will follow (they cost one more store per 8 steps and state) and never in the fused form
+    want_hs = bool(want_hs) and _scan.LANE_STATES and not fused and N <= 64 and L > 256
+    res = selective_scan_fwd(x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N],
+                             xdbl[:, :, R + N:], Ds.detach().float(), dt_bias.detach().float().reshape(-1), True, 1, 2,
+                             2 * D, True, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None,
+                             want_hs=want_hs)
+    out, states = res[0], res[1]
     y = merge4(out.view(B, 4, D, L), H, W)
-    return [y, x2, xdbl, dts, states]
+    return [y, x2, xdbl, dts, states, res[2] if want_hs else x.new_empty(0, dtype=torch.float32)]
 
 
 def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: torch.Tensor, states: torch.Tensor,
                   x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor, A_logs: torch.Tensor, Ds: torch.Tensor,
-                  dt_bias: torch.Tensor) -> List[torch.Tensor]:
+                  dt_bias: torch.Tensor, lane_states: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """-> [dx (B, D, H, W) io dtype, dx_proj_weight, ddt_projs_weight, dA_logs, dDs, ddt_bias] (fp32)"""
     B, _, D, L = x2.shape
     H, W = dy.shape[2], dy.shape[3]
@@ -182,7 +189,8 @@ def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: t
     res = selective_scan_bwd(
         x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:],
         Ds.detach().float(), dt_bias.detach().float().reshape(-1), g2.view(B, 2 * D, L), states, True, 1, 2, 2 * D, 2 * D, True,
-        dbc_into=dxdbl, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None)
+        dbc_into=dxdbl, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None,
+        hs=lane_states if (lane_states is not None and lane_states.numel()) else None)
     du, ddts, dA, _, _, dD, dbias = res[:7]
     dx2 = proj_dgrad(ddts, dxdbl, du, x_proj_weight, dt_projs_weight)   # fused: every row of dxdbl is already in place
     dx = cross_merge2(dx2, H, W)
@@ -192,9 +200,10 @@ def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: t
     return [dx, dwx, dwdt, dA, dD, dbias.view(4, D)]
 
 
-_LIB.define("ss2d_core_fwd(Tensor x, Tensor x_proj_weight, Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias) -> Tensor[]")
+_LIB.define("ss2d_core_fwd(Tensor x, Tensor x_proj_weight, Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias, "
+            "bool want_hs=False) -> Tensor[]")
 _LIB.define("ss2d_core_bwd(Tensor dy, Tensor x2, Tensor xdbl, Tensor dts, Tensor states, Tensor x_proj_weight, "
-            "Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias) -> Tensor[]")
+            "Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias, Tensor? lane_states=None) -> Tensor[]")
 _LIB.impl("ss2d_core_fwd", ss2d_core_fwd, "CUDA")
 _LIB.impl("ss2d_core_bwd", ss2d_core_bwd, "CUDA")
 
@@ -205,12 +214,14 @@ class SS2DCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias):
-        y, x2, xdbl, dts, states = torch.ops.vmambair.ss2d_core_fwd(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias)
-        ctx.save_for_backward(x2, xdbl, dts, states, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias)
+        # lane states only when a backward will follow: they cost one more store per 8 steps and state in the forward scan
+        y, x2, xdbl, dts, states, hs = torch.ops.vmambair.ss2d_core_fwd(x, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias,
+                                                                       any(ctx.needs_input_grad))
+        ctx.save_for_backward(x2, xdbl, dts, states, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias, hs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias = ctx.saved_tensors
-        dx, dwx, dwdt, dA, dD, dbias = torch.ops.vmambair.ss2d_core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias)
+        x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias, hs = ctx.saved_tensors
+        dx, dwx, dwdt, dA, dD, dbias = torch.ops.vmambair.ss2d_core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias, hs)
         return (dx, dwx.to(wx.dtype), dwdt.to(wdt.dtype), dA.to(A_logs.dtype), dD.to(Ds.dtype), dbias.to(dt_bias.dtype))

@@ -71,8 +71,15 @@ def _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod=0, dt_weight=None
     return batch, dim, seqlen, dstate, n_groups
 
 
+#: ``VMAMBAIR_SCAN_LANE_STATES=1``: the autograd nodes of this package ask the forward scan for lane states (the state entering
+#: every 8-step block) and the backward loads them instead of re-running the forward recurrence from ``x``.  Default OFF: measured
+#: slower on the headline (forward kernel +7 %, backward -1 %).  The C ABI and ``selective_scan_fwd(want_hs=True)``
+#: take the form regardless of this switch.
+LANE_STATES = os.environ.get("VMAMBAIR_SCAN_LANE_STATES", "0") == "1"
+
+
 def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start=None, u_row_mod=0,
-              a_log_form=False, dt_weight=None):
+              a_log_form=False, dt_weight=None, hs=None):
     batch, dim, seqlen, dstate, n_groups = dims
     P.batch, P.dim, P.seqlen, P.dstate, P.n_groups = batch, dim, seqlen, dstate, n_groups
     P.delta_softplus = 1 if delta_softplus else 0
@@ -92,19 +99,23 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
     P.u, P.delta, P.A, P.B, P.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
     P.D, P.delta_bias = _ptr(D), _ptr(delta_bias)
     P.out, P.x = _ptr(out), _ptr(x)
+    P.hs = _ptr(hs) if (hs is not None and hs.numel()) else None
 
 
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], delta_softplus: bool,
                        nrows: int = 1, rev_group_start: Optional[int] = None, u_row_mod: int = 0,
-                       a_log_form: bool = False, dt_weight: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                       a_log_form: bool = False, dt_weight: Optional[torch.Tensor] = None,
+                       want_hs: bool = False) -> List[torch.Tensor]:
     """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``.
     ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling; ``dt_weight``: ``delta`` is the rank-R factor and the
-    kernels evaluate delta themselves -- see include/vmambair_oss.h."""
+    kernels evaluate delta themselves -- see include/vmambair_oss.h.  ``want_hs``: -> ``[out, x, hs]`` with the lane states
+    (the state entering every 8-step block) for ``selective_scan_bwd(..., hs=hs)``."""
     host = _host.ops()
     if host is not None and u.is_cuda:   # compiled boundary (csrc_host/oss_torch_host.cpp): same checks, same C ABI
         return list(host.scan_fwd(u, delta, A, B, C, D, delta_bias, bool(delta_softplus),
-                                  -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), bool(a_log_form), dt_weight))
+                                  -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), bool(a_log_form), dt_weight,
+                                  bool(want_hs)))
     dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight)
     batch, dim, seqlen, dstate, _ = dims
     lib = _capi.load()
@@ -116,10 +127,12 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     else:
         out = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
     x = torch.empty((batch, dim, n_chunks, 2 * dstate), dtype=torch.float32, device=u.device)
+    hs = torch.empty(int(lib.oss_scan_lane_state_floats(batch, dim, seqlen, dstate)), dtype=torch.float32, device=u.device) \
+        if want_hs else None
     if batch == 0 or seqlen == 0:  # nothing to launch (empty tensors have no device pointer)
-        return [out, x]
+        return [out, x] + ([hs] if want_hs else [])
     P = _capi.ScanFwdParams()
-    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight)
+    _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight, hs)
     # scratch for the time-segmented launch (under-filled grids: batch-1 tiles, few-row levels); a few hundred KB
     ws_bytes = int(lib.oss_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate, dims[4]))
     if ws_bytes:
@@ -128,7 +141,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_fwd(P, _DT[u.dtype], stream), "oss_scan_fwd")
-    return [out, x]
+    return [out, x] + ([hs] if want_hs else [])
 
 
 def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
@@ -137,7 +150,8 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
                        rev_group_start: Optional[int] = None, u_row_mod: int = 0,
                        dout_row_mod: int = 0, a_log_form: bool = False,
                        dbc_into: Optional[torch.Tensor] = None,
-                       dt_weight: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+                       dt_weight: Optional[torch.Tensor] = None,
+                       hs: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``.
@@ -147,7 +161,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     if host is not None and u.is_cuda:   # compiled boundary: [du, ddelta, dA, dB, dC, dD, dbias, ddt_weight], empty = absent
         r = host.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, bool(delta_softplus),
                           -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), int(dout_row_mod), bool(a_log_form),
-                          dbc_into, dt_weight)
+                          dbc_into, dt_weight, hs)
         du, ddelta, dA, dB, dC, dD, dbias, ddtw = r
         if dbc_into is not None:   # written in place (a mutated argument is not returned): the views are made here
             rows, N = dbc_into.shape[2], A.shape[1]
@@ -169,6 +183,10 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
         _check(tuple(x.shape) == (batch, dim, n_chunks, 2 * dstate), "x has the wrong shape")
     fused = dt_weight is not None
     _check(not fused or dbc_into is not None, "dt_weight needs dbc_into (the gradient of x_dbl the kernel fills)")
+    if hs is not None:
+        _check(hs.dtype == torch.float32 and hs.is_cuda and hs.is_contiguous() and
+               hs.numel() == int(lib.oss_scan_lane_state_floats(batch, dim, seqlen, dstate)),
+               "hs must be the lane-state tensor the forward call returned")
     du = torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
     ddelta = None if fused else torch.empty((batch, dim, seqlen), dtype=u.dtype, device=u.device)
     ddtw = torch.empty((dim, dt_weight.shape[1]), dtype=torch.float32, device=u.device) if fused else None
@@ -193,7 +211,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     ws_bytes = int(lib.oss_scan_bwd_workspace_bytes(batch, dim, seqlen, dstate, n_groups))
     ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.float32, device=u.device)
     P = _capi.ScanBwdParams()
-    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight)
+    _fill_fwd(P.f, u, delta, A, B, C, D, delta_bias, None, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight, hs)
     P.dout_batch_stride, P.dout_d_stride = dout.stride(0), dout.stride(1)
     P.du_batch_stride, P.du_d_stride = du.stride(0), du.stride(1)
     if fused:
