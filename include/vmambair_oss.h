@@ -196,6 +196,34 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
                         int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride, int64_t dy_channel_stride,
                         oss_stream_t stream);
 
+/* The depth-wise convolution fused with the element-wise step that follows it, without ever storing the convolution
+ * (16-bit io only; oss_dwconv3x3_fused_ok(io, H, W, 1 | 2) says whether a shape qualifies: width % 8 == 0, width / 8 divides 64,
+ * and 1 (silu) or 2 (gate) planes of (H + 2) x W elements fit the 160 KiB LDS of a workgroup; pointers 16-byte aligned and strides
+ * multiples of 8 elements, else OSS_ERR_SHAPE).
+ *   oss_dwconv3x3_silu_fwd: y = silu(conv(x) + bias)                         (SS2D_1: x = act(conv2d(x)), MambaSISR6_arch.py:486)
+ *   oss_dwconv3x3_silu_bwd: dx, dweight, dbias of it from x and dy -- the convolution is recomputed from the rows of x the
+ *                           weight gradient reads anyway, dy * silu' stays in LDS between the two passes of ONE launch
+ *   oss_dwgate_fwd:         out (batch, hidden, H, W) = gelu(x1) * x2 with x1, x2 = the two channel halves of
+ *                           conv(t) + bias, t (batch, 2 hidden, H, W)         (FeedForward.forward, MambaSISR6_arch.py:213-217)
+ *   oss_dwgate_bwd:         dt, dweight (2 hidden, 9), dbias of it from t and dout, one launch
+ * partials: batch * channels * 10 floats of scratch (channels = 2 hidden for the gate); dbias may be NULL.  The gradients that
+ * reach the convolution are rounded to the io type before both uses, as the separate kernels hand them over. */
+int oss_dwconv3x3_fused_ok(oss_dtype io, int height, int width, int channels_per_workgroup);
+int oss_dwconv3x3_silu_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int channels,
+                           int height, int width, int64_t x_batch_stride, int64_t x_channel_stride, int64_t y_batch_stride,
+                           int64_t y_channel_stride, oss_stream_t stream);
+int oss_dwconv3x3_silu_bwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *dy, void *dx,
+                           float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
+                           int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride, int64_t dy_channel_stride,
+                           int64_t dx_batch_stride, int64_t dx_channel_stride, oss_stream_t stream);
+int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
+                   int height, int width, int64_t t_batch_stride, int64_t t_channel_stride, int64_t out_batch_stride,
+                   int64_t out_channel_stride, oss_stream_t stream);
+int oss_dwgate_bwd(oss_dtype io, const void *t, const float *weight, const float *bias, const void *dout, void *dt,
+                   float *dweight, float *dbias, float *partials, int batch, int hidden, int height, int width,
+                   int64_t t_batch_stride, int64_t t_channel_stride, int64_t dout_batch_stride, int64_t dout_channel_stride,
+                   int64_t dt_batch_stride, int64_t dt_channel_stride, oss_stream_t stream);
+
 /* 1x1 convolutions of the OSS block (in_conv / out_conv / project_in / project_out,
  * MambaSISR6_arch.py:205,211,281,329) as MFMA GEMMs on NCHW tensors; io = OSS_BF16 or OSS_F16 (fp32
  * I/O is rejected with OSS_ERR_SHAPE: it stays on the vendor conv).  weight: float (Cout, Cin)

@@ -232,3 +232,115 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
         if d > tol * sc + floor:
             wrong.append((k, d, sc))
     assert not wrong, wrong
+
+
+# ---- fused forms of oss_dwconv.hip: the convolution is never stored, the backward is one launch ---------------------------
+FUSED_SHAPES = [(2, 12, 64, 64), (1, 6, 32, 32), (3, 4, 16, 16), (2, 8, 8, 8), (1, 2, 128, 128), (2, 4, 5, 512), (2, 6, 37, 16),
+                (1, 254, 16, 64)]
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_fused_conv_silu_one_launch_backward(shape, dt, has_bias):
+    """silu(conv2d(x)) (MambaSISR6_arch.py:486) through oss_dwconv3x3_silu_fwd / _bwd against plain PyTorch fp32, and against the
+    separate kernels (which store the convolution): same rounding points, so the two HIP paths agree far inside the tolerance"""
+    torch.manual_seed(11)
+    B, C, H, W = shape
+    assert ops.dwconv.fused_ok(torch.empty(shape, dtype=dt, device=DEV), 1)
+    x = torch.randn(shape).to(dt)
+    w, b = torch.randn(C, 1, 3, 3) * 0.3, (torch.randn(C) * 0.1 if has_bias else None)
+    dy = torch.randn(shape).to(dt)
+    xr, wr = x.float().clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if has_bias else None
+    yr = F.silu(F.conv2d(xr, wr, br, padding=1, groups=C))
+    yr.backward(dy.float())
+    xd, wd = x.to(DEV), w.to(DEV)
+    bd = b.to(DEV) if has_bias else None
+    y = torch.ops.vmambair.dwconv3x3_silu_fwd(xd, wd, bd)
+    dx, dw, db = torch.ops.vmambair.dwconv3x3_silu_bwd(xd, wd, bd, dy.to(DEV), None)
+    y0, pre = torch.ops.vmambair.dwconv3x3_fwd(xd, wd, bd, True)
+    dx0, dw0, db0 = torch.ops.vmambair.dwconv3x3_bwd(xd, wd, dy.to(DEV), has_bias, pre, None)
+    rt = 1e-2 if dt == torch.bfloat16 else 2e-3
+    assert_close(y, yr, rt, 2 * rt, "y")
+    assert torch.equal(y, y0), "forward differs from the separate kernels"
+    assert_close(dx, xr.grad, 2 * rt, 4 * rt, "dx")
+    assert_close(dw.cpu(), wr.grad, 2 * rt, 2 * rt * float(wr.grad.abs().max()), "dw")
+    assert_close(dx, dx0.float(), rt, 2 * rt, "dx vs separate")
+    assert_close(dw, dw0, rt, rt * float(dw0.abs().max()), "dw vs separate")
+    if has_bias:
+        assert_close(db.cpu(), br.grad, 2 * rt, 2 * rt * float(br.grad.abs().max()), "db")
+        assert_close(db, db0, rt, rt * float(db0.abs().max()), "db vs separate")
+
+
+def test_fused_conv_silu_writes_into_a_half_buffer_and_reruns_bit_exact():
+    """the SS2D_1 use: dx lands in one half of the gradient buffer of in_conv's output (ops.PairGrad); reruns are bit-identical"""
+    torch.manual_seed(12)
+    B, C, H, W = 2, 24, 32, 32
+    xz = torch.randn(B, 2 * C, H, W, device=DEV).to(torch.bfloat16)
+    x = xz[:, :C]
+    w, b = torch.randn(C, 1, 3, 3, device=DEV) * 0.3, torch.randn(C, device=DEV) * 0.1
+    dy = torch.randn(B, C, H, W, device=DEV).to(torch.bfloat16)
+    buf = torch.zeros(B, 2 * C, H, W, device=DEV, dtype=torch.bfloat16)
+    dx, dw, db = torch.ops.vmambair.dwconv3x3_silu_bwd(x, w, b, dy, buf[:, :C])
+    assert dx.numel() == 0 and float(buf[:, C:].abs().max()) == 0.0
+    dx2, dw2, db2 = torch.ops.vmambair.dwconv3x3_silu_bwd(x.contiguous(), w, b, dy, None)
+    assert torch.equal(buf[:, :C], dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("shape", FUSED_SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("has_bias", [False, True])
+def test_fused_conv_gelu_gate(shape, dt, has_bias):
+    """x1, x2 = dwconv(t).chunk(2); gelu(x1) * x2 (FeedForward.forward, MambaSISR6_arch.py:213-217) as one node: against plain
+    PyTorch fp32 and against the separate kernels (dwconv -> gelu_gate; three backward launches)"""
+    torch.manual_seed(13)
+    B, C2, H, W = shape
+    Hd = C2 // 2
+    assert ops.dwconv.fused_ok(torch.empty(shape, dtype=dt, device=DEV), 2)
+    t = torch.randn(shape).to(dt)
+    w, b = torch.randn(C2, 1, 3, 3) * 0.3, (torch.randn(C2) * 0.1 if has_bias else None)
+    dout = torch.randn(B, Hd, H, W).to(dt)
+    tr, wr = t.float().clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if has_bias else None
+    x1, x2 = F.conv2d(tr, wr, br, padding=1, groups=C2).chunk(2, dim=1)
+    outr = F.gelu(x1) * x2
+    outr.backward(dout.float())
+    conv = torch.nn.Conv2d(C2, C2, 3, padding=1, groups=C2, bias=has_bias).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        if has_bias:
+            conv.bias.copy_(b)
+    td = t.to(DEV).requires_grad_()
+    out = ops.dwconv3x3_gelu_gate(td, conv)
+    assert out.grad_fn.__class__.__name__.startswith("DWGateFn")
+    out.backward(dout.to(DEV))
+    rt = 1e-2 if dt == torch.bfloat16 else 2e-3
+    assert_close(out, outr, rt, 2 * rt, "out")
+    assert_close(td.grad, tr.grad, 2 * rt, 6 * rt, "dt")
+    assert_close(conv.weight.grad.cpu(), wr.grad, 2 * rt, 3 * rt * float(wr.grad.abs().max()), "dw")
+    if has_bias:
+        assert_close(conv.bias.grad.cpu(), br.grad, 2 * rt, 3 * rt * float(br.grad.abs().max()), "db")
+    # the separate kernels on the same tensors
+    conv0 = torch.nn.Conv2d(C2, C2, 3, padding=1, groups=C2, bias=has_bias).to(DEV)
+    conv0.load_state_dict(conv.state_dict())
+    t0 = t.to(DEV).requires_grad_()
+    out0 = ops.gelu_gate(ops.dwconv3x3(t0, conv0))
+    out0.backward(dout.to(DEV))
+    assert_close(out, out0.float(), rt, 2 * rt, "out vs separate")
+    assert_close(td.grad, t0.grad.float(), rt, 4 * rt, "dt vs separate")
+    assert_close(conv.weight.grad, conv0.weight.grad, rt, 2 * rt * float(conv0.weight.grad.abs().max()), "dw vs separate")
+
+
+def test_shapes_the_fused_forms_leave_to_the_separate_kernels():
+    """fp32 I/O, widths whose lane groups do not tile a wave, planes beyond the LDS: fused_ok says no and the nodes fall back"""
+    for shape, dt, planes in (((1, 4, 16, 16), torch.float32, 1), ((1, 4, 16, 24), torch.bfloat16, 1), ((1, 4, 9, 12), torch.bfloat16, 2),
+                              ((1, 2, 512, 512), torch.bfloat16, 2)):
+        assert not ops.dwconv.fused_ok(torch.empty(shape, dtype=dt, device=DEV), planes)
+    conv = torch.nn.Conv2d(8, 8, 3, padding=1, groups=8, bias=False).to(DEV)
+    t = torch.randn(2, 8, 9, 12, device=DEV).to(torch.bfloat16).requires_grad_()
+    out = ops.dwconv3x3_gelu_gate(t, conv)
+    assert out.grad_fn.__class__.__name__.startswith("GeluGateFn")
+    x1, x2 = F.conv2d(t.float(), conv.weight, None, padding=1, groups=8).chunk(2, dim=1)
+    assert_close(out, F.gelu(x1) * x2, 2e-2, 4e-2, "fallback")
+    assert bool(ops.dwconv.fused_ok(torch.empty((1, 2, 256, 256), dtype=torch.bfloat16, device=DEV), 1))   # 129 KiB: one plane still fits

@@ -305,7 +305,44 @@ int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const fl
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3(io, x, weight, bias, y, batch, channels, height, width, xsb, xsc, ysb, ysc, flip,
-                     reinterpret_cast<hipStream_t>(stream), pre_silu);
+                     reinterpret_cast<hipStream_t>(stream), pre_silu, pre_silu != nullptr);
+}
+
+int oss_dwconv3x3_fused_ok(oss_dtype io, int height, int width, int channels_per_workgroup) {
+    return dwconv3x3_fused_ok(io, height, width, channels_per_workgroup);
+}
+
+int oss_dwconv3x3_silu_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int channels,
+                           int height, int width, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, oss_stream_t stream) {
+    if (!x || !weight || !y) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwconv3x3(io, x, weight, bias, y, batch, channels, height, width, xsb, xsc, ysb, ysc, 0,
+                     reinterpret_cast<hipStream_t>(stream), nullptr, 1);
+}
+
+int oss_dwconv3x3_silu_bwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *dy, void *dx,
+                           float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
+                           int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    if (!x || !weight || !dy || !dx || !dweight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwconv3x3_bwd_fused(io, 0, x, weight, bias, dy, dx, dweight, dbias, partials, batch, channels, height, width, xsb, xsc,
+                               gsb, gsc, dsb, dsc, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
+                   int height, int width, int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, oss_stream_t stream) {
+    if (!t || !weight || !out) return OSS_ERR_NULL;
+    if (batch <= 0 || hidden <= 0 || height <= 0 || width <= 0 || hidden > 32767 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwgate_fwd(io, t, weight, bias, out, batch, hidden, height, width, tsb, tsc, osb, osc, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_dwgate_bwd(oss_dtype io, const void *t, const float *weight, const float *bias, const void *dout, void *dt,
+                   float *dweight, float *dbias, float *partials, int batch, int hidden, int height, int width, int64_t tsb,
+                   int64_t tsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    if (!t || !weight || !dout || !dt || !dweight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || hidden <= 0 || height <= 0 || width <= 0 || hidden > 32767 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwconv3x3_bwd_fused(io, 1, t, weight, bias, dout, dt, dweight, dbias, partials, batch, 2 * hidden, height, width, tsb,
+                               tsc, gsb, gsc, dsb, dsc, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,

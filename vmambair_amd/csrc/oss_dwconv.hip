@@ -43,7 +43,8 @@ template <typename T, bool VEC>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                      T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
-                     int flip, T *__restrict__ pre /* contiguous (B, C, H, W) or NULL: the conv output before silu; y = silu(conv) */) {
+                     int flip, T *__restrict__ pre /* contiguous (B, C, H, W) or NULL: receives the conv output before the activation */,
+                     int act /* y = silu(conv) */) {
     const int c = blockIdx.y, b = blockIdx.z;
     const T *xp = x + b * xsb + c * xsc;
     T *yp = y + b * ysb + c * ysc;
@@ -74,8 +75,8 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
             for (int j = 0; j < 4; ++j)
                 acc[j] = __builtin_fmaf(k0, v[j], __builtin_fmaf(k1, v[j + 1], __builtin_fmaf(k2, v[j + 2], acc[j])));
         }
-        if (pp) {  // fused activation: keep the pre-activation for the backward, emit silu
-            Vec4<T>::store(pp + (int64_t)h * W + w0, acc);
+        if (pp) Vec4<T>::store(pp + (int64_t)h * W + w0, acc);   // kept for the backward
+        if (act) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = silu_f32(acc[j]);
         }
@@ -96,10 +97,8 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
                 acc = __builtin_fmaf(k[(dy + 1) * 3 + dx + 1], to_f32(xp[(int64_t)hh * W + wc]), acc);
             }
         }
-        if (pp) {
-            pp[p] = from_f32<T>(acc);
-            acc = silu_f32(acc);
-        }
+        if (pp) pp[p] = from_f32<T>(acc);
+        if (act) acc = silu_f32(acc);
         yp[p] = from_f32<T>(acc);
     }
 }
@@ -136,7 +135,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                           T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
-                          int flip, T *__restrict__ pre) {
+                          int flip, T *__restrict__ pre, int act) {
     const int c = blockIdx.y, b = blockIdx.z;
     const T *xp = x + b * xsb + c * xsc;
     T *yp = y + b * ysb + c * ysc;
@@ -164,8 +163,8 @@ oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, 
             acc[j] = __builtin_fmaf(k0, v[j], __builtin_fmaf(k1, v[j + 1], __builtin_fmaf(k2, v[j + 2], acc[j])));
     }
     if (!live) return;
-    if (pp) {  // fused activation: keep the pre-activation for the backward, emit silu
-        store8<T>(pp + (int64_t)h * W + w0, acc);
+    if (pp) store8<T>(pp + (int64_t)h * W + w0, acc);   // kept for the backward of the unfused path
+    if (act) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = silu_f32(acc[j]);
     }
@@ -233,6 +232,175 @@ oss_dwconv3x3_wgrad_wide_kernel(const T *__restrict__ x, const T *__restrict__ d
     if (threadIdx.x < 10)
         part[(size_t)b * C * 10 + (threadIdx.x < 9 ? (size_t)c * 9 + threadIdx.x : (size_t)9 * C + c)] =
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// ---- the convolution together with what follows it, without materialising the convolution --------------------------
+// SS2D_1: x = silu(conv2d(x)) (MambaSISR6_arch.py:486); EFFN: x1, x2 = dwconv(t).chunk(2); gelu(x1) * x2 (:213-217).
+// The convolution output is never stored: the forward writes only what the next layer reads, and the backward recomputes it
+// from the rows of the input it needs anyway for the weight gradient.  One workgroup of the backward owns the whole (H, W)
+// plane of its channel (pair): pass 1 forms the gradient that reaches the convolution (rounded to the I/O type, as the
+// separate kernels hand it over), leaves it in LDS and accumulates the weight / bias gradient partials; pass 2 convolves
+// the LDS planes with the mirrored taps -- three launches (activation backward, weight gradient, input gradient) and
+// four plane round trips through HBM become one launch that reads x, dy and writes dx.
+enum { kDwSilu = 0, kDwGate = 1 };
+
+__device__ __forceinline__ float gelu_cdf(float a) { return 0.5f * (1.f + erff(a * 0.70710678118654752f)); }
+
+template <typename T>
+__device__ __forceinline__ void conv_rows(const float (&v)[3][10], const float *__restrict__ k, float bv, float (&acc)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bv;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[j] = __builtin_fmaf(k[r * 3], v[r][j], __builtin_fmaf(k[r * 3 + 1], v[r][j + 1], __builtin_fmaf(k[r * 3 + 2], v[r][j + 2], acc[j])));
+}
+
+// out[b, c] = gelu(conv(t[b, c])) * conv(t[b, c + Hd]);  grid (groups of 256 lanes, Hd, B)
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
+                      int Hd, int H, int W, int64_t tsb, int64_t tsc, int64_t osb, int64_t osc) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const T *p1 = t + b * tsb + c * tsc, *p2 = p1 + Hd * tsc;
+    T *op = out + b * osb + c * osc;
+    const float *k1 = w + c * 9, *k2 = w + (c + Hd) * 9;
+    const float b1 = bias ? bias[c] : 0.f, b2 = bias ? bias[c + Hd] : 0.f;
+    const int lpr = W >> 3, ngroups = lpr * H;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < ngroups;
+    const int gc = live ? g : ngroups - 1;
+    const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
+    const bool first = cg == 0, last = cg == lpr - 1;
+    float v[3][10], x1[8], x2[8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) row10<T>(p1, h, r - 1, H, W, w0, first, last, v[r]);
+    conv_rows<T>(v, k1, b1, x1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) row10<T>(p2, h, r - 1, H, W, w0, first, last, v[r]);
+    conv_rows<T>(v, k2, b2, x2);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x1[j] = x1[j] * gelu_cdf(x1[j]) * x2[j];
+    store8<T>(op + (int64_t)h * W + w0, x1);
+}
+
+// MODE kDwSilu: one channel per workgroup, grid (C, B); dy is the gradient of silu(conv(x) + bias).
+// MODE kDwGate: channels c and c + Hd, grid (Hd, B); dy (B, Hd, H, W) is the gradient of gelu(x1) * x2.
+// dynamic LDS: NCH planes of (H + 2) rows of W elements of T (rows 0 and H + 1 stay zero: the padding of pass 2)
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256, 4)   // 4 waves per SIMD = 4 workgroups per CU: the headline's 1016 gate workgroups in one round
+oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                               const T *__restrict__ dy, T *__restrict__ dx, float *__restrict__ part /*[B][C][10]*/,
+                               int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc) {
+    constexpr int NCH = MODE == kDwGate ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    T *sg = reinterpret_cast<T *>(dw_smem);
+    const int c0 = blockIdx.x, b = blockIdx.y;
+    const int cstep = C / NCH;                       // kDwGate: the partner channel is c0 + Hd
+    const size_t plane = (size_t)(H + 2) * W;
+    const T *gp = dy + b * gsb + c0 * gsc;
+    const int lpr = W >> 3, ngroups = lpr * H;
+    // zero the two padding rows of every LDS plane
+    for (int i = threadIdx.x; i < NCH * 2 * lpr; i += 256) {
+        const int ch = i / (2 * lpr), r = i - ch * 2 * lpr, row = r < lpr ? 0 : H + 1, col = (r < lpr ? r : r - lpr) << 3;
+        *reinterpret_cast<u32x4 *>(sg + ch * plane + (size_t)row * W + col) = u32x4{0u, 0u, 0u, 0u};
+    }
+    float acc[NCH][10];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[ch][i] = 0.f;
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {   // uniform trip count: every lane takes part in the DPP halo exchange
+        const int g = g0 + threadIdx.x;
+        const bool live = g < ngroups;
+        const int gc = live ? g : ngroups - 1;
+        const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
+        const bool first = cg == 0, last = cg == lpr - 1;
+        float gv[8], v[NCH][3][10], pre[NCH][8], gq[NCH][8];
+        load8<T>(gp + (int64_t)h * W + w0, gv);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = c0 + ch * cstep;
+            const T *xp = x + b * xsb + c * xsc;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) row10<T>(xp, h, r - 1, H, W, w0, first, last, v[ch][r]);
+            conv_rows<T>(v[ch], w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (MODE == kDwSilu) {
+                gq[0][j] = gv[j] * dsilu_f32(pre[0][j]);
+            } else {
+                const float a = pre[0][j], cdf = gelu_cdf(a);
+                const float pdf = 0.3989422804014327f * exp2_hw(-0.5f * a * a * kLog2e);
+                gq[0][j] = gv[j] * pre[1][j] * __builtin_fmaf(a, pdf, cdf);
+                gq[1][j] = gv[j] * a * cdf;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (live) store8<T>(sg + ch * plane + (size_t)(h + 1) * W + w0, gq[ch]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gq[ch][j] = live ? to_f32(from_f32<T>(gq[ch][j])) : 0.f;   // both gradients see the rounded value
+            acc[ch][9] += ((gq[ch][0] + gq[ch][1]) + (gq[ch][2] + gq[ch][3])) + ((gq[ch][4] + gq[ch][5]) + (gq[ch][6] + gq[ch][7]));
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int dxx = 0; dxx < 3; ++dxx) {
+                    float a = acc[ch][r * 3 + dxx];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a = __builtin_fmaf(gq[ch][j], v[ch][r][j + dxx], a);
+                    acc[ch][r * 3 + dxx] = a;
+                }
+        }
+    }
+    __shared__ float red[4][NCH * 10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const float s = segment_sum_to_last<64>(acc[ch][i]);
+            if (lane == 63) red[wave][ch * 10 + i] = s;
+        }
+    __syncthreads();   // the LDS planes are complete, and so is red[]
+    if (threadIdx.x < NCH * 10) {
+        const int ch = threadIdx.x / 10, i = threadIdx.x - ch * 10, c = c0 + ch * cstep;
+        part[(size_t)b * C * 10 + (i < 9 ? (size_t)c * 9 + i : (size_t)9 * C + c)] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+    // pass 2: dx = the mirrored stencil over the LDS planes (row h of the image is LDS row h + 1)
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {
+        const int g = g0 + threadIdx.x;
+        const bool live = g < ngroups;
+        const int gc = live ? g : ngroups - 1;
+        const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
+        const bool first = cg == 0, last = cg == lpr - 1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = c0 + ch * cstep;
+            const T *sp = sg + ch * plane;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float m[8], vv[10];
+                load8<T>(sp + (size_t)(h + r) * W + w0, m);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vv[j + 1] = m[j];
+                vv[0] = shift_from_prev_lane(vv[8], 0.f, first);
+                vv[9] = shift_from_next_lane(vv[1], 0.f, last);
+                const float k0 = w[c * 9 + 8 - r * 3], k1 = w[c * 9 + 7 - r * 3], k2 = w[c * 9 + 6 - r * 3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = __builtin_fmaf(k0, vv[j], __builtin_fmaf(k1, vv[j + 1], __builtin_fmaf(k2, vv[j + 2], o[j])));
+            }
+            if (live) store8<T>(dx + b * dsb + c * dsc + (int64_t)h * W + w0, o);
+        }
+    }
 }
 
 // the 8-pixel kernels apply when a row's W / 8 lane groups tile a wave and every plane / row start is 16-byte aligned
@@ -348,14 +516,14 @@ oss_dwconv3x3_wgrad_finish(const float *__restrict__ part, float *__restrict__ d
 
 template <typename T>
 static int dwconv_launch(const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
-                         int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre) {
+                         int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre, int act) {
     const T *xp = reinterpret_cast<const T *>(x);
     T *yp = reinterpret_cast<T *>(y);
     T *prp = reinterpret_cast<T *>(pre);
     if constexpr (sizeof(T) == 2) {
         if (wide_ok<T>(W, {xp, yp, prp}, {xsb, xsc, ysb, ysc})) {
             dim3 grid(((W / 8) * H + 255) / 256, C, B);
-            hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp);
+            hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp, act);
             return (int)hipGetLastError();
         }
     }
@@ -365,22 +533,88 @@ static int dwconv_launch(const void *x, const float *w, const float *bias, void 
     if (vec) {
         const int groups = (W / 4) * H;
         dim3 grid((groups + 255) / 256, C, B);
-        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp);
+        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, true>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp, act);
     } else {
         dim3 grid((H * W + 255) / 256, C, B);
-        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp);
+        hipLaunchKernelGGL((oss_dwconv3x3_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp, act);
     }
     return (int)hipGetLastError();
 }
 
 int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
-              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre) {
+              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre, int act) {
     switch (io) {
-        case OSS_F32: return dwconv_launch<float>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre);
-        case OSS_F16: return dwconv_launch<f16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre);
-        case OSS_BF16: return dwconv_launch<bf16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre);
+        case OSS_F32: return dwconv_launch<float>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre, act);
+        case OSS_F16: return dwconv_launch<f16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre, act);
+        case OSS_BF16: return dwconv_launch<bf16_t>(x, w, bias, y, B, C, H, W, xsb, xsc, ysb, ysc, flip, s, pre, act);
     }
     return OSS_ERR_SHAPE;
+}
+
+// ---- fused forms: host side ------------------------------------------------------------------------------------------
+static size_t fused_lds_bytes(int nch, int H, int W, size_t esize) { return (size_t)nch * (H + 2) * W * esize; }
+
+// shapes the fused kernels take: 16-bit I/O, rows of W / 8 lane groups that tile a wave, the channel (pair)'s planes in LDS
+int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch) {
+    if (io != OSS_F16 && io != OSS_BF16) return 0;
+    if (nch < 1 || nch > 2 || H <= 0 || W <= 0 || W % 8 != 0 || W > 512 || (64 % (W / 8)) != 0) return 0;
+    return fused_lds_bytes(nch, H, W, 2) + 4 * 20 * sizeof(float) <= kMaxLdsBytes ? 1 : 0;
+}
+
+static bool aligned16(std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
+    for (const void *p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
+    for (int64_t st : strides)
+        if (st % 8 != 0) return false;
+    return true;
+}
+
+template <typename T>
+static int dwgate_fwd_launch(const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
+                             int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s) {
+    if (!aligned16({t, out}, {tsb, tsc, osb, osc})) return OSS_ERR_SHAPE;
+    dim3 grid(((W / 8) * H + 255) / 256, Hd, B);
+    hipLaunchKernelGGL((oss_dwgate_fwd_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T *>(t), w, bias,
+                       reinterpret_cast<T *>(out), Hd, H, W, tsb, tsc, osb, osc);
+    return (int)hipGetLastError();
+}
+
+int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
+               int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s) {
+    if (!dwconv3x3_fused_ok(io, H, W, 2)) return OSS_ERR_SHAPE;
+    return io == OSS_F16 ? dwgate_fwd_launch<f16_t>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s)
+                         : dwgate_fwd_launch<bf16_t>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s);
+}
+
+template <typename T, int MODE>
+static int bwd_fused_launch(const void *x, const float *w, const float *bias, const void *dy, void *dx, float *dw, float *db,
+                            float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
+                            int64_t dsb, int64_t dsc, hipStream_t s) {
+    constexpr int NCH = MODE == kDwGate ? 2 : 1;
+    if (!aligned16({x, dy, dx}, {xsb, xsc, gsb, gsc, dsb, dsc})) return OSS_ERR_SHAPE;
+    static LdsGate gate;
+    const size_t smem = fused_lds_bytes(NCH, H, W, sizeof(T));
+    auto kern = oss_dwconv3x3_bwd_fused_kernel<T, MODE>;
+    if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
+    hipLaunchKernelGGL(kern, dim3(C / NCH, B), dim3(256), smem, s, reinterpret_cast<const T *>(x), w, bias,
+                       reinterpret_cast<const T *>(dy), reinterpret_cast<T *>(dx), part, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc);
+    if (defer_finish())
+        defer_sum(part, B, (size_t)C * 10, (size_t)C * (db ? 10 : 9), dw, (size_t)C * 9, db);
+    else
+        hipLaunchKernelGGL(oss_dwconv3x3_wgrad_finish, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, dw, db, B, C);
+    return (int)hipGetLastError();
+}
+
+int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, const float *bias, const void *dy, void *dx,
+                        float *dw, float *db, float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb,
+                        int64_t gsc, int64_t dsb, int64_t dsc, hipStream_t s) {
+    const int nch = mode == kDwGate ? 2 : 1;
+    if (!dwconv3x3_fused_ok(io, H, W, nch) || C % nch != 0) return OSS_ERR_SHAPE;
+    if (mode == kDwGate)
+        return io == OSS_F16 ? bwd_fused_launch<f16_t, kDwGate>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s)
+                             : bwd_fused_launch<bf16_t, kDwGate>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s);
+    return io == OSS_F16 ? bwd_fused_launch<f16_t, kDwSilu>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s)
+                         : bwd_fused_launch<bf16_t, kDwSilu>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s);
 }
 
 template <typename T>

@@ -54,7 +54,14 @@ int scan_bwd_dispatch(const oss_scan_bwd_params &p, int variant, int seg_req, hi
 int scan_bwd_rows_per_wg(int variant);
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups);
 int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int C, int H, int W,
-              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre = nullptr);
+              int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre = nullptr, int act = 0);
+// the convolution fused with what follows it (oss_dwconv.hip): mode 0 = silu (SS2D_1), 1 = gelu gate of the EFFN
+int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch);
+int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
+               int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s);
+int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, const float *bias, const void *dy, void *dx,
+                        float *dw, float *db, float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb,
+                        int64_t gsc, int64_t dsb, int64_t dsc, hipStream_t s);
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
                     int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre = nullptr,
                     void *dpre = nullptr);

@@ -24,7 +24,8 @@ from .channel import ChannelGateFn, chan_gate_bwd, chan_gate_fwd, chan_supported
 from .pointwise import Conv1x1Fn, conv1x1, conv1x1_bwd, conv1x1_fwd  # noqa: F401
 from .core import (SS2DCoreFn, core_supported, cross_merge2, cross_scan2, fused_dt_supported, proj_dgrad, proj_fwd,  # noqa: F401
                    proj_set_path, proj_wgrad, ss2d_core_bwd, ss2d_core_fwd)
-from .dwconv import DWConv3x3Fn, dwconv3x3, dwconv3x3_bwd, dwconv3x3_fwd  # noqa: F401
+from .dwconv import (DWConv3x3Fn, DWGateFn, dwconv3x3, dwconv3x3_bwd, dwconv3x3_fwd, dwconv3x3_gelu_gate,  # noqa: F401
+                     dwconv3x3_silu_bwd, dwconv3x3_silu_fwd, dwgate_bwd, dwgate_fwd)
 from .ffn import GeluGateFn, gelu_gate, gelu_gate_bwd, gelu_gate_fwd  # noqa: F401
 from .layernorm import _CODE_DT, _DT_CODE, LayerNormNCHWFn, layer_norm_nchw, ln_nchw_bwd, ln_nchw_fwd  # noqa: F401
 from .scan import merge4, selective_scan_bwd, selective_scan_fwd  # noqa: F401

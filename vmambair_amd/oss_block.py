@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import (ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, gelu_gate, layer_norm_nchw,
+from .ops import (ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw,
                   split_halves)
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
@@ -71,8 +71,8 @@ class FeedForward(nn.Module):
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
-        h = dwconv3x3(conv1x1(x, self.project_in), self.dwconv)
-        return conv1x1(gelu_gate(h), self.project_out, residual)  # gelu(x1) * x2 on the two channel halves, one kernel
+        # dwconv -> chunk -> gelu(x1) * x2 as one node that never stores the convolution (ops/dwconv.py: DWGateFn)
+        return conv1x1(dwconv3x3_gelu_gate(conv1x1(x, self.project_in), self.dwconv), self.project_out, residual)
 
 
 def _dt_proj_init(dt_rank: int, d_inner: int, dt_scale=1.0, dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
