@@ -244,6 +244,9 @@ size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels
  * of 32 x 32 tiles (fewer re-reads of the operands, fewer waves).  Same results up to the summation order; initial value from
  * the environment variable VMAMBAIR_WGRAD_TILE. */
 void oss_conv1x1_wgrad_set_tile(int mode);
+/* pixels per partial product of the GROUPED weight-gradient launch (oss_flush_wgrads), in units of 512: default 4 (env
+ * VMAMBAIR_WGRAD_SPAN); 1 reproduces the one-problem launches bit for bit, larger values write fewer partial vectors */
+void oss_conv1x1_wgrad_set_span(int mult);
 int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *dbias, float *partials, int batch,
                       int cout, int cin, int pixels, int64_t dy_batch_stride, int64_t dy_channel_stride,
                       int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
@@ -332,7 +335,7 @@ int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, i
  * small finishing launch that adds the partial vectors in a fixed order (~12 such launches per OSS block).  After
  * oss_set_defer_finish(1) those launches are not issued: each call registers its reduction with the library instead
  * (scratch buffers and gradient outputs must then stay alive and unread), and oss_flush_finishes runs ALL of them as
- * one launch: it writes the chunk table (oss_deferred_chunks() entries of sizeof(oss_sum_chunk) bytes, one per <= 64
+ * one launch: it writes the chunk table (oss_deferred_chunks() entries of sizeof(oss_sum_chunk) bytes, one per <= 1024
  * outputs) into host_table (pinned; must stay alive if the call is captured into a hipGraph), copies it to
  * device_table on the stream and launches the summation there.  Same fixed summation order on every run.
  * oss_set_defer_finish(0/1) also drops whatever was registered and not flushed. */

@@ -45,9 +45,9 @@ static std::vector<oss_sum_chunk> g_defer_chunks;
 bool defer_finish() { return g_defer_finish.load() != 0; }
 void defer_sum(const float *src, int K, size_t stride, size_t V, float *dst0, size_t n0, float *dst1) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
-    for (size_t j = 0; j < V;) {   // chunks of <= 64 outputs that do not straddle the dst0 / dst1 boundary
+    for (size_t j = 0; j < V;) {   // chunks of <= 1024 outputs that do not straddle the dst0 / dst1 boundary
         const size_t lim = j < n0 ? n0 : V;
-        const size_t n = std::min<size_t>(64, lim - j);
+        const size_t n = std::min<size_t>(1024, lim - j);
         oss_sum_chunk c;
         c.src = src;
         c.dst = j < n0 ? dst0 + j : dst1 + (j - n0);
@@ -411,6 +411,7 @@ int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstat
     return proj_mfma_ok(io, batch, D, C, R, seqlen) && R >= 1 && R <= kMaxDtRank && dstate <= 64 && seqlen >= 512;
 }
 void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
+void oss_conv1x1_wgrad_set_span(int mult) { conv1x1_wgrad_set_span(mult); }
 
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {

@@ -637,10 +637,10 @@ __device__ __forceinline__ void
 wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ part, int M, int N, int P,
            int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
            int64_t gs_hi, int NB /* N, or N + 1: a virtual all-ones row of x whose column of dW is dbias */,
-           int slab, int nslabs, int by, int bz) {
+           int slab, int nslabs, int by, int bz, int span /* pixels per partial product: a multiple of kWgradSlab */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = by / G, g = by - b * G;
-    const int pbeg = slab * kWgradSlab, pend = min(P, pbeg + kWgradSlab);
+    const int pbeg = slab * span, pend = min(P, pbeg + span);
     const int col = lane & 31, kg = lane >> 5;
     const int mt = (M + 31) >> 5, nt = (NB + 31) >> 5;
     const T *gb = dy + b * gsb + g * gsg;
@@ -667,7 +667,7 @@ wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict_
 
         int pk = pbeg;
 #ifndef OSS_EXP_WGRAD_DIRECT
-        if (aligned && pend - pbeg == kWgradSlab) {
+        for (; aligned && pend - pk >= kWgradSlab; pk += kWgradSlab) {   // full kWgradSlab pieces of the span, one after the other
             // A full slab, operands through LDS.  The MFMA fragment of a lane is 8 consecutive pixels of ITS OWN row (row =
             // lane & 31): loaded straight from memory, one 16-byte load instruction touches 32 rows -- 64 separate cache
             // lines of which it uses 16 bytes each -- and the texture addresser, which takes a cycle per line, was busy for
@@ -683,8 +683,8 @@ wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int mr2 = min(m0 + r8 + 8 * j, M - 1), nr2 = min(n0 + r8 + 8 * j, N - 1);
-                pa[j] = gb + (mr2 / Mh) * gs_hi + (mr2 % Mh) * gsm + pbeg + q * 8;
-                px[j] = xb + nr2 * xsn + pbeg + q * 8;
+                pa[j] = gb + (mr2 / Mh) * gs_hi + (mr2 % Mh) * gsm + pk + q * 8;
+                px[j] = xb + nr2 * xsn + pk + q * 8;
             }
             // a window of WIN pieces in flight: piece pc + WIN is requested as soon as piece pc has left its registers
             constexpr int WIN = PIECES < 4 ? PIECES : 4;
@@ -725,11 +725,11 @@ wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict_
                     acc = Mfma<T>::run(af, bf, acc);
                 }
             }
-            pk = pend;
-        } else
-#endif
-        if (aligned && pend - pbeg == kWgradSlab) {
-            // a full slab: ALL its operand loads (2 x 16 bytes per k-step and lane) are issued before the first MFMA.
+            __builtin_amdgcn_wave_barrier();   // the next piece's LDS writes stay behind this piece's reads
+        }
+#else
+        if (aligned && pend - pk == kWgradSlab) {
+            // (timing experiment) a full slab: ALL its operand loads (2 x 16 bytes per k-step and lane) are issued before the first MFMA.
             // A k-step is one MFMA (64 cycles) but a load is a ~1 us round trip: walked 64 pixels at a time (8 loads,
             // wait, 4 MFMAs) the kernel was a chain of 8 round trips at 1.5 waves per SIMD.
             constexpr int IT = kWgradSlab / 16;
@@ -740,8 +740,8 @@ wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict_
                 qa[u] = u32x4{(uint32_t)lane, (uint32_t)u, 1u, 2u};
                 qb[u] = u32x4{(uint32_t)lane, (uint32_t)u, 3u, 4u};
 #else
-                qa[u] = *reinterpret_cast<const u32x4 *>(ga + pbeg + u * 16 + kg * 8);
-                qb[u] = *reinterpret_cast<const u32x4 *>(xa + pbeg + u * 16 + kg * 8);
+                qa[u] = *reinterpret_cast<const u32x4 *>(ga + pk + u * 16 + kg * 8);
+                qb[u] = *reinterpret_cast<const u32x4 *>(xa + pk + u * 16 + kg * 8);
 #endif
             }
 #pragma unroll
@@ -751,7 +751,9 @@ wgrad_body(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict_
                 acc = Mfma<T>::run(af, bf, acc);
             }
             pk = pend;
-        } else if (aligned) {
+        } else
+#endif
+        if (aligned) {
             // 4 k-steps (64 pixels) per iteration: all eight 16-byte loads are issued before the first MFMA needs them
             for (; pk + 64 <= pend; pk += 64) {
                 u32x4 qa[4], qb[4];
@@ -811,7 +813,7 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
                          int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, int G, int64_t gsg, int64_t xsg, int Mh,
                          int64_t gs_hi, int NB) {
     wgrad_body<T>(dy, x, part, M, N, P, gsb, gsm, xsb, xsn, G, gsg, xsg, Mh, gs_hi, NB, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y,
-                  (int)blockIdx.z);
+                  (int)blockIdx.z, kWgradSlab);
 }
 
 // Grouped launch: ALL weight-gradient products of a backward pass as one kernel.  Nobody needs a weight gradient before the
@@ -828,6 +830,7 @@ struct WgradDesc {
     int M, N, P, G, Mh, NB, slabs, bgs /* batch * G */;
     unsigned first_block;
     int io;
+    int span, reserved_;   // pixels per partial product
 };
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -838,7 +841,7 @@ oss_conv1x1_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint
     const unsigned r = local / (unsigned)d.slabs;
     const int by = (int)(r % (unsigned)d.bgs), bz = (int)(r / (unsigned)d.bgs);
     wgrad_body<T>(reinterpret_cast<const T *>(d.dy), reinterpret_cast<const T *>(d.x), d.part, d.M, d.N, d.P, d.gsb, d.gsm, d.xsb,
-                  d.xsn, d.G, d.gsg, d.xsg, d.Mh, d.gs_hi, d.NB, slab, d.slabs, by, bz);
+                  d.xsn, d.G, d.gsg, d.xsg, d.Mh, d.gs_hi, d.NB, slab, d.slabs, by, bz, d.span);
 }
 
 // out[j] = sum over the nslab partial vectors (fixed order), j < nw -> dw[j], else db[j - nw].
@@ -1151,18 +1154,37 @@ static void wgrad_tiles_launch(int mode, const T *dy, const T *x, float *part, i
 
 int conv1x1_wgrad_slabs(int P) { return (P + kWgradSlab - 1) / kWgradSlab; }
 
+// Pixels per partial product of the GROUPED launch, in units of kWgradSlab.  One-problem launches keep 1 (they need every
+// workgroup they can get); in the grouped launch thousands of workgroups are queued anyway and every partial vector is
+// M x N floats written once and read once by the finishing sum -- at 512 pixels the headline step moved 0.9 GB of partials
+// each way (the finishing launch ran 222 us at memory speed).  Initial value from VMAMBAIR_WGRAD_SPAN.
+static std::atomic<int> g_wgrad_span{-1};
+static int wgrad_span_mult() {
+    int m = g_wgrad_span.load();
+    if (m < 0) {
+        const char *e = std::getenv("VMAMBAIR_WGRAD_SPAN");
+        m = e ? std::atoi(e) : 4;
+        m = m < 1 ? 1 : (m > 64 ? 64 : m);
+        g_wgrad_span.store(m);
+    }
+    return m;
+}
+void conv1x1_wgrad_set_span(int mult) { g_wgrad_span.store(mult < 1 ? 1 : (mult > 64 ? 64 : mult)); }
+
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
                   int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G, int64_t gsg, int64_t xsg, int Mh,
                   int64_t gs_hi, float *db) {
     const int NB = N + (db ? 1 : 0);
     if (G < 1 || (size_t)B * G > 65535) return OSS_ERR_SHAPE;
     if (Mh <= 0 || Mh > M) Mh = M;
-    const int slabs = conv1x1_wgrad_slabs(P);
+    int slabs = conv1x1_wgrad_slabs(P);
     const int tiles = ((M + 31) / 32) * ((NB + 31) / 32);
     dim3 grid(slabs, B * G, (tiles + 3) / 4);
     const int tmode = wgrad_tile_mode();
     if (defer_wgrad() && !tmode && (io == OSS_BF16 || io == OSS_F16) && (size_t)slabs * B * G * ((tiles + 3) / 4) < (1u << 24)) {
         WgradDesc d;
+        d.span = kWgradSlab * wgrad_span_mult(); d.reserved_ = 0;
+        slabs = (P + d.span - 1) / d.span;   // never more than conv1x1_wgrad_slabs(P): the caller's partial buffer is large enough
         d.dy = dy; d.x = x; d.part = part;
         d.gsb = gsb; d.gsm = gsm; d.xsb = xsb; d.xsn = xsn; d.gsg = gsg; d.xsg = xsg; d.gs_hi = gs_hi;
         d.M = M; d.N = N; d.P = P; d.G = G; d.Mh = Mh; d.NB = NB; d.slabs = slabs; d.bgs = B * G;

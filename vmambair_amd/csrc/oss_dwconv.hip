@@ -124,9 +124,11 @@ __device__ __forceinline__ void row10(const T *plane, int h, int dy, int H, int 
     const int hh = h + dy;
     const bool ok = hh >= 0 && hh < H;
     float m[8];
-    load8<T>(plane + (int64_t)(ok ? hh : h) * W + w0, m);
+    u32x4 q = *reinterpret_cast<const u32x4 *>(plane + (int64_t)(ok ? hh : h) * W + w0);
+    if (!ok) q = u32x4{0u, 0u, 0u, 0u};   // a row outside the image: four selects on the packed words instead of eight on the values
+    unpack2<T>(q.x, m[0], m[1]); unpack2<T>(q.y, m[2], m[3]); unpack2<T>(q.z, m[4], m[5]); unpack2<T>(q.w, m[6], m[7]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j + 1] = ok ? m[j] : 0.f;
+    for (int j = 0; j < 8; ++j) v[j + 1] = m[j];
     v[0] = shift_from_prev_lane(v[8], 0.f, first);
     v[9] = shift_from_next_lane(v[1], 0.f, last);
 }
@@ -244,7 +246,22 @@ oss_dwconv3x3_wgrad_wide_kernel(const T *__restrict__ x, const T *__restrict__ d
 // four plane round trips through HBM become one launch that reads x, dy and writes dx.
 enum { kDwSilu = 0, kDwGate = 1 };
 
-__device__ __forceinline__ float gelu_cdf(float a) { return 0.5f * (1.f + erff(a * 0.70710678118654752f)); }
+// Phi(a) and phi(a) of the exact (erf) gelu from ONE exponential: erf(|z|) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),
+// t = 1 / (1 + p |z|)  (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- fp32 round-off level, four orders of magnitude under the
+// rounding of the 16-bit tensors these kernels read and write), and with z = a / sqrt(2) the exponential is the one of
+// phi(a) = exp(-a^2 / 2) / sqrt(2 pi).  The library erff costs ~35 instructions behind a divergent branch; this is 12.
+__device__ __forceinline__ void gelu_parts(float a, float &cdf, float &pdf) {
+    const float e = exp2_hw(-0.5f * a * a * kLog2e);
+    const float z = fabsf(a) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float half_tail = 0.5f * poly * t * e;          // (1 - erf|z|) / 2
+    cdf = a >= 0.f ? 1.f - half_tail : half_tail;
+    pdf = 0.3989422804014327f * e;
+}
 
 template <typename T>
 __device__ __forceinline__ void conv_rows(const float (&v)[3][10], const float *__restrict__ k, float bv, float (&acc)[8]) {
@@ -282,7 +299,11 @@ oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, cons
     conv_rows<T>(v, k2, b2, x2);
     if (!live) return;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x1[j] = x1[j] * gelu_cdf(x1[j]) * x2[j];
+    for (int j = 0; j < 8; ++j) {
+        float cdf, pdf;
+        gelu_parts(x1[j], cdf, pdf);
+        x1[j] = x1[j] * cdf * x2[j];
+    }
     store8<T>(op + (int64_t)h * W + w0, x1);
 }
 
@@ -307,82 +328,71 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
         const int ch = i / (2 * lpr), r = i - ch * 2 * lpr, row = r < lpr ? 0 : H + 1, col = (r < lpr ? r : r - lpr) << 3;
         *reinterpret_cast<u32x4 *>(sg + ch * plane + (size_t)row * W + col) = u32x4{0u, 0u, 0u, 0u};
     }
-    float acc[NCH][10];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-        for (int i = 0; i < 10; ++i) acc[ch][i] = 0.f;
+    // pass 1: the gradient that reaches the convolution, rounded to T, into the LDS planes
     for (int g0 = 0; g0 < ngroups; g0 += 256) {   // uniform trip count: every lane takes part in the DPP halo exchange
         const int g = g0 + threadIdx.x;
         const bool live = g < ngroups;
         const int gc = live ? g : ngroups - 1;
         const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
         const bool first = cg == 0, last = cg == lpr - 1;
-        float gv[8], v[NCH][3][10], pre[NCH][8], gq[NCH][8];
+        float gv[8], pre[NCH][8], gq[NCH][8];
         load8<T>(gp + (int64_t)h * W + w0, gv);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int c = c0 + ch * cstep;
             const T *xp = x + b * xsb + c * xsc;
+            float v[3][10];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) row10<T>(xp, h, r - 1, H, W, w0, first, last, v[ch][r]);
-            conv_rows<T>(v[ch], w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
+            for (int r = 0; r < 3; ++r) row10<T>(xp, h, r - 1, H, W, w0, first, last, v[r]);
+            conv_rows<T>(v, w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
+            __builtin_amdgcn_sched_barrier(0);   // one channel's rows at a time in registers
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if constexpr (MODE == kDwSilu) {
                 gq[0][j] = gv[j] * dsilu_f32(pre[0][j]);
             } else {
-                const float a = pre[0][j], cdf = gelu_cdf(a);
-                const float pdf = 0.3989422804014327f * exp2_hw(-0.5f * a * a * kLog2e);
+                const float a = pre[0][j];
+                float cdf, pdf;
+                gelu_parts(a, cdf, pdf);
                 gq[0][j] = gv[j] * pre[1][j] * __builtin_fmaf(a, pdf, cdf);
                 gq[1][j] = gv[j] * a * cdf;
             }
         }
+        if (live) {
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (live) store8<T>(sg + ch * plane + (size_t)(h + 1) * W + w0, gq[ch]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gq[ch][j] = live ? to_f32(from_f32<T>(gq[ch][j])) : 0.f;   // both gradients see the rounded value
-            acc[ch][9] += ((gq[ch][0] + gq[ch][1]) + (gq[ch][2] + gq[ch][3])) + ((gq[ch][4] + gq[ch][5]) + (gq[ch][6] + gq[ch][7]));
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int dxx = 0; dxx < 3; ++dxx) {
-                    float a = acc[ch][r * 3 + dxx];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a = __builtin_fmaf(gq[ch][j], v[ch][r][j + dxx], a);
-                    acc[ch][r * 3 + dxx] = a;
-                }
+            for (int ch = 0; ch < NCH; ++ch) store8<T>(sg + ch * plane + (size_t)(h + 1) * W + w0, gq[ch]);
         }
     }
+    __syncthreads();   // the LDS planes are complete
+    // pass 2: with q = the gradient rows h - 1 .. h + 1 out of LDS (row h of the image is LDS row h + 1; both gradients below see
+    // the rounded values),  dx[p] = sum_t k[8 - t] q[p + t]  (the mirrored stencil)  and, from the same registers,
+    // dw[8 - t] += x[p] q[p + t],  db += q[p]
+    // (one channel at a time, all of its groups: the second channel's rows, addresses and sums would not fit the 128 registers
+    // of four waves per SIMD next to the first one's)
     __shared__ float red[4][NCH * 10];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = c0 + ch * cstep;
+        const T *sp = sg + ch * plane;
+        const T *xp = x + b * xsb + c * xsc;
+        T *dxp = dx + b * dsb + c * dsc;
+        float acc[10];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const float s = segment_sum_to_last<64>(acc[ch][i]);
-            if (lane == 63) red[wave][ch * 10 + i] = s;
-        }
-    __syncthreads();   // the LDS planes are complete, and so is red[]
-    if (threadIdx.x < NCH * 10) {
-        const int ch = threadIdx.x / 10, i = threadIdx.x - ch * 10, c = c0 + ch * cstep;
-        part[(size_t)b * C * 10 + (i < 9 ? (size_t)c * 9 + i : (size_t)9 * C + c)] =
-            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    }
-    // pass 2: dx = the mirrored stencil over the LDS planes (row h of the image is LDS row h + 1)
-    for (int g0 = 0; g0 < ngroups; g0 += 256) {
-        const int g = g0 + threadIdx.x;
-        const bool live = g < ngroups;
-        const int gc = live ? g : ngroups - 1;
-        const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
-        const bool first = cg == 0, last = cg == lpr - 1;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int c = c0 + ch * cstep;
-            const T *sp = sg + ch * plane;
-            float o[8];
+        for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+        for (int g0 = 0; g0 < ngroups; g0 += 256) {
+            const int g = g0 + threadIdx.x;
+            const bool live = g < ngroups;
+            const int gc = live ? g : ngroups - 1;
+            const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
+            const bool first = cg == 0, last = cg == lpr - 1;
+            float xc[8], o[8];
+            {
+                u32x4 q = *reinterpret_cast<const u32x4 *>(xp + (int64_t)h * W + w0);
+                if (!live) q = u32x4{0u, 0u, 0u, 0u};   // a lane that shadows the last group adds nothing to the sums
+                unpack2<T>(q.x, xc[0], xc[1]); unpack2<T>(q.y, xc[2], xc[3]); unpack2<T>(q.z, xc[4], xc[5]); unpack2<T>(q.w, xc[6], xc[7]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
@@ -397,9 +407,31 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     o[j] = __builtin_fmaf(k0, vv[j], __builtin_fmaf(k1, vv[j + 1], __builtin_fmaf(k2, vv[j + 2], o[j])));
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    float a = acc[8 - (r * 3 + cc)];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a = __builtin_fmaf(xc[j], vv[j + cc], a);
+                    acc[8 - (r * 3 + cc)] = a;
+                }
+                if (r == 1) {
+                    const float sq = ((vv[1] + vv[2]) + (vv[3] + vv[4])) + ((vv[5] + vv[6]) + (vv[7] + vv[8]));
+                    acc[9] += live ? sq : 0.f;
+                }
             }
-            if (live) store8<T>(dx + b * dsb + c * dsc + (int64_t)h * W + w0, o);
+            if (live) store8<T>(dxp + (int64_t)h * W + w0, o);
         }
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const float s = segment_sum_to_last<64>(acc[i]);
+            if (lane == 63) red[wave][ch * 10 + i] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NCH * 10) {
+        const int ch = threadIdx.x / 10, i = threadIdx.x - ch * 10, c = c0 + ch * cstep;
+        part[(size_t)b * C * 10 + (i < 9 ? (size_t)c * 9 + i : (size_t)9 * C + c)] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
 }
 

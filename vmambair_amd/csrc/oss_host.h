@@ -78,6 +78,7 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const void *res = nullptr);
 int conv1x1_wgrad_slabs(int P);
 void conv1x1_wgrad_set_tile(int mode);
+void conv1x1_wgrad_set_span(int mult);
 int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float *part, int B, int M, int N, int P,
                   int64_t gsb, int64_t gsm, int64_t xsb, int64_t xsn, hipStream_t s, int G = 1, int64_t gsg = 0, int64_t xsg = 0,
                   int Mh = 0, int64_t gs_hi = 0, float *db = nullptr);

@@ -66,32 +66,75 @@ oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__re
 }
 
 // One launch for ALL deferred partial-sum reductions of a backward pass (weight-gradient split-K slabs, per-workgroup
-// LayerNorm / depth-wise-conv / channel-branch partials): chunk c = 64 consecutive outputs of one reduction,
-// out[j] = sum_{k < K} src[k * stride + j] in a fixed order (4 slices of the k range, combined in a fixed order).
+// LayerNorm / depth-wise-conv / channel-branch partials): chunk c = up to 1024 consecutive outputs of one reduction, four per
+// lane (16-byte loads when source and destination allow), out[j] = sum_{k < K} src[k * stride + j] in a FIXED order -- the k range
+// in 4 interleaved slices of 4 interleaved partial sums each, combined pairwise (the same on every run; the separate
+// finishing kernels each have their own fixed order).
+// (Round 2 gave every 64 outputs a workgroup of their own: 190 K workgroups of two loads per lane, 228 us per step.)
+__device__ __forceinline__ float sum_slices(const float (&a)[4][4]) {
+    float r[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) r[sl] = (a[sl][0] + a[sl][1]) + (a[sl][2] + a[sl][3]);
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 __global__ void __launch_bounds__(256)
 oss_sum_partials_kernel(const oss_sum_chunk *__restrict__ chunks) {
-    __shared__ float red[4][64];
     const oss_sum_chunk c = chunks[blockIdx.x];
-    const int colx = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const float *src = reinterpret_cast<const float *>(c.src);
-    float s = 0.f;
-    if (colx < c.n) {
-        const float *pp = src + c.j0 + colx;
-        const size_t st = (size_t)c.stride;
-        int k = slice;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (; k + 12 < c.K; k += 16) {
-            s0 += pp[(size_t)k * st];
-            s1 += pp[(size_t)(k + 4) * st];
-            s2 += pp[(size_t)(k + 8) * st];
-            s3 += pp[(size_t)(k + 12) * st];
+    const int j = threadIdx.x * 4;
+    if (j >= c.n) return;
+    const float *pp = reinterpret_cast<const float *>(c.src) + c.j0 + j;
+    float *dst = reinterpret_cast<float *>(c.dst) + j;
+    const size_t st = (size_t)c.stride;
+    const bool vec = j + 4 <= c.n && ((reinterpret_cast<uintptr_t>(pp) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (st & 3) == 0;
+    // acc[slice][i] takes k = slice + 4 i + 16 m, i.e. element [q & 3][q >> 2] of a group of 16 rows; the register arrays
+    // are only ever indexed by unrolled constants (a run-time index would move them to scratch memory), so the tail of the
+    // k range is a group of wave-uniformly predicated loads that add zeros
+    if (vec) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[a][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < c.K; k += 16) {
+            f32x4 v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                v[q] = k + q < c.K ? *reinterpret_cast<const f32x4 *>(pp + (size_t)(k + q) * st) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] += v[q];
         }
-        for (; k < c.K; k += 4) s0 += pp[(size_t)k * st];
-        s = (s0 + s1) + (s2 + s3);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a[4][4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[sl][i] = acc[sl][i][e];
+            o[e] = sum_slices(a);
+        }
+        *reinterpret_cast<f32x4 *>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+    } else {
+        const int ne = min(4, c.n - j);
+        float a[4][4][4];   // [element][slice][i]
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[e][sl][i] = 0.f;
+        for (int k = 0; k < c.K; k += 16) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    a[e][q & 3][q >> 2] += (k + q < c.K && e < ne) ? pp[(size_t)(k + q) * st + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < ne) dst[e] = sum_slices(a[e]);
     }
-    red[slice][colx] = s;
-    __syncthreads();
-    if (slice == 0 && colx < c.n) reinterpret_cast<float *>(c.dst)[colx] = (red[0][colx] + red[1][colx]) + (red[2][colx] + red[3][colx]);
 }
 
 int sum_partials_multi(const oss_sum_chunk *chunks, int n_chunks, hipStream_t s) {
