@@ -414,6 +414,17 @@ int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const flo
                     float *dweight, float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels,
                     int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
                     int64_t gate_channel_stride, int64_t dgate_batch_stride, oss_stream_t stream);
+/* The same with the incoming gradient taken as dy * (1 + dy_mul[b, c]) + add_scale * dy_add[b, c] (both (batch, channels) float;
+ * dy_mul NULL: no factor): the backward of SS2D_1's channel gate  out = y2 * c + y2 | y2 + c,  c = f(mean_hw(y2))
+ * (MambaSISR6_arch.py:495-496) is  d y2 = g * (1 + c) | g  +  d pooled / (H W), an affine map per (image, channel) of the gradient g
+ * that reaches `out` -- applied here on load instead of in a pass of its own (oss_row_affine) that writes d y2 only for this
+ * kernel to read it back. */
+int oss_ln_nchw_bwd_affine(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
+                           const void *gate, const void *dy, const float *dy_mul, const float *dy_add, float add_scale,
+                           const float *mean, const float *rstd, void *dx, void *dgate, float *dweight, float *dbias, float *partials,
+                           const void *skip_grad, int batch, int channels, int pixels, int64_t x_batch_stride,
+                           int64_t x_channel_stride, int64_t gate_batch_stride, int64_t gate_channel_stride,
+                           int64_t dgate_batch_stride, oss_stream_t stream);
 
 /* Optional per-launch timing of the two scan kernels (bench.py's roofline leg): when enabled every
  * main forward / backward kernel launch is bracketed by HIP events recorded on the launch stream.

@@ -111,7 +111,13 @@ def install():
         B, C, H, W = x.shape
         return [y.to(codes[out_code]), mu.reshape(B, H * W), rstd.reshape(B, H * W)]
 
-    def ln_bwd(x, weight, bias, gate, dy, mean, rstd, skip_grad=None, dgate_into=None):
+    def ln_bwd(x, weight, bias, gate, dy, mean, rstd, skip_grad=None, dgate_into=None, dy_mul=None, dy_add=None, add_scale=1.0):
+        if dy_add is not None:   # the channel gate's backward folded into the load (ops/layernorm.py)
+            dyf = dy.float()
+            if dy_mul is not None:
+                dyf = dyf * (1.0 + dy_mul.float())[:, :, None, None]
+            dy = (dyf + add_scale * dy_add.float()[:, :, None, None])
+        out_dt = dy.dtype if dy_add is None else (gate.dtype if gate is not None else x.dtype)
         leaves = [x.detach().float().requires_grad_(), weight.detach().float().requires_grad_()]
         bb = bias.detach().float().requires_grad_() if bias is not None else None
         gg = gate.detach().float().requires_grad_() if gate is not None else None
@@ -121,7 +127,7 @@ def install():
         gr = list(torch.autograd.grad(y, ins, dy.float()))
         dx, dw = gr.pop(0), gr.pop(0)
         db = gr.pop(0) if bb is not None else torch.empty(0)
-        dg = gr.pop(0).to(dy.dtype) if gg is not None else torch.empty(0)
+        dg = gr.pop(0).to(out_dt) if gg is not None else torch.empty(0)
         if skip_grad is not None:
             dx = dx + skip_grad.float()
         if dgate_into is not None and gg is not None and dgate_into.dtype == dg.dtype:
@@ -205,7 +211,7 @@ def install():
         return [out.to(y2.dtype), c, e, e, e, e, e, e, e]
 
     def chan_bwd(g, y2, c, pooled, zt, dts, hs, y, yc, stat, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
-                 cn_w, cn_b, mul_mode):
+                 cn_w, cn_b, mul_mode, fold=False):
         prm = [cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b, cn_w, cn_b]
         leaves = [y2.detach().float().requires_grad_()] + [None if t is None else t.detach().float().requires_grad_() for t in prm]
         with torch.enable_grad():
@@ -218,7 +224,11 @@ def install():
         # flat layout of oss_chan_bwd: cn_w, cn_b, cout_w, cout_b, A_logs, Dsc, dt_bias, Wdtc, Wxc, cin_w, cin_b
         flat = torch.cat([get(lv[9], 0), get(lv[10], 0), get(lv[7], dc), get(lv[8], 1), get(lv[5], 0), get(lv[6], 0),
                           get(lv[4], 0), get(lv[3], 0), get(lv[2], 0), get(lv[0], dc), get(lv[1], dc)])
-        return [gr[id(leaves[0])].to(y2.dtype), flat]
+        dy2 = gr[id(leaves[0])]
+        if fold:   # d pooled alone: dy2 = g * (1 + c) [or g] + d pooled / (H W)
+            direct = g.float() * (1.0 + c.float())[:, :, None, None] if mul_mode else g.float()
+            return [(dy2 - direct).sum(dim=(2, 3)), flat]
+        return [dy2.to(y2.dtype), flat]
 
     def gg_fwd(h):
         x1, x2 = h.float().chunk(2, dim=1)

@@ -251,3 +251,65 @@ def test_conv1x1_with_fused_residual(B, Cin, Cout, H, W):
     assert_close(y, want, 2e-2, 3e-2, "conv + residual")
     y.backward(dy.to(DEV))
     assert torch.equal(rd.grad.cpu(), dy), "the residual's gradient is dy itself"
+
+
+@pytest.mark.parametrize("shape,gated,xdt", [((2, 96, 64, 64), True, torch.float32), ((3, 48, 16, 24), True, torch.float32),
+                                            ((2, 192, 8, 8), True, torch.float32), ((2, 96, 32, 32), False, torch.bfloat16),
+                                            ((1, 600, 4, 6), True, torch.float32)])
+@pytest.mark.parametrize("with_mul", [True, False])
+def test_layernorm_backward_with_the_channel_gate_folded_into_its_load(shape, gated, xdt, with_mul):
+    """oss_ln_nchw_bwd_affine: dy * (1 + mul[b, c]) + s * add[b, c] formed on load == the same backward given the materialised
+    gradient (what oss_row_affine used to write), for the register-resident and the streaming (C = 600) kernels"""
+    torch.manual_seed(21)
+    B, C, H, W = shape
+    x = torch.randn(shape, device=DEV).to(xdt)
+    w, b = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    gate = torch.randn(shape, device=DEV).to(torch.bfloat16) if gated else None
+    dy = torch.randn(shape, device=DEV).to(torch.bfloat16)
+    mul = torch.randn(B, C, device=DEV) * 0.3 if with_mul else None
+    add = torch.randn(B, C, device=DEV)
+    scale = 1.0 / (H * W)
+    y, mean, rstd = ops.ln_nchw_fwd(x, w, b, gate, 2)
+    dy_eff = dy.float() * ((1.0 + mul)[:, :, None, None] if with_mul else 1.0) + scale * add[:, :, None, None]
+    ref = ops.ln_nchw_bwd(x, w, b, gate, dy_eff, mean, rstd) if not gated and xdt == torch.bfloat16 else None
+    # reference: plain PyTorch fp32 autograd of LN (* silu(gate)) with the effective gradient
+    xr, wr, br = x.float().clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    gr_ = gate.float().clone().requires_grad_() if gated else None
+    mu = xr.mean(1, keepdim=True)
+    var = xr.var(1, keepdim=True, unbiased=False)
+    yr = (xr - mu) * (var + 1e-5).rsqrt() * wr.view(1, -1, 1, 1) + br.view(1, -1, 1, 1)
+    if gated:
+        yr = yr * torch.nn.functional.silu(gr_)
+    yr.backward(dy_eff)
+    dx, dgate, dw, db = torch.ops.vmambair.ln_nchw_bwd(x, w, b, gate, dy, mean, rstd, None, None, mul, add, scale)
+    lo = xdt == torch.float32
+    assert_close(dx, xr.grad, 2e-3 if lo else 2e-2, 2e-3 if lo else 4e-2, "dx")
+    assert_close(dw, wr.grad, 2e-3, 2e-3 * float(wr.grad.abs().max()), "dw")
+    assert_close(db, br.grad, 2e-3, 2e-3 * float(br.grad.abs().max()), "db")
+    if gated:
+        assert_close(dgate, gr_.grad, 2e-2, 4e-2, "dgate")
+    assert ref is None or ref[0].shape == dx.shape
+
+
+def test_norm_channel_gate_node_matches_the_two_separate_nodes():
+    """NormChannelGateFn (out_norm * silu(z) -> channel branch -> gate, d y2 never materialised) against LayerNormNCHWFn followed by
+    ChannelGateFn on the same tensors: every gradient to bf16 round-off of the one tensor (d y2) the fused node does not round"""
+    from vmambair_amd import oss_block
+    torch.manual_seed(22)
+    m = oss_block.SS2D_1(d_model=48, ssm_ratio=1, variant="srgan").to(DEV)
+    x = torch.randn(2, 48, 32, 32, device=DEV)
+    gy = torch.randn(2, 48, 32, 32, device=DEV)
+    res = []
+    for fused in (True, False):
+        oss_block.NORM_CHAN_FUSED = fused
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        y.backward(gy)
+        res.append((y.detach().float(), xi.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    oss_block.NORM_CHAN_FUSED = True
+    assert torch.equal(res[0][0], res[1][0]), "the forward is the same kernels"
+    assert_close(res[0][1], res[1][1], 2e-2, 2e-2 * float(res[1][1].abs().max()), "dx")
+    for k, g in res[1][2].items():
+        assert_close(res[0][2][k], g, 3e-2, 3e-2 * max(float(g.abs().max()), 1e-6), k)

@@ -596,6 +596,20 @@ int oss_ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weig
                        pixels, xsb, xsc, gsb, gsc, reinterpret_cast<hipStream_t>(stream), skip_grad, dgate_batch_stride);
 }
 
+int oss_ln_nchw_bwd_affine(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate,
+                           const void *dy, const float *dy_mul, const float *dy_add, float add_scale, const float *mean,
+                           const float *rstd, void *dx,
+                           void *dgate, float *dweight, float *dbias, float *partials, const void *skip_grad, int batch,
+                           int channels, int pixels, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
+                           int64_t dgate_batch_stride, oss_stream_t stream) {
+    if (!x || !weight || !dy || !mean || !rstd || !dx || !dweight || !partials || !dy_add) return OSS_ERR_NULL;
+    if (gate && !dgate) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
+    return ln_nchw_bwd(xt, yt, x, weight, bias, gate, dy, mean, rstd, dx, dgate, dweight, dbias, partials, batch, channels,
+                       pixels, xsb, xsc, gsb, gsc, reinterpret_cast<hipStream_t>(stream), skip_grad, dgate_batch_stride, dy_mul,
+                       dy_add, add_scale);
+}
+
 size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels) {
     if (batch <= 0 || channels <= 0 || pixels <= 0) return 0;
     return ln_nchw_bwd_partial_floats(batch, channels, pixels);

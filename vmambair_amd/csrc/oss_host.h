@@ -72,7 +72,8 @@ size_t ln_nchw_bwd_partial_floats(int B, int C, int P);
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
                 float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s,
-                const void *res = nullptr, int64_t dgsb = 0);
+                const void *res = nullptr, int64_t dgsb = 0, const float *dy_mul = nullptr, const float *dy_add = nullptr,
+                float add_scale = 1.f);
 int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, hipStream_t s);
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const void *res = nullptr);

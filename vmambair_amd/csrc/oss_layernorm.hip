@@ -156,7 +156,11 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
                        const float *__restrict__ rstd_in, TX *__restrict__ dx, TY *__restrict__ dgate,
                        float *__restrict__ part /*[nblk][2][C]*/, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb,
                        int64_t gsc, const TX *__restrict__ res /* (B, C, P) or NULL: added to dx (gradient of a skip connection) */,
-                       int64_t dgsb /* batch stride of dgate (channel stride P): lets it land in one half of a wider buffer */) {
+                       int64_t dgsb /* batch stride of dgate (channel stride P): lets it land in one half of a wider buffer */,
+                       const float *__restrict__ dy_mul, const float *__restrict__ dy_add, float add_scale /* dy_add != NULL: the
+                       gradient that enters is dy * (1 + dy_mul[b, c]) + add_scale * dy_add[b, c] (dy_mul NULL: dy + ...), both
+                       (B, C) -- the backward of SS2D_1's channel gate (y2 * c + y2 with c a function of mean_hw(y2)) folded into
+                       this kernel's load instead of a pass of its own */) {
     __shared__ float red[2][kLnMaxWaves * 64 * V];
     // per-channel dweight / dbias partials of this workgroup, staged here and written out in one coalesced pass: stored
     // to global memory channel by channel inside the first pass, every store dragged an s_waitcnt vmcnt behind it that
@@ -191,11 +195,16 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
     for (int u = 0; u < V; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
     // the wave's weights and biases as ONE vector load each (lane i = channel slot i): a scalar load per channel, waited for
     // inside the pass, was a round trip per channel
-    float wvec = 0.f, bvec = 0.f;
+    float wvec = 0.f, bvec = 0.f, mvec = 1.f, avec = 0.f;
+    const bool affine = dy_add != nullptr, scaled = dy_mul != nullptr;
+    const float *mulp = scaled ? dy_mul + (size_t)b * C : w, *addp = affine ? dy_add + (size_t)b * C : w;   // always readable
     if constexpr (CPW > 0) {
         const int cs = min(wave + min(lane, CPW - 1) * nw, C - 1);
         wvec = w[cs];
         bvec = with_bias ? bias[cs] : 0.f;
+        const float mr = mulp[cs], ar = addp[cs];
+        mvec = scaled ? 1.f + mr : 1.f;
+        avec = affine ? ar * add_scale : 0.f;
     }
     auto first = [&](int c, float wc, const float (&xval)[V], const float (&gy)[V], const float (&zval)[V]) {
         float aw = 0.f, ab = 0.f;
@@ -239,6 +248,14 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
 #pragma unroll
                 for (int u = 0; u < V; ++u) rv[i][u] = 0.f;
         }
+        if (affine) {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                const float mi = ln_lane_bcast(mvec, i), ai = ln_lane_bcast(avec, i);
+#pragma unroll
+                for (int u = 0; u < V; ++u) gv[i][u] = __builtin_fmaf(gv[i][u], mi, ai);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < CPW; ++i) { const int c = wave + i * nw; if (c < C) first(c, ln_lane_bcast(wvec, i), xv[i], gv[i], zv[i]); }
     } else {
@@ -246,6 +263,11 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
             float t[V], g[V], z[V];
             load_v<TX, V>(xp + c * xsc, t);
             load_v<TY, V>(gyp + (size_t)c * P, g);
+            if (affine) {
+                const float mi = scaled ? 1.f + mulp[c] : 1.f, ai = addp[c] * add_scale;
+#pragma unroll
+                for (int u = 0; u < V; ++u) g[u] = __builtin_fmaf(g[u], mi, ai);
+            }
 #pragma unroll
             for (int u = 0; u < V; ++u) z[u] = 0.f;
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
@@ -293,6 +315,11 @@ oss_ln_nchw_bwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
             float t[V], g[V], z[V], r[V];
             load_v<TX, V>(xp + c * xsc, t);
             load_v<TY, V>(gyp + (size_t)c * P, g);
+            if (affine) {
+                const float mi = scaled ? 1.f + mulp[c] : 1.f, ai = addp[c] * add_scale;
+#pragma unroll
+                for (int u = 0; u < V; ++u) g[u] = __builtin_fmaf(g[u], mi, ai);
+            }
 #pragma unroll
             for (int u = 0; u < V; ++u) { z[u] = 0.f; r[u] = 0.f; }
             if constexpr (GATE) load_v<TY, V>(gp + c * gsc, z);
@@ -378,7 +405,9 @@ static int ln_fwd_t(const void *x, const float *w, const float *bias, const void
 template <typename TX, typename TY>
 static int ln_bwd_t(const void *x, const float *w, const float *bias, const void *gate, const void *dy, const float *mean,
                     const float *rstd, void *dx, void *dgate, float *dw, float *db, float *part, int B, int C, int P,
-                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res, int64_t dgsb) {
+                    int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res, int64_t dgsb,
+                    const float *dy_mul, const float *dy_add, float add_scale) {
+    if (dy_mul != nullptr && dy_add == nullptr) return OSS_ERR_NULL;
     if (dgsb <= 0) dgsb = (int64_t)C * P;
     const int nw = ln_waves(B, C, P);
     const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, dy, dx) && dgsb % 2 == 0 &&
@@ -393,8 +422,8 @@ static int ln_bwd_t(const void *x, const float *w, const float *bias, const void
     const TY *dyp = reinterpret_cast<const TY *>(dy);
     TX *dxp = reinterpret_cast<TX *>(dx);
     TY *dgp = reinterpret_cast<TY *>(dgate);
-    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, true, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp, dgsb);
-    else      OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, false, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp, dgsb);
+    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, true, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp, dgsb, dy_mul, dy_add, add_scale);
+    else      OSS_LN_LAUNCH(oss_ln_nchw_bwd_kernel, false, xp, w, bias, gp, dyp, mean, rstd, dxp, dgp, part, C, P, xsb, xsc, gsb, gsc, rp, dgsb, dy_mul, dy_add, add_scale);
     if (defer_finish())
         defer_sum(part, nblk, (size_t)2 * C, (size_t)(db ? 2 : 1) * C, dw, (size_t)C, db);
     else
@@ -423,8 +452,8 @@ int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,
                 float *part, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *res,
-                int64_t dgsb) {
-    OSS_LN_DISPATCH(ln_bwd_t, x, w, bias, gate, dy, mean, rstd, dx, dgate, dw, db, part, B, C, P, xsb, xsc, gsb, gsc, s, res, dgsb)
+                int64_t dgsb, const float *dy_mul, const float *dy_add, float add_scale) {
+    OSS_LN_DISPATCH(ln_bwd_t, x, w, bias, gate, dy, mean, rstd, dx, dgate, dw, db, part, B, C, P, xsb, xsc, gsb, gsc, s, res, dgsb, dy_mul, dy_add, add_scale)
 }
 
 }  // namespace oss

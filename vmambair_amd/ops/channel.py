@@ -67,8 +67,9 @@ def chan_gate_bwd(g: torch.Tensor, y2: torch.Tensor, c: torch.Tensor, pooled: to
                   hs: torch.Tensor, y: torch.Tensor, yc: torch.Tensor, stat: torch.Tensor, cin_w: Optional[torch.Tensor],
                   cin_b: Optional[torch.Tensor], Wxc: torch.Tensor, Wdtc: torch.Tensor, dt_bias: torch.Tensor,
                   A_logs: torch.Tensor, Dsc: torch.Tensor, cout_w: Optional[torch.Tensor], cout_b: Optional[torch.Tensor],
-                  cn_w: torch.Tensor, cn_b: torch.Tensor, mul_mode: bool) -> List[torch.Tensor]:
-    """-> [dy2 (y2 dtype), grads (flat fp32, layout of oss_chan_bwd)]"""
+                  cn_w: torch.Tensor, cn_b: torch.Tensor, mul_mode: bool, fold: bool = False) -> List[torch.Tensor]:
+    """-> [dy2 (y2 dtype), grads (flat fp32, layout of oss_chan_bwd)]; ``fold``: -> [dpooled (B, d) fp32, grads] instead -- the
+    caller forms  dy2 = g * (1 + c) [or g] + dpooled / (H W)  itself (NormChannelGateFn: inside the LayerNorm backward's load)"""
     B, d, H, W = y2.shape
     y2, g = _planes(y2), _planes(g)
     if g.dtype != y2.dtype:
@@ -81,7 +82,7 @@ def chan_gate_bwd(g: torch.Tensor, y2: torch.Tensor, c: torch.Tensor, pooled: to
     gc, dpool = torch.empty((B, d), **f), torch.empty((B, d), **f)
     grads = torch.empty((int(lib.oss_chan_grad_floats(d, dc, Rc, Cc)),), **f)
     scratch = torch.empty((int(lib.oss_chan_bwd_scratch_floats(B, d, dc, Rc, Cc)),), **f)
-    dy2 = torch.empty((B, d, H, W), dtype=y2.dtype, device=dev)
+    dy2 = None if fold else torch.empty((B, d, H, W), dtype=y2.dtype, device=dev)
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream().cuda_stream
         # gradient of c: sum over the pixels of g * y2 (mul_add) or of g (add)
@@ -90,6 +91,8 @@ def chan_gate_bwd(g: torch.Tensor, y2: torch.Tensor, c: torch.Tensor, pooled: to
         _capi.check(lib.oss_chan_bwd(_chan_params(B, d, pooled, prm, (zt, dts, hs, y, yc, stat), c), gc.data_ptr(),
                                      dpool.data_ptr(), grads.data_ptr(), scratch.data_ptr(), st), "oss_chan_bwd")
         _keep(scratch, grads)
+        if fold:
+            return [dpool, grads]
         # dy2 = g * (1 + c) [or g] + dpooled / (H W)
         _capi.check(lib.oss_row_affine(_DT[y2.dtype], g.data_ptr(), c.data_ptr() if mul_mode else None, dpool.data_ptr(),
                                        dy2.data_ptr(), B, d, H * W, g.stride(0), g.stride(1), 1.0 / (H * W), st), "oss_row_affine")
@@ -100,7 +103,7 @@ _CH = "Tensor? cin_w, Tensor? cin_b, Tensor Wxc, Tensor Wdtc, Tensor dt_bias, Te
       "Tensor? cout_b, Tensor cn_w, Tensor cn_b, bool mul_mode"
 _LIB.define(f"chan_gate_fwd(Tensor y2, {_CH}) -> Tensor[]")
 _LIB.define(f"chan_gate_bwd(Tensor g, Tensor y2, Tensor c, Tensor pooled, Tensor zt, Tensor dts, Tensor hs, Tensor y, Tensor yc, "
-            f"Tensor stat, {_CH}) -> Tensor[]")
+            f"Tensor stat, {_CH}, bool fold=False) -> Tensor[]")
 _LIB.impl("chan_gate_fwd", chan_gate_fwd, "CUDA")
 _LIB.impl("chan_gate_bwd", chan_gate_bwd, "CUDA")
 
@@ -137,3 +140,56 @@ class ChannelGateFn(torch.autograd.Function):
         d_cinw, d_cinb = take(dc, cin_w), take(dc, cin_b)
         _keep_views(gr, (d_cnw, d_cnb, d_coutw, d_coutb, d_A, d_D, d_bias, d_wdtc, d_wxc, d_cinw, d_cinb))
         return dy2, d_cinw, d_cinb, d_wxc, d_wdtc, d_bias, d_A, d_D, d_coutw, d_coutb, d_cnw, d_cnb, None
+
+
+class NormChannelGateFn(torch.autograd.Function):
+    """``out_norm(y) * silu(z)`` (MambaSISR6_arch.py:433-434,488-493) followed by the channel branch + gate (:438-496) as ONE
+    autograd node over the same kernels as LayerNormNCHWFn -> ChannelGateFn.  What the single node buys: the gate's backward
+    ``d y2 = g * (1 + c) + d pooled / (H W)`` is an affine map per (image, channel) of the incoming gradient, so it is applied
+    inside the LayerNorm backward's load (``oss_ln_nchw_bwd_affine``) and d y2 is never written or read back."""
+
+    @staticmethod
+    def forward(ctx, y, ln_w, ln_b, z, out_dtype, gate_grad_into, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
+                cn_w, cn_b, mul_mode):
+        from .layernorm import _DT_CODE
+        y2, mean, rstd = torch.ops.vmambair.ln_nchw_fwd(y, ln_w, ln_b, z, _DT_CODE[out_dtype])
+        out, *saved = torch.ops.vmambair.chan_gate_fwd(y2, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
+                                                       cn_w, cn_b, mul_mode)
+        ctx.mul_mode, ctx.gate_grad_into, ctx.has_lnb = mul_mode, gate_grad_into, ln_b is not None
+        ctx.save_for_backward(y, ln_w, ln_b, z, mean, rstd, y2, *saved, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
+                              cn_w, cn_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y, ln_w, ln_b, z, mean, rstd, y2, c, pooled, zt, dts, hs, ys, yc, stat, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc,
+         cout_w, cout_b, cn_w, cn_b) = ctx.saved_tensors
+        g = g.contiguous()
+        if g.dtype != y2.dtype:
+            g = g.to(y2.dtype)
+        dpool, gr = torch.ops.vmambair.chan_gate_bwd(g, y2, c, pooled, zt, dts, hs, ys, yc, stat, cin_w, cin_b, Wxc, Wdtc, dt_bias,
+                                                     A_logs, Dsc, cout_w, cout_b, cn_w, cn_b, ctx.mul_mode, True)
+        into = None
+        if ctx.gate_grad_into is not None and z.dtype == g.dtype:
+            into = ctx.gate_grad_into[0].half(ctx.gate_grad_into[1], z)
+        H, W = y2.shape[2], y2.shape[3]
+        dy_, dz, dlw, dlb = torch.ops.vmambair.ln_nchw_bwd(y, ln_w, ln_b, z, g, mean, rstd, None, into,
+                                                          c if ctx.mul_mode else None, dpool, 1.0 / (H * W))
+        if into is not None and dz.numel() == 0 and z.numel() != 0:
+            dz = into
+        L, dc, Rc, Cc = cn_w.numel(), Wdtc.shape[1], Wdtc.shape[2], Wxc.shape[1]
+        o = [0]
+
+        def take(n, like):
+            t = gr[o[0]:o[0] + n]
+            o[0] += n
+            return None if like is None else t.view(like.shape).to(like.dtype)
+
+        d_cnw, d_cnb = take(L, cn_w), take(L, cn_b)
+        d_coutw, d_coutb = take(dc, cout_w), take(1, cout_b)
+        d_A, d_D, d_bias = take(2 * dc * 16, A_logs), take(2 * dc, Dsc), take(2 * dc, dt_bias)
+        d_wdtc, d_wxc = take(2 * dc * Rc, Wdtc), take(2 * Cc * dc, Wxc)
+        d_cinw, d_cinb = take(dc, cin_w), take(dc, cin_b)
+        _keep_views(gr, (d_cnw, d_cnb, d_coutw, d_coutb, d_A, d_D, d_bias, d_wdtc, d_wxc, d_cinw, d_cinb))
+        return (dy_, dlw.to(ln_w.dtype), dlb.to(ln_b.dtype) if ctx.has_lnb else None, dz.to(z.dtype), None, None,
+                d_cinw, d_cinb, d_wxc, d_wdtc, d_bias, d_A, d_D, d_coutw, d_coutb, d_cnw, d_cnb, None)

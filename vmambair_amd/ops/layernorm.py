@@ -50,9 +50,12 @@ def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
                 dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, skip_grad: Optional[torch.Tensor] = None,
-                dgate_into: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                dgate_into: Optional[torch.Tensor] = None, dy_mul: Optional[torch.Tensor] = None,
+                dy_add: Optional[torch.Tensor] = None, add_scale: float = 1.0) -> List[torch.Tensor]:
     """-> [dx (x dtype) (+ skip_grad), dgate (dy dtype) or empty, dweight (C), dbias (C) or empty].  ``dgate_into``: a
-    (B, C, H, W) view with channel stride H*W (one half of a wider buffer) that receives dgate."""
+    (B, C, H, W) view with channel stride H*W (one half of a wider buffer) that receives dgate.  ``dy_add`` (B, C) fp32
+    [and ``dy_mul``]: the gradient that enters is ``dy * (1 + dy_mul[b, c]) + add_scale * dy_add[b, c]``, formed on load (the
+    backward of the channel gate that follows out_norm in SS2D_1, ops/channel.py: NormChannelGateFn)."""
     B, Cc, H, W = x.shape
     P = H * W
     x = _planes(x)
@@ -78,11 +81,18 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     part = torch.empty((max(1, lib.oss_ln_nchw_bwd_partial_floats(B, Cc, P)),), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         st = torch.cuda.current_stream().cuda_stream
-        _capi.check(lib.oss_ln_nchw_bwd(_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
-                                        dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dgate),
-                                        dw.data_ptr(), _ptr(db), part.data_ptr(), _ptr(skip_grad), B, Cc, P, x.stride(0), x.stride(1),
-                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1),
-                                        0 if dgate is None else dgate.stride(0), st), "oss_ln_nchw_bwd")
+        tail = (mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dgate), dw.data_ptr(), _ptr(db), part.data_ptr(),
+                _ptr(skip_grad), B, Cc, P, x.stride(0), x.stride(1), 0 if gate is None else gate.stride(0),
+                0 if gate is None else gate.stride(1), 0 if dgate is None else dgate.stride(0), st)
+        head = (_DT[x.dtype], _DT[dy.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate), dy.data_ptr())
+        if dy_add is not None:
+            _check(dy_add.dtype == torch.float32 and tuple(dy_add.shape) == (B, Cc) and dy_add.is_contiguous() and
+                   (dy_mul is None or (dy_mul.dtype == torch.float32 and tuple(dy_mul.shape) == (B, Cc) and dy_mul.is_contiguous())),
+                   "ln_nchw_bwd: dy_mul / dy_add must be contiguous (B, C) float32")
+            _capi.check(lib.oss_ln_nchw_bwd_affine(*head, _ptr(dy_mul), dy_add.data_ptr(), float(add_scale), *tail), "oss_ln_nchw_bwd_affine")
+        else:
+            _check(dy_mul is None, "ln_nchw_bwd: dy_mul needs dy_add")
+            _capi.check(lib.oss_ln_nchw_bwd(*head, *tail), "oss_ln_nchw_bwd")
     _keep(part, dw, db)
     e = x.new_empty(0, dtype=torch.float32)
     return [dx, dgate if (dgate is not None and not in_place) else e, dw, db if db is not None else e]
@@ -90,7 +100,7 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 _LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
 _LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd, "
-            "Tensor? skip_grad, Tensor(a!)? dgate_into) -> Tensor[]")
+            "Tensor? skip_grad, Tensor(a!)? dgate_into, Tensor? dy_mul=None, Tensor? dy_add=None, float add_scale=1.0) -> Tensor[]")
 _LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
 _LIB.impl("ln_nchw_bwd", ln_nchw_bwd, "CUDA")
 _DT_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}

@@ -17,13 +17,19 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import (ChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw,
+from .ops import (ChannelGateFn, NormChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw,
                   split_halves)
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
+
+#: ``VMAMBAIR_NORM_CHAN_FUSED=0``: out_norm and the channel gate stay two autograd nodes (the gate's backward writes d y2 in a pass
+#: of its own) -- A-B timing of ops/channel.py: NormChannelGateFn
+NORM_CHAN_FUSED = os.environ.get("VMAMBAIR_NORM_CHAN_FUSED", "1") == "1"
 
 #: per reference tree: (dc_inner or None for the RealSR rank-R form, channel-gate mode)
 VARIANTS = {
@@ -287,17 +293,26 @@ class SS2D_1(nn.Module):
         # x, z = xz.chunk(2, dim=1): the gradients of the halves are written by their producers into ONE buffer (no cat)
         x, z, pair = split_halves(xz)
         x = dwconv3x3(x, self.conv2d, act=True, grad_into=None if pair is None else (pair, 0))  # silu in the conv's epilogue
+        chan_fused = self.omni and self.fused_channel and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
+            chan_supported(self.dc_inner or 1, self.dc_state, self.d_inner)
+        lift = self.dc_inner is not None
+        chan_args = (self.conv_cin.weight if lift else None, self.conv_cin.bias if lift else None, self.xc_proj_weight,
+                     self.dtc_projs_weight, self.dtc_projs_bias, self.Ac_logs, self.Dsc, self.conv_cout.weight if lift else None,
+                     self.conv_cout.bias if lift else None, self.channel_norm.body.weight, self.channel_norm.body.bias,
+                     self.gate != "add") if chan_fused else None
+        if chan_fused and NORM_CHAN_FUSED and self.fused_core and isinstance(self.out_norm, LayerNorm) and \
+                core_supported(self.d_inner, self.dt_rank, self.d_state):
+            # spatial core, then out_norm * silu(z) + channel branch + gate as ONE node: the gate's backward is folded into the
+            # LayerNorm backward's load (ops/channel.py: NormChannelGateFn)
+            y = SS2DCoreFn.apply(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
+            y2 = NormChannelGateFn.apply(y, self.out_norm.body.weight, self.out_norm.body.bias, z, x.dtype,
+                                         None if pair is None else (pair, 1), *chan_args)
+            return conv1x1(y2, self.out_conv, residual)
         # out_norm(merge) * silu(z), fused in the LayerNorm kernel
         y2 = self.forward_core(x, gate=z, gate_grad_into=None if pair is None else (pair, 1))
-        if self.omni and self.fused_channel and y2.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
-                chan_supported(self.dc_inner or 1, self.dc_state, self.d_inner):
+        if chan_fused and y2.dtype in (torch.float32, torch.float16, torch.bfloat16):
             # pooling + channel scans + LayerNorm + gate as one autograd node (oss_channel.hip)
-            lift = self.dc_inner is not None
-            y2 = ChannelGateFn.apply(
-                y2, self.conv_cin.weight if lift else None, self.conv_cin.bias if lift else None, self.xc_proj_weight,
-                self.dtc_projs_weight, self.dtc_projs_bias, self.Ac_logs, self.Dsc, self.conv_cout.weight if lift else None,
-                self.conv_cout.bias if lift else None, self.channel_norm.body.weight, self.channel_norm.body.bias,
-                self.gate != "add")
+            y2 = ChannelGateFn.apply(y2, *chan_args)
             return conv1x1(y2, self.out_conv, residual)
         c = self.cforward_core(y2)
         y2 = (y2 + c) if self.gate == "add" else torch.addcmul(y2, y2, c)  # y2 * c + y2
