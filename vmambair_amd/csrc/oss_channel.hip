@@ -137,76 +137,90 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     }
     __syncthreads();
     OSS_STAMP();
-    constexpr int S = NT / 128;   // time segments per direction
+    // ---- the two channel-direction scans, time across the lanes (round 3) -------------------------------------------------
+    // wave = (direction k, group of NPG states); lane p of a 128-step chunk owns steps 2p, 2p + 1 of the direction's walk.
+    // Per (row, state): the two local steps, one 64-lane scan of the recurrence monoid (oss_device.h: segment_scan), the chunk
+    // carry -- instead of a lane per (row, state) walking the steps one after the other (round 2: four 24-step segments per
+    // direction, two passes each, every step paying cross-lane sums over the states and its own LDS round trips: 5.3 us of the
+    // 13 us kernel at L = 96, 36.6 of 56.5 at L = 384).  Sums over the states of a group stay in the lane; the groups' partial
+    // sums of y are added into LDS in group order (fixed order: reruns are bit-identical).
+    static_assert(NT == 512, "wave = (direction, one of four state groups)");
+    constexpr int GPD = NT / 128, NPG = kChN / GPD;   // state groups per direction, states per group
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {
-        const int k = wave / S, seg = wave - k * S, i = lane >> 4, n = lane & 15;
-        const bool act = i < dc;
-        const int row = k * dc + (act ? i : 0);
-        const float A2 = -__expf(p.A_logs[row * kChN + n]) * kLog2e;
-        const float Dv = p.Dsc[row], bias = p.dt_bias[row];
-        const float *dr = (use_lds ? dlsF : db) + row * L, *ur = seq + (act ? i : 0) * L;
-        float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
-        const int Ls = ((L + S - 1) / S + kChU - 1) / kChU * kChU;   // steps per segment, whole fetch chunks
-        const int tb = min(seg * Ls, L), te = min(tb + Ls, L);
-        auto delta_at = [&](int l) {
-            if constexpr (use_lds) { return dr[l]; } else { float e; return softplus_thr(dr[l] + bias, e); }
-        };
-        // pass A: the recurrence alone from a zero state -> (product of a, end state) of this segment.  A step past the
-        // segment's end takes delta = 0: a = 1, B u delta = 0, i.e. the identity.
-        float hl = 0.f, sdl = 0.f;
-        for (int t0 = tb; t0 < te; t0 += kChU) {
-            float dlv[kChU], buv[kChU];
+        const int k = wave / GPD, ng = wave - k * GPD, n0 = ng * NPG;
+        float A2[4][NPG], carry[4][NPG], Dv[4];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = min(t0 + j, te - 1), l = k ? L - 1 - t : t;
-                const float dl = t0 + j < te ? delta_at(l) : 0.f;
-                dlv[j] = dl;
-                buv[j] = dl * zb[(k * L + l) * Cc + Rc + n] * ur[l];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = k * dc + min(i, dc - 1);
+            Dv[i] = p.Dsc[row];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                hl = __builtin_fmaf(exp2_hw(dlv[j] * A2), hl, buv[j]);
-                sdl += dlv[j];
-            }
+            for (int nn = 0; nn < NPG; ++nn) { A2[i][nn] = -__expf(p.A_logs[row * kChN + n0 + nn]) * kLog2e; carry[i][nn] = 0.f; }
         }
-        segP[tid] = exp2_hw(sdl * A2);
-        segH[tid] = hl;
-        __syncthreads();
-        float h = 0.f;   // the state entering this segment: segments 0 .. seg-1 of the direction, in order
-        for (int q = 0; q < seg; ++q) h = __builtin_fmaf(segP[(k * S + q) * 64 + lane], h, segH[(k * S + q) * 64 + lane]);
-        // pass B, per chunk of kChU steps: (1) fetch + everything that does not depend on the recurrence (exp, B u),
-        // (2) the recurrence itself -- one dependent FMA per step, (3) the outputs (independent reductions)
-        for (int t0 = tb; t0 < te; t0 += kChU) {
-            float av[kChU], bu[kChU], us[kChU], Cs[kChU], hv[kChU];
+        const int nchunk = (L + 127) >> 7;
+        for (int c = 0; c < nchunk; ++c) {
+            const int t0 = c * 128 + 2 * lane;
+            const bool v0 = t0 < L, v1 = t0 + 1 < L;
+            const int tc0 = min(t0, L - 1), tc1 = min(t0 + 1, L - 1);
+            const int l0 = k ? L - 1 - tc0 : tc0, l1 = k ? L - 1 - tc1 : tc1;
+            const float *z0 = zb + (k * L + l0) * Cc + Rc + n0, *z1 = zb + (k * L + l1) * Cc + Rc + n0;
+            float B0[NPG], B1[NPG], C0[NPG], C1[NPG];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = min(t0 + j, te - 1), l = k ? L - 1 - t : t;
-                const float *zr = zb + (k * L + l) * Cc + Rc;
-                const float dl = delta_at(l);
-                us[j] = ur[l];
-                av[j] = exp2_hw(dl * A2);
-                bu[j] = dl * zr[n] * us[j];
-                Cs[j] = zr[kChN + n];
-            }
+            for (int nn = 0; nn < NPG; ++nn) { B0[nn] = z0[nn]; B1[nn] = z1[nn]; C0[nn] = z0[kChN + nn]; C1[nn] = z1[kChN + nn]; }
+            float yv0[4], yv1[4];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                h = __builtin_fmaf(av[j], h, bu[j]);   // steps past the end repeat the last one; their results are dropped
-                hv[j] = h;
-            }
+            for (int i = 0; i < 4; ++i) {
+                yv0[i] = 0.f; yv1[i] = 0.f;
+                if (i < dc) {   // (uniform)
+                    const int row = k * dc + i;
+                    float dl0, dl1;
+                    if constexpr (use_lds) { dl0 = dlsF[row * L + l0]; dl1 = dlsF[row * L + l1]; }
+                    else {
+                        float e;
+                        const float bias = p.dt_bias[row];
+                        dl0 = softplus_thr(db[row * L + l0] + bias, e);
+                        dl1 = softplus_thr(db[row * L + l1] + bias, e);
+                    }
+                    dl0 = v0 ? dl0 : 0.f;   // a step past the end: a = 1, B u delta = 0 -- the identity
+                    dl1 = v1 ? dl1 : 0.f;
+                    const float u0 = seq[i * L + l0], u1 = seq[i * L + l1];
+                    float hv0[NPG], hv1[NPG];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = t0 + j;
-                if (t < te) {
-                    const int l = k ? L - 1 - t : t;
-                    if (act) hr[l * kChN + n] = hv[j];
-                    const float tot = segment_sum_to_last<16>(Cs[j] * hv[j]);
-                    if (n == 15 && act) ybuf[row * L + l] = __builtin_fmaf(Dv, us[j], tot);
+                    for (int nn = 0; nn < NPG; ++nn) {
+                        const float a0 = exp2_hw(dl0 * A2[i][nn]), a1 = exp2_hw(dl1 * A2[i][nn]);
+                        const float b0 = dl0 * B0[nn] * u0, b1 = dl1 * B1[nn] * u1;
+                        float P = a0 * a1, h = __builtin_fmaf(a1, b0, b1);      // the lane's two steps from a zero state
+                        segment_scan<64>(P, h);
+                        const float hp = shift_from_prev_lane(h, 0.f, false), Pp = shift_from_prev_lane(P, 1.f, false);
+                        const float hin = __builtin_fmaf(Pp, carry[i][nn], hp);  // the state entering the lane's steps
+                        const float h0 = __builtin_fmaf(a0, hin, b0), h1 = __builtin_fmaf(a1, h0, b1);
+                        hv0[nn] = h0; hv1[nn] = h1;
+                        yv0[i] = __builtin_fmaf(C0[nn], h0, yv0[i]);
+                        yv1[i] = __builtin_fmaf(C1[nn], h1, yv1[i]);
+                        carry[i][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h1), 63));
+                    }
+                    float *hr = p.hs + (((size_t)b * 2 * dc + row) * L) * kChN + n0;
+                    static_assert(NPG == 4, "one 16-byte store per (row, step)");
+                    if (v0) *reinterpret_cast<f32x4 *>(hr + (size_t)l0 * kChN) = f32x4{hv0[0], hv0[1], hv0[2], hv0[3]};
+                    if (v1) *reinterpret_cast<f32x4 *>(hr + (size_t)l1 * kChN) = f32x4{hv1[0], hv1[1], hv1[2], hv1[3]};
+                    if (ng == 0) { yv0[i] = __builtin_fmaf(Dv[i], u0, yv0[i]); yv1[i] = __builtin_fmaf(Dv[i], u1, yv1[i]); }
                 }
+            }
+            for (int r = 0; r < GPD; ++r) {   // y[row][l] = D u + the groups' sums over their states, in group order
+                if (ng == r) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < dc) {
+                            float *yr = ybuf + (k * dc + i) * L;
+                            if (v0) yr[l0] = r ? yr[l0] + yv0[i] : yv0[i];
+                            if (v1) yr[l1] = r ? yr[l1] + yv1[i] : yv1[i];
+                        }
+                    }
+                }
+                __syncthreads();
             }
         }
     }
-    __syncthreads();
     OSS_STAMP();
     float part = 0.f;
     for (int l = tid; l < L; l += NT) {
@@ -310,136 +324,152 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     OSS_STAMP();
     const float *yb = p.y + (size_t)b * 2 * dc * L;
     const float *zb = p.zt + (size_t)b * 2 * L * Cc;
-    constexpr int S = NT / 128;   // time segments per direction (see the header comment)
+    // ---- both reverse recurrences, time across the lanes (round 3; the forward kernel's layout walked backwards) -----------
+    // wave = (direction k, group of NPG states); lane p of a 128-step chunk owns the steps tau = 2p, 2p + 1 counted from the
+    // END of the direction's walk (t = L - 1 - tau), so  dh_t = dy_t C_t + a_{t+1} dh_{t+1}  is a forward scan in tau with
+    // the pair (a_{t+1}, dy_t C_t): one 64-lane scan per (row, state) and chunk instead of a serial walk with cross-lane sums
+    // per step (round 2: 15 of the kernel's 27 us at L = 96, 61 of 103 at L = 384).  Sums over the rows of a direction (dB,
+    // dC) and over a group's states stay in the lane; the groups' partial sums of d delta / du are added in LDS in group
+    // order, the last group finishes them (softplus', D, the row sums): fixed order, bit-identical reruns.
+    static_assert(NT == 512, "wave = (direction, one of four state groups)");
+    constexpr int GPD = NT / 128, NPG = kChN / GPD;
+    static_assert(NPG == 4, "16-byte accesses of a group's states");
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {
-        const int k = wave / S, seg = wave - k * S, i = lane >> 4, n = lane & 15;
-        const bool act = i < dc;
-        const int row = k * dc + (act ? i : 0);
-        const float A = -__expf(p.A_logs[row * kChN + n]), A2 = A * kLog2e;
-        const float Dv = p.Dsc[row], bias = p.dt_bias[row];
-        const float cw = act ? (lift ? p.cout_w[i] : 1.f) : 0.f;
-        const float *dr = (use_lds ? dlsL : db) + row * L, *ur = seq + (act ? i : 0) * L;
-        const float *sgr = use_lds ? sgsL + row * L : nullptr;
-        const float *hr = p.hs + ((size_t)b * 2 * dc + row) * L * kChN;
-        const int Ls = ((L + S - 1) / S + kChU - 1) / kChU * kChU;
-        const int tb = min(seg * Ls, L), te = min(tb + Ls, L);   // this wave walks t = te-1 ... tb
-        float dA = 0.f, dD = 0.f, dbs = 0.f;
-        // raw operands of the steps t0, t0 - 1, ...: fetched one chunk ahead of the arithmetic
-        auto fetch = [&](int t0, float (&xs)[kChU], float (&Bs)[kChU], float (&Cs)[kChU], float (&hv)[kChU + 1]) {
+        const int k = wave / GPD, ng = wave - k * GPD, n0 = ng * NPG;
+        float Av[4][NPG], carry[4][NPG], carry_a[4][NPG], accA[4][NPG], Dv[4], cwv[4], dbs[4], dDs[4];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
-                const float *zr = zb + (k * L + l) * Cc + Rc;
-                xs[j] = dr[l];
-                Bs[j] = zr[n];
-                Cs[j] = zr[kChN + n];
-                hv[j] = hr[l * kChN + n];
-            }
-            const int t = t0 - kChU;  // the state before the chunk's last step
-            const int tc = max(t, 0), l = k ? L - 1 - tc : tc;
-            hv[kChU] = t >= 0 ? hr[l * kChN + n] : 0.f;
-        };
-        float xs[kChU], Bs[kChU], Cs[kChU], hv[kChU + 1];
-        if (te > tb) fetch(te - 1, xs, Bs, Cs, hv);   // in flight across pass A
-        // pass A: the reverse recurrence alone from a zero carry -> (product of a, carry leaving the segment at tb)
-        float cl = 0.f, sdl = 0.f;
-        for (int t0 = te - 1; t0 >= tb; t0 -= kChU) {
-            float dlv[kChU], gv[kChU];
+        for (int i = 0; i < 4; ++i) {
+            const int row = k * dc + min(i, dc - 1);
+            Dv[i] = p.Dsc[row];
+            cwv[i] = i < dc ? (lift ? p.cout_w[i] : 1.f) : 0.f;
+            dbs[i] = 0.f; dDs[i] = 0.f;
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = max(t0 - j, tb), l = k ? L - 1 - t : t;
-                const bool on = t0 - j >= tb;
-                float dl;
-                if constexpr (use_lds) { dl = dr[l]; } else { float e; dl = softplus_thr(dr[l] + bias, e); }
-                dlv[j] = on ? dl : 0.f;
-                gv[j] = on ? cw * dys[l] * zb[(k * L + l) * Cc + Rc + kChN + n] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < kChU; ++j) {   // off steps: a = 1, g = 0 -- the identity
-                cl = exp2_hw(dlv[j] * A2) * (gv[j] + cl);
-                sdl += dlv[j];
+            for (int nn = 0; nn < NPG; ++nn) {
+                Av[i][nn] = -__expf(p.A_logs[row * kChN + n0 + nn]);
+                carry[i][nn] = 0.f; carry_a[i][nn] = 1.f; accA[i][nn] = 0.f;
             }
         }
-        float *segP = red + kChRed, *segC = segP + NT;
-        segP[tid] = exp2_hw(sdl * A2);
-        segC[tid] = cl;
-        __syncthreads();
-        float carry = 0.f;   // a_{t+1} dh_{t+1} entering this segment from the later ones, latest first
-        for (int q = S - 1; q > seg; --q) carry = __builtin_fmaf(segP[(k * S + q) * 64 + lane], carry, segC[(k * S + q) * 64 + lane]);
-        for (int t0 = te - 1; t0 >= tb; t0 -= kChU) {
-            float nxs[kChU], nBs[kChU], nCs[kChU], nhv[kChU + 1];
-            if (t0 - kChU >= tb) fetch(t0 - kChU, nxs, nBs, nCs, nhv);
-            // (1) recurrence-independent terms, (2) the reverse recurrence (two dependent FMAs per step),
-            // (3) the gradients of the step (independent of each other)
-            float us[kChU], dyv[kChU], dls[kChU], sg[kChU], av[kChU], dhv[kChU];
+        const int nchunk = (L + 127) >> 7;
+        for (int c = 0; c < nchunk; ++c) {
+            const int u0 = c * 128 + 2 * lane;                         // tau of the lane's first step
+            const bool v0 = u0 < L, v1 = u0 + 1 < L, v2 = u0 + 2 < L;  // (tau + 2: the step before the lane's second one)
+            const int c0 = min(u0, L - 1), c1 = min(u0 + 1, L - 1), c2 = min(u0 + 2, L - 1);
+            // position along the channel axis of step tau: direction 0 walks l upwards (t = l), direction 1 downwards
+            const int l0 = k ? c0 : L - 1 - c0, l1 = k ? c1 : L - 1 - c1, l2 = k ? c2 : L - 1 - c2;
+            const float *z0 = zb + (k * L + l0) * Cc + Rc + n0, *z1 = zb + (k * L + l1) * Cc + Rc + n0;
+            float B0[NPG], B1[NPG], C0[NPG], C1[NPG];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = max(t0 - j, 0), l = k ? L - 1 - t : t;
-                if constexpr (use_lds) {
-                    dls[j] = xs[j];
-                    sg[j] = sgr[l];
-                } else {
-                    const float x = xs[j] + bias;
-                    float e;
-                    dls[j] = softplus_thr(x, e);
-                    sg[j] = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
-                }
-                av[j] = exp2_hw(dls[j] * A2);
-                us[j] = ur[l];
-                dyv[j] = t0 - j >= tb ? cw * dys[l] : 0.f;
-            }
+            for (int nn = 0; nn < NPG; ++nn) { B0[nn] = z0[nn]; B1[nn] = z1[nn]; C0[nn] = z0[kChN + nn]; C1[nn] = z1[kChN + nn]; }
+            const float dys0 = v0 ? dys[l0] : 0.f, dys1 = v1 ? dys[l1] : 0.f;
+            float dB0[NPG], dB1[NPG], dC0[NPG], dC1[NPG], ddl0[4], ddl1[4], du0[4], du1[4];
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const bool on = t0 - j >= tb;
-                const float dh = __builtin_fmaf(dyv[j], Cs[j], carry);
-                dhv[j] = dh;
-                carry = on ? av[j] * dh : carry;
-            }
+            for (int nn = 0; nn < NPG; ++nn) { dB0[nn] = 0.f; dB1[nn] = 0.f; dC0[nn] = 0.f; dC1[nn] = 0.f; }
 #pragma unroll
-            for (int j = 0; j < kChU; ++j) {
-                const int t = t0 - j;
-                if (t >= tb) {
-                    const int l = k ? L - 1 - t : t;
-                    const float dl = dls[j], u = us[j], Bv = Bs[j], a = av[j], dh = dhv[j];
-                    const float h = hv[j], hp = t > 0 ? hv[j + 1] : 0.f;
-                    const float dCs = sum_over_rows(dyv[j] * h, lane);
-                    const float dBs = sum_over_rows(dh * dl * u, lane);
-                    if (i == 0) {
-                        float *dz = dzb + (k * L + l) * Cc + Rc;
-                        dz[n] = dBs;
-                        dz[kChN + n] = dCs;
+            for (int i = 0; i < 4; ++i) {
+                ddl0[i] = 0.f; ddl1[i] = 0.f; du0[i] = 0.f; du1[i] = 0.f;
+                if (i < dc) {   // (uniform)
+                    const int row = k * dc + i;
+                    float dl0, dl1;
+                    if constexpr (use_lds) { dl0 = dlsL[row * L + l0]; dl1 = dlsL[row * L + l1]; }
+                    else {
+                        float e;
+                        const float bias = p.dt_bias[row];
+                        dl0 = softplus_thr(db[row * L + l0] + bias, e);
+                        dl1 = softplus_thr(db[row * L + l1] + bias, e);
                     }
-                    const float ddl = segment_sum_to_last<16>(dh * __builtin_fmaf(A * a, hp, Bv * u));
-                    const float du = segment_sum_to_last<16>(dh * dl * Bv);
-                    dA = __builtin_fmaf(dh * dl * a, hp, dA);
-                    if (n == 15 && act) {
-                        const float ddt = ddl * sg[j];
-                        ddb[row * L + l] = ddt;
-                        dub[row * L + l] = __builtin_fmaf(dyv[j], Dv, du);
-                        dbs += ddt;
-                        dD = __builtin_fmaf(dyv[j], u, dD);
+                    dl0 = v0 ? dl0 : 0.f;   // a step past the end: a = 1, nothing flows
+                    dl1 = v1 ? dl1 : 0.f;
+                    const float us0 = seq[i * L + l0], us1 = seq[i * L + l1];
+                    const float dy0 = cwv[i] * dys0, dy1 = cwv[i] * dys1;
+                    const float *hr = p.hs + (((size_t)b * 2 * dc + row) * L) * kChN + n0;
+                    const f32x4 hq0 = *reinterpret_cast<const f32x4 *>(hr + (size_t)l0 * kChN);
+                    const f32x4 hq1 = *reinterpret_cast<const f32x4 *>(hr + (size_t)l1 * kChN);
+                    const f32x4 hq2 = *reinterpret_cast<const f32x4 *>(hr + (size_t)l2 * kChN);
+#pragma unroll
+                    for (int nn = 0; nn < NPG; ++nn) {
+                        const float A = Av[i][nn];
+                        const float a0 = exp2_hw(dl0 * A * kLog2e), a1 = exp2_hw(dl1 * A * kLog2e);
+                        // the factor in front of the incoming dh at step tau is a of step tau - 1 (= t + 1)
+                        const float al0 = shift_from_prev_lane(a1, carry_a[i][nn], false), al1 = a0;
+                        const float g0 = dy0 * C0[nn], g1 = dy1 * C1[nn];
+                        float P = al0 * al1, h = __builtin_fmaf(al1, g0, g1);
+                        segment_scan<64>(P, h);
+                        const float hp = shift_from_prev_lane(h, 0.f, false), Pp = shift_from_prev_lane(P, 1.f, false);
+                        const float din = __builtin_fmaf(Pp, carry[i][nn], hp);   // a_{t+1} dh_{t+1} summed into the lane's first step
+                        const float dh0 = __builtin_fmaf(al0, din, g0), dh1 = __builtin_fmaf(al1, dh0, g1);
+                        carry[i][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dh1), 63));
+                        carry_a[i][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 63));
+                        const float h0 = hq0[nn], h1 = hq1[nn];
+                        const float hp0 = v1 ? h1 : 0.f, hp1 = v2 ? hq2[nn] : 0.f;   // the state BEFORE the step (0 before t = 0)
+                        dC0[nn] = __builtin_fmaf(dy0, h0, dC0[nn]);
+                        dC1[nn] = __builtin_fmaf(dy1, h1, dC1[nn]);
+                        dB0[nn] = __builtin_fmaf(dh0 * dl0, us0, dB0[nn]);
+                        dB1[nn] = __builtin_fmaf(dh1 * dl1, us1, dB1[nn]);
+                        ddl0[i] = __builtin_fmaf(dh0, __builtin_fmaf(A * a0, hp0, B0[nn] * us0), ddl0[i]);
+                        ddl1[i] = __builtin_fmaf(dh1, __builtin_fmaf(A * a1, hp1, B1[nn] * us1), ddl1[i]);
+                        du0[i] = __builtin_fmaf(dh0 * dl0, B0[nn], du0[i]);
+                        du1[i] = __builtin_fmaf(dh1 * dl1, B1[nn], du1[i]);
+                        accA[i][nn] = __builtin_fmaf(dh0 * dl0 * a0, hp0, __builtin_fmaf(dh1 * dl1 * a1, hp1, accA[i][nn]));
                     }
                 }
             }
-            if (t0 - kChU >= tb) {
+            {   // dB, dC of the group's states (already summed over the direction's rows)
+                float *dz0 = dzb + (k * L + l0) * Cc + Rc + n0, *dz1 = dzb + (k * L + l1) * Cc + Rc + n0;
 #pragma unroll
-                for (int j = 0; j < kChU; ++j) { xs[j] = nxs[j]; Bs[j] = nBs[j]; Cs[j] = nCs[j]; hv[j] = nhv[j]; }
-                hv[kChU] = nhv[kChU];
+                for (int nn = 0; nn < NPG; ++nn) {
+                    if (v0) { dz0[nn] = dB0[nn]; dz0[kChN + nn] = dC0[nn]; }
+                    if (v1) { dz1[nn] = dB1[nn]; dz1[kChN + nn] = dC1[nn]; }
+                }
+            }
+            for (int r = 0; r < GPD; ++r) {   // d delta, du: the groups' sums over their states, added in group order
+                if (ng == r) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < dc) {
+                            const int row = k * dc + i;
+                            float *dd = ddb + row * L, *dq = dub + row * L;
+                            float t0 = r ? dd[l0] + ddl0[i] : ddl0[i], t1 = r ? dd[l1] + ddl1[i] : ddl1[i];
+                            float q0 = r ? dq[l0] + du0[i] : du0[i], q1 = r ? dq[l1] + du1[i] : du1[i];
+                            if (r == GPD - 1) {   // complete: through softplus', plus the D path; the row sums
+                                float sg0, sg1;
+                                if constexpr (use_lds) { sg0 = sgsL[row * L + l0]; sg1 = sgsL[row * L + l1]; }
+                                else {
+                                    const float bias = p.dt_bias[row];
+                                    const float x0 = db[row * L + l0] + bias, x1 = db[row * L + l1] + bias;
+                                    const float e0 = exp2_hw(x0 * kLog2e), e1 = exp2_hw(x1 * kLog2e);
+                                    sg0 = (x0 <= 20.f) ? e0 * __builtin_amdgcn_rcpf(1.f + e0) : 1.f;
+                                    sg1 = (x1 <= 20.f) ? e1 * __builtin_amdgcn_rcpf(1.f + e1) : 1.f;
+                                }
+                                const float dy0 = cwv[i] * dys0, dy1 = cwv[i] * dys1;
+                                t0 *= sg0; t1 *= sg1;
+                                q0 = __builtin_fmaf(dy0, Dv[i], q0); q1 = __builtin_fmaf(dy1, Dv[i], q1);
+                                dbs[i] += (v0 ? t0 : 0.f) + (v1 ? t1 : 0.f);
+                                dDs[i] += (v0 ? dy0 * seq[i * L + l0] : 0.f) + (v1 ? dy1 * seq[i * L + l1] : 0.f);
+                            }
+                            if (v0) { dd[l0] = t0; dq[l0] = q0; }
+                            if (v1) { dd[l1] = t1; dq[l1] = q1; }
+                        }
+                    }
+                }
+                __syncthreads();
             }
         }
-        // the segments' partial sums of dA / dD / dbias, combined in segment order by the wave of segment 0
-        float *accA = segC + NT, *accD = accA + NT, *accB = accD + NT;
-        accA[tid] = dA; accD[tid] = dD; accB[tid] = dbs;
-        __syncthreads();
-        if (seg == 0 && act) {
-            float tA = 0.f, tD = 0.f, tB = 0.f;
-            for (int q = 0; q < S; ++q) {
-                const int o = (k * S + q) * 64 + lane;
-                tA += accA[o]; tD += accD[o]; tB += accB[o];
+        // sums over the steps: dA_log per (row, state) from every wave, dD / d dt_bias per row from the last group's waves
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < dc) {
+                const int row = k * dc + i;
+#pragma unroll
+                for (int nn = 0; nn < NPG; ++nn) {
+                    const float tA = segment_sum_to_last<64>(accA[i][nn]);
+                    if (lane == 63) gp[sl.dA + row * kChN + n0 + nn] = tA * Av[i][nn];   // d/dA_log: A = -exp(A_log)
+                }
+                if (ng == GPD - 1) {
+                    const float tB = segment_sum_to_last<64>(dbs[i]), tD = segment_sum_to_last<64>(dDs[i]);
+                    if (lane == 63) { gp[sl.dbias + row] = tB; gp[sl.dD + row] = tD; }
+                }
             }
-            gp[sl.dA + row * kChN + n] = tA * A;  // d/dA_log: A = -exp(A_log)
-            if (n == 15) { gp[sl.dD + row] = tD; gp[sl.dbias + row] = tB; }
         }
         // gradients of conv_cout (sums over l of dyc * (y0 + y1), and of dyc): wave o does output o; slot dc = the bias
         if (wave <= dc) {
