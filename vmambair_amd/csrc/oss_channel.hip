@@ -70,8 +70,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *ybuf = seq + dc * L;      // [2 dc][L]
     float *ycs = ybuf + 2 * dc * L;  // [L]
     float *red = ycs + L;            // [kChRed]
-    float *segP = red + kChRed;      // [NT]: product of a over a wave's time segment, per lane
-    float *segH = segP + NT;         // [NT]: the segment's end state from a zero start
+    float *ypart = red + kChRed;     // [4][2 dc][L]: the state groups' partial sums of y
     for (int l = tid; l < L; l += NT) {
         const float pl = p.pooled[(size_t)b * L + l];
         for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
@@ -81,7 +80,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *zg = p.zt + (size_t)b * 2 * L * Cc;  // [k][l][c]
     float *dg = p.dts + (size_t)b * 2 * dc * L;
     float *zb, *db, *dlsF = nullptr;   // dlsF [2 dc][L]: softplus(dts + bias), computed once per (row, l) for the 16 state lanes
-    if constexpr (use_lds) { zb = segH + NT; db = zb + 2 * L * Cc; dlsF = db + 2 * dc * L; } else { zb = zg; db = dg; }
+    if constexpr (use_lds) { zb = ypart + 4 * 2 * dc * L; db = zb + 2 * L * Cc; dlsF = db + 2 * dc * L; } else { zb = zg; db = dg; }
     // z[k][l][c] = sum_i Wxc[k][c][i] seq[i][l]: a thread keeps the dc weights of its column (k, c) in registers and walks l
     // (one output per iteration with its index arithmetic and dc dependent L2 loads measured 13 of the kernel's 32 us at
     // L = 96, profiles/r01_chan_phase_timing.txt)
@@ -142,8 +141,8 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     // Per (row, state): the two local steps, one 64-lane scan of the recurrence monoid (oss_device.h: segment_scan), the chunk
     // carry -- instead of a lane per (row, state) walking the steps one after the other (round 2: four 24-step segments per
     // direction, two passes each, every step paying cross-lane sums over the states and its own LDS round trips: 5.3 us of the
-    // 13 us kernel at L = 96, 36.6 of 56.5 at L = 384).  Sums over the states of a group stay in the lane; the groups' partial
-    // sums of y are added into LDS in group order (fixed order: reruns are bit-identical).
+    // 13 us kernel at L = 96, 36.6 of 56.5 at L = 384).  Sums over the states of a group stay in the lane; the four groups'
+    // partial sums of y go to LDS and are added in group order afterwards (fixed order: reruns are bit-identical).
     static_assert(NT == 512, "wave = (direction, one of four state groups)");
     constexpr int GPD = NT / 128, NPG = kChN / GPD;   // state groups per direction, states per group
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -184,16 +183,19 @@ oss_chan_fwd_kernel(oss_chan_params p) {
                     dl0 = v0 ? dl0 : 0.f;   // a step past the end: a = 1, B u delta = 0 -- the identity
                     dl1 = v1 ? dl1 : 0.f;
                     const float u0 = seq[i * L + l0], u1 = seq[i * L + l1];
-                    float hv0[NPG], hv1[NPG];
+                    float hv0[NPG], hv1[NPG], a0[NPG], a1[NPG], b0[NPG], b1[NPG], P[NPG], h[NPG];
 #pragma unroll
                     for (int nn = 0; nn < NPG; ++nn) {
-                        const float a0 = exp2_hw(dl0 * A2[i][nn]), a1 = exp2_hw(dl1 * A2[i][nn]);
-                        const float b0 = dl0 * B0[nn] * u0, b1 = dl1 * B1[nn] * u1;
-                        float P = a0 * a1, h = __builtin_fmaf(a1, b0, b1);      // the lane's two steps from a zero state
-                        segment_scan<64>(P, h);
-                        const float hp = shift_from_prev_lane(h, 0.f, false), Pp = shift_from_prev_lane(P, 1.f, false);
+                        a0[nn] = exp2_hw(dl0 * A2[i][nn]); a1[nn] = exp2_hw(dl1 * A2[i][nn]);
+                        b0[nn] = dl0 * B0[nn] * u0; b1[nn] = dl1 * B1[nn] * u1;
+                        P[nn] = a0[nn] * a1[nn]; h[nn] = __builtin_fmaf(a1[nn], b0[nn], b1[nn]);   // the lane's two steps from a zero state
+                    }
+                    segment_scan4_64(P, h);
+#pragma unroll
+                    for (int nn = 0; nn < NPG; ++nn) {
+                        const float hp = shift_from_prev_lane(h[nn], 0.f, false), Pp = shift_from_prev_lane(P[nn], 1.f, false);
                         const float hin = __builtin_fmaf(Pp, carry[i][nn], hp);  // the state entering the lane's steps
-                        const float h0 = __builtin_fmaf(a0, hin, b0), h1 = __builtin_fmaf(a1, h0, b1);
+                        const float h0 = __builtin_fmaf(a0[nn], hin, b0[nn]), h1 = __builtin_fmaf(a1[nn], h0, b1[nn]);
                         hv0[nn] = h0; hv1[nn] = h1;
                         yv0[i] = __builtin_fmaf(C0[nn], h0, yv0[i]);
                         yv1[i] = __builtin_fmaf(C1[nn], h1, yv1[i]);
@@ -206,21 +208,20 @@ oss_chan_fwd_kernel(oss_chan_params p) {
                     if (ng == 0) { yv0[i] = __builtin_fmaf(Dv[i], u0, yv0[i]); yv1[i] = __builtin_fmaf(Dv[i], u1, yv1[i]); }
                 }
             }
-            for (int r = 0; r < GPD; ++r) {   // y[row][l] = D u + the groups' sums over their states, in group order
-                if (ng == r) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (i < dc) {
-                            float *yr = ybuf + (k * dc + i) * L;
-                            if (v0) yr[l0] = r ? yr[l0] + yv0[i] : yv0[i];
-                            if (v1) yr[l1] = r ? yr[l1] + yv1[i] : yv1[i];
-                        }
-                    }
+            for (int i = 0; i < 4; ++i) {   // the group's partial sums of y (group 0: + D u)
+                if (i < dc) {
+                    float *yr = ypart + (ng * 2 * dc + k * dc + i) * L;
+                    if (v0) yr[l0] = yv0[i];
+                    if (v1) yr[l1] = yv1[i];
                 }
-                __syncthreads();
             }
         }
     }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * dc * L; idx += NT)   // y = D u + the groups' sums over their states, in group order
+        ybuf[idx] = ((ypart[idx] + ypart[2 * dc * L + idx]) + ypart[2 * 2 * dc * L + idx]) + ypart[3 * 2 * dc * L + idx];
+    __syncthreads();
     OSS_STAMP();
     float part = 0.f;
     for (int l = tid; l < L; l += NT) {
@@ -273,11 +274,41 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     OSS_STAMP();
     const bool lift = p.cin_w != nullptr;
     const ChanSlots sl(L, dc, Rc, Cc);
+    // the scan phase's layout (see there): wave = (direction, group of NPG states), lane = two steps of a 128-step chunk.  The
+    // operands it reads from HBM -- B, C and the saved states, written by the forward pass milliseconds ago -- are requested
+    // HERE for the first chunk, and for chunk c + 1 while chunk c is computed: one memory latency under the LayerNorm phase
+    // instead of one in front of every chunk.
+    static_assert(NT == 512, "wave = (direction, one of four state groups)");
+    constexpr int GPD = NT / 128, NPG = kChN / GPD;
+    static_assert(NPG == 4, "16-byte accesses of a group's states");
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int sk = wave / GPD, sng = wave - sk * GPD, sn0 = sng * NPG;
+    struct ScanOps { float B0[NPG], B1[NPG], C0[NPG], C1[NPG]; f32x4 hq0[4], hq1[4], hq2[4]; };
+    auto fetch_ops = [&](int c, ScanOps &o) {
+        const int u0 = c * 128 + 2 * lane;
+        const int c0 = min(u0, L - 1), c1 = min(u0 + 1, L - 1), c2 = min(u0 + 2, L - 1);
+        const int l0 = sk ? c0 : L - 1 - c0, l1 = sk ? c1 : L - 1 - c1, l2 = sk ? c2 : L - 1 - c2;
+        const float *zsrc = p.zt + (size_t)b * 2 * L * Cc;
+        const float *z0 = zsrc + (sk * L + l0) * Cc + Rc + sn0, *z1 = zsrc + (sk * L + l1) * Cc + Rc + sn0;
+#pragma unroll
+        for (int nn = 0; nn < NPG; ++nn) { o.B0[nn] = z0[nn]; o.B1[nn] = z1[nn]; o.C0[nn] = z0[kChN + nn]; o.C1[nn] = z1[kChN + nn]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *hr = p.hs + (((size_t)b * 2 * dc + sk * dc + min(i, dc - 1)) * L) * kChN + sn0;
+            o.hq0[i] = *reinterpret_cast<const f32x4 *>(hr + (size_t)l0 * kChN);
+            o.hq1[i] = *reinterpret_cast<const f32x4 *>(hr + (size_t)l1 * kChN);
+            o.hq2[i] = *reinterpret_cast<const f32x4 *>(hr + (size_t)l2 * kChN);
+        }
+    };
+    ScanOps cur;
+    fetch_ops(0, cur);
     float *seq = sm;              // [dc][L]
     float *dys = seq + dc * L;    // [L]   grad of yc
     float *dsq = dys + L;         // [dc][L] grad of seq
-    float *red = dsq + dc * L;    // [kChRed], then [5][NT] scratch of the time segments (pairs to chain, partial sums)
-    float *sWx = red + kChRed + 5 * NT;   // [2][Cc][dc]  xc_proj weights (read 2 Cc times per output of the dseq pass)
+    float *red = dsq + dc * L;    // [kChRed]
+    float *dpl = red + kChRed;    // [4][2 dc][L]: the state groups' partial sums of d delta (before softplus') ...
+    float *dpu = dpl + 4 * 2 * dc * L;   // ... and of du
+    float *sWx = dpu + 4 * 2 * dc * L;   // [2][Cc][dc]  xc_proj weights (read 2 Cc times per output of the dseq pass)
     float *zdt = sWx + 2 * Cc * dc;   // [2][L][Rc]  the dt columns of z (operands of the dtc_projs weight gradient)
     float *lds_end = zdt + (stage_zdt ? 2 * L * Rc : 0);
     float *gp = gpart + (size_t)b * sl.total;
@@ -329,21 +360,15 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
     // END of the direction's walk (t = L - 1 - tau), so  dh_t = dy_t C_t + a_{t+1} dh_{t+1}  is a forward scan in tau with
     // the pair (a_{t+1}, dy_t C_t): one 64-lane scan per (row, state) and chunk instead of a serial walk with cross-lane sums
     // per step (round 2: 15 of the kernel's 27 us at L = 96, 61 of 103 at L = 384).  Sums over the rows of a direction (dB,
-    // dC) and over a group's states stay in the lane; the groups' partial sums of d delta / du are added in LDS in group
-    // order, the last group finishes them (softplus', D, the row sums): fixed order, bit-identical reruns.
-    static_assert(NT == 512, "wave = (direction, one of four state groups)");
-    constexpr int GPD = NT / 128, NPG = kChN / GPD;
-    static_assert(NPG == 4, "16-byte accesses of a group's states");
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // dC) and over a group's states stay in the lane; the four groups' partial sums of d delta / du go to LDS and a pass with
+    // one wave per row adds them in group order and finishes them (softplus', D, the row sums): fixed order, bit-identical reruns.
     {
-        const int k = wave / GPD, ng = wave - k * GPD, n0 = ng * NPG;
-        float Av[4][NPG], carry[4][NPG], carry_a[4][NPG], accA[4][NPG], Dv[4], cwv[4], dbs[4], dDs[4];
+        const int k = sk, ng = sng, n0 = sn0;
+        float Av[4][NPG], carry[4][NPG], carry_a[4][NPG], accA[4][NPG], cwv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = k * dc + min(i, dc - 1);
-            Dv[i] = p.Dsc[row];
             cwv[i] = i < dc ? (lift ? p.cout_w[i] : 1.f) : 0.f;
-            dbs[i] = 0.f; dDs[i] = 0.f;
 #pragma unroll
             for (int nn = 0; nn < NPG; ++nn) {
                 Av[i][nn] = -__expf(p.A_logs[row * kChN + n0 + nn]);
@@ -357,10 +382,10 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
             const int c0 = min(u0, L - 1), c1 = min(u0 + 1, L - 1), c2 = min(u0 + 2, L - 1);
             // position along the channel axis of step tau: direction 0 walks l upwards (t = l), direction 1 downwards
             const int l0 = k ? c0 : L - 1 - c0, l1 = k ? c1 : L - 1 - c1, l2 = k ? c2 : L - 1 - c2;
-            const float *z0 = zb + (k * L + l0) * Cc + Rc + n0, *z1 = zb + (k * L + l1) * Cc + Rc + n0;
-            float B0[NPG], B1[NPG], C0[NPG], C1[NPG];
-#pragma unroll
-            for (int nn = 0; nn < NPG; ++nn) { B0[nn] = z0[nn]; B1[nn] = z1[nn]; C0[nn] = z0[kChN + nn]; C1[nn] = z1[kChN + nn]; }
+            ScanOps nxt;
+            if (c + 1 < nchunk) fetch_ops(c + 1, nxt);   // in flight while this chunk is computed
+            float (&B0)[NPG] = cur.B0, (&B1)[NPG] = cur.B1, (&C0)[NPG] = cur.C0, (&C1)[NPG] = cur.C1;
+            f32x4 (&hq0)[4] = cur.hq0, (&hq1)[4] = cur.hq1, (&hq2)[4] = cur.hq2;
             const float dys0 = v0 ? dys[l0] : 0.f, dys1 = v1 ? dys[l1] : 0.f;
             float dB0[NPG], dB1[NPG], dC0[NPG], dC1[NPG], ddl0[4], ddl1[4], du0[4], du1[4];
 #pragma unroll
@@ -382,35 +407,35 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
                     dl1 = v1 ? dl1 : 0.f;
                     const float us0 = seq[i * L + l0], us1 = seq[i * L + l1];
                     const float dy0 = cwv[i] * dys0, dy1 = cwv[i] * dys1;
-                    const float *hr = p.hs + (((size_t)b * 2 * dc + row) * L) * kChN + n0;
-                    const f32x4 hq0 = *reinterpret_cast<const f32x4 *>(hr + (size_t)l0 * kChN);
-                    const f32x4 hq1 = *reinterpret_cast<const f32x4 *>(hr + (size_t)l1 * kChN);
-                    const f32x4 hq2 = *reinterpret_cast<const f32x4 *>(hr + (size_t)l2 * kChN);
+                    float a0[NPG], a1[NPG], al0[NPG], g0[NPG], g1[NPG], P[NPG], h[NPG];
+#pragma unroll
+                    for (int nn = 0; nn < NPG; ++nn) {
+                        a0[nn] = exp2_hw(dl0 * Av[i][nn] * kLog2e); a1[nn] = exp2_hw(dl1 * Av[i][nn] * kLog2e);
+                        // the factor in front of the incoming dh at step tau is a of step tau - 1 (= t + 1)
+                        al0[nn] = shift_from_prev_lane(a1[nn], carry_a[i][nn], false);
+                        g0[nn] = dy0 * C0[nn]; g1[nn] = dy1 * C1[nn];
+                        P[nn] = al0[nn] * a0[nn]; h[nn] = __builtin_fmaf(a0[nn], g0[nn], g1[nn]);
+                    }
+                    segment_scan4_64(P, h);
 #pragma unroll
                     for (int nn = 0; nn < NPG; ++nn) {
                         const float A = Av[i][nn];
-                        const float a0 = exp2_hw(dl0 * A * kLog2e), a1 = exp2_hw(dl1 * A * kLog2e);
-                        // the factor in front of the incoming dh at step tau is a of step tau - 1 (= t + 1)
-                        const float al0 = shift_from_prev_lane(a1, carry_a[i][nn], false), al1 = a0;
-                        const float g0 = dy0 * C0[nn], g1 = dy1 * C1[nn];
-                        float P = al0 * al1, h = __builtin_fmaf(al1, g0, g1);
-                        segment_scan<64>(P, h);
-                        const float hp = shift_from_prev_lane(h, 0.f, false), Pp = shift_from_prev_lane(P, 1.f, false);
-                        const float din = __builtin_fmaf(Pp, carry[i][nn], hp);   // a_{t+1} dh_{t+1} summed into the lane's first step
-                        const float dh0 = __builtin_fmaf(al0, din, g0), dh1 = __builtin_fmaf(al1, dh0, g1);
+                        const float hp = shift_from_prev_lane(h[nn], 0.f, false), Pp = shift_from_prev_lane(P[nn], 1.f, false);
+                        const float din = __builtin_fmaf(Pp, carry[i][nn], hp);   // a_{t+1} dh_{t+1} reaching the lane's first step
+                        const float dh0 = __builtin_fmaf(al0[nn], din, g0[nn]), dh1 = __builtin_fmaf(a0[nn], dh0, g1[nn]);
                         carry[i][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dh1), 63));
-                        carry_a[i][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), 63));
-                        const float h0 = hq0[nn], h1 = hq1[nn];
-                        const float hp0 = v1 ? h1 : 0.f, hp1 = v2 ? hq2[nn] : 0.f;   // the state BEFORE the step (0 before t = 0)
+                        carry_a[i][nn] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1[nn]), 63));
+                        const float h0 = hq0[i][nn], h1 = hq1[i][nn];
+                        const float hp0 = v1 ? h1 : 0.f, hp1 = v2 ? hq2[i][nn] : 0.f;   // the state BEFORE the step (0 before t = 0)
                         dC0[nn] = __builtin_fmaf(dy0, h0, dC0[nn]);
                         dC1[nn] = __builtin_fmaf(dy1, h1, dC1[nn]);
                         dB0[nn] = __builtin_fmaf(dh0 * dl0, us0, dB0[nn]);
                         dB1[nn] = __builtin_fmaf(dh1 * dl1, us1, dB1[nn]);
-                        ddl0[i] = __builtin_fmaf(dh0, __builtin_fmaf(A * a0, hp0, B0[nn] * us0), ddl0[i]);
-                        ddl1[i] = __builtin_fmaf(dh1, __builtin_fmaf(A * a1, hp1, B1[nn] * us1), ddl1[i]);
+                        ddl0[i] = __builtin_fmaf(dh0, __builtin_fmaf(A * a0[nn], hp0, B0[nn] * us0), ddl0[i]);
+                        ddl1[i] = __builtin_fmaf(dh1, __builtin_fmaf(A * a1[nn], hp1, B1[nn] * us1), ddl1[i]);
                         du0[i] = __builtin_fmaf(dh0 * dl0, B0[nn], du0[i]);
                         du1[i] = __builtin_fmaf(dh1 * dl1, B1[nn], du1[i]);
-                        accA[i][nn] = __builtin_fmaf(dh0 * dl0 * a0, hp0, __builtin_fmaf(dh1 * dl1 * a1, hp1, accA[i][nn]));
+                        accA[i][nn] = __builtin_fmaf(dh0 * dl0 * a0[nn], hp0, __builtin_fmaf(dh1 * dl1 * a1[nn], hp1, accA[i][nn]));
                     }
                 }
             }
@@ -422,54 +447,51 @@ oss_chan_bwd_kernel(oss_chan_params p, const float *__restrict__ gc /*(B, L): gr
                     if (v1) { dz1[nn] = dB1[nn]; dz1[kChN + nn] = dC1[nn]; }
                 }
             }
-            for (int r = 0; r < GPD; ++r) {   // d delta, du: the groups' sums over their states, added in group order
-                if (ng == r) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (i < dc) {
-                            const int row = k * dc + i;
-                            float *dd = ddb + row * L, *dq = dub + row * L;
-                            float t0 = r ? dd[l0] + ddl0[i] : ddl0[i], t1 = r ? dd[l1] + ddl1[i] : ddl1[i];
-                            float q0 = r ? dq[l0] + du0[i] : du0[i], q1 = r ? dq[l1] + du1[i] : du1[i];
-                            if (r == GPD - 1) {   // complete: through softplus', plus the D path; the row sums
-                                float sg0, sg1;
-                                if constexpr (use_lds) { sg0 = sgsL[row * L + l0]; sg1 = sgsL[row * L + l1]; }
-                                else {
-                                    const float bias = p.dt_bias[row];
-                                    const float x0 = db[row * L + l0] + bias, x1 = db[row * L + l1] + bias;
-                                    const float e0 = exp2_hw(x0 * kLog2e), e1 = exp2_hw(x1 * kLog2e);
-                                    sg0 = (x0 <= 20.f) ? e0 * __builtin_amdgcn_rcpf(1.f + e0) : 1.f;
-                                    sg1 = (x1 <= 20.f) ? e1 * __builtin_amdgcn_rcpf(1.f + e1) : 1.f;
-                                }
-                                const float dy0 = cwv[i] * dys0, dy1 = cwv[i] * dys1;
-                                t0 *= sg0; t1 *= sg1;
-                                q0 = __builtin_fmaf(dy0, Dv[i], q0); q1 = __builtin_fmaf(dy1, Dv[i], q1);
-                                dbs[i] += (v0 ? t0 : 0.f) + (v1 ? t1 : 0.f);
-                                dDs[i] += (v0 ? dy0 * seq[i * L + l0] : 0.f) + (v1 ? dy1 * seq[i * L + l1] : 0.f);
-                            }
-                            if (v0) { dd[l0] = t0; dq[l0] = q0; }
-                            if (v1) { dd[l1] = t1; dq[l1] = q1; }
-                        }
-                    }
+            for (int i = 0; i < 4; ++i) {   // the group's partial sums of d delta (before softplus') and du
+                if (i < dc) {
+                    const int o = (ng * 2 * dc + k * dc + i) * L;
+                    if (v0) { dpl[o + l0] = ddl0[i]; dpu[o + l0] = du0[i]; }
+                    if (v1) { dpl[o + l1] = ddl1[i]; dpu[o + l1] = du1[i]; }
                 }
-                __syncthreads();
             }
+            if (c + 1 < nchunk) cur = nxt;
         }
-        // sums over the steps: dA_log per (row, state) from every wave, dD / d dt_bias per row from the last group's waves
+        // dA_log per (row, state): the sum over the steps
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < dc) {
-                const int row = k * dc + i;
 #pragma unroll
                 for (int nn = 0; nn < NPG; ++nn) {
                     const float tA = segment_sum_to_last<64>(accA[i][nn]);
-                    if (lane == 63) gp[sl.dA + row * kChN + n0 + nn] = tA * Av[i][nn];   // d/dA_log: A = -exp(A_log)
-                }
-                if (ng == GPD - 1) {
-                    const float tB = segment_sum_to_last<64>(dbs[i]), tD = segment_sum_to_last<64>(dDs[i]);
-                    if (lane == 63) { gp[sl.dbias + row] = tB; gp[sl.dD + row] = tD; }
+                    if (lane == 63) gp[sl.dA + (k * dc + i) * kChN + n0 + nn] = tA * Av[i][nn];   // d/dA_log: A = -exp(A_log)
                 }
             }
+        }
+        __syncthreads();
+        // wave = row: the groups' partial sums in group order, through softplus', plus the D path; dD and d dt_bias of the row
+        if (wave < 2 * dc) {
+            const int row = wave, i = row % dc;
+            const float Dr = p.Dsc[row], cw = lift ? p.cout_w[i] : 1.f, bias = p.dt_bias[row];
+            float sB = 0.f, sD = 0.f;
+            for (int l = lane; l < L; l += 64) {
+                const int o = row * L + l, st = 2 * dc * L;
+                const float tl = ((dpl[o] + dpl[st + o]) + dpl[2 * st + o]) + dpl[3 * st + o];
+                const float tu = ((dpu[o] + dpu[st + o]) + dpu[2 * st + o]) + dpu[3 * st + o];
+                float sg;
+                if constexpr (use_lds) { sg = sgsL[o]; }
+                else {
+                    const float x = db[o] + bias, e = exp2_hw(x * kLog2e);
+                    sg = (x <= 20.f) ? e * __builtin_amdgcn_rcpf(1.f + e) : 1.f;
+                }
+                const float dy = cw * dys[l], ddt = tl * sg;
+                ddb[o] = ddt;
+                dub[o] = __builtin_fmaf(dy, Dr, tu);
+                sB += ddt;
+                sD = __builtin_fmaf(dy, seq[i * L + l], sD);
+            }
+            const float tB = segment_sum_to_last<64>(sB), tD = segment_sum_to_last<64>(sD);
+            if (lane == 63) { gp[sl.dbias + row] = tB; gp[sl.dD + row] = tD; }
         }
         // gradients of conv_cout (sums over l of dyc * (y0 + y1), and of dyc): wave o does output o; slot dc = the bias
         if (wave <= dc) {
@@ -624,7 +646,7 @@ oss_row_affine_kernel(const T *__restrict__ x, const float *__restrict__ mul, co
 // ---------------------------------------------------------------------------------------------
 size_t chan_grad_floats(int L, int dc, int Rc, int Cc) { return (size_t)ChanSlots(L, dc, Rc, Cc).total; }
 
-constexpr size_t kChanLdsMax = 96 * 1024;
+constexpr size_t kChanLdsMax = 160 * 1024;   // the whole LDS of a CU: one workgroup per image, a handful of images
 static int chan_enable_lds(const void *kern, size_t bytes) {
     if (bytes <= 48 * 1024) return 0;
     return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChanLdsMax);
@@ -642,8 +664,8 @@ static int chan_check(const oss_chan_params &p) {
 
 int chan_fwd(const oss_chan_params &p, hipStream_t s) {
     if (int e = chan_check(p)) return e;
-    size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + kChRed + 2 * kChNT);
-    if (smem > 48 * 1024) return OSS_ERR_SHAPE;
+    size_t smem = sizeof(float) * ((size_t)(3 * p.dc + 1) * p.L + kChRed + 4 * 2 * (size_t)p.dc * p.L);
+    if (smem > kChanLdsMax) return OSS_ERR_SHAPE;
     const size_t extra = sizeof(float) * (2 * (size_t)p.L * p.Cc + 4 * (size_t)p.dc * p.L);
     const int use_lds = smem + extra <= kChanLdsMax ? 1 : 0;
     if (use_lds) smem += extra;
@@ -651,6 +673,7 @@ int chan_fwd(const oss_chan_params &p, hipStream_t s) {
         if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel<true, kChNT>), smem)) return e;
         hipLaunchKernelGGL((oss_chan_fwd_kernel<true, kChNT>), dim3(p.B), dim3(kChNT), smem, s, p);
     } else {
+        if (int e = chan_enable_lds(reinterpret_cast<const void *>(oss_chan_fwd_kernel<false, kChNT>), smem)) return e;
         hipLaunchKernelGGL((oss_chan_fwd_kernel<false, kChNT>), dim3(p.B), dim3(kChNT), smem, s, p);
     }
     return (int)hipGetLastError();
@@ -659,7 +682,7 @@ int chan_fwd(const oss_chan_params &p, hipStream_t s) {
 int chan_bwd(const oss_chan_params &p, const float *gc, float *dpool, float *gsum, float *scratch, hipStream_t s) {
     if (int e = chan_check(p)) return e;
     if (!gc || !dpool || !gsum || !scratch) return OSS_ERR_NULL;
-    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + kChRed + 5 * kChNT + 2 * (size_t)p.Cc * p.dc);
+    size_t smem = sizeof(float) * ((size_t)(2 * p.dc + 1) * p.L + kChRed + 2 * 4 * 2 * (size_t)p.dc * p.L + 2 * (size_t)p.Cc * p.dc);
     if (smem > kChanLdsMax) return OSS_ERR_SHAPE;
     const size_t zdt_bytes = sizeof(float) * 2 * (size_t)p.L * p.Rc;
     const int stage_zdt = smem + zdt_bytes <= kChanLdsMax ? 1 : 0;

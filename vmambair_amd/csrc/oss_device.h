@@ -479,6 +479,24 @@ __device__ __forceinline__ void segment_scan(float &P, float &h) {
     }
 }
 #undef OSS_DPP_STEP
+// Four independent (P, h) pairs scanned together over the 64 lanes: the same steps as segment_scan<64>, interleaved, so that the
+// pairs fill each other's DPP wait states and latencies (oss_channel.hip: the four states of a lane group).
+#define OSS_DPP_STEP4(CTRL)                                    \
+    "v_fmac_f32_dpp %0, %0, %4 " CTRL " bank_mask:0xf\n\t"   \
+    "v_fmac_f32_dpp %1, %1, %5 " CTRL " bank_mask:0xf\n\t"   \
+    "v_fmac_f32_dpp %2, %2, %6 " CTRL " bank_mask:0xf\n\t"   \
+    "v_fmac_f32_dpp %3, %3, %7 " CTRL " bank_mask:0xf\n\t"   \
+    "v_mul_f32_dpp %4, %4, %4 " CTRL " bank_mask:0xf\n\t"    \
+    "v_mul_f32_dpp %5, %5, %5 " CTRL " bank_mask:0xf\n\t"    \
+    "v_mul_f32_dpp %6, %6, %6 " CTRL " bank_mask:0xf\n\t"    \
+    "v_mul_f32_dpp %7, %7, %7 " CTRL " bank_mask:0xf\n\t"
+__device__ __forceinline__ void segment_scan4_64(float (&P)[4], float (&h)[4]) {
+    asm volatile("s_nop 1\n\t" OSS_DPP_STEP4("row_shr:1 row_mask:0xf") OSS_DPP_STEP4("row_shr:2 row_mask:0xf")
+                 OSS_DPP_STEP4("row_shr:4 row_mask:0xf") OSS_DPP_STEP4("row_shr:8 row_mask:0xf")
+                 OSS_DPP_STEP4("row_bcast:15 row_mask:0xa") OSS_DPP_STEP4("row_bcast:31 row_mask:0xc")
+                 : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]));
+}
+#undef OSS_DPP_STEP4
 
 // Builtin (compiler-scheduled) form of the same scan; kept as the readable definition and used by
 // the unit check that both forms agree.

@@ -14,8 +14,11 @@ from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_vi
 
 
 def chan_supported(dc: int, n_state: int, d_inner: int) -> bool:
-    """shapes oss_channel.hip covers: dc_state 16, dc_inner <= 4, LDS-resident rows (every reference config)"""
-    return n_state == 16 and 1 <= dc <= 4 and (3 * dc + 1) * d_inner * 4 + 16 <= 48 * 1024
+    """shapes oss_channel.hip covers: dc_state 16, dc_inner <= 4, the rows of one image LDS-resident in both kernels (every
+    reference config: d_inner <= 384; the backward's resident set -- sequences, gradients, the four state groups' partial sums --
+    is the larger one: (18 dc + 1) d_inner + 2 dc (dc + 32) + 8 floats of the CU's 160 KiB)"""
+    lds_bwd = 4 * ((18 * dc + 1) * d_inner + 2 * dc * (dc + 32 + 8) + 8)
+    return n_state == 16 and 1 <= dc <= 4 and lds_bwd <= 160 * 1024
 
 
 def _chan_params(B, L, pooled, prm, saved, c):
