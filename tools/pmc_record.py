@@ -21,9 +21,11 @@ FWD = {(64, 8, 8): 0, (32, 16, 8): 1, (16, 16, 4): 2, (64, 16, 8): 3, (64, 4, 4)
 
 def key_of(name):
     """kernel name of the trace -> the key bench.py builds from the library's profiler buckets"""
-    m = re.search(r"oss_scan_bwd2_kernel<([^,]+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>", name)
+    m = re.search(r"oss_scan_bwd2_kernel<([^,]+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?(?:, (\w+))?>", name)
     if m:
         seg = " segmented" if m.group(6) == "true" else ""
+        if m.group(7) == "true":   # the instantiation that loads the forward pass's lane states: not the product's default
+            seg += " lane states"
         return f"oss_scan_bwd_kernel variant {BWD2[int(m.group(2))]} io {IO[m.group(1)]}{seg}"
     m = re.search(r"oss_scan_fwd_kernel<([^,]+), (\d+), (\d+), (\d+), (\w+)(?:, (\d+))?>", name)
     if m:
