@@ -243,6 +243,14 @@ size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels
 /* Tuning override of oss_conv1x1_wgrad / oss_proj_wgrad: MFMA tiles per wave, 0 = 1 x 1 (default), 12 / 21 / 22 = rows x columns
  * of 32 x 32 tiles (fewer re-reads of the operands, fewer waves).  Same results up to the summation order; initial value from
  * the environment variable VMAMBAIR_WGRAD_TILE. */
+/* Workgroup-level form of oss_conv1x1_fwd / oss_conv1x1_dgrad without residual (oss_conv1x1_wg.hip): cin % 16 == 0, cin <= 192,
+ * pixels % 128 == 0, 16-byte aligned tensors; anything else returns OSS_ERR_SHAPE (callers then use the wave-level kernels).
+ * transposed_weight = 1: weight is (cin, cout) row-major, i.e. the call is the input gradient of a (cin, cout) convolution. */
+int oss_conv1x1_wg(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout, int cin,
+                   int pixels, int64_t x_batch_stride, int64_t x_channel_stride, int transposed_weight, oss_stream_t stream);
+/* A-B switches of the dispatch inside oss_conv1x1_fwd / _dgrad: on = 0 never takes the workgroup-level kernel (env
+ * VMAMBAIR_CONV1X1_WG=0); pixels = 64 | 128 forces its tile width, 0 = by grid size */
+void oss_conv1x1_set_wg(int on, int pixels);
 void oss_conv1x1_wgrad_set_tile(int mode);
 /* pixels per partial product of the GROUPED weight-gradient launch (oss_flush_wgrads), in units of 512: default 4 (env
  * VMAMBAIR_WGRAD_SPAN); 1 reproduces the one-problem launches bit for bit, larger values write fewer partial vectors */

@@ -120,7 +120,10 @@ def test_fused_scan_merge_node_equals_separate_ops():
                                             # fewer chunks than slots; several row tiles per wave (prefetch); K = 128 / 192 widths;
                                             # weight-gradient slabs: full (512 pixels), rolling window, ragged tail
                                             (1, 80, 100, 16, 16), (1, 40, 33, 8, 16), (2, 192, 96, 32, 32), (1, 128, 64, 16, 32),
-                                            (1, 96, 510, 64, 64), (1, 48, 192, 32, 48), (1, 96, 97, 24, 24)])
+                                            (1, 96, 510, 64, 64), (1, 48, 192, 32, 48), (1, 96, 97, 24, 24),
+                                            # round 3: the workgroup-level kernel (K % 16 == 0, H W % 128 == 0) with ragged row tiles,
+                                            # one / two / twelve k-steps, fewer row tiles than waves
+                                            (1, 96, 97, 16, 16), (2, 32, 40, 16, 8), (1, 16, 8, 8, 16), (1, 192, 33, 16, 8), (2, 64, 255, 16, 16)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_conv1x1_mfma(dt, B, Cin, Cout, H, W, has_bias):
     """MFMA 1x1 convolution (fwd, input grad, weight grad) against F.conv2d in fp32 on the same

@@ -410,6 +410,14 @@ void oss_proj_set_path(int force_vector_alu) { proj_force_valu(force_vector_alu)
 int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstate, int seqlen) {
     return proj_mfma_ok(io, batch, D, C, R, seqlen) && R >= 1 && R <= kMaxDtRank && dstate <= 64 && seqlen >= 512;
 }
+int oss_conv1x1_wg(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout, int cin,
+                   int pixels, int64_t xsb, int64_t xsc, int transposed_weight, oss_stream_t stream) {
+    if (!x || !weight || !y) return OSS_ERR_NULL;
+    if (batch <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return conv1x1_wg(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, transposed_weight, reinterpret_cast<hipStream_t>(stream));
+}
+
+void oss_conv1x1_set_wg(int on, int pixels) { conv1x1_set_wg(on); conv1x1_wg_set_pixels(pixels); }
 void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
 void oss_conv1x1_wgrad_set_span(int mult) { conv1x1_wgrad_set_span(mult); }
 

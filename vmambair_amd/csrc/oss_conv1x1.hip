@@ -971,8 +971,27 @@ static void conv1x1_launch(const T *x, const float *w, const float *bias, T *y, 
     }
 }
 
+// 0 = never the workgroup-level kernel of oss_conv1x1_wg.hip (A-B timing).  Initial value from VMAMBAIR_CONV1X1_WG (default on).
+static std::atomic<int> g_conv_wg{-1};
+static bool conv_wg_on() {
+    int m = g_conv_wg.load();
+    if (m < 0) {
+        const char *e = std::getenv("VMAMBAIR_CONV1X1_WG");
+        m = (e && std::atoi(e) == 0) ? 0 : 1;
+        g_conv_wg.store(m);
+    }
+    return m != 0;
+}
+
+void conv1x1_set_wg(int on) { g_conv_wg.store(on ? 1 : 0); }
+
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const void *res) {
+    {
+        const bool wt = (ws_m == 1 && ws_k == M), plain = (ws_k == 1 && ws_m == K);
+        if ((wt || plain) && conv_wg_on() && conv1x1_wg_ok(io, M, K, P, xsb, xsk, x, y, w, res))
+            return conv1x1_wg(io, x, w, bias, y, B, M, K, P, xsb, xsk, wt ? 1 : 0, s, res);
+    }
     switch (io) {
         case OSS_BF16:
             conv1x1_launch<bf16_t>(reinterpret_cast<const bf16_t *>(x), w, bias, reinterpret_cast<bf16_t *>(y), B, M, K, P, xsb,

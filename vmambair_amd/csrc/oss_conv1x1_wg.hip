@@ -1,0 +1,219 @@
+// oss_conv1x1_wg.hip -- workgroup-level forward / input-gradient form of the 1x1 convolutions of the OSS block
+// (in_conv, out_conv, project_in and their siblings, SRGAN/VmambaIR/archs/MambaSISR6_arch.py:205,211,281,329) for K % 16 == 0,
+// K <= 192, H W % 128 == 0, 16-bit I/O, incl. bias and the fused skip connection.
+//
+// The wave-level kernels of oss_conv1x1.hip build the MFMA activation operand (8 input channels of ONE pixel per lane) from
+// 4-byte loads that walk the channel axis of an NCHW tensor -- one load per channel and pixel pair, every wave its own copy
+// -- and store their results 4 bytes per lane; at the headline shapes they run as chains of latencies at one wave per SIMD
+// (DESIGN.md section 9).  Here a workgroup
+//   1. copies its activation tile x[b, 0..K, p0..p0+128) into LDS AS IT LIES IN MEMORY ([channel][pixel], 16-byte accesses on
+//      both sides: each element crosses the CU's load path once per workgroup instead of once per wave and row-tile split),
+//   2. reads the operand fragments back with ds_read_b64_tr_b16 -- the LDS transpose-read of gfx950: a 16-lane group reads a
+//      [4 channels][16 pixels] block, 8 bytes per lane, and every lane receives the four channels of ONE pixel -- so the
+//      [pixel][8 channels] fragment the MFMA wants comes out of a [channel][pixel] image without any strided access,
+//   3. gives every wave whole 32-row tiles of the output over all 128 pixels (four MFMA column tiles per weight fragment),
+//   4. sends the results through a wave-private LDS tile and out as 16-byte stores along the pixel axis.
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include "oss_device.h"
+#include "oss_host.h"
+#include "oss_mfma.h"
+
+namespace oss {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// W(m, k) = w[m * ws_m + k * ws_k] as in oss_conv1x1.hip: forward ws_m = K, ws_k = 1; input gradient ws_m = 1, ws_k = M.
+// PT: pixels per workgroup (128; 64 when 128-pixel tiles would leave the chip with fewer than two workgroups per CU).
+// RES: y = W x + bias + res (the block's skip connection); the results then wait in LDS as fp32 so that the sum is rounded once.
+// PF: the next row tile's weight fragments are requested before the current tile's MFMAs (KS <= 6: two tiles' raw fragments fit).
+template <typename T, int KS, bool WT, int PT, bool RES, bool PF>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ y,
+                      int M, int P, int64_t xsb, int64_t xsk, const T *__restrict__ res) {
+    constexpr int K = 16 * KS, PITCH = PT + 8, NCT = PT / 32;   // LDS row pitch in elements: 16-byte aligned rows, banks spread
+    using OT = typename std::conditional<RES, float, T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    T *xs = reinterpret_cast<T *>(wg_smem);                    // [K][PITCH]
+    OT *os = reinterpret_cast<OT *>(xs + K * PITCH);           // [4 waves][32][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, p0 = blockIdx.x * PT;
+    const T *xb = x + b * xsb + p0;
+    const int col = lane & 31, kg = lane >> 5;
+    const int mt_total = (M + 31) >> 5;
+    struct WRaw { f32x4 lo[KS], hi[KS]; float bl; };
+    auto issue = [&](int mt, WRaw &r) {   // weight fragments + the bias value of row m0 + col: one group of loads
+        const int mrow = min(mt * 32 + col, M - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = ks * 16 + kg * 8;
+            if constexpr (!WT) {
+                r.lo[ks] = *reinterpret_cast<const f32x4 *>(w + (size_t)mrow * K + k0);
+                r.hi[ks] = *reinterpret_cast<const f32x4 *>(w + (size_t)mrow * K + k0 + 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r.lo[ks][e] = w[(size_t)(k0 + e) * M + mrow];
+                    r.hi[ks][e] = w[(size_t)(k0 + 4 + e) * M + mrow];
+                }
+            }
+        }
+        r.bl = bias ? bias[mrow] : 0.f;
+    };
+    WRaw cur;
+    if (wave < mt_total) issue(wave, cur);   // in flight across the activation copy
+    // 1. the activation tile, 16 bytes per lane: lane -> (channel, 8-pixel chunk), a row's chunks on consecutive lanes
+    constexpr int CPR = PT / 8;   // chunks per row
+    for (int idx = tid; idx < K * CPR; idx += 256) {
+        const int c = idx / CPR, pc = idx - c * CPR;
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(xb + c * xsk + 8 * pc);
+        *reinterpret_cast<u32x4 *>(xs + c * PITCH + 8 * pc) = q;
+    }
+    __syncthreads();
+    const int i16 = lane & 15, g = lane >> 4;
+    // transpose-read address of this lane inside a [4][16] block: row i16 / 4, pixels 4 (i16 % 4) .. + 3; the lane then HOLDS
+    // pixel i16 of the block.  Blocks of the 16-lane groups: pixels 16 (g & 1) + .. of the column tile, channels 8 (g >> 1) + ..
+    const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * PITCH + 16 * (g & 1) + 4 * (i16 & 3);
+    OT *ow = os + wave * 32 * PITCH;
+    for (int mt = wave; mt < mt_total; mt += 4) {
+        const int m0 = mt * 32;
+        WRaw nxt;
+        if constexpr (PF) { if (mt + 4 < mt_total) issue(mt + 4, nxt); }
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const s16x8 af = m0 + col < M ? cvt8<T>(cur.lo[ks], cur.hi[ks]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const T *bp = xs + ks * 16 * PITCH + ct * 32 + tr_off;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp + 4 * PITCH));
+                const s16x8 bf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                acc[ct] = Mfma<T>::run(af, bf, acc[ct]);
+            }
+        }
+        // 4. results (+ bias) -> the wave's LDS tile [row][pixel] -> 16-byte stores (+ the residual, rounded once)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const float bv = __int_as_float(__builtin_amdgcn_ds_bpermute(row << 2, __float_as_int(cur.bl)));
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                if constexpr (RES) ow[row * PITCH + ct * 32 + col] = acc[ct][r] + bv;
+                else               ow[row * PITCH + ct * 32 + col] = from_f32<T>(acc[ct][r] + bv);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 32 * CPR / 64; ++q) {
+            const int chunk = q * 64 + lane, row = chunk / CPR, pc = chunk - row * CPR;
+            if (m0 + row < M) {
+                const size_t o = ((size_t)b * M + m0 + row) * P + p0 + 8 * pc;
+                if constexpr (RES) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(ow + row * PITCH + 8 * pc);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(ow + row * PITCH + 8 * pc + 4);
+                    const u32x4 rq = *reinterpret_cast<const u32x4 *>(res + o);
+                    float r8[8];
+                    unpack2<T>(rq.x, r8[0], r8[1]); unpack2<T>(rq.y, r8[2], r8[3]); unpack2<T>(rq.z, r8[4], r8[5]); unpack2<T>(rq.w, r8[6], r8[7]);
+                    *reinterpret_cast<u32x4 *>(y + o) = u32x4{pack2<T>(v0.x + r8[0], v0.y + r8[1]), pack2<T>(v0.z + r8[2], v0.w + r8[3]),
+                                                              pack2<T>(v1.x + r8[4], v1.y + r8[5]), pack2<T>(v1.z + r8[6], v1.w + r8[7])};
+                } else {
+                    *reinterpret_cast<u32x4 *>(y + o) = *reinterpret_cast<const u32x4 *>(ow + row * PITCH + 8 * pc);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (PF) { cur = nxt; } else { if (mt + 4 < mt_total) issue(mt + 4, cur); }
+    }
+}
+
+static size_t wg_lds_bytes(int K, int pt, bool res) { return ((size_t)K * 2 + 4 * 32 * (res ? 4 : 2)) * (pt + 8); }
+// pixels per workgroup: 0 = by shape, 64 / 128 = forced (A-B timing).  Measured at batch 8 x 64 x 64 (tools/conv_wg_test.py):
+// K = 96 / 192 want 128 pixels (four column tiles per weight fragment), K = 48 wants 64 (twice the workgroups of a small problem).
+static std::atomic<int> g_wg_pixels{-1};
+void conv1x1_wg_set_pixels(int pt) { g_wg_pixels.store(pt == 64 || pt == 128 ? pt : 0); }
+static int wg_pixels(int B, int K, int P) {
+    int f = g_wg_pixels.load();
+    if (f < 0) {
+        const char *e = std::getenv("VMAMBAIR_CONV1X1_WG_PIXELS");
+        const int v = e ? std::atoi(e) : 0;
+        f = (v == 64 || v == 128) ? v : 0;
+        g_wg_pixels.store(f);
+    }
+    if (f) return f;
+    return (K <= 48 && (long)B * (P / 128) < 1024) ? 64 : 128;
+}
+
+// 1 when the workgroup-level kernel takes the shape
+int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,
+                  const void *res) {
+    // The fused skip connection (RES) is written and parity-green, but inside the training step it measured SLOWER than the
+    // wave-level kernel (10.6 vs 9.4 us at 96 -> 96: the residual arrives cold from HBM behind the fp32 LDS round trip), so
+    // those calls stay where they were and the RES instantiations are not built.
+    if (res) return 0;
+    if (io != OSS_BF16 && io != OSS_F16) return 0;
+    if (K % 16 != 0 || K < 16 || K > 192 || P % 128 != 0 || M < 1) return 0;
+    if (xsb % 8 != 0 || xsk % 8 != 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(res)) & 15u)
+        return 0;
+    return wg_lds_bytes(K, 128, res != nullptr) <= kMaxLdsBytes ? 1 : 0;
+}
+
+template <typename T, bool WT>
+static int wg_launch(const T *x, const float *w, const float *bias, T *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk,
+                     const T *res, hipStream_t s) {
+    const int pt = wg_pixels(B, K, P);
+    const size_t smem = wg_lds_bytes(K, pt, res != nullptr);
+    dim3 grid(P / pt, B);
+#define OSS_WG3(KS_, PT_, RES_)                                                                                      \
+    do {                                                                                                             \
+        static LdsGate gate;                                                                                         \
+        auto kern = oss_conv1x1_wg_kernel<T, KS_, WT, PT_, RES_, (KS_ <= 6)>;                                        \
+        if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;                         \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, x, w, bias, y, M, P, xsb, xsk, res);                      \
+    } while (0)
+#define OSS_WG(KS_)                                                                                                  \
+    do {                                                                                                             \
+        if (pt == 128) OSS_WG3(KS_, 128, false); else OSS_WG3(KS_, 64, false);                                       \
+    } while (0)
+    switch (K / 16) {
+        case 1: OSS_WG(1); break;
+        case 2: OSS_WG(2); break;
+        case 3: OSS_WG(3); break;
+        case 4: OSS_WG(4); break;
+        case 5: OSS_WG(5); break;
+        case 6: OSS_WG(6); break;
+        case 7: OSS_WG(7); break;
+        case 8: OSS_WG(8); break;
+        case 9: OSS_WG(9); break;
+        case 10: OSS_WG(10); break;
+        case 11: OSS_WG(11); break;
+        case 12: OSS_WG(12); break;
+        default: return OSS_ERR_SHAPE;
+    }
+#undef OSS_WG
+#undef OSS_WG3
+    return (int)hipGetLastError();
+}
+
+// wt = 0: y = W x + bias [+ res] with w (M, K) row-major; wt = 1: W(m, k) = w[k * M + m] (the input gradient of a (K, M) weight)
+int conv1x1_wg(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
+               int64_t xsk, int wt, hipStream_t s, const void *res) {
+    if (!conv1x1_wg_ok(io, M, K, P, xsb, xsk, x, y, w, res)) return OSS_ERR_SHAPE;
+    if (io == OSS_BF16)
+        return wt ? wg_launch<bf16_t, true>(reinterpret_cast<const bf16_t *>(x), w, bias, reinterpret_cast<bf16_t *>(y), B, M, K, P, xsb, xsk,
+                                            reinterpret_cast<const bf16_t *>(res), s)
+                  : wg_launch<bf16_t, false>(reinterpret_cast<const bf16_t *>(x), w, bias, reinterpret_cast<bf16_t *>(y), B, M, K, P, xsb, xsk,
+                                             reinterpret_cast<const bf16_t *>(res), s);
+    return wt ? wg_launch<f16_t, true>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
+                                       reinterpret_cast<const f16_t *>(res), s)
+              : wg_launch<f16_t, false>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
+                                        reinterpret_cast<const f16_t *>(res), s);
+}
+
+}  // namespace oss

@@ -75,6 +75,13 @@ int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const
                 const void *res = nullptr, int64_t dgsb = 0, const float *dy_mul = nullptr, const float *dy_add = nullptr,
                 float add_scale = 1.f);
 int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, hipStream_t s);
+// workgroup-level 1x1 convolution (oss_conv1x1_wg.hip)
+void conv1x1_set_wg(int on);
+void conv1x1_wg_set_pixels(int pt);
+int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,
+                  const void *res = nullptr);
+int conv1x1_wg(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
+               int64_t xsk, int wt, hipStream_t s, const void *res = nullptr);
 int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
             int64_t xsk, int64_t ws_m, int64_t ws_k, hipStream_t s, const void *res = nullptr);
 int conv1x1_wgrad_slabs(int P);
