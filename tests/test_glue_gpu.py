@@ -316,3 +316,31 @@ def test_norm_channel_gate_node_matches_the_two_separate_nodes():
     assert_close(res[0][1], res[1][1], 2e-2, 2e-2 * float(res[1][1].abs().max()), "dx")
     for k, g in res[1][2].items():
         assert_close(res[0][2][k], g, 3e-2, 3e-2 * max(float(g.abs().max()), 1e-6), k)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 192, 32, 32), (1, 96, 510, 16, 16), (2, 48, 254, 16, 8), (1, 192, 96, 16, 16),
+                                            (1, 16, 40, 8, 16), (2, 80, 33, 16, 8), (1, 176, 97, 8, 32)])
+def test_conv1x1_workgroup_level_kernel_is_bit_identical_to_the_wave_level_ones(dt, B, Cin, Cout, H, W):
+    """oss_conv1x1_wg.hip (LDS-resident activation tile, ds_read_b64_tr_b16 fragments, 64- and 128-pixel workgroups) through the
+    same entry points as the wave-level kernels of oss_conv1x1.hip: forward (+ bias) and input gradient, torch.equal"""
+    from vmambair_amd import _capi
+    lib = _capi.load()
+    torch.manual_seed(3)
+    x = torch.randn(B, Cin, H, W, device=DEV).to(dt)
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (Cin ** -0.5)
+    b = torch.randn(Cout, device=DEV)
+    dy = torch.randn(B, Cout, H, W, device=DEV).to(dt)
+    outs = []
+    try:
+        for on, pix in ((0, 0), (1, 128), (1, 64), (1, 0)):
+            lib.oss_conv1x1_set_wg(on, pix)
+            y = ops.conv1x1_fwd(x, w, b)
+            dx = ops.conv1x1_bwd(x, w, dy, True)[0]
+            torch.cuda.synchronize()
+            outs.append((y.clone(), dx.clone()))
+    finally:
+        lib.oss_conv1x1_set_wg(1, 0)
+    for y, dx in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][1])
+    assert_close(outs[0][0], F.conv2d(x.float(), w.to(dt).float(), b), 2e-2 if dt == torch.bfloat16 else 3e-3, 3e-2, "y vs torch")
