@@ -248,6 +248,15 @@ size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels
  * transposed_weight = 1: weight is (cin, cout) row-major, i.e. the call is the input gradient of a (cin, cout) convolution. */
 int oss_conv1x1_wg(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout, int cin,
                    int pixels, int64_t x_batch_stride, int64_t x_channel_stride, int transposed_weight, oss_stream_t stream);
+/* LayerNorm over channels followed by a 1x1 convolution as ONE launch (norm1 -> in_conv, norm2 -> project_in of the OSS block,
+ * MambaSISR6_arch.py:514-516 with :144-195, :205, :281): n = LN(x) (weight, bias or NULL for the BiasFree form, eps), written out
+ * together with mean / rstd (batch, pixels) for the backward passes (oss_ln_nchw_bwd, oss_conv1x1_wgrad take them as before), and
+ * y = W n + bias.  Shapes of oss_conv1x1_wg: cin % 16 == 0, cin <= 192, pixels % 128 == 0, 16-bit io, 16-byte aligned tensors;
+ * oss_ln_conv1x1_ok says whether (io, cout, cin, pixels) qualifies. */
+int oss_ln_conv1x1_ok(oss_dtype io, int cout, int cin, int pixels);
+int oss_ln_conv1x1_fwd(oss_dtype io, const void *x, const float *ln_weight, const float *ln_bias, float eps, void *n, float *mean,
+                       float *rstd, const float *weight, const float *bias, void *y, int batch, int cout, int cin, int pixels,
+                       int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
 /* A-B switches of the dispatch inside oss_conv1x1_fwd / _dgrad: on = 0 never takes the workgroup-level kernel (env
  * VMAMBAIR_CONV1X1_WG=0); pixels = 64 | 128 forces its tile width, 0 = by grid size */
 void oss_conv1x1_set_wg(int on, int pixels);

@@ -344,3 +344,60 @@ def test_conv1x1_workgroup_level_kernel_is_bit_identical_to_the_wave_level_ones(
     for y, dx in outs[1:]:
         assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][1])
     assert_close(outs[0][0], F.conv2d(x.float(), w.to(dt).float(), b), 2e-2 if dt == torch.bfloat16 else 3e-3, 3e-2, "y vs torch")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ln_bias", [(2, 96, 192, 32, 32, True), (1, 48, 254, 16, 16, True), (2, 96, 510, 16, 8, False),
+                                                     (1, 192, 384, 16, 8, True), (2, 48, 96, 64, 64, True), (1, 16, 33, 8, 16, False)])
+def test_layernorm_fused_into_the_1x1_convolution(dt, B, Cin, Cout, H, W, ln_bias):
+    """LNConv1x1Fn (norm1 -> in_conv, norm2 -> project_in in one forward launch: the LayerNorm runs on the convolution's LDS-resident
+    activation tile) against plain PyTorch fp32 and against the two separate nodes on the same tensors, incl. the skip connection's
+    gradient through the alias output and both LayerNorm forms (WithBias / BiasFree)"""
+    torch.manual_seed(5)
+    x = (torch.randn(B, Cin, H, W, device=DEV) * 1.5 + 0.3).to(dt)
+    lw = torch.randn(Cin, device=DEV) * 0.2 + 1.0
+    lb = torch.randn(Cin, device=DEV) * 0.1 if ln_bias else None
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (Cin ** -0.5)
+    b = torch.randn(Cout, device=DEV)
+    dy = torch.randn(B, Cout, H, W, device=DEV).to(dt)
+    dskip = torch.randn(B, Cin, H, W, device=DEV).to(dt)
+    conv = torch.nn.Conv2d(Cin, Cout, 1).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(b)
+    assert ops.ln_conv1x1_ok(x, conv.weight)
+    res = []
+    for fused in (True, False):
+        conv.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        lwi = lw.clone().requires_grad_()
+        lbi = lb.clone().requires_grad_() if ln_bias else None
+        if fused:
+            y, skip = ops.ln_conv1x1(xi, lwi, lbi, conv)
+        else:
+            n, skip = ops.layer_norm_nchw(xi, lwi, lbi, None, dt, True)
+            y = ops.conv1x1(n, conv)
+        torch.autograd.backward([y, skip], [dy, dskip])
+        res.append((y.detach().float(), xi.grad.float(), lwi.grad.clone(), lbi.grad.clone() if ln_bias else None,
+                    conv.weight.grad.clone(), conv.bias.grad.clone()))
+    # plain PyTorch fp32 on the same 16-bit inputs
+    xr = x.float().clone().requires_grad_()
+    lwr, wr, br = lw.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    lbr = lb.clone().requires_grad_() if ln_bias else None
+    mu = xr.mean(1, keepdim=True)
+    rs = (xr.var(1, keepdim=True, unbiased=False) + 1e-5).rsqrt()
+    n = (xr - mu) * rs * lwr.view(1, -1, 1, 1) + lbr.view(1, -1, 1, 1) if ln_bias else xr * rs * lwr.view(1, -1, 1, 1)
+    yr = F.conv2d(n, wr, br)
+    torch.autograd.backward([yr, xr * 1.0], [dy.float(), dskip.float()])
+    rt = 2e-2 if dt == torch.bfloat16 else 3e-3
+    assert_close(res[0][0], yr, 2 * rt, 4 * rt, "y vs torch")
+    assert_close(res[0][1], xr.grad, 2 * rt, 4 * rt * float(xr.grad.abs().max()), "dx vs torch")
+    assert_close(res[0][4], wr.grad, 2 * rt, 2 * rt * float(wr.grad.abs().max()), "dW vs torch")
+    # the two HIP paths: the same to the rounding of the normalised activations (summation order of the statistics differs)
+    assert_close(res[0][0], res[1][0], rt, 2 * rt, "y")
+    assert_close(res[0][1], res[1][1], rt, 2 * rt * float(res[1][1].abs().max()), "dx")
+    assert_close(res[0][2], res[1][2], rt, rt * float(res[1][2].abs().max()), "d ln weight")
+    if ln_bias:
+        assert_close(res[0][3], res[1][3], rt, rt * float(res[1][3].abs().max()), "d ln bias")
+    assert_close(res[0][4], res[1][4], rt, rt * float(res[1][4].abs().max()), "dW")
+    assert_close(res[0][5], res[1][5], 1e-4, 1e-4 * float(res[1][5].abs().max()), "db")

@@ -417,6 +417,22 @@ int oss_conv1x1_wg(oss_dtype io, const void *x, const float *weight, const float
     return conv1x1_wg(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, transposed_weight, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_ln_conv1x1_ok(oss_dtype io, int cout, int cin, int pixels) {
+    static const float dummy = 0.f;   // shape / dtype rules only: an aligned stand-in for the pointers
+    const void *a = reinterpret_cast<const void *>(uintptr_t(256));
+    (void)dummy;
+    return conv1x1_wg_ok(io, cout, cin, pixels, (int64_t)cin * pixels, pixels, a, a, reinterpret_cast<const float *>(a), nullptr);
+}
+
+int oss_ln_conv1x1_fwd(oss_dtype io, const void *x, const float *ln_weight, const float *ln_bias, float eps, void *n, float *mean,
+                       float *rstd, const float *weight, const float *bias, void *y, int batch, int cout, int cin, int pixels,
+                       int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    if (!x || !ln_weight || !n || !mean || !rstd || !weight || !y) return OSS_ERR_NULL;
+    if (batch <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return ln_conv1x1_wg(io, x, ln_weight, ln_bias, eps, n, mean, rstd, weight, bias, y, batch, cout, cin, pixels, xsb, xsc,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 void oss_conv1x1_set_wg(int on, int pixels) { conv1x1_set_wg(on); conv1x1_wg_set_pixels(pixels); }
 void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
 void oss_conv1x1_wgrad_set_span(int mult) { conv1x1_wgrad_set_span(mult); }

@@ -13,6 +13,7 @@
 //      [pixel][8 channels] fragment the MFMA wants comes out of a [channel][pixel] image without any strided access,
 //   3. gives every wave whole 32-row tiles of the output over all 128 pixels (four MFMA column tiles per weight fragment),
 //   4. sends the results through a wave-private LDS tile and out as 16-byte stores along the pixel axis.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -28,10 +29,21 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // PT: pixels per workgroup (128; 64 when 128-pixel tiles would leave the chip with fewer than two workgroups per CU).
 // RES: y = W x + bias + res (the block's skip connection); the results then wait in LDS as fp32 so that the sum is rounded once.
 // PF: the next row tile's weight fragments are requested before the current tile's MFMAs (KS <= 6: two tiles' raw fragments fit).
-template <typename T, int KS, bool WT, int PT, bool RES, bool PF>
+// LN: the activation tile is first LayerNorm-ed over its channels, per pixel, inside LDS (SS2D_1 / EFFN read norm1(x) / norm2(x):
+// MambaSISR6_arch.py:514-516, LayerNorm :144-195) -- the normalised tile is also written out (the weight gradient's operand) with
+// mean / rstd (the LayerNorm backward's), so the separate LayerNorm launch and its round trip through memory are gone.
+template <typename T>
+struct WgLnArgs {
+    const float *w, *b;   // LayerNorm weight, bias (NULL: the BiasFree form, x * rstd * w)
+    T *n;                 // (B, K, P) normalised activations
+    float *mean, *rstd;   // (B, P)
+    float eps;
+};
+
+template <typename T, int KS, bool WT, int PT, bool RES, bool PF, bool LN>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ y,
-                      int M, int P, int64_t xsb, int64_t xsk, const T *__restrict__ res) {
+                      int M, int P, int64_t xsb, int64_t xsk, const T *__restrict__ res, WgLnArgs<T> ln) {
     constexpr int K = 16 * KS, PITCH = PT + 8, NCT = PT / 32;   // LDS row pitch in elements: 16-byte aligned rows, banks spread
     using OT = typename std::conditional<RES, float, T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
@@ -62,7 +74,10 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
         r.bl = bias ? bias[mrow] : 0.f;
     };
     WRaw cur;
-    if (wave < mt_total) issue(wave, cur);   // in flight across the activation copy
+    // row tiles of this workgroup: (wave + 4 j) * gridDim.z + blockIdx.z -- the launch may split a problem's row tiles over
+    // gridDim.z workgroups (each stages the activation tile again) when the pixel tiles alone would not fill the chip
+    const int nz = gridDim.z, zi = blockIdx.z;
+    if (wave * nz + zi < mt_total) issue(wave * nz + zi, cur);   // in flight across the activation copy
     // 1. the activation tile, 16 bytes per lane: lane -> (channel, 8-pixel chunk), a row's chunks on consecutive lanes
     constexpr int CPR = PT / 8;   // chunks per row
     for (int idx = tid; idx < K * CPR; idx += 256) {
@@ -71,15 +86,63 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
         *reinterpret_cast<u32x4 *>(xs + c * PITCH + 8 * pc) = q;
     }
     __syncthreads();
+    if constexpr (LN) {
+        // 256 / PT threads per pixel, each with K / TPP channels of the pixel's column in registers: two-pass mean / variance in
+        // fp32 as oss_ln_nchw_fwd_kernel, the partial sums of a pixel combined through LDS in a fixed order
+        constexpr int TPP = 256 / PT, CPT = K / TPP;
+        static_assert(K % TPP == 0, "channels split evenly over a pixel's threads");
+        float *red = reinterpret_cast<float *>(os);          // [TPP][PT], the output staging area is still unused
+        const int px = tid % PT, part = tid / PT;
+        float v[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) v[i] = to_f32(xs[(part * CPT + i) * PITCH + px]);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) sum += v[i];
+        red[part * PT + px] = sum;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < TPP; ++q) tot += red[q * PT + px];
+        const float mu = tot / (float)K;
+        __syncthreads();
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { const float d = v[i] - mu; sq = __builtin_fmaf(d, d, sq); }
+        red[part * PT + px] = sq;
+        __syncthreads();
+        float qt = 0.f;
+#pragma unroll
+        for (int q = 0; q < TPP; ++q) qt += red[q * PT + px];
+        const float rstd = 1.0f / sqrtf(qt / (float)K + ln.eps);
+        if (part == 0 && zi == 0) {
+            ln.mean[(size_t)b * P + p0 + px] = mu;
+            ln.rstd[(size_t)b * P + p0 + px] = rstd;
+        }
+        const bool with_bias = ln.b != nullptr;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = part * CPT + i;
+            const float wc = ln.w[c], bc = with_bias ? ln.b[c] : 0.f;
+            const float o = with_bias ? (v[i] - mu) * rstd * wc + bc : v[i] * rstd * wc;
+            xs[c * PITCH + px] = from_f32<T>(o);
+        }
+        __syncthreads();   // (also: red[] has been read by everyone before the output staging reuses it)
+        T *nb = ln.n + (size_t)b * K * P + p0;
+        for (int idx = tid; zi == 0 && idx < K * CPR; idx += 256) {
+            const int c = idx / CPR, pc = idx - c * CPR;
+            *reinterpret_cast<u32x4 *>(nb + (size_t)c * P + 8 * pc) = *reinterpret_cast<const u32x4 *>(xs + c * PITCH + 8 * pc);
+        }
+    }
     const int i16 = lane & 15, g = lane >> 4;
     // transpose-read address of this lane inside a [4][16] block: row i16 / 4, pixels 4 (i16 % 4) .. + 3; the lane then HOLDS
     // pixel i16 of the block.  Blocks of the 16-lane groups: pixels 16 (g & 1) + .. of the column tile, channels 8 (g >> 1) + ..
     const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * PITCH + 16 * (g & 1) + 4 * (i16 & 3);
     OT *ow = os + wave * 32 * PITCH;
-    for (int mt = wave; mt < mt_total; mt += 4) {
+    for (int mt = wave * nz + zi; mt < mt_total; mt += 4 * nz) {
         const int m0 = mt * 32;
         WRaw nxt;
-        if constexpr (PF) { if (mt + 4 < mt_total) issue(mt + 4, nxt); }
+        if constexpr (PF) { if (mt + 4 * nz < mt_total) issue(mt + 4 * nz, nxt); }
         f32x16 acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -128,16 +191,18 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (PF) { cur = nxt; } else { if (mt + 4 < mt_total) issue(mt + 4, cur); }
+        if constexpr (PF) { cur = nxt; } else { if (mt + 4 * nz < mt_total) issue(mt + 4 * nz, cur); }
     }
 }
 
 static size_t wg_lds_bytes(int K, int pt, bool res) { return ((size_t)K * 2 + 4 * 32 * (res ? 4 : 2)) * (pt + 8); }
-// pixels per workgroup: 0 = by shape, 64 / 128 = forced (A-B timing).  Measured at batch 8 x 64 x 64 (tools/conv_wg_test.py):
-// K = 96 / 192 want 128 pixels (four column tiles per weight fragment), K = 48 wants 64 (twice the workgroups of a small problem).
+// pixels per workgroup (64 | 128) and the row-tile split (gridDim.z): 0 = by shape, else forced (A-B timing).  Measured
+// (tools/conv_wg_test.py, and inside the SR and Deraining steps): K = 96 / 192 want 128 pixels when that still gives a
+// workgroup per CU, K <= 48 wants 64; a launch with fewer workgroups than CUs (Deraining levels 1.. at batch 4) loses to the
+// wave-level kernels unless its row tiles are split over more workgroups.
 static std::atomic<int> g_wg_pixels{-1};
 void conv1x1_wg_set_pixels(int pt) { g_wg_pixels.store(pt == 64 || pt == 128 ? pt : 0); }
-static int wg_pixels(int B, int K, int P) {
+static void wg_shape(int B, int M, int K, int P, int &pt, int &nz) {
     int f = g_wg_pixels.load();
     if (f < 0) {
         const char *e = std::getenv("VMAMBAIR_CONV1X1_WG_PIXELS");
@@ -145,8 +210,13 @@ static int wg_pixels(int B, int K, int P) {
         f = (v == 64 || v == 128) ? v : 0;
         g_wg_pixels.store(f);
     }
-    if (f) return f;
-    return (K <= 48 && (long)B * (P / 128) < 1024) ? 64 : 128;
+    const long t128 = (long)B * (P / 128);
+    pt = f ? f : ((K <= 48 && t128 < 1024) || t128 < 256 ? 64 : 128);
+    const long wgs = (long)B * (P / pt);
+    const int groups = ((M + 31) / 32 + 3) / 4;           // row tiles in units of a workgroup's four waves
+    static const int target = [] { const char *e = std::getenv("VMAMBAIR_CONV1X1_WG_TARGET"); return e ? std::atoi(e) : 256; }();
+    nz = (int)std::min<long>(groups, (target + wgs - 1) / wgs);
+    if (nz < 1) nz = 1;
 }
 
 // 1 when the workgroup-level kernel takes the shape
@@ -164,18 +234,19 @@ int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, c
     return wg_lds_bytes(K, 128, res != nullptr) <= kMaxLdsBytes ? 1 : 0;
 }
 
-template <typename T, bool WT>
+template <typename T, bool WT, bool LN = false>
 static int wg_launch(const T *x, const float *w, const float *bias, T *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk,
-                     const T *res, hipStream_t s) {
-    const int pt = wg_pixels(B, K, P);
+                     const T *res, hipStream_t s, WgLnArgs<T> ln = WgLnArgs<T>{}) {
+    int pt, nz;
+    wg_shape(B, M, K, P, pt, nz);
     const size_t smem = wg_lds_bytes(K, pt, res != nullptr);
-    dim3 grid(P / pt, B);
+    dim3 grid(P / pt, B, nz);
 #define OSS_WG3(KS_, PT_, RES_)                                                                                      \
     do {                                                                                                             \
         static LdsGate gate;                                                                                         \
-        auto kern = oss_conv1x1_wg_kernel<T, KS_, WT, PT_, RES_, (KS_ <= 6)>;                                        \
+        auto kern = oss_conv1x1_wg_kernel<T, KS_, WT, PT_, RES_, (KS_ <= 6), LN>;                                        \
         if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;                         \
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, x, w, bias, y, M, P, xsb, xsk, res);                      \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, x, w, bias, y, M, P, xsb, xsk, res, ln);                      \
     } while (0)
 #define OSS_WG(KS_)                                                                                                  \
     do {                                                                                                             \
@@ -214,6 +285,20 @@ int conv1x1_wg(oss_dtype io, const void *x, const float *w, const float *bias, v
                                        reinterpret_cast<const f16_t *>(res), s)
               : wg_launch<f16_t, false>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
                                         reinterpret_cast<const f16_t *>(res), s);
+}
+
+// n = LayerNorm(x) (ln_w, ln_b or NULL), mean, rstd written out; y = W n + bias.  Same shape rules as conv1x1_wg (forward only).
+int ln_conv1x1_wg(oss_dtype io, const void *x, const float *ln_w, const float *ln_b, float eps, void *n, float *mean, float *rstd,
+                  const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk, hipStream_t s) {
+    if (!conv1x1_wg_ok(io, M, K, P, xsb, xsk, x, y, w, nullptr) || (reinterpret_cast<uintptr_t>(n) & 15u)) return OSS_ERR_SHAPE;
+    if (io == OSS_BF16) {
+        WgLnArgs<bf16_t> a{ln_w, ln_b, reinterpret_cast<bf16_t *>(n), mean, rstd, eps};
+        return wg_launch<bf16_t, false, true>(reinterpret_cast<const bf16_t *>(x), w, bias, reinterpret_cast<bf16_t *>(y), B, M, K, P, xsb,
+                                              xsk, nullptr, s, a);
+    }
+    WgLnArgs<f16_t> a{ln_w, ln_b, reinterpret_cast<f16_t *>(n), mean, rstd, eps};
+    return wg_launch<f16_t, false, true>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
+                                         nullptr, s, a);
 }
 
 }  // namespace oss

@@ -76,6 +76,8 @@ int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const
                 float add_scale = 1.f);
 int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, hipStream_t s);
 // workgroup-level 1x1 convolution (oss_conv1x1_wg.hip)
+int ln_conv1x1_wg(oss_dtype io, const void *x, const float *ln_w, const float *ln_b, float eps, void *n, float *mean, float *rstd,
+                  const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk, hipStream_t s);
 void conv1x1_set_wg(int on);
 void conv1x1_wg_set_pixels(int pt);
 int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,

@@ -21,7 +21,8 @@ from ._common import (WgradTable, flush_wgrads, pending_wgrad_table_bytes, pendi
                       deferred_finishes, flush_finishes, orphaned_deferred_outputs, pending_finish_chunks, scan_chunk,
                       PairGrad, split_halves, wgrad_side_stream)
 from .channel import ChannelGateFn, NormChannelGateFn, chan_gate_bwd, chan_gate_fwd, chan_supported  # noqa: F401
-from .pointwise import Conv1x1Fn, conv1x1, conv1x1_bwd, conv1x1_fwd  # noqa: F401
+from .pointwise import (Conv1x1Fn, LNConv1x1Fn, conv1x1, conv1x1_bwd, conv1x1_fwd, ln_conv1x1, ln_conv1x1_fwd,  # noqa: F401
+                        ln_conv1x1_ok)
 from .core import (SS2DCoreFn, core_supported, cross_merge2, cross_scan2, fused_dt_supported, proj_dgrad, proj_fwd,  # noqa: F401
                    proj_set_path, proj_wgrad, ss2d_core_bwd, ss2d_core_fwd)
 from .dwconv import (DWConv3x3Fn, DWGateFn, dwconv3x3, dwconv3x3_bwd, dwconv3x3_fwd, dwconv3x3_gelu_gate,  # noqa: F401

@@ -104,3 +104,71 @@ def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, residual: Optional[torch.Ten
             return Conv1x1Fn.apply(x, conv.weight, conv.bias, residual)
     y = conv(x)
     return y if residual is None else residual + y
+
+
+# ---- LayerNorm -> 1x1 convolution as one forward launch (oss_conv1x1_wg.hip, LN form) -----------------------------------------
+#: ``VMAMBAIR_LN_CONV_FUSED=0``: norm1 / norm2 stay launches of their own in front of in_conv / project_in (A-B timing)
+LN_CONV_FUSED = os.environ.get("VMAMBAIR_LN_CONV_FUSED", "1") == "1"
+
+
+def ln_conv1x1_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """does the fused LayerNorm + 1x1-conv forward take these tensors?"""
+    if not (LN_CONV_FUSED and CONV1X1_IMPL == "mfma" and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+            and x.numel() and weight.dim() == 4 and weight.shape[2] == 1 and weight.shape[3] == 1):
+        return False
+    B, Cin, H, W = x.shape
+    if not (x.stride(3) == 1 and x.stride(2) == W and x.stride(1) % 8 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+        return False
+    return bool(_capi.load().oss_ln_conv1x1_ok(_DT[x.dtype], weight.shape[0], Cin, H * W))
+
+
+def ln_conv1x1_fwd(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: Optional[torch.Tensor], weight: torch.Tensor,
+                   bias: Optional[torch.Tensor]) -> List[torch.Tensor]:
+    """``n = LayerNorm_channels(x); y = F.conv2d(n, weight, bias)`` in one launch -> [y, n, mean (B, H W), rstd (B, H W)]"""
+    B, Cin, H, W = x.shape
+    Cout, P = weight.shape[0], H * W
+    w = weight.detach().float().reshape(Cout, Cin).contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    lw = ln_weight.detach().float().contiguous()
+    lb = None if ln_bias is None else ln_bias.detach().float().contiguous()
+    y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+    n = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
+    mean = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B, P), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.load().oss_ln_conv1x1_fwd(_DT[x.dtype], x.data_ptr(), lw.data_ptr(), _ptr(lb), 1e-5, n.data_ptr(), mean.data_ptr(),
+                                                    rstd.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), B, Cout, Cin, P, x.stride(0),
+                                                    x.stride(1), torch.cuda.current_stream().cuda_stream), "oss_ln_conv1x1_fwd")
+    return [y, n, mean, rstd]
+
+
+_LIB.define("ln_conv1x1_fwd(Tensor x, Tensor ln_weight, Tensor? ln_bias, Tensor weight, Tensor? bias) -> Tensor[]")
+_LIB.impl("ln_conv1x1_fwd", ln_conv1x1_fwd, "CUDA")
+
+
+class LNConv1x1Fn(torch.autograd.Function):
+    """``conv1x1(LayerNorm(x))`` with ``x`` itself returned as a second output (the alias the block's skip connection uses, as
+    LayerNormNCHWFn(passthrough=True)): one launch forward; backward = the 1x1 convolution's (input + weight gradient on the saved
+    normalised activations) followed by the LayerNorm's, which also takes the skip connection's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, ln_weight, ln_bias, weight, bias):
+        y, n, mean, rstd = torch.ops.vmambair.ln_conv1x1_fwd(x, ln_weight, ln_bias, weight, bias)
+        ctx.has_bias, ctx.has_lnb = bias is not None, ln_bias is not None
+        ctx.save_for_backward(x, ln_weight, ln_bias, n, mean, rstd, weight)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip=None):
+        x, ln_weight, ln_bias, n, mean, rstd, weight = ctx.saved_tensors
+        if dy is None:   # only the alias was used
+            return dskip, None, None, None, None
+        dn, dw, db = torch.ops.vmambair.conv1x1_bwd(n, weight, dy, ctx.has_bias)
+        dx, _, dlw, dlb = torch.ops.vmambair.ln_nchw_bwd(x, ln_weight, ln_bias, None, dn, mean, rstd, dskip, None)
+        return (dx, dlw.to(ln_weight.dtype), dlb.to(ln_bias.dtype) if ctx.has_lnb else None, dw.to(weight.dtype),
+                db if ctx.has_bias else None)
+
+
+def ln_conv1x1(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: Optional[torch.Tensor], conv: torch.nn.Conv2d):
+    """-> (conv(LayerNorm(x)), x alias for the skip connection); the caller checked ``ln_conv1x1_ok``"""
+    return LNConv1x1Fn.apply(x, ln_weight, ln_bias, conv.weight, conv.bias)

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import (ChannelGateFn, NormChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw,
+from .ops import (ChannelGateFn, NormChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw, ln_conv1x1, ln_conv1x1_ok,
                   split_halves)
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
@@ -65,6 +65,19 @@ class LayerNorm(nn.Module):
         return layer_norm_nchw(x, self.body.weight, self.body.bias, gate, out_dtype, passthrough, gate_grad_into)
 
 
+def _norm_then_conv(x: torch.Tensor, norm: "LayerNorm", conv: nn.Conv2d):
+    """``conv(norm(x))`` and the alias of ``x`` that the block's skip connection adds back: ONE launch when the shapes allow
+    (ops/pointwise.py: LNConv1x1Fn -- the LayerNorm runs on the 1x1 convolution's LDS-resident activation tile), else the
+    LayerNorm launch followed by the convolution"""
+    xa = x
+    if torch.is_autocast_enabled("cuda") and x.is_cuda and x.dtype == torch.float32:
+        xa = None   # an fp32 stream under autocast: the LayerNorm kernel narrows it itself (kept on the two-launch path)
+    if xa is not None and ln_conv1x1_ok(xa, conv.weight):
+        return ln_conv1x1(xa, norm.body.weight, norm.body.bias, conv)
+    n, skip = norm(x, passthrough=True)
+    return conv1x1(n, conv), skip
+
+
 class FeedForward(nn.Module):
     """EFFN: 1x1 (D -> 2h) -> depth-wise 3x3 -> gelu(x1) * x2 -> 1x1 (h -> D), h = int(D * factor)
     (MambaSISR6_arch.py:201-218)."""
@@ -76,9 +89,15 @@ class FeedForward(nn.Module):
         self.dwconv = nn.Conv2d(hidden * 2, hidden * 2, kernel_size=3, stride=1, padding=1, groups=hidden * 2, bias=bias)
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
-    def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, residual: torch.Tensor = None, pre_norm: "LayerNorm" = None) -> torch.Tensor:
+        """``pre_norm``: x is the un-normalised stream and the block's norm2 is applied here, fused into project_in; the skip
+        connection is then x itself"""
+        if pre_norm is not None:
+            t, residual = _norm_then_conv(x, pre_norm, self.project_in)
+        else:
+            t = conv1x1(x, self.project_in)
         # dwconv -> chunk -> gelu(x1) * x2 as one node that never stores the convolution (ops/dwconv.py: DWGateFn)
-        return conv1x1(dwconv3x3_gelu_gate(conv1x1(x, self.project_in), self.dwconv), self.project_out, residual)
+        return conv1x1(dwconv3x3_gelu_gate(t, self.dwconv), self.project_out, residual)
 
 
 def _dt_proj_init(dt_rank: int, d_inner: int, dt_scale=1.0, dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4):
@@ -287,9 +306,13 @@ class SS2D_1(nn.Module):
         return F.layer_norm(y.reshape(b, d), (d,), self.channel_norm.body.weight, self.channel_norm.body.bias,
                             1e-5).view(b, d, 1, 1).to(xc.dtype)
 
-    def forward(self, x: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
-        """``residual``: the block's skip connection, added in the epilogue of the out_conv kernel"""
-        xz = conv1x1(x, self.in_conv)
+    def forward(self, x: torch.Tensor, residual: torch.Tensor = None, pre_norm: "LayerNorm" = None) -> torch.Tensor:
+        """``residual``: the block's skip connection, added in the epilogue of the out_conv kernel.  ``pre_norm``: x is the
+        un-normalised stream and the block's norm1 is applied here, fused into in_conv; the skip connection is then x itself"""
+        if pre_norm is not None:
+            xz, residual = _norm_then_conv(x, pre_norm, self.in_conv)
+        else:
+            xz = conv1x1(x, self.in_conv)
         # x, z = xz.chunk(2, dim=1): the gradients of the halves are written by their producers into ONE buffer (no cat)
         x, z, pair = split_halves(xz)
         x = dwconv3x3(x, self.conv2d, act=True, grad_into=None if pair is None else (pair, 0))  # silu in the conv's epilogue
@@ -333,7 +356,6 @@ class MamberBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # x + f(norm(x)): the sum happens in the epilogue of f's last 1x1 conv, and the skip connection's gradient
         # re-enters through the LayerNorm node (``passthrough``), which adds it to dx inside its backward kernel
-        n1, skip = self.norm1(x, passthrough=True)
-        x = self.attn(n1, residual=skip)
-        n2, skip = self.norm2(x, passthrough=True)
-        return self.ffn(n2, residual=skip)
+        # (round 3: the norms run inside the first 1x1 convolution of attn / ffn -- _norm_then_conv)
+        x = self.attn(x, pre_norm=self.norm1)
+        return self.ffn(x, pre_norm=self.norm2)
