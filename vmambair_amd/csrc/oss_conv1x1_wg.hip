@@ -87,45 +87,71 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
     }
     __syncthreads();
     if constexpr (LN) {
-        // 256 / PT threads per pixel, each with K / TPP channels of the pixel's column in registers: two-pass mean / variance in
-        // fp32 as oss_ln_nchw_fwd_kernel, the partial sums of a pixel combined through LDS in a fixed order
-        constexpr int TPP = 256 / PT, CPT = K / TPP;
-        static_assert(K % TPP == 0, "channels split evenly over a pixel's threads");
-        float *red = reinterpret_cast<float *>(os);          // [TPP][PT], the output staging area is still unused
-        const int px = tid % PT, part = tid / PT;
-        float v[CPT];
+        // a thread owns FOUR adjacent pixels (one 8-byte LDS access per channel) and every NPARTth .. channel: two-pass mean /
+        // variance in fp32 as oss_ln_nchw_fwd_kernel, the partial sums of a pixel combined through LDS in a fixed order
+        constexpr int QPT = PT / 4, NPART = 256 / QPT, CPT = (K + NPART - 1) / NPART;   // 128 px: 32 quads x 8 parts
+        float *red = reinterpret_cast<float *>(os);          // [NPART][PT], the output staging area is still unused
+        const int quad = tid % QPT, part = tid / QPT, px = 4 * quad;
+        float v[CPT][4];
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) v[i] = to_f32(xs[(part * CPT + i) * PITCH + px]);
-        float sum = 0.f;
+        for (int i = 0; i < CPT; ++i) {
+            const int c = part + i * NPART;
+            if (c < K) {
+                const u32x2 q = *reinterpret_cast<const u32x2 *>(xs + c * PITCH + px);
+                unpack2<T>(q.x, v[i][0], v[i][1]); unpack2<T>(q.y, v[i][2], v[i][3]);
+            } else {
+                v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+            }
+        }
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) sum += v[i];
-        red[part * PT + px] = sum;
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum[u] += v[i][u];
+        *reinterpret_cast<f32x4 *>(red + part * PT + px) = f32x4{sum[0], sum[1], sum[2], sum[3]};
         __syncthreads();
-        float tot = 0.f;
+        float mu[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < TPP; ++q) tot += red[q * PT + px];
-        const float mu = tot / (float)K;
+        for (int q = 0; q < NPART; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(red + q * PT + px);
+            mu[0] += t.x; mu[1] += t.y; mu[2] += t.z; mu[3] += t.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mu[u] /= (float)K;
         __syncthreads();
-        float sq = 0.f;
+        float sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) { const float d = v[i] - mu; sq = __builtin_fmaf(d, d, sq); }
-        red[part * PT + px] = sq;
+        for (int i = 0; i < CPT; ++i) {
+            if (part + i * NPART < K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const float d = v[i][u] - mu[u]; sq[u] = __builtin_fmaf(d, d, sq[u]); }
+            }
+        }
+        *reinterpret_cast<f32x4 *>(red + part * PT + px) = f32x4{sq[0], sq[1], sq[2], sq[3]};
         __syncthreads();
-        float qt = 0.f;
+        float rstd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < TPP; ++q) qt += red[q * PT + px];
-        const float rstd = 1.0f / sqrtf(qt / (float)K + ln.eps);
+        for (int q = 0; q < NPART; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(red + q * PT + px);
+            rstd[0] += t.x; rstd[1] += t.y; rstd[2] += t.z; rstd[3] += t.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rstd[u] = 1.0f / sqrtf(rstd[u] / (float)K + ln.eps);
         if (part == 0 && zi == 0) {
-            ln.mean[(size_t)b * P + p0 + px] = mu;
-            ln.rstd[(size_t)b * P + p0 + px] = rstd;
+            *reinterpret_cast<f32x4 *>(ln.mean + (size_t)b * P + p0 + px) = f32x4{mu[0], mu[1], mu[2], mu[3]};
+            *reinterpret_cast<f32x4 *>(ln.rstd + (size_t)b * P + p0 + px) = f32x4{rstd[0], rstd[1], rstd[2], rstd[3]};
         }
         const bool with_bias = ln.b != nullptr;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = part * CPT + i;
-            const float wc = ln.w[c], bc = with_bias ? ln.b[c] : 0.f;
-            const float o = with_bias ? (v[i] - mu) * rstd * wc + bc : v[i] * rstd * wc;
-            xs[c * PITCH + px] = from_f32<T>(o);
+            const int c = part + i * NPART;
+            if (c < K) {
+                const float wc = ln.w[c], bc = with_bias ? ln.b[c] : 0.f;
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = with_bias ? (v[i][u] - mu[u]) * rstd[u] * wc + bc : v[i][u] * rstd[u] * wc;
+                *reinterpret_cast<u32x2 *>(xs + c * PITCH + px) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+            }
         }
         __syncthreads();   // (also: red[] has been read by everyone before the output staging reuses it)
         T *nb = ln.n + (size_t)b * K * P + p0;
