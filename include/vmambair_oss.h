@@ -257,6 +257,17 @@ int oss_ln_conv1x1_ok(oss_dtype io, int cout, int cin, int pixels);
 int oss_ln_conv1x1_fwd(oss_dtype io, const void *x, const float *ln_weight, const float *ln_bias, float eps, void *n, float *mean,
                        float *rstd, const float *weight, const float *bias, void *y, int batch, int cout, int cin, int pixels,
                        int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
+/* The backward of that pair's activation path as ONE launch: dn = W^T dy (oss_conv1x1_dgrad) never leaves the CU, the LayerNorm
+ * backward (oss_ln_nchw_bwd: x, mean, rstd, + skip_grad, d weight / d bias through `partials` =
+ * oss_conv1x1_dgrad_ln_bwd_partial_floats(batch, cin, pixels) floats and the usual (deferred) finishing sum) runs on it in LDS.
+ * Shapes: cin <= 128, cout % 16 == 0, 2 cin <= cout <= 192, pixels % 128 == 0 (oss_conv1x1_dgrad_ln_bwd_ok); x, skip_grad, dx contiguous
+ * (batch, cin, pixels); dy (batch, cout, pixels) with element strides.  The weight gradient stays oss_conv1x1_wgrad on n. */
+int oss_conv1x1_dgrad_ln_bwd_ok(oss_dtype io, int cout, int cin, int pixels, int batch);
+size_t oss_conv1x1_dgrad_ln_bwd_partial_floats(int batch, int cin, int pixels);
+int oss_conv1x1_dgrad_ln_bwd(oss_dtype io, const void *dy, const float *weight, const void *x, const float *ln_weight, int ln_has_bias,
+                             const float *mean, const float *rstd, const void *skip_grad, void *dx, float *dln_weight, float *dln_bias,
+                             float *partials, int batch, int cout, int cin, int pixels, int64_t dy_batch_stride,
+                             int64_t dy_channel_stride, oss_stream_t stream);
 /* A-B switches of the dispatch inside oss_conv1x1_fwd / _dgrad: on = 0 never takes the workgroup-level kernel (env
  * VMAMBAIR_CONV1X1_WG=0); pixels = 64 | 128 forces its tile width, 0 = by grid size */
 void oss_conv1x1_set_wg(int on, int pixels);

@@ -75,7 +75,8 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd",
            "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
-           "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
+           "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_conv1x1_dgrad_ln_bwd_ok",
+           "oss_conv1x1_dgrad_ln_bwd_partial_floats", "oss_conv1x1_dgrad_ln_bwd", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
            "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
@@ -185,6 +186,13 @@ def load():
     lib.oss_ln_conv1x1_fwd.restype = C.c_int
     lib.oss_ln_conv1x1_fwd.argtypes = ([C.c_int] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_int64] * 2 +
                                        [C.c_void_p])
+    lib.oss_conv1x1_dgrad_ln_bwd_ok.restype = C.c_int
+    lib.oss_conv1x1_dgrad_ln_bwd_ok.argtypes = [C.c_int] * 5
+    lib.oss_conv1x1_dgrad_ln_bwd_partial_floats.restype = C.c_size_t
+    lib.oss_conv1x1_dgrad_ln_bwd_partial_floats.argtypes = [C.c_int] * 3
+    lib.oss_conv1x1_dgrad_ln_bwd.restype = C.c_int
+    lib.oss_conv1x1_dgrad_ln_bwd.argtypes = ([C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_int64] * 2 +
+                                             [C.c_void_p])
     lib.oss_conv1x1_set_wg.restype = None
     lib.oss_conv1x1_set_wg.argtypes = [C.c_int, C.c_int]
     lib.oss_conv1x1_wgrad_set_span.restype = None

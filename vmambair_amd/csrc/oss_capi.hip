@@ -433,6 +433,22 @@ int oss_ln_conv1x1_fwd(oss_dtype io, const void *x, const float *ln_weight, cons
                          reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_conv1x1_dgrad_ln_bwd_ok(oss_dtype io, int cout, int cin, int pixels, int batch) {
+    return conv1x1_dgrad_lnbwd_ok(io, cin, cout, pixels, batch);
+}
+size_t oss_conv1x1_dgrad_ln_bwd_partial_floats(int batch, int cin, int pixels) {
+    if (batch <= 0 || cin <= 0 || pixels <= 0) return 0;
+    return conv1x1_dgrad_lnbwd_partial_floats(batch, cin, pixels);
+}
+int oss_conv1x1_dgrad_ln_bwd(oss_dtype io, const void *dy, const float *weight, const void *x, const float *ln_weight, int ln_has_bias,
+                             const float *mean, const float *rstd, const void *skip_grad, void *dx, float *dln_weight, float *dln_bias,
+                             float *partials, int batch, int cout, int cin, int pixels, int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    if (!dy || !weight || !x || !ln_weight || !mean || !rstd || !dx || !dln_weight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || batch > 65535) return OSS_ERR_SHAPE;
+    return conv1x1_dgrad_lnbwd(io, dy, weight, x, ln_weight, ln_has_bias, mean, rstd, skip_grad, dx, dln_weight, dln_bias, partials, batch,
+                               cin, cout, pixels, gsb, gsc, reinterpret_cast<hipStream_t>(stream));
+}
+
 void oss_conv1x1_set_wg(int on, int pixels) { conv1x1_set_wg(on); conv1x1_wg_set_pixels(pixels); }
 void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
 void oss_conv1x1_wgrad_set_span(int mult) { conv1x1_wgrad_set_span(mult); }

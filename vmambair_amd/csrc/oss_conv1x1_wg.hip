@@ -313,6 +313,253 @@ int conv1x1_wg(oss_dtype io, const void *x, const float *w, const float *bias, v
                                         reinterpret_cast<const f16_t *>(res), s);
 }
 
+// ---- input gradient of a 1x1 convolution + the backward of the LayerNorm in front of it, one launch ---------------------------
+// (in_conv after norm1: dn = W^T dy never leaves the CU.)  M = dim <= 128 output rows, so after the MFMA loop the workgroup holds
+// dn for ALL channels of its pixels in LDS (the output staging tiles, rounded to T as the separate kernels hand it over); the
+// LayerNorm backward of oss_layernorm.hip is a per-pixel function of (dn, x, mean, rstd) over the channels plus the skip
+// connection's gradient:
+//   s1 = sum_c g w,  s2 = sum_c g w xh;   dx = rstd (g w - s1 / C - xh s2 / C) + skip     (WithBias; BiasFree as in the LN kernel)
+// and per-channel partial sums of g xh (d weight) and g (d bias) over the workgroup's pixels, finished in a fixed order later.
+template <typename T>
+struct WgLnBwdArgs {
+    const T *x;             // (B, M, P) LayerNorm input
+    const float *w;         // LayerNorm weight
+    const float *mean, *rstd;
+    const T *skip;          // (B, M, P) gradient arriving over the skip connection, or NULL
+    T *dx;                  // (B, M, P)
+    float *part;            // [workgroup][2 M]: partial d weight, d bias
+    int with_bias;
+};
+
+template <typename T, int KS, int PT>
+__global__ void __launch_bounds__(256)
+oss_conv1x1_dgrad_lnbwd_kernel(const T *__restrict__ dy, const float *__restrict__ w, int M, int P, int64_t xsb, int64_t xsk,
+                               WgLnBwdArgs<T> a) {
+    constexpr int K = 16 * KS, PITCH = PT + 8, NCT = PT / 32, CPR = PT / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    T *xs = reinterpret_cast<T *>(wg_smem);                    // [K][PITCH] the dy tile; later x tile | skip tile (2 M <= K rows)
+    T *os = xs + K * PITCH;                                    // [4 waves][32][PITCH]: dn, all row tiles
+    float *red = reinterpret_cast<float *>(os + 4 * 32 * PITCH);   // [2][8][PT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, p0 = blockIdx.x * PT;
+    const T *xb = dy + b * xsb + p0;
+    const int col = lane & 31, kg = lane >> 5;
+    const int mt_total = (M + 31) >> 5;      // <= 4: one row tile per wave
+    // this wave's weight fragments (input gradient: W(m, k) = w[k * M + m])
+    f32x4 wlo[KS], whi[KS];
+    {
+        const int mrow = min(wave * 32 + col, M - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = ks * 16 + kg * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wlo[ks][e] = w[(size_t)(k0 + e) * M + mrow];
+                whi[ks][e] = w[(size_t)(k0 + 4 + e) * M + mrow];
+            }
+        }
+    }
+    for (int idx = tid; idx < K * CPR; idx += 256) {
+        const int c = idx / CPR, pc = idx - c * CPR;
+        *reinterpret_cast<u32x4 *>(xs + c * PITCH + 8 * pc) = *reinterpret_cast<const u32x4 *>(xb + c * xsk + 8 * pc);
+    }
+    // the LayerNorm input and the skip gradient of the tile: requested now, parked in LDS after the MFMAs
+    constexpr int NLD = (128 * CPR + 255) / 256;   // 16-byte chunks per thread for <= 128 rows
+    u32x4 xq[NLD], sq[NLD];
+    const T *xin = a.x + (size_t)b * M * P + p0, *sin = a.skip ? a.skip + (size_t)b * M * P + p0 : xin;
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int idx = min(q * 256 + tid, M * CPR - 1), c = idx / CPR, pc = idx - c * CPR;
+        xq[q] = *reinterpret_cast<const u32x4 *>(xin + (size_t)c * P + 8 * pc);
+        sq[q] = *reinterpret_cast<const u32x4 *>(sin + (size_t)c * P + 8 * pc);
+    }
+    __syncthreads();
+    const int i16 = lane & 15, g = lane >> 4;
+    const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * PITCH + 16 * (g & 1) + 4 * (i16 & 3);
+    if (wave < mt_total) {
+        const int m0 = wave * 32;
+        f32x16 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const s16x8 af = m0 + col < M ? cvt8<T>(wlo[ks], whi[ks]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const T *bp = xs + ks * 16 * PITCH + ct * 32 + tr_off;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp + 4 * PITCH));
+                const s16x8 bf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                acc[ct] = Mfma<T>::run(af, bf, acc[ct]);
+            }
+        }
+        T *ow = os + wave * 32 * PITCH;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) ow[row * PITCH + ct * 32 + col] = from_f32<T>(acc[ct][r]);
+        }
+    }
+    __syncthreads();   // dn complete in os; the dy tile in xs is no longer needed
+    T *xt = xs, *st = xs + M * PITCH;   // (K >= 2 M rows: checked by the host)
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int idx = q * 256 + tid;
+        if (idx < M * CPR) {
+            const int c = idx / CPR, pc = idx - c * CPR;
+            *reinterpret_cast<u32x4 *>(xt + c * PITCH + 8 * pc) = xq[q];
+            *reinterpret_cast<u32x4 *>(st + c * PITCH + 8 * pc) = sq[q];
+        }
+    }
+    __syncthreads();
+    // the LayerNorm backward: a thread owns four adjacent pixels and the channels part, part + NPART, ...
+    constexpr int QPT = PT / 4, NPART = 256 / QPT, CMAX = (128 + NPART - 1) / NPART;
+    const int quad = tid % QPT, part = tid / QPT, px = 4 * quad;
+    const bool with_bias = a.with_bias != 0, has_skip = a.skip != nullptr;
+    float mu[4], rs[4];
+    {
+        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(a.mean + (size_t)b * P + p0 + px);
+        const f32x4 r4 = *reinterpret_cast<const f32x4 *>(a.rstd + (size_t)b * P + p0 + px);
+        mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+        rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+    }
+    float gv[CMAX][4], xv[CMAX][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float *pw = a.part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * M;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) {
+        const int c = part + i * NPART;
+        float aw = 0.f, ab = 0.f;
+        if (c < M) {
+            const u32x2 gq = *reinterpret_cast<const u32x2 *>(os + ((c >> 5) * 32 + (c & 31)) * PITCH + px);
+            const u32x2 xq2 = *reinterpret_cast<const u32x2 *>(xt + c * PITCH + px);
+            unpack2<T>(gq.x, gv[i][0], gv[i][1]); unpack2<T>(gq.y, gv[i][2], gv[i][3]);
+            unpack2<T>(xq2.x, xv[i][0], xv[i][1]); unpack2<T>(xq2.y, xv[i][2], xv[i][3]);
+            const float wc = a.w[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xh = with_bias ? (xv[i][u] - mu[u]) * rs[u] : xv[i][u] * rs[u];
+                const float gg = gv[i][u];
+                aw = __builtin_fmaf(gg, xh, aw);
+                ab += gg;
+                const float gw = gg * wc;
+                s1[u] += gw;
+                s2[u] = __builtin_fmaf(gw, with_bias ? xh : xv[i][u], s2[u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { gv[i][u] = 0.f; xv[i][u] = 0.f; }
+        }
+        // d weight / d bias partials of channel c over the workgroup's pixels: the 32 or 16 quads of this part are adjacent lanes
+        const float tw = segment_sum_to_last<QPT>(aw), tb = segment_sum_to_last<QPT>(ab);
+        if ((lane & (QPT - 1)) == QPT - 1 && c < M) { pw[c] = tw; pw[M + c] = tb; }
+    }
+    *reinterpret_cast<f32x4 *>(red + part * PT + px) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+    *reinterpret_cast<f32x4 *>(red + (NPART + part) * PT + px) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+    __syncthreads();
+    float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NPART; ++q) {
+        const f32x4 t1 = *reinterpret_cast<const f32x4 *>(red + q * PT + px), t2 = *reinterpret_cast<const f32x4 *>(red + (NPART + q) * PT + px);
+        m1[0] += t1.x; m1[1] += t1.y; m1[2] += t1.z; m1[3] += t1.w;
+        m2[0] += t2.x; m2[1] += t2.y; m2[2] += t2.z; m2[3] += t2.w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { m1[u] /= (float)M; m2[u] /= (float)M; }
+    T *dxb = a.dx + (size_t)b * M * P + p0;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) {
+        const int c = part + i * NPART;
+        if (c < M) {
+            const float wc = a.w[c];
+            float sk[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_skip) {
+                const u32x2 s2q = *reinterpret_cast<const u32x2 *>(st + c * PITCH + px);
+                unpack2<T>(s2q.x, sk[0], sk[1]); unpack2<T>(s2q.y, sk[2], sk[3]);
+            }
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xh = (xv[i][u] - mu[u]) * rs[u];
+                const float gw = gv[i][u] * wc;
+                d[u] = (with_bias ? rs[u] * (gw - m1[u] - xh * m2[u]) : rs[u] * gw - xh * rs[u] * rs[u] * m2[u]) + sk[u];
+            }
+            *reinterpret_cast<u32x2 *>(dxb + (size_t)c * P + px) = u32x2{pack2<T>(d[0], d[1]), pack2<T>(d[2], d[3])};
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+oss_wg_lnbwd_finish(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db, int nblk, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    float sum = 0.f;
+    for (int k = 0; k < nblk; ++k) sum += part[(size_t)k * 2 * C + i];
+    if (i < C) dw[i] = sum;
+    else if (db) db[i - C] = sum;
+}
+
+size_t conv1x1_dgrad_lnbwd_partial_floats(int B, int M, int P) { return (size_t)B * (P / 64) * 2 * M; }
+
+int conv1x1_dgrad_lnbwd_ok(oss_dtype io, int M, int K, int P, int B) {
+    if (io != OSS_BF16 && io != OSS_F16) return 0;
+    if (K % 16 != 0 || K < 2 * M || K > 192 || M < 1 || M > 128 || P % 128 != 0) return 0;
+    return 1;
+}
+
+template <typename T>
+static int lnbwd_launch(const T *dy, const float *w, int B, int M, int K, int P, int64_t xsb, int64_t xsk, WgLnBwdArgs<T> a, float *dlw,
+                        float *dlb, hipStream_t s) {
+    const int pt = (long)B * (P / 128) >= 256 ? 128 : 64;
+    const size_t smem = sizeof(uint16_t) * ((size_t)K + 4 * 32) * (pt + 8) + sizeof(float) * 2 * 8 * 128;
+    dim3 grid(P / pt, B);
+#define OSS_LNB(KS_, PT_)                                                                                   \
+    do {                                                                                                    \
+        static LdsGate gate;                                                                                \
+        auto kern = oss_conv1x1_dgrad_lnbwd_kernel<T, KS_, PT_>;                                            \
+        if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;                \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, dy, w, M, P, xsb, xsk, a);                       \
+    } while (0)
+#define OSS_LNB2(KS_) do { if (pt == 128) OSS_LNB(KS_, 128); else OSS_LNB(KS_, 64); } while (0)
+    switch (K / 16) {
+        case 2: OSS_LNB2(2); break;
+        case 3: OSS_LNB2(3); break;
+        case 4: OSS_LNB2(4); break;
+        case 6: OSS_LNB2(6); break;
+        case 8: OSS_LNB2(8); break;
+        case 12: OSS_LNB2(12); break;
+        default: return OSS_ERR_SHAPE;
+    }
+#undef OSS_LNB2
+#undef OSS_LNB
+    const int nblk = (int)(grid.x * grid.y);
+    if (defer_finish())
+        defer_sum(a.part, nblk, (size_t)2 * M, (size_t)(dlb ? 2 : 1) * M, dlw, (size_t)M, dlb);
+    else
+        hipLaunchKernelGGL(oss_wg_lnbwd_finish, dim3((2 * M + 255) / 256), dim3(256), 0, s, a.part, dlw, dlb, nblk, M);
+    return (int)hipGetLastError();
+}
+
+// dx = LayerNorm_backward(W^T dy; x, mean, rstd) + skip, d ln weight / bias; dy (B, K, P), w (K, M) row-major
+int conv1x1_dgrad_lnbwd(oss_dtype io, const void *dy, const float *w, const void *x, const float *ln_w, int with_bias, const float *mean,
+                        const float *rstd, const void *skip, void *dx, float *dlw, float *dlb, float *part, int B, int M, int K, int P,
+                        int64_t xsb, int64_t xsk, hipStream_t s) {
+    if (!conv1x1_dgrad_lnbwd_ok(io, M, K, P, B) || xsb % 8 != 0 || xsk % 8 != 0) return OSS_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(dx) |
+         reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15u)
+        return OSS_ERR_SHAPE;
+    if (io == OSS_BF16) {
+        WgLnBwdArgs<bf16_t> a{reinterpret_cast<const bf16_t *>(x), ln_w, mean, rstd, reinterpret_cast<const bf16_t *>(skip),
+                              reinterpret_cast<bf16_t *>(dx), part, with_bias};
+        return lnbwd_launch<bf16_t>(reinterpret_cast<const bf16_t *>(dy), w, B, M, K, P, xsb, xsk, a, dlw, dlb, s);
+    }
+    WgLnBwdArgs<f16_t> a{reinterpret_cast<const f16_t *>(x), ln_w, mean, rstd, reinterpret_cast<const f16_t *>(skip),
+                         reinterpret_cast<f16_t *>(dx), part, with_bias};
+    return lnbwd_launch<f16_t>(reinterpret_cast<const f16_t *>(dy), w, B, M, K, P, xsb, xsk, a, dlw, dlb, s);
+}
+
 // n = LayerNorm(x) (ln_w, ln_b or NULL), mean, rstd written out; y = W n + bias.  Same shape rules as conv1x1_wg (forward only).
 int ln_conv1x1_wg(oss_dtype io, const void *x, const float *ln_w, const float *ln_b, float eps, void *n, float *mean, float *rstd,
                   const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk, hipStream_t s) {

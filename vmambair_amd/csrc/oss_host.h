@@ -78,6 +78,11 @@ int merge4(oss_dtype io, const void *out, float *y, int B, int D, int H, int W, 
 // workgroup-level 1x1 convolution (oss_conv1x1_wg.hip)
 int ln_conv1x1_wg(oss_dtype io, const void *x, const float *ln_w, const float *ln_b, float eps, void *n, float *mean, float *rstd,
                   const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk, hipStream_t s);
+size_t conv1x1_dgrad_lnbwd_partial_floats(int B, int M, int P);
+int conv1x1_dgrad_lnbwd_ok(oss_dtype io, int M, int K, int P, int B);
+int conv1x1_dgrad_lnbwd(oss_dtype io, const void *dy, const float *w, const void *x, const float *ln_w, int with_bias, const float *mean,
+                        const float *rstd, const void *skip, void *dx, float *dlw, float *dlb, float *part, int B, int M, int K, int P,
+                        int64_t xsb, int64_t xsk, hipStream_t s);
 void conv1x1_set_wg(int on);
 void conv1x1_wg_set_pixels(int pt);
 int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,

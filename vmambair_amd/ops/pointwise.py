@@ -163,10 +163,68 @@ class LNConv1x1Fn(torch.autograd.Function):
         x, ln_weight, ln_bias, n, mean, rstd, weight = ctx.saved_tensors
         if dy is None:   # only the alias was used
             return dskip, None, None, None, None
-        dn, dw, db = torch.ops.vmambair.conv1x1_bwd(n, weight, dy, ctx.has_bias)
-        dx, _, dlw, dlb = torch.ops.vmambair.ln_nchw_bwd(x, ln_weight, ln_bias, None, dn, mean, rstd, dskip, None)
+        dx, dlw, dlb, dw, db = torch.ops.vmambair.ln_conv1x1_bwd(x, ln_weight, ln_bias, n, mean, rstd, weight, dy, dskip, ctx.has_bias)
         return (dx, dlw.to(ln_weight.dtype), dlb.to(ln_bias.dtype) if ctx.has_lnb else None, dw.to(weight.dtype),
                 db if ctx.has_bias else None)
+
+
+#: ``VMAMBAIR_LN_BWD_FUSED=0``: the LayerNorm backward stays a launch of its own behind the convolution's input gradient
+LN_BWD_FUSED = os.environ.get("VMAMBAIR_LN_BWD_FUSED", "1") == "1"
+
+
+def ln_conv1x1_bwd(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: Optional[torch.Tensor], n: torch.Tensor, mean: torch.Tensor,
+                   rstd: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, dskip: Optional[torch.Tensor],
+                   has_bias: bool) -> List[torch.Tensor]:
+    """backward of ``conv1x1(LayerNorm(x))`` -> [dx (+ dskip), d ln weight, d ln bias or empty, dweight (Cout, Cin, 1, 1) fp32,
+    dbias or empty].  Weight gradient on the saved normalised activations (``oss_conv1x1_wgrad``, recorded for the grouped launch as
+    usual); then ``W^T dy`` and the LayerNorm backward in ONE launch when the shape allows (``oss_conv1x1_dgrad_ln_bwd``: in_conv after
+    norm1), else as the two kernels."""
+    B, Cin, H, W = x.shape
+    Cout, P = weight.shape[0], H * W
+    lib = _capi.load()
+    dyp = _planes(dy)
+    if dyp.dtype != x.dtype:
+        dyp = dyp.to(x.dtype)
+    fused = LN_BWD_FUSED and x.is_contiguous() and (dskip is None or dskip.dtype == x.dtype) and dyp.data_ptr() % 16 == 0 and \
+        dyp.stride(0) % 8 == 0 and dyp.stride(1) % 8 == 0 and bool(lib.oss_conv1x1_dgrad_ln_bwd_ok(_DT[x.dtype], Cout, Cin, P, B))
+    if not fused:
+        dn, dw, db = conv1x1_bwd(n, weight, dyp, has_bias)
+        from .layernorm import ln_nchw_bwd
+        dx, _, dlw, dlb = ln_nchw_bwd(x, ln_weight, ln_bias, None, dn, mean, rstd, dskip, None)
+        return [dx, dlw, dlb, dw, db]
+    w = weight.detach().float().reshape(Cout, Cin).contiguous()
+    lw = ln_weight.detach().float().contiguous()
+    n = _planes(n)
+    if dskip is not None:
+        dskip = dskip.contiguous()
+    dx = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
+    f = dict(dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        with _fork_for_wgrad(n, dyp):
+            dw = torch.empty((Cout, Cin), **f)
+            db = torch.empty((Cout,), **f) if has_bias else None
+            part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), **f)
+            _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dyp.data_ptr(), n.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
+                                              Cout, Cin, P, dyp.stride(0), dyp.stride(1), n.stride(0), n.stride(1),
+                                              torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
+            _keep(part, dw, db)
+            _keep_operands(dyp, n)
+        dlw = torch.empty((Cin,), **f)
+        dlb = torch.empty((Cin,), **f) if ln_bias is not None else None
+        lpart = torch.empty(int(lib.oss_conv1x1_dgrad_ln_bwd_partial_floats(B, Cin, P)), **f)
+        _capi.check(lib.oss_conv1x1_dgrad_ln_bwd(_DT[x.dtype], dyp.data_ptr(), w.data_ptr(), x.data_ptr(), lw.data_ptr(),
+                                                 1 if ln_bias is not None else 0, mean.data_ptr(), rstd.data_ptr(), _ptr(dskip),
+                                                 dx.data_ptr(), dlw.data_ptr(), _ptr(dlb), lpart.data_ptr(), B, Cout, Cin, P,
+                                                 dyp.stride(0), dyp.stride(1), torch.cuda.current_stream().cuda_stream),
+                    "oss_conv1x1_dgrad_ln_bwd")
+        _keep(lpart, dlw, dlb)
+    e = x.new_empty(0, dtype=torch.float32)
+    return [dx, dlw, dlb if dlb is not None else e, dw.view(Cout, Cin, 1, 1), db if db is not None else e]
+
+
+_LIB.define("ln_conv1x1_bwd(Tensor x, Tensor ln_weight, Tensor? ln_bias, Tensor n, Tensor mean, Tensor rstd, Tensor weight, Tensor dy, "
+            "Tensor? dskip, bool has_bias) -> Tensor[]")
+_LIB.impl("ln_conv1x1_bwd", ln_conv1x1_bwd, "CUDA")
 
 
 def ln_conv1x1(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: Optional[torch.Tensor], conv: torch.nn.Conv2d):
