@@ -348,7 +348,8 @@ def test_conv1x1_workgroup_level_kernel_is_bit_identical_to_the_wave_level_ones(
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ln_bias", [(2, 96, 192, 32, 32, True), (1, 48, 254, 16, 16, True), (2, 96, 510, 16, 8, False),
-                                                     (1, 192, 384, 16, 8, True), (2, 48, 96, 64, 64, True), (1, 16, 33, 8, 16, False)])
+                                                     (1, 192, 384, 16, 8, True), (2, 48, 96, 64, 64, True), (1, 16, 33, 8, 16, False),
+                                                     (4, 96, 510, 64, 64, True), (8, 48, 254, 32, 64, False)])
 def test_layernorm_fused_into_the_1x1_convolution(dt, B, Cin, Cout, H, W, ln_bias):
     """LNConv1x1Fn (norm1 -> in_conv, norm2 -> project_in in one forward launch: the LayerNorm runs on the convolution's LDS-resident
     activation tile) against plain PyTorch fp32 and against the two separate nodes on the same tensors, incl. the skip connection's
