@@ -125,3 +125,29 @@ def test_compiled_torch_boundary_is_built_and_registers_its_ops():
         assert _host.mode() == "ctypes" and _host.ops() is None
     finally:
         _host.use(None)
+
+
+def test_shape_rules_of_the_fused_kernels_are_pure_host_queries():
+    """which shapes the round-3 fused forms take (no GPU needed: the rules live in the library, the Python layer only asks)"""
+    lib = _capi.load()
+    BF16, F16, F32 = 2, 1, 0
+    # depth-wise conv + silu (1 plane per workgroup) / + gelu gate (2 planes): 16-bit, W % 8 == 0 with W / 8 dividing 64, planes in LDS
+    assert lib.oss_dwconv3x3_fused_ok(BF16, 64, 64, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F16, 128, 128, 2) == 1
+    assert lib.oss_dwconv3x3_fused_ok(F32, 64, 64, 1) == 0          # fp32 I/O stays on the separate kernels
+    assert lib.oss_dwconv3x3_fused_ok(BF16, 160, 160, 1) == 0       # RealSR's 160-wide tiles: 20 lane groups do not tile a wave
+    assert lib.oss_dwconv3x3_fused_ok(BF16, 16, 24, 2) == 0
+    assert lib.oss_dwconv3x3_fused_ok(BF16, 256, 256, 1) == 1 and lib.oss_dwconv3x3_fused_ok(BF16, 256, 256, 2) == 0   # 129 / 258 KiB
+    assert lib.oss_dwconv3x3_fused_ok(BF16, 64, 64, 3) == 0
+    # LayerNorm inside the 1x1 convolution: cin % 16 == 0, cin <= 192, pixels % 128 == 0
+    assert lib.oss_ln_conv1x1_ok(BF16, 192, 96, 4096) == 1 and lib.oss_ln_conv1x1_ok(F16, 510, 96, 25600) == 1
+    assert lib.oss_ln_conv1x1_ok(BF16, 768, 384, 1024) == 0         # level 4 of the UNet: K = 384
+    assert lib.oss_ln_conv1x1_ok(BF16, 192, 96, 4000) == 0 and lib.oss_ln_conv1x1_ok(F32, 192, 96, 4096) == 0
+    assert lib.oss_ln_conv1x1_ok(BF16, 254, 127, 4096) == 0
+    # input gradient + LayerNorm backward: cin <= 128, 2 cin <= cout <= 192
+    assert lib.oss_conv1x1_dgrad_ln_bwd_ok(BF16, 192, 96, 4096, 8) == 1 and lib.oss_conv1x1_dgrad_ln_bwd_ok(F16, 96, 48, 1024, 1) == 1
+    assert lib.oss_conv1x1_dgrad_ln_bwd_ok(BF16, 510, 96, 4096, 8) == 0    # project_in: the wave-level kernel + its own LayerNorm launch
+    assert lib.oss_conv1x1_dgrad_ln_bwd_ok(BF16, 96, 96, 4096, 8) == 0     # fewer than 2 cin rows to park x and the skip gradient in
+    assert lib.oss_conv1x1_dgrad_ln_bwd_ok(BF16, 384, 192, 1024, 8) == 0
+    n = lib.oss_conv1x1_dgrad_ln_bwd_partial_floats(8, 96, 4096)
+    assert n == 8 * (4096 // 64) * 2 * 96
+    assert lib.oss_conv1x1_dgrad_ln_bwd_partial_floats(0, 96, 4096) == 0
