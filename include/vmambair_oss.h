@@ -332,6 +332,11 @@ typedef struct {
     float *yc;                      /* (B, L)          saved: LayerNorm input                                */
     float *stat;                    /* (B, 2)          saved: LayerNorm mean, rstd                           */
     float *c;                       /* (B, L)          OUT: the gate vector                                  */
+    /* oss_chan_fwd only.  pool_part != NULL: `pooled` is an OUTPUT -- pooled[b, l] = pool_scale * sum_k pool_part[b, k, l] over the
+     * n_part per-workgroup output sums oss_ln_nchw_fwd_pool left (summed in k order) -- instead of an input.                 */
+    const float *pool_part;         /* (B, n_part, L) or NULL                                                */
+    int n_part;
+    float pool_scale;               /* 1 / (H W)                                                             */
 } oss_chan_params;
 int oss_chan_fwd(const oss_chan_params *p, oss_stream_t stream);
 /* gc: gradient of c (B, L).  OUT dpooled (B, L); grads: oss_chan_grad_floats() floats = the parameter gradients
@@ -437,6 +442,15 @@ int oss_ln_nchw_fwd(oss_dtype x_type, oss_dtype y_type, const void *x, const flo
                     const void *gate, void *y, float *mean, float *rstd, int batch, int channels, int pixels,
                     int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
                     int64_t gate_channel_stride, float eps, oss_stream_t stream);
+/* oss_ln_nchw_fwd that also leaves, per workgroup of 128 pixels and channel, the sum of its OUTPUT values (as stored) in pool_part
+ * (batch, oss_ln_nchw_fwd_pool_tiles(...), channels): the pooled descriptor of SS2D_1's channel branch without a pass over y
+ * (oss_chan_params.pool_part).  _pool_tiles returns 0 for shapes that do not take the 128-pixel form (odd pixels / strides). */
+int oss_ln_nchw_fwd_pool_tiles(int channels, int pixels, int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
+                               int64_t gate_channel_stride);
+int oss_ln_nchw_fwd_pool(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
+                         const void *gate, void *y, float *mean, float *rstd, float *pool_part, int batch, int channels, int pixels,
+                         int64_t x_batch_stride, int64_t x_channel_stride, int64_t gate_batch_stride,
+                         int64_t gate_channel_stride, float eps, oss_stream_t stream);
 int oss_ln_nchw_bwd(oss_dtype x_type, oss_dtype y_type, const void *x, const float *weight, const float *bias,
                     const void *gate, const void *dy, const float *mean, const float *rstd, void *dx, void *dgate,
                     float *dweight, float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels,

@@ -106,10 +106,10 @@ def install():
 
     codes = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}
 
-    def ln_fwd(x, weight, bias, gate, out_code):
+    def ln_fwd(x, weight, bias, gate, out_code, want_pool=False):
         y, mu, rstd = _ln_ref(x, weight, bias, gate)
         B, C, H, W = x.shape
-        return [y.to(codes[out_code]), mu.reshape(B, H * W), rstd.reshape(B, H * W)]
+        return [y.to(codes[out_code]), mu.reshape(B, H * W), rstd.reshape(B, H * W)] + ([torch.empty(0)] if want_pool else [])
 
     def ln_bwd(x, weight, bias, gate, dy, mean, rstd, skip_grad=None, dgate_into=None, dy_mul=None, dy_add=None, add_scale=1.0):
         if dy_add is not None:   # the channel gate's backward folded into the load (ops/layernorm.py)
@@ -202,7 +202,7 @@ def install():
         c = F.layer_norm(y, (d,), cn_w, cn_b, 1e-5).view(b, d, 1, 1)
         return (y2 * c + y2) if mul_mode else (y2 + c), c.view(b, d)
 
-    def chan_fwd(y2, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b, cn_w, cn_b, mul_mode):
+    def chan_fwd(y2, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b, cn_w, cn_b, mul_mode, pool_part=None):
         f = lambda t: None if t is None else t.float()
         with torch.no_grad():
             out, c = _chan_ref(y2.float(), f(cin_w), f(cin_b), Wxc.float(), Wdtc.float(), dt_bias.float(), A_logs.float(),

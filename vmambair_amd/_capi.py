@@ -58,7 +58,8 @@ class ScanBwdParams(C.Structure):
 class ChanParams(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("dc", C.c_int), ("Rc", C.c_int), ("Cc", C.c_int), ("reserved_", C.c_int)] + \
         [(n, C.c_void_p) for n in ("pooled", "cin_w", "cin_b", "Wxc", "Wdtc", "dt_bias", "A_logs", "Dsc", "cout_w", "cout_b",
-                                    "cn_w", "cn_b", "zt", "dts", "hs", "y", "yc", "stat", "c")]
+                                    "cn_w", "cn_b", "zt", "dts", "hs", "y", "yc", "stat", "c", "pool_part")] + \
+        [("n_part", C.c_int), ("pool_scale", C.c_float)]
 
 
 class AdamChunk(C.Structure):
@@ -74,7 +75,7 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments",
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd",
-           "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
+           "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_fwd_pool", "oss_ln_nchw_fwd_pool_tiles", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_conv1x1_dgrad_ln_bwd_ok",
            "oss_conv1x1_dgrad_ln_bwd_partial_floats", "oss_conv1x1_dgrad_ln_bwd", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
@@ -150,6 +151,10 @@ def load():
         fn.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_int64] * 6 + [C.c_void_p]
     lib.oss_ln_nchw_fwd.restype = C.c_int
     lib.oss_ln_nchw_fwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
+    lib.oss_ln_nchw_fwd_pool_tiles.restype = C.c_int
+    lib.oss_ln_nchw_fwd_pool_tiles.argtypes = [C.c_int, C.c_int] + [C.c_int64] * 4
+    lib.oss_ln_nchw_fwd_pool.restype = C.c_int
+    lib.oss_ln_nchw_fwd_pool.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
     lib.oss_ln_nchw_bwd_partial_floats.restype = C.c_size_t
     lib.oss_ln_nchw_bwd_partial_floats.argtypes = [C.c_int] * 3
     lib.oss_ln_nchw_bwd.restype = C.c_int

@@ -625,6 +625,20 @@ int oss_ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weig
                        reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_ln_nchw_fwd_pool_tiles(int channels, int pixels, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc) {
+    if (channels <= 0 || pixels <= 0) return 0;
+    return ln_nchw_fwd_pool_tiles(channels, pixels, xsb, xsc, gsb, gsc);
+}
+
+int oss_ln_nchw_fwd_pool(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate, void *y,
+                         float *mean, float *rstd, float *pool_part, int batch, int channels, int pixels, int64_t xsb, int64_t xsc,
+                         int64_t gsb, int64_t gsc, float eps, oss_stream_t stream) {
+    if (!x || !weight || !y || !mean || !rstd || !pool_part) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
+    return ln_nchw_fwd(xt, yt, x, weight, bias, gate, y, mean, rstd, batch, channels, pixels, xsb, xsc, gsb, gsc, eps,
+                       reinterpret_cast<hipStream_t>(stream), pool_part);
+}
+
 int oss_ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate,
                     const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dweight,
                     float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels, int64_t xsb,

@@ -72,7 +72,24 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *red = ycs + L;            // [kChRed]
     float *ypart = red + kChRed;     // [4][2 dc][L]: the state groups' partial sums of y
     for (int l = tid; l < L; l += NT) {
-        const float pl = p.pooled[(size_t)b * L + l];
+        float pl;
+        if (p.pool_part) {   // (uniform) the pooled descriptor from the LayerNorm forward's per-workgroup output sums, in order
+            const float *pp = p.pool_part + (size_t)b * p.n_part * L + l;
+            float sum = 0.f;
+            int k = 0;
+            for (; k + 8 <= p.n_part; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)(k + q) * L];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += v[q];
+            }
+            for (; k < p.n_part; ++k) sum += pp[(size_t)k * L];
+            pl = sum * p.pool_scale;
+            const_cast<float *>(p.pooled)[(size_t)b * L + l] = pl;   // kept for the backward
+        } else {
+            pl = p.pooled[(size_t)b * L + l];
+        }
         for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
     }
     __syncthreads();

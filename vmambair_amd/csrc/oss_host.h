@@ -67,7 +67,8 @@ int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, floa
                     void *dpre = nullptr);
 int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate, void *y,
                 float *mean, float *rstd, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
-                hipStream_t s);
+                hipStream_t s, float *pool_part = nullptr);
+int ln_nchw_fwd_pool_tiles(int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc);
 size_t ln_nchw_bwd_partial_floats(int B, int C, int P);
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,
                 const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dw, float *db,

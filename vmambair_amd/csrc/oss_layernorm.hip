@@ -49,7 +49,10 @@ template <typename TX, typename TY, bool GATE, int CPW, int V, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                        const TY *__restrict__ gate, TY *__restrict__ y, float *__restrict__ mean_out,
-                       float *__restrict__ rstd_out, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps) {
+                       float *__restrict__ rstd_out, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
+                       float *__restrict__ pool_part /* [B][gridDim.x][C] or NULL: per channel, the sum of the workgroup's OUTPUT values
+                       (as stored, i.e. rounded to TY) -- SS2D_1's channel branch starts from mean_hw of this tensor (MambaSISR6_arch.py:
+                       438-441), and a channel belongs to one wave here, so the pooling pass over y comes down to a 64-lane sum */) {
     __shared__ float red[2][kLnMaxWaves * 64 * V];
     constexpr int NI = CPW > 0 ? CPW : 1;
     const int b = blockIdx.y;
@@ -127,6 +130,13 @@ oss_ln_nchw_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w, co
             if constexpr (GATE) o[u] *= silu_f(zval[u]);
         }
         if (ok) store_v<TY, V>(yp + (size_t)c * P, o);
+        if (pool_part) {   // (uniform)
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < V; ++u) t += ok ? to_f32(from_f32<TY>(o[u])) : 0.f;
+            t = segment_sum_to_last<64>(t);
+            if (lane == 63) pool_part[((size_t)b * gridDim.x + blockIdx.x) * C + c] = t;
+        }
     };
     if constexpr (CPW > 0) {
 #pragma unroll
@@ -389,7 +399,7 @@ size_t ln_nchw_bwd_partial_floats(int B, int C, int P) { return (size_t)((P + 63
 
 template <typename TX, typename TY>
 static int ln_fwd_t(const void *x, const float *w, const float *bias, const void *gate, void *y, float *mean, float *rstd,
-                    int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps, hipStream_t s) {
+                    int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps, hipStream_t s, float *pool_part) {
     const int nw = ln_waves(B, C, P);
     const bool pairs = ln_pairs(C, P, xsb, xsc, gsb, gsc, x, gate, y, mean) && (reinterpret_cast<uintptr_t>(rstd) & 7u) == 0;
     const int tile = ln_tile(pairs);
@@ -397,8 +407,9 @@ static int ln_fwd_t(const void *x, const float *w, const float *bias, const void
     const TX *xp = reinterpret_cast<const TX *>(x);
     const TY *gp = reinterpret_cast<const TY *>(gate);
     TY *yp = reinterpret_cast<TY *>(y);
-    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_fwd_kernel, true, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
-    else      OSS_LN_LAUNCH(oss_ln_nchw_fwd_kernel, false, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps);
+    if (pool_part && !pairs) return OSS_ERR_SHAPE;   // the caller sized pool_part for 128-pixel workgroups (ln_nchw_fwd_pool_tiles)
+    if (gate) OSS_LN_LAUNCH(oss_ln_nchw_fwd_kernel, true, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps, pool_part);
+    else      OSS_LN_LAUNCH(oss_ln_nchw_fwd_kernel, false, xp, w, bias, gp, yp, mean, rstd, C, P, xsb, xsc, gsb, gsc, eps, pool_part);
     return (int)hipGetLastError();
 }
 
@@ -445,8 +456,14 @@ static int ln_bwd_t(const void *x, const float *w, const float *bias, const void
 
 int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate, void *y,
                 float *mean, float *rstd, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
-                hipStream_t s) {
-    OSS_LN_DISPATCH(ln_fwd_t, x, w, bias, gate, y, mean, rstd, B, C, P, xsb, xsc, gsb, gsc, eps, s)
+                hipStream_t s, float *pool_part) {
+    OSS_LN_DISPATCH(ln_fwd_t, x, w, bias, gate, y, mean, rstd, B, C, P, xsb, xsc, gsb, gsc, eps, s, pool_part)
+}
+
+// workgroups per image of the forward when its output sums are wanted (0: the shape does not take the 128-pixel form)
+int ln_nchw_fwd_pool_tiles(int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc) {
+    const void *a = reinterpret_cast<const void *>(uintptr_t(256));
+    return ln_pairs(C, P, xsb, xsc, gsb, gsc, a, a, a, a) ? (P + 127) / 128 : 0;
 }
 
 int ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate,

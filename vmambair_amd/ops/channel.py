@@ -30,15 +30,18 @@ def _chan_params(B, L, pooled, prm, saved, c):
                     ("A_logs", A_logs), ("Dsc", Dsc), ("cout_w", cout_w), ("cout_b", cout_b), ("cn_w", cn_w), ("cn_b", cn_b),
                     ("zt", zt), ("dts", dts), ("hs", hs), ("y", y), ("yc", yc), ("stat", stat), ("c", c)):
         setattr(P, name, _ptr(t))
+    P.pool_part, P.n_part, P.pool_scale = None, 0, 0.0
     return P
 
 
 def chan_gate_fwd(y2: torch.Tensor, cin_w: Optional[torch.Tensor], cin_b: Optional[torch.Tensor], Wxc: torch.Tensor,
                   Wdtc: torch.Tensor, dt_bias: torch.Tensor, A_logs: torch.Tensor, Dsc: torch.Tensor,
                   cout_w: Optional[torch.Tensor], cout_b: Optional[torch.Tensor], cn_w: torch.Tensor, cn_b: torch.Tensor,
-                  mul_mode: bool) -> List[torch.Tensor]:
+                  mul_mode: bool, pool_part: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """``y2 * c + y2`` (mul_mode) or ``y2 + c`` with c = the channel branch of SS2D_1 evaluated on mean_hw(y2)
-    (MambaSISR6_arch.py:438-496) -> [out, c, pooled, zt, dts, hs, y, yc, stat] (all but ``out`` are saved for bwd)."""
+    (MambaSISR6_arch.py:438-496) -> [out, c, pooled, zt, dts, hs, y, yc, stat] (all but ``out`` are saved for bwd).
+    ``pool_part`` (B, tiles, d) fp32: the per-workgroup sums of y2 its producer left (``ln_nchw_fwd(want_pool=True)``): the pooling
+    pass over y2 is skipped and ``pooled`` is formed inside the channel kernel."""
     _check(y2.is_cuda and y2.dim() == 4 and y2.dtype in _DT, "chan_gate: y2 must be a (B, d, H, W) GPU tensor")
     B, d, H, W = y2.shape
     y2 = _planes(y2)
@@ -57,9 +60,15 @@ def chan_gate_fwd(y2: torch.Tensor, cin_w: Optional[torch.Tensor], cin_b: Option
     lib = _capi.load()
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream().cuda_stream
-        _capi.check(lib.oss_rowsum(_DT[y2.dtype], y2.data_ptr(), None, pooled.data_ptr(), B, d, H * W, y2.stride(0), y2.stride(1),
-                                   0, 0, 1.0 / (H * W), st), "oss_rowsum")
-        _capi.check(lib.oss_chan_fwd(_chan_params(B, d, pooled, prm, saved, c), st), "oss_chan_fwd")
+        P = _chan_params(B, d, pooled, prm, saved, c)
+        if pool_part is not None and pool_part.numel():
+            _check(pool_part.dtype == torch.float32 and pool_part.is_contiguous() and pool_part.dim() == 3 and
+                   pool_part.shape[0] == B and pool_part.shape[2] == d, "chan_gate: pool_part must be contiguous (B, tiles, d) float32")
+            P.pool_part, P.n_part, P.pool_scale = pool_part.data_ptr(), pool_part.shape[1], 1.0 / (H * W)
+        else:
+            _capi.check(lib.oss_rowsum(_DT[y2.dtype], y2.data_ptr(), None, pooled.data_ptr(), B, d, H * W, y2.stride(0), y2.stride(1),
+                                       0, 0, 1.0 / (H * W), st), "oss_rowsum")
+        _capi.check(lib.oss_chan_fwd(P, st), "oss_chan_fwd")
         _capi.check(lib.oss_row_affine(_DT[y2.dtype], y2.data_ptr(), c.data_ptr() if mul_mode else None,
                                        None if mul_mode else c.data_ptr(), out.data_ptr(), B, d, H * W, y2.stride(0),
                                        y2.stride(1), 1.0, st), "oss_row_affine")
@@ -104,7 +113,7 @@ def chan_gate_bwd(g: torch.Tensor, y2: torch.Tensor, c: torch.Tensor, pooled: to
 
 _CH = "Tensor? cin_w, Tensor? cin_b, Tensor Wxc, Tensor Wdtc, Tensor dt_bias, Tensor A_logs, Tensor Dsc, Tensor? cout_w, " \
       "Tensor? cout_b, Tensor cn_w, Tensor cn_b, bool mul_mode"
-_LIB.define(f"chan_gate_fwd(Tensor y2, {_CH}) -> Tensor[]")
+_LIB.define(f"chan_gate_fwd(Tensor y2, {_CH}, Tensor? pool_part=None) -> Tensor[]")
 _LIB.define(f"chan_gate_bwd(Tensor g, Tensor y2, Tensor c, Tensor pooled, Tensor zt, Tensor dts, Tensor hs, Tensor y, Tensor yc, "
             f"Tensor stat, {_CH}, bool fold=False) -> Tensor[]")
 _LIB.impl("chan_gate_fwd", chan_gate_fwd, "CUDA")
@@ -145,6 +154,10 @@ class ChannelGateFn(torch.autograd.Function):
         return dy2, d_cinw, d_cinb, d_wxc, d_wdtc, d_bias, d_A, d_D, d_coutw, d_coutb, d_cnw, d_cnb, None
 
 
+#: ``VMAMBAIR_POOL_FUSED=0``: the mean over the pixels that starts the channel branch stays a pass of its own over y2 (A-B timing)
+POOL_FUSED = os.environ.get("VMAMBAIR_POOL_FUSED", "1") == "1"
+
+
 class NormChannelGateFn(torch.autograd.Function):
     """``out_norm(y) * silu(z)`` (MambaSISR6_arch.py:433-434,488-493) followed by the channel branch + gate (:438-496) as ONE
     autograd node over the same kernels as LayerNormNCHWFn -> ChannelGateFn.  What the single node buys: the gate's backward
@@ -155,9 +168,12 @@ class NormChannelGateFn(torch.autograd.Function):
     def forward(ctx, y, ln_w, ln_b, z, out_dtype, gate_grad_into, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
                 cn_w, cn_b, mul_mode):
         from .layernorm import _DT_CODE
-        y2, mean, rstd = torch.ops.vmambair.ln_nchw_fwd(y, ln_w, ln_b, z, _DT_CODE[out_dtype])
+        # the pooled descriptor of the channel branch comes out of the LayerNorm launch (per-workgroup sums of its output)
+        res = torch.ops.vmambair.ln_nchw_fwd(y, ln_w, ln_b, z, _DT_CODE[out_dtype], POOL_FUSED)
+        y2, mean, rstd = res[0], res[1], res[2]
+        pool = res[3] if len(res) > 3 and res[3].numel() else None
         out, *saved = torch.ops.vmambair.chan_gate_fwd(y2, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
-                                                       cn_w, cn_b, mul_mode)
+                                                       cn_w, cn_b, mul_mode, pool)
         ctx.mul_mode, ctx.gate_grad_into, ctx.has_lnb = mul_mode, gate_grad_into, ln_b is not None
         ctx.save_for_backward(y, ln_w, ln_b, z, mean, rstd, y2, *saved, cin_w, cin_b, Wxc, Wdtc, dt_bias, A_logs, Dsc, cout_w, cout_b,
                               cn_w, cn_b)

@@ -19,8 +19,10 @@ _LN_PAIRS = {(torch.float32, torch.float32), (torch.float32, torch.float16), (to
 
 
 def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
-                out_code: int) -> List[torch.Tensor]:
-    """-> [y (B, C, H, W) of dtype ``out_code``, mean (B, H*W), rstd (B, H*W)]; eps = 1e-5."""
+                out_code: int, want_pool: bool = False) -> List[torch.Tensor]:
+    """-> [y (B, C, H, W) of dtype ``out_code``, mean (B, H*W), rstd (B, H*W)]; eps = 1e-5.  ``want_pool``: a fourth tensor
+    (B, tiles, C) fp32 with the per-workgroup sums of y over its pixels (``oss_ln_nchw_fwd_pool``; the channel branch's pooled
+    descriptor without a pass over y) -- empty when the shape does not take that form."""
     _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "ln_nchw: x must be a (B, C, H, W) GPU tensor")
     out_dtype = _CODE_DT[int(out_code)]
     _check((x.dtype, out_dtype) in _LN_PAIRS, f"ln_nchw: unsupported dtype pair {x.dtype} -> {out_dtype}")
@@ -37,15 +39,23 @@ def ln_nchw_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     mean = torch.empty((B, P), dtype=torch.float32, device=x.device)
     rstd = torch.empty((B, P), dtype=torch.float32, device=x.device)
     if x.numel() == 0:
-        return [y, mean, rstd]
+        return [y, mean, rstd] + ([x.new_empty(0, dtype=torch.float32)] if want_pool else [])
     lib = _capi.load()
+    gs0, gs1 = (0, 0) if gate is None else (gate.stride(0), gate.stride(1))
+    tiles = int(lib.oss_ln_nchw_fwd_pool_tiles(Cc, P, x.stride(0), x.stride(1), gs0, gs1)) if want_pool else 0
+    aligned = all(t is None or t.data_ptr() % 8 == 0 for t in (x, gate, y, mean, rstd))
     with torch.cuda.device(x.device):
         st = torch.cuda.current_stream().cuda_stream
+        if tiles > 0 and aligned:
+            pool = torch.empty((B, tiles, Cc), dtype=torch.float32, device=x.device)
+            _capi.check(lib.oss_ln_nchw_fwd_pool(_DT[x.dtype], _DT[out_dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
+                                                 y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), pool.data_ptr(), B, Cc, P,
+                                                 x.stride(0), x.stride(1), gs0, gs1, 1e-5, st), "oss_ln_nchw_fwd_pool")
+            return [y, mean, rstd, pool]
         _capi.check(lib.oss_ln_nchw_fwd(_DT[x.dtype], _DT[out_dtype], x.data_ptr(), w.data_ptr(), _ptr(b), _ptr(gate),
                                         y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, Cc, P, x.stride(0), x.stride(1),
-                                        0 if gate is None else gate.stride(0), 0 if gate is None else gate.stride(1),
-                                        1e-5, st), "oss_ln_nchw_fwd")
-    return [y, mean, rstd]
+                                        gs0, gs1, 1e-5, st), "oss_ln_nchw_fwd")
+    return [y, mean, rstd] + ([x.new_empty(0, dtype=torch.float32)] if want_pool else [])
 
 
 def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], gate: Optional[torch.Tensor],
@@ -98,7 +108,7 @@ def ln_nchw_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return [dx, dgate if (dgate is not None and not in_place) else e, dw, db if db is not None else e]
 
 
-_LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code) -> Tensor[]")
+_LIB.define("ln_nchw_fwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, int out_code, bool want_pool=False) -> Tensor[]")
 _LIB.define("ln_nchw_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor? gate, Tensor dy, Tensor mean, Tensor rstd, "
             "Tensor? skip_grad, Tensor(a!)? dgate_into, Tensor? dy_mul=None, Tensor? dy_add=None, float add_scale=1.0) -> Tensor[]")
 _LIB.impl("ln_nchw_fwd", ln_nchw_fwd, "CUDA")
