@@ -5,8 +5,12 @@ refinement, bf16 autocast, batch 8 per MI355X, fwd + L1 loss + bwd + Adam + EMA,
 reference step: SRGAN/options/MambaSISR15_x4.yml:55-90, SRGAN/VmambaIR/models/MambaSISR_model.py:120-147).
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by ``python -m torch.distributed.run --nproc-per-node N ...``: one process per
-  GPU, DDP over RCCL, the image batch sharded by rank (per-GPU batch fixed => weak scaling).
+  N > 1: one process per GPU, DDP over RCCL, the image batch sharded by rank (per-GPU batch fixed => weak scaling).
+  Either the caller starts the ranks (``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK /
+  LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment), or -- when WORLD_SIZE is not set -- this script
+  starts them itself (``launch_ranks``: re-executes itself under torch.distributed.run on 127.0.0.1 and a free port,
+  passes the ranks' output through and returns their exit code; the reference's counterpart is
+  ``python -m torch.distributed.launch --nproc_per_node=N``, SRGAN/train_S1.sh:1-8).
 Prints ONE JSON line on rank 0 with the metric, ``roofline`` (dominant scan kernel: algorithmic
 bytes / HIP-event kernel time, measured inside the timed region by the library's own events) and
 ``cpu_baseline`` (the same training step on the host cores with the CPU oracle as the scan, N = 1
@@ -359,6 +363,35 @@ def secondary_workloads():
     return out
 
 
+def launch_ranks(n, argv):
+    """``--gpus N`` without a launcher around us: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+    127.0.0.1 -- the container hostname may not resolve -- and a free port), stream their output (rank 0's JSON line is the
+    last stdout line) and return their exit code.  Under torch.distributed.run already (WORLD_SIZE set) this is never called."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    log(f"--gpus {n}: no WORLD_SIZE in the environment, starting the ranks: {' '.join(cmd)}")
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(world, rank):
+    """``--rendezvous-only`` (tests/test_ddp_gloo.py): the launcher path without a GPU -- the ranks meet over gloo, agree on
+    the world size with one all-reduce, rank 0 prints a line.  Everything up to the first device call of a real run."""
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok", "backend": "gloo", "n_ranks": dist.get_world_size(), "sum_of_ranks_plus_1": float(t.item()),
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +413,7 @@ def main():
     ap.add_argument("--skip-roofline", action="store_true",
                     help="graph mode: do not run the trailing eager steps that time the scan kernels (profiling runs)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
@@ -392,10 +426,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: use --nproc-per-node {args.gpus}")
+    if args.rendezvous_only:
+        return rendezvous_only(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP scan has no CPU path)")
+    if torch.cuda.device_count() < max(world, local_rank + 1):
+        raise SystemExit(f"--gpus {world}: rank {rank} needs GPU {local_rank}, but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "on this node (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -189,3 +189,33 @@ def test_shard_indices_follow_the_reference_sampler():
     perm = torch.randperm(12, generator=g)
     for r in range(4):
         assert torch.equal(ddp.shard_indices(10, r, 4, epoch=3), (perm % 10)[r::4])
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it (the reference's launcher line is
+    SRGAN/train_S1.sh:1-8): the script re-executes itself under torch.distributed.run, the two ranks rendezvous on
+    127.0.0.1 (gloo here: no GPU), rank 0's JSON line is the last stdout line and the exit code is the ranks'."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rendezvous-only"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["rendezvous"] == "ok" and line["n_ranks"] == 2 and line["sum_of_ranks_plus_1"] == 3.0
+    assert line["master"].startswith("127.0.0.1:")
+    assert "starting the ranks" in r.stderr
+
+
+def test_bench_gpus_n_fails_on_the_device_count_not_on_the_launcher():
+    """On a box with fewer GPUs than ranks the self-launched run must end with the device-count message (or the no-GPU
+    message here), never with 'needs torch.distributed.run'."""
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the run would start")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert "needs torch.distributed.run" not in r.stderr
+    assert ("needs a GPU" in r.stderr) or ("GPU(s) are visible" in r.stderr), r.stderr[-1500:]

@@ -1,6 +1,6 @@
 """Workgroup-level 1x1-conv kernel (oss_conv1x1_wg.hip) against the wave-level kernels of oss_conv1x1.hip through the SAME entry
 points (oss_conv1x1_fwd / _dgrad; the dispatch switched with oss_conv1x1_set_wg): same values, time per call.
-python tools/conv_wg_test.py   (GPU box)"""
+python tools/conv_wg_bench.py   (GPU box)"""
 import os
 import sys
 
