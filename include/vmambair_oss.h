@@ -97,13 +97,14 @@ typedef struct {
      * (cus/selective_scan_fwd_kernel.cuh:101-102).  Ignored by oss_scan_bwd (which has its own workspace). */
     void *workspace;
     size_t workspace_bytes;
-    /* Optional lane states (round 3): oss_scan_lane_state_floats() floats, layout [batch][dim][dstate][L8] with
+    /* Optional lane states (round 3; OPT-IN BUILD FEATURE since round 4 -- oss_scan_features() & OSS_FEATURE_LANE_STATES; a
+     * library built without it ignores the field): oss_scan_lane_state_floats() floats, layout [batch][dim][dstate][L8] with
      * L8 = round_up(ceil(seqlen / 8), 64): entry k of a (batch, row, state) line is the state h ENTERING scan steps 8k .. 8k+7
      * (h after step 8k - 1; 0 for k = 0).  oss_scan_fwd writes them when hs != NULL (a by-product of its second pass);
      * oss_scan_bwd given the same buffer in f.hs reads them instead of re-running the forward recurrence and one lane scan per
      * state (round-2 kernels, dstate <= 64, not the fused-delta form) -- same gradients to fp32 round-off.  NULL = recompute
-     * from `x`, as the reference's backward does (cus/selective_scan_bwd_kernel.cuh:184-186).  The torch layers keep the
-     * buffer in the tail of the opaque `x` tensor's storage, so no caller-visible signature changes. */
+     * from `x`, as the reference's backward does (cus/selective_scan_bwd_kernel.cuh:184-186).  The torch layers carry the
+     * buffer as a third tensor next to (out, x): selective_scan_fwd(..., want_hs) -> [out, x, hs], selective_scan_bwd(..., hs). */
     float *hs;
 } oss_scan_fwd_params;
 
@@ -386,8 +387,12 @@ int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chu
  * (16-bit I/O) do not launch: each call records its problem (operands, partial buffer and outputs must stay alive and unread)
  * and -- with oss_set_defer_finish(1) -- its finishing sum; oss_flush_wgrads then runs EVERY recorded product as one grouped
  * launch (the descriptor table, oss_deferred_wgrad_table_bytes() bytes, goes through host_table -- pinned, kept alive when
- * the call is captured into a hipGraph -- to device_table).  Call it before oss_flush_finishes.  Results are bit-identical to
- * the one-launch-per-product form: same tiles, same partial layout, same summation order.
+ * the call is captured into a hipGraph -- to device_table).  Call it before oss_flush_finishes.  With
+ * oss_conv1x1_wgrad_set_span(1) the results are bit-identical to the one-launch-per-product form (same tiles, same partial
+ * layout, same summation order); the default span (4: a workgroup walks four 512-pixel pieces into one accumulator, a quarter
+ * of the partial vectors) changes the order of the fp32 additions -- equal to round-off, bit-identical from run to run.
+ * A product recorded while oss_set_defer_finish is off is rejected (OSS_ERR_WORKSPACE): its finishing sum would read partials
+ * that do not exist before the flush.
  * oss_set_defer_wgrad(0/1) also drops whatever was recorded and not flushed. */
 void oss_set_defer_wgrad(int on);
 size_t oss_deferred_wgrads(void);
@@ -397,7 +402,8 @@ int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes
 /* Adam + EMA of the training step (MambaSISR_model.py:120-147: torch.optim.Adam without amsgrad / weight decay,
  * then ema = decay * ema + (1 - decay) * param) as one elementwise launch over a chunk table in device memory:
  * one entry per <= OSS_ADAM_CHUNK consecutive elements of one parameter tensor (all float; ema may be NULL).
- * state: 4 floats in device memory {step count, 1 - beta1^t, 1 - beta2^t, learning rate}; the call advances the step
+ * state: 4 floats in device memory {step count, 1 - beta1^t, 1 - beta2^t, learning rate} (the fourth is read only with
+ * lr < 0; a caller that always passes lr >= 0 may hand over 3); the call advances the step
  * count first (so the launch pair can be replayed inside a hipGraph).  lr >= 0: the learning rate of this call (baked into
  * a captured launch); lr < 0: the kernel reads state[3], which the host may rewrite between replays -- the reference
  * trainings change the rate during a run (MultiStepLR, SRGAN/options/MambaSISR15_x4.yml:84-87;
@@ -499,6 +505,23 @@ int oss_prof_marker(int which, oss_stream_t stream);
 const char *oss_scan_build_id(void);
 
 const char *oss_version(void);
+
+/* Opt-in build features of the loaded library (vmambair_amd/_build.py: VMAMBAIR_BUILD_FEATURES=fused_dt,lane_states).  Both are
+ * measured losers kept in the tree for the record; the shipped library has neither: dt_weight != NULL
+ * is then rejected with OSS_ERR_SHAPE, oss_scan_fused_dt_ok() and oss_scan_lane_state_floats() answer 0, `hs` is ignored. */
+#define OSS_FEATURE_FUSED_DT 1
+#define OSS_FEATURE_LANE_STATES 2
+int oss_scan_features(void);
+
+/* ABI guard.  oss_scan_fwd_params / oss_scan_bwd_params / oss_chan_params cross the boundary BY POINTER, so a binding layer
+ * compiled against another revision of this header would hand the kernels garbage pointers.  OSS_ABI_VERSION is bumped with
+ * every change of a struct or of an entry point's argument list; oss_abi_struct_bytes(which) is the library's own sizeof
+ * (which: 0 = oss_scan_fwd_params, 1 = oss_scan_bwd_params, 2 = oss_chan_params; 0 for anything else).  Every binding layer
+ * in this tree (vmambair_amd/_capi.py, csrc_host/oss_torch_host.cpp through vmambair_amd/_host.py) compares both with its
+ * own compile-time values when it loads and refuses to run on a mismatch. */
+#define OSS_ABI_VERSION 5
+int oss_abi_version(void);
+size_t oss_abi_struct_bytes(int which);
 
 #ifdef __cplusplus
 }

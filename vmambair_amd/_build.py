@@ -19,7 +19,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 
 #: the files the scan kernels are compiled from: their hash is the library's oss_scan_build_id()
-SCAN_FILES = ("oss_scan_fwd.hip", "oss_scan_bwd.hip", "oss_scan_bwd_v2.h", "oss_scan_bwd_pair.h", "oss_device.h")
+SCAN_FILES = ("oss_scan_fwd.hip", "oss_scan_bwd.hip", "oss_scan_bwd_v2.h", "oss_device.h")
+
+#: opt-in instantiations (csrc/oss_host.h: kBuildFusedDt / kBuildLaneStates): VMAMBAIR_BUILD_FEATURES=fused_dt,lane_states
+FEATURE_FLAGS = {"fused_dt": "-DOSS_WITH_FUSED_DT=1", "lane_states": "-DOSS_WITH_LANE_STATES=1"}
+
+
+def feature_flags():
+    names = [n for n in os.environ.get("VMAMBAIR_BUILD_FEATURES", "").replace(" ", "").split(",") if n]
+    unknown = [n for n in names if n not in FEATURE_FLAGS]
+    if unknown:
+        raise ValueError(f"VMAMBAIR_BUILD_FEATURES: unknown feature(s) {unknown}; known: {sorted(FEATURE_FLAGS)}")
+    return [FEATURE_FLAGS[n] for n in sorted(set(names))]
 
 
 def scan_build_id() -> str:
@@ -27,6 +38,7 @@ def scan_build_id() -> str:
     h = hashlib.sha256()
     for f in SCAN_FILES:
         h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(feature_flags()).encode())
     return h.hexdigest()[:12]
 
 
@@ -79,12 +91,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     idfile = os.path.join(OBJ_DIR, "scan_build_id.txt")
     if not (os.path.exists(idfile) and open(idfile).read() == bid):   # the id is compiled into oss_capi.o
         open(idfile, "w").write(bid)
-        capi = os.path.join(CSRC, "oss_capi.hip")
-        if capi not in todo:
-            todo.append(capi)
+        # ... and the build features are compiled into the scan translation units
+        for name in ("oss_capi.hip", *[f for f in SCAN_FILES if f.endswith(".hip")]):
+            if os.path.join(CSRC, name) not in todo:
+                todo.append(os.path.join(CSRC, name))
 
     def compile_one(src):
-        cmd = [hipcc, *FLAGS, f'-DOSS_SCAN_BUILD_ID="{bid}"', "-c", src, "-o", _obj(src) + ".tmp"]
+        cmd = [hipcc, *FLAGS, *feature_flags(), f'-DOSS_SCAN_BUILD_ID="{bid}"', "-c", src, "-o", _obj(src) + ".tmp"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

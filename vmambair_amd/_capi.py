@@ -11,6 +11,7 @@ import os
 from . import _build
 
 OSS_F32, OSS_F16, OSS_BF16 = 0, 1, 2
+FEATURE_FUSED_DT, FEATURE_LANE_STATES = 1, 2   # oss_scan_features(): opt-in build features (VMAMBAIR_BUILD_FEATURES)
 
 ERRORS = {
     -1: "OSS_ERR_NULL: a required pointer is NULL",
@@ -82,7 +83,10 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
            "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
            "oss_flush_finishes", "oss_set_defer_wgrad", "oss_deferred_wgrads", "oss_deferred_wgrad_table_bytes", "oss_flush_wgrads",
-           "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version"]
+           "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version", "oss_scan_features", "oss_abi_version", "oss_abi_struct_bytes"]
+
+#: include/vmambair_oss.h: OSS_ABI_VERSION this binding was written against
+ABI_VERSION = 5
 
 _lib = None
 
@@ -243,8 +247,32 @@ def load():
     lib.oss_prof_marker.argtypes = [C.c_int, C.c_void_p]
     lib.oss_scan_build_id.restype = C.c_char_p
     lib.oss_version.restype = C.c_char_p
+    if not hasattr(lib, "oss_abi_version"):
+        raise RuntimeError(f"{path} predates the ABI guard of include/vmambair_oss.h: rebuild it (__graft_entry__.build())")
+    lib.oss_abi_version.restype = C.c_int
+    lib.oss_scan_features.restype = C.c_int
+    lib.oss_abi_struct_bytes.restype = C.c_size_t
+    lib.oss_abi_struct_bytes.argtypes = [C.c_int]
+    # the structs cross the boundary by pointer: a library built from another revision of the header would misread them
+    mine = (ABI_VERSION, C.sizeof(ScanFwdParams), C.sizeof(ScanBwdParams), C.sizeof(ChanParams))
+    theirs = (lib.oss_abi_version(), *(lib.oss_abi_struct_bytes(i) for i in range(3)))
+    if mine != theirs:
+        raise RuntimeError(f"{path}: ABI mismatch with vmambair_amd/_capi.py (version, sizeof fwd / bwd / chan params): "
+                           f"library {theirs}, binding {mine}; rebuild with __graft_entry__.build()")
     _lib = lib
     return lib
+
+
+def has_feature(bit: int) -> bool:
+    """opt-in build features of the loaded library (include/vmambair_oss.h: oss_scan_features)"""
+    return bool(load().oss_scan_features() & bit)
+
+
+def require_feature(bit: int, what: str) -> None:
+    if not has_feature(bit):
+        name = {FEATURE_FUSED_DT: "fused_dt", FEATURE_LANE_STATES: "lane_states"}[bit]
+        raise RuntimeError(f"{what}: {lib_path()} was built without the opt-in feature '{name}' "
+                           f"(rebuild with VMAMBAIR_BUILD_FEATURES={name}; DESIGN.md 4.3 / section 9 say why it is off)")
 
 
 def check(rc: int, what: str) -> None:

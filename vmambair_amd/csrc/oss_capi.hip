@@ -91,39 +91,26 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     return 0;
 }
 
-// VMAMBAIR_SCAN_BWD_PAIR=0/1: A-B switch for the packed two-states-per-pass backward (variants 8 / 9)
-static bool bwd_pair_enabled() {
-    static const int on = [] {
-        const char *e = std::getenv("VMAMBAIR_SCAN_BWD_PAIR");
-        return e ? std::atoi(e) : 0;
-    }();
-    return on != 0;
-}
-
 int scan_bwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_groups) {
     const int rows_per_group = dim / n_groups;
-    if (seqlen <= 256 || rows_per_group < 8) return 1;
-    const bool pair = bwd_pair_enabled() && dstate >= 2;
-    // <= one 8-row workgroup per CU: nothing is gained by leaving register room for a second one, so take the
-    // build without spills (u:(8,192,4096): 0.196 ms against 0.229, profiles/r01_sweep_v4_bwd_variants.txt)
+    // short sequences, few rows per group, dstate > 64 (the round-2 kernel keeps one lane per state): the round-1 kernel
+    if (seqlen <= 256 || rows_per_group < 8 || dstate > 64) return 1;
     const long wgs = (long)batch * n_groups * ((rows_per_group + 7) / 8);
-    const bool v2 = dstate <= 64 && !pair;   // round-2 kernel (oss_scan_bwd_v2.h): u:(8,192,4096) 0.172 ms against 0.203,
-                                             // u:(8,384,4096) 0.235 against 0.284 (profiles/r02_scan_bwd_v2_experiments.txt)
+    // round-2 kernel (oss_scan_bwd_v2.h) from here on: u:(8,192,4096) 0.172 ms against 0.203 for the round-1 kernel,
+    // u:(8,384,4096) 0.235 against 0.284 (profiles/r02_scan_bwd_v2_experiments.txt)
     // long sequences whose 12-row tiles leave CUs idle: 12-row workgroups cut into time segments (scan_pick_segments) instead
     // of ever smaller row tiles -- a third of the dB / dC partial tiles of the 4-row form and three waves per SIMD
     // (u:(4,192,16384) bf16: 0.328 + 0.029 ms in 4 segments against 0.590 + 0.087 for variant 13; u:(1,384,25600) f16:
     // 0.293 + 0.022 in 9 segments against 1.316 -- profiles/r03_segment_sweep.txt)
     // (u:(8,192,4096) bf16, 128 such workgroups: 0.166 + 0.015 ms in 2 segments against 0.168 + 0.020 for variant 11)
-    if (v2 && seqlen >= 2048 && rows_per_group % 12 == 0 && (long)batch * n_groups * (rows_per_group / 12) < 192) return 10;
+    if (seqlen >= 2048 && rows_per_group % 12 == 0 && (long)batch * n_groups * (rows_per_group / 12) < 192) return 10;
     // very few rows (Deraining level 0 at batch 4: 96 8-row workgroups for 256 CUs): 4-row workgroups spread the same waves over
     // twice the CUs, one wave per SIMD instead of two (u:(4,192,16384): 0.585 ms against 0.684)
-    if (wgs <= 128 && v2 && rows_per_group % 4 == 0) return 13;
-    if (wgs <= 256) return pair ? 9 : (v2 ? 11 : 3);
+    if (wgs <= 128 && rows_per_group % 4 == 0) return 13;
+    if (wgs <= 256) return 11;
     // more rows per workgroup: fewer dB / dC partial tiles and an even load (u:(8,384,4096) bf16: 0.271 ms against
     // 0.355; u:(32,384,4096): 1.07 against 1.14)
-    // (variant 6 = 4 with all 16 states staged at once: 0.2655 against 0.275 ms)
-    if (rows_per_group >= 12) return pair ? 8 : (v2 ? 10 : (dstate <= 16 ? 6 : 4));
-    return pair ? 9 : 0;
+    return rows_per_group >= 12 ? 10 : 11;
 }
 
 // ---- per-launch event timing (oss_prof_*) -----------------------------------------------------
@@ -198,7 +185,7 @@ static double bwd_own_bytes(const oss_scan_bwd_params &q, int s) {
 
 static int check_fwd(const oss_scan_fwd_params *p) {
     if (!p || !p->u || !p->delta || !p->A || !p->B || !p->C) return OSS_ERR_NULL;
-    if (p->dt_weight && (p->dt_rank < 1 || p->dt_rank > kMaxDtRank)) return OSS_ERR_SHAPE;
+    if (p->dt_weight && (!kBuildFusedDt || p->dt_rank < 1 || p->dt_rank > kMaxDtRank)) return OSS_ERR_SHAPE;
     if (p->batch < 0 || p->dim <= 0 || p->seqlen < 0 || p->dstate <= 0 || p->n_groups <= 0) return OSS_ERR_SHAPE;
     if (p->dim % p->n_groups != 0) return OSS_ERR_SHAPE;  // selective_scan.cpp:190
     if (p->dstate > OSS_MAX_DSTATE) return OSS_ERR_DSTATE;  // selective_scan.cpp:191
@@ -262,7 +249,7 @@ size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, 
 }
 
 size_t oss_scan_lane_state_floats(int batch, int dim, int seqlen, int dstate) {
-    if (batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0) return 0;
+    if (!kBuildLaneStates || batch <= 0 || dim <= 0 || seqlen <= 0 || dstate <= 0) return 0;
     return (size_t)batch * dim * dstate * lane_state_stride(seqlen);
 }
 
@@ -408,7 +395,7 @@ int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, 
 
 void oss_proj_set_path(int force_vector_alu) { proj_force_valu(force_vector_alu); }
 int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstate, int seqlen) {
-    return proj_mfma_ok(io, batch, D, C, R, seqlen) && R >= 1 && R <= kMaxDtRank && dstate <= 64 && seqlen >= 512;
+    return kBuildFusedDt && proj_mfma_ok(io, batch, D, C, R, seqlen) && R >= 1 && R <= kMaxDtRank && dstate <= 64 && seqlen >= 512;
 }
 int oss_conv1x1_wg(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout, int cin,
                    int pixels, int64_t xsb, int64_t xsc, int transposed_weight, oss_stream_t stream) {
@@ -717,6 +704,7 @@ void oss_scan_set_segments(int fwd_segments, int bwd_segments) {
 }
 int oss_scan_last_segments(int which) { return which == 0 ? g_last_fwd_segments.load() : g_last_bwd_segments.load(); }
 int oss_scan_last_lane_states(void) { return g_last_bwd_lane_states.load(); }
+int oss_scan_features(void) { return (kBuildFusedDt ? OSS_FEATURE_FUSED_DT : 0) | (kBuildLaneStates ? OSS_FEATURE_LANE_STATES : 0); }
 
 // copy kernels of oss_hbm_copy.  Default (mode 2): one 16-byte element per lane and a grid as large as the buffer -- the
 // dispatcher streams short workgroups faster than any loop keeps loads in flight: 6.12 TB/s on 1 GiB, against 5.58 for
@@ -822,6 +810,16 @@ int oss_prof_marker(int which, oss_stream_t stream) {
 #endif
 const char *oss_scan_build_id(void) { return OSS_SCAN_BUILD_ID; }
 
-const char *oss_version(void) { return "vmambair_oss 0.3 (gfx950)"; }
+const char *oss_version(void) { return "vmambair_oss 0.4 (gfx950)"; }
+
+int oss_abi_version(void) { return OSS_ABI_VERSION; }
+size_t oss_abi_struct_bytes(int which) {
+    switch (which) {
+        case 0: return sizeof(oss_scan_fwd_params);
+        case 1: return sizeof(oss_scan_bwd_params);
+        case 2: return sizeof(oss_chan_params);
+        default: return 0;
+    }
+}
 
 }  // extern "C"

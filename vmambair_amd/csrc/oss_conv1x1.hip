@@ -821,8 +821,9 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
 // work (302 launches = 3.2 ms of a 40 ms step, profiles/r03_rocprof_bench_steady_state_v1.txt).  With oss_set_defer_wgrad(1)
 // conv1x1_wgrad() only records its problem; oss_flush_wgrads() copies the descriptor table to the device and runs this
 // kernel over every recorded problem's workgroups back to back (block -> problem through a 16-bit table), so the chip is
-// full for the whole launch and the operands stream at memory speed.  Same per-problem arithmetic, same partial layout, same
-// finishing sums: bit-identical weight gradients.
+// full for the whole launch and the operands stream at memory speed.  Same per-problem arithmetic; with a span of one 512-pixel
+// piece per partial (oss_conv1x1_wgrad_set_span(1)) also the same partial layout and finishing sums, i.e. bit-identical weight
+// gradients -- the default span of 4 pieces adds the same terms in another order (equal to fp32 round-off, run-to-run stable).
 struct WgradDesc {
     const void *dy, *x;
     float *part;
@@ -1201,6 +1202,9 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
     dim3 grid(slabs, B * G, (tiles + 3) / 4);
     const int tmode = wgrad_tile_mode();
     if (defer_wgrad() && !tmode && (io == OSS_BF16 || io == OSS_F16) && (size_t)slabs * B * G * ((tiles + 3) / 4) < (1u << 24)) {
+        // a recorded product's partials do not exist until oss_flush_wgrads: its finishing sum must be deferred too (it would
+        // otherwise run right below, on a buffer nobody has written yet)
+        if (!defer_finish()) return OSS_ERR_WORKSPACE;
         WgradDesc d;
         d.span = kWgradSlab * wgrad_span_mult(); d.reserved_ = 0;
         slabs = (P + d.span - 1) / d.span;   // never more than conv1x1_wgrad_slabs(P): the caller's partial buffer is large enough

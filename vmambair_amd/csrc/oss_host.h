@@ -30,6 +30,22 @@ struct LdsGate {
     }
 };
 
+// Opt-in instantiations: two measured losers stay in the tree behind build flags instead of in the shipped
+// library -- delta computed inside the scans (`FD`, DESIGN.md 4.3: 177.0 against 205.9 images/s) and lane states saved by the
+// forward pass for the backward (`HS`, DESIGN.md section 9: backward -1 %, forward +7 %).  vmambair_amd/_build.py passes
+// -DOSS_WITH_FUSED_DT / -DOSS_WITH_LANE_STATES when VMAMBAIR_BUILD_FEATURES names them; oss_scan_features() reports what
+// the loaded library has, oss_scan_fused_dt_ok() / oss_scan_lane_state_floats() answer 0 without the feature.
+#ifdef OSS_WITH_FUSED_DT
+constexpr bool kBuildFusedDt = true;
+#else
+constexpr bool kBuildFusedDt = false;
+#endif
+#ifdef OSS_WITH_LANE_STATES
+constexpr bool kBuildLaneStates = true;
+#else
+constexpr bool kBuildLaneStates = false;
+#endif
+
 // Time-segmented launches (oss_scan_fwd.hip: FwdSeg, oss_scan_bwd_v2.h: BwdSeg).  seg_req: -1 = heuristic, 0 / 1 = never,
 // n > 1 = n segments (clamped to the number of chunks).
 constexpr int kMaxSegments = 64;

@@ -432,7 +432,6 @@ oss_scan_bwd_finish(const FinishArgs a) {
 }
 
 }  // namespace oss
-#include "oss_scan_bwd_pair.h"
 #include "oss_scan_bwd_v2.h"
 namespace oss {
 
@@ -529,24 +528,6 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
     return launch_finish<T>(p, ws, wdD, wdb, stream);
 }
 
-// two states per pass in packed fp32 (oss_scan_bwd_pair.h)
-template <typename T, int I, int WAVES, int NBB, int MINW>
-static int launch_bwd_pair(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTimer *timer) {
-    constexpr int TC = 64 * I;
-    const oss_scan_fwd_params &f = p.f;
-    BwdWs ws;
-    float *wdD, *wdb;
-    int rc = carve_ws(p, WAVES, ws, wdD, wdb);
-    if (rc != OSS_OK) return rc;
-    const size_t np = (size_t)((f.dstate + 1) & ~1);
-    const size_t smem = sizeof(float) * (2 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + 3 * np * WAVES + WAVES);
-    static LdsGate gate;
-    rc = launch_main(oss_scan_bwd_pair_kernel<T, I, WAVES, NBB, MINW>, smem, gate,
-                     (unsigned)(f.batch * f.n_groups * ws.tiles), WAVES * 64, p, ws, stream, timer);
-    if (rc != OSS_OK) return rc;
-    return launch_finish<T>(p, ws, wdD, wdb, stream);
-}
-
 #ifndef OSS_CARRY_WAVES
 #define OSS_CARRY_WAVES 0   // 0 = the main kernel's row tile
 #endif
@@ -556,7 +537,10 @@ constexpr int kCarryWaves = OSS_CARRY_WAVES;
 template <typename T, int WAVES, int NBB, int MINW, bool FD = false>
 static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t stream, LaunchTimer *timer) {
     if constexpr (!FD) {
-        if (p.f.dt_weight) return launch_bwd2<T, WAVES, NBB, MINW, true>(p, seg_req, stream, timer);
+        if (p.f.dt_weight) {
+            if constexpr (kBuildFusedDt) return launch_bwd2<T, WAVES, NBB, MINW, true>(p, seg_req, stream, timer);
+            else return OSS_ERR_SHAPE;   // this library was built without OSS_WITH_FUSED_DT
+        }
     }
     constexpr int TC = 512;
     const oss_scan_fwd_params &f = p.f;
@@ -577,7 +561,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     if (rc != OSS_OK) return rc;
     g_last_bwd_segments.store(n_seg);
     // lane states saved by the forward pass (f.hs): the kernels that load them instead of re-running the forward recurrence
-    const bool hs = !FD && f.hs != nullptr;
+    const bool hs = kBuildLaneStates && !FD && f.hs != nullptr;
     // two tile buffers, two slab buffers (+ dt weights | + two buffers of this wave's lane states)
     const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * TC + (FD ? WAVES * kMaxDtRank : 0) +
                                          (hs ? 2 * (size_t)WAVES * NBB * 64 : 0));
@@ -596,11 +580,16 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_seg - 1))), dim3(CW * 64), sizeof(float) * kNB * TC,
                                stream, p, sg, ctiles);
             static LdsGate gate_s, gate_sh;
-            if (hs) {
-                auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, true>;
-                if (const int e = gate_sh.ensure(reinterpret_cast<const void *>(km), smem)) return e;
-                hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
-            } else {
+            bool launched = false;
+            if constexpr (kBuildLaneStates) {
+                if (hs) {
+                    auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, true>;
+                    if (const int e = gate_sh.ensure(reinterpret_cast<const void *>(km), smem)) return e;
+                    hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
+                    launched = true;
+                }
+            }
+            if (!launched) {
                 auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, false>;
                 if (const int e = gate_s.ensure(reinterpret_cast<const void *>(km), smem)) return e;
                 hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
@@ -610,12 +599,14 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             if (rc != OSS_OK) return rc;
             return launch_finish<T>(p, ws, wdD, wdb, stream, n_seg);
         }
-        if (hs) {
-            static LdsGate gate_h;
-            rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, false, true>, smem, gate_h, wgs, WAVES * 64, p, ws, stream,
-                             timer, BwdSeg{nullptr, 1, n_chunks});
-            if (rc != OSS_OK) return rc;
-            return launch_finish<T>(p, ws, wdD, wdb, stream);
+        if constexpr (kBuildLaneStates) {
+            if (hs) {
+                static LdsGate gate_h;
+                rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, false, true>, smem, gate_h, wgs, WAVES * 64, p, ws,
+                                 stream, timer, BwdSeg{nullptr, 1, n_chunks});
+                if (rc != OSS_OK) return rc;
+                return launch_finish<T>(p, ws, wdD, wdb, stream);
+            }
         }
     }
     static LdsGate gate;
@@ -625,17 +616,12 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     return launch_finish<T>(p, ws, wdD, wdb, stream);
 }
 
-// variant table: (lanes per row, items per lane = waves per workgroup, states per LDS tile)
-//   0: 64 x 8 x 8,  8 states  (TC 512, 8 rows/WG, 64 KiB LDS)
-//   1: 64 x 4 x 4, 16 states  (TC 256, 4 rows/WG, 40 KiB LDS)  short sequences / few rows per group
-//   2: variant 0 walking two states at a time (96 KiB LDS, <= 256 VGPRs): grids of <= ~1 workgroup per CU
-//   3: variant 0 with <= 256 VGPRs (no spills; 2 waves per SIMD)
-//   4: 64 x 8 x 12 (12 rows/WG, 3 waves per SIMD, no spills): row counts that give <= 256 such workgroups
-//   5: 64 x 8 x 6  (6 rows/WG, no spills): 48-row groups at batch 8 = exactly 256 workgroups
-//   8: two states per pass in packed fp32, 12 rows/WG (130 KiB LDS, 3 waves per SIMD)     oss_scan_bwd_pair.h
-//   9: likewise, 8 rows/WG, all 16 states staged at once (<= 256 VGPRs)
-//  10: round-2 kernel, 12 rows/WG (128 KiB LDS)   11: 8 rows/WG   12: 6 rows/WG   13: 4 rows/WG (two workgroups per CU)
-static const int kBwdRows[] = {8, 4, 8, 8, 12, 6, 12, 8, 12, 8, 12, 8, 6, 4};
+// variant table (numbers kept from rounds 1-3; 0 and 2..9 -- the other round-1 row tiles and the packed two-states-per-pass
+// kernels, all measured slower than the round-2 kernel -- were removed in round 4 and now mean variant 1):
+//   1: round-1 kernel, 64 lanes x 4 items, 4 rows/WG, 16 states per LDS tile (TC 256, 40 KiB LDS): short sequences, few rows
+//      per group, dstate > 64 (the round-2 kernel keeps one lane per state) and the fallback when a launch would not fit LDS
+//  10: round-2 kernel (oss_scan_bwd_v2.h), 12 rows/WG (128 KiB LDS)   11: 8 rows/WG   12: 6 rows/WG   13: 4 rows/WG
+static const int kBwdRows[] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 12, 8, 6, 4};
 int scan_bwd_rows_per_wg(int variant) { return kBwdRows[(variant < 0 || variant > 13) ? 1 : variant]; }
 
 template <typename T>
@@ -655,20 +641,8 @@ static int scan_bwd_dispatch_(const oss_scan_bwd_params &p, int variant, int seg
         if (p.f.dstate > 64 || p.f.dt_rank < 1 || p.f.dt_rank > kMaxDtRank || !p.ddt || !p.ddt_weight) return OSS_ERR_SHAPE;
         if (variant < 10) variant = 13;
     }
-    if (variant >= 10 && p.f.dstate > 64) {   // the round-2 kernel keeps one lane per state: same-row-count round-1 kernel
-        static const int same_rows[] = {6, 3, 5, 1};
-        variant = same_rows[variant - 10];
-    }
+    if (variant >= 10 && p.f.dstate > 64) variant = 1;   // the round-2 kernel keeps one lane per state
     switch (variant) {
-        case 0: return launch_bwd<T, 64, 8, 8, 8, 1, 4>(p, stream, timer);
-        case 2: return launch_bwd<T, 64, 8, 8, 8, 2, 2>(p, stream, timer);
-        case 3: return launch_bwd<T, 64, 8, 8, 8, 1, 2>(p, stream, timer);
-        case 4: return launch_bwd<T, 64, 8, 12, 8, 1, 3>(p, stream, timer);
-        case 5: return launch_bwd<T, 64, 8, 6, 8, 1, 2>(p, stream, timer);
-        case 6: return launch_bwd<T, 64, 8, 12, 16, 1, 3>(p, stream, timer);   // variant 4 staging all 16 states at once
-        case 7: return launch_bwd<T, 64, 8, 8, 16, 1, 2>(p, stream, timer);    // variant 3 likewise
-        case 8: return launch_bwd_pair<T, 8, 12, 8, 3>(p, stream, timer);
-        case 9: return launch_bwd_pair<T, 8, 8, 16, 2>(p, stream, timer);
         case 10: return launch_bwd2<T, 12, 4, 3>(p, seg_req, stream, timer);
         case 11: return launch_bwd2<T, 8, 4, 2>(p, seg_req, stream, timer);
         case 12: return launch_bwd2<T, 6, 4, 2>(p, seg_req, stream, timer);

@@ -91,7 +91,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
     float *x_row = p.x + ((size_t)b * p.dim + d) * n_xchunks * 2 * N;
     const size_t hs_stride = lane_state_stride(L);
-    float *hs_line = (SEG != 1 && p.hs) ? p.hs + ((size_t)b * p.dim + d) * N * hs_stride : nullptr;
+    float *hs_line = (kBuildLaneStates && SEG != 1 && p.hs) ? p.hs + ((size_t)b * p.dim + d) * N * hs_stride : nullptr;
 
     // carries start at (h, P) = (0, 1); A is pre-scaled once (fwd_kernel.cuh:125-127)
     for (int idx = tid; idx < N * ROWS; idx += NT) {
@@ -247,7 +247,10 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
 template <typename T, int LPR, int I, int WAVES, bool FD = false>
 static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t stream) {
     if constexpr (!FD) {
-        if (p.dt_weight) return launch_fwd<T, LPR, I, WAVES, true>(p, seg_req, stream);
+        if (p.dt_weight) {
+            if constexpr (kBuildFusedDt) return launch_fwd<T, LPR, I, WAVES, true>(p, seg_req, stream);
+            else return OSS_ERR_SHAPE;   // this library was built without OSS_WITH_FUSED_DT
+        }
     }
     constexpr int ROWS = WAVES * (64 / LPR);
     constexpr int TC = LPR * I;
@@ -293,7 +296,8 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
 //   2: 16 x 16 x 4   (TC  256, 16 rows/WG)   fewest scan steps, needs many rows
 //   3: 64 x 16 x 8   (TC 1024,  8 rows/WG)
 //   4: 64 x 4  x 4   (TC  256,  4 rows/WG)   short sequences / few rows per group
-//   5: 64 x 8  x 12  (TC  512, 12 rows/WG), 6: 64 x 16 x 12 (TC 1024, 12 rows/WG): row counts that give <= 256 such workgroups
+//   6: 64 x 16 x 12  (TC 1024, 12 rows/WG): row counts that give <= 256 such workgroups
+//   (5 = 64 x 8 x 12 and 7 = 64 x 16 x 6 were never picked by scan_fwd_pick_variant: removed in round 4, the numbers now mean 4)
 template <typename T>
 int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream) {
     switch (variant) {
@@ -301,9 +305,7 @@ int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hi
         case 1: return launch_fwd<T, 32, 16, 8>(p, seg_req, stream);
         case 2: return launch_fwd<T, 16, 16, 4>(p, seg_req, stream);
         case 3: return launch_fwd<T, 64, 16, 8>(p, seg_req, stream);
-        case 5: return launch_fwd<T, 64, 8, 12>(p, seg_req, stream);   // 12 rows per workgroup: one workgroup per CU at 3072 rows
-        case 6: return launch_fwd<T, 64, 16, 12>(p, seg_req, stream);
-        case 7: return launch_fwd<T, 64, 16, 6>(p, seg_req, stream);
+        case 6: return launch_fwd<T, 64, 16, 12>(p, seg_req, stream);   // 12 rows per workgroup: one workgroup per CU at 3072 rows
         default: return launch_fwd<T, 64, 4, 4>(p, seg_req, stream);
     }
 }

@@ -51,6 +51,18 @@ void check_rc(int rc, const char *what) {
     }
 }
 
+// second line of defence inside the operators: the library the dynamic linker really bound (first scan call only)
+void abi_check_once() {
+    static const bool ok = [] {
+        TORCH_CHECK(oss_abi_version() == OSS_ABI_VERSION && oss_abi_struct_bytes(0) == sizeof(oss_scan_fwd_params) &&
+                        oss_abi_struct_bytes(1) == sizeof(oss_scan_bwd_params),
+                    "libvmambair_torch.so was compiled against another revision of include/vmambair_oss.h than libvmambair_oss.so "
+                    "(ABI ", OSS_ABI_VERSION, " vs ", oss_abi_version(), "): rebuild both with __graft_entry__.build()");
+        return true;
+    }();
+    (void)ok;
+}
+
 struct Dims { int64_t batch, dim, seqlen, dstate, n_groups; };
 
 // cus/selective_scan.cpp:165-215 (same order of checks)
@@ -158,6 +170,8 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
     }
     Tensor x = at::empty({d.batch, d.dim, (int64_t)n_chunks, 2 * d.dstate}, u.options().dtype(at::kFloat));
     OptTensor hs;
+    TORCH_CHECK(!want_hs || (oss_scan_features() & OSS_FEATURE_LANE_STATES),
+                "want_hs: libvmambair_oss.so was built without the opt-in feature 'lane_states' (VMAMBAIR_BUILD_FEATURES)");
     if (want_hs)
         hs = at::empty({(int64_t)oss_scan_lane_state_floats((int)d.batch, (int)d.dim, (int)d.seqlen, (int)d.dstate)},
                        u.options().dtype(at::kFloat));
@@ -175,6 +189,7 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
         P.workspace_bytes = (size_t)ws.numel() * 4;
     }
     hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    abi_check_once();
     check_rc(oss_scan_fwd(&P, io_of(u), reinterpret_cast<oss_stream_t>(stream)), "oss_scan_fwd");
     if (want_hs) return {out, x, *hs};
     return {out, x};
@@ -266,11 +281,20 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
     P.dout_row_mod = (int)dout_row_mod;
     P.dBC_group_stride = into ? dbc_into->stride(1) : 0;
     hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    abi_check_once();
     check_rc(oss_scan_bwd(&P, io_of(u), reinterpret_cast<oss_stream_t>(stream)), "oss_scan_bwd");
     return {du, ddelta, dA, dB, dC, dD, dbias, ddtw};
 }
 
 }  // namespace
+
+// what THIS translation unit was compiled against (vmambair_amd/_host.py compares with the C-ABI library's own values before
+// it routes a single call through here: a host library left over from an older include/vmambair_oss.h fills structs the
+// kernels would misread)
+extern "C" int vmambair_host_abi_version(void) { return OSS_ABI_VERSION; }
+extern "C" size_t vmambair_host_struct_bytes(int which) {
+    return which == 0 ? sizeof(oss_scan_fwd_params) : which == 1 ? sizeof(oss_scan_bwd_params) : 0;
+}
 
 TORCH_LIBRARY(vmambair_host, m) {
     m.def("scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, bool delta_softplus, "

@@ -16,7 +16,7 @@ cus/selective_scan.cpp:174).
 """
 from .. import _capi  # noqa: F401
 from . import _common, channel, core, dwconv, ffn, layernorm, pointwise, scan  # noqa: F401
-from ._common import (WgradTable, flush_wgrads, pending_wgrad_table_bytes, pending_wgrads, _keep_operands,  # noqa: F401
+from ._common import (WGRAD_STATS, WgradTable, flush_wgrads, pending_wgrad_table_bytes, pending_wgrads, _keep_operands,  # noqa: F401
                       FinishTable, _DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr,  # noqa: F401
                       deferred_finishes, flush_finishes, orphaned_deferred_outputs, pending_finish_chunks, scan_chunk,
                       PairGrad, split_halves, wgrad_side_stream)

@@ -48,17 +48,32 @@ _DEFER_OUTS: Optional[list] = None
 #: the 1x1-conv / projection weight-gradient products are only RECORDED by the library and ``flush_wgrads`` runs all of them as
 #: one grouped launch at the end of the backward (include/vmambair_oss.h: oss_set_defer_wgrad).
 DEFER_WGRADS = os.environ.get("VMAMBAIR_DEFER_WGRAD", "1") == "1"
+#: A recorded product keeps BOTH of its operands (the incoming gradient dy and the saved activation) alive until the grouped
+#: launch is queued, i.e. they are no longer released as the backward walks up the net.  The bytes so held are bounded: when
+#: they pass this budget the products recorded so far run as one grouped launch right away (``wgrad_flusher`` of
+#: ``deferred_finishes``) and their operands are released -- a handful of grouped launches instead of one keeps nearly all of
+#: the gain.  4 GiB never triggers at the headline shapes (batch 8: ~2.6 GB held); 0 = unbounded.
+WGRAD_KEEP_BUDGET = int(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "4096")) * (1 << 20))
+_WGRAD_OPERANDS: Optional[list] = None
+_WGRAD_STORAGES: Optional[set] = None
+_WGRAD_HELD = 0            # bytes of distinct storages held for recorded products since the last grouped launch
+_WGRAD_FLUSHER = None
+WGRAD_STATS = {"held_bytes_max": 0, "budget_flushes": 0}   # since the last ``deferred_finishes`` entry (bench.py, tests)
 
 
 @contextlib.contextmanager
-def deferred_finishes(wgrads: Optional[bool] = None):
+def deferred_finishes(wgrads: Optional[bool] = None, wgrad_flusher=None):
     """Defer every partial-sum finishing launch issued inside the context -- and (``wgrads``, default ``DEFER_WGRADS``) the
     weight-gradient products themselves; the caller MUST call ``flush_wgrads`` and then ``flush_finishes`` (with the context
-    still open) before any weight gradient is read."""
-    global _DEFER_KEEP, _DEFER_OUTS
+    still open) before any weight gradient is read.  ``wgrad_flusher``: a callable that runs ``flush_wgrads`` on a table of the
+    caller's; it is called in the middle of the backward whenever the operands held for recorded products pass
+    ``WGRAD_KEEP_BUDGET`` (without one the budget is not enforced)."""
+    global _DEFER_KEEP, _DEFER_OUTS, _WGRAD_OPERANDS, _WGRAD_STORAGES, _WGRAD_HELD, _WGRAD_FLUSHER
     lib = _capi.load()
     assert _DEFER_KEEP is None, "deferred_finishes() does not nest"
     _DEFER_KEEP, _DEFER_OUTS = [], []
+    _WGRAD_OPERANDS, _WGRAD_STORAGES, _WGRAD_HELD, _WGRAD_FLUSHER = [], set(), 0, wgrad_flusher
+    WGRAD_STATS.update(held_bytes_max=0, budget_flushes=0)
     lib.oss_set_defer_finish(1)
     lib.oss_set_defer_wgrad(1 if (DEFER_WGRADS if wgrads is None else wgrads) else 0)
     try:
@@ -66,13 +81,34 @@ def deferred_finishes(wgrads: Optional[bool] = None):
     finally:
         lib.oss_set_defer_finish(0)
         lib.oss_set_defer_wgrad(0)
-        _DEFER_KEEP = _DEFER_OUTS = None
+        _DEFER_KEEP = _DEFER_OUTS = _WGRAD_OPERANDS = _WGRAD_STORAGES = _WGRAD_FLUSHER = None
 
 
 def _keep_operands(*tensors) -> None:
     """operands of a RECORDED (not yet launched) weight-gradient product: alive until ``flush_wgrads`` has queued the launch"""
-    if _DEFER_KEEP is not None:
-        _DEFER_KEEP.extend(t for t in tensors if t is not None)
+    global _WGRAD_HELD
+    if _WGRAD_OPERANDS is None:
+        return
+    for t in tensors:
+        if t is None:
+            continue
+        _WGRAD_OPERANDS.append(t)
+        st = t.untyped_storage()
+        if st.data_ptr() not in _WGRAD_STORAGES:
+            _WGRAD_STORAGES.add(st.data_ptr())
+            _WGRAD_HELD += st.nbytes()
+    WGRAD_STATS["held_bytes_max"] = max(WGRAD_STATS["held_bytes_max"], _WGRAD_HELD)
+    if WGRAD_KEEP_BUDGET and _WGRAD_FLUSHER is not None and _WGRAD_HELD > WGRAD_KEEP_BUDGET:
+        WGRAD_STATS["budget_flushes"] += 1
+        _WGRAD_FLUSHER()   # -> flush_wgrads(table): queues the grouped launch and releases the operands
+
+
+def _release_operands() -> None:
+    global _WGRAD_HELD
+    if _WGRAD_OPERANDS is not None:
+        _WGRAD_OPERANDS.clear()
+        _WGRAD_STORAGES.clear()
+        _WGRAD_HELD = 0
 
 
 def _keep(scratch: torch.Tensor, *outs) -> None:
@@ -146,6 +182,7 @@ def flush_wgrads(table: WgradTable) -> None:
         if not capturing:
             table.copied = torch.cuda.Event()
             table.copied.record()
+    _release_operands()   # the launch that reads them is queued on this stream: stream order protects the memory
 
 
 def pending_finish_chunks() -> int:

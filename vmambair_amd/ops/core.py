@@ -34,7 +34,10 @@ FUSED_DT = os.environ.get("VMAMBAIR_FUSED_DT", "0") == "1"
 
 def fused_dt_supported(dtype: torch.dtype, B: int, D: int, Cc: int, R: int, N: int, L: int) -> bool:
     """delta computed inside the scan kernels: 16-bit I/O, dt_rank <= 8, L >= 512 (include/vmambair_oss.h)"""
-    return FUSED_DT and bool(_capi.load().oss_scan_fused_dt_ok(_DT[dtype], B, D, Cc, R, N, L))
+    if not FUSED_DT:
+        return False
+    _capi.require_feature(_capi.FEATURE_FUSED_DT, "VMAMBAIR_FUSED_DT=1 / ops.core.FUSED_DT")   # never a silent fall-back
+    return bool(_capi.load().oss_scan_fused_dt_ok(_DT[dtype], B, D, Cc, R, N, L))
 
 
 def _dims_core(x, x_proj_weight, dt_projs_weight, A_logs):
@@ -165,6 +168,8 @@ def ss2d_core_fwd(x: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight:
     xdbl, dts = proj_fwd(x2, x_proj_weight, dt_projs_weight, want_dts=not fused)
     # fused: delta = dt_projs_weight . xdbl[:, :, :R] is evaluated inside the scan kernels (dts stays empty)
     # lane states only when a backward will follow (they cost one more store per 8 steps and state) and never in the fused form
+    if want_hs and _scan.LANE_STATES:
+        _capi.require_feature(_capi.FEATURE_LANE_STATES, "VMAMBAIR_SCAN_LANE_STATES=1 / ops.scan.LANE_STATES")
     want_hs = bool(want_hs) and _scan.LANE_STATES and not fused and N <= 64 and L > 256
     res = selective_scan_fwd(x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N],
                              xdbl[:, :, R + N:], Ds.detach().float(), dt_bias.detach().float().reshape(-1), True, 1, 2,

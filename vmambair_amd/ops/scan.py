@@ -111,6 +111,10 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling; ``dt_weight``: ``delta`` is the rank-R factor and the
     kernels evaluate delta themselves -- see include/vmambair_oss.h.  ``want_hs``: -> ``[out, x, hs]`` with the lane states
     (the state entering every 8-step block) for ``selective_scan_bwd(..., hs=hs)``."""
+    if want_hs:
+        _capi.require_feature(_capi.FEATURE_LANE_STATES, "selective_scan_fwd(want_hs=True)")
+    if dt_weight is not None:
+        _capi.require_feature(_capi.FEATURE_FUSED_DT, "selective_scan_fwd(dt_weight=...)")
     host = _host.ops()
     if host is not None and u.is_cuda:   # compiled boundary (csrc_host/oss_torch_host.cpp): same checks, same C ABI
         return list(host.scan_fwd(u, delta, A, B, C, D, delta_bias, bool(delta_softplus),

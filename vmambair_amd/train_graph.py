@@ -130,6 +130,7 @@ class GraphedTrainStep:
             self._shadow_tmp = [torch.zeros_like(m) for m in self._masters]
         self.ftables = [None] * self.nmicro
         self.wtables = [None] * self.nmicro
+        self.wgrad_stats = None   # of the last deferred backward: bytes held for recorded products, grouped launches (ops/_common.py)
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
@@ -145,7 +146,24 @@ class GraphedTrainStep:
             with _ops.wgrad_side_stream(self.wside):
                 loss.backward()
             return
-        with _ops.deferred_finishes():
+        tables = self.wtables[slot] if self.wtables[slot] is not None else []
+        self.wtables[slot] = tables
+        used = [0]
+
+        def flush_wgrads_now():
+            # one pinned table per grouped launch of a backward: a captured copy node reads its host buffer at REPLAY time,
+            # so two launches of one graph must not share one
+            nb = _ops.pending_wgrad_table_bytes()
+            k = used[0]
+            if k == len(tables):
+                tables.append(None)
+            if tables[k] is None or tables[k].capacity < nb:
+                assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient tables must exist before the capture"
+                tables[k] = _ops.WgradTable(self.device, nb)
+            _ops.flush_wgrads(tables[k])
+            used[0] = k + 1
+
+        with _ops.deferred_finishes(wgrad_flusher=flush_wgrads_now if self.wside is None else None):
             with _ops.wgrad_side_stream(self.wside):
                 loss.backward()
             if self.wside is not None:
@@ -154,12 +172,9 @@ class GraphedTrainStep:
                 lost = _ops.orphaned_deferred_outputs(leaves)
                 if lost:
                     raise RuntimeError(f"{lost} deferred weight gradients were copied before the flush (see ops.py CONTRACT)")
-            if _ops.pending_wgrads():   # the recorded weight-gradient products, as ONE grouped launch (ops/_common.py)
-                nb = _ops.pending_wgrad_table_bytes()
-                if self.wtables[slot] is None or self.wtables[slot].capacity < nb:
-                    assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient table must exist before the capture"
-                    self.wtables[slot] = _ops.WgradTable(self.device, nb)
-                _ops.flush_wgrads(self.wtables[slot])
+            if _ops.pending_wgrads():   # the recorded weight-gradient products, as ONE grouped launch (ops/_common.py) --
+                flush_wgrads_now()      # or the last of a few, when the operands held passed WGRAD_KEEP_BUDGET on the way
+            self.wgrad_stats = dict(_ops.WGRAD_STATS, grouped_launches=used[0])
             n = _ops.pending_finish_chunks()
             if self.ftables[slot] is None or self.ftables[slot].capacity < n:   # first (eager, warm-up) step: sizes the table
                 assert not torch.cuda.is_current_stream_capturing(), "the finish table must exist before the capture"
