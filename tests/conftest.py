@@ -58,3 +58,37 @@ def assert_close(a, b, rtol, atol, what=""):
         raise AssertionError(f"{what}: {int(bad.sum())}/{a.numel()} elements off; worst |diff|="
                              f"{diff.flatten()[i].item():.3e} at flat index {i} (got {a.flatten()[i].item():.6e}, "
                              f"want {b.flatten()[i].item():.6e}), max|ref|={b.abs().max().item():.3e}")
+
+
+def reseed_parameters(net, seed=0):
+    """Overwrite every parameter with values that depend only on (seed, parameter NAME, shape): the reference's arch (inside
+    tests/golden/make_golden.py, build container) and this repo's mirror (here and on the GPU box) then hold identical weights
+    without a 48 MB state dict in the fixture.  CPU generator, so the values do not depend on the device either.
+    Scales follow what the reference's initialisers produce: fan-in uniform weights, A_log in [0, log 16], dt biases whose
+    softplus is a small step, norm / skip scales around 1."""
+    import math
+    import zlib
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7fffffff)
+            r = torch.rand(p.shape, generator=g, dtype=torch.float32)
+            leaf = name.rsplit(".", 1)[-1]
+            if "A_log" in leaf:
+                v = r * math.log(16.0)
+            elif leaf in ("dt_projs_bias", "dt_projs_biasc") or leaf.startswith("dt_") and leaf.endswith("bias"):
+                v = -5.0 + 3.0 * r
+            elif leaf.startswith("Ds"):
+                v = 0.5 + r
+            elif p.dim() == 1:
+                v = (0.5 + r) if leaf == "weight" else 0.2 * (r - 0.5)
+            else:
+                fan_in = p.shape[-1] if ("projs_weight" in leaf or "proj_weight" in leaf) else p[0].numel()
+                v = (2.0 * r - 1.0) * math.sqrt(3.0 / max(1, fan_in))
+            p.copy_(v.to(p.dtype))
+    return net
+
+
+def seeded_tensor(tag, shape, seed=0):
+    import zlib
+    g = torch.Generator().manual_seed((zlib.crc32(tag.encode()) ^ (seed * 2654435761)) & 0x7fffffff)
+    return torch.rand(shape, generator=g, dtype=torch.float32)

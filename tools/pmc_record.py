@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 IO = {"float": "f32", "oss::f16_t": "f16", "oss::bf16_t": "bf16"}
 BWD2 = {12: 10, 8: 11, 6: 12, 4: 13}
-FWD = {(64, 8, 8): 0, (32, 16, 8): 1, (16, 16, 4): 2, (64, 16, 8): 3, (64, 4, 4): 4, (64, 8, 12): 5, (64, 16, 12): 6, (64, 16, 6): 7}
+FWD = {(64, 8, 8): 0, (32, 16, 8): 1, (16, 16, 4): 2, (64, 16, 8): 3, (64, 4, 4): 4, (64, 16, 12): 6}
 
 
 def key_of(name):
@@ -60,6 +60,14 @@ def main():
     lib = _capi.load()
     fetch = read(os.path.join(ROOT, "gpurun_out", "pmc_FETCH_SIZE.txt"))
     write = read(os.path.join(ROOT, "gpurun_out", "pmc_WRITE_SIZE.txt"))
+    prev = {}
+    if os.path.exists(out):   # several shapes go into one record (one call of this script per shape), as long as the build is the same
+        try:
+            prev = json.load(open(out))
+        except ValueError:
+            prev = {}
+        if prev.get("_build_id") != lib.oss_scan_build_id().decode():
+            prev = {}
     rec = {"_build_id": lib.oss_scan_build_id().decode(), "_library": lib.oss_version().decode(),
            "_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic.sh), average per dispatch at "
                        + note + "; KiB as reported -> bytes, FETCH_SIZE x 2 (gfx950: 128-B read requests tallied as 64 B, "
@@ -92,7 +100,11 @@ def main():
                 e["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * wps / c["SQ_WAVE_CYCLES"], 4)
         if c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
+        e["shape"] = note
         rec[k] = e
+    for k, v in prev.items():   # entries of the shapes recorded before
+        if not k.startswith("_") and k not in rec:
+            rec[k] = v
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec)[:600])
 

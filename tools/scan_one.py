@@ -10,8 +10,10 @@ from vmambair_amd import ops  # noqa: E402
 
 dev = "cuda:0"
 torch.manual_seed(0)
-B, D, L, N = 8, 96, 4096, 16
-dt = torch.bfloat16
+# SHAPE="B,D,L" DTYPE=bf16|f16|f32: other calls of the trees (Deraining level 0: 4,48,16384; RealSR tile: 1,96,25600 f16)
+B, D, L = (int(v) for v in os.environ.get("SHAPE", "8,96,4096").split(","))
+N = 16
+dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[os.environ.get("DTYPE", "bf16")]
 x2 = torch.randn(B, 2 * D, L, device=dev).to(dt)
 delta = (torch.randn(B, 4 * D, L, device=dev) * 0.5).to(dt)
 A_log = torch.log(torch.arange(1, N + 1, device=dev).float()).repeat(4 * D, 1).contiguous()

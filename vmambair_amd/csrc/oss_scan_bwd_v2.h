@@ -105,6 +105,28 @@ constexpr bool kV2HcvEarly = true;
 #else
 constexpr bool kV2HcvEarly = false;
 #endif
+// round 4: (a) the slab in a bank-conflict-free image (SlabQ below) and (b) the chunk-edge factor exp2(A delta_first) of all
+// states as ONE v_exp_f32 per chunk (lane n = state n) instead of one per state pass.  OSS_EXP_V2_OLD_SLAB / _OLD_AEDGE
+// restore the round-2 forms for A-B timing (tools/build_experiment.sh).
+#ifdef OSS_EXP_V2_OLD_SLAB
+constexpr bool kV2SlabQ = false;
+#else
+constexpr bool kV2SlabQ = true;
+#endif
+#ifdef OSS_EXP_V2_OLD_AEDGE
+constexpr bool kV2EdgeLanes = false;
+#else
+constexpr bool kV2EdgeLanes = true;
+#endif
+// SlabQ: one row's dB (or dC) terms of one state, 512 scan positions = 64 lanes x 2 quads.  The round-2 image was time order
+// (lane p wrote its quads at floats 8p and 8p + 4: a 32-byte lane stride, so a 16-lane phase of a ds_write_b128 covered only
+// half of the 64 banks, two-way conflicts on every slab write -- SQ_LDS_BANK_CONFLICT 31 % of the LDS cycles,
+// profiles/r03_pmc_sq_scan.txt).  Now quad k of lane p sits at float k * kSlabK + 4 p: consecutive lanes write consecutive
+// 16-byte pieces; kSlabK = 256 + 32 puts the second quads half a bank sweep away from the first ones, so that the summing
+// lanes -- lane s reads quad (s & 1) of position base + (s >> 1), i.e. scan positions base * 8 + 4 s: the partial rows still
+// leave as fully coalesced 16-byte stores -- are conflict-free too.
+constexpr int kSlabK = 288;            // floats between the two quads of a lane
+constexpr int kSlabA = 2 * kSlabK;     // floats per (row, dB | dC) array
 // SEG: time-segmented launch (workgroup = (batch, group, row tile, SEGMENT of cps chunks)) for calls whose row-tile grid
 // leaves CUs idle.  The reference walks a row's chunks last to first inside one block (cus/selective_scan_bwd_kernel.cuh:
 // 120-125,184); here a segment starts from (a) the forward state saved in x -- free, x holds one every 256 steps -- and
@@ -141,8 +163,10 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sT = smem;                          // [2 buffers][B | C][NBB][TC]  tile_off layout
-    float *slab = smem + 2 * 2 * NBB * TC;     // [2][ROWS][2][TC]  per-row dB / dC terms of one state, time order; two buffers
-    float *sW = slab + 2 * ROWS * 2 * TC;      // FD: [ROWS][kMaxDtRank] dt weights of the workgroup's rows (zero-padded)
+    constexpr bool SQ = kV2SlabQ && !FD;       // the fused-delta form also parks its ddelta rows in the slab, in time order
+    constexpr int SA = SQ ? kSlabA : TC;       // floats per (row, dB | dC) array of the slab
+    float *slab = smem + 2 * 2 * NBB * TC;     // [2][ROWS][2][SA]  per-row dB / dC terms of one state; two buffers
+    float *sW = slab + 2 * ROWS * 2 * SA;      // FD: [ROWS][kMaxDtRank] dt weights of the workgroup's rows (zero-padded)
     float *sH = sW;                            // HS: [2 buffers][WAVES][NBB][64] lane states of this wave's row (never with FD)
 
     const oss_scan_fwd_params &f = p.f;
@@ -251,6 +275,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
         A2v = (f.a_log_form ? -__expf(av) : av) * kLog2e;
     }
     float dln_c = 0.f;  // delta of the first step of the later chunk (wave-uniform); 0 past the end
+    float aev = 1.f;    // lane n: exp2(A_n * dln_c), a_{t+1} across the chunk edge (kV2EdgeLanes)
 
     float dD_acc = 0.f, db_acc = 0.f;
     float dWv = 0.f;   // FD: lane r = gradient of dt_weight[d, r]
@@ -381,9 +406,10 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
         }
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
         const float Sshift = S - dl[0] + dln_lane;  // sum of delta over steps tl+1 .. tl+I
+        if constexpr (kV2EdgeLanes) aev = exp2_hw(dln_c * A2v);
         // lane-dependent parts of the slab-sum addresses: a half wave = 32 groups of 4 scan positions x one half of the rows
         const int sl = SPLIT ? (lane & 31) : lane;
-        const float *sum_src = slab + 4 * sl + (SPLIT ? (lane >> 5) * (HR * 2 * TC) : 0);
+        const float *sum_src = slab + (SQ ? (sl & 1) * kSlabK + 4 * (sl >> 1) : 4 * sl) + (SPLIT ? (lane >> 5) * (HR * 2 * SA) : 0);
         float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * sl) : (t0 + 4 * sl));
 
         // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
@@ -423,7 +449,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
                 }
             }
             // ---- reverse recurrence: element (a_{t+1}, C_t g_t)   (bwd_kernel.cuh:170-193)
-            const float a_edge = exp2_hw(dln_c * A2);
+            const float a_edge = kV2EdgeLanes ? lane_get(aev, n) : exp2_hw(dln_c * A2);
             const float a_nl = shift_from_next_lane(a[0], a_edge, seg_last);
             float dloc = 0.f;
 #pragma unroll
@@ -440,7 +466,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
             float dh = segment_mirror<LPR>(dex_m, lane);              // dh entering this lane from the right
             dhcv = lane_set(dhcv, lane, n, lane_get(dfull_m, 63));    // mirrored-last lane = first lane in time
             // ---- reverse pass with gradients (bwd_kernel.cuh:196-206); p_t = a_t h_{t-1}
-            float *sb = slab + ((par * ROWS + wrow) * 2) * TC + pos * I;
+            float *sb = slab + ((par * ROWS + wrow) * 2) * SA + (SQ ? pos * 4 : pos * I);
             float dA_acc = 0.f;
 #pragma unroll
             for (int k = I / 4 - 1; k >= 0; --k) {
@@ -460,8 +486,8 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
                     vC[j] = gg[i] * hh[i];
                 }
 #ifndef OSS_EXP_V2_NOSLAB   // (OSS_EXP_*: timing experiments only, tools/build_experiment.sh -- results are wrong)
-                *reinterpret_cast<f32x4 *>(sb + 4 * k) = f32x4{vB[0], vB[1], vB[2], vB[3]};
-                *reinterpret_cast<f32x4 *>(sb + TC + 4 * k) = f32x4{vC[0], vC[1], vC[2], vC[3]};
+                *reinterpret_cast<f32x4 *>(sb + (SQ ? kSlabK : 4) * k) = f32x4{vB[0], vB[1], vB[2], vB[3]};
+                *reinterpret_cast<f32x4 *>(sb + SA + (SQ ? kSlabK : 4) * k) = f32x4{vC[0], vC[1], vC[2], vC[3]};
 #else
                 if (vB[0] + vC[3] == 12345.678f) sb[0] = vB[1] + vC[2];
 #endif
@@ -481,11 +507,12 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
             if (rw < RW) {
                 for (int task = rw; task < NTASK; task += RW) {
                     const int arr = task / (NTASK / 2), off = (task % (NTASK / 2)) * (TC / (NTASK / 2));
-                    const float *src = sum_src + (size_t)buf * ROWS * 2 * TC + arr * TC + off;
+                    // SlabQ: the task's positions start at off / 8, two quads per position -> off / 2 floats into the image
+                    const float *src = sum_src + (size_t)buf * ROWS * 2 * SA + arr * SA + (SQ ? off / 2 : off);
                     f32x4 acc = *reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
                     for (int r = 1; r < HR; ++r) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * TC);
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * 2 * SA);
                         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                     }
                     if constexpr (SPLIT) {

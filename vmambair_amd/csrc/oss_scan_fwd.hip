@@ -63,13 +63,27 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     const int L = p.seqlen, N = p.dstate;
     const int rows_per_group = p.dim / p.n_groups;
     const int tiles_per_group = (rows_per_group + ROWS - 1) / ROWS;
-    int bid = blockIdx.x;
-    const int tile = bid % tiles_per_group; bid /= tiles_per_group;
-    int seg = 0;
-    if constexpr (SEG != 0) {
-        const int ns = SEG == 1 ? sg.n_seg - 1 : sg.n_seg;   // the last segment has no successor: no local pass
-        seg = bid % ns; bid /= ns;
+    // workgroup -> (batch, group, [segment,] row tile).  The row tiles of one (batch, group, segment) stage the same B / C rows;
+    // consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so when the number of such sets divides
+    // by 8 the tiles of a set get ids with the same residue mod 8 and share ONE L2's copy of B / C instead of pulling eight
+    // (as the backward does, oss_scan_bwd_v2.h; round 3 measured FETCH = 2.5 x the input bytes for this kernel at
+    // u:(8,384,4096): tile = id % 8 dealt a group's eight tiles to the eight XCDs).  Speed only: nothing depends on placement.
+    int bid = blockIdx.x, tile;
+    const int ns = SEG == 0 ? 1 : (SEG == 1 ? sg.n_seg - 1 : sg.n_seg);   // the last segment has no successor: no local pass
+#ifdef OSS_EXP_FWD_NO_XCD   // (OSS_EXP_*: A-B timing builds only, tools/build_experiment.sh)
+    constexpr bool kXcdOrder = false;
+#else
+    constexpr bool kXcdOrder = true;
+#endif
+    if (kXcdOrder && (p.batch * p.n_groups * ns) % 8 == 0) {
+        const int xcd = bid & 7, s_ = bid >> 3;
+        tile = s_ % tiles_per_group;
+        bid = (s_ / tiles_per_group) * 8 + xcd;
+    } else {
+        tile = bid % tiles_per_group; bid /= tiles_per_group;
     }
+    int seg = 0;
+    if constexpr (SEG != 0) { seg = bid % ns; bid /= ns; }
     const int g = bid % p.n_groups;
     const int b = bid / p.n_groups;
     const int row_in_group = tile * ROWS + wrow;
