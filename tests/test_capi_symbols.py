@@ -131,11 +131,12 @@ def test_shape_rules_of_the_fused_kernels_are_pure_host_queries():
     """which shapes the round-3 fused forms take (no GPU needed: the rules live in the library, the Python layer only asks)"""
     lib = _capi.load()
     BF16, F16, F32 = 2, 1, 0
-    # depth-wise conv + silu (1 plane per workgroup) / + gelu gate (2 planes): 16-bit, W % 8 == 0 with W / 8 dividing 64, planes in LDS
+    # depth-wise conv + silu (1 plane per workgroup) / + gelu gate (2 planes): 16-bit, W % 8 == 0, planes in LDS
     assert lib.oss_dwconv3x3_fused_ok(BF16, 64, 64, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F16, 128, 128, 2) == 1
     assert lib.oss_dwconv3x3_fused_ok(F32, 64, 64, 1) == 0          # fp32 I/O stays on the separate kernels
-    assert lib.oss_dwconv3x3_fused_ok(BF16, 160, 160, 1) == 0       # RealSR's 160-wide tiles: 20 lane groups do not tile a wave
-    assert lib.oss_dwconv3x3_fused_ok(BF16, 16, 24, 2) == 0
+    # (round 4) rows whose W / 8 lane groups straddle waves are taken too (EDGE instantiations): RealSR's 160-wide tiles, W = 24
+    assert lib.oss_dwconv3x3_fused_ok(F16, 160, 160, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F16, 160, 160, 2) == 1
+    assert lib.oss_dwconv3x3_fused_ok(BF16, 16, 24, 2) == 1 and lib.oss_dwconv3x3_fused_ok(BF16, 16, 20, 2) == 0
     assert lib.oss_dwconv3x3_fused_ok(BF16, 256, 256, 1) == 1 and lib.oss_dwconv3x3_fused_ok(BF16, 256, 256, 2) == 0   # 129 / 258 KiB
     assert lib.oss_dwconv3x3_fused_ok(BF16, 64, 64, 3) == 0
     # LayerNorm inside the 1x1 convolution: cin % 16 == 0, cin <= 192, pixels % 128 == 0

@@ -25,7 +25,9 @@ def ref(x, w, b, dy):
 @pytest.mark.parametrize("shape", [(2, 48, 64, 64), (1, 254, 16, 24), (3, 5, 7, 9), (2, 96, 12, 10), (1, 3, 1, 1), (2, 8, 33, 4),
                                    # 16-bit I/O: the 8-pixels-per-lane kernels (W / 8 lanes per row = 4, 1, 16, 64, 2 with a ragged
                                    # last workgroup) next to widths they must leave to the 4-pixel kernels (24, 12, 4)
-                                   (2, 16, 32, 32), (3, 8, 8, 8), (1, 4, 6, 128), (1, 2, 5, 512), (2, 5, 37, 16)])
+                                   (2, 16, 32, 32), (3, 8, 8, 8), (1, 4, 6, 128), (1, 2, 5, 512), (2, 5, 37, 16),
+                                   # (round 4) rows that straddle waves: W / 8 = 20, 18, 40, 5
+                                   (1, 6, 24, 160), (2, 3, 13, 144), (1, 2, 9, 320), (2, 4, 11, 40)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_dwconv_matches_torch(dtype, shape, has_bias):
     torch.manual_seed(0)
@@ -235,8 +237,10 @@ def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
 
 
 # ---- fused forms of oss_dwconv.hip: the convolution is never stored, the backward is one launch ---------------------------
+# (round 4) widths whose W / 8 lane groups do not tile a wave -- 24 (3 groups), 160 (20: the RealSR tiles), 144 (18: their edge
+# tiles), 192 / 320 (the Deraining tree's progressive patches) -- take the EDGE instantiations: rows straddle waves
 FUSED_SHAPES = [(2, 12, 64, 64), (1, 6, 32, 32), (3, 4, 16, 16), (2, 8, 8, 8), (1, 2, 128, 128), (2, 4, 5, 512), (2, 6, 37, 16),
-                (1, 254, 16, 64)]
+                (1, 254, 16, 64), (1, 4, 16, 24), (1, 6, 160, 160), (2, 4, 144, 160), (1, 4, 9, 144), (1, 2, 48, 192), (1, 2, 7, 320)]
 
 
 @pytest.mark.parametrize("shape", FUSED_SHAPES)
@@ -333,8 +337,8 @@ def test_fused_conv_gelu_gate(shape, dt, has_bias):
 
 
 def test_shapes_the_fused_forms_leave_to_the_separate_kernels():
-    """fp32 I/O, widths whose lane groups do not tile a wave, planes beyond the LDS: fused_ok says no and the nodes fall back"""
-    for shape, dt, planes in (((1, 4, 16, 16), torch.float32, 1), ((1, 4, 16, 24), torch.bfloat16, 1), ((1, 4, 9, 12), torch.bfloat16, 2),
+    """fp32 I/O, widths that are not a multiple of 8 pixels, planes beyond the LDS: fused_ok says no and the nodes fall back"""
+    for shape, dt, planes in (((1, 4, 16, 16), torch.float32, 1), ((1, 4, 16, 20), torch.bfloat16, 1), ((1, 4, 9, 12), torch.bfloat16, 2),
                               ((1, 2, 512, 512), torch.bfloat16, 2)):
         assert not ops.dwconv.fused_ok(torch.empty(shape, dtype=dt, device=DEV), planes)
     conv = torch.nn.Conv2d(8, 8, 3, padding=1, groups=8, bias=False).to(DEV)

@@ -10,6 +10,7 @@
 #include <initializer_list>
 #include "oss_device.h"
 #include "oss_host.h"
+#include "oss_stencil.h"
 
 namespace oss {
 
@@ -103,37 +104,8 @@ oss_dwconv3x3_kernel(const T *__restrict__ x, const float *__restrict__ w, const
     }
 }
 
-// ---- 16-bit I/O, 8 pixels per lane ------------------------------------------------------------------------------
-// One 16-byte access per lane and image row, and the two halo pixels of a lane's 8-pixel group come from the
-// neighbouring lanes by DPP (wave_shr / wave_shl) instead of two more (2-byte) loads: 3 load instructions per 8 outputs
-// against 9 per 4 in the kernel above, which is what bounds it (2-byte-per-lane global accesses move 128 B per wave
-// instruction on gfx950).  Needs W % 8 == 0 with W / 8 (lanes per image row) dividing 64, so that a row's groups never
-// straddle a wave, and 16-byte aligned planes.
-template <typename T>
-__device__ __forceinline__ void load8(const T *p, float (&v)[8]) {
-    const u32x4 q = *reinterpret_cast<const u32x4 *>(p);
-    unpack2<T>(q.x, v[0], v[1]); unpack2<T>(q.y, v[2], v[3]); unpack2<T>(q.z, v[4], v[5]); unpack2<T>(q.w, v[6], v[7]);
-}
-template <typename T>
-__device__ __forceinline__ void store8(T *p, const float (&v)[8]) {
-    *reinterpret_cast<u32x4 *>(p) = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
-}
-// v[0..9] = pixels w0-1 .. w0+8 of image row h + dy (zeros outside the image); every lane of the wave must call it
-template <typename T>
-__device__ __forceinline__ void row10(const T *plane, int h, int dy, int H, int W, int w0, bool first, bool last, float (&v)[10]) {
-    const int hh = h + dy;
-    const bool ok = hh >= 0 && hh < H;
-    float m[8];
-    u32x4 q = *reinterpret_cast<const u32x4 *>(plane + (int64_t)(ok ? hh : h) * W + w0);
-    if (!ok) q = u32x4{0u, 0u, 0u, 0u};   // a row outside the image: four selects on the packed words instead of eight on the values
-    unpack2<T>(q.x, m[0], m[1]); unpack2<T>(q.y, m[2], m[3]); unpack2<T>(q.z, m[4], m[5]); unpack2<T>(q.w, m[6], m[7]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j + 1] = m[j];
-    v[0] = shift_from_prev_lane(v[8], 0.f, first);
-    v[9] = shift_from_next_lane(v[1], 0.f, last);
-}
-
-template <typename T>
+// ---- 16-bit I/O, 8 pixels per lane: load8 / store8 / row10 of oss_stencil.h ------------------------------------------
+template <typename T, bool EDGE = false>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                           T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
@@ -158,7 +130,7 @@ oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, 
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
         float v[10];
-        row10<T>(xp, h, dy, H, W, w0, first, last, v);
+        row10<T, EDGE>(xp, h, dy, H, W, w0, first, last, v);
         const float k0 = k[(dy + 1) * 3], k1 = k[(dy + 1) * 3 + 1], k2 = k[(dy + 1) * 3 + 2];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -174,7 +146,7 @@ oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, 
 }
 
 // weight / bias gradient partials of one (channel, batch) plane, same access scheme
-template <typename T>
+template <typename T, bool EDGE = false>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_wgrad_wide_kernel(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part /*[B][C][10]*/,
                                 int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
@@ -213,7 +185,7 @@ oss_dwconv3x3_wgrad_wide_kernel(const T *__restrict__ x, const T *__restrict__ d
 #pragma unroll
         for (int dyy = -1; dyy <= 1; ++dyy) {
             float v[10];
-            row10<T>(xp, h, dyy, H, W, w0, first, last, v);
+            row10<T, EDGE>(xp, h, dyy, H, W, w0, first, last, v);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 float a = acc[(dyy + 1) * 3 + dx];
@@ -275,7 +247,7 @@ __device__ __forceinline__ void conv_rows(const float (&v)[3][10], const float *
 }
 
 // out[b, c] = gelu(conv(t[b, c])) * conv(t[b, c + Hd]);  grid (groups of 256 lanes, Hd, B)
-template <typename T>
+template <typename T, bool EDGE = false>
 __global__ void __launch_bounds__(256)
 oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
                       int Hd, int H, int W, int64_t tsb, int64_t tsc, int64_t osb, int64_t osc) {
@@ -292,10 +264,10 @@ oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, cons
     const bool first = cg == 0, last = cg == lpr - 1;
     float v[3][10], x1[8], x2[8];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) row10<T>(p1, h, r - 1, H, W, w0, first, last, v[r]);
+    for (int r = 0; r < 3; ++r) row10<T, EDGE>(p1, h, r - 1, H, W, w0, first, last, v[r]);
     conv_rows<T>(v, k1, b1, x1);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) row10<T>(p2, h, r - 1, H, W, w0, first, last, v[r]);
+    for (int r = 0; r < 3; ++r) row10<T, EDGE>(p2, h, r - 1, H, W, w0, first, last, v[r]);
     conv_rows<T>(v, k2, b2, x2);
     if (!live) return;
 #pragma unroll
@@ -310,7 +282,7 @@ oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, cons
 // MODE kDwSilu: one channel per workgroup, grid (C, B); dy is the gradient of silu(conv(x) + bias).
 // MODE kDwGate: channels c and c + Hd, grid (Hd, B); dy (B, Hd, H, W) is the gradient of gelu(x1) * x2.
 // dynamic LDS: NCH planes of (H + 2) rows of W elements of T (rows 0 and H + 1 stay zero: the padding of pass 2)
-template <typename T, int MODE>
+template <typename T, int MODE, bool EDGE = false>
 __global__ void __launch_bounds__(256, 4)   // 4 waves per SIMD = 4 workgroups per CU: the headline's 1016 gate workgroups in one round
 oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                const T *__restrict__ dy, T *__restrict__ dx, float *__restrict__ part /*[B][C][10]*/,
@@ -343,7 +315,7 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
             const T *xp = x + b * xsb + c * xsc;
             float v[3][10];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) row10<T>(xp, h, r - 1, H, W, w0, first, last, v[r]);
+            for (int r = 0; r < 3; ++r) row10<T, EDGE>(xp, h, r - 1, H, W, w0, first, last, v[r]);
             conv_rows<T>(v, w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
             __builtin_amdgcn_sched_barrier(0);   // one channel's rows at a time in registers
         }
@@ -403,6 +375,11 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
                 for (int j = 0; j < 8; ++j) vv[j + 1] = m[j];
                 vv[0] = shift_from_prev_lane(vv[8], 0.f, first);
                 vv[9] = shift_from_next_lane(vv[1], 0.f, last);
+                if constexpr (EDGE) {   // a row's groups straddle waves: the halo pixel across the wave edge comes from the LDS plane
+                    const T *rp = sp + (size_t)(h + r) * W + w0;
+                    if (lane == 0 && !first) vv[0] = to_f32(rp[-1]);
+                    if (lane == 63 && !last) vv[9] = to_f32(rp[8]);
+                }
                 const float k0 = w[c * 9 + 8 - r * 3], k1 = w[c * 9 + 7 - r * 3], k2 = w[c * 9 + 6 - r * 3];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -438,7 +415,7 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
 // the 8-pixel kernels apply when a row's W / 8 lane groups tile a wave and every plane / row start is 16-byte aligned
 template <typename T>
 static bool wide_ok(int W, std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
-    if (sizeof(T) != 2 || W % 8 != 0 || W > 512 || (64 % (W / 8)) != 0) return false;
+    if (sizeof(T) != 2 || W % 8 != 0 || W > 512) return false;   // (64 % (W / 8)) != 0: the EDGE instantiations
     for (const void *p : ptrs)
         if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
     for (int64_t st : strides)
@@ -555,7 +532,10 @@ static int dwconv_launch(const void *x, const float *w, const float *bias, void 
     if constexpr (sizeof(T) == 2) {
         if (wide_ok<T>(W, {xp, yp, prp}, {xsb, xsc, ysb, ysc})) {
             dim3 grid(((W / 8) * H + 255) / 256, C, B);
-            hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp, act);
+            if ((64 % (W / 8)) != 0)
+                hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T, true>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp, act);
+            else
+                hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, ysb, ysc, flip, prp, act);
             return (int)hipGetLastError();
         }
     }
@@ -586,10 +566,12 @@ int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, vo
 // ---- fused forms: host side ------------------------------------------------------------------------------------------
 static size_t fused_lds_bytes(int nch, int H, int W, size_t esize) { return (size_t)nch * (H + 2) * W * esize; }
 
-// shapes the fused kernels take: 16-bit I/O, rows of W / 8 lane groups that tile a wave, the channel (pair)'s planes in LDS
+// shapes the fused kernels take: 16-bit I/O, rows of W / 8 lane groups (EDGE instantiations when they do not tile a wave), the
+// channel (pair)'s planes in LDS
+static bool dw_edge(int W) { return (64 % (W / 8)) != 0; }
 int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch) {
     if (io != OSS_F16 && io != OSS_BF16) return 0;
-    if (nch < 1 || nch > 2 || H <= 0 || W <= 0 || W % 8 != 0 || W > 512 || (64 % (W / 8)) != 0) return 0;
+    if (nch < 1 || nch > 2 || H <= 0 || W <= 0 || W % 8 != 0 || W > 512) return 0;
     return fused_lds_bytes(nch, H, W, 2) + 4 * 20 * sizeof(float) <= kMaxLdsBytes ? 1 : 0;
 }
 
@@ -606,8 +588,12 @@ static int dwgate_fwd_launch(const void *t, const float *w, const float *bias, v
                              int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s) {
     if (!aligned16({t, out}, {tsb, tsc, osb, osc})) return OSS_ERR_SHAPE;
     dim3 grid(((W / 8) * H + 255) / 256, Hd, B);
-    hipLaunchKernelGGL((oss_dwgate_fwd_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T *>(t), w, bias,
-                       reinterpret_cast<T *>(out), Hd, H, W, tsb, tsc, osb, osc);
+    if (dw_edge(W))
+        hipLaunchKernelGGL((oss_dwgate_fwd_kernel<T, true>), grid, dim3(256), 0, s, reinterpret_cast<const T *>(t), w, bias,
+                           reinterpret_cast<T *>(out), Hd, H, W, tsb, tsc, osb, osc);
+    else
+        hipLaunchKernelGGL((oss_dwgate_fwd_kernel<T, false>), grid, dim3(256), 0, s, reinterpret_cast<const T *>(t), w, bias,
+                           reinterpret_cast<T *>(out), Hd, H, W, tsb, tsc, osb, osc);
     return (int)hipGetLastError();
 }
 
@@ -624,10 +610,11 @@ static int bwd_fused_launch(const void *x, const float *w, const float *bias, co
                             int64_t dsb, int64_t dsc, hipStream_t s) {
     constexpr int NCH = MODE == kDwGate ? 2 : 1;
     if (!aligned16({x, dy, dx}, {xsb, xsc, gsb, gsc, dsb, dsc})) return OSS_ERR_SHAPE;
-    static LdsGate gate;
+    static LdsGate gate, gate_e;
     const size_t smem = fused_lds_bytes(NCH, H, W, sizeof(T));
-    auto kern = oss_dwconv3x3_bwd_fused_kernel<T, MODE>;
-    if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
+    const bool edge = dw_edge(W);
+    auto kern = edge ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, true> : oss_dwconv3x3_bwd_fused_kernel<T, MODE, false>;
+    if (const int e = (edge ? gate_e : gate).ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
     hipLaunchKernelGGL(kern, dim3(C / NCH, B), dim3(256), smem, s, reinterpret_cast<const T *>(x), w, bias,
                        reinterpret_cast<const T *>(dy), reinterpret_cast<T *>(dx), part, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc);
     if (defer_finish())
@@ -664,7 +651,12 @@ static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, flo
     if constexpr (sizeof(T) == 2) wide = wide_ok<T>(W, {xp, gp, prp, dpp}, {xsb, xsc, gsb, gsc});
     if constexpr (sizeof(T) == 2) {
         if (wide)
-            hipLaunchKernelGGL((oss_dwconv3x3_wgrad_wide_kernel<T>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
+        {
+            if ((64 % (W / 8)) != 0)
+                hipLaunchKernelGGL((oss_dwconv3x3_wgrad_wide_kernel<T, true>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
+            else
+                hipLaunchKernelGGL((oss_dwconv3x3_wgrad_wide_kernel<T, false>), dim3(C, B), dim3(256), 0, s, xp, gp, part, C, H, W, xsb, xsc, gsb, gsc, prp, dpp);
+        }
     }
     if (wide) {
     } else if (vec)

@@ -1,0 +1,51 @@
+// oss_stencil.h -- 3x3-stencil access helpers shared by the depth-wise convolutions (oss_dwconv.hip) and the thin dense 3x3
+// convolutions (oss_conv3x3_thin.hip): 16-bit I/O, 8 consecutive pixels of one image row per lane.
+#pragma once
+#include "oss_device.h"
+
+namespace oss {
+
+// One 16-byte access per lane and image row, and the two halo pixels of a lane's 8-pixel group come from the
+// neighbouring lanes by DPP (wave_shr / wave_shl) instead of two more (2-byte) loads: 3 load instructions per 8 outputs
+// against 9 per 4 in the kernel above, which is what bounds it (2-byte-per-lane global accesses move 128 B per wave
+// instruction on gfx950).  Needs W % 8 == 0 with W / 8 (lanes per image row) dividing 64, so that a row's groups never
+// straddle a wave, and 16-byte aligned planes.
+template <typename T>
+__device__ __forceinline__ void load8(const T *p, float (&v)[8]) {
+    const u32x4 q = *reinterpret_cast<const u32x4 *>(p);
+    unpack2<T>(q.x, v[0], v[1]); unpack2<T>(q.y, v[2], v[3]); unpack2<T>(q.z, v[4], v[5]); unpack2<T>(q.w, v[6], v[7]);
+}
+template <typename T>
+__device__ __forceinline__ void store8(T *p, const float (&v)[8]) {
+    *reinterpret_cast<u32x4 *>(p) = u32x4{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]), pack2<T>(v[4], v[5]), pack2<T>(v[6], v[7])};
+}
+// v[0..9] = pixels w0-1 .. w0+8 of image row h + dy (zeros outside the image); every lane of the wave must call it.
+// EDGE (round 4): rows whose W / 8 lane groups do not tile a wave (W = 160: 20 groups; the RealSR tiles, the Deraining tree's
+// progressive patch sizes 160 / 192 / 320 / 384) straddle waves, and DPP cannot reach across one: the first lane of a wave
+// that is not the first group of its row (and the last lane that is not the last group) fetches its one halo pixel from memory
+// -- two one-lane loads per wave and row instead of falling back to the 4-pixel kernel (three times the load instructions).
+template <typename T, bool EDGE = false>
+__device__ __forceinline__ void row10(const T *plane, int h, int dy, int H, int W, int w0, bool first, bool last, float (&v)[10]) {
+    const int hh = h + dy;
+    const bool ok = hh >= 0 && hh < H;
+    float m[8];
+    const T *rowp = plane + (int64_t)(ok ? hh : h) * W + w0;
+    u32x4 q = *reinterpret_cast<const u32x4 *>(rowp);
+    if (!ok) q = u32x4{0u, 0u, 0u, 0u};   // a row outside the image: four selects on the packed words instead of eight on the values
+    unpack2<T>(q.x, m[0], m[1]); unpack2<T>(q.y, m[2], m[3]); unpack2<T>(q.z, m[4], m[5]); unpack2<T>(q.w, m[6], m[7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j + 1] = m[j];
+    v[0] = shift_from_prev_lane(v[8], 0.f, first);
+    v[9] = shift_from_next_lane(v[1], 0.f, last);
+    if constexpr (EDGE) {
+        const int lane = threadIdx.x & 63;
+        if (lane == 0 && !first) v[0] = ok ? to_f32(rowp[-1]) : 0.f;
+        if (lane == 63 && !last) v[9] = ok ? to_f32(rowp[8]) : 0.f;
+    }
+}
+
+
+// lanes per image row do not tile a wave -> the EDGE instantiations (rows straddle waves)
+static inline bool stencil_edge(int W) { return (64 % (W / 8)) != 0; }
+
+}  // namespace oss
