@@ -506,6 +506,29 @@ const char *oss_scan_build_id(void);
 
 const char *oss_version(void);
 
+/* Dense 3x3 convolutions (stride 1, zero padding 1, NCHW) with a THIN side -- at most 4 channels in or out: the layers the UNets
+ * open and close with (OverlapPatchEmbed conv(3 -> 48), SRGAN/VmambaIR/archs/MambaSISR6_arch.py:520-528; the x4 tail's last
+ * conv(96 -> 3) at the output resolution, archs/common.py:45-60; Mamber32.output, Deraining/basicsr/models/archs/
+ * mamber32_arch.py:608).  HBM-bound stencils, not GEMMs: 16-bit I/O, fp32 master weights (cout, cin, 3, 3) and bias, fp32
+ * accumulation, 8 pixels per lane.  oss_conv3x3_thin_ok says whether a shape qualifies (bf16 / fp16, width % 8 == 0,
+ * min(cin, cout) <= 4); pointers 16-byte aligned, plane strides (elements) multiples of 8, planes contiguous.
+ *   fwd:   y = conv(x) + bias
+ *   dgrad: dx = the transposed convolution of dy
+ *   wgrad: dweight (cout, cin, 3, 3) and -- cout <= 4 only -- dbias, through `partial`
+ *          (oss_conv3x3_thin_wgrad_partial_floats floats, no init): one partial vector per image, added in batch order by the
+ *          deferred finishing launch (oss_set_defer_finish) or right away. */
+int oss_conv3x3_thin_ok(oss_dtype io, int cin, int cout, int height, int width);
+int oss_conv3x3_thin_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cin, int cout,
+                         int height, int width, int64_t x_batch_stride, int64_t x_channel_stride, int64_t y_batch_stride,
+                         int64_t y_channel_stride, oss_stream_t stream);
+int oss_conv3x3_thin_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cin, int cout, int height,
+                           int width, int64_t dy_batch_stride, int64_t dy_channel_stride, int64_t dx_batch_stride,
+                           int64_t dx_channel_stride, oss_stream_t stream);
+size_t oss_conv3x3_thin_wgrad_partial_floats(int batch, int cin, int cout);
+int oss_conv3x3_thin_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partial, int batch, int cin,
+                           int cout, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride,
+                           int64_t dy_channel_stride, oss_stream_t stream);
+
 /* Opt-in build features of the loaded library (vmambair_amd/_build.py: VMAMBAIR_BUILD_FEATURES=fused_dt,lane_states).  Both are
  * measured losers kept in the tree for the record; the shipped library has neither: dt_weight != NULL
  * is then rejected with OSS_ERR_SHAPE, oss_scan_fused_dt_ok() and oss_scan_lane_state_floats() answer 0, `hs` is ignored. */
@@ -519,7 +542,7 @@ int oss_scan_features(void);
  * (which: 0 = oss_scan_fwd_params, 1 = oss_scan_bwd_params, 2 = oss_chan_params; 0 for anything else).  Every binding layer
  * in this tree (vmambair_amd/_capi.py, csrc_host/oss_torch_host.cpp through vmambair_amd/_host.py) compares both with its
  * own compile-time values when it loads and refuses to run on a mismatch. */
-#define OSS_ABI_VERSION 5
+#define OSS_ABI_VERSION 6
 int oss_abi_version(void);
 size_t oss_abi_struct_bytes(int which);
 

@@ -83,10 +83,11 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
            "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
            "oss_flush_finishes", "oss_set_defer_wgrad", "oss_deferred_wgrads", "oss_deferred_wgrad_table_bytes", "oss_flush_wgrads",
-           "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version", "oss_scan_features", "oss_abi_version", "oss_abi_struct_bytes"]
+           "oss_conv3x3_thin_ok", "oss_conv3x3_thin_fwd", "oss_conv3x3_thin_dgrad", "oss_conv3x3_thin_wgrad_partial_floats",
+           "oss_conv3x3_thin_wgrad", "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version", "oss_scan_features", "oss_abi_version", "oss_abi_struct_bytes"]
 
 #: include/vmambair_oss.h: OSS_ABI_VERSION this binding was written against
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -241,6 +242,16 @@ def load():
     lib.oss_deferred_wgrad_table_bytes.restype = C.c_size_t
     lib.oss_flush_wgrads.restype = C.c_int
     lib.oss_flush_wgrads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.oss_conv3x3_thin_ok.restype = C.c_int
+    lib.oss_conv3x3_thin_ok.argtypes = [C.c_int] * 5
+    lib.oss_conv3x3_thin_fwd.restype = C.c_int
+    lib.oss_conv3x3_thin_fwd.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_int64] * 4 + [C.c_void_p]
+    lib.oss_conv3x3_thin_dgrad.restype = C.c_int
+    lib.oss_conv3x3_thin_dgrad.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_int64] * 4 + [C.c_void_p]
+    lib.oss_conv3x3_thin_wgrad_partial_floats.restype = C.c_size_t
+    lib.oss_conv3x3_thin_wgrad_partial_floats.argtypes = [C.c_int] * 3
+    lib.oss_conv3x3_thin_wgrad.restype = C.c_int
+    lib.oss_conv3x3_thin_wgrad.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_hbm_copy.restype = C.c_int
     lib.oss_hbm_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_prof_marker.restype = C.c_int

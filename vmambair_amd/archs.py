@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .oss_block import MamberBlock, conv1x1
+from .ops.conv3x3 import conv3x3
 
 
 def _conv3(cin: int, cout: int, bias: bool) -> nn.Conv2d:
@@ -27,7 +28,7 @@ class OverlapPatchEmbed(nn.Module):
         self.proj = _conv3(in_c, embed_dim, bias)
 
     def forward(self, x):
-        return self.proj(x)
+        return conv3x3(x, self.proj)   # 3 -> dim: the in-tree thin-convolution kernels for 16-bit activations
 
 
 class Downsample(nn.Module):
@@ -112,7 +113,9 @@ class MambaSISR6(_OSSUNet):
         self.tail = _x4_tail(dim * 2, out_channels)
 
     def forward(self, inp_img):
-        return self.tail(self.body(inp_img)) + F.interpolate(inp_img, scale_factor=self.scale, mode="nearest")
+        # tail = Sequential(upsampler, conv_last): the last layer (2 dim -> out_channels at the output resolution) on the in-tree
+        # thin-convolution kernels; parameter names (tail.0.*, tail.1.*) are the reference's
+        return conv3x3(self.tail[0](self.body(inp_img)), self.tail[1]) + F.interpolate(inp_img, scale_factor=self.scale, mode="nearest")
 
 
 class MambaRealSR11(MambaSISR6):
@@ -133,7 +136,7 @@ class Mamber32(_OSSUNet):
         self.output = _conv3(dim * 2, out_channels, bias)
 
     def forward(self, inp_img):
-        return self.output(self.body(inp_img)) + inp_img
+        return conv3x3(self.body(inp_img), self.output) + inp_img
 
 
 class Mamber33(Mamber32):

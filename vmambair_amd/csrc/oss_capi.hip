@@ -512,6 +512,27 @@ int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, i
     return gelu_gate_bwd(io, h, dout, dh, batch, half_elems, h_batch_stride, dout_batch_stride, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_conv3x3_thin_ok(oss_dtype io, int cin, int cout, int height, int width) { return conv3x3_thin_ok(io, cin, cout, height, width); }
+int oss_conv3x3_thin_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cin, int cout,
+                         int height, int width, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, oss_stream_t stream) {
+    if (!x || !weight || !y) return OSS_ERR_NULL;
+    return conv3x3_thin_fwd(io, x, weight, bias, y, batch, cin, cout, height, width, xsb, xsc, ysb, ysc, reinterpret_cast<hipStream_t>(stream));
+}
+int oss_conv3x3_thin_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cin, int cout, int height,
+                           int width, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    if (!dy || !weight || !dx) return OSS_ERR_NULL;
+    return conv3x3_thin_dgrad(io, dy, weight, dx, batch, cin, cout, height, width, gsb, gsc, dsb, dsc, reinterpret_cast<hipStream_t>(stream));
+}
+size_t oss_conv3x3_thin_wgrad_partial_floats(int batch, int cin, int cout) {
+    return (batch <= 0 || cin <= 0 || cout <= 0) ? 0 : conv3x3_thin_wgrad_partial_floats(batch, cin, cout);
+}
+int oss_conv3x3_thin_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partial, int batch, int cin,
+                           int cout, int height, int width, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    if (!x || !dy || !dweight || !partial) return OSS_ERR_NULL;
+    return conv3x3_thin_wgrad(io, x, dy, dweight, dbias, partial, batch, cin, cout, height, width, xsb, xsc, gsb, gsc,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
 void oss_set_defer_wgrad(int on) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
     g_defer_wgrad.store(on ? 1 : 0);

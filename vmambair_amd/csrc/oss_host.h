@@ -81,6 +81,15 @@ int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, c
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
                     int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre = nullptr,
                     void *dpre = nullptr);
+// thin dense 3x3 convolutions (oss_conv3x3_thin.hip): <= 4 channels in or out
+int conv3x3_thin_ok(oss_dtype io, int Cin, int Cout, int H, int W);
+int conv3x3_thin_fwd(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int Cin, int Cout, int H, int W,
+                     int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, hipStream_t s);
+int conv3x3_thin_dgrad(oss_dtype io, const void *dy, const float *w, void *dx, int B, int Cin, int Cout, int H, int W, int64_t gsb,
+                       int64_t gsc, int64_t dsb, int64_t dsc, hipStream_t s);
+size_t conv3x3_thin_wgrad_partial_floats(int B, int Cin, int Cout);
+int conv3x3_thin_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int Cin, int Cout, int H,
+                       int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s);
 int ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *w, const float *bias, const void *gate, void *y,
                 float *mean, float *rstd, int B, int C, int P, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, float eps,
                 hipStream_t s, float *pool_part = nullptr);

@@ -80,6 +80,8 @@ class GraphedTrainStep:
                 if dense_conv and m.kernel_size == (1, 1) and _ops.pointwise.CONV1X1_IMPL == "mfma" and owner.rsplit(".", 1)[-1] in (
                         "in_conv", "out_conv", "project_in", "project_out", "reduce_chan_level2", "reduce_chan_level3"):
                     continue  # the MFMA 1x1 kernels read the fp32 masters and narrow them in their loader
+                if dense_conv and m.kernel_size == (3, 3) and min(m.in_channels, m.out_channels) <= 4 and _ops.conv3x3.THIN_IMPL:
+                    continue  # patch_embed / the tail's last layer: the thin-convolution kernels read the fp32 masters (ops/conv3x3.py)
                 # x_proj_weight / dt_projs_weight: the fused spatial core (SS2DCoreFn) reads the fp32 masters
                 fused_proj = getattr(m, "fused_core", False) and getattr(m, "omni", False)
                 if dense_conv or (leaf in ("x_proj_weight", "dt_projs_weight") and not fused_proj):
