@@ -445,3 +445,52 @@ def test_channel_branch_from_the_pooled_sums_matches_the_pooling_pass():
     assert_close(a[2], bb[2], 1e-5, 1e-6, "pooled")
     assert_close(a[1], bb[1], 1e-4, 1e-5, "c")
     assert_close(a[0], bb[0].float(), 1e-2, 1e-2, "out")
+
+
+# ---- round 4: fp32 I/O on v_mfma_f32_32x32x2_f32 (csrc/oss_conv1x1_f32.hip) -- the reference's own precision -------------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 384, 64, 64), (1, 48, 96, 16, 24), (2, 127, 48, 8, 8), (1, 96, 254, 12, 10),
+                                            (3, 5, 7, 2, 6), (1, 255, 96, 16, 16), (2, 384, 384, 8, 8), (1, 96, 510, 32, 32),
+                                            (1, 33, 65, 4, 5), (2, 192, 96, 32, 32)])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_conv1x1_fp32_matrix_core_kernels(B, Cin, Cout, H, W, has_bias):
+    """fp32 activations, fp32 weights, true fp32 products: forward, input gradient and weight gradient against F.conv2d with TF32
+    off -- odd channel counts (127 / 255 / 33: a half-empty last k-step), ragged row tiles, pixel counts that are not a multiple of
+    the 128-pixel tile or of the 512-pixel weight-gradient slab, a skip connection in the epilogue"""
+    torch.manual_seed(1)
+    x = torch.randn(B, Cin, H, W)
+    w = torch.randn(Cout, Cin, 1, 1) * (Cin ** -0.5)
+    b = torch.randn(Cout) if has_bias else None
+    dy = torch.randn(B, Cout, H, W)
+    res = torch.randn(B, Cout, H, W)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if has_bias else None
+    yr = F.conv2d(xr.double(), wr.double(), None if br is None else br.double()) + res.double()
+    yr.backward(dy.double())
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if has_bias else None
+    assert ops.pointwise.f32_ok(xd)
+    y = ops.Conv1x1Fn.apply(xd, wd, bd, res.to(DEV))
+    assert y.dtype == torch.float32
+    y.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+    assert_close(y, yr.float(), 2e-5, 2e-5 * float(yr.abs().max()), "y")
+    assert_close(xd.grad, xr.grad, 2e-5, 2e-5 * float(xr.grad.abs().max()), "dx")
+    assert_close(wd.grad, wr.grad, 1e-4, 2e-5 * float(wr.grad.abs().max()), "dw")
+    if has_bias:
+        assert_close(bd.grad, br.grad, 1e-4, 2e-5 * float(br.grad.abs().max()), "db")
+
+
+def test_conv1x1_fp32_route_and_fallbacks(monkeypatch):
+    """``conv1x1()`` sends fp32 activations (no autocast) to the matrix-core kernels, keeps the vendor convolution for pixel counts
+    that are not a multiple of 4 and under VMAMBAIR_CONV1X1_F32=0; channel-slice views are taken as they are"""
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(32, 48, 1, bias=False).to(DEV)
+    big = torch.randn(2, 64, 16, 16, device=DEV)
+    x = big[:, 16:48].requires_grad_()
+    y = ops.conv1x1(x, conv)
+    assert y.grad_fn.__class__.__name__.startswith("Conv1x1Fn")
+    assert_close(y, conv(x), 2e-5, 2e-5, "fp32 view")
+    odd = torch.randn(1, 32, 3, 5, device=DEV)
+    assert not ops.conv1x1(odd, conv).grad_fn.__class__.__name__.startswith("Conv1x1Fn")
+    monkeypatch.setattr(ops.pointwise, "CONV1X1_F32", False)
+    assert not ops.conv1x1(x, conv).grad_fn.__class__.__name__.startswith("Conv1x1Fn")

@@ -447,6 +447,16 @@ int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *d
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t L = seqlen;
+    if (io == OSS_F32) {   // fp32 I/O: both products on the fp32 matrix-core kernel (oss_conv1x1_f32.hip), same scratch regions
+        // dx_proj_weight[k][c][d] = sum_{b,l} dxdbl[b, k, c, l] x2[b, k % 2, d, l]
+        int e = rows_f32_wgrad(reinterpret_cast<const float *>(dxdbl), reinterpret_cast<const float *>(x2), dx_proj_weight, partials, batch,
+                               4, 2, C, D, seqlen, 4 * C * L, C * L, L, 2 * D * L, D * L, L, s);
+        if (e || !ddts) return e;
+        // ddt_projs_weight[k][d][r] = sum_{b,l} ddts[b, k, d, l] xdbl[b, k, r, l]
+        float *part2 = partials + (size_t)batch * conv1x1_wgrad_slabs(seqlen) * 2 * (2 * (size_t)C) * D;
+        return rows_f32_wgrad(reinterpret_cast<const float *>(ddts), reinterpret_cast<const float *>(xdbl), ddt_projs_weight, part2, batch, 4,
+                              4, D, R, seqlen, 4 * D * L, D * L, L, 4 * C * L, C * L, L, s);
+    }
     // x_proj_weight: one problem per flattening j; its 2C rows are the rows of directions j and j + 2 of dxdbl
     int e = conv1x1_wgrad(io, dxdbl, x2, dx_proj_weight, partials, batch, 2 * C, D, seqlen, 4 * C * L, L, 2 * D * L, L, s,
                           /*G*/ 2, /*gsg*/ C * L, /*xsg*/ D * L, /*Mh*/ C, /*gs_hi*/ 2 * C * L);

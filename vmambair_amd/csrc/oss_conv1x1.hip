@@ -1002,7 +1002,9 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
             conv1x1_launch<f16_t>(reinterpret_cast<const f16_t *>(x), w, bias, reinterpret_cast<f16_t *>(y), B, M, K, P, xsb, xsk,
                                   ws_m, ws_k, s, reinterpret_cast<const f16_t *>(res));
             break;
-        default: return OSS_ERR_SHAPE;  // fp32 I/O stays on the vendor conv (no reduced-precision path for fp32)
+        default:   // fp32 I/O: true fp32 on the matrix cores (oss_conv1x1_f32.hip), no reduced-precision detour
+            return conv1x1_f32(reinterpret_cast<const float *>(x), w, bias, reinterpret_cast<float *>(y), B, M, K, P, xsb, xsk, ws_m, ws_k,
+                               s, reinterpret_cast<const float *>(res));
     }
     return (int)hipGetLastError();
 }
@@ -1196,6 +1198,11 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
                   int64_t gs_hi, float *db) {
     const int NB = N + (db ? 1 : 0);
     if (G < 1 || (size_t)B * G > 65535) return OSS_ERR_SHAPE;
+    if (io == OSS_F32) {   // plain 1x1 weight gradient only (the projection products call rows_f32_wgrad themselves); no bias column
+        if (db || G != 1 || (Mh > 0 && Mh != M)) return OSS_ERR_SHAPE;
+        return rows_f32_wgrad(reinterpret_cast<const float *>(dy), reinterpret_cast<const float *>(x), dw, part, B, 1, 1, M, N, P, gsb, 0,
+                              gsm, xsb, 0, xsn, s);
+    }
     if (Mh <= 0 || Mh > M) Mh = M;
     int slabs = conv1x1_wgrad_slabs(P);
     const int tiles = ((M + 31) / 32) * ((NB + 31) / 32);

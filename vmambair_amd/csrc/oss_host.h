@@ -81,6 +81,12 @@ int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, c
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
                     int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre = nullptr,
                     void *dpre = nullptr);
+// fp32 I/O on v_mfma_f32_32x32x2_f32 (oss_conv1x1_f32.hip)
+int conv1x1_f32(const float *x, const float *w, const float *bias, float *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk,
+                int64_t wsm, int64_t wsk, hipStream_t s, const float *res);
+size_t rows_f32_wgrad_partial_floats(int B, int G, int M, int N, int P);
+int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int B, int G, int GB, int M, int N, int P, int64_t asb,
+                   int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, hipStream_t s);
 // thin dense 3x3 convolutions (oss_conv3x3_thin.hip): <= 4 channels in or out
 int conv3x3_thin_ok(oss_dtype io, int Cin, int Cout, int H, int W);
 int conv3x3_thin_fwd(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int Cin, int Cout, int H, int W,

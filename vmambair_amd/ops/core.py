@@ -132,12 +132,14 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
     B, _, D, L = x2.shape
     Cc = xdbl.shape[2]
     dev = x2.device
-    if x2.dtype == torch.float32:
-        # fp32 I/O: the two weight gradients are plain library GEMMs (the MFMA split-K kernels are 16-bit)
+    if x2.dtype == torch.float32 and (L % 4 != 0 or os.environ.get("VMAMBAIR_PROJ_WGRAD_F32", "1") != "1"):
+        # fp32 I/O at a length the matrix-core kernel does not take (rows must be whole 16-byte quads): plain library GEMMs
         dz = dxdbl.view(B, 2, 2, Cc, L)   # [b, kk, j]: direction k = j + 2 kk
         dwx = torch.einsum("bhjcl,bjdl->hjcd", dz, x2).reshape(4, Cc, D)
         dwdt = torch.einsum("bkdl,bkrl->kdr", ddts.view(B, 4, D, L), xdbl[:, :, :R])
         return [dwx, dwdt]
+    # (round 4) fp32 I/O otherwise: the same library call as the 16-bit types -- oss_proj_wgrad runs both products on
+    # v_mfma_f32_32x32x2_f32 (csrc/oss_conv1x1_f32.hip); rounds 1-3 used the two einsums above (11 ms of the fp32 step)
     lib = _capi.load()
     with torch.cuda.device(dev):
         with _fork_for_wgrad(x2, xdbl, dxdbl, ddts):

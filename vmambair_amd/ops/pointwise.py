@@ -1,4 +1,6 @@
-"""1x1 convolutions of the OSS block as MFMA GEMMs on NCHW: bf16 / fp16 I/O, fp32 master weights (MambaSISR6_arch.py:205,211,281,329).
+"""1x1 convolutions of the OSS block as MFMA GEMMs on NCHW (MambaSISR6_arch.py:205,211,281,329): bf16 / fp16 I/O with fp32 master
+weights on the 16-bit matrix instructions, and (round 4) fp32 I/O -- the reference's own precision -- on v_mfma_f32_32x32x2_f32
+(csrc/oss_conv1x1_f32.hip: true fp32 products, no reduced-precision detour).
 """
 from __future__ import annotations
 
@@ -16,11 +18,13 @@ from ._common import (_keep_operands,
 def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.conv2d(x, weight, bias) [+ residual]`` for a (Cout, Cin, 1, 1) weight; x bf16/fp16 (B, Cin, H, W)."""
-    _check(x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16), "conv1x1: x must be bf16/fp16 on the GPU")
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "conv1x1: x must be bf16 / fp16 / fp32 on the GPU")
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     _check(tuple(weight.shape) == (Cout, Cin, 1, 1), "conv1x1: weight must be (Cout, Cin, 1, 1)")
     x = _planes(x)
+    if x.dtype == torch.float32 and not f32_ok(x):
+        x = x.contiguous()
     w = weight.detach().float().reshape(Cout, Cin).contiguous()
     b = None if bias is None else bias.detach().float().contiguous()
     if residual is not None:
@@ -44,19 +48,26 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
     x, dy = _planes(x), _planes(dy)
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)
+    f32 = x.dtype == torch.float32
+    if f32:
+        x = x if f32_ok(x) else x.contiguous()
+        dy = dy if f32_ok(dy) else dy.contiguous()
     w = weight.detach().float().reshape(Cout, Cin).contiguous()
     dx = torch.empty((B, Cin, H, W), dtype=x.dtype, device=x.device)
     lib = _capi.load()
     with torch.cuda.device(x.device):
         with _fork_for_wgrad(x, dy):
             dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
-            db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
+            # the fp32 weight-gradient kernel has no bias column: a 1x1 bias (none of the archs' blocks has one) is a plain sum
+            db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if (has_bias and not f32) else None
             part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
             _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
                                               Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
                                               torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
             _keep(part, dw, db)
             _keep_operands(dy, x)
+            if has_bias and db is None:
+                db = dy.sum(dim=(0, 2, 3))
         _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
                                           dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
     return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]
@@ -82,11 +93,20 @@ class Conv1x1Fn(torch.autograd.Function):
         return dx, dw.to(weight.dtype), (db if ctx.has_bias else None), (dy if ctx.has_res else None)
 
 
+def f32_ok(t: torch.Tensor) -> bool:
+    """fp32 planes the matrix-core kernels of oss_conv1x1_f32.hip take as they are: 16-byte aligned rows, pixels % 4 == 0"""
+    return (t.shape[2] * t.shape[3]) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0
+
+
+#: ``VMAMBAIR_CONV1X1_F32=0`` keeps fp32 activations on the vendor convolution (rounds 1-3; A-B timing)
+CONV1X1_F32 = os.environ.get("VMAMBAIR_CONV1X1_F32", "1") == "1"
+
 #: "mfma" (default) or "vendor".  16-bit activations go to the in-tree MFMA kernels (pixel-pair tiles: 4-byte
 #: activation loads and result stores, fp32 master weights narrowed in the loader, split-K weight gradient):
 #: 1 launch forward, 3 backward, against ~4 + ~8 of the vendor path (NCHW<->NHWC transposes, casts, tensor-ops
-#: around one implicit-GEMM kernel) and faster per call (profiles/r01_opbench_v14.txt).  float32 activations
-#: always take the vendor conv.  ``VMAMBAIR_CONV1X1=vendor`` keeps everything on the vendor path (A-B timing).
+#: around one implicit-GEMM kernel) and faster per call (profiles/r01_opbench_v14.txt).  float32 activations (no
+#: autocast: the reference's own precision) take the fp32 matrix-core kernels (round 4; ``CONV1X1_F32``).
+#: ``VMAMBAIR_CONV1X1=vendor`` keeps everything on the vendor path (A-B timing).
 CONV1X1_IMPL = os.environ.get("VMAMBAIR_CONV1X1", "mfma")
 
 
@@ -98,7 +118,8 @@ def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, residual: Optional[torch.Ten
     if CONV1X1_IMPL == "mfma" and x.is_cuda:
         if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
             x = x.to(torch.get_autocast_dtype("cuda"))
-        if x.dtype in (torch.bfloat16, torch.float16):
+        if x.dtype in (torch.bfloat16, torch.float16) or (x.dtype == torch.float32 and CONV1X1_F32 and x.dim() == 4 and
+                                                          (x.shape[2] * x.shape[3]) % 4 == 0 and not torch.is_autocast_enabled("cuda")):
             if residual is not None and residual.dtype != x.dtype:  # e.g. an fp32 stream: keep torch's type promotion
                 return residual + Conv1x1Fn.apply(x, conv.weight, conv.bias, None)
             return Conv1x1Fn.apply(x, conv.weight, conv.bias, residual)
