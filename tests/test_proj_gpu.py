@@ -62,7 +62,8 @@ SHAPES = [  # (B, D, R, N, L)
 
 @pytest.fixture(params=["mfma", "valu"])
 def proj_path(request):
-    """16-bit I/O has two implementations (matrix cores / vector ALU); float I/O only the second"""
+    """two implementations each: matrix cores (16-bit: v_mfma_f32_32x32x16; float I/O, round 4: v_mfma_f32_32x32x2_f32 for lengths
+    that are a multiple of 4) / vector ALU"""
     ops.proj_set_path(request.param == "valu")
     yield request.param
     ops.proj_set_path(False)
@@ -71,8 +72,6 @@ def proj_path(request):
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"D{s[1]}L{s[4]}" for s in SHAPES])
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_projections_forward_backward(shape, dt, proj_path):
-    if dt == torch.float32 and proj_path == "mfma":
-        pytest.skip("float I/O always runs on the vector-ALU kernels")
     torch.manual_seed(2)
     B, D, R, N, L = shape
     Cc = R + 2 * N

@@ -23,19 +23,37 @@ namespace oss {
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 // ---- forward / input gradient -------------------------------------------------------------------------------------------------
-// Y[b][m][p] = sum_k w[m * wsm + k * wsk] X[b][k][p] (+ bias[m]) (+ res[b][m][p]);  one wave = (32 MT) rows x 128 pixels.
-// grid (ceil(P / 128), ceil(M / (32 MT)), B), 64 threads.  P % 4 == 0, 16-byte aligned rows (host-checked).
-template <int MT>
-__global__ void __launch_bounds__(64, 2)   // <= 256 registers (accumulators included): two waves per SIMD keep the matrix pipe fed across the loads
-oss_conv1x1_f32_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ y,
-                       int M, int K, int P, int64_t xsb, int64_t xsk, int64_t ysb, int64_t ysm, int64_t wsm, int64_t wsk,
-                       const float *__restrict__ res) {
-    const int lane = threadIdx.x, col = lane & 31, kg = lane >> 5;
+// Y[b][g][m][p] = sum_k W[g](m, k) X[b][g % GX][k][p] (+ bias[m]) (+ res[b][g][m][p]) (+ the old Y: accumulate)
+//   W[g](m, k) = w[g * wsg + m * wsm + k * wsk];  X row k of (b, g % GX): x + b * xsb + (g % GX) * xsg + k * xsk;  likewise y, res.
+// G = 1 is the 1x1 convolution (transposed weight strides: its input gradient); G = 4, GX = 2 the x_proj product of the four scan
+// directions (directions k and k + 2 read the same flattening, MambaSISR6_arch.py:401-408), G = GX = 4 the dt_proj product.
+// One wave = (32 MT) rows x 128 pixels; grid (ceil(P / 128), ceil(M / (32 MT)), B * G), 64 threads.  P % 4 == 0, 16-byte aligned rows.
+struct F32Gemm {
+    const float *x, *w, *bias, *res;
+    float *y;
+    int M, K, P, G, GX, accumulate;
+    int64_t xsb, xsg, xsk, wsg, wsm, wsk, ysb, ysg, ysm, rsb, rsg, rsm;
+};
+// SPLIT: a call with few tiles (a 1x1 convolution at batch 8 is 768 tiles for 1024 SIMDs) leaves every wave alone on its SIMD with
+// nothing to cover its loads -- measured 57 us per launch against ~5 us of matrix time (profiles/r04_ab_fp32_kernels.txt).  The
+// four waves of a 256-thread workgroup then take a quarter of K each (four times the waves, a quarter of the dependent
+// load -> MFMA rounds per wave) and wave 0 adds the four accumulator sets through LDS in wave order (deterministic).
+template <int MT, bool SPLIT>
+__global__ void __launch_bounds__(SPLIT ? 256 : 64, 2)   // <= 256 registers (accumulators included)
+oss_conv1x1_f32_kernel(const F32Gemm a_) {
+    const F32Gemm &a = a_;
+    const int lane = threadIdx.x & 63, col = lane & 31, kg = lane >> 5;
+    const int wave = SPLIT ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int p0 = blockIdx.x * 128 + 4 * col;
     const int m0 = blockIdx.y * 32 * MT;
-    const int b = blockIdx.z;
-    const bool pok = p0 < P;
-    const float *xb = x + b * xsb + (pok ? p0 : 0);
+    const int b = blockIdx.z / a.G, g = blockIdx.z - b * a.G;
+    const int M = a.M;
+    // this wave's channels [kbeg, K): an even number per wave, so that every k-step of two belongs to one wave
+    const int kq = SPLIT ? (((a.K + 3) / 4 + 1) & ~1) : a.K;
+    const int kbeg = SPLIT ? wave * kq : 0, K = SPLIT ? min(a.K, kbeg + kq) : a.K;
+    const bool pok = p0 < a.P;
+    const float *xb = a.x + b * a.xsb + (g % a.GX) * a.xsg + (pok ? p0 : 0);
+    const float *wb = a.w + g * a.wsg;
     f32x16 acc[MT][4];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -49,72 +67,165 @@ oss_conv1x1_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
     for (int t = 0; t < MT; ++t) {
         const int m = m0 + 32 * t + col;
         mok[t] = m < M;
-        wr[t] = w + (int64_t)(mok[t] ? m : 0) * wsm;
+        wr[t] = wb + (int64_t)(mok[t] ? m : 0) * a.wsm;
     }
-    constexpr int U = 2;   // k-steps whose loads are issued together
-    for (int k0 = 0; k0 < K; k0 += 2 * U) {
+    constexpr int U = SPLIT ? 4 : (MT == 1 ? 4 : 2);   // k-steps whose loads are issued together
+    for (int k0 = kbeg; k0 < K; k0 += 2 * U) {
         f32x4 xv[U];
-        float a[U][MT];
+        float av[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 2 * u + kg;
             const bool kok = k < K;
             const int kc = kok ? k : 0;
-            xv[u] = *reinterpret_cast<const f32x4 *>(xb + (int64_t)kc * xsk);
+            xv[u] = *reinterpret_cast<const f32x4 *>(xb + (int64_t)kc * a.xsk);
             if (!(kok && pok)) xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const float v = wr[t][(int64_t)kc * wsk];
-                a[u][t] = (kok && mok[t]) ? v : 0.f;
+                const float v = wr[t][(int64_t)kc * a.wsk];
+                av[u][t] = (kok && mok[t]) ? v : 0.f;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // every load of the round is issued before its first MFMA (the scheduler otherwise pairs them up)
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[t][q] = mfma_f32(a[u][t], xv[u][q], acc[t][q]);
+                for (int q = 0; q < 4; ++q) acc[t][q] = mfma_f32(av[u][t], xv[u][q], acc[t][q]);
+    }
+    if constexpr (SPLIT) {
+        extern __shared__ __attribute__((aligned(16))) float red[];   // [3 waves][MT * 16 quads][64 lanes][4]
+        if (wave > 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<f32x4 *>(red + ((size_t)((wave - 1) * MT * 16 + t * 16 + r) * 64 + lane) * 4) =
+                        f32x4{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll 1   // one wave's set at a time: the compiler otherwise hoists all 192 quads into registers (spills)
+        for (int w2 = 0; w2 < 3; ++w2)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(red + ((size_t)(w2 * MT * 16 + t * 16 + r) * 64 + lane) * 4);
+                    acc[t][0][r] += v.x; acc[t][1][r] += v.y; acc[t][2][r] += v.z; acc[t][3][r] += v.w;
+                }
     }
     if (!pok) return;
+    float *yb = a.y + b * a.ysb + g * a.ysg + p0;
+    const float *rb = a.res ? a.res + b * a.rsb + g * a.rsg + p0 : nullptr;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
             if (m < M) {
-                const float bv = bias ? bias[m] : 0.f;
+                const float bv = a.bias ? a.bias[m] : 0.f;
                 f32x4 o = {acc[t][0][r] + bv, acc[t][1][r] + bv, acc[t][2][r] + bv, acc[t][3][r] + bv};
-                if (res) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(res + b * ysb + (int64_t)m * ysm + p0);
+                if (rb) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(rb + (int64_t)m * a.rsm);
                     o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
                 }
-                *reinterpret_cast<f32x4 *>(y + b * ysb + (int64_t)m * ysm + p0) = o;
+                if (a.accumulate) {
+                    const f32x4 ov = *reinterpret_cast<const f32x4 *>(yb + (int64_t)m * a.ysm);
+                    o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w;
+                }
+                *reinterpret_cast<f32x4 *>(yb + (int64_t)m * a.ysm) = o;
             }
         }
 }
 
-int conv1x1_f32_ok(int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const void *res) {
-    if (M < 1 || K < 1 || P < 4 || P % 4 != 0) return 0;
-    if (xsb % 4 != 0 || xsk % 4 != 0) return 0;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15u) return 0;
-    return 1;
+static bool f32_aligned(std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
+    for (const void *p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
+    for (int64_t st : strides)
+        if (st % 4 != 0) return false;
+    return true;
+}
+
+int gemm_f32(const F32Gemm &a, int B, hipStream_t s) {
+    if (a.M < 1 || a.K < 1 || a.P < 4 || a.P % 4 != 0 || a.G < 1 || a.GX < 1) return OSS_ERR_SHAPE;
+    if (!f32_aligned({a.x, a.y, a.res}, {a.xsb, a.xsg, a.xsk, a.ysb, a.ysg, a.ysm, a.rsb, a.rsg, a.rsm})) return OSS_ERR_SHAPE;
+    if (B <= 0 || (long)B * a.G > 65535) return OSS_ERR_SHAPE;
+    const long px = (a.P + 127) / 128, bg = (long)B * a.G;
+    const long waves64 = px * ((a.M + 63) / 64) * bg, waves32 = px * ((a.M + 31) / 32) * bg;
+    if (waves64 >= 3072 && a.M > 32) {          // plenty of tiles: 64-row tiles, one wave each
+        const dim3 grid(px, (a.M + 63) / 64, bg);
+        hipLaunchKernelGGL((oss_conv1x1_f32_kernel<2, false>), grid, dim3(64), 0, s, a);
+    } else if (waves32 >= 3072 || a.K < 32) {   // 32-row tiles, one wave each (a short K has nothing to split)
+        const dim3 grid(px, (a.M + 31) / 32, bg);
+        hipLaunchKernelGGL((oss_conv1x1_f32_kernel<1, false>), grid, dim3(64), 0, s, a);
+    } else {                                    // few tiles: four waves per tile, a quarter of K each
+        const dim3 grid(px, (a.M + 31) / 32, bg);
+        static LdsGate gate;
+        const size_t smem = sizeof(float) * 3 * 16 * 64 * 4;
+        auto kern = oss_conv1x1_f32_kernel<1, true>;
+        if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    }
+    return (int)hipGetLastError();
 }
 
 int conv1x1_f32(const float *x, const float *w, const float *bias, float *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk,
                 int64_t wsm, int64_t wsk, hipStream_t s, const float *res) {
-    if (!conv1x1_f32_ok(M, K, P, xsb, xsk, x, y, res)) return OSS_ERR_SHAPE;
-    if (B <= 0 || B > 65535) return OSS_ERR_SHAPE;
-    const int64_t ysb = (int64_t)M * P, ysm = P;
-    // 64-row tiles when that still gives every SIMD a wave, else 32-row tiles (twice the waves, the activations read twice as often)
-    const long waves64 = (long)((P + 127) / 128) * ((M + 63) / 64) * B;
-    if (waves64 >= 1024 && M > 32) {
-        const dim3 grid((P + 127) / 128, (M + 63) / 64, B);
-        hipLaunchKernelGGL(oss_conv1x1_f32_kernel<2>, grid, dim3(64), 0, s, x, w, bias, y, M, K, P, xsb, xsk, ysb, ysm, wsm, wsk, res);
-    } else {
-        const dim3 grid((P + 127) / 128, (M + 31) / 32, B);
-        hipLaunchKernelGGL(oss_conv1x1_f32_kernel<1>, grid, dim3(64), 0, s, x, w, bias, y, M, K, P, xsb, xsk, ysb, ysm, wsm, wsk, res);
+    F32Gemm a{};
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.y = y;
+    a.M = M; a.K = K; a.P = P; a.G = 1; a.GX = 1; a.accumulate = 0;
+    a.xsb = xsb; a.xsg = 0; a.xsk = xsk; a.wsg = 0; a.wsm = wsm; a.wsk = wsk;
+    a.ysb = (int64_t)M * P; a.ysg = 0; a.ysm = P; a.rsb = a.ysb; a.rsg = 0; a.rsm = P;
+    return gemm_f32(a, B, s);
+}
+
+// x_proj / dt_proj of the four scan directions at fp32 I/O (MambaSISR6_arch.py:406-411) -- the products oss_proj_fwd / oss_proj_dgrad
+// run on the vector ALU for float tensors in rounds 1-3 (7.8 ms of the fp32 step, profiles/r04_rocprof_bench_fp32_steady_state.txt)
+int proj_f32_ok(int B, int D, int C, int R, int L, std::initializer_list<const void *> ptrs) {
+    if (L < 4 || L % 4 != 0 || B <= 0 || 4L * B > 65535 || D < 1 || R < 1 || C <= R) return 0;
+    for (const void *p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return 0;
+    return 1;
+}
+// xdbl[b, k] (C rows) = Wx[k] (C x D) x2[b, k % 2] (D rows);  dts[b, k] (D rows) = Wdt[k] (D x R) xdbl[b, k][:R]
+int proj_fwd_f32(const float *x2, const float *Wx, const float *Wdt, float *xdbl, float *dts, int B, int D, int C, int R, int L,
+                 hipStream_t s) {
+    const int64_t l = L;
+    F32Gemm a{};
+    a.x = x2; a.w = Wx; a.y = xdbl; a.M = C; a.K = D; a.P = L; a.G = 4; a.GX = 2;
+    a.xsb = 2 * D * l; a.xsg = D * l; a.xsk = l; a.wsg = (int64_t)C * D; a.wsm = D; a.wsk = 1;
+    a.ysb = 4 * C * l; a.ysg = C * l; a.ysm = l;
+    int e = gemm_f32(a, B, s);
+    if (e || !dts) return e;
+    F32Gemm d{};
+    d.x = xdbl; d.w = Wdt; d.y = dts; d.M = D; d.K = R; d.P = L; d.G = 4; d.GX = 4;
+    d.xsb = 4 * C * l; d.xsg = C * l; d.xsk = l; d.wsg = (int64_t)D * R; d.wsm = R; d.wsk = 1;
+    d.ysb = 4 * D * l; d.ysg = D * l; d.ysm = l;
+    return gemm_f32(d, B, s);
+}
+// dxdbl[b, k][:R] = Wdt[k]^T ddts[b, k];  dx2[b, j] = Wx[j]^T dxdbl[b, j] + Wx[j + 2]^T dxdbl[b, j + 2] (+ du[b, j] + du[b, j + 2])
+int proj_dgrad_f32(const float *ddts, float *dxdbl, const float *du, const float *Wx, const float *Wdt, float *dx2, int B, int D, int C,
+                   int R, int L, hipStream_t s) {
+    const int64_t l = L;
+    F32Gemm t{};
+    t.x = ddts; t.w = Wdt; t.y = dxdbl; t.M = R; t.K = D; t.P = L; t.G = 4; t.GX = 4;
+    t.xsb = 4 * D * l; t.xsg = D * l; t.xsk = l; t.wsg = (int64_t)D * R; t.wsm = 1; t.wsk = R;
+    t.ysb = 4 * C * l; t.ysg = C * l; t.ysm = l;
+    int e = gemm_f32(t, B, s);
+    if (e) return e;
+    for (int kk = 0; kk < 2; ++kk) {   // directions j (kk = 0) and j + 2 (kk = 1) of flattening j, the second pass accumulates
+        F32Gemm a{};
+        a.x = dxdbl + kk * 2 * C * l; a.w = Wx + kk * 2 * (int64_t)C * D; a.y = dx2;
+        a.res = du ? du + kk * 2 * D * l : nullptr;
+        a.M = D; a.K = C; a.P = L; a.G = 2; a.GX = 2; a.accumulate = kk;
+        a.xsb = 4 * C * l; a.xsg = C * l; a.xsk = l; a.wsg = (int64_t)C * D; a.wsm = 1; a.wsk = D;
+        a.ysb = 2 * D * l; a.ysg = D * l; a.ysm = l; a.rsb = 4 * D * l; a.rsg = D * l; a.rsm = l;
+        e = gemm_f32(a, B, s);
+        if (e) return e;
     }
-    return (int)hipGetLastError();
+    return 0;
 }
 
 // ---- weight gradient (and every other "rows x rows over pixels" product) ------------------------------------------------------
@@ -155,7 +266,7 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int U = 2;   // 8-pixel steps whose loads are issued together
+    constexpr int U = (TM + TN <= 2) ? 8 : 4;   // 8-pixel steps whose loads are issued together (each wave is often alone on its SIMD)
     for (int p = pbeg; p < pend; p += 8 * U) {
         f32x4 av[U][TM], bv[U][TN];
 #pragma unroll
@@ -174,6 +285,7 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
                 if (!(ok && bok[j])) bv[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // all loads of the round in flight before the first MFMA
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -232,7 +344,7 @@ int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int
     const int slabs = rows_f32_wgrad_slabs(P);
     // 64 x 32 tiles; 32 x 32 when the wider tile would leave most SIMDs without a wave
     const int t21 = ((M + 63) / 64) * ((N + 31) / 32), t11 = ((M + 31) / 32) * ((N + 31) / 32);
-    if ((long)t21 * slabs * B * G >= 768 && M > 32) {
+    if ((long)t21 * slabs * B * G >= 2048 && M > 32) {
         const dim3 grid(slabs, B * G, (t21 + 3) / 4);
         hipLaunchKernelGGL((oss_rows_f32_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn);
     } else {

@@ -4,6 +4,7 @@
 #include "../../include/vmambair_oss.h"
 
 #include <atomic>
+#include <initializer_list>
 
 namespace oss {
 struct bf16_t;
@@ -84,6 +85,11 @@ int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, floa
 // fp32 I/O on v_mfma_f32_32x32x2_f32 (oss_conv1x1_f32.hip)
 int conv1x1_f32(const float *x, const float *w, const float *bias, float *y, int B, int M, int K, int P, int64_t xsb, int64_t xsk,
                 int64_t wsm, int64_t wsk, hipStream_t s, const float *res);
+int proj_f32_ok(int B, int D, int C, int R, int L, std::initializer_list<const void *> ptrs);
+int proj_fwd_f32(const float *x2, const float *Wx, const float *Wdt, float *xdbl, float *dts, int B, int D, int C, int R, int L,
+                 hipStream_t s);
+int proj_dgrad_f32(const float *ddts, float *dxdbl, const float *du, const float *Wx, const float *Wdt, float *dx2, int B, int D, int C,
+                   int R, int L, hipStream_t s);
 size_t rows_f32_wgrad_partial_floats(int B, int G, int M, int N, int P);
 int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int B, int G, int GB, int M, int N, int P, int64_t asb,
                    int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, hipStream_t s);

@@ -801,6 +801,9 @@ int proj_fwd(oss_dtype io, const void *x2, const float *Wx, const float *Wdt, vo
     if (proj_mfma_ok(io, B, D, C, R, L))
         return io == OSS_BF16 ? proj_fwd_mfma_t<bf16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s)
                               : proj_fwd_mfma_t<f16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
+    if (io == OSS_F32 && dts && !g_proj_force_valu && proj_f32_ok(B, D, C, R, L, {x2, xdbl, dts}))   // (round 4) fp32 matrix cores
+        return proj_fwd_f32(reinterpret_cast<const float *>(x2), Wx, Wdt, reinterpret_cast<float *>(xdbl), reinterpret_cast<float *>(dts),
+                            B, D, C, R, L, s);
     switch (io) {
         case OSS_F32: return proj_fwd_t<float>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
         case OSS_F16: return proj_fwd_t<f16_t>(x2, Wx, Wdt, xdbl, dts, B, D, C, R, L, s);
@@ -815,6 +818,9 @@ int proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, cons
     if (proj_mfma_ok(io, B, D, C, R, L))
         return io == OSS_BF16 ? proj_dgrad_mfma_t<bf16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s)
                               : proj_dgrad_mfma_t<f16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);
+    if (io == OSS_F32 && ddts && !g_proj_force_valu && proj_f32_ok(B, D, C, R, L, {ddts, dxdbl, du, dx2}))
+        return proj_dgrad_f32(reinterpret_cast<const float *>(ddts), reinterpret_cast<float *>(dxdbl), reinterpret_cast<const float *>(du),
+                              Wx, Wdt, reinterpret_cast<float *>(dx2), B, D, C, R, L, s);
     switch (io) {
         case OSS_F32: return proj_dgrad_t<float>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);
         case OSS_F16: return proj_dgrad_t<f16_t>(ddts, dxdbl, du, Wx, Wdt, dx2, B, D, C, R, L, s);

@@ -30,6 +30,9 @@ def conv1x1_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     if residual is not None:
         _check(tuple(residual.shape) == (B, Cout, H, W), "conv1x1: residual must have the output's shape")
         residual = residual.to(x.dtype).contiguous()
+    if x.dtype == torch.float32 and CONV1X1_F32_WGRAD_ONLY:
+        y = torch.nn.functional.conv2d(x, weight.detach().float(), b)
+        return y if residual is None else y + residual
     y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
     if x.numel() == 0:
         return y
@@ -68,8 +71,11 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
             _keep_operands(dy, x)
             if has_bias and db is None:
                 db = dy.sum(dim=(0, 2, 3))
-        _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
-                                          dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
+        if f32 and CONV1X1_F32_WGRAD_ONLY:
+            dx = torch.nn.functional.conv_transpose2d(dy, weight.detach().float())
+        else:
+            _capi.check(lib.oss_conv1x1_dgrad(_DT[x.dtype], dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, Cout, Cin, P,
+                                              dy.stride(0), dy.stride(1), torch.cuda.current_stream().cuda_stream), "oss_conv1x1_dgrad")
     return [dx, dw.view(Cout, Cin, 1, 1), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 
@@ -98,8 +104,10 @@ def f32_ok(t: torch.Tensor) -> bool:
     return (t.shape[2] * t.shape[3]) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0
 
 
-#: ``VMAMBAIR_CONV1X1_F32=0`` keeps fp32 activations on the vendor convolution (rounds 1-3; A-B timing)
-CONV1X1_F32 = os.environ.get("VMAMBAIR_CONV1X1_F32", "1") == "1"
+#: ``VMAMBAIR_CONV1X1_F32=0`` keeps fp32 activations on the vendor convolution (rounds 1-3; A-B timing); ``=wgrad``: the in-tree
+#: kernel for the weight gradient only, forward and input gradient on the vendor's NCHW GEMM (A-B timing)
+CONV1X1_F32 = os.environ.get("VMAMBAIR_CONV1X1_F32", "1") != "0"
+CONV1X1_F32_WGRAD_ONLY = os.environ.get("VMAMBAIR_CONV1X1_F32", "1") == "wgrad"
 
 #: "mfma" (default) or "vendor".  16-bit activations go to the in-tree MFMA kernels (pixel-pair tiles: 4-byte
 #: activation loads and result stores, fp32 master weights narrowed in the loader, split-K weight gradient):
