@@ -21,6 +21,22 @@
 namespace oss {
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// Out-of-range operands are loaded from a clamped (valid) address and zeroed with a bit mask: a `cond ? load : 0` makes hipcc branch
+// around the load and end the branch with s_waitcnt vmcnt(0) -- every load its own memory round trip (checked in the ISA:
+// `L j L w0` per k-step; DESIGN.md 4.4 rule 6).
+// ... and masking the loaded value right away would make the round's MFMAs wait for the NEXT round's loads; instead an operand
+// that must read as zero is loaded FROM a zero quad: the predicate goes into the address (two selects), nothing touches the value.
+// (The select is done on integers and the result is read through an explicit global-address-space pointer: selecting between a
+// kernel-argument pointer and the address of a __device__ variable as C++ pointers yields a FLAT pointer, flat loads count in
+// both wait counters, and the compiler then waits vmcnt(0) before every MFMA round.)
+__device__ const float g_zero_quad[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+typedef const f32x4 __attribute__((address_space(1))) *GlobalQuadPtr;
+typedef const float __attribute__((address_space(1))) *GlobalFloatPtr;
+__device__ __forceinline__ uintptr_t addr_or_zero(const float *p, bool ok) {
+    return ok ? reinterpret_cast<uintptr_t>(p) : reinterpret_cast<uintptr_t>(&g_zero_quad[0]);
+}
+__device__ __forceinline__ f32x4 quad_or_zero(const float *p, bool ok) { return *reinterpret_cast<GlobalQuadPtr>(addr_or_zero(p, ok)); }
+__device__ __forceinline__ float float_or_zero(const float *p, bool ok) { return *reinterpret_cast<GlobalFloatPtr>(addr_or_zero(p, ok)); }
 
 // ---- forward / input gradient -------------------------------------------------------------------------------------------------
 // Y[b][g][m][p] = sum_k W[g](m, k) X[b][g % GX][k][p] (+ bias[m]) (+ res[b][g][m][p]) (+ the old Y: accumulate)
@@ -69,30 +85,43 @@ oss_conv1x1_f32_kernel(const F32Gemm a_) {
         mok[t] = m < M;
         wr[t] = wb + (int64_t)(mok[t] ? m : 0) * a.wsm;
     }
-    constexpr int U = SPLIT ? 4 : (MT == 1 ? 4 : 2);   // k-steps whose loads are issued together
-    for (int k0 = kbeg; k0 < K; k0 += 2 * U) {
-        f32x4 xv[U];
-        float av[U][MT];
+    // Rounds of U k-steps: the loads of round r + 1 are issued BEFORE the MFMAs of round r (two register sets), so that a wave
+    // alone on its SIMD still keeps the matrix pipe busy across the ~1.5 us a load round trip takes under load (the first version
+    // issued a round's loads, waited, then ran its MFMAs: 57 us per 1x1 convolution against ~15 us of matrix time).
+    constexpr int U = MT == 1 ? 4 : 2;
+    auto load_round = [&](int k0, f32x4 (&xv)[U], float (&av)[U][MT]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 2 * u + kg;
             const bool kok = k < K;
             const int kc = kok ? k : 0;
-            xv[u] = *reinterpret_cast<const f32x4 *>(xb + (int64_t)kc * a.xsk);
-            if (!(kok && pok)) xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xv[u] = quad_or_zero(xb + (int64_t)kc * a.xsk, kok && pok);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const float v = wr[t][(int64_t)kc * a.wsk];
-                av[u][t] = (kok && mok[t]) ? v : 0.f;
-            }
+            for (int t = 0; t < MT; ++t) av[u][t] = float_or_zero(wr[t] + (int64_t)kc * a.wsk, kok && mok[t]);
         }
-        __builtin_amdgcn_sched_barrier(0);   // every load of the round is issued before its first MFMA (the scheduler otherwise pairs them up)
+    };
+    auto mfma_round = [&](const f32x4 (&xv)[U], const float (&av)[U][MT]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[t][q] = mfma_f32(av[u][t], xv[u][q], acc[t][q]);
+    };
+    f32x4 xa[U], xc[U];
+    float aa[U][MT], ac[U][MT];
+    // The prefetches are UNCONDITIONAL (a round past K reads the zero quad): behind a branch the compiler cannot count on them
+    // being in flight and falls back to waiting for (nearly) everything before the round's first MFMA (checked in the ISA).
+    load_round(kbeg, xa, aa);
+    for (int k0 = kbeg; k0 < K; k0 += 4 * U) {
+        load_round(k0 + 2 * U, xc, ac);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_round(xa, aa);
+        __builtin_amdgcn_sched_barrier(0);
+        load_round(k0 + 4 * U, xa, aa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 2 * U < K) mfma_round(xc, ac);
+        __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SPLIT) {
         extern __shared__ __attribute__((aligned(16))) float red[];   // [3 waves][MT * 16 quads][64 lanes][4]
@@ -120,24 +149,43 @@ oss_conv1x1_f32_kernel(const F32Gemm a_) {
     float *yb = a.y + b * a.ysb + g * a.ysg + p0;
     const float *rb = a.res ? a.res + b * a.rsb + g * a.rsg + p0 : nullptr;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < MT; ++t) {
+        // what the epilogue adds (skip connection, the previous pass of an accumulating call) is fetched as ONE group of loads per
+        // row tile -- a load per row behind its own branch was sixteen serial round trips
+        f32x4 add[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float bv = float_or_zero(a.bias + m, m < M);
+                add[r] = f32x4{bv, bv, bv, bv};
+            }
+        }
+        if (rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const f32x4 rv = quad_or_zero(rb + (int64_t)m * a.rsm, m < M);
+                add[r].x += rv.x; add[r].y += rv.y; add[r].z += rv.z; add[r].w += rv.w;
+            }
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const f32x4 ov = quad_or_zero(yb + (int64_t)m * a.ysm, m < M);
+                add[r].x += ov.x; add[r].y += ov.y; add[r].z += ov.z; add[r].w += ov.w;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (m < M) {
-                const float bv = a.bias ? a.bias[m] : 0.f;
-                f32x4 o = {acc[t][0][r] + bv, acc[t][1][r] + bv, acc[t][2][r] + bv, acc[t][3][r] + bv};
-                if (rb) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4 *>(rb + (int64_t)m * a.rsm);
-                    o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-                }
-                if (a.accumulate) {
-                    const f32x4 ov = *reinterpret_cast<const f32x4 *>(yb + (int64_t)m * a.ysm);
-                    o.x += ov.x; o.y += ov.y; o.z += ov.z; o.w += ov.w;
-                }
-                *reinterpret_cast<f32x4 *>(yb + (int64_t)m * a.ysm) = o;
-            }
+            const f32x4 o = {acc[t][0][r] + add[r].x, acc[t][1][r] + add[r].y, acc[t][2][r] + add[r].z, acc[t][3][r] + add[r].w};
+            if (m < M) *reinterpret_cast<f32x4 *>(yb + (int64_t)m * a.ysm) = o;
         }
+    }
 }
 
 static bool f32_aligned(std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
@@ -266,9 +314,9 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int U = (TM + TN <= 2) ? 8 : 4;   // 8-pixel steps whose loads are issued together (each wave is often alone on its SIMD)
-    for (int p = pbeg; p < pend; p += 8 * U) {
-        f32x4 av[U][TM], bv[U][TN];
+    // rounds of U 8-pixel steps, the next round's loads in flight during the current round's MFMAs (two register sets)
+    constexpr int U = (TM + TN <= 2) ? 4 : 2;
+    auto load_round = [&](int p, f32x4 (&av)[U][TM], f32x4 (&bv)[U][TN]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int pp = p + 8 * u;
@@ -276,16 +324,15 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
             const int pc = ok ? pp + 4 * kg : pbeg;   // (a quad past the end reads the slab's first one and is zeroed)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                av[u][i] = *reinterpret_cast<const f32x4 *>(ar[i] + pc);
-                if (!(ok && aok[i])) av[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                av[u][i] = quad_or_zero(ar[i] + pc, ok && aok[i]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bv[u][j] = *reinterpret_cast<const f32x4 *>(br[j] + pc);
-                if (!(ok && bok[j])) bv[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bv[u][j] = quad_or_zero(br[j] + pc, ok && bok[j]);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // all loads of the round in flight before the first MFMA
+    };
+    auto mfma_round = [&](const f32x4 (&av)[U][TM], const f32x4 (&bv)[U][TN]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -294,6 +341,18 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[i][j] = mfma_f32(av[u][i][q], bv[u][j][q], acc[i][j]);
+    };
+    f32x4 a0[U][TM], b0[U][TN], a1[U][TM], b1[U][TN];
+    load_round(pbeg, a0, b0);   // (prefetches unconditional, rounds past the slab read the zero quad: see the GEMM kernel)
+    for (int p = pbeg; p < pend; p += 16 * U) {
+        load_round(p + 8 * U, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_round(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_round(p + 16 * U, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p + 8 * U < pend) mfma_round(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float *pb = part + ((size_t)(b * gridDim.x + slab) * G + g) * M * N;
 #pragma unroll
@@ -344,7 +403,7 @@ int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int
     const int slabs = rows_f32_wgrad_slabs(P);
     // 64 x 32 tiles; 32 x 32 when the wider tile would leave most SIMDs without a wave
     const int t21 = ((M + 63) / 64) * ((N + 31) / 32), t11 = ((M + 31) / 32) * ((N + 31) / 32);
-    if ((long)t21 * slabs * B * G >= 2048 && M > 32) {
+    if ((long)t21 * slabs * B * G >= 1024 && M > 32) {
         const dim3 grid(slabs, B * G, (t21 + 3) / 4);
         hipLaunchKernelGGL((oss_rows_f32_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn);
     } else {
