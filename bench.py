@@ -166,8 +166,10 @@ def bench_realsr_tiled(args):
     if recs:
         dom = max(recs, key=lambda r: r["total_ms"])
         ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+        kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}" + (" segmented" if dom["segmented"] else "")
+        traffic, traffic_note, _ = pmc_lookup(lib, kkey)
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": None, "kernel": f"{dom['kernel']} variant {dom['variant']} io {dom['io']}" + (" segmented" if dom["segmented"] else ""),
+                "traffic": traffic, "traffic_note": traffic_note, "kernel": kkey,
                 "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches": dom["launches"],
                 "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
                 "segments": {"fwd_last_call": int(lib.oss_scan_last_segments(0))},
@@ -230,9 +232,17 @@ def bench_srgan_split64(args):
 def pmc_lookup(lib, kkey):
     """HBM bytes per launch of kernel ``kkey`` from the PMC record under profiles/ (separate rocprofv3 --pmc passes,
     tools/pmc_traffic.sh + tools/pmc_record.py) -- only when the record was measured on THIS build of the scan kernels
-    (``oss_scan_build_id()``); a record of another build is reported as stale, never silently (VERDICT r2 #10)."""
+    (``oss_scan_build_id()``); a record of another build is reported as stale, never silently.
+    Time-segmented calls are two launches (the profiler bucket times both): the local / carry pass is added to the main one."""
     prof_dir = os.path.join(ROOT, "profiles")
     build = lib.oss_scan_build_id().decode()
+    extra = []
+    if kkey.endswith(" segmented"):
+        io = kkey.split(" io ")[1].split()[0]
+        if "fwd" in kkey:
+            extra = [kkey.replace(" segmented", " local pass")]
+        else:
+            extra = [f"oss_scan_bwd_carry_kernel rows 12 io {io}"]
     try:
         names = sorted((f for f in os.listdir(prof_dir) if f.endswith("pmc_traffic.json")), reverse=True)
         for f in names:
@@ -243,9 +253,11 @@ def pmc_lookup(lib, kkey):
                 return None, (f"stale: profiles/{f} was measured on scan-kernel build {rec.get('_build_id', '(unrecorded)')}, "
                               f"this library is {build}"), None
             e = rec[kkey]
-            return int(e["fetch_bytes"] + e["write_bytes"]), \
-                f"FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes, build {build} [profiles/{f}]", \
-                e.get("valu_busy", e.get("valu_active_share_of_wave_cycles"))
+            total = int(e["fetch_bytes"] + e["write_bytes"]) + sum(int(rec[k]["fetch_bytes"] + rec[k]["write_bytes"]) for k in extra if k in rec)
+            note = f"FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes, build {build} [profiles/{f}]"
+            if extra:
+                note += "; main + " + ("local" if "fwd" in kkey else "carry") + " pass, at " + str(e.get("shape", ""))
+            return total, note, e.get("valu_busy", e.get("valu_active_share_of_wave_cycles"))
     except (OSError, ValueError, KeyError):
         pass
     return None, "no PMC record for this kernel", None
@@ -352,8 +364,9 @@ def secondary_workloads():
             roof = j.get("roofline") or {}
             out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
                          "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "workload": j["config"]["workload"],
-                         "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
-                                                                "launches", "alg_bytes_per_launch", "frac_with_finish", "segments")},
+                         "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_note",
+                                                                "avg_launch_ms", "launches", "alg_bytes_per_launch", "frac_with_finish",
+                                                                "segments")},
                          "seconds": round(time.time() - t0, 1)}
             if name == "realsr_tiled":
                 out[name]["tiles_per_s"] = j["config"].get("tiles_per_s")
@@ -516,6 +529,10 @@ def main():
     lib.oss_prof_enable(0)
     log(f"timed {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.item())
+    # peak device memory of the captured step (graph pool included) and what the deferred weight gradients held (ADVICE r3:
+    # recorded products keep both operands alive until the grouped launch; bounded by VMAMBAIR_WGRAD_KEEP_MB, ops/_common.py)
+    peak_mem_gb = round(torch.cuda.max_memory_allocated(dev) / 1e9, 3)
+    wgrad_stats = getattr(step, "wgrad_stats", None) if args.graph else None
     allreduce_ms = step.collect_allreduce_ms() if (args.graph and world > 1) else None
     prof_note = "HIP events around every scan kernel launch inside the timed region"
     if args.graph and args.skip_roofline:
@@ -636,7 +653,12 @@ def main():
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "allreduce_overlapped": False,
-                       "allreduce_bytes": 4 * sum(p.numel() for p in net.parameters()) if world > 1 else 0},
+                       "allreduce_bytes": 4 * sum(p.numel() for p in net.parameters()) if world > 1 else 0,
+                       "peak_memory_GB": peak_mem_gb,
+                       "deferred_weight_gradients": None if not wgrad_stats else {
+                           "grouped_launches": wgrad_stats.get("grouped_launches"), "budget_flushes": wgrad_stats.get("budget_flushes"),
+                           "operands_held_GB_max": round(wgrad_stats.get("held_bytes_max", 0) / 1e9, 3),
+                           "budget_GB": round(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "4096")) / 1024, 2)}},
             "final_loss": round(loss_val, 5), "roofline": roof, "cpu_baseline": cpu, "secondary": second,
         }
         print(json.dumps(line), flush=True)
