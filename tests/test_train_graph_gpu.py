@@ -305,3 +305,57 @@ def test_two_rank_rccl_step_equals_single_process_whole_batch():
         step(blob["lq"].to(DEV), blob["gt"].to(DEV))     # whole batch of 4: mean loss = mean of the two rank means
     for p, q in zip(net.parameters(), blob["params"]):
         assert float((p.detach().cpu() - q).abs().max()) <= 2 * 2e-4 * 2 + 1e-5
+
+
+def test_resume_from_a_reference_style_state_needs_the_ema_weights(tmp_path):
+    """a ``.state`` file as the REFERENCE writes it has no EMA weights (they live in ``net_g_<iter>.pth`` under
+    ``params_ema``, Deraining/basicsr/models/base_model.py:234-244,312-334).  ``resume_training`` must not continue silently from
+    freshly initialised EMA weights: it raises unless ``ema_from`` names that checkpoint -- and then restores them by name"""
+    from vmambair_amd import checkpoint
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(4)
+    lq, gt = torch.rand(2, 3, 16, 16, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+
+    def fresh():
+        torch.manual_seed(12)
+        return MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    net_b = fresh()
+    b = GraphedTrainStep(net_b, autocast_dtype=None, warmup=1)
+    for _ in range(3):
+        b(lq, gt)
+    sd = b.state_dict()
+    ref_state = {"epoch": 0, "iter": 3, "optimizers": sd["optimizers"], "schedulers": [{"last_epoch": 2}]}   # no 'ema'
+    names = [n for n, p in net_b.named_parameters() if p.requires_grad]
+    wpath = str(tmp_path / "net_g_3.pth")
+    torch.save({"params": net_b.state_dict(), "params_ema": {**net_b.state_dict(), **{n: e.clone() for n, e in zip(names, b.ema)}}}, wpath)
+    net_c = fresh()
+    checkpoint.load_network(net_c, wpath, strict=True)
+    c = GraphedTrainStep(net_c, autocast_dtype=None, warmup=1)
+    with pytest.raises(ValueError, match="params_ema"):
+        checkpoint.resume_training(c, ref_state)
+    assert checkpoint.resume_training(c, ref_state, ema_from=wpath) == {"epoch": 0, "iter": 3}
+    for e1, e2 in zip(b.ema, c.ema):
+        assert torch.equal(e1, e2)
+    d = GraphedTrainStep(fresh(), autocast_dtype=None, warmup=1, ema_decay=0.0)      # a step without EMA weights takes the file as it is
+    assert checkpoint.resume_training(d, ref_state)["iter"] == 3
+
+
+def test_train_loop_drives_the_schedule_and_saves_states(tmp_path):
+    """``checkpoint.train_loop``: current_iter += 1, schedule(current_iter) -> set_lr BEFORE the step (update_learning_rate,
+    base_model.py:183-205), a training state every ``save_every`` iterations"""
+    from vmambair_amd import checkpoint, lr_schedule
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(5)
+    net = MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    step = GraphedTrainStep(net, autocast_dtype=None, warmup=1)
+    lq, gt = torch.rand(2, 3, 16, 16, device=DEV), torch.rand(2, 3, 64, 64, device=DEV)
+    seen = []
+    sched = lambda it: lr_schedule.multistep(it, 2e-4, [3, 5], 0.5)   # noqa: E731
+    last = checkpoint.train_loop(step, [(lq, gt)] * 10, sched, total_iters=6, save_every=2, states_dir=str(tmp_path),
+                                 on_iter=lambda it, loss: seen.append((it, step.lr, float(loss))))
+    assert last == 6 and step.iteration == 6
+    assert [round(lr / 2e-4, 3) for _, lr, _ in seen] == [1.0, 1.0, 1.0, 0.5, 0.5, 0.25]   # milestones at last_epoch 3 and 5
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["2.state", "4.state", "6.state"]
+    assert all(torch.isfinite(torch.tensor(l)) for _, _, l in seen)

@@ -121,7 +121,8 @@ def save_training_state(step, states_dir: str, epoch: int, current_iter: int) ->
     ``state_dict()`` returning ``{'iter', 'optimizers', 'ema'}``).  The optimizer entry has ``torch.optim.Adam(W)``'s layout
     (vmambair_amd/optim.py), so the reference's ``resume_training`` can load it into its torch optimizer and this module can
     load a ``.state`` file the reference wrote.  ``schedulers`` holds the one thing a closed-form schedule needs -- the
-    iteration -- in ``_LRScheduler.state_dict()``'s field name (``last_epoch`` = iterations stepped so far = iter - 1 + 1)."""
+    iteration -- in ``_LRScheduler.state_dict()``'s field name: ``last_epoch`` = scheduler steps taken so far = ``iter - 1`` (the
+    reference steps its scheduler before every iteration but the first, base_model.py:183-193)."""
     if current_iter == -1:
         return None
     sd = step.state_dict()
@@ -135,13 +136,53 @@ def save_training_state(step, states_dir: str, epoch: int, current_iter: int) ->
     return path
 
 
-def resume_training(step, resume_state: Union[str, dict]) -> dict:
+def resume_training(step, resume_state: Union[str, dict], ema_from: Optional[str] = None) -> dict:
     """``BaseModel.resume_training`` (base_model.py:336-351) + the iteration bookkeeping of ``train.py`` (:176-190): puts the
-    optimizer moments, step count, learning rate (and EMA weights when the file has them) back -> ``{'epoch', 'iter'}``
-    to continue from.  ``resume_state``: a path or the loaded dict."""
+    optimizer moments, step count and learning rate back -> ``{'epoch', 'iter'}`` to continue from.  ``resume_state``: a path
+    or the loaded dict.
+
+    EMA weights: a ``.state`` file written by THIS package carries them (``'ema'``); one written by the reference does not -- the
+    reference keeps its EMA net in the network checkpoint (``params_ema`` of ``net_g_<iter>.pth``, base_model.py:234-244) and
+    restores it through ``load_network``.  For a step that tracks EMA weights such a file therefore needs ``ema_from`` = that
+    ``.pth`` (its ``params_ema`` is loaded into the step's EMA tensors by parameter name); without it this raises instead of
+    silently continuing from freshly initialised EMA weights."""
     if isinstance(resume_state, str):
         resume_state = torch.load(resume_state, map_location="cpu", weights_only=False)
     opts = resume_state["optimizers"]
     assert len(opts) == 1, "Wrong lengths of optimizers"   # the reference's own assertion (base_model.py:344-345)
-    step.load_state_dict({"iter": resume_state["iter"], "optimizers": opts, "ema": resume_state.get("ema")})
+    ema = resume_state.get("ema")
+    tracks_ema = getattr(step, "ema", None) is not None
+    if ema is None and tracks_ema:
+        if ema_from is None:
+            raise ValueError("the training state has no 'ema' entry (a .state file written by the reference: its EMA weights live in "
+                             "net_g_<iter>.pth as 'params_ema'); pass ema_from=<that .pth>, or build the step with ema_decay=0")
+        blob = read_state(ema_from, "params_ema")
+        names = [n for n, p in bare_model(step.net).named_parameters() if p.requires_grad]
+        missing = [n for n in names if n not in blob]
+        if missing:
+            raise KeyError(f"{ema_from}: params_ema lacks {len(missing)} parameters, e.g. {missing[:3]}")
+        ema = [blob[n].detach().clone() for n in names]
+    step.load_state_dict({"iter": resume_state["iter"], "optimizers": opts, "ema": ema})
     return {"epoch": int(resume_state["epoch"]), "iter": int(resume_state["iter"])}
+
+
+def train_loop(step, batches, schedule, start_iter: int = 0, total_iters: Optional[int] = None, save_every: int = 0,
+               states_dir: Optional[str] = None, epoch: int = 0, on_iter=None) -> int:
+    """The reference's inner training loop (Deraining/basicsr/train.py:226-271, SRGAN/VmambaIR/train.py) around a
+    ``GraphedTrainStep``: for every batch, ``current_iter += 1``; the schedule is evaluated at that iteration and handed to
+    ``step.set_lr`` BEFORE the step (``update_learning_rate(current_iter)``, base_model.py:183-205) -- this is the caller of
+    ``lr_schedule.py`` and ``set_lr`` -- then the optimisation step; every ``save_every`` iterations the training state is
+    written.  ``batches``: an iterable of ``(lq, gt)``; ``schedule``: ``iteration -> learning rate`` (e.g.
+    ``lambda it: lr_schedule.multistep(it, 2e-4, [50000, 70000], 0.5)``).  -> the last iteration run."""
+    it = int(start_iter)
+    for lq, gt in batches:
+        if total_iters is not None and it >= total_iters:
+            break
+        it += 1
+        step.set_lr(float(schedule(it)))
+        loss = step(lq, gt)
+        if on_iter is not None:
+            on_iter(it, loss)
+        if save_every and states_dir and it % save_every == 0:
+            save_training_state(step, states_dir, epoch, it)
+    return it
