@@ -346,3 +346,27 @@ def test_split_halves_gradients_land_in_one_buffer(oracle_cpu_kernel):
     finally:
         blk.split_halves = keep
     assert torch.allclose(x2.grad, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_flops_counter_follows_the_reference_rules(oracle_cpu_kernel):
+    """``net.flops()`` (counterpart of MambaSISR6_arch.py:101-138,646-664 without fvcore): the scan term is the reference's
+    9 B L D N + B D L per call, convolutions count one flop per multiply-accumulate, the string has the reference's format"""
+    from vmambair_amd.archs import MambaSISR6
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1)
+    s = net.flops((3, 16, 16))
+    assert s.startswith("params(M) ") and " GFLOPs " in s
+    t = net.flops_table
+    # scans by hand: block widths d = 8, 16, 32, 64, 32, 16, 16, 16 at 16^2, 8^2, 4^2, 2^2, 4^2, 8^2, 16^2, 16^2 pixels
+    from vmambair_amd.oss_block import SS2D_1
+    ratio = {m.d_inner // m.d_model for m in net.modules() if isinstance(m, SS2D_1)}
+    assert len(ratio) == 1
+    want = 0
+    for d, hw in ((8, 16), (16, 8), (32, 4), (64, 2), (32, 4), (16, 8), (16, 16), (16, 16)):
+        L, D = hw * hw, ratio.pop() * d if False else next(iter(ratio)) * d
+        want += 9 * L * 4 * D * 16 + 4 * D * L              # spatial: one call, D = 4 d_inner
+        want += 9 * D * (2 * 4) * 16 + (2 * 4) * D           # channel: L = d_inner, D = 2 dc_inner (dc_inner = 4)
+    assert abs(t["scan"] * 1e9 - want) < 1, (t["scan"] * 1e9, want)
+    # patch_embed alone: 16 * 16 outputs x 8 channels x 3 x 9 MACs
+    assert t["conv"] * 1e9 > 16 * 16 * 8 * 27 and t["proj"] > 0
+    assert float(s.split("GFLOPs ")[1]) == pytest.approx(sum(t.values()), rel=1e-12)

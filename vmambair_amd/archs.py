@@ -88,6 +88,54 @@ class _OSSUNet(nn.Module):
         self.decoder_level1 = stage(d2, num_blocks[0], heads[0])
         self.refinement = stage(d2, num_refinement_blocks, heads[0])
 
+    def flops(self, shape=(3, 64, 64)) -> str:
+        """Counterpart of the reference's ``flops()`` (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:101-138,646-664: fvcore's
+        ``flop_count`` with a handler that prices every ``SelectiveScan`` call at ``9 B L D N + B D L``) without fvcore -- the same
+        counting rules applied to the shapes this net's layers see for one ``(1, *shape)`` input: a multiply-accumulate is one flop
+        (fvcore's convention for convolutions / einsums), elementwise ops, norms, activations, flips and shuffles are ignored, the
+        six scans of an OSS module (four spatial directions as ONE call with D = 4 d_inner, two channel directions with
+        D = 2 dc_inner) by the reference's formula.  -> ``"params(M) <p> GFLOPs <g>"`` (the reference's format); ``flops_table``
+        holds the per-kind breakdown.  fvcore is not in the build image, so the total is not pinned against the reference's
+        printout (BASELINE.md quotes only the scan term)."""
+        from .oss_block import SS2D_1
+        tally = {"conv": 0, "proj": 0, "scan": 0}
+        hooks = []
+
+        def conv_hook(m, inp, out):
+            tally["conv"] += out.numel() * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+
+        def ss2d_hook(m, inp, out):
+            b, _, h, w = inp[0].shape
+            L, D, R, N = h * w, m.d_inner, m.dt_rank, m.d_state
+            tally["proj"] += b * 4 * L * D * (R + 2 * N) + b * 4 * L * D * R                      # x_proj, dt_proj einsums
+            tally["scan"] += 9 * b * L * (4 * D) * N + b * (4 * D) * L                            # flops_selective_scan_fn
+            dc = m.dc_inner if m.dc_inner is not None else 1
+            Rc, Nc, Lc = m.dtc_rank, m.dc_state, D                                               # channel branch: L = d_inner
+            tally["proj"] += b * 2 * Lc * dc * (Rc + 2 * Nc) + b * 2 * Lc * dc * Rc
+            tally["scan"] += 9 * b * Lc * (2 * dc) * Nc + b * (2 * dc) * Lc
+            if m.dc_inner is not None:                                                            # conv_cin / conv_cout on the (b, 1, d, 1) map
+                tally["conv"] += 2 * b * dc * Lc
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                hooks.append(mod.register_forward_hook(conv_hook))
+            elif isinstance(mod, SS2D_1):
+                hooks.append(mod.register_forward_hook(ss2d_hook))
+        try:
+            p0 = next(self.parameters())
+            with torch.no_grad():
+                was = self.training
+                self.eval()
+                self(torch.randn((1, *shape), device=p0.device, dtype=p0.dtype))
+                self.train(was)
+        finally:
+            for h_ in hooks:
+                h_.remove()
+        # the channel branch's 1-channel convolutions are applied as affine maps (no Conv2d forward): counted in ss2d_hook above;
+        # conv_cin / conv_cout modules therefore never fire the conv hook
+        params = sum(p.numel() for p in self.parameters())
+        self.flops_table = {k: v / 1e9 for k, v in tally.items()}
+        return f"params(M) {params / 1e6} GFLOPs {sum(tally.values()) / 1e9}"
+
     def body(self, inp_img: torch.Tensor) -> torch.Tensor:
         e1 = self.encoder_level1(self.patch_embed(inp_img))
         e2 = self.encoder_level2(self.down1_2(e1))
