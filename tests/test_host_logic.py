@@ -361,9 +361,10 @@ def test_flops_counter_follows_the_reference_rules(oracle_cpu_kernel):
     from vmambair_amd.oss_block import SS2D_1
     ratio = {m.d_inner // m.d_model for m in net.modules() if isinstance(m, SS2D_1)}
     assert len(ratio) == 1
+    r = next(iter(ratio))          # d_inner / d_model of every OSS module of this net
     want = 0
     for d, hw in ((8, 16), (16, 8), (32, 4), (64, 2), (32, 4), (16, 8), (16, 16), (16, 16)):
-        L, D = hw * hw, ratio.pop() * d if False else next(iter(ratio)) * d
+        L, D = hw * hw, r * d
         want += 9 * L * 4 * D * 16 + 4 * D * L              # spatial: one call, D = 4 d_inner
         want += 9 * D * (2 * 4) * 16 + (2 * 4) * D           # channel: L = d_inner, D = 2 dc_inner (dc_inner = 4)
     assert abs(t["scan"] * 1e9 - want) < 1, (t["scan"] * 1e9, want)
