@@ -658,7 +658,7 @@ def main():
                        "deferred_weight_gradients": None if not wgrad_stats else {
                            "grouped_launches": wgrad_stats.get("grouped_launches"), "budget_flushes": wgrad_stats.get("budget_flushes"),
                            "operands_held_GB_max": round(wgrad_stats.get("held_bytes_max", 0) / 1e9, 3),
-                           "budget_GB": round(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "4096")) / 1024, 2)}},
+                           "budget_GB": round(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "8192")) / 1024, 2)}},
             "final_loss": round(loss_val, 5), "roofline": roof, "cpu_baseline": cpu, "secondary": second,
         }
         print(json.dumps(line), flush=True)

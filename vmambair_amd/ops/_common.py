@@ -52,8 +52,10 @@ DEFER_WGRADS = os.environ.get("VMAMBAIR_DEFER_WGRAD", "1") == "1"
 #: launch is queued, i.e. they are no longer released as the backward walks up the net.  The bytes so held are bounded: when
 #: they pass this budget the products recorded so far run as one grouped launch right away (``wgrad_flusher`` of
 #: ``deferred_finishes``) and their operands are released -- a handful of grouped launches instead of one keeps nearly all of
-#: the gain.  4 GiB never triggers at the headline shapes (batch 8: ~2.6 GB held); 0 = unbounded.
-WGRAD_KEEP_BUDGET = int(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "4096")) * (1 << 20))
+#: the gain.  8 GiB: the headline step (batch 8) stays ONE grouped launch (4 GiB made it two: 1.52 against 1.49 ms,
+#: profiles/r04_rocprof_bench_steady_state_v1_thin_conv.txt); what a step held is in the bench line
+#: (``deferred_weight_gradients``); 0 = unbounded.
+WGRAD_KEEP_BUDGET = int(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "8192")) * (1 << 20))
 _WGRAD_OPERANDS: Optional[list] = None
 _WGRAD_STORAGES: Optional[set] = None
 _WGRAD_HELD = 0            # bytes of distinct storages held for recorded products since the last grouped launch
