@@ -128,8 +128,9 @@ def bench_realsr_tiled(args):
     img = torch.rand(1, 3, 512, 512, device=dev)
     res = {}
     ref = None
-    for name, graph, bt in (("eager", False, 1), ("graph", True, 1), ("graph_4_tiles_stacked", True, 4)):
-        drv = RealSREnhancer(net, 4, tile=128, tile_pad=16, pre_pad=0, half=True, use_graph=graph, batch_tiles=bt)
+    for name, graph, bt, conc in (("eager", False, 1, False), ("graph", True, 1, False), ("graph_4_tiles_stacked", True, 4, False),
+                                  ("graph_4_tiles_stacked_shapes_side_by_side", True, 4, True)):
+        drv = RealSREnhancer(net, 4, tile=128, tile_pad=16, pre_pad=0, half=True, use_graph=graph, batch_tiles=bt, concurrent_shapes=conc)
         out = drv.enhance_tensor(img)   # capture / warm-up
         for _ in range(max(0, args.warmup - 1)):
             drv.enhance_tensor(img)
@@ -152,7 +153,7 @@ def bench_realsr_tiled(args):
         if ref is None:
             ref = out.float().clone()
         res[name] = {"s_per_image": round(dt, 4), "images_per_s": round(1.0 / dt, 3), "tiles_per_s": round(tiles / dt, 2),
-                     "tiles_per_image": tiles, "graphs": drv.tiled.n_graphs, "tiles_per_forward": bt,
+                     "tiles_per_image": tiles, "graphs": drv.tiled.n_graphs, "tiles_per_forward": bt, "shapes_side_by_side": conc,
                      "max_abs_diff_vs_eager": float((out.float() - ref).abs().max())}
     # roofline of the dominant scan kernel: the same tiles once more, eager, with the library's events on
     drv = RealSREnhancer(net, 4, tile=128, tile_pad=16, pre_pad=0, half=True, use_graph=False)

@@ -195,6 +195,15 @@ def test_realsr_enhancer_fp16_on_gpu_matches_cpu_twin():
     assert_close(got4, want, 3e-2, 3e-2, "tiled fp16 output, tiles stacked")
     assert_close(got4, got, 2e-2, 2e-2, "stacked against tile by tile")
     assert drv4.tiled.tiles_run == drv.tiled.tiles_run
+    # (round 4) the groups of different padded shapes replayed side by side, one HIP stream per shape: the same graphs and
+    # kernels in an overlapping order -- bit-identical image, on the capturing call and on the replaying ones
+    drv4c = RealSREnhancer(net_g, 4, tile=32, tile_pad=8, pre_pad=10, half=True, use_graph=True, batch_tiles=4, concurrent_shapes=True)
+    first = drv4c.enhance_tensor(img).clone()
+    for _ in range(3):
+        again = drv4c.enhance_tensor(img)
+        torch.cuda.synchronize()
+        assert torch.equal(again, first)
+    assert torch.equal(first, got4) and len(drv4c.tiled._streams) == drv4c.tiled.n_graphs > 1
 
 
 def test_tiles_stacked_on_the_batch_axis_give_the_same_image():

@@ -30,6 +30,14 @@ def tile_plan(height: int, width: int, tile: int, pad: int) -> Iterator[Tuple[in
             yield y0, y1, x0, x1, py0, py1, px0, px1
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 class TiledSR:
     """``out = TiledSR(net, scale)(img)``: ``img`` (B, C, H, W) -> (B, C, H*scale, W*scale), tile by tile.
 
@@ -37,13 +45,19 @@ class TiledSR:
     narrowed inside the kernels); ``use_graph``: capture one hipGraph per padded-tile shape (GPU only)."""
 
     def __init__(self, net: torch.nn.Module, scale: int = 4, tile: int = 128, tile_pad: int = 16,
-                 autocast_dtype: Optional[torch.dtype] = torch.float16, use_graph: bool = True, batch_tiles: int = 1):
+                 autocast_dtype: Optional[torch.dtype] = torch.float16, use_graph: bool = True, batch_tiles: int = 1,
+                 concurrent_shapes: bool = False):
         assert tile > 0 and tile_pad >= 0
         self.net, self.scale, self.tile, self.pad = net.eval(), scale, tile, tile_pad
         self.autocast_dtype, self.use_graph = autocast_dtype, use_graph
         # > 1: tiles of the same padded shape go through the net together, stacked on the batch axis (single-image input only).
         # The reference runs them one by one (utils.py:118-160); nothing in the nets mixes batch entries, so the result is the same.
         self.batch_tiles = max(1, int(batch_tiles))
+        # (round 4) with ``batch_tiles``: the groups of DIFFERENT padded shapes (corner / edge / interior: four at 512 x 512) are
+        # independent forwards, each too small to fill 256 CUs at batch 4 -- replay their graphs side by side, one HIP stream per
+        # shape, and join before the result is read.  Same graphs, same kernels, same results; only the launch order overlaps.
+        self.concurrent_shapes = bool(concurrent_shapes)
+        self._streams: Dict[Tuple[int, ...], torch.cuda.Stream] = {}
         self._graphs: Dict[Tuple[int, int, int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor, torch.Tensor]] = {}
         self.tiles_run = 0
 
@@ -88,19 +102,36 @@ class TiledSR:
             for t in tile_plan(H, W, self.tile, self.pad):
                 groups.setdefault((t[5] - t[4], t[7] - t[6]), []).append(t)
             graphed = self.use_graph and img.is_cuda
+            side = graphed and self.concurrent_shapes
+            main = torch.cuda.current_stream() if side else None
+            used = []
             for tiles in groups.values():
-                for k in range(0, len(tiles), self.batch_tiles):
-                    grp = tiles[k:k + self.batch_tiles]
-                    chops = [img[:, :, py0:py1, px0:px1] for (_, _, _, _, py0, py1, px0, px1) in grp]
-                    if graphed and len(grp) < self.batch_tiles:       # one graph per shape: pad the group with repeats
-                        chops = chops + [chops[-1]] * (self.batch_tiles - len(grp))
-                    o = self._run_tile(torch.cat(chops, 0).contiguous())
-                    self.tiles_run += len(grp) - 1
-                    if out is None:
-                        out = o.new_zeros((1, o.shape[1], H * s, W * s))
-                    for n, (y0, y1, x0, x1, py0, py1, px0, px1) in enumerate(grp):
-                        oy, ox = (y0 - py0) * s, (x0 - px0) * s
-                        out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[n:n + 1, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+                st = None
+                if side:
+                    shape_key = (tiles[0][5] - tiles[0][4], tiles[0][7] - tiles[0][6])
+                    if (self.batch_tiles, C, *shape_key) in self._graphs:   # (first call: captured on the main stream, sequentially)
+                        st = self._streams.setdefault(shape_key, torch.cuda.Stream(device=img.device))
+                        if out is None:   # the first group's output fixes dtype / channels: allocate before any side stream writes
+                            o0 = self._graphs[(self.batch_tiles, C, *shape_key)][2]
+                            out = o0.new_zeros((1, o0.shape[1], H * s, W * s))
+                        st.wait_stream(main)
+                        used.append(st)
+                ctx = torch.cuda.stream(st) if st is not None else _NullCtx()
+                with ctx:
+                  for k in range(0, len(tiles), self.batch_tiles):
+                      grp = tiles[k:k + self.batch_tiles]
+                      chops = [img[:, :, py0:py1, px0:px1] for (_, _, _, _, py0, py1, px0, px1) in grp]
+                      if graphed and len(grp) < self.batch_tiles:       # one graph per shape: pad the group with repeats
+                          chops = chops + [chops[-1]] * (self.batch_tiles - len(grp))
+                      o = self._run_tile(torch.cat(chops, 0).contiguous())
+                      self.tiles_run += len(grp) - 1
+                      if out is None:
+                          out = o.new_zeros((1, o.shape[1], H * s, W * s))
+                      for n, (y0, y1, x0, x1, py0, py1, px0, px1) in enumerate(grp):
+                          oy, ox = (y0 - py0) * s, (x0 - px0) * s
+                          out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[n:n + 1, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+            for st in used:   # join: whoever reads `out` next runs after every shape's stream
+                main.wait_stream(st)
             return out
         for y0, y1, x0, x1, py0, py1, px0, px1 in tile_plan(H, W, self.tile, self.pad):
             o = self._run_tile(img[:, :, py0:py1, px0:px1].contiguous())
@@ -137,12 +168,14 @@ class RealSREnhancer:
     conversion / alpha handling of ``enhance`` (cv2) stay with the caller.  Pinned by tests/golden/g6_tiles.npz."""
 
     def __init__(self, net: torch.nn.Module, scale: int, tile: int = 0, tile_pad: int = 10, pre_pad: int = 10,
-                 half: bool = False, use_graph: bool = True, device: Optional[torch.device] = None, batch_tiles: int = 1):
+                 half: bool = False, use_graph: bool = True, device: Optional[torch.device] = None, batch_tiles: int = 1,
+                 concurrent_shapes: bool = False):
         self.scale, self.tile_size, self.tile_pad, self.pre_pad, self.half = scale, tile, tile_pad, pre_pad, half
         self.device = device if device is not None else next(net.parameters(), torch.zeros(())).device
         acdt = torch.float16 if half else None
         graph = use_graph and torch.device(self.device).type == "cuda"
-        self.tiled = TiledSR(net, scale, tile=max(tile, 1), tile_pad=tile_pad, autocast_dtype=acdt, use_graph=graph, batch_tiles=batch_tiles)
+        self.tiled = TiledSR(net, scale, tile=max(tile, 1), tile_pad=tile_pad, autocast_dtype=acdt, use_graph=graph, batch_tiles=batch_tiles,
+                             concurrent_shapes=concurrent_shapes)
         self.whole = GraphedForward(net, acdt, use_graph=graph)
         self.mod_scale = None
         self.mod_pad_h = self.mod_pad_w = 0
