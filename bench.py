@@ -426,6 +426,9 @@ def main():
                          "all-reduce outside the graph for N > 1)")
     ap.add_argument("--skip-roofline", action="store_true",
                     help="graph mode: do not run the trailing eager steps that time the scan kernels (profiling runs)")
+    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("VMAMBAIR_MIOPEN_FIND", "0")),
+                    help="1: torch.backends.cudnn.benchmark = True -- the vendor library searches its solvers for the UNet skeleton's 3x3 "
+                         "convolutions during the warm-up (before the capture) instead of taking its heuristic's pick")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -437,6 +440,8 @@ def main():
     if args.config == "srgan-split64":
         return bench_srgan_split64(args)
 
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
