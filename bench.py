@@ -431,6 +431,11 @@ def main():
                          "convolutions during the warm-up (before the capture) instead of taking its heuristic's pick")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="N > 1 smoke run on a box with FEWER GPUs than ranks: every rank uses GPU (rank %% device_count) and the ranks talk "
+                         "over gloo instead of RCCL (RCCL refuses two ranks on one device).  Exercises the whole multi-rank flow of this "
+                         "script -- broadcast, two graphs, flat gradient all-reduce, max-over-ranks timing -- but NOT RCCL; its line is "
+                         "marked and is not a measurement")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
@@ -453,14 +458,19 @@ def main():
         return rendezvous_only(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP scan has no CPU path)")
-    if torch.cuda.device_count() < max(world, local_rank + 1):
+    if args.share_gpu:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    if torch.cuda.device_count() < (1 if args.share_gpu else max(world, local_rank + 1)):
         raise SystemExit(f"--gpus {world}: rank {rank} needs GPU {local_rank}, but only {torch.cuda.device_count()} GPU(s) are visible "
                          "on this node (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from vmambair_amd import _capi
     from vmambair_amd.archs import build_network
@@ -657,6 +667,8 @@ def main():
                                      "Adam 2e-4 (0.9,0.99) + EMA 0.999"), "loss": "L1",
                        # multi-GPU exchange: ONE flat fp32 all-reduce between the forward+backward graph and the optimizer graph
                        "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       **({"smoke_only": "--share-gpu: ranks share GPUs and talk over gloo -- flow check of the multi-rank path, not a measurement"}
+                          if args.share_gpu else {}),
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "allreduce_overlapped": False,
                        "allreduce_bytes": 4 * sum(p.numel() for p in net.parameters()) if world > 1 else 0,
