@@ -511,6 +511,7 @@ def main():
             for p_ in net.parameters():
                 dist.broadcast(p_.data, 0)
         step = GraphedTrainStep(net, autocast_dtype=acdt, micro_streams=args.micro_streams,
+                                split_graphs=os.environ.get("VMAMBAIR_BENCH_SPLIT", "0") == "1",   # A-B: the two-graph form of N > 1 on one rank
                                 overlap_wgrads=os.environ.get("VMAMBAIR_OVERLAP_WGRADS", "0") == "1", **opt_kw)
         log("capturing the training step")
         step.capture(lq, gt)
