@@ -29,6 +29,8 @@ micro-batch branches (``micro_streams``) are described at their code below and i
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Optional
 
 import torch
@@ -430,6 +432,16 @@ class GraphedTrainStep:
         self._activate(key)
         self.static_lq.copy_(lq, non_blocking=True)
         self.static_gt.copy_(gt, non_blocking=True)
+        if os.environ.get("VMAMBAIR_STEP_TRACE", "0") == "1" and self.split:   # diagnosis only: host seconds per phase, fenced
+            import time
+            t = [time.perf_counter()]
+            self.graph_fb.replay(); torch.cuda.synchronize(); t.append(time.perf_counter())
+            self._allreduce(); torch.cuda.synchronize(); t.append(time.perf_counter())
+            self.graph_opt.replay(); torch.cuda.synchronize(); t.append(time.perf_counter())
+            print(f"[step trace rank {dist.get_rank() if self.world > 1 else 0}] fwd+bwd graph {t[1] - t[0]:.3f} s, all-reduce "
+                  f"{t[2] - t[1]:.3f} s, optimizer graph {t[3] - t[2]:.3f} s", flush=True)
+            self.iteration += 1
+            return self.static_loss
         self.graph_fb.replay()
         if self.split:
             if self.allreduce_ms is not None and self.world > 1:
