@@ -115,7 +115,15 @@ class FlatGrads:
         """mean over ranks, in place (a no-op without an initialised process group / with one rank)"""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
+        gloo_on_gpu = self.flat.is_cuda and dist.get_backend() == "gloo"
+        if gloo_on_gpu:
+            # gloo stages device tensors through the host.  Fed from a stream with a whole training step still queued it ran at
+            # 10-23 s per step on the MI355X box (two ranks sharing the GPU, `bench.py --share-gpu`), fenced at 11 ms: gloo is a
+            # flow check here, never the product's collective (RCCL enqueues on the stream), so fence it.
+            torch.cuda.synchronize()
         dist.all_reduce(self.flat)
+        if gloo_on_gpu:
+            torch.cuda.synchronize()
         self.flat.div_(dist.get_world_size())
 
 
