@@ -426,9 +426,13 @@ def main():
                          "all-reduce outside the graph for N > 1)")
     ap.add_argument("--skip-roofline", action="store_true",
                     help="graph mode: do not run the trailing eager steps that time the scan kernels (profiling runs)")
-    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("VMAMBAIR_MIOPEN_FIND", "0")),
-                    help="1: torch.backends.cudnn.benchmark = True -- the vendor library searches its solvers for the UNet skeleton's 3x3 "
-                         "convolutions during the warm-up (before the capture) instead of taking its heuristic's pick")
+    ap.add_argument("--miopen-find", type=int, default=None,
+                    help="1: torch.backends.cudnn.benchmark = True, as the reference's training pipelines set it "
+                         "(SRGAN/VmambaIR/train_pipeline.py:97, Deraining/basicsr/train.py:135) -- the vendor library searches its solvers "
+                         "for the UNet skeleton's GEMM-shaped 3x3 convolutions during the warm-up (before the capture) instead of taking "
+                         "its heuristic's pick: 228.1 -> 232.0 images/s, 37 s more start-up (profiles/r04_multirank_flow_check_and_"
+                         "miopen_find.txt).  Default: 1 for the 16-bit training workloads, 0 for --dtype fp32 (3 minutes of search for "
+                         "+0.3 %) and for the inference configs; VMAMBAIR_MIOPEN_FIND overrides the default")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true",
@@ -445,6 +449,9 @@ def main():
     if args.config == "srgan-split64":
         return bench_srgan_split64(args)
 
+    if args.miopen_find is None:
+        env = os.environ.get("VMAMBAIR_MIOPEN_FIND")
+        args.miopen_find = int(env) if env is not None else (1 if (args.dtype == "bf16" and args.config in ("sr", "deraining")) else 0)
     if args.miopen_find:
         torch.backends.cudnn.benchmark = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -503,6 +510,23 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if world > 1 and args.miopen_find:
+        # the vendor library's solver search writes its picks to a per-user database: let rank 0 search first (one untimed eager
+        # forward + backward, no collectives), then the other ranks, which find the entries -- eight searches at once would only
+        # contend for that file
+        def prewarm():
+            with torch.autocast("cuda", dtype=acdt, enabled=acdt is not None):
+                out = net(lq)
+            F.l1_loss(out.float(), gt).backward()
+            for p_ in net.parameters():
+                p_.grad = None
+            torch.cuda.synchronize()
+        for first in (True, False):
+            if (rank == 0) == first:
+                prewarm()
+            dist.barrier()
+        log("vendor solver search done (rank 0 first)")
 
     if args.graph:
         # whole step replayed as a hipGraph; N > 1: one flat-gradient all-reduce between two graphs
@@ -664,6 +688,7 @@ def main():
                                     f"MambaSISR6 dim48 [15,1,1,1]+15, {args.dtype} autocast (scan arithmetic f32), batch {B} per GPU"),
                        "global_batch": world * B, "per_gpu_batch": B, "lq": list(lq.shape[-2:]), "gt": list(gt.shape[-2:]),
                        "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if args.graph else "eager",
+                       "vendor_conv_solver_search": bool(args.miopen_find),
                        "optimizer": ("AdamW 3e-4 (0.9,0.999) decay 1e-4 + clip_grad_norm 0.01, no EMA" if derain else
                                      "Adam 2e-4 (0.9,0.99) + EMA 0.999"), "loss": "L1",
                        # multi-GPU exchange: ONE flat fp32 all-reduce between the forward+backward graph and the optimizer graph
