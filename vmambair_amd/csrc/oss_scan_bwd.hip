@@ -577,7 +577,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             auto kc = oss_scan_bwd_carry_kernel<T, CW>;
             if (timer) { timer->segmented(); timer->begin(stream); }
             if (g_finish_timer) g_finish_timer->segmented();
-            hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_seg - 1))), dim3(CW * 64), sizeof(float) * kNB * TC,
+            hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_seg - 1))), dim3(CW * 64), sizeof(float) * 2 * kNB * TC,
                                stream, p, sg, ctiles);
             static LdsGate gate_s, gate_sh;
             bool launched = false;

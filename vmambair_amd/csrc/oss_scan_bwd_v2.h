@@ -743,16 +743,24 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
 // of the reverse recurrence dh_t = C_t g_t + a_{t+1} dh_{t+1} (cus/selective_scan_bwd_kernel.cuh:170-193) over the
 // segment's steps [t0, t1).  Only the recurrence itself: delta (+ softplus), dout, C -- 4 vector instructions and one
 // v_exp_f32 per (element, state) against the main kernel's ~28.  Same lane / chunk decomposition as the main kernel
-// (row = one wave, 64 lanes x 8 steps), all of a chunk's C rows staged at once.
+// (row = one wave, 64 lanes x 8 steps).
+// (round 4) The pass was 0.36 of a main pass in time for a fifth of its instructions: per chunk it loaded delta / dout, waited,
+// staged the C tile synchronously between two barriers, and updated the running product of a with two v_readlane + a
+// select per state.  Now (as in the main kernel) the NEXT chunk's delta / dout / C-tile loads are issued before the current
+// chunk's state loop and committed to a second LDS tile buffer after it (one barrier per tile batch), and the product of a
+// over a chunk is exp2(A_n * (sum of delta over the chunk, shifted by one step)) -- ONE v_exp_f32 per chunk with lane n =
+// state n, after one wave reduction of the per-lane sums, instead of a chain through every state's scan.
 template <typename T, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tiles_per_group) {
     constexpr int LPR = 64, I = 8, TC = LPR * I, NT = WAVES * 64, ROWS = WAVES;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [kNB][TC] C tile, tile_off image
+    constexpr int Q = TC / 4;                          // 4-position groups per tile row
+    constexpr int QPT = (kNB * Q + NT - 1) / NT;       // groups of one tile batch per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][kNB][TC] C tiles, tile_off image
     const oss_scan_fwd_params &f = p.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool seg_first = (lane == 0), seg_last = (lane == LPR - 1);
+    const bool seg_last = (lane == LPR - 1);
     const int L = f.seqlen, N = f.dstate, G = f.n_groups;
     const int rows_per_group = f.dim / G;
     int bid = blockIdx.x;
@@ -786,23 +794,61 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
             dln_c = x;
         }
     }
+    // ---- staging: global -> registers (issue), registers -> LDS (commit)
+    constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
+    RawQuad<T> pc[QPT];
+    auto stage_issue = [&](int t0s, int n0s) {
+        const int nbs = min(kNB, N - n0s);
+        const bool fullchunk = (t0s + TC <= L);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int idx = tid + j * NT;
+            const int n = idx / Q, k = idx - n * Q;
+            if (idx < nbs * Q) {
+                const int s0 = t0s + 4 * k;
+                const int m0 = rev ? (L - 4 - s0) : s0;
+                const T *rc = gC + (int64_t)(n0s + n) * f.C_dstate_stride;
+                const bool fast = fullchunk && ((reinterpret_cast<uintptr_t>(rc + m0) & amask) == 0);
+                pc[j] = load_quad<T>(rc, m0, L, fast);
+            }
+        }
+    };
+    auto stage_commit = [&](int buf, int n0s) {
+        const int nbs = min(kNB, N - n0s);
+        float *dC_ = smem + (size_t)buf * kNB * TC;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int idx = tid + j * NT;
+            const int n = idx / Q, k = idx - n * Q;
+            if (idx < nbs * Q) *reinterpret_cast<f32x4 *>(dC_ + tile_off<LPR, I>(n, (4 * k) / I, (4 * k) % I)) = quad_to_f32<T>(pc[j], rev);
+        }
+    };
+    // delta / dout of a chunk as raw items: issued one chunk ahead
+    RawItems<T, I> rd, rg;
+    auto rows_issue = [&](int t0s) {
+        const int tl = t0s + lane * I;
+        const int valid = max(0, min(I, L - tl));
+        if (raw_fast_ok<I>(dt_row, tl, valid, L, rev) && raw_fast_ok<I>(g_row, tl, valid, L, rev)) {
+            rd = load_raw_fast<I>(dt_row, tl, L, rev);
+            rg = load_raw_fast<I>(g_row, tl, L, rev);
+        } else {
+            rd = load_raw_slow<I>(dt_row, tl, valid, L, rev);
+            rg = load_raw_slow<I>(g_row, tl, valid, L, rev);
+        }
+    };
+    int tbuf = 0;
+    rows_issue((c_end - 1) * TC);
+    stage_issue((c_end - 1) * TC, 0);
+    stage_commit(0, 0);
+    __syncthreads();
     for (int c = c_end - 1; c >= c_begin; --c) {
         const int t0 = c * TC;
         const int tl = t0 + lane * I;
         const int valid = max(0, min(I, L - tl));
         float dl[I], gg[I];
-        {
-            RawItems<T, I> rd, rg;
-            if (raw_fast_ok<I>(dt_row, tl, valid, L, rev) && raw_fast_ok<I>(g_row, tl, valid, L, rev)) {
-                rd = load_raw_fast<I>(dt_row, tl, L, rev);
-                rg = load_raw_fast<I>(g_row, tl, L, rev);
-            } else {
-                rd = load_raw_slow<I>(dt_row, tl, valid, L, rev);
-                rg = load_raw_slow<I>(g_row, tl, valid, L, rev);
-            }
-            unpack_raw_dir<I>(rd, rev, dl);
-            unpack_raw_dir<I>(rg, rev, gg);
-        }
+        unpack_raw_dir<I>(rd, rev, dl);
+        unpack_raw_dir<I>(rg, rev, gg);
+        if (c > c_begin) rows_issue(t0 - TC);   // the next (earlier) chunk's rows: in flight during this chunk's state loops
         float S = 0.f;
 #pragma unroll
         for (int i = 0; i < I; ++i) {
@@ -812,18 +858,21 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
             S += dl[i];
         }
         const float dln_lane = shift_from_next_lane(dl[0], dln_c, seg_last);
-        const float Sshift = S - dl[0] + dln_lane;
+        const float Sshift = S - dl[0] + dln_lane;   // sum of delta over steps tl+1 .. tl+I
+        // product of a_{t+1} over the chunk = exp2(A * sum over the wave of Sshift): one reduction + one v_exp_f32 per chunk
+        const float Stot = lane_get(segment_sum_to_last<LPR>(Sshift), 63);
+        Pv *= exp2_hw(Stot * A2v);
         for (int n0 = 0; n0 < N; n0 += kNB) {
             const int nb = min(kNB, N - n0);
-            __syncthreads();   // the previous tile has been read by everyone
-            stage_bc_tiles<T, LPR, I, NT, false>(smem, nullptr, gC + (int64_t)n0 * f.C_dstate_stride, gC, f.C_dstate_stride,
-                                                 f.C_dstate_stride, nb, t0, L, rev, tid);
-            __syncthreads();
+            const bool more_here = n0 + kNB < N;
+            const bool have_next = more_here || c > c_begin;
+            if (have_next) stage_issue(more_here ? t0 : t0 - TC, more_here ? n0 + kNB : 0);
+            const float *tc = smem + (size_t)tbuf * kNB * TC + lane * 4;
             for (int nn = 0; nn < nb; ++nn) {
                 const int n = n0 + nn;
                 const float A2 = lane_get(A2v, n), dhc = lane_get(dhcv, n);
                 float ct[I];
-                read_tile<I>(smem + nn * TC + lane * 4, ct);
+                read_tile<I>(tc + nn * TC, ct);
                 float a[I];
 #pragma unroll
                 for (int i = 0; i < I; ++i) a[i] = exp2_hw(dl[i] * A2);
@@ -840,8 +889,10 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
                 segment_scan<LPR>(Pm, dm);
                 const float dfull_m = __builtin_fmaf(Pm, dhc, dm);   // mirrored-last lane: dh at the chunk's first step
                 dhcv = lane_set(dhcv, lane, n, lane_get(dfull_m, 63));
-                Pv = lane_set(Pv, lane, n, lane_get(Pv, n) * lane_get(Pm, 63));
             }
+            if (have_next) stage_commit(tbuf ^ 1, more_here ? n0 + kNB : 0);
+            __syncthreads();   // the next batch's tile is complete, this one has been read by everyone
+            tbuf ^= 1;
         }
         dln_c = lane_get(dl[0], 0);
     }
