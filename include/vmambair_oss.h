@@ -225,6 +225,21 @@ int oss_dwgate_bwd(oss_dtype io, const void *t, const float *weight, const float
                    int64_t t_batch_stride, int64_t t_channel_stride, int64_t dout_batch_stride, int64_t dout_channel_stride,
                    int64_t dt_batch_stride, int64_t dt_channel_stride, oss_stream_t stream);
 
+/* The same convolution + silu together with cross_scan_2d's two forward flattenings (MambaSISR6_arch.py:399-404, 486): the scans of
+ * SS2D_1 read silu(conv2d(x)) row-major AND column-major, and their input gradient comes back as one tensor per flattening.
+ *   oss_dwconv3x3_silu_flat2_fwd: x2 (batch, 2, channels, H * W) contiguous = [silu(conv(x) + bias) | the same planes transposed,
+ *                                 element (h, w) at w * H + h] -- what oss_dwconv3x3_silu_fwd + oss_cross_scan2 produce, bit for bit
+ *   oss_dwconv3x3_silu_flat2_bwd: as oss_dwconv3x3_silu_bwd with dy(h, w) = g2[:, 0](h, w) + g2[:, 1](w, h) rounded to the io type --
+ *                                 what oss_cross_merge2 + oss_dwconv3x3_silu_bwd produce, bit for bit; g2 (batch, 2, channels, H * W)
+ * oss_dwconv3x3_flat2_ok(io, H, W): fused_ok(io, H, W, 1), H % 8 == 0, W / 8 a power of two <= 32; else OSS_ERR_SHAPE. */
+int oss_dwconv3x3_flat2_ok(oss_dtype io, int height, int width);
+int oss_dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *x2, int batch, int channels,
+                                 int height, int width, int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream);
+int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *g2, void *dx,
+                                 float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
+                                 int64_t x_batch_stride, int64_t x_channel_stride, int64_t dx_batch_stride, int64_t dx_channel_stride,
+                                 oss_stream_t stream);
+
 /* 1x1 convolutions of the OSS block (in_conv / out_conv / project_in / project_out,
  * MambaSISR6_arch.py:205,211,281,329) as MFMA GEMMs on NCHW tensors; io = OSS_BF16 or OSS_F16 (fp32
  * I/O is rejected with OSS_ERR_SHAPE: it stays on the vendor conv).  weight: float (Cout, Cin)

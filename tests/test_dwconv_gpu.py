@@ -348,3 +348,81 @@ def test_shapes_the_fused_forms_leave_to_the_separate_kernels():
     x1, x2 = F.conv2d(t.float(), conv.weight, None, padding=1, groups=8).chunk(2, dim=1)
     assert_close(out, F.gelu(x1) * x2, 2e-2, 4e-2, "fallback")
     assert bool(ops.dwconv.fused_ok(torch.empty((1, 2, 256, 256), dtype=torch.bfloat16, device=DEV), 1))   # 129 KiB: one plane still fits
+
+
+# (round 4) SS2D_1's convolution together with cross_scan_2d's two forward flattenings (MambaSISR6_arch.py:399-404, 486)
+FLAT2_SHAPES = [(2, 96, 64, 64), (1, 192, 32, 32), (2, 384, 16, 16), (1, 768, 8, 8), (1, 48, 128, 128), (1, 6, 24, 64), (2, 5, 8, 256),
+                (1, 3, 40, 8)]
+
+
+@pytest.mark.parametrize("shape", FLAT2_SHAPES)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("has_bias", [True, False])
+def test_flat2_forms_are_bit_identical_to_the_separate_launches(shape, dt, has_bias):
+    """x2 = [silu(conv(x)) | its transpose] from ONE launch == dwconv3x3_silu_fwd + cross_scan2; the backward that reads the two
+    flattenings' gradients == cross_merge2 + dwconv3x3_silu_bwd.  Bit for bit: the merged gradient is rounded where the merge
+    launch stored it."""
+    torch.manual_seed(1)
+    B, C, H, W = shape
+    x = torch.randn(shape, device=DEV).to(dt)
+    w = (torch.randn(C, 1, 3, 3, device=DEV) * 0.3)
+    b = torch.randn(C, device=DEV) if has_bias else None
+    assert ops.flat2_ok(x)
+    x2 = torch.ops.vmambair.dwconv3x3_silu_flat2_fwd(x, w, b)
+    y = torch.ops.vmambair.dwconv3x3_silu_fwd(x, w, b)
+    assert torch.equal(x2, ops.cross_scan2(y))
+    # against fp32 torch as well: silu(conv) row-major and column-major
+    ref = F.silu(F.conv2d(x.float(), w, b, padding=1, groups=C))
+    assert_close(x2[:, 0].reshape(shape), ref, 2e-2, 2e-2, "row-major")
+    assert_close(x2[:, 1].reshape(B, C, W, H).transpose(2, 3), ref, 2e-2, 2e-2, "column-major")
+    g2 = torch.randn(B, 2, C, H * W, device=DEV).to(dt)
+    dx, dw, db = torch.ops.vmambair.dwconv3x3_silu_flat2_bwd(x, w, b, g2, None)
+    dx0, dw0, db0 = torch.ops.vmambair.dwconv3x3_silu_bwd(x, w, b, ops.cross_merge2(g2, H, W), None)
+    assert torch.equal(dx, dx0) and torch.equal(dw, dw0) and torch.equal(db, db0)
+    # written into a strided half buffer: same bits, nothing outside the half touched
+    buf = torch.full((B, 2 * C, H, W), 7.0, device=DEV).to(dt)
+    r = torch.ops.vmambair.dwconv3x3_silu_flat2_bwd(x, w, b, g2, buf[:, C:])
+    assert r[0].numel() == 0 and torch.equal(buf[:, C:], dx0) and bool((buf[:, :C] == 7.0).all())
+
+
+def test_shapes_the_flat2_form_leaves_to_the_separate_launches():
+    """H not a multiple of 8, W / 8 not a power of two or beyond 32 lane groups, fp32: flat2_ok says no"""
+    for shape, dt in (((1, 4, 12, 64), torch.bfloat16), ((1, 4, 16, 160), torch.bfloat16), ((1, 4, 8, 512), torch.bfloat16),
+                      ((1, 4, 16, 64), torch.float32), ((1, 4, 16, 20), torch.float16)):
+        assert not ops.flat2_ok(torch.empty(shape, dtype=dt, device=DEV))
+    for shape in ((1, 4, 16, 64), (1, 4, 8, 8), (1, 4, 128, 128), (1, 4, 64, 256)):
+        assert ops.flat2_ok(torch.empty(shape, dtype=torch.bfloat16, device=DEV))
+
+
+@pytest.mark.parametrize("variant,hw", [("srgan", (32, 32)), ("mamber32", (16, 64)), ("realsr", (8, 8))])
+def test_block_with_the_conv_core_node_is_bit_identical(variant, hw, monkeypatch):
+    """SS2D_1 with ConvCoreFn (convolution + flattenings + core as one node) against the separate nodes: same outputs, same
+    gradients of the input and of every parameter, bit for bit, under bf16 autocast"""
+    from vmambair_amd.oss_block import MamberBlock
+    torch.manual_seed(2)
+    blk = MamberBlock(48, variant=variant).to(DEV)
+    x = torch.randn(2, 48, *hw, device=DEV)
+
+    def run():
+        blk.zero_grad()
+        xi = x.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = blk(xi)
+        names, todo = set(), [out.grad_fn]
+        while todo:   # which autograd nodes built this output?
+            fn = todo.pop()
+            if fn is not None and fn not in names:
+                names.add(fn)
+                todo.extend(f for f, _ in fn.next_functions)
+        out.float().square().mean().backward()
+        return (out.detach().clone(), xi.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()},
+                {type(f).__name__ for f in names})
+
+    o1, g1, p1, nodes1 = run()
+    monkeypatch.setattr(ops.dwconv, "DW_FLAT2", False)
+    o0, g0, p0, nodes0 = run()
+    assert any(n.startswith("ConvCoreFn") for n in nodes1) and not any(n.startswith("ConvCoreFn") for n in nodes0)
+    assert any(n.startswith("SS2DCoreFn") for n in nodes0) and not any(n.startswith("SS2DCoreFn") for n in nodes1)
+    assert torch.equal(o1, o0) and torch.equal(g1, g0)
+    for n in p0:
+        assert torch.equal(p1[n], p0[n]), n

@@ -75,7 +75,8 @@ SUM_CHUNK_BYTES = 40   # sizeof(oss_sum_chunk)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fwd_workspace_bytes", "oss_scan_lane_state_floats", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments",
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
-           "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd",
+           "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd", "oss_dwconv3x3_flat2_ok", "oss_dwconv3x3_silu_flat2_fwd",
+           "oss_dwconv3x3_silu_flat2_bwd",
            "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_fwd_pool", "oss_ln_nchw_fwd_pool_tiles", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_conv1x1_dgrad_ln_bwd_ok",
            "oss_conv1x1_dgrad_ln_bwd_partial_floats", "oss_conv1x1_dgrad_ln_bwd", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
@@ -154,6 +155,12 @@ def load():
     for fn in (lib.oss_dwconv3x3_silu_bwd, lib.oss_dwgate_bwd):
         fn.restype = C.c_int
         fn.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_int64] * 6 + [C.c_void_p]
+    lib.oss_dwconv3x3_flat2_ok.restype = C.c_int
+    lib.oss_dwconv3x3_flat2_ok.argtypes = [C.c_int] * 3
+    lib.oss_dwconv3x3_silu_flat2_fwd.restype = C.c_int
+    lib.oss_dwconv3x3_silu_flat2_fwd.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_int64] * 2 + [C.c_void_p]
+    lib.oss_dwconv3x3_silu_flat2_bwd.restype = C.c_int
+    lib.oss_dwconv3x3_silu_flat2_bwd.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_void_p]
     lib.oss_ln_nchw_fwd.restype = C.c_int
     lib.oss_ln_nchw_fwd.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
     lib.oss_ln_nchw_fwd_pool_tiles.restype = C.c_int

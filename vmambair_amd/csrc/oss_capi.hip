@@ -316,6 +316,24 @@ int oss_dwconv3x3_silu_bwd(oss_dtype io, const void *x, const float *weight, con
                                gsb, gsc, dsb, dsc, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_dwconv3x3_flat2_ok(oss_dtype io, int height, int width) { return dwconv3x3_flat2_ok(io, height, width); }
+
+int oss_dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *x2, int batch, int channels,
+                                 int height, int width, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    if (!x || !weight || !x2) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwconv3x3_silu_flat2_fwd(io, x, weight, bias, x2, batch, channels, height, width, xsb, xsc, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *g2, void *dx,
+                                 float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
+                                 int64_t xsb, int64_t xsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    if (!x || !weight || !g2 || !dx || !dweight || !partials) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
+    return dwconv3x3_silu_flat2_bwd(io, x, weight, bias, g2, dx, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, dsb,
+                                    dsc, reinterpret_cast<hipStream_t>(stream));
+}
+
 int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
                    int height, int width, int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, oss_stream_t stream) {
     if (!t || !weight || !out) return OSS_ERR_NULL;

@@ -19,6 +19,7 @@
 #include <atomic>
 #include <cstdlib>
 #include "oss_device.h"
+#include "oss_global_ptr.h"
 #include "oss_host.h"
 #include "oss_mfma.h"
 
@@ -841,7 +842,9 @@ oss_conv1x1_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint
     const int slab = (int)(local % (unsigned)d.slabs);
     const unsigned r = local / (unsigned)d.slabs;
     const int by = (int)(r % (unsigned)d.bgs), bz = (int)(r / (unsigned)d.bgs);
-    wgrad_body<T>(reinterpret_cast<const T *>(d.dy), reinterpret_cast<const T *>(d.x), d.part, d.M, d.N, d.P, d.gsb, d.gsm, d.xsb,
+    // table pointers are generic until told otherwise: FLAT loads would serialise the operand window behind every LDS wait
+    const WgradDesc *dt = descs + block_problem[blockIdx.x];
+    wgrad_body<T>(table_ptr<const T>(&dt->dy), table_ptr<const T>(&dt->x), table_ptr<float>(&dt->part), d.M, d.N, d.P, d.gsb, d.gsm, d.xsb,
                   d.xsn, d.G, d.gsg, d.xsg, d.Mh, d.gs_hi, d.NB, slab, d.slabs, by, bz, d.span);
 }
 

@@ -109,7 +109,12 @@ template <typename T, bool EDGE = false>
 __global__ void __launch_bounds__(256)
 oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                           T *__restrict__ y, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc,
-                          int flip, T *__restrict__ pre, int act) {
+                          int flip, T *__restrict__ pre, int act,
+                          T *__restrict__ yt = nullptr /* (flat2 form) the same plane once more, column-major: element (h, w) at
+                          w * H + h, planes at yt + b * ysb + c * ysc -- the second flattening that SS2D_1's scans walk
+                          (cross_scan_2d, MambaSISR6_arch.py:399-404), written here instead of by a transpose launch of its own.
+                          Needs 256 % (W / 8) == 0, 256 / (W / 8) % 8 == 0 and H % 8 == 0 (flat2_ok) */) {
+    __shared__ __attribute__((aligned(16))) T tile[2048];   // flat2 form: the workgroup's 256 groups of 8 pixels, row-major
     const int c = blockIdx.y, b = blockIdx.z;
     const T *xp = x + b * xsb + c * xsc;
     T *yp = y + b * ysb + c * ysc;
@@ -136,13 +141,31 @@ oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, 
         for (int j = 0; j < 8; ++j)
             acc[j] = __builtin_fmaf(k0, v[j], __builtin_fmaf(k1, v[j + 1], __builtin_fmaf(k2, v[j + 2], acc[j])));
     }
-    if (!live) return;
-    if (pp) store8<T>(pp + (int64_t)h * W + w0, acc);   // kept for the backward of the unfused path
+    if (!live && !yt) return;
+    if (live && pp) store8<T>(pp + (int64_t)h * W + w0, acc);   // kept for the backward of the unfused path
     if (act) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = silu_f32(acc[j]);
     }
-    store8<T>(yp + (int64_t)h * W + w0, acc);
+    if (live) store8<T>(yp + (int64_t)h * W + w0, acc);
+    if (yt) {
+        // the workgroup's R = 256 / lpr rows through LDS: written as computed (lane = 8 pixels of a row), read back with lane = (column,
+        // 8 rows) -- consecutive lanes read consecutive 2-byte columns of a row (no bank conflicts) and store 16 bytes of a column
+        if (live) store8<T>(tile + threadIdx.x * 8, acc);
+        __syncthreads();
+        const int rows = 256 / lpr, hb = blockIdx.x * rows;
+        const int wc = threadIdx.x % W, hq = threadIdx.x / W;   // W * rows / 8 = 256 octets
+        const int h0 = hb + hq * 8;
+        if (h0 < H) {   // H % 8 == 0: an octet is inside the plane as a whole
+            uint32_t q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = tile[(hq * 8 + 2 * j) * W + wc].v, hi = tile[(hq * 8 + 2 * j + 1) * W + wc].v;
+                q[j] = lo | (hi << 16);
+            }
+            *reinterpret_cast<u32x4 *>(yt + b * ysb + c * ysc + (int64_t)wc * H + h0) = u32x4{q[0], q[1], q[2], q[3]};
+        }
+    }
 }
 
 // weight / bias gradient partials of one (channel, batch) plane, same access scheme
@@ -286,7 +309,10 @@ template <typename T, int MODE, bool EDGE = false>
 __global__ void __launch_bounds__(256, 4)   // 4 waves per SIMD = 4 workgroups per CU: the headline's 1016 gate workgroups in one round
 oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                const T *__restrict__ dy, T *__restrict__ dx, float *__restrict__ part /*[B][C][10]*/,
-                               int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc) {
+                               int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc,
+                               const T *__restrict__ dyt = nullptr /* (flat2 form, kDwSilu) the gradient of the column-major flattening,
+                               same strides: dy(h, w) += dyt[w * H + h], the sum rounded to T -- the adjoint of cross_scan_2d's two
+                               forward flattenings (MambaSISR6_arch.py:399-404) read here instead of merged by a launch of its own */) {
     constexpr int NCH = MODE == kDwGate ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
     T *sg = reinterpret_cast<T *>(dw_smem);
@@ -309,6 +335,16 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
         const bool first = cg == 0, last = cg == lpr - 1;
         float gv[8], pre[NCH][8], gq[NCH][8];
         load8<T>(gp + (int64_t)h * W + w0, gv);
+        if constexpr (MODE == kDwSilu) {
+            if (dyt) {   // 8 two-byte loads: the 8 lanes that share a column group read 16 consecutive bytes of each column
+                const T *tp = dyt + b * gsb + c0 * gsc + (int64_t)w0 * H + h;
+                float tv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tv[j] = to_f32(tp[(int64_t)j * H]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j] + tv[j]));   // as the merge launch stored it
+            }
+        }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int c = c0 + ch * cstep;
@@ -607,7 +643,7 @@ int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, v
 template <typename T, int MODE>
 static int bwd_fused_launch(const void *x, const float *w, const float *bias, const void *dy, void *dx, float *dw, float *db,
                             float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
-                            int64_t dsb, int64_t dsc, hipStream_t s) {
+                            int64_t dsb, int64_t dsc, hipStream_t s, const void *dyt = nullptr) {
     constexpr int NCH = MODE == kDwGate ? 2 : 1;
     if (!aligned16({x, dy, dx}, {xsb, xsc, gsb, gsc, dsb, dsc})) return OSS_ERR_SHAPE;
     static LdsGate gate, gate_e;
@@ -616,12 +652,51 @@ static int bwd_fused_launch(const void *x, const float *w, const float *bias, co
     auto kern = edge ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, true> : oss_dwconv3x3_bwd_fused_kernel<T, MODE, false>;
     if (const int e = (edge ? gate_e : gate).ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
     hipLaunchKernelGGL(kern, dim3(C / NCH, B), dim3(256), smem, s, reinterpret_cast<const T *>(x), w, bias,
-                       reinterpret_cast<const T *>(dy), reinterpret_cast<T *>(dx), part, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc);
+                       reinterpret_cast<const T *>(dy), reinterpret_cast<T *>(dx), part, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc,
+                       reinterpret_cast<const T *>(dyt));
     if (defer_finish())
         defer_sum(part, B, (size_t)C * 10, (size_t)C * (db ? 10 : 9), dw, (size_t)C * 9, db);
     else
         hipLaunchKernelGGL(oss_dwconv3x3_wgrad_finish, dim3((C * 10 + 255) / 256), dim3(256), 0, s, part, dw, db, B, C);
     return (int)hipGetLastError();
+}
+
+// ---- flat2 forms: the depth-wise convolution of SS2D_1 together with cross_scan_2d's two forward flattenings -----------------------
+// forward: x2 (B, 2, C, H * W) = [silu(conv(x)) row-major | the same column-major]; backward: dy = g2[:, 0] + transpose(g2[:, 1])
+int dwconv3x3_flat2_ok(oss_dtype io, int H, int W) {
+    if (!dwconv3x3_fused_ok(io, H, W, 1) || H % 8 != 0) return 0;
+    const int lpr = W / 8;
+    return (256 % lpr == 0 && (256 / lpr) % 8 == 0) ? 1 : 0;
+}
+
+template <typename T>
+static int flat2_fwd_launch(const void *x, const float *w, const float *bias, void *x2, int B, int C, int H, int W, int64_t xsb,
+                            int64_t xsc, hipStream_t s) {
+    const int64_t L = (int64_t)H * W;
+    const T *xp = reinterpret_cast<const T *>(x);
+    T *yp = reinterpret_cast<T *>(x2);
+    if (!wide_ok<T>(W, {xp, yp}, {xsb, xsc, L})) return OSS_ERR_SHAPE;
+    dim3 grid(((W / 8) * H + 255) / 256, C, B);
+    hipLaunchKernelGGL((oss_dwconv3x3_wide_kernel<T, false>), grid, dim3(256), 0, s, xp, w, bias, yp, C, H, W, xsb, xsc, 2 * C * L, L, 0,
+                       (T *)nullptr, 1, yp + C * L);
+    return (int)hipGetLastError();
+}
+
+int dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *w, const float *bias, void *x2, int B, int C, int H, int W,
+                             int64_t xsb, int64_t xsc, hipStream_t s) {
+    if (!dwconv3x3_flat2_ok(io, H, W)) return OSS_ERR_SHAPE;
+    return io == OSS_F16 ? flat2_fwd_launch<f16_t>(x, w, bias, x2, B, C, H, W, xsb, xsc, s)
+                         : flat2_fwd_launch<bf16_t>(x, w, bias, x2, B, C, H, W, xsb, xsc, s);
+}
+
+int dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *w, const float *bias, const void *g2, void *dx, float *dw,
+                             float *db, float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t dsb, int64_t dsc,
+                             hipStream_t s) {
+    if (!dwconv3x3_flat2_ok(io, H, W)) return OSS_ERR_SHAPE;
+    const int64_t L = (int64_t)H * W;
+    const char *gt = reinterpret_cast<const char *>(g2) + (size_t)C * L * 2;
+    return io == OSS_F16 ? bwd_fused_launch<f16_t, kDwSilu>(x, w, bias, g2, dx, dw, db, part, B, C, H, W, xsb, xsc, 2 * C * L, L, dsb, dsc, s, gt)
+                         : bwd_fused_launch<bf16_t, kDwSilu>(x, w, bias, g2, dx, dw, db, part, B, C, H, W, xsb, xsc, 2 * C * L, L, dsb, dsc, s, gt);
 }
 
 int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, const float *bias, const void *dy, void *dx,

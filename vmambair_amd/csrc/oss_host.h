@@ -79,6 +79,13 @@ int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, v
 int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, const float *bias, const void *dy, void *dx,
                         float *dw, float *db, float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t gsb,
                         int64_t gsc, int64_t dsb, int64_t dsc, hipStream_t s);
+// the silu form together with cross_scan_2d's two flattenings / their adjoint (x2, g2: (B, 2, C, H * W) contiguous)
+int dwconv3x3_flat2_ok(oss_dtype io, int H, int W);
+int dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *w, const float *bias, void *x2, int B, int C, int H, int W,
+                             int64_t xsb, int64_t xsc, hipStream_t s);
+int dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *w, const float *bias, const void *g2, void *dx, float *dw,
+                             float *db, float *part, int B, int C, int H, int W, int64_t xsb, int64_t xsc, int64_t dsb, int64_t dsc,
+                             hipStream_t s);
 int dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dw, float *db, float *part, int B, int C, int H,
                     int W, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, hipStream_t s, const void *pre = nullptr,
                     void *dpre = nullptr);

@@ -8,6 +8,7 @@
 // (no amsgrad, eps outside the sqrt of the bias-corrected second moment); optional decoupled weight decay = torch.optim.AdamW
 // and a gradient scale read from device memory = clip_grad_norm_ (the Deraining step: image_restoration_model.py:121-167).
 #include "oss_device.h"
+#include "oss_global_ptr.h"
 #include "oss_host.h"
 
 namespace oss {
@@ -34,9 +35,11 @@ oss_adam_ema_kernel(const oss_adam_chunk *__restrict__ chunks, const float *__re
     // gs: gradient-clipping coefficient (clip_grad_norm_: grads *= min(1, max_norm / (total_norm + 1e-6))) read from
     // device memory so that the launch can sit in a hipGraph; decay_keep = 1 - lr * weight_decay (AdamW, decoupled)
     const float gs = grad_scale ? *grad_scale : 1.f;
-    float *p = reinterpret_cast<float *>(c.param), *m = reinterpret_cast<float *>(c.exp_avg);
-    float *v = reinterpret_cast<float *>(c.exp_avg_sq), *e = reinterpret_cast<float *>(c.ema);
-    const float *g = reinterpret_cast<const float *>(c.grad);
+    // pointers out of the chunk table: told to be global (oss_global_ptr.h), else every access below is a FLAT instruction
+    const oss_adam_chunk *ct = chunks + blockIdx.x;
+    float *p = table_ptr<float>(&ct->param), *m = table_ptr<float>(&ct->exp_avg);
+    float *v = table_ptr<float>(&ct->exp_avg_sq), *e = table_ptr<float>(&ct->ema);
+    const float *g = table_ptr<const float>(&ct->grad);
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(e)) & 15u) == 0;
     for (int i = threadIdx.x * 4; i < c.n; i += 1024) {
@@ -83,8 +86,8 @@ oss_sum_partials_kernel(const oss_sum_chunk *__restrict__ chunks) {
     const oss_sum_chunk c = chunks[blockIdx.x];
     const int j = threadIdx.x * 4;
     if (j >= c.n) return;
-    const float *pp = reinterpret_cast<const float *>(c.src) + c.j0 + j;
-    float *dst = reinterpret_cast<float *>(c.dst) + j;
+    const float *pp = table_ptr<const float>(&chunks[blockIdx.x].src) + c.j0 + j;   // table pointers: global (oss_global_ptr.h)
+    float *dst = table_ptr<float>(&chunks[blockIdx.x].dst) + j;
     const size_t st = (size_t)c.stride;
     const bool vec = j + 4 <= c.n && ((reinterpret_cast<uintptr_t>(pp) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 && (st & 3) == 0;
     // acc[slice][i] takes k = slice + 4 i + 16 m, i.e. element [q & 3][q >> 2] of a group of 16 rows; the register arrays

@@ -24,10 +24,10 @@ from ._common import (WGRAD_STATS, WgradTable, flush_wgrads, pending_wgrad_table
 from .channel import ChannelGateFn, NormChannelGateFn, chan_gate_bwd, chan_gate_fwd, chan_supported  # noqa: F401
 from .pointwise import (Conv1x1Fn, LNConv1x1Fn, conv1x1, conv1x1_bwd, conv1x1_fwd, ln_conv1x1, ln_conv1x1_fwd,  # noqa: F401
                         ln_conv1x1_ok)
-from .core import (SS2DCoreFn, core_supported, cross_merge2, cross_scan2, fused_dt_supported, proj_dgrad, proj_fwd,  # noqa: F401
-                   proj_set_path, proj_wgrad, ss2d_core_bwd, ss2d_core_fwd)
+from .core import (ConvCoreFn, SS2DCoreFn, conv_core_ok, core_supported, cross_merge2, cross_scan2, fused_dt_supported, proj_dgrad, proj_fwd,  # noqa: F401
+                   proj_set_path, proj_wgrad, ss2d_conv_core_bwd, ss2d_conv_core_fwd, ss2d_core_bwd, ss2d_core_fwd)
 from .dwconv import (DWConv3x3Fn, DWGateFn, dwconv3x3, dwconv3x3_bwd, dwconv3x3_fwd, dwconv3x3_gelu_gate,  # noqa: F401
-                     dwconv3x3_silu_bwd, dwconv3x3_silu_fwd, dwgate_bwd, dwgate_fwd)
+                     dwconv3x3_silu_bwd, dwconv3x3_silu_flat2_bwd, dwconv3x3_silu_flat2_fwd, dwconv3x3_silu_fwd, dwgate_bwd, dwgate_fwd, flat2_ok)
 from .conv3x3 import ThinConv3x3Fn, conv3x3_thin_bwd, conv3x3_thin_fwd  # noqa: F401
 from .conv3x3 import conv3x3 as conv3x3_layer  # noqa: F401
 from .ffn import GeluGateFn, gelu_gate, gelu_gate_bwd, gelu_gate_fwd  # noqa: F401

@@ -165,7 +165,14 @@ def ss2d_core_fwd(x: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight:
         e = x.new_empty
         return [e((B, D, H, W), dtype=torch.float32), e((B, 2, D, L)), e((B, 4, Cc, L)), e((B, 4 * D, L)), e(0, dtype=torch.float32),
                 e(0, dtype=torch.float32)]
-    x2 = cross_scan2(x)
+    return _core_fwd_from_x2(cross_scan2(x), H, W, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias, want_hs)
+
+
+def _core_fwd_from_x2(x2, H, W, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias, want_hs):
+    """the spatial core from the two flattenings on (shared by ``ss2d_core_fwd`` and ``ss2d_conv_core_fwd``)"""
+    B, _, D, L = x2.shape
+    Cc, R, N = x_proj_weight.shape[1], dt_projs_weight.shape[2], A_logs.shape[1]
+    x = x2
     fused = fused_dt_supported(x2.dtype, B, D, Cc, R, N, L)
     xdbl, dts = proj_fwd(x2, x_proj_weight, dt_projs_weight, want_dts=not fused)
     # fused: delta = dt_projs_weight . xdbl[:, :, :R] is evaluated inside the scan kernels (dts stays empty)
@@ -184,7 +191,7 @@ def ss2d_core_fwd(x: torch.Tensor, x_proj_weight: torch.Tensor, dt_projs_weight:
 
 def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: torch.Tensor, states: torch.Tensor,
                   x_proj_weight: torch.Tensor, dt_projs_weight: torch.Tensor, A_logs: torch.Tensor, Ds: torch.Tensor,
-                  dt_bias: torch.Tensor, lane_states: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                  dt_bias: torch.Tensor, lane_states: Optional[torch.Tensor] = None, merge: bool = True) -> List[torch.Tensor]:
     """-> [dx (B, D, H, W) io dtype, dx_proj_weight, ddt_projs_weight, dA_logs, dDs, ddt_bias] (fp32)"""
     B, _, D, L = x2.shape
     H, W = dy.shape[2], dy.shape[3]
@@ -200,17 +207,48 @@ def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: t
         hs=lane_states if (lane_states is not None and lane_states.numel()) else None)
     du, ddts, dA, _, _, dD, dbias = res[:7]
     dx2 = proj_dgrad(ddts, dxdbl, du, x_proj_weight, dt_projs_weight)   # fused: every row of dxdbl is already in place
-    dx = cross_merge2(dx2, H, W)
+    dx = cross_merge2(dx2, H, W) if merge else dx2   # merge = False: the caller's depth-wise-conv backward reads both flattenings
     dwx, dwdt = proj_wgrad(x2, xdbl, dxdbl, ddts, R)
     if fused:
         dwdt = res[7].view(4, D, R)
     return [dx, dwx, dwdt, dA, dD, dbias.view(4, D)]
 
 
+def ss2d_conv_core_fwd(xin: torch.Tensor, conv_weight: torch.Tensor, conv_bias: Optional[torch.Tensor], x_proj_weight: torch.Tensor,
+                       dt_projs_weight: torch.Tensor, A_logs: torch.Tensor, Ds: torch.Tensor, dt_bias: torch.Tensor,
+                       want_hs: bool = False) -> List[torch.Tensor]:
+    """``x = act(conv2d(x)); forward_core(x)`` up to ``out_norm`` (MambaSISR6_arch.py:486-487, 395-431): as ``ss2d_core_fwd`` with the
+    depth-wise convolution + silu in front writing the two flattenings itself (no convolution output, no transpose launch)"""
+    from .dwconv import dwconv3x3_silu_flat2_fwd
+    B, D, H, W, Cc, R, N = _dims_core(xin, x_proj_weight, dt_projs_weight, A_logs)
+    x2 = dwconv3x3_silu_flat2_fwd(xin, conv_weight, conv_bias)
+    return _core_fwd_from_x2(x2, H, W, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias, want_hs)
+
+
+def ss2d_conv_core_bwd(dy: torch.Tensor, xin: torch.Tensor, conv_weight: torch.Tensor, conv_bias: Optional[torch.Tensor], x2: torch.Tensor,
+                       xdbl: torch.Tensor, dts: torch.Tensor, states: torch.Tensor, x_proj_weight: torch.Tensor,
+                       dt_projs_weight: torch.Tensor, A_logs: torch.Tensor, Ds: torch.Tensor, dt_bias: torch.Tensor,
+                       lane_states: Optional[torch.Tensor] = None, dx_into: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """-> [dxin or empty (written into ``dx_into``), dconv_weight, dconv_bias or empty, dx_proj_weight, ddt_projs_weight, dA_logs, dDs,
+    ddt_bias]"""
+    from .dwconv import dwconv3x3_silu_flat2_bwd
+    dx2, dwx, dwdt, dA, dD, dbias = ss2d_core_bwd(dy, x2, xdbl, dts, states, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias,
+                                                  lane_states, merge=False)
+    dxin, dcw, dcb = dwconv3x3_silu_flat2_bwd(xin, conv_weight, conv_bias, dx2, dx_into)
+    return [dxin, dcw, dcb, dwx, dwdt, dA, dD, dbias]
+
+
 _LIB.define("ss2d_core_fwd(Tensor x, Tensor x_proj_weight, Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias, "
             "bool want_hs=False) -> Tensor[]")
 _LIB.define("ss2d_core_bwd(Tensor dy, Tensor x2, Tensor xdbl, Tensor dts, Tensor states, Tensor x_proj_weight, "
             "Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias, Tensor? lane_states=None) -> Tensor[]")
+_LIB.define("ss2d_conv_core_fwd(Tensor xin, Tensor conv_weight, Tensor? conv_bias, Tensor x_proj_weight, Tensor dt_projs_weight, "
+            "Tensor A_logs, Tensor Ds, Tensor dt_bias, bool want_hs=False) -> Tensor[]")
+_LIB.define("ss2d_conv_core_bwd(Tensor dy, Tensor xin, Tensor conv_weight, Tensor? conv_bias, Tensor x2, Tensor xdbl, Tensor dts, "
+            "Tensor states, Tensor x_proj_weight, Tensor dt_projs_weight, Tensor A_logs, Tensor Ds, Tensor dt_bias, "
+            "Tensor? lane_states=None, Tensor(a!)? dx_into=None) -> Tensor[]")
+_LIB.impl("ss2d_conv_core_fwd", ss2d_conv_core_fwd, "CUDA")
+_LIB.impl("ss2d_conv_core_bwd", ss2d_conv_core_bwd, "CUDA")
 _LIB.impl("ss2d_core_fwd", ss2d_core_fwd, "CUDA")
 _LIB.impl("ss2d_core_bwd", ss2d_core_bwd, "CUDA")
 
@@ -232,3 +270,35 @@ class SS2DCoreFn(torch.autograd.Function):
         x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias, hs = ctx.saved_tensors
         dx, dwx, dwdt, dA, dD, dbias = torch.ops.vmambair.ss2d_core_bwd(dy, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias, hs)
         return (dx, dwx.to(wx.dtype), dwdt.to(wdt.dtype), dA.to(A_logs.dtype), dD.to(Ds.dtype), dbias.to(dt_bias.dtype))
+
+
+class ConvCoreFn(torch.autograd.Function):
+    """``SS2D_1``: ``x = act(conv2d(x))`` and the spatial core behind it as ONE autograd node (MambaSISR6_arch.py:486-487): the
+    depth-wise convolution writes the two flattenings the scans read, and its backward reads the two flattenings' gradients --
+    ``SS2DCoreFn`` + ``DWConv3x3Fn`` without the transpose / merge launches and the (B, D, H, W) tensors between them."""
+
+    @staticmethod
+    def forward(ctx, xin, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias, grad_into=None):
+        ctx.grad_into = grad_into   # (PairGrad, half index) or None: where the input gradient should land (ops/_common.py)
+        y, x2, xdbl, dts, states, hs = torch.ops.vmambair.ss2d_conv_core_fwd(xin, conv_weight, conv_bias, x_proj_weight, dt_projs_weight,
+                                                                            A_logs, Ds, dt_bias, any(ctx.needs_input_grad))
+        ctx.save_for_backward(xin, conv_weight, conv_bias, x2, xdbl, dts, states, x_proj_weight, dt_projs_weight, A_logs, Ds, dt_bias, hs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, cw, cb, x2, xdbl, dts, states, wx, wdt, A_logs, Ds, dt_bias, hs = ctx.saved_tensors
+        into = ctx.grad_into[0].half(ctx.grad_into[1], xin) if ctx.grad_into is not None else None
+        dxin, dcw, dcb, dwx, dwdt, dA, dD, dbias = torch.ops.vmambair.ss2d_conv_core_bwd(dy, xin, cw, cb, x2, xdbl, dts, states, wx, wdt,
+                                                                                        A_logs, Ds, dt_bias, hs, into)
+        if into is not None and dxin.numel() == 0 and xin.numel() != 0:
+            dxin = into   # written in place: the half of the PairGrad buffer IS the gradient
+        return (dxin, dcw.to(cw.dtype), (dcb.to(cb.dtype) if cb is not None else None), dwx.to(wx.dtype), dwdt.to(wdt.dtype),
+                dA.to(A_logs.dtype), dD.to(Ds.dtype), dbias.to(dt_bias.dtype), None)
+
+
+def conv_core_ok(xin: torch.Tensor, conv: torch.nn.Conv2d, D: int, R: int, N: int) -> bool:
+    """does ``ConvCoreFn`` take this input?  16-bit GPU tensor, a 3x3 depth-wise convolution, shapes of both kernel families"""
+    from .dwconv import flat2_ok
+    return (xin.dim() == 4 and xin.numel() > 0 and tuple(conv.weight.shape) == (D, 1, 3, 3) and xin.shape[1] == D and
+            core_supported(D, R, N) and flat2_ok(xin))

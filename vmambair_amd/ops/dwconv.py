@@ -85,6 +85,62 @@ def dwconv3x3_silu_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     return [x.new_empty(0) if in_place else dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
 
 
+#: ``VMAMBAIR_DW_FLAT2=0``: SS2D_1's convolution and the two flattenings behind it stay separate launches (A-B timing)
+DW_FLAT2 = os.environ.get("VMAMBAIR_DW_FLAT2", "1") == "1"
+
+
+def flat2_ok(x: torch.Tensor) -> bool:
+    """does the convolution + silu + both-flattenings form (``dwconv3x3_silu_flat2_*``) take this tensor?"""
+    if not (DW_FLAT2 and fused_ok(x, 1)):
+        return False
+    return bool(_capi.load().oss_dwconv3x3_flat2_ok(_DT[x.dtype], x.shape[2], x.shape[3]))
+
+
+def dwconv3x3_silu_flat2_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """-> x2 (B, 2, C, H*W): ``silu(conv(x))`` flattened row-major and column-major (the two forward directions of
+    ``cross_scan_2d``, MambaSISR6_arch.py:399-404) out of ONE launch; bit-identical to ``dwconv3x3_silu_fwd`` + ``cross_scan2``"""
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16), "dwconv3x3_silu_flat2: x must be a 16-bit (B, C, H, W) GPU tensor")
+    B, Cc, H, W = x.shape
+    _check(tuple(weight.shape) == (Cc, 1, 3, 3), "dwconv3x3_silu_flat2: weight must be (C, 1, 3, 3)")
+    w, b = _w9(weight, bias)
+    x = _planes(x)
+    if not _aligned(x):
+        x = x.contiguous()
+    x2 = torch.empty((B, 2, Cc, H * W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.load().oss_dwconv3x3_silu_flat2_fwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), x2.data_ptr(), B, Cc, H, W,
+                                                              x.stride(0), x.stride(1), torch.cuda.current_stream().cuda_stream),
+                    "oss_dwconv3x3_silu_flat2_fwd")
+    return x2
+
+
+def dwconv3x3_silu_flat2_bwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], g2: torch.Tensor,
+                             dx_into: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """backward of ``dwconv3x3_silu_flat2_fwd``: g2 (B, 2, C, H*W) holds the gradients of the two flattenings, their merge
+    (``cross_merge2``) happens in the load of the one-launch backward -> [dx or empty (written into ``dx_into``), dweight, dbias or empty]"""
+    B, Cc, H, W = x.shape
+    x = _planes(x)
+    if not _aligned(x):
+        x = x.contiguous()
+    _check(g2.dtype == x.dtype and tuple(g2.shape) == (B, 2, Cc, H * W), "dwconv3x3_silu_flat2_bwd: g2 must be (B, 2, C, H*W) of x's dtype")
+    g2 = g2.contiguous()
+    in_place = dx_into is not None and dx_into.dtype == x.dtype and tuple(dx_into.shape) == (B, Cc, H, W) and \
+        dx_into.stride(3) == 1 and dx_into.stride(2) == W and _aligned(dx_into)
+    dx = dx_into if in_place else torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    w, b = _w9(weight, bias)
+    lib = _capi.load()
+    dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cc,), dtype=torch.float32, device=x.device) if bias is not None else None
+    part = torch.empty((B, Cc, 10), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(lib.oss_dwconv3x3_silu_flat2_bwd(_DT[x.dtype], x.data_ptr(), w.data_ptr(), _ptr(b), g2.data_ptr(), dx.data_ptr(),
+                                                     dw.data_ptr(), _ptr(db), part.data_ptr(), B, Cc, H, W, x.stride(0), x.stride(1),
+                                                     dx.stride(0), dx.stride(1), torch.cuda.current_stream().cuda_stream),
+                    "oss_dwconv3x3_silu_flat2_bwd")
+        _keep(part, dw, db)
+    return [x.new_empty(0) if in_place else dx, dw.view(Cc, 1, 3, 3), db if db is not None else x.new_empty(0, dtype=torch.float32)]
+
+
 def dwgate_fwd(t: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """``x1, x2 = F.conv2d(t, weight, bias, padding=1, groups=2 Hd).chunk(2, dim=1); gelu(x1) * x2`` (MambaSISR6_arch.py:213-217)
     in one pass that never stores the convolution"""
@@ -183,12 +239,16 @@ _LIB.define("dwconv3x3_fwd(Tensor x, Tensor weight, Tensor? bias, bool act) -> T
 _LIB.define("dwconv3x3_bwd(Tensor x, Tensor weight, Tensor dy, bool has_bias, Tensor? pre, Tensor(a!)? dx_into) -> Tensor[]")
 _LIB.define("dwconv3x3_silu_fwd(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
 _LIB.define("dwconv3x3_silu_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor dy, Tensor(a!)? dx_into) -> Tensor[]")
+_LIB.define("dwconv3x3_silu_flat2_fwd(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
+_LIB.define("dwconv3x3_silu_flat2_bwd(Tensor x, Tensor weight, Tensor? bias, Tensor g2, Tensor(a!)? dx_into) -> Tensor[]")
 _LIB.define("dwgate_fwd(Tensor t, Tensor weight, Tensor? bias) -> Tensor")
 _LIB.define("dwgate_bwd(Tensor t, Tensor weight, Tensor? bias, Tensor dout) -> Tensor[]")
 _LIB.impl("dwconv3x3_fwd", dwconv3x3_fwd, "CUDA")
 _LIB.impl("dwconv3x3_bwd", dwconv3x3_bwd, "CUDA")
 _LIB.impl("dwconv3x3_silu_fwd", dwconv3x3_silu_fwd, "CUDA")
 _LIB.impl("dwconv3x3_silu_bwd", dwconv3x3_silu_bwd, "CUDA")
+_LIB.impl("dwconv3x3_silu_flat2_fwd", dwconv3x3_silu_flat2_fwd, "CUDA")
+_LIB.impl("dwconv3x3_silu_flat2_bwd", dwconv3x3_silu_flat2_bwd, "CUDA")
 _LIB.impl("dwgate_fwd", dwgate_fwd, "CUDA")
 _LIB.impl("dwgate_bwd", dwgate_bwd, "CUDA")
 

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import (ChannelGateFn, NormChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw, ln_conv1x1, ln_conv1x1_ok,
+from .ops import (ChannelGateFn, ConvCoreFn, NormChannelGateFn, SS2DCoreFn, chan_supported, conv1x1, conv_core_ok, core_supported, dwconv3x3, dwconv3x3_gelu_gate, gelu_gate, layer_norm_nchw, ln_conv1x1, ln_conv1x1_ok,
                   split_halves)
 from .selective_scan import CrossScan2, OmniScanFn, OmniScanMergeFn, SelectiveScanFP32, selective_scan_fn
 
@@ -315,7 +315,15 @@ class SS2D_1(nn.Module):
             xz = conv1x1(x, self.in_conv)
         # x, z = xz.chunk(2, dim=1): the gradients of the halves are written by their producers into ONE buffer (no cat)
         x, z, pair = split_halves(xz)
-        x = dwconv3x3(x, self.conv2d, act=True, grad_into=None if pair is None else (pair, 0))  # silu in the conv's epilogue
+        into = None if pair is None else (pair, 0)
+        y_core = None
+        if self.omni and self.fused_core and x.is_cuda and conv_core_ok(x, self.conv2d, self.d_inner, self.dt_rank, self.d_state):
+            # (round 4) conv2d + silu + the spatial core as ONE node: the convolution writes the two flattenings the scans walk and
+            # its backward reads their two gradients (ops/core.py: ConvCoreFn) -- no transpose / merge launches in between
+            y_core = ConvCoreFn.apply(x, self.conv2d.weight, self.conv2d.bias, self.x_proj_weight, self.dt_projs_weight, self.A_logs,
+                                      self.Ds, self.dt_projs_bias, into)
+        else:
+            x = dwconv3x3(x, self.conv2d, act=True, grad_into=into)  # silu in the conv's epilogue
         chan_fused = self.omni and self.fused_channel and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and \
             chan_supported(self.dc_inner or 1, self.dc_state, self.d_inner)
         lift = self.dc_inner is not None
@@ -327,12 +335,16 @@ class SS2D_1(nn.Module):
                 core_supported(self.d_inner, self.dt_rank, self.d_state):
             # spatial core, then out_norm * silu(z) + channel branch + gate as ONE node: the gate's backward is folded into the
             # LayerNorm backward's load (ops/channel.py: NormChannelGateFn)
-            y = SS2DCoreFn.apply(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
+            y = y_core if y_core is not None else \
+                SS2DCoreFn.apply(x, self.x_proj_weight, self.dt_projs_weight, self.A_logs, self.Ds, self.dt_projs_bias)
             y2 = NormChannelGateFn.apply(y, self.out_norm.body.weight, self.out_norm.body.bias, z, x.dtype,
                                          None if pair is None else (pair, 1), *chan_args)
             return conv1x1(y2, self.out_conv, residual)
         # out_norm(merge) * silu(z), fused in the LayerNorm kernel
-        y2 = self.forward_core(x, gate=z, gate_grad_into=None if pair is None else (pair, 1))
+        if y_core is not None:
+            y2 = self._out_norm(y_core, x.dtype, z, None if pair is None else (pair, 1))
+        else:
+            y2 = self.forward_core(x, gate=z, gate_grad_into=None if pair is None else (pair, 1))
         if chan_fused and y2.dtype in (torch.float32, torch.float16, torch.bfloat16):
             # pooling + channel scans + LayerNorm + gate as one autograd node (oss_channel.hip)
             y2 = ChannelGateFn.apply(y2, *chan_args)
