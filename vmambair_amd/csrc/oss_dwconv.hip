@@ -305,7 +305,13 @@ oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, cons
 // MODE kDwSilu: one channel per workgroup, grid (C, B); dy is the gradient of silu(conv(x) + bias).
 // MODE kDwGate: channels c and c + Hd, grid (Hd, B); dy (B, Hd, H, W) is the gradient of gelu(x1) * x2.
 // dynamic LDS: NCH planes of (H + 2) rows of W elements of T (rows 0 and H + 1 stay zero: the padding of pass 2)
-template <typename T, int MODE, bool EDGE = false>
+// KEEP (round 4; planes of <= 512 lane groups, i.e. <= 4096 pixels, non-EDGE widths): the kernel was a chain of dependent round trips --
+// pass 1 loaded one channel's three rows, waited, convolved, then the partner channel's; pass 2 loaded x AGAIN, group by group, each
+// load waited for on the spot (PMC at the headline gate shape: 26 % of the waves' cycles issuing vector instructions, 38 % parked).
+// Now every load of a pass-1 group (dy, 3 rows x NCH channels) is in flight before the first is used, and the centre rows stay in
+// registers (16 bytes per channel and group, at most 2 groups per lane) for pass 2, which then reads LDS only.
+template <typename T, int MODE, bool EDGE = false, bool KEEP = false, bool MERGE = false /* KEEP form: dyt is there (a template
+parameter, not `if (dyt)`: behind a branch the compiler converts the loaded values where they were loaded, i.e. waits for them there) */>
 __global__ void __launch_bounds__(256, 4)   // 4 waves per SIMD = 4 workgroups per CU: the headline's 1016 gate workgroups in one round
 oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                const T *__restrict__ dy, T *__restrict__ dx, float *__restrict__ part /*[B][C][10]*/,
@@ -313,7 +319,9 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
                                const T *__restrict__ dyt = nullptr /* (flat2 form, kDwSilu) the gradient of the column-major flattening,
                                same strides: dy(h, w) += dyt[w * H + h], the sum rounded to T -- the adjoint of cross_scan_2d's two
                                forward flattenings (MambaSISR6_arch.py:399-404) read here instead of merged by a launch of its own */) {
+    static_assert(!(KEEP && EDGE), "KEEP: rows whose lane groups tile a wave");
     constexpr int NCH = MODE == kDwGate ? 2 : 1;
+    constexpr int NKEEP = KEEP ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
     T *sg = reinterpret_cast<T *>(dw_smem);
     const int c0 = blockIdx.x, b = blockIdx.y;
@@ -321,40 +329,38 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
     const size_t plane = (size_t)(H + 2) * W;
     const T *gp = dy + b * gsb + c0 * gsc;
     const int lpr = W >> 3, ngroups = lpr * H;
+    u32x4 xkeep[NKEEP][NCH];   // KEEP: the centre row of x of the lane's pass-1 groups (pass 2 walks the same groups)
     // zero the two padding rows of every LDS plane
     for (int i = threadIdx.x; i < NCH * 2 * lpr; i += 256) {
         const int ch = i / (2 * lpr), r = i - ch * 2 * lpr, row = r < lpr ? 0 : H + 1, col = (r < lpr ? r : r - lpr) << 3;
         *reinterpret_cast<u32x4 *>(sg + ch * plane + (size_t)row * W + col) = u32x4{0u, 0u, 0u, 0u};
     }
     // pass 1: the gradient that reaches the convolution, rounded to T, into the LDS planes
-    for (int g0 = 0; g0 < ngroups; g0 += 256) {   // uniform trip count: every lane takes part in the DPP halo exchange
+    struct Raw { u32x4 g, rq[NCH][3]; uint32_t tv[MERGE ? 8 : 1]; };   // as loaded, one register each: a conversion (or packing two of them) at issue time would be a wait
+    auto coords = [&](int g0, bool &live, int &h, int &w0, bool &first, bool &last) {
         const int g = g0 + threadIdx.x;
-        const bool live = g < ngroups;
+        live = g < ngroups;
         const int gc = live ? g : ngroups - 1;
-        const int h = gc / lpr, cg = gc - h * lpr, w0 = cg << 3;
-        const bool first = cg == 0, last = cg == lpr - 1;
-        float gv[8], pre[NCH][8], gq[NCH][8];
-        load8<T>(gp + (int64_t)h * W + w0, gv);
-        if constexpr (MODE == kDwSilu) {
-            if (dyt) {   // 8 two-byte loads: the 8 lanes that share a column group read 16 consecutive bytes of each column
-                const T *tp = dyt + b * gsb + c0 * gsc + (int64_t)w0 * H + h;
-                float tv[8];
+        h = gc / lpr;
+        const int cg = gc - h * lpr;
+        w0 = cg << 3; first = cg == 0; last = cg == lpr - 1;
+    };
+    auto issue = [&](int g0, Raw &r) {   // KEEP: every load of a pass-1 group, nothing waited for
+        bool live, first, last; int h, w0;
+        coords(g0, live, h, w0, first, last);
+        r.g = *reinterpret_cast<const u32x4 *>(gp + (int64_t)h * W + w0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tv[j] = to_f32(tp[(int64_t)j * H]);
+        for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j] + tv[j]));   // as the merge launch stored it
-            }
+            for (int k = 0; k < 3; ++k) r.rq[ch][k] = row10_issue<T>(x + b * xsb + (c0 + ch * cstep) * xsc, h, k - 1, H, W, w0);
+        if constexpr (MERGE) {   // 8 two-byte loads: the 8 lanes that share a column group read 16 consecutive bytes of each column
+            const T *tp = dyt + b * gsb + c0 * gsc + (int64_t)w0 * H + h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r.tv[j] = tp[(int64_t)j * H].v;
         }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int c = c0 + ch * cstep;
-            const T *xp = x + b * xsb + c * xsc;
-            float v[3][10];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) row10<T, EDGE>(xp, h, r - 1, H, W, w0, first, last, v[r]);
-            conv_rows<T>(v, w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
-            __builtin_amdgcn_sched_barrier(0);   // one channel's rows at a time in registers
-        }
+    };
+    auto finish = [&](bool live, int h, int w0, const float (&gv)[8], const float (&pre)[NCH][8]) {
+        float gq[NCH][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if constexpr (MODE == kDwSilu) {
@@ -371,6 +377,74 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) store8<T>(sg + ch * plane + (size_t)(h + 1) * W + w0, gq[ch]);
         }
+    };
+    auto process = [&](int g0, const Raw &r, u32x4 (&keep)[NCH]) {
+        bool live, first, last; int h, w0;
+        coords(g0, live, h, w0, first, last);
+        float gv[8], pre[NCH][8];
+        unpack2<T>(r.g.x, gv[0], gv[1]); unpack2<T>(r.g.y, gv[2], gv[3]); unpack2<T>(r.g.z, gv[4], gv[5]); unpack2<T>(r.g.w, gv[6], gv[7]);
+        if constexpr (MERGE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j] + to_f32(T{(uint16_t)r.tv[j]})));   // as the merge launch stored it
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = c0 + ch * cstep;
+            float v[3][10];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) row10_finish<T>(r.rq[ch][k], h, k - 1, H, first, last, v[k]);
+            conv_rows<T>(v, w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
+            keep[ch] = r.rq[ch][1];
+        }
+        finish(live, h, w0, gv, pre);
+    };
+    auto pass1 = [&](int g0) {   // the loads of one channel at a time, each waited for where it is used
+        bool live, first, last; int h, w0;
+        coords(g0, live, h, w0, first, last);
+        float gv[8], pre[NCH][8];
+        load8<T>(gp + (int64_t)h * W + w0, gv);
+        if constexpr (MODE == kDwSilu) {
+            if (dyt) {
+                const T *tp = dyt + b * gsb + c0 * gsc + (int64_t)w0 * H + h;
+                float tv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tv[j] = to_f32(tp[(int64_t)j * H]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j] + tv[j]));   // as the merge launch stored it
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = c0 + ch * cstep;
+            const T *xp = x + b * xsb + c * xsc;
+            float v[3][10];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) row10<T, EDGE>(xp, h, k - 1, H, W, w0, first, last, v[k]);
+            conv_rows<T>(v, w + c * 9, bias ? bias[c] : 0.f, pre[ch]);
+            __builtin_amdgcn_sched_barrier(0);   // one channel's rows at a time in registers
+        }
+        finish(live, h, w0, gv, pre);
+    };
+    if constexpr (KEEP) {
+        const bool two = ngroups > 256;
+        Raw r0, r1;
+        issue(0, r0);
+        if constexpr (MODE == kDwSilu) {   // one channel: both groups' loads fit the registers of four waves per SIMD
+            if (two) issue(256, r1);
+            __builtin_amdgcn_sched_barrier(0);   // everything above is in flight before anything below waits
+            process(0, r0, xkeep[0]);
+            if (two) process(256, r1, xkeep[1]);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            process(0, r0, xkeep[0]);
+            if (two) {
+                issue(256, r1);
+                __builtin_amdgcn_sched_barrier(0);
+                process(256, r1, xkeep[1]);
+            }
+        }
+    } else {
+        for (int g0 = 0; g0 < ngroups; g0 += 256) pass1(g0);   // uniform trip count: every lane takes part in the DPP halo exchange
     }
     __syncthreads();   // the LDS planes are complete
     // pass 2: with q = the gradient rows h - 1 .. h + 1 out of LDS (row h of the image is LDS row h + 1; both gradients below see
@@ -389,7 +463,7 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
         float acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-        for (int g0 = 0; g0 < ngroups; g0 += 256) {
+        auto pass2 = [&](int g0, const u32x4 &kept) {
             const int g = g0 + threadIdx.x;
             const bool live = g < ngroups;
             const int gc = live ? g : ngroups - 1;
@@ -397,7 +471,9 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
             const bool first = cg == 0, last = cg == lpr - 1;
             float xc[8], o[8];
             {
-                u32x4 q = *reinterpret_cast<const u32x4 *>(xp + (int64_t)h * W + w0);
+                u32x4 q;
+                if constexpr (KEEP) q = kept;
+                else q = *reinterpret_cast<const u32x4 *>(xp + (int64_t)h * W + w0);
                 if (!live) q = u32x4{0u, 0u, 0u, 0u};   // a lane that shadows the last group adds nothing to the sums
                 unpack2<T>(q.x, xc[0], xc[1]); unpack2<T>(q.y, xc[2], xc[3]); unpack2<T>(q.z, xc[4], xc[5]); unpack2<T>(q.w, xc[6], xc[7]);
             }
@@ -433,6 +509,12 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
                 }
             }
             if (live) store8<T>(dxp + (int64_t)h * W + w0, o);
+        };
+        if constexpr (KEEP) {
+            pass2(0, xkeep[0][ch]);
+            if (ngroups > 256) pass2(256, xkeep[1][ch]);
+        } else {
+            for (int g0 = 0; g0 < ngroups; g0 += 256) pass2(g0, xkeep[0][0]);
         }
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
@@ -646,11 +728,19 @@ static int bwd_fused_launch(const void *x, const float *w, const float *bias, co
                             int64_t dsb, int64_t dsc, hipStream_t s, const void *dyt = nullptr) {
     constexpr int NCH = MODE == kDwGate ? 2 : 1;
     if (!aligned16({x, dy, dx}, {xsb, xsc, gsb, gsc, dsb, dsc})) return OSS_ERR_SHAPE;
-    static LdsGate gate, gate_e;
+    static LdsGate gate, gate_e, gate_k;
     const size_t smem = fused_lds_bytes(NCH, H, W, sizeof(T));
     const bool edge = dw_edge(W);
-    auto kern = edge ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, true> : oss_dwconv3x3_bwd_fused_kernel<T, MODE, false>;
-    if (const int e = (edge ? gate_e : gate).ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
+    static const bool keep_ok = [] { const char *e = getenv("VMAMBAIR_DW_KEEP"); return !(e && e[0] == '0'); }();   // A-B timing
+    const bool keep = keep_ok && !edge && (W / 8) * H <= 512;   // <= 2 groups per lane: the centre rows of x stay in registers
+    auto kern = edge ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, true, false>
+                     : (keep ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, true> : oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, false>);
+    LdsGate *g = edge ? &gate_e : (keep ? &gate_k : &gate);
+    if constexpr (MODE == kDwSilu) {
+        static LdsGate gate_m;
+        if (keep && dyt) { kern = oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, true, true>; g = &gate_m; }
+    }
+    if (const int e = g->ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
     hipLaunchKernelGGL(kern, dim3(C / NCH, B), dim3(256), smem, s, reinterpret_cast<const T *>(x), w, bias,
                        reinterpret_cast<const T *>(dy), reinterpret_cast<T *>(dx), part, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc,
                        reinterpret_cast<const T *>(dyt));

@@ -45,6 +45,26 @@ __device__ __forceinline__ void row10(const T *plane, int h, int dy, int H, int 
 }
 
 
+// row10 in two halves, for kernels that put several rows' loads in flight before the first one is used (non-EDGE widths only):
+// row10_issue returns the raw 16 bytes of image row h + dy (of row h when that row is outside the image) -- no use of the loaded
+// value, so no wait; row10_finish turns them into v[0..9] exactly as row10 does (zeros for a row outside the image, halo by DPP).
+template <typename T>
+__device__ __forceinline__ u32x4 row10_issue(const T *plane, int h, int dy, int H, int W, int w0) {
+    const int hh = h + dy;
+    return *reinterpret_cast<const u32x4 *>(plane + (int64_t)((hh >= 0 && hh < H) ? hh : h) * W + w0);
+}
+template <typename T>
+__device__ __forceinline__ void row10_finish(u32x4 q, int h, int dy, int H, bool first, bool last, float (&v)[10]) {
+    const int hh = h + dy;
+    if (!(hh >= 0 && hh < H)) q = u32x4{0u, 0u, 0u, 0u};
+    float m[8];
+    unpack2<T>(q.x, m[0], m[1]); unpack2<T>(q.y, m[2], m[3]); unpack2<T>(q.z, m[4], m[5]); unpack2<T>(q.w, m[6], m[7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j + 1] = m[j];
+    v[0] = shift_from_prev_lane(v[8], 0.f, first);
+    v[9] = shift_from_next_lane(v[1], 0.f, last);
+}
+
 // lanes per image row do not tile a wave -> the EDGE instantiations (rows straddle waves)
 static inline bool stencil_edge(int W) { return (64 % (W / 8)) != 0; }
 
