@@ -836,33 +836,15 @@ struct WgradDesc {
 };
 template <typename T>
 __global__ void __launch_bounds__(256)
-oss_conv1x1_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint16_t *__restrict__ block_problem,
-                                 int xcd_order /* 0 (VMAMBAIR_WGRAD_XCD_ORDER=0, A-B timing): the tile groups of a problem far apart */) {
+oss_conv1x1_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint16_t *__restrict__ block_problem) {
     const WgradDesc d = descs[block_problem[blockIdx.x]];
     const unsigned local = blockIdx.x - d.first_block;
-    int slab, by, bz;
-    {
-        // (round 4) Workgroups that read the SAME pixels of the same tensors -- the tile groups bz of one (slab, batch) -- used to sit
-        // slabs * bgs blocks apart, i.e. started at unrelated times, and the operand window of the chip (512 workgroups x 128 KB in
-        // flight) is far larger than the L2s: every tile group fetched its operands from memory again (PMC: 5.9 GB per launch for
-        // 1.5 GB of operands, 38 % L2 misses, the launch at 4 TB/s of fabric traffic; profiles/r04_pmc_grouped_wgrad.txt).  Blocks
-        // are dealt to the 8 XCDs round-robin, so the tile groups of one problem now take CONSECUTIVE slots of ONE XCD (block ids 8
-        // apart): they start together, walk the pixels in step and meet in that XCD's L2.  Same tiles, same partials, same bits.
-        const unsigned S = (unsigned)d.slabs * (unsigned)d.bgs;
-        const unsigned nbz = (unsigned)(((((d.M + 31) >> 5) * ((d.NB + 31) >> 5)) + 3) >> 2);
-        unsigned pi;
-        if (xcd_order && nbz > 1 && (S & 7u) == 0) {
-            const unsigned q = local >> 3;
-            bz = (int)(q % nbz);
-            pi = (q / nbz) * 8 + (local & 7u);
-        } else {
-            bz = (int)(local / S);
-            pi = local % S;
-        }
-        slab = (int)(pi % (unsigned)d.slabs);
-        by = (int)(pi / (unsigned)d.slabs);
-    }
-    // table pointers are generic until told otherwise: FLAT loads would serialise the operand window behind every LDS wait
+    const int slab = (int)(local % (unsigned)d.slabs);
+    const unsigned r = local / (unsigned)d.slabs;
+    const int by = (int)(r % (unsigned)d.bgs), bz = (int)(r / (unsigned)d.bgs);
+    // (round 4, measured and removed: the tile groups bz of one (slab, batch) on consecutive slots of ONE XCD so that they meet in its
+    // L2 -- 233.2 images/s without against 232.5 / 232.8 with, FETCH_SIZE 5.75 GB either way: the launch's 5.9 GB are the operands
+    // themselves, held since the forward / backward pass, read once at 4 TB/s; profiles/r04_pmc_grouped_wgrad.txt)
     const WgradDesc *dt = descs + block_problem[blockIdx.x];
     wgrad_body<T>(table_ptr<const T>(&dt->dy), table_ptr<const T>(&dt->x), table_ptr<float>(&dt->part), d.M, d.N, d.P, d.gsb, d.gsm, d.xsb,
                   d.xsn, d.G, d.gsg, d.xsg, d.Mh, d.gs_hi, d.NB, slab, d.slabs, by, bz, d.span);
@@ -1278,13 +1260,12 @@ size_t wgrad_desc_bytes() { return sizeof(WgradDesc); }
 // descs: n descriptors in host memory with first_block filled; d_descs / d_map: their device copies (already queued on s)
 int wgrad_grouped_launch(int io, const void *d_descs, const void *d_map, unsigned total_blocks, hipStream_t s) {
     if (total_blocks == 0) return 0;
-    static const int xcd_order = [] { const char *e = getenv("VMAMBAIR_WGRAD_XCD_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
     if (io == OSS_BF16)
         hipLaunchKernelGGL(oss_conv1x1_wgrad_grouped_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, s,
-                           reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map), xcd_order);
+                           reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map));
     else if (io == OSS_F16)
         hipLaunchKernelGGL(oss_conv1x1_wgrad_grouped_kernel<f16_t>, dim3(total_blocks), dim3(256), 0, s,
-                           reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map), xcd_order);
+                           reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map));
     else
         return OSS_ERR_SHAPE;
     return (int)hipGetLastError();

@@ -25,6 +25,36 @@ namespace oss {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Copy of a [K][PT] activation tile (16-byte chunks, rows xsk apart) into LDS rows of PITCH elements, 256 threads.
+// (round 4) Written as `for (idx = tid; idx < K * CPR; idx += 256) lds[..] = global[..]` this was a loop of load -> s_waitcnt vmcnt(0)
+// -> ds_write round trips, one per chunk and thread (6 at K = 96, 12 at K = 192), at the head of a kernel that runs ONE workgroup
+// per CU -- nothing else on the CU to hide them behind.  Now the loads of up to GROUP chunks are issued back to back before the
+// first LDS write waits for its data.
+template <typename T, int K, int PT, int PITCH, int GROUP = 6>
+__device__ __forceinline__ void copy_tile_to_lds(const T *__restrict__ src, int64_t xsk, T *__restrict__ dst, int tid) {
+    constexpr int CPR = PT / 8, TOTAL = K * CPR, NCP = (TOTAL + 255) / 256;
+#pragma unroll
+    for (int i0 = 0; i0 < NCP; i0 += GROUP) {
+        u32x4 q[GROUP];
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) {
+            if (i0 + i < NCP) {
+                const int idx = min(tid + (i0 + i) * 256, TOTAL - 1);
+                const int c = idx / CPR, pc = idx - c * CPR;
+                q[i] = *reinterpret_cast<const u32x4 *>(src + c * xsk + 8 * pc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GROUP; ++i) {
+            if (i0 + i < NCP) {
+                const int idx = tid + (i0 + i) * 256;
+                const int c = idx / CPR, pc = idx - c * CPR;
+                if (TOTAL % 256 == 0 || idx < TOTAL) *reinterpret_cast<u32x4 *>(dst + c * PITCH + 8 * pc) = q[i];
+            }
+        }
+    }
+}
+
 // W(m, k) = w[m * ws_m + k * ws_k] as in oss_conv1x1.hip: forward ws_m = K, ws_k = 1; input gradient ws_m = 1, ws_k = M.
 // PT: pixels per workgroup (128; 64 when 128-pixel tiles would leave the chip with fewer than two workgroups per CU).
 // RES: y = W x + bias + res (the block's skip connection); the results then wait in LDS as fp32 so that the sum is rounded once.
@@ -78,12 +108,21 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
     // gridDim.z workgroups (each stages the activation tile again) when the pixel tiles alone would not fill the chip
     const int nz = gridDim.z, zi = blockIdx.z;
     if (wave * nz + zi < mt_total) issue(wave * nz + zi, cur);   // in flight across the activation copy
+    // (round 4) LayerNorm weight / bias of all K channels: requested here with everything else, parked in LDS behind the output staging
+    // area.  They used to be read where they are used, `if (c < K) { wc = ln.w[c]; ...` -- a branch, two loads and s_waitcnt vmcnt(0)
+    // per channel of the thread: 12 dependent round trips at K = 96 in a kernel that runs one workgroup per CU.
+    float *lnw_s = reinterpret_cast<float *>(os + 4 * 32 * PITCH), *lnb_s = lnw_s + K;
+    float lnw_r = 0.f, lnb_r = 0.f;
+    if constexpr (LN) {
+        const int c = min(tid, K - 1);
+        lnw_r = ln.w[c];
+        lnb_r = ln.b ? ln.b[c] : 0.f;
+    }
     // 1. the activation tile, 16 bytes per lane: lane -> (channel, 8-pixel chunk), a row's chunks on consecutive lanes
     constexpr int CPR = PT / 8;   // chunks per row
-    for (int idx = tid; idx < K * CPR; idx += 256) {
-        const int c = idx / CPR, pc = idx - c * CPR;
-        const u32x4 q = *reinterpret_cast<const u32x4 *>(xb + c * xsk + 8 * pc);
-        *reinterpret_cast<u32x4 *>(xs + c * PITCH + 8 * pc) = q;
+    copy_tile_to_lds<T, K, PT, PITCH>(xb, xsk, xs, tid);
+    if constexpr (LN) {
+        if (tid < K) { lnw_s[tid] = lnw_r; lnb_s[tid] = lnb_r; }
     }
     __syncthreads();
     if constexpr (LN) {
@@ -142,14 +181,17 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
             *reinterpret_cast<f32x4 *>(ln.rstd + (size_t)b * P + p0 + px) = f32x4{rstd[0], rstd[1], rstd[2], rstd[3]};
         }
         const bool with_bias = ln.b != nullptr;
+        float mu_c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mu_c[u] = with_bias ? mu[u] : 0.f;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = part + i * NPART;
             if (c < K) {
-                const float wc = ln.w[c], bc = with_bias ? ln.b[c] : 0.f;
+                const float wc = lnw_s[c], bc = lnb_s[c];
                 float o[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) o[u] = with_bias ? (v[i][u] - mu[u]) * rstd[u] * wc + bc : v[i][u] * rstd[u] * wc;
+                for (int u = 0; u < 4; ++u) o[u] = (v[i][u] - mu_c[u]) * rstd[u] * wc + bc;   // BiasFree: mu_c = 0, bc = 0 (x * rstd * w)
                 *reinterpret_cast<u32x2 *>(xs + c * PITCH + px) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
             }
         }
@@ -221,7 +263,7 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
     }
 }
 
-static size_t wg_lds_bytes(int K, int pt, bool res) { return ((size_t)K * 2 + 4 * 32 * (res ? 4 : 2)) * (pt + 8); }
+static size_t wg_lds_bytes(int K, int pt, bool res) { return ((size_t)K * 2 + 4 * 32 * (res ? 4 : 2)) * (pt + 8) + 2 * (size_t)K * sizeof(float); }   // + the LayerNorm weight / bias image
 // pixels per workgroup (64 | 128) and the row-tile split (gridDim.z): 0 = by shape, else forced (A-B timing).  Measured
 // (tools/conv_wg_test.py, and inside the SR and Deraining steps): K = 96 / 192 want 128 pixels when that still gives a
 // workgroup per CU, K <= 48 wants 64; a launch with fewer workgroups than CUs (Deraining levels 1.. at batch 4) loses to the
@@ -349,6 +391,12 @@ __device__ __forceinline__ void wg_lnbwd_stage(const WgLnBwdArgs<T> &a, const T 
         rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
     }
     float gv[CMAX][4], xv[CMAX][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // (round 4) the LayerNorm weights of this thread's channels, all requested here (clamped index, no branch).  Read where they are
+    // used -- `if (c < M) { wc = a.w[c]; ...` in both loops below -- each was a branch + load + s_waitcnt vmcnt(0): 2 x 16 dependent
+    // round trips in a kernel that runs one or two workgroups per CU.
+    float wcs[CMAX];
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) wcs[i] = a.w[min(part + i * NPART, M - 1)];
     float *pw = a.part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * M;
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) {
@@ -359,7 +407,7 @@ __device__ __forceinline__ void wg_lnbwd_stage(const WgLnBwdArgs<T> &a, const T 
             const u32x2 xq2 = *reinterpret_cast<const u32x2 *>(xt + c * PITCH + px);
             unpack2<T>(gq.x, gv[i][0], gv[i][1]); unpack2<T>(gq.y, gv[i][2], gv[i][3]);
             unpack2<T>(xq2.x, xv[i][0], xv[i][1]); unpack2<T>(xq2.y, xv[i][2], xv[i][3]);
-            const float wc = a.w[c];
+            const float wc = wcs[i];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float xh = with_bias ? (xv[i][u] - mu[u]) * rs[u] : xv[i][u] * rs[u];
@@ -395,7 +443,7 @@ __device__ __forceinline__ void wg_lnbwd_stage(const WgLnBwdArgs<T> &a, const T 
     for (int i = 0; i < CMAX; ++i) {
         const int c = part + i * NPART;
         if (c < M) {
-            const float wc = a.w[c];
+            const float wc = wcs[i];
             float sk[4] = {0.f, 0.f, 0.f, 0.f};
             if (has_skip) {
                 const u32x2 s2q = *reinterpret_cast<const u32x2 *>(st + c * PITCH + px);
@@ -441,10 +489,7 @@ oss_conv1x1_dgrad_lnbwd_kernel(const T *__restrict__ dy, const float *__restrict
             }
         }
     }
-    for (int idx = tid; idx < K * CPR; idx += 256) {
-        const int c = idx / CPR, pc = idx - c * CPR;
-        *reinterpret_cast<u32x4 *>(xs + c * PITCH + 8 * pc) = *reinterpret_cast<const u32x4 *>(xb + c * xsk + 8 * pc);
-    }
+    copy_tile_to_lds<T, K, PT, PITCH>(xb, xsk, xs, tid);
     // the LayerNorm input and the skip gradient of the tile: requested now, parked in LDS after the MFMAs
     constexpr int NLD = (128 * CPR + 255) / 256;   // 16-byte chunks per thread for <= 128 rows
     u32x4 xq[NLD], sq[NLD];
