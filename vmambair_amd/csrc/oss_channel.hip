@@ -53,6 +53,9 @@ __device__ __forceinline__ float sum_over_rows(float v, int lane) {
 // backward either way); without it every phase pays a round trip through L2
 // (a template parameter, not a runtime pointer select: generic-address loads would tie the LDS and vector-memory
 // wait counters together inside the serial scan loop)
+// (round 4, measured and reverted: every parameter of the phases below requested in one batch at the top of the kernel, with clamped
+// indices and stand-in pointers instead of `cond ? p[i] : 0` -- most of those loads are wave-uniform and were scalar loads already;
+// 16.7 us per launch against 15.4 as it stands, profiles/r04_serial_loads.txt)
 template <bool use_lds, int NT>
 __global__ void __launch_bounds__(NT)
 oss_chan_fwd_kernel(oss_chan_params p) {
@@ -66,38 +69,6 @@ oss_chan_fwd_kernel(oss_chan_params p) {
 #endif
     OSS_STAMP();
     const bool lift = p.cin_w != nullptr;
-    // (round 4) Every parameter the phases below read, requested HERE in one batch with clamped indices and stand-in pointers (a load
-    // under `cond ? p[i] : 0` or `if (...)` is a branch + load + s_waitcnt vmcnt(0) of its own; the kernel had 25 of them, one
-    // dependent L2 / HBM round trip each, phase after phase -- most of its 15 us on a handful of kilobytes).
-    constexpr int GPD = NT / 128, NPG = kChN / GPD;   // state groups per direction, states per group (the scan phase)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const float *cinw_p = lift ? p.cin_w : p.Dsc, *cinb_p = lift ? p.cin_b : p.Dsc;      // stand-ins: any readable floats
-    const float *coutw_p = lift ? p.cout_w : p.Dsc, *coutb_p = lift ? p.cout_b : p.Dsc;
-    float cinw[4], cinb[4], coutw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int ii = min(i, dc - 1); cinw[i] = cinw_p[ii]; cinb[i] = cinb_p[ii]; coutw[i] = coutw_p[ii]; }
-    const float coutb = coutb_p[0];
-    const int ncol_ = 2 * Cc, col_first = tid % (ncol_ < NT ? ncol_ : NT);
-    float wv0[4];        // xc_proj weights of this thread's first column (phase 1)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wv0[i] = p.Wxc[min(col_first, ncol_ - 1) * dc + min(i, dc - 1)];
-    const int nrow_ = 2 * dc, tpr_ = NT / nrow_, row_dt = min(tid / tpr_, nrow_ - 1);
-    const float brow0 = p.dt_bias[row_dt];
-    float wr0[8];        // dtc_projs weights of this thread's row (phase 2)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) wr0[r] = p.Wdtc[row_dt * Rc + min(r, Rc - 1)];
-    float Alog0[4][NPG], Dv0[4];   // the scan phase's A_log / D of this wave's (direction, state group)
-    {
-        const int k = wave / GPD, n0 = (wave - k * GPD) * NPG;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = k * dc + min(i, dc - 1);
-            Dv0[i] = p.Dsc[row];
-#pragma unroll
-            for (int nn = 0; nn < NPG; ++nn) Alog0[i][nn] = p.A_logs[row * kChN + n0 + nn];
-        }
-    }
-    const float cnw0 = p.cn_w[min(tid, L - 1)], cnb0 = p.cn_b[min(tid, L - 1)];   // channel_norm of the first output of this thread
     float *seq = sm;                 // [dc][L]
     float *ybuf = seq + dc * L;      // [2 dc][L]
     float *ycs = ybuf + 2 * dc * L;  // [L]
@@ -122,9 +93,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         } else {
             pl = p.pooled[(size_t)b * L + l];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < dc) seq[i * L + l] = lift ? __builtin_fmaf(cinw[i], pl, cinb[i]) : pl;
+        for (int i = 0; i < dc; ++i) seq[i * L + l] = lift ? __builtin_fmaf(p.cin_w[i], pl, p.cin_b[i]) : pl;
     }
     __syncthreads();
     OSS_STAMP();
@@ -143,10 +112,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
             if (sub >= tpc) break;
             float wv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wv[i] = col == col_first ? wv0[i] : p.Wxc[col * dc + min(i, dc - 1)];   // (a second column per thread only when 2 Cc > NT)
-                if (i >= dc) wv[i] = 0.f;
-            }
+            for (int i = 0; i < 4; ++i) wv[i] = i < dc ? p.Wxc[col * dc + i] : 0.f;
             const int k = col / Cc, c = col - k * Cc;
 #pragma unroll 4
             for (int l = sub; l < L; l += tpc) {
@@ -167,10 +133,10 @@ oss_chan_fwd_kernel(oss_chan_params p) {
         const int row = tid / tpr, sub = tid - row * tpr;
         if (row < nrow) {
             const int k = row / dc;
-            const float brow = brow0;   // row == row_dt
+            const float brow = p.dt_bias[row];
             float wr[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) wr[r] = r < Rc ? wr0[r] : 0.f;
+            for (int r = 0; r < 8; ++r) wr[r] = r < Rc ? p.Wdtc[row * Rc + r] : 0.f;
 #pragma unroll 2
             for (int l = sub; l < L; l += tpr) {
                 const float *zr = zb + (k * L + l) * Cc;
@@ -198,15 +164,17 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     // 13 us kernel at L = 96, 36.6 of 56.5 at L = 384).  Sums over the states of a group stay in the lane; the four groups'
     // partial sums of y go to LDS and are added in group order afterwards (fixed order: reruns are bit-identical).
     static_assert(NT == 512, "wave = (direction, one of four state groups)");
+    constexpr int GPD = NT / 128, NPG = kChN / GPD;   // state groups per direction, states per group
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     {
         const int k = wave / GPD, ng = wave - k * GPD, n0 = ng * NPG;
         float A2[4][NPG], carry[4][NPG], Dv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = k * dc + min(i, dc - 1);
-            Dv[i] = Dv0[i];
+            Dv[i] = p.Dsc[row];
 #pragma unroll
-            for (int nn = 0; nn < NPG; ++nn) { A2[i][nn] = -__expf(Alog0[i][nn]) * kLog2e; carry[i][nn] = 0.f; }
+            for (int nn = 0; nn < NPG; ++nn) { A2[i][nn] = -__expf(p.A_logs[row * kChN + n0 + nn]) * kLog2e; carry[i][nn] = 0.f; }
         }
         const int nchunk = (L + 127) >> 7;
         for (int c = 0; c < nchunk; ++c) {
@@ -277,10 +245,8 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     OSS_STAMP();
     float part = 0.f;
     for (int l = tid; l < L; l += NT) {
-        float s = lift ? coutb : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < dc) s = __builtin_fmaf(lift ? coutw[i] : 1.f, ybuf[i * L + l] + ybuf[(dc + i) * L + l], s);
+        float s = lift ? p.cout_b[0] : 0.f;
+        for (int i = 0; i < dc; ++i) s = __builtin_fmaf(lift ? p.cout_w[i] : 1.f, ybuf[i * L + l] + ybuf[(dc + i) * L + l], s);
         ycs[l] = s;
         part += s;
     }
@@ -291,8 +257,7 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     const float rstd = 1.0f / sqrtf(block_sum<NT>(q, red, tid) / (float)L + 1e-5f);
     for (int l = tid; l < L; l += NT) {
         p.yc[(size_t)b * L + l] = ycs[l];
-        const float cw = l == tid ? cnw0 : p.cn_w[l], cb = l == tid ? cnb0 : p.cn_b[l];   // (more outputs per thread only when L > NT)
-        p.c[(size_t)b * L + l] = __builtin_fmaf((ycs[l] - mu) * rstd, cw, cb);
+        p.c[(size_t)b * L + l] = __builtin_fmaf((ycs[l] - mu) * rstd, p.cn_w[l], p.cn_b[l]);
     }
     if (tid == 0) { p.stat[b * 2] = mu; p.stat[b * 2 + 1] = rstd; }
 #ifdef OSS_EXP_CHAN_TIMING

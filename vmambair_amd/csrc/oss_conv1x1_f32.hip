@@ -155,28 +155,45 @@ oss_conv1x1_f32_kernel(const F32Gemm a_) {
         f32x4 add[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) add[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (each group: all sixteen loads first, into registers of their own, then the sums -- written as one loop the compiler kept
+        // load r, s_waitcnt vmcnt(0), use r, load r + 1, ... : the ISA had two runs of sixteen `global_load ; s_waitcnt vmcnt(0)` pairs)
         if (a.bias) {
+            float bvs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const float bv = float_or_zero(a.bias + m, m < M);
-                add[r] = f32x4{bv, bv, bv, bv};
+                bvs[r] = float_or_zero(a.bias + m, m < M);
             }
-        }
-        if (rb) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const f32x4 rv = quad_or_zero(rb + (int64_t)m * a.rsm, m < M);
-                add[r].x += rv.x; add[r].y += rv.y; add[r].z += rv.z; add[r].w += rv.w;
+            for (int r = 0; r < 16; ++r) add[r] = f32x4{bvs[r], bvs[r], bvs[r], bvs[r]};
+        }
+        if (rb) {   // eight rows at a time: sixteen 16-byte temporaries next to MT = 2's accumulators do not fit the register file
+#pragma unroll
+            for (int h = 0; h < 16; h += 8) {
+                f32x4 rvs[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int m = m0 + 32 * t + ((h + r) & 3) + 8 * ((h + r) >> 2) + 4 * kg;
+                    rvs[r] = quad_or_zero(rb + (int64_t)m * a.rsm, m < M);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { add[h + r].x += rvs[r].x; add[h + r].y += rvs[r].y; add[h + r].z += rvs[r].z; add[h + r].w += rvs[r].w; }
             }
         }
         if (a.accumulate) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const f32x4 ov = quad_or_zero(yb + (int64_t)m * a.ysm, m < M);
-                add[r].x += ov.x; add[r].y += ov.y; add[r].z += ov.z; add[r].w += ov.w;
+            for (int h = 0; h < 16; h += 8) {
+                f32x4 ovs[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int m = m0 + 32 * t + ((h + r) & 3) + 8 * ((h + r) >> 2) + 4 * kg;
+                    ovs[r] = quad_or_zero(yb + (int64_t)m * a.ysm, m < M);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { add[h + r].x += ovs[r].x; add[h + r].y += ovs[r].y; add[h + r].z += ovs[r].z; add[h + r].w += ovs[r].w; }
             }
         }
 #pragma unroll
