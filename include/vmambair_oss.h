@@ -198,7 +198,7 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
                         oss_stream_t stream);
 
 /* The depth-wise convolution fused with the element-wise step that follows it, without ever storing the convolution
- * (16-bit io only; oss_dwconv3x3_fused_ok(io, H, W, 1 | 2) says whether a shape qualifies: width % 8 == 0, width / 8 divides 64,
+ * (16-bit io, and OSS_F32 since ABI 6 / round 4; oss_dwconv3x3_fused_ok(io, H, W, 1 | 2) says whether a shape qualifies: width % 8 == 0,
  * and 1 (silu) or 2 (gate) planes of (H + 2) x W elements fit the 160 KiB LDS of a workgroup; pointers 16-byte aligned and strides
  * multiples of 8 elements, else OSS_ERR_SHAPE).
  *   oss_dwconv3x3_silu_fwd: y = silu(conv(x) + bias)                         (SS2D_1: x = act(conv2d(x)), MambaSISR6_arch.py:486)

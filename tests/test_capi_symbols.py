@@ -133,7 +133,10 @@ def test_shape_rules_of_the_fused_kernels_are_pure_host_queries():
     BF16, F16, F32 = 2, 1, 0
     # depth-wise conv + silu (1 plane per workgroup) / + gelu gate (2 planes): 16-bit, W % 8 == 0, planes in LDS
     assert lib.oss_dwconv3x3_fused_ok(BF16, 64, 64, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F16, 128, 128, 2) == 1
-    assert lib.oss_dwconv3x3_fused_ok(F32, 64, 64, 1) == 0          # fp32 I/O stays on the separate kernels
+    # (round 4) float I/O too -- planes of twice the bytes: 64 x 64 gate fits, 160 x 160 gate (207 KiB) does not
+    assert lib.oss_dwconv3x3_fused_ok(F32, 64, 64, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F32, 64, 64, 2) == 1
+    assert lib.oss_dwconv3x3_fused_ok(F32, 160, 160, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F32, 160, 160, 2) == 0
+    assert lib.oss_dwconv3x3_flat2_ok(F32, 64, 64) == 1 and lib.oss_dwconv3x3_flat2_ok(BF16, 12, 64) == 0 and lib.oss_dwconv3x3_flat2_ok(BF16, 16, 160) == 0
     # (round 4) rows whose W / 8 lane groups straddle waves are taken too (EDGE instantiations): RealSR's 160-wide tiles, W = 24
     assert lib.oss_dwconv3x3_fused_ok(F16, 160, 160, 1) == 1 and lib.oss_dwconv3x3_fused_ok(F16, 160, 160, 2) == 1
     assert lib.oss_dwconv3x3_fused_ok(BF16, 16, 24, 2) == 1 and lib.oss_dwconv3x3_fused_ok(BF16, 16, 20, 2) == 0

@@ -157,13 +157,10 @@ oss_dwconv3x3_wide_kernel(const T *__restrict__ x, const float *__restrict__ w, 
         const int wc = threadIdx.x % W, hq = threadIdx.x / W;   // W * rows / 8 = 256 octets
         const int h0 = hb + hq * 8;
         if (h0 < H) {   // H % 8 == 0: an octet is inside the plane as a whole
-            uint32_t q[4];
+            float col8[8];   // (exact: the tile holds values already rounded to T)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t lo = tile[(hq * 8 + 2 * j) * W + wc].v, hi = tile[(hq * 8 + 2 * j + 1) * W + wc].v;
-                q[j] = lo | (hi << 16);
-            }
-            *reinterpret_cast<u32x4 *>(yt + b * ysb + c * ysc + (int64_t)wc * H + h0) = u32x4{q[0], q[1], q[2], q[3]};
+            for (int j = 0; j < 8; ++j) col8[j] = to_f32(tile[(hq * 8 + j) * W + wc]);
+            store8<T>(yt + b * ysb + c * ysc + (int64_t)wc * H + h0, col8);
         }
     }
 }
@@ -240,6 +237,11 @@ oss_dwconv3x3_wgrad_wide_kernel(const T *__restrict__ x, const T *__restrict__ d
 // the LDS planes with the mirrored taps -- three launches (activation backward, weight gradient, input gradient) and
 // four plane round trips through HBM become one launch that reads x, dy and writes dx.
 enum { kDwSilu = 0, kDwGate = 1 };
+// one element as a 2- or 4-byte load left it in a register -> fp32
+template <typename T> __device__ __forceinline__ float raw_item_f32(uint32_t r) {
+    if constexpr (sizeof(T) == 4) return __uint_as_float(r);
+    else return to_f32(T{(uint16_t)r});
+}
 
 // Phi(a) and phi(a) of the exact (erf) gelu from ONE exponential: erf(|z|) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),
 // t = 1 / (1 + p |z|)  (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- fp32 round-off level, four orders of magnitude under the
@@ -329,14 +331,14 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
     const size_t plane = (size_t)(H + 2) * W;
     const T *gp = dy + b * gsb + c0 * gsc;
     const int lpr = W >> 3, ngroups = lpr * H;
-    u32x4 xkeep[NKEEP][NCH];   // KEEP: the centre row of x of the lane's pass-1 groups (pass 2 walks the same groups)
+    Raw8<T> xkeep[NKEEP][NCH];   // KEEP: the centre row of x of the lane's pass-1 groups (pass 2 walks the same groups)
     // zero the two padding rows of every LDS plane
     for (int i = threadIdx.x; i < NCH * 2 * lpr; i += 256) {
         const int ch = i / (2 * lpr), r = i - ch * 2 * lpr, row = r < lpr ? 0 : H + 1, col = (r < lpr ? r : r - lpr) << 3;
-        *reinterpret_cast<u32x4 *>(sg + ch * plane + (size_t)row * W + col) = u32x4{0u, 0u, 0u, 0u};
+        store8_raw<T>(sg + ch * plane + (size_t)row * W + col, zero8<T>());
     }
     // pass 1: the gradient that reaches the convolution, rounded to T, into the LDS planes
-    struct Raw { u32x4 g, rq[NCH][3]; uint32_t tv[MERGE ? 8 : 1]; };   // as loaded, one register each: a conversion (or packing two of them) at issue time would be a wait
+    struct Raw { Raw8<T> g, rq[NCH][3]; uint32_t tv[MERGE ? 8 : 1]; };   // as loaded, one register each: a conversion (or packing two of them) at issue time would be a wait
     auto coords = [&](int g0, bool &live, int &h, int &w0, bool &first, bool &last) {
         const int g = g0 + threadIdx.x;
         live = g < ngroups;
@@ -348,7 +350,7 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
     auto issue = [&](int g0, Raw &r) {   // KEEP: every load of a pass-1 group, nothing waited for
         bool live, first, last; int h, w0;
         coords(g0, live, h, w0, first, last);
-        r.g = *reinterpret_cast<const u32x4 *>(gp + (int64_t)h * W + w0);
+        r.g = load8_raw<T>(gp + (int64_t)h * W + w0);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
@@ -356,7 +358,10 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
         if constexpr (MERGE) {   // 8 two-byte loads: the 8 lanes that share a column group read 16 consecutive bytes of each column
             const T *tp = dyt + b * gsb + c0 * gsc + (int64_t)w0 * H + h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r.tv[j] = tp[(int64_t)j * H].v;
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (sizeof(T) == 4) r.tv[j] = __float_as_uint(tp[(int64_t)j * H]);
+                else                          r.tv[j] = tp[(int64_t)j * H].v;
+            }
         }
     };
     auto finish = [&](bool live, int h, int w0, const float (&gv)[8], const float (&pre)[NCH][8]) {
@@ -378,14 +383,14 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
             for (int ch = 0; ch < NCH; ++ch) store8<T>(sg + ch * plane + (size_t)(h + 1) * W + w0, gq[ch]);
         }
     };
-    auto process = [&](int g0, const Raw &r, u32x4 (&keep)[NCH]) {
+    auto process = [&](int g0, const Raw &r, Raw8<T> (&keep)[NCH]) {
         bool live, first, last; int h, w0;
         coords(g0, live, h, w0, first, last);
         float gv[8], pre[NCH][8];
-        unpack2<T>(r.g.x, gv[0], gv[1]); unpack2<T>(r.g.y, gv[2], gv[3]); unpack2<T>(r.g.z, gv[4], gv[5]); unpack2<T>(r.g.w, gv[6], gv[7]);
+        unpack8<T>(r.g, gv);
         if constexpr (MERGE) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j] + to_f32(T{(uint16_t)r.tv[j]})));   // as the merge launch stored it
+            for (int j = 0; j < 8; ++j) gv[j] = to_f32(from_f32<T>(gv[j] + raw_item_f32<T>(r.tv[j])));   // as the merge launch stored it
         }
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
@@ -463,7 +468,7 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
         float acc[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-        auto pass2 = [&](int g0, const u32x4 &kept) {
+        auto pass2 = [&](int g0, const Raw8<T> &kept) {
             const int g = g0 + threadIdx.x;
             const bool live = g < ngroups;
             const int gc = live ? g : ngroups - 1;
@@ -471,11 +476,11 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
             const bool first = cg == 0, last = cg == lpr - 1;
             float xc[8], o[8];
             {
-                u32x4 q;
+                Raw8<T> q;
                 if constexpr (KEEP) q = kept;
-                else q = *reinterpret_cast<const u32x4 *>(xp + (int64_t)h * W + w0);
-                if (!live) q = u32x4{0u, 0u, 0u, 0u};   // a lane that shadows the last group adds nothing to the sums
-                unpack2<T>(q.x, xc[0], xc[1]); unpack2<T>(q.y, xc[2], xc[3]); unpack2<T>(q.z, xc[4], xc[5]); unpack2<T>(q.w, xc[6], xc[7]);
+                else q = load8_raw<T>(xp + (int64_t)h * W + w0);
+                if (!live) q = zero8<T>();   // a lane that shadows the last group adds nothing to the sums
+                unpack8<T>(q, xc);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
@@ -533,7 +538,7 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
 // the 8-pixel kernels apply when a row's W / 8 lane groups tile a wave and every plane / row start is 16-byte aligned
 template <typename T>
 static bool wide_ok(int W, std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
-    if (sizeof(T) != 2 || W % 8 != 0 || W > 512) return false;   // (64 % (W / 8)) != 0: the EDGE instantiations
+    if (W % 8 != 0 || W > 512) return false;   // (64 % (W / 8)) != 0: the EDGE instantiations; float I/O since round 4
     for (const void *p : ptrs)
         if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
     for (int64_t st : strides)
@@ -647,7 +652,7 @@ static int dwconv_launch(const void *x, const float *w, const float *bias, void 
     const T *xp = reinterpret_cast<const T *>(x);
     T *yp = reinterpret_cast<T *>(y);
     T *prp = reinterpret_cast<T *>(pre);
-    if constexpr (sizeof(T) == 2) {
+    {
         if (wide_ok<T>(W, {xp, yp, prp}, {xsb, xsc, ysb, ysc})) {
             dim3 grid(((W / 8) * H + 255) / 256, C, B);
             if ((64 % (W / 8)) != 0)
@@ -688,9 +693,9 @@ static size_t fused_lds_bytes(int nch, int H, int W, size_t esize) { return (siz
 // channel (pair)'s planes in LDS
 static bool dw_edge(int W) { return (64 % (W / 8)) != 0; }
 int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch) {
-    if (io != OSS_F16 && io != OSS_BF16) return 0;
+    if (io != OSS_F16 && io != OSS_BF16 && io != OSS_F32) return 0;   // (float I/O: round 4 -- the reference's own training precision)
     if (nch < 1 || nch > 2 || H <= 0 || W <= 0 || W % 8 != 0 || W > 512) return 0;
-    return fused_lds_bytes(nch, H, W, 2) + 4 * 20 * sizeof(float) <= kMaxLdsBytes ? 1 : 0;
+    return fused_lds_bytes(nch, H, W, io == OSS_F32 ? 4 : 2) + 4 * 20 * sizeof(float) <= kMaxLdsBytes ? 1 : 0;
 }
 
 static bool aligned16(std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> strides) {
@@ -718,6 +723,7 @@ static int dwgate_fwd_launch(const void *t, const float *w, const float *bias, v
 int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
                int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s) {
     if (!dwconv3x3_fused_ok(io, H, W, 2)) return OSS_ERR_SHAPE;
+    if (io == OSS_F32) return dwgate_fwd_launch<float>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s);
     return io == OSS_F16 ? dwgate_fwd_launch<f16_t>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s)
                          : dwgate_fwd_launch<bf16_t>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s);
 }
@@ -732,13 +738,18 @@ static int bwd_fused_launch(const void *x, const float *w, const float *bias, co
     const size_t smem = fused_lds_bytes(NCH, H, W, sizeof(T));
     const bool edge = dw_edge(W);
     static const bool keep_ok = [] { const char *e = getenv("VMAMBAIR_DW_KEEP"); return !(e && e[0] == '0'); }();   // A-B timing
-    const bool keep = keep_ok && !edge && (W / 8) * H <= 512;   // <= 2 groups per lane: the centre rows of x stay in registers
-    auto kern = edge ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, true, false>
-                     : (keep ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, true> : oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, false>);
-    LdsGate *g = edge ? &gate_e : (keep ? &gate_k : &gate);
-    if constexpr (MODE == kDwSilu) {
-        static LdsGate gate_m;
-        if (keep && dyt) { kern = oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, true, true>; g = &gate_m; }
+    // <= 2 groups per lane: the centre rows of x stay in registers (16-bit I/O: the float form's raw rows are twice the registers and
+    // end up in scratch memory -- it keeps the row-by-row loads)
+    bool keep = false;
+    auto kern = edge ? oss_dwconv3x3_bwd_fused_kernel<T, MODE, true, false> : oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, false>;
+    LdsGate *g = edge ? &gate_e : &gate;
+    if constexpr (sizeof(T) == 2) {
+        keep = keep_ok && !edge && (W / 8) * H <= 512;
+        if (keep) { kern = oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, true>; g = &gate_k; }
+        if constexpr (MODE == kDwSilu) {
+            static LdsGate gate_m;
+            if (keep && dyt) { kern = oss_dwconv3x3_bwd_fused_kernel<T, MODE, false, true, true>; g = &gate_m; }
+        }
     }
     if (const int e = g->ensure(reinterpret_cast<const void *>(kern), smem + 4 * NCH * 10 * sizeof(float))) return e;
     hipLaunchKernelGGL(kern, dim3(C / NCH, B), dim3(256), smem, s, reinterpret_cast<const T *>(x), w, bias,
@@ -775,6 +786,7 @@ static int flat2_fwd_launch(const void *x, const float *w, const float *bias, vo
 int dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *w, const float *bias, void *x2, int B, int C, int H, int W,
                              int64_t xsb, int64_t xsc, hipStream_t s) {
     if (!dwconv3x3_flat2_ok(io, H, W)) return OSS_ERR_SHAPE;
+    if (io == OSS_F32) return flat2_fwd_launch<float>(x, w, bias, x2, B, C, H, W, xsb, xsc, s);
     return io == OSS_F16 ? flat2_fwd_launch<f16_t>(x, w, bias, x2, B, C, H, W, xsb, xsc, s)
                          : flat2_fwd_launch<bf16_t>(x, w, bias, x2, B, C, H, W, xsb, xsc, s);
 }
@@ -784,7 +796,8 @@ int dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *w, const 
                              hipStream_t s) {
     if (!dwconv3x3_flat2_ok(io, H, W)) return OSS_ERR_SHAPE;
     const int64_t L = (int64_t)H * W;
-    const char *gt = reinterpret_cast<const char *>(g2) + (size_t)C * L * 2;
+    const char *gt = reinterpret_cast<const char *>(g2) + (size_t)C * L * (io == OSS_F32 ? 4 : 2);
+    if (io == OSS_F32) return bwd_fused_launch<float, kDwSilu>(x, w, bias, g2, dx, dw, db, part, B, C, H, W, xsb, xsc, 2 * C * L, L, dsb, dsc, s, gt);
     return io == OSS_F16 ? bwd_fused_launch<f16_t, kDwSilu>(x, w, bias, g2, dx, dw, db, part, B, C, H, W, xsb, xsc, 2 * C * L, L, dsb, dsc, s, gt)
                          : bwd_fused_launch<bf16_t, kDwSilu>(x, w, bias, g2, dx, dw, db, part, B, C, H, W, xsb, xsc, 2 * C * L, L, dsb, dsc, s, gt);
 }
@@ -794,6 +807,9 @@ int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, c
                         int64_t gsc, int64_t dsb, int64_t dsc, hipStream_t s) {
     const int nch = mode == kDwGate ? 2 : 1;
     if (!dwconv3x3_fused_ok(io, H, W, nch) || C % nch != 0) return OSS_ERR_SHAPE;
+    if (io == OSS_F32)
+        return mode == kDwGate ? bwd_fused_launch<float, kDwGate>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s)
+                               : bwd_fused_launch<float, kDwSilu>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s);
     if (mode == kDwGate)
         return io == OSS_F16 ? bwd_fused_launch<f16_t, kDwGate>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s)
                              : bwd_fused_launch<bf16_t, kDwGate>(x, w, bias, dy, dx, dw, db, part, B, C, H, W, xsb, xsc, gsb, gsc, dsb, dsc, s);
@@ -813,8 +829,8 @@ static int wgrad_launch(const void *x, const void *dy, float *dw, float *db, flo
                                          reinterpret_cast<uintptr_t>(dpp)) & amask) == 0 &&
                      (xsb % 4 == 0) && (xsc % 4 == 0) && (gsb % 4 == 0) && (gsc % 4 == 0);
     bool wide = false;
-    if constexpr (sizeof(T) == 2) wide = wide_ok<T>(W, {xp, gp, prp, dpp}, {xsb, xsc, gsb, gsc});
-    if constexpr (sizeof(T) == 2) {
+    wide = wide_ok<T>(W, {xp, gp, prp, dpp}, {xsb, xsc, gsb, gsc});
+    {
         if (wide)
         {
             if ((64 % (W / 8)) != 0)

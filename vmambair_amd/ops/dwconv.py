@@ -16,11 +16,15 @@ from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_vi
 #: ``VMAMBAIR_DW_FUSED=0``: the convolution and the activation / gate behind it run as the separate kernels of rounds 1-2
 #: (convolution output stored, three backward launches) instead of the fused forms of oss_dwconv.hip (A-B timing).
 DW_FUSED = os.environ.get("VMAMBAIR_DW_FUSED", "1") == "1"
+#: ``VMAMBAIR_DW_FUSED_F32=0``: fp32 tensors stay on the separate kernels as in rounds 1-3 (A-B timing of the float instantiations)
+DW_FUSED_F32 = os.environ.get("VMAMBAIR_DW_FUSED_F32", "1") == "1"
 
 
 def fused_ok(x: torch.Tensor, planes: int) -> bool:
     """does the fused (convolution never stored) form take this tensor?  ``planes``: 1 = conv + silu, 2 = conv + gelu gate"""
-    if not (DW_FUSED and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and x.numel()):
+    if not (DW_FUSED and x.is_cuda and x.dim() == 4 and x.dtype in _DT and x.numel()):   # float I/O since round 4
+        return False
+    if x.dtype == torch.float32 and not DW_FUSED_F32:
         return False
     return bool(_capi.load().oss_dwconv3x3_fused_ok(_DT[x.dtype], x.shape[2], x.shape[3], planes))
 
@@ -99,7 +103,7 @@ def flat2_ok(x: torch.Tensor) -> bool:
 def dwconv3x3_silu_flat2_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """-> x2 (B, 2, C, H*W): ``silu(conv(x))`` flattened row-major and column-major (the two forward directions of
     ``cross_scan_2d``, MambaSISR6_arch.py:399-404) out of ONE launch; bit-identical to ``dwconv3x3_silu_fwd`` + ``cross_scan2``"""
-    _check(x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16), "dwconv3x3_silu_flat2: x must be a 16-bit (B, C, H, W) GPU tensor")
+    _check(x.is_cuda and x.dim() == 4 and x.dtype in _DT, "dwconv3x3_silu_flat2: x must be a (B, C, H, W) GPU tensor")
     B, Cc, H, W = x.shape
     _check(tuple(weight.shape) == (Cc, 1, 3, 3), "dwconv3x3_silu_flat2: weight must be (C, 1, 3, 3)")
     w, b = _w9(weight, bias)
