@@ -1203,10 +1203,10 @@ int conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dw, float 
                   int64_t gs_hi, float *db) {
     const int NB = N + (db ? 1 : 0);
     if (G < 1 || (size_t)B * G > 65535) return OSS_ERR_SHAPE;
-    if (io == OSS_F32) {   // plain 1x1 weight gradient only (the projection products call rows_f32_wgrad themselves); no bias column
-        if (db || G != 1 || (Mh > 0 && Mh != M)) return OSS_ERR_SHAPE;
+    if (io == OSS_F32) {   // plain 1x1 weight gradient only (the projection products call rows_f32_wgrad themselves)
+        if (G != 1 || (Mh > 0 && Mh != M)) return OSS_ERR_SHAPE;
         return rows_f32_wgrad(reinterpret_cast<const float *>(dy), reinterpret_cast<const float *>(x), dw, part, B, 1, 1, M, N, P, gsb, 0,
-                              gsm, xsb, 0, xsn, s);
+                              gsm, xsb, 0, xsn, s, db);
     }
     if (Mh <= 0 || Mh > M) Mh = M;
     int slabs = conv1x1_wgrad_slabs(P);

@@ -30,12 +30,18 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return 
 // kernel-argument pointer and the address of a __device__ variable as C++ pointers yields a FLAT pointer, flat loads count in
 // both wait counters, and the compiler then waits vmcnt(0) before every MFMA round.)
 __device__ const float g_zero_quad[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+__device__ const float g_one_quad[4] __attribute__((aligned(16))) = {1.f, 1.f, 1.f, 1.f};   // the virtual all-ones row of the bias column
 typedef const f32x4 __attribute__((address_space(1))) *GlobalQuadPtr;
 typedef const float __attribute__((address_space(1))) *GlobalFloatPtr;
 __device__ __forceinline__ uintptr_t addr_or_zero(const float *p, bool ok) {
     return ok ? reinterpret_cast<uintptr_t>(p) : reinterpret_cast<uintptr_t>(&g_zero_quad[0]);
 }
 __device__ __forceinline__ f32x4 quad_or_zero(const float *p, bool ok) { return *reinterpret_cast<GlobalQuadPtr>(addr_or_zero(p, ok)); }
+// ... or four ones (`one`, when ok): the address is chosen before the load, nothing is selected after it
+__device__ __forceinline__ f32x4 quad_one_or_zero(const float *p, bool ok, bool one) {
+    const uintptr_t a = ok ? (one ? reinterpret_cast<uintptr_t>(&g_one_quad[0]) : reinterpret_cast<uintptr_t>(p)) : reinterpret_cast<uintptr_t>(&g_zero_quad[0]);
+    return *reinterpret_cast<GlobalQuadPtr>(a);
+}
 __device__ __forceinline__ float float_or_zero(const float *p, bool ok) { return *reinterpret_cast<GlobalFloatPtr>(addr_or_zero(p, ok)); }
 
 // ---- forward / input gradient -------------------------------------------------------------------------------------------------
@@ -301,17 +307,19 @@ constexpr int kF32WgradSlab = 512;   // pixels per partial product
 template <int TM, int TN>
 __global__ void __launch_bounds__(256)
 oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__ bm, float *__restrict__ part, int M, int N, int P, int G,
-                          int GB, int64_t asb, int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn) {
+                          int GB, int64_t asb, int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn,
+                          int NB /* N, or N + 1 (G == 1): a virtual all-ones row of Bm whose column of the product is sum_p A = the bias
+                          gradient of a 1x1 convolution -- it used to be a torch sum over dy of its own, 100 launches per fp32 step */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kg = lane >> 5;
     const int b = blockIdx.y / G, g = blockIdx.y - b * G, slab = blockIdx.x;
-    const int mt = (M + 32 * TM - 1) / (32 * TM), nt = (N + 32 * TN - 1) / (32 * TN);
+    const int mt = (M + 32 * TM - 1) / (32 * TM), nt = (NB + 32 * TN - 1) / (32 * TN);
     const int tile = blockIdx.z * 4 + wave;
     if (tile >= mt * nt) return;
     const int m0 = (tile / nt) * 32 * TM, n0 = (tile % nt) * 32 * TN;
     const int pbeg = slab * kF32WgradSlab, pend = min(P, pbeg + kF32WgradSlab);
     const float *ab = a + b * asb + g * asg, *bb = bm + b * bsb + (g % GB) * bsg;
     const float *ar[TM], *br[TN];
-    bool aok[TM], bok[TN];
+    bool aok[TM], bok[TN], bone[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + 32 * i + col;
@@ -321,8 +329,9 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + 32 * j + col;
-        bok[j] = n < N;
-        br[j] = bb + (int64_t)(bok[j] ? n : 0) * bsn;
+        bone[j] = n == N && NB > N;
+        bok[j] = n < N || bone[j];
+        br[j] = bb + (int64_t)(n < N ? n : 0) * bsn;
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -345,7 +354,7 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bv[u][j] = quad_or_zero(br[j] + pc, ok && bok[j]);
+                bv[u][j] = quad_one_or_zero(br[j] + pc, ok && bok[j], bone[j]);
             }
         }
     };
@@ -371,7 +380,8 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
         if (p + 8 * U < pend) mfma_round(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    float *pb = part + ((size_t)(b * gridDim.x + slab) * G + g) * M * N;
+    const size_t pvec = (size_t)G * M * N + (NB > N ? M : 0);   // one partial vector per (batch, slab): [G][M][N], then the M bias sums
+    float *pb = part + (size_t)(b * gridDim.x + slab) * pvec + (size_t)g * M * N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -381,12 +391,13 @@ oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (m < M && n < N) pb[(size_t)m * N + n] = acc[i][j][r];
+                else if (m < M && n == N && NB > N) pb[(size_t)M * N + m] = acc[i][j][r];   // (G == 1)
             }
         }
 }
 
 __global__ void __launch_bounds__(256)
-oss_rows_f32_wgrad_finish(const float *__restrict__ part, float *__restrict__ out, int K, size_t pvec) {
+oss_rows_f32_wgrad_finish(const float *__restrict__ part, float *__restrict__ out, int K, size_t pvec, size_t nw, float *__restrict__ db) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= pvec) return;
     float s = 0.f;
@@ -399,7 +410,8 @@ oss_rows_f32_wgrad_finish(const float *__restrict__ part, float *__restrict__ ou
         for (int j = 0; j < 8; ++j) s += v[j];
     }
     for (; k < K; ++k) s += part[(size_t)k * pvec + i];
-    out[i] = s;
+    if (i < nw) out[i] = s;
+    else db[i - nw] = s;   // the bias column
 }
 
 int rows_f32_wgrad_slabs(int P) { return (P + kF32WgradSlab - 1) / kF32WgradSlab; }
@@ -414,24 +426,25 @@ int rows_f32_wgrad_ok(int M, int N, int P, const void *a, const void *bm, std::i
 }
 
 int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int B, int G, int GB, int M, int N, int P, int64_t asb,
-                   int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, hipStream_t s) {
+                   int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, hipStream_t s, float *db) {
     if (!rows_f32_wgrad_ok(M, N, P, a, bm, {asb, asg, asm_, bsb, bsg, bsn})) return OSS_ERR_SHAPE;
-    if (B <= 0 || G <= 0 || GB <= 0 || (size_t)B * G > 65535) return OSS_ERR_SHAPE;
+    if (B <= 0 || G <= 0 || GB <= 0 || (size_t)B * G > 65535 || (db && G != 1)) return OSS_ERR_SHAPE;
+    const int NB = N + (db ? 1 : 0);
     const int slabs = rows_f32_wgrad_slabs(P);
     // 64 x 32 tiles; 32 x 32 when the wider tile would leave most SIMDs without a wave
-    const int t21 = ((M + 63) / 64) * ((N + 31) / 32), t11 = ((M + 31) / 32) * ((N + 31) / 32);
+    const int t21 = ((M + 63) / 64) * ((NB + 31) / 32), t11 = ((M + 31) / 32) * ((NB + 31) / 32);
     if ((long)t21 * slabs * B * G >= 1024 && M > 32) {
         const dim3 grid(slabs, B * G, (t21 + 3) / 4);
-        hipLaunchKernelGGL((oss_rows_f32_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn);
+        hipLaunchKernelGGL((oss_rows_f32_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn, NB);
     } else {
         const dim3 grid(slabs, B * G, (t11 + 3) / 4);
-        hipLaunchKernelGGL((oss_rows_f32_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn);
+        hipLaunchKernelGGL((oss_rows_f32_wgrad_kernel<1, 1>), grid, dim3(256), 0, s, a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn, NB);
     }
-    const size_t pvec = (size_t)G * M * N;
+    const size_t nw = (size_t)G * M * N, pvec = nw + (db ? M : 0);
     if (defer_finish())
-        defer_sum(part, slabs * B, pvec, pvec, out, pvec, nullptr);
+        defer_sum(part, slabs * B, pvec, pvec, out, nw, db);
     else
-        hipLaunchKernelGGL(oss_rows_f32_wgrad_finish, dim3((unsigned)((pvec + 255) / 256)), dim3(256), 0, s, part, out, slabs * B, pvec);
+        hipLaunchKernelGGL(oss_rows_f32_wgrad_finish, dim3((unsigned)((pvec + 255) / 256)), dim3(256), 0, s, part, out, slabs * B, pvec, nw, db);
     return (int)hipGetLastError();
 }
 

@@ -99,7 +99,7 @@ int proj_dgrad_f32(const float *ddts, float *dxdbl, const float *du, const float
                    int R, int L, hipStream_t s);
 size_t rows_f32_wgrad_partial_floats(int B, int G, int M, int N, int P);
 int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int B, int G, int GB, int M, int N, int P, int64_t asb,
-                   int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, hipStream_t s);
+                   int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, hipStream_t s, float *db = nullptr);
 // thin dense 3x3 convolutions (oss_conv3x3_thin.hip): <= 4 channels in or out
 int conv3x3_thin_ok(oss_dtype io, int Cin, int Cout, int H, int W);
 int conv3x3_thin_fwd(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int Cin, int Cout, int H, int W,

@@ -61,16 +61,15 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
     with torch.cuda.device(x.device):
         with _fork_for_wgrad(x, dy):
             dw = torch.empty((Cout, Cin), dtype=torch.float32, device=x.device)
-            # the fp32 weight-gradient kernel has no bias column: a 1x1 bias (none of the archs' blocks has one) is a plain sum
-            db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if (has_bias and not f32) else None
+            # (round 4: the fp32 weight-gradient kernel has the bias column too -- in_conv / out_conv carry a bias, and `dy.sum` was
+            # 100 launches of a vendor reduction per fp32 step)
+            db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
             part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
             _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
                                               Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
                                               torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
             _keep(part, dw, db)
             _keep_operands(dy, x)
-            if has_bias and db is None:
-                db = dy.sum(dim=(0, 2, 3))
         if f32 and CONV1X1_F32_WGRAD_ONLY:
             dx = torch.nn.functional.conv_transpose2d(dy, weight.detach().float())
         else:
