@@ -448,6 +448,11 @@ oss_rows_f32_wgrad_finish(const float *__restrict__ part, float *__restrict__ ou
     else db[i - nw] = s;   // the bias column
 }
 
+// (round 4, measured and removed: these products as ONE grouped launch, as the 16-bit path runs them -- shared descriptor, 32 x 32 tiles.
+// 2 launches of 3.6 ms = 7.2 ms per step against 7.3 ms for the 302 separate launches, 148.6 against 150.5 images/s: the operands are
+// cold by then (11.8 GB held) and this kernel reads them 16 bytes per row and load instruction, 32 cache lines each -- the separate
+// launches find them in the L2 / MALL of the pass that produced them.  A grouped form would need the LDS-staged operand tiles of the
+// 16-bit kernel first.  profiles/r04_fp32_grouped_wgrad_no_gain.txt)
 int rows_f32_wgrad_slabs(int P) { return (P + kF32WgradSlab - 1) / kF32WgradSlab; }
 size_t rows_f32_wgrad_partial_floats(int B, int G, int M, int N, int P) { return (size_t)B * rows_f32_wgrad_slabs(P) * G * M * N; }
 
