@@ -575,8 +575,8 @@ size_t oss_deferred_wgrad_table_bytes(void) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
     size_t blocks = 0;
     for (unsigned b : g_wgrad_blocks) blocks += b;
-    // per I/O type present: descriptors (padded to 256 bytes) + one 16-bit problem index per workgroup (padded) -- an upper bound
-    return ((g_wgrad_descs.size() + 255) & ~(size_t)255) + 2 * blocks + 3 * 512;
+    // descriptors (padded to 256 bytes) + one 16-bit problem index per workgroup
+    return ((g_wgrad_descs.size() + 255) & ~(size_t)255) + 2 * blocks;
 }
 int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes, oss_stream_t stream) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
@@ -585,42 +585,27 @@ int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes
     if (!host_table || !device_table) return OSS_ERR_NULL;
     if (n > 65535) return OSS_ERR_SHAPE;
     const size_t db = wgrad_desc_bytes();
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    unsigned char *hbase = reinterpret_cast<unsigned char *>(host_table), *dbase = reinterpret_cast<unsigned char *>(device_table);
-    size_t off = 0;
-    int rc = 0;
-    // one grouped launch per I/O type present (a step has one; fp32 products next to 16-bit ones -- float activations under
-    // autocast -- get a launch of their own): [descriptors, padded to 256 bytes | one 16-bit problem index per workgroup] each
-    for (int io : {(int)OSS_BF16, (int)OSS_F16, (int)OSS_F32}) {
-        size_t cnt = 0, total = 0;
-        for (size_t i = 0; i < n; ++i)
-            if (wgrad_desc_io(g_wgrad_descs.data() + i * db) == io) { ++cnt; total += g_wgrad_blocks[i]; }
-        if (cnt == 0) continue;
-        if (total > 0x7fffffffu) return OSS_ERR_SHAPE;
-        const size_t desc_bytes = (cnt * db + 255) & ~(size_t)255;
-        const size_t bytes = (desc_bytes + 2 * total + 255) & ~(size_t)255;
-        if (off + bytes > capacity_bytes) return OSS_ERR_WORKSPACE;
-        uint16_t *map = reinterpret_cast<uint16_t *>(hbase + off + desc_bytes);
-        unsigned first = 0;
-        size_t j = 0;
-        for (size_t i = 0; i < n; ++i) {
-            unsigned char *d = g_wgrad_descs.data() + i * db;
-            if (wgrad_desc_io(d) != io) continue;
-            wgrad_desc_set_first_block(d, first);
-            std::memcpy(hbase + off + j * db, d, db);
-            for (unsigned k = 0; k < g_wgrad_blocks[i]; ++k) map[first + k] = (uint16_t)j;
-            first += g_wgrad_blocks[i];
-            ++j;
-        }
-        const hipError_t e = hipMemcpyAsync(dbase + off, hbase + off, desc_bytes + 2 * total, hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) return (int)e;
-        rc = wgrad_grouped_launch(io, dbase + off, dbase + off + desc_bytes, (unsigned)total, s);
-        if (rc != 0) break;
-        off += bytes;
+    const size_t desc_bytes = (g_wgrad_descs.size() + 255) & ~(size_t)255;
+    size_t total = 0;
+    for (unsigned b : g_wgrad_blocks) total += b;
+    if (desc_bytes + 2 * total > capacity_bytes) return OSS_ERR_WORKSPACE;
+    if (total > 0x7fffffffu) return OSS_ERR_SHAPE;
+    const int io = wgrad_desc_io(g_wgrad_descs.data());
+    unsigned first = 0;
+    uint16_t *map = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(host_table) + desc_bytes);
+    for (size_t i = 0; i < n; ++i) {
+        if (wgrad_desc_io(g_wgrad_descs.data() + i * db) != io) return OSS_ERR_SHAPE;   // one I/O type per flush
+        wgrad_desc_set_first_block(g_wgrad_descs.data() + i * db, first);
+        for (unsigned k = 0; k < g_wgrad_blocks[i]; ++k) map[first + k] = (uint16_t)i;
+        first += g_wgrad_blocks[i];
     }
+    std::memcpy(host_table, g_wgrad_descs.data(), g_wgrad_descs.size());
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const hipError_t e = hipMemcpyAsync(device_table, host_table, desc_bytes + 2 * total, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
     g_wgrad_descs.clear();
     g_wgrad_blocks.clear();
-    return rc;
+    return wgrad_grouped_launch(io, device_table, reinterpret_cast<unsigned char *>(device_table) + desc_bytes, (unsigned)total, s);
 }
 
 void oss_set_defer_finish(int on) {

@@ -825,7 +825,15 @@ oss_conv1x1_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, floa
 // full for the whole launch and the operands stream at memory speed.  Same per-problem arithmetic; with a span of one 512-pixel
 // piece per partial (oss_conv1x1_wgrad_set_span(1)) also the same partial layout and finishing sums, i.e. bit-identical weight
 // gradients -- the default span of 4 pieces adds the same terms in another order (equal to fp32 round-off, run-to-run stable).
-// (struct WgradDesc: oss_host.h -- shared with the fp32 form in oss_conv1x1_f32.hip)
+struct WgradDesc {
+    const void *dy, *x;
+    float *part;
+    int64_t gsb, gsm, xsb, xsn, gsg, xsg, gs_hi;
+    int M, N, P, G, Mh, NB, slabs, bgs /* batch * G */;
+    unsigned first_block;
+    int io;
+    int span, reserved_;   // pixels per partial product
+};
 template <typename T>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint16_t *__restrict__ block_problem) {
@@ -1252,7 +1260,6 @@ size_t wgrad_desc_bytes() { return sizeof(WgradDesc); }
 // descs: n descriptors in host memory with first_block filled; d_descs / d_map: their device copies (already queued on s)
 int wgrad_grouped_launch(int io, const void *d_descs, const void *d_map, unsigned total_blocks, hipStream_t s) {
     if (total_blocks == 0) return 0;
-    if (io == OSS_F32) return rows_f32_wgrad_grouped_launch(d_descs, d_map, total_blocks, s);
     if (io == OSS_BF16)
         hipLaunchKernelGGL(oss_conv1x1_wgrad_grouped_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, s,
                            reinterpret_cast<const WgradDesc *>(d_descs), reinterpret_cast<const uint16_t *>(d_map));

@@ -15,7 +15,6 @@
 // fp32 MFMA is 1/16 of the bf16 rate (256 flop / clock / CU), so these kernels are bound by the matrix pipe, not by their loads.
 #include <initializer_list>
 #include "oss_device.h"
-#include "oss_global_ptr.h"
 #include "oss_host.h"
 #include "oss_mfma.h"
 
@@ -305,18 +304,16 @@ int proj_dgrad_f32(const float *ddts, float *dxdbl, const float *du, const float
 //   A row (b, g, m):  a + b * asb + g * asg + m * asm;   Bm row (b, g % GB, n):  bm + b * bsb + (g % GB) * bsg + n * bsn
 // one wave = a (32 TM) x (32 TN) tile of one (b, g, slab); grid (slabs, B * G, ceil(tiles / 4)), 256 threads (4 tiles).
 constexpr int kF32WgradSlab = 512;   // pixels per partial product
-// The body is shared by the one-problem launch and the grouped launch (oss_rows_f32_wgrad_grouped_kernel): `slab` of `nslabs`,
-// `by` = batch * G + group, `bz` = group of four tiles -- the launch coordinates of the one-problem grid.
 template <int TM, int TN>
-__device__ __forceinline__ void
-rows_f32_wgrad_body(const float *__restrict__ a, const float *__restrict__ bm, float *__restrict__ part, int M, int N, int P, int G,
-                    int GB, int64_t asb, int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, int slab, int nslabs, int by, int bz,
+__global__ void __launch_bounds__(256)
+oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__ bm, float *__restrict__ part, int M, int N, int P, int G,
+                          int GB, int64_t asb, int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn,
                           int NB /* N, or N + 1 (G == 1): a virtual all-ones row of Bm whose column of the product is sum_p A = the bias
                           gradient of a 1x1 convolution -- it used to be a torch sum over dy of its own, 100 launches per fp32 step */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kg = lane >> 5;
-    const int b = by / G, g = by - b * G;
+    const int b = blockIdx.y / G, g = blockIdx.y - b * G, slab = blockIdx.x;
     const int mt = (M + 32 * TM - 1) / (32 * TM), nt = (NB + 32 * TN - 1) / (32 * TN);
-    const int tile = bz * 4 + wave;
+    const int tile = blockIdx.z * 4 + wave;
     if (tile >= mt * nt) return;
     const int m0 = (tile / nt) * 32 * TM, n0 = (tile % nt) * 32 * TN;
     const int pbeg = slab * kF32WgradSlab, pend = min(P, pbeg + kF32WgradSlab);
@@ -384,7 +381,7 @@ rows_f32_wgrad_body(const float *__restrict__ a, const float *__restrict__ bm, f
         __builtin_amdgcn_sched_barrier(0);
     }
     const size_t pvec = (size_t)G * M * N + (NB > N ? M : 0);   // one partial vector per (batch, slab): [G][M][N], then the M bias sums
-    float *pb = part + (size_t)(b * nslabs + slab) * pvec + (size_t)g * M * N;
+    float *pb = part + (size_t)(b * gridDim.x + slab) * pvec + (size_t)g * M * N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -397,37 +394,6 @@ rows_f32_wgrad_body(const float *__restrict__ a, const float *__restrict__ bm, f
                 else if (m < M && n == N && NB > N) pb[(size_t)M * N + m] = acc[i][j][r];   // (G == 1)
             }
         }
-}
-
-template <int TM, int TN>
-__global__ void __launch_bounds__(256)
-oss_rows_f32_wgrad_kernel(const float *__restrict__ a, const float *__restrict__ bm, float *__restrict__ part, int M, int N, int P, int G,
-                          int GB, int64_t asb, int64_t asg, int64_t asm_, int64_t bsb, int64_t bsg, int64_t bsn, int NB) {
-    rows_f32_wgrad_body<TM, TN>(a, bm, part, M, N, P, G, GB, asb, asg, asm_, bsb, bsg, bsn, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y,
-                                (int)blockIdx.z, NB);
-}
-
-// Grouped launch (round 4): every recorded fp32 weight-gradient product of a backward pass as one kernel, as the 16-bit path has had
-// since round 3 (oss_conv1x1.hip: oss_conv1x1_wgrad_grouped_kernel) -- the fp32 step ran them as 302 launches of 19 / 41 us, each an
-// under-filled round of workgroups.  32 x 32 tiles throughout (the chip is full either way); same tiles, partial layout and finishing
-// sums as the one-problem launch of the <1, 1> form.
-__global__ void __launch_bounds__(256)
-oss_rows_f32_wgrad_grouped_kernel(const WgradDesc *__restrict__ descs, const uint16_t *__restrict__ block_problem) {
-    const WgradDesc *dt = descs + block_problem[blockIdx.x];
-    const WgradDesc d = *dt;
-    const unsigned local = blockIdx.x - d.first_block;
-    const int slab = (int)(local % (unsigned)d.slabs);
-    const unsigned r = local / (unsigned)d.slabs;
-    const int by = (int)(r % (unsigned)d.bgs), bz = (int)(r / (unsigned)d.bgs);
-    rows_f32_wgrad_body<1, 1>(table_ptr<const float>(&dt->dy), table_ptr<const float>(&dt->x), table_ptr<float>(&dt->part), d.M, d.N, d.P,
-                              d.G, d.Mh, d.gsb, d.gsg, d.gsm, d.xsb, d.xsg, d.xsn, slab, d.slabs, by, bz, d.NB);
-}
-
-int rows_f32_wgrad_grouped_launch(const void *d_descs, const void *d_map, unsigned total_blocks, hipStream_t s) {
-    if (total_blocks == 0) return 0;
-    hipLaunchKernelGGL(oss_rows_f32_wgrad_grouped_kernel, dim3(total_blocks), dim3(256), 0, s, reinterpret_cast<const WgradDesc *>(d_descs),
-                       reinterpret_cast<const uint16_t *>(d_map));
-    return (int)hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256)
@@ -470,20 +436,6 @@ int rows_f32_wgrad(const float *a, const float *bm, float *out, float *part, int
     if (B <= 0 || G <= 0 || GB <= 0 || (size_t)B * G > 65535 || (db && G != 1)) return OSS_ERR_SHAPE;
     const int NB = N + (db ? 1 : 0);
     const int slabs = rows_f32_wgrad_slabs(P);
-    const int t11g = ((M + 31) / 32) * ((NB + 31) / 32);
-    if (defer_wgrad() && defer_finish() && (size_t)slabs * B * G * ((t11g + 3) / 4) < (1u << 24)) {
-        // recorded, not launched: oss_flush_wgrads runs every recorded product as one grouped launch; the partials do not exist until
-        // then, so the finishing sum is deferred with it
-        WgradDesc d{};
-        d.dy = a; d.x = bm; d.part = part;
-        d.gsb = asb; d.gsg = asg; d.gsm = asm_; d.xsb = bsb; d.xsg = bsg; d.xsn = bsn; d.gs_hi = 0;
-        d.M = M; d.N = N; d.P = P; d.G = G; d.Mh = GB; d.NB = NB; d.slabs = slabs; d.bgs = B * G;
-        d.first_block = 0; d.io = (int)OSS_F32; d.span = kF32WgradSlab; d.reserved_ = 0;
-        defer_wgrad_push(&d, sizeof(d), (unsigned)(slabs * B * G * ((t11g + 3) / 4)));
-        const size_t nwd = (size_t)G * M * N, pvd = nwd + (db ? M : 0);
-        defer_sum(part, slabs * B, pvd, pvd, out, nwd, db);
-        return 0;
-    }
     // 64 x 32 tiles; 32 x 32 when the wider tile would leave most SIMDs without a wave
     const int t21 = ((M + 63) / 64) * ((NB + 31) / 32), t11 = ((M + 31) / 32) * ((NB + 31) / 32);
     if ((long)t21 * slabs * B * G >= 1024 && M > 32) {

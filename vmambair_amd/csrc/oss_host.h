@@ -165,18 +165,6 @@ int gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int B
 // (out[j] = sum_{k<K} src[k * stride + j], j < n0 -> dst0[j], else dst1[j - n0]) and oss_flush_finishes runs them all
 // oss_set_defer_wgrad(1): conv1x1_wgrad() records its problem instead of launching; oss_flush_wgrads runs them all as ONE
 // grouped launch (oss_conv1x1.hip: oss_conv1x1_wgrad_grouped_kernel)
-// one recorded weight-gradient product of the grouped launch (16-bit form: oss_conv1x1.hip wgrad_body; fp32 form: oss_conv1x1_f32.hip
-// rows_f32_wgrad_body, which reads dy / x as its A / Bm operands, gsb / gsg / gsm and xsb / xsg / xsn as their strides and Mh as GB)
-struct WgradDesc {
-    const void *dy, *x;
-    float *part;
-    int64_t gsb, gsm, xsb, xsn, gsg, xsg, gs_hi;
-    int M, N, P, G, Mh, NB, slabs, bgs /* batch * G */;
-    unsigned first_block;
-    int io;
-    int span, reserved_;   // pixels per partial product
-};
-int rows_f32_wgrad_grouped_launch(const void *d_descs, const void *d_map, unsigned total_blocks, hipStream_t s);
 bool defer_wgrad();
 void defer_wgrad_push(const void *desc, size_t bytes, unsigned blocks);
 size_t wgrad_desc_bytes();
