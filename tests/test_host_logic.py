@@ -371,3 +371,19 @@ def test_flops_counter_follows_the_reference_rules(oracle_cpu_kernel):
     # patch_embed alone: 16 * 16 outputs x 8 channels x 3 x 9 MACs
     assert t["conv"] * 1e9 > 16 * 16 * 8 * 27 and t["proj"] > 0
     assert float(s.split("GFLOPs ")[1]) == pytest.approx(sum(t.values()), rel=1e-12)
+
+
+def test_conv_core_node_is_gpu_only_and_shape_gated():
+    """SS2D_1's conv + flattenings + core node (ops/core.py: ConvCoreFn) is never chosen for a CPU tensor -- the CPU path keeps the
+    separate ops that the oracle twins implement -- and its shape rule is the library's (oss_dwconv3x3_flat2_ok)"""
+    import torch
+    from vmambair_amd import ops
+    from vmambair_amd.oss_block import SS2D_1
+    m = SS2D_1(d_model=48, ssm_ratio=1, variant="srgan")
+    x = torch.randn(1, m.d_inner, 16, 16)
+    assert not ops.flat2_ok(x) and not ops.dwconv.fused_ok(x, 1)
+    assert not ops.conv_core_ok(x, m.conv2d, m.d_inner, m.dt_rank, m.d_state)
+    lib = ops._capi.load()
+    # 16-bit and float I/O, H % 8 == 0, W / 8 a power of two <= 32
+    assert lib.oss_dwconv3x3_flat2_ok(2, 64, 64) == 1 and lib.oss_dwconv3x3_flat2_ok(0, 128, 128) == 1
+    assert lib.oss_dwconv3x3_flat2_ok(2, 60, 64) == 0 and lib.oss_dwconv3x3_flat2_ok(1, 160, 160) == 0 and lib.oss_dwconv3x3_flat2_ok(2, 8, 512) == 0
