@@ -272,6 +272,9 @@ __device__ __forceinline__ void conv_rows(const float (&v)[3][10], const float *
 }
 
 // out[b, c] = gelu(conv(t[b, c])) * conv(t[b, c + Hd]);  grid (groups of 256 lanes, Hd, B)
+// (round 4, measured and removed: two vertically adjacent groups per lane -- 8 row loads per two outputs instead of 12, the headline
+// launch 4 waves per SIMD in one round instead of 7.9 at 6 resident: 13.3 us per launch either way, 236.8 / 235.9 against 236.7 / 236.8
+// images/s; tools/r4_call20.sh)
 template <typename T, bool EDGE = false>
 __global__ void __launch_bounds__(256)
 oss_dwgate_fwd_kernel(const T *__restrict__ t, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ out,
