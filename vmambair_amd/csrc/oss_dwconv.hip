@@ -451,6 +451,15 @@ oss_dwconv3x3_bwd_fused_kernel(const T *__restrict__ x, const float *__restrict_
                 process(256, r1, xkeep[1]);
             }
         }
+    } else if constexpr (!EDGE && sizeof(T) == 2 && MODE == kDwGate) {
+        // planes of more than 512 groups (the Deraining tree's 128 x 128 level): the group's seven loads in flight together, as in the
+        // KEEP form; x is loaded again in pass 2
+        for (int g0 = 0; g0 < ngroups; g0 += 256) {   // uniform trip count: every lane takes part in the DPP halo exchange
+            Raw r;
+            issue(g0, r);
+            __builtin_amdgcn_sched_barrier(0);
+            process(g0, r, xkeep[0]);
+        }
     } else {
         for (int g0 = 0; g0 < ngroups; g0 += 256) pass1(g0);   // uniform trip count: every lane takes part in the DPP halo exchange
     }
