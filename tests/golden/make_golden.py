@@ -577,6 +577,8 @@ if __name__ == "__main__":
         make_g8()
     if "g8small" in which:
         make_g8("small", (2, 1, 1, 1), 2)
+    if "g8full32" in which:   # the bench's depth on a 32 x 32 input: a quarter of the scan steps of `g8` (hours, not half a day, of the
+        make_g8("full32", (15, 1, 1, 1), 15, hw=32)   # reference's step-by-step selective_scan_ref under autograd)
     if "g1" in which:
         make_g1()
     if "g2" in which:
