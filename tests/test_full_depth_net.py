@@ -103,6 +103,7 @@ def test_hip_whole_net_matches_the_reference(tag):
     # trained net's -- |y| reaches 45 and every block adds its bf16 rounding to a residual stream that large -- so the limits
     # are wider than test_configs_gpu.py's for the default initialisation (measured there 5e-3 / 8e-3; here, [2,1,1,1]+2:
     # 3.1e-2 output, 1.2e-1 gradient, cosine 1.000).  The direction of the gradient is what the optimizer consumes: cosine.
-    # 50 blocks deep (full32, measured on the MI355X: output 9.3e-2, loss 10.4816 vs 10.3527 = 1.2e-2, gradient 1.2e-1, cosine 0.9994)
+    # 50 blocks deep (measured on the MI355X -- full32: output 9.3e-2, loss 10.4816 vs 10.3527 = 1.2e-2, gradient 1.2e-1, cosine 0.9994;
+    # full: 4.4e-2, 13.029 vs 12.983, 6.2e-2, 0.998)
     lim_y, lim_g, lim_c, lim_l = (6e-2, 2.5e-1, 0.97, 1e-2) if tag == "small" else (1.5e-1, 2.5e-1, 0.99, 3e-2)
     assert ey <= lim_y and abs(l_b - l_f) <= lim_l * abs(l_f) and eg <= lim_g and cos >= lim_c, (ey, l_b, l_f, eg, cos)
