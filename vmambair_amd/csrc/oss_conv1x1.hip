@@ -567,6 +567,10 @@ oss_conv1x1_pairw_kernel(const T *__restrict__ x, const float *__restrict__ w, c
     pair_epilogue<T>(acca, accb, bias, res ? res + (size_t)b * M * P + (pok ? p : 0) : nullptr, yb + p, m0, kg, M, P, pok);
 }
 
+// (round 4, measured and removed: the K walk software-pipelined for MT = 1 -- chunks of 4 k-steps, the next chunk's 32 activation loads
+// requested behind the current chunk's weight fragments and in flight during its 8 MFMAs: 24.4 us per launch against 19.3 for the
+// form below at project_in's input gradient (K = 510 / 254), 233.5 against 235.4 images/s; twice the weight-fragment round trips and a
+// drain of the prefetch at the loop head cost more than the overlap bought.  tools/r4_call33.sh)
 // K is walked in chunks of KS k-steps (KS * 16 channels) whose activation fragments live in registers; up to MT
 // output row tiles per workgroup are accumulated across the chunks, so any K and M are covered by one kernel
 // (grid.z splits M into groups of <= MT tiles).
