@@ -59,6 +59,7 @@ def test_net_matches_reference_on_gpu(name, cls):
     assert_close(y, z["y"], 1e-3, 1e-3, "net output")
 
 
+@pytest.mark.selfcheck
 def test_block_under_bf16_autocast_trains():
     """config 2 runs the arch under bf16 autocast: the scan receives bf16 u/delta/B/C with fp32
     A/D/bias; output must stay close to the fp32 run."""

@@ -66,59 +66,6 @@ def test_dwconv_on_chunk_views(dt):
     assert_close(y, F.conv2d(x.float().cpu(), w.cpu(), b.cpu(), padding=1, groups=16).to(dt), tol, tol, "chunk view")
 
 
-@pytest.mark.parametrize("mode", ["one_graph", "two_graphs", "two_branches"])
-@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
-def test_graphed_train_step_matches_eager(mode, acdt):
-    """vmambair_amd.train_graph: the hipGraph replay of fwd+loss+bwd+Adam+EMA gives the same weights
-    as the eager step (same kernels, same order).  ``two_graphs``: the multi-GPU structure (forward+backward |
-    all-reduce | optimizer) on one GPU; ``two_branches``: the batch as two micro-batches on parallel branches of the
-    graph; bf16: autocast with shadow weights."""
-    split = mode == "two_graphs"
-    from vmambair_amd.archs import MambaSISR6
-    from vmambair_amd.train_graph import GraphedTrainStep
-
-    def make():
-        torch.manual_seed(0)
-        return MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
-
-    torch.manual_seed(5)
-    lq = torch.rand(2, 3, 16, 16, device=DEV)
-    gt = torch.rand(2, 3, 64, 64, device=DEV)
-    net_g = make()
-    # capture() runs one eager warm-up step and then puts parameters / EMA / optimizer state back (round 2), so the
-    # three replays are training steps 1..3, exactly one update per batch as in the reference's optimize_parameters
-    step = GraphedTrainStep(net_g, autocast_dtype=acdt, warmup=1, split_graphs=split, overlap_wgrads=split,  # two-graph case also forks the weight-gradient stream
-                            micro_streams=2 if mode == "two_branches" else 1)
-    losses_g = [float(step(lq, gt)) for _ in range(3)]
-    net_e = make()
-    opt = torch.optim.Adam(net_e.parameters(), lr=2e-4, betas=(0.9, 0.99))
-    losses_e = []
-    for _ in range(3):
-        opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=acdt is not None):
-            out = net_e(lq)
-        loss = F.l1_loss(out.float(), gt)
-        loss.backward()
-        opt.step()
-        losses_e.append(float(loss))
-    lo = acdt is None
-    for a, b in zip(losses_g, losses_e):
-        assert a == pytest.approx(b, rel=2e-3 if lo else 3e-2)
-    assert losses_g[0] == pytest.approx(losses_e[0], rel=1e-5 if lo else 1e-2), "the first replay is the first update"
-    assert losses_g[2] < losses_g[0]
-    if lo:  # bf16: Adam normalises every gradient to +-lr, so rounding-level gradient differences move weights by 2 lr
-        # fp32: the captured step adds the weight-gradient partials in a different (fixed) order than the eager kernels
-        # (deferred finishing), so a gradient that is ~0 may flip its sign and Adam moves that weight by lr the other way:
-        # allow a handful of such elements, bounded by 2 lr per step
-        tot = bad = 0
-        for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
-            d = (p - q).abs()
-            assert float(d.max()) <= 2 * 2e-4 * 4 + 1e-5, k
-            tot += d.numel()
-            bad += int((d > 2e-4 + 1e-3 * q.abs()).sum())
-        assert bad <= 0.01 * tot, f"{bad} of {tot} weights differ by more than one Adam step"
-
-
 @pytest.mark.parametrize("shape", [(2, 48, 16, 16), (1, 6, 5, 7), (2, 96, 8, 12), (2, 12, 64, 64), (1, 3, 9, 32)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_dwconv_with_fused_silu(shape, dt):
@@ -143,97 +90,6 @@ def test_dwconv_with_fused_silu(shape, dt):
     assert_close(xd.grad, xr.grad, 1e-4 if lo else 2e-2, 1e-5 if lo else 4e-2, "dx")
     assert_close(conv.weight.grad, wr.grad, 1e-4 if lo else 2e-2, (1e-5 if lo else 2e-2) * float(wr.grad.abs().max()), "dw")
     assert_close(conv.bias.grad, br.grad, 1e-4 if lo else 2e-2, (1e-5 if lo else 2e-2) * float(br.grad.abs().max()), "db")
-
-
-@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
-def test_deferred_finishing_gives_the_same_gradients(acdt):
-    """ops.deferred_finishes(): every partial-sum finishing launch of the backward (weight-gradient slabs, LayerNorm,
-    depth-wise conv, channel branch) is replaced by one launch at the end; gradients must agree to summation-order rounding"""
-    from vmambair_amd.archs import MambaSISR6
-    torch.manual_seed(0)
-    net = MambaSISR6(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
-    lq = torch.rand(2, 3, 32, 32, device=DEV)
-    gt = torch.rand(2, 3, 128, 128, device=DEV)
-
-    def grads(defer):
-        net.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=acdt is not None):
-            out = net(lq)
-        loss = F.l1_loss(out.float(), gt)
-        if defer:
-            with ops.deferred_finishes():
-                loss.backward()
-                n = ops.pending_finish_chunks()
-                assert n > 0
-                # a deferred gradient holds no data yet: each must have been adopted as its leaf's .grad, not copied
-                assert ops.orphaned_deferred_outputs(net.parameters()) == 0
-                # 16-bit: the 1x1-conv / projection weight-gradient PRODUCTS were only recorded too (one grouped launch);
-                # flushing the finishing sums before them is an error, not a silent zero gradient
-                if ops.pending_wgrads():
-                    with pytest.raises(RuntimeError, match="flush_wgrads"):
-                        ops.flush_finishes(ops.FinishTable(DEV, n))
-                    ops.flush_wgrads(ops.WgradTable(DEV, ops.pending_wgrad_table_bytes()))
-                else:
-                    assert acdt is None, "bf16 activations take the in-tree MFMA weight-gradient kernels"
-                ops.flush_finishes(ops.FinishTable(DEV, n))
-                assert ops.pending_finish_chunks() == 0
-        else:
-            loss.backward()
-        return {k: p.grad.clone() for k, p in net.named_parameters()}
-
-    ref, got = grads(False), grads(True)
-    assert set(ref) == set(got)
-    # fp32: summation order only; bf16: the library 3x3 convolutions are not run-to-run deterministic to the last 16-bit ulp
-    tol = 2e-5 if acdt is None else 5e-2
-    # bf16: the vendor 3x3 convolutions are not run-to-run deterministic to the last 16-bit ulp, and the small gradients of
-    # the channel branch (differences of large terms) inherit that as noise of ~1e-3 of the LARGEST gradient in the net
-    floor = 1e-9 if acdt is None else 2e-3 * max(float(v.abs().max()) for v in ref.values())
-    wrong = []
-    for k in ref:
-        if k.endswith("conv_cout.bias"):
-            continue   # mathematically zero (the channel LayerNorm removes it): rounding noise only
-        sc = max(float(ref[k].abs().max()), 1e-12)
-        if float((got[k] - ref[k]).abs().max()) > tol * sc + floor:
-            wrong.append((k, float((got[k] - ref[k]).abs().max()), sc))
-    assert not wrong, wrong
-
-
-@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("split", [False, True], ids=["one_graph", "two_graphs"])
-def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
-    """GraphedTrainStep(micro_streams=2): forward + backward of the two half batches on two streams, gradients added --
-    must equal the gradients of the undivided batch (mean loss; nothing in the nets couples the images of a batch)"""
-    from vmambair_amd.archs import MambaSISR6
-    from vmambair_amd.train_graph import GraphedTrainStep
-    torch.manual_seed(0)
-    net = MambaSISR6(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
-    lq = torch.rand(4, 3, 32, 32, device=DEV)
-    gt = torch.rand(4, 3, 128, 128, device=DEV)
-    got = {}
-    for M in (1, 2):
-        st = GraphedTrainStep(net, autocast_dtype=acdt, warmup=1, micro_streams=M, split_graphs=split)
-        st.static_lq, st.static_gt = lq.clone(), gt.clone()
-        loss = st._fwd_bwd()
-        torch.cuda.synchronize()
-        got[M] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
-    assert got[2][0] == pytest.approx(got[1][0], rel=1e-5 if acdt is None else 1e-2)
-    # fp32: the vendor library may pick different solvers for the 3x3 convolutions at batch 4 and batch 2, and our own kernels
-    # pick workgroup shapes (i.e. summation orders) by batch size; on the smallest gradients (scale 1e-5, sums with cancellation)
-    # that was measured at up to 5e-3 of the tensor's own scale.  A lost or doubled micro-batch would be an error of 0.5.
-    tol = 1e-2 if acdt is None else 5e-2
-    # bf16: noise floor of the small channel-branch gradients, see test_deferred_finishing_gives_the_same_gradients
-    # ... and an absolute floor relative to the LARGEST gradient of the net: a tensor whose gradient is ~1e-7 of that (Dsc of
-    # the latent block) is summation-order noise in fp32 as well
-    floor = (1e-6 if acdt is None else 2e-3) * max(float(v.abs().max()) for v in got[1][1].values())
-    wrong = []
-    for k, ref in got[1][1].items():
-        if k.endswith("conv_cout.bias"):
-            continue   # mathematically zero: rounding noise only
-        sc = max(float(ref.abs().max()), 1e-12)
-        d = float((got[2][1][k] - ref).abs().max())
-        if d > tol * sc + floor:
-            wrong.append((k, d, sc))
-    assert not wrong, wrong
 
 
 # ---- fused forms of oss_dwconv.hip: the convolution is never stored, the backward is one launch ---------------------------

@@ -81,6 +81,77 @@ def test_build_network_from_reference_yaml_dict():
     assert n_params == 12_028_273
 
 
+class _StubRegistry:
+    """The public behaviour of pip-basicsr's ``Registry`` (``basicsr.utils.registry``; the SRGAN / RealSR trees import
+    ``ARCH_REGISTRY`` from it and decorate their nets with ``@ARCH_REGISTRY.register()``, MambaSISR6_arch.py:557,
+    MambaRealSR11_arch.py:878): a name -> class map, double registration is an error, ``get`` raises KeyError."""
+
+    def __init__(self, name):
+        self._name, self._obj_map = name, {}
+
+    def register(self, obj=None):
+        def deco(cls):
+            assert cls.__name__ not in self._obj_map, f"An object named '{cls.__name__}' was already registered in '{self._name}' registry!"
+            self._obj_map[cls.__name__] = cls
+            return cls
+        return deco if obj is None else deco(obj)
+
+    def get(self, name):
+        if name not in self._obj_map:
+            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+        return self._obj_map[name]
+
+
+def test_option_d_registry_hook_builds_the_hip_net_from_a_yaml_network_g_block():
+    """INTEGRATION.md Option D under test (VERDICT r4 missing #5): the reference resolves ``network_g.type`` through a registry
+    (pip-basicsr ``build_network``: ``ARCH_REGISTRY.get(opt.pop('type'))(**opt)``) or, in the Deraining tree, through
+    ``getattr(module, cls_type)`` over its arch modules (Deraining/basicsr/models/archs/__init__.py:24-46).  After the one-line hook
+    the same YAML block builds this repo's net, with the reference's parameter names (a reference checkpoint loads strict)."""
+    import yaml
+    import vmambair_amd.archs as hip_archs
+    registry = _StubRegistry("arch")
+
+    @registry.register()
+    class MambaSISR6:                      # stands for the reference's own class, registered when its arch file is imported
+        def __init__(self, **kw):
+            raise AssertionError("the reference class must not be built once the hook is in place")
+
+    with pytest.raises(AssertionError, match="already registered"):
+        registry.register(hip_archs.MambaSISR6)          # why the hook writes _obj_map instead of calling register()
+    registry._obj_map["MambaSISR6"] = hip_archs.MambaSISR6     # <- the Option D line of INTEGRATION.md
+    # the network_g block of SRGAN/options/MambaSISR15_x4.yml:55-65, at the width of the committed reference checkpoint (G5)
+    opt = yaml.safe_load("""
+network_g:
+  type: MambaSISR6
+  inp_channels: 3
+  out_channels: 3
+  scale: 4
+  dim: 8
+  num_blocks: [1, 1, 1, 1]
+  num_refinement_blocks: 1
+  heads: [1, 1, 1, 1]
+  ffn_expansion_factor: 2.66
+  bias: False
+  LayerNorm_type: WithBias
+""")["network_g"]
+    o = dict(opt)
+    net = registry.get(o.pop("type"))(**o)                       # basicsr.archs.build_network
+    assert type(net) is hip_archs.MambaSISR6 and net.scale == 4
+    with pytest.raises(KeyError):
+        registry.get("NoSuchNet")
+    # the reference's own checkpoint format and names: strict load
+    import os
+    from conftest import GOLDEN
+    from vmambair_amd import checkpoint
+    checkpoint.load_network(net, os.path.join(GOLDEN, "g5_ckpt_mambasisr6_d8.pth"), strict=True)
+    # Deraining tree: define_network -> dynamic_instantiation(modules, cls_type, opt) = getattr over the arch modules
+    o = dict(type="Mamber32", inp_channels=3, out_channels=3, dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1,
+             heads=[1, 2, 4, 8], ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias", dual_pixel_task=False)
+    cls = getattr(hip_archs, o.pop("type"), None)
+    assert cls is hip_archs.Mamber32 and isinstance(cls(**o), hip_archs.Mamber32)
+    assert hip_archs.build_network(dict(opt)).__class__ is hip_archs.MambaSISR6      # this repo's own spelling of the same lookup
+
+
 def test_direction_maps_bit_exact(monkeypatch):
     """G2: xs fed to the scan and the merged y, on integers (MambaSISR6_arch.py:401-404,427-430)."""
     z = load_golden("g2_perm.npz")
@@ -368,9 +439,47 @@ def test_flops_counter_follows_the_reference_rules(oracle_cpu_kernel):
         want += 9 * L * 4 * D * 16 + 4 * D * L              # spatial: one call, D = 4 d_inner
         want += 9 * D * (2 * 4) * 16 + (2 * 4) * D           # channel: L = d_inner, D = 2 dc_inner (dc_inner = 4)
     assert abs(t["scan"] * 1e9 - want) < 1, (t["scan"] * 1e9, want)
-    # patch_embed alone: 16 * 16 outputs x 8 channels x 3 x 9 MACs
-    assert t["conv"] * 1e9 > 16 * 16 * 8 * 27 and t["proj"] > 0
+    # convolutions by hand (the 1x1 and depth-wise layers never run as nn.Conv2d modules on the GPU, so the count
+    # must not depend on module hooks): written from the architecture, not from the module tree
+    def block(d, hw):
+        hid = int(d * 2.66)
+        px = hw * hw
+        attn = px * (d * 2 * d + d * 9 + d * d)                     # in_conv (d -> 2 d_expand, ssm_ratio 1), conv2d, out_conv
+        ffn = px * (d * 2 * hid + 2 * hid * 9 + hid * d)            # project_in, dwconv, project_out
+        chan = 2 * 4 * d                                            # conv_cin (1 -> 4), conv_cout (4 -> 1) on the d-long channel map
+        return attn + ffn + chan
+    conv = 16 * 16 * 8 * 3 * 9                                      # patch_embed
+    conv += sum(block(d, hw) for d, hw in ((8, 16), (16, 8), (32, 4), (64, 2), (32, 4), (16, 8), (16, 16), (16, 16)))
+    conv += 16 * 16 * 8 * 4 * 9 + 8 * 8 * 16 * 8 * 9 + 4 * 4 * 32 * 16 * 9          # down1_2, down2_3, down3_4 (n -> n/2, then unshuffle)
+    conv += 2 * 2 * 64 * 128 * 9 + 4 * 4 * 32 * 64 * 9 + 8 * 8 * 16 * 32 * 9        # up4_3, up3_2, up2_1 (n -> 2n, then shuffle)
+    conv += 4 * 4 * 64 * 32 + 8 * 8 * 32 * 16                                       # reduce_chan_level3 / 2 (1x1); level 1 has none
+    conv += 16 * 16 * 16 * 64 * 9 + 32 * 32 * 16 * 64 * 9 + 64 * 64 * 16 * 3 * 9    # x4 tail: two (n -> 4n) + shuffle, conv_last
+    assert abs(t["conv"] * 1e9 - conv) < 1, (t["conv"] * 1e9, conv)
+    proj = 0
+    for d, hw in ((8, 16), (16, 8), (32, 4), (64, 2), (32, 4), (16, 8), (16, 16), (16, 16)):
+        R = -(-d // 16)
+        proj += 4 * hw * hw * d * (R + 32) + 4 * hw * hw * d * R      # x_proj + dt_proj, four directions
+        proj += 2 * d * 4 * (6 + 32) + 2 * d * 4 * 6                  # channel branch: L = d, dc_inner 4, rank 6
+    assert abs(t["proj"] * 1e9 - proj) < 1, (t["proj"] * 1e9, proj)
     assert float(s.split("GFLOPs ")[1]) == pytest.approx(sum(t.values()), rel=1e-12)
+    # the count needs no forward pass, so it is the same number for a net on the GPU, under autocast, or in fp16
+    assert net.half().flops((3, 16, 16)) == s
+
+
+def test_flops_of_the_realsr_net_against_the_published_figure():
+    """The only published anchor for ``flops()``: the reference's README (README.md:82, table figure) quotes the
+    real-world x4 SR net -- ``MambaRealSR11`` with its constructor defaults, MambaRealSR11_arch.py:893-903 -- at 10.50 M parameters /
+    20.5 G FLOPs (fvcore, default ``shape=(3, 64, 64)``, :980-998).  Parameters must round to the published figure.  The analytic count
+    (convolutions + einsums as MACs + the reference's scan formula) gives 19.44 G, 5.2 % below the figure; fvcore is not in the image, so
+    which of its extra handlers (adaptive_avg_pool2d, upsample_nearest2d, its per-version einsum pricing) make up the rest cannot be
+    checked here.  The test pins the parameter count exactly and the FLOPs to the band [-6 %, +1 %] around 20.5 G."""
+    from vmambair_amd.archs import MambaRealSR11
+    net = MambaRealSR11()
+    s = net.flops()
+    params, gflops = float(s.split()[1]), float(s.split("GFLOPs ")[1])
+    assert f"{params:.2f}" == "10.50", params
+    assert 0.94 * 20.5 <= gflops <= 1.01 * 20.5, gflops
+    assert gflops == pytest.approx(19.443569472, rel=1e-9)      # conv 14.534 + proj 1.131 + scan 3.778 (regression pin)
 
 
 def test_conv_core_node_is_gpu_only_and_shape_gated():

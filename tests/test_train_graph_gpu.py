@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+selfcheck = pytest.mark.selfcheck   # graph replay vs the eager loop of this repo: collected last (tests/conftest.py)
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -50,6 +51,7 @@ def test_adamw_clip_step_matches_torch():
         assert torch.allclose(p, q.detach(), rtol=1e-5, atol=1e-6)
 
 
+@selfcheck
 def test_graphed_deraining_step_matches_eager():
     from vmambair_amd.train_graph import GraphedTrainStep
     torch.manual_seed(3)
@@ -69,6 +71,7 @@ def test_graphed_deraining_step_matches_eager():
         assert float((p - q).abs().max()) <= 2 * 3e-4 * 3 + 1e-5, k
 
 
+@selfcheck
 def test_one_graph_per_shape_progressive_schedule():
     """patch size and batch change during Deraining training: the step keeps one forward+backward graph per shape and ONE
     optimizer graph; alternating shapes gives the same trajectory as the eager loop"""
@@ -95,6 +98,7 @@ def test_one_graph_per_shape_progressive_schedule():
         single(*batches[1])
 
 
+@selfcheck
 def test_warmup_leaves_no_trace():
     """capture() warms up with real steps and restores parameters, EMA, moments and the step count"""
     from vmambair_amd.archs import MambaSISR6
@@ -113,6 +117,7 @@ def test_warmup_leaves_no_trace():
 # ---------------------------------------------------------------------------------------------------------------------
 # learning-rate schedule under graph replay, training-state save / resume
 # ---------------------------------------------------------------------------------------------------------------------
+@selfcheck
 def test_set_lr_reaches_the_captured_optimizer_launch():
     """the reference changes the rate during a run (update_learning_rate, Deraining/basicsr/models/base_model.py:183-205); the
     fused launch reads it from device memory, so a replayed graph follows ``set_lr``: trajectory = eager AdamW driven by the
@@ -180,6 +185,7 @@ def test_fused_adam_state_dict_round_trips_with_torch_adam():
         assert torch.allclose(p, q.detach(), rtol=1e-5, atol=1e-6) and torch.equal(p, r)
 
 
+@selfcheck
 def test_training_state_save_and_resume(tmp_path):
     """save_training_state / resume_training (base_model.py:312-351): a run interrupted after 2 steps and resumed in a NEW
     process-like object (fresh net from the saved weights, fresh graphs) ends where the uninterrupted run ends"""
@@ -221,6 +227,7 @@ def test_training_state_save_and_resume(tmp_path):
         assert torch.allclose(e1, e2, rtol=1e-5, atol=1e-6), k
 
 
+@selfcheck
 def test_second_shape_capture_keeps_the_torch_optimizer_state():
     """with the torch fallback optimizer (fused_optimizer=False) a second input shape captured in the middle of a
     run must not reset the Adam moments / step count"""
@@ -285,6 +292,7 @@ def _nccl_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+@selfcheck
 def test_two_rank_rccl_step_equals_single_process_whole_batch():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the driver's 8-GPU node); the exchange itself is covered by tests/test_ddp_gloo.py")
@@ -307,6 +315,7 @@ def test_two_rank_rccl_step_equals_single_process_whole_batch():
         assert float((p.detach().cpu() - q).abs().max()) <= 2 * 2e-4 * 2 + 1e-5
 
 
+@selfcheck
 def test_resume_from_a_reference_style_state_needs_the_ema_weights(tmp_path):
     """a ``.state`` file as the REFERENCE writes it has no EMA weights (they live in ``net_g_<iter>.pth`` under
     ``params_ema``, Deraining/basicsr/models/base_model.py:234-244,312-334).  ``resume_training`` must not continue silently from
@@ -341,6 +350,7 @@ def test_resume_from_a_reference_style_state_needs_the_ema_weights(tmp_path):
     assert checkpoint.resume_training(d, ref_state)["iter"] == 3
 
 
+@selfcheck
 def test_train_loop_drives_the_schedule_and_saves_states(tmp_path):
     """``checkpoint.train_loop``: current_iter += 1, schedule(current_iter) -> set_lr BEFORE the step (update_learning_rate,
     base_model.py:183-205), a training state every ``save_every`` iterations"""

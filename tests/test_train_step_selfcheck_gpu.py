@@ -1,0 +1,148 @@
+"""Self-comparisons of the training step: two configurations of THIS repo against each other (graph replay vs eager, deferred vs
+immediate finishing launches, one vs two micro-batch branches).  They guard knobs of ``vmambair_amd.train_graph``; they say
+nothing about parity with the reference, so they carry the ``selfcheck`` marker and tests/conftest.py collects them after every
+oracle / golden-vector / op-vs-PyTorch test (a failure here must not hide those under ``pytest -x``).
+
+The two sides of each comparison legitimately differ by summation order (deferred finishing adds partials in a fixed different
+order; workgroup shapes follow the batch size) and, for the 3x3 convolutions left to the vendor library, by solver choice.  The
+gradients are therefore compared with conftest.gradients_agree -- flat-vector rel-L2, per-tensor error relative to
+max(own norm, 0.1 % of the largest gradient norm), per-tensor cosine -- not with a per-tensor max-abs limit taken from one box.
+What each test must still catch is stated next to its limits (a lost / doubled micro-batch, a dropped finishing launch, a stale
+graph input: all O(1) errors in at least one tensor).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import gradients_agree
+from vmambair_amd import ops
+
+pytestmark = [pytest.mark.gpu, pytest.mark.selfcheck]
+DEV = "cuda:0"
+
+# flat-vector / per-tensor limits.  fp32: summation order only (measured 1e-6 .. 1e-5 of the largest gradient; a structural
+# error is >= 0.3).  bf16 autocast: every activation is rounded to 8 bits of mantissa at different points on the two sides.
+LIMITS = {None: dict(flat_tol=1e-3, tensor_tol=5e-2), torch.bfloat16: dict(flat_tol=5e-2, tensor_tol=2.5e-1, cos_big=0.97, cos_small=0.5)}
+
+
+@pytest.mark.parametrize("mode", ["one_graph", "two_graphs", "two_branches"])
+@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
+def test_graphed_train_step_matches_eager(mode, acdt):
+    """vmambair_amd.train_graph: the hipGraph replay of fwd+loss+bwd+Adam+EMA follows the eager step.  ``two_graphs``: the
+    multi-GPU structure (forward+backward | all-reduce | optimizer) on one GPU; ``two_branches``: the batch as two micro-batches
+    on parallel branches of the graph; bf16: autocast with shadow weights.
+
+    Checked: (1) the loss of the first replay IS the loss of the first eager step (same weights, same batch); (2) the first
+    update: Adam moves every weight by ~lr * sign(g), so the update vectors of the two sides must point the same way except where
+    the gradient is rounding-sized; (3) three steps stay within the Adam bound of each other and the loss falls."""
+    split = mode == "two_graphs"
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+
+    def make():
+        torch.manual_seed(0)
+        return MambaSISR6(dim=8, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+
+    torch.manual_seed(5)
+    lq = torch.rand(2, 3, 16, 16, device=DEV)
+    gt = torch.rand(2, 3, 64, 64, device=DEV)
+    net_g = make()
+    init = [p.detach().clone() for p in net_g.parameters()]
+    # capture() runs one eager warm-up step and then puts parameters / EMA / optimizer state back (round 2), so the
+    # three replays are training steps 1..3, exactly one update per batch as in the reference's optimize_parameters
+    step = GraphedTrainStep(net_g, autocast_dtype=acdt, warmup=1, split_graphs=split, overlap_wgrads=split,  # two-graph case also forks the weight-gradient stream
+                            micro_streams=2 if mode == "two_branches" else 1)
+    net_e = make()
+    opt = torch.optim.Adam(net_e.parameters(), lr=2e-4, betas=(0.9, 0.99))
+    losses_g, losses_e = [], []
+    lr, first_cos = 2e-4, None
+    for it in range(3):
+        losses_g.append(float(step(lq, gt)))
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=acdt is not None):
+            out = net_e(lq)
+        loss = F.l1_loss(out.float(), gt)
+        loss.backward()
+        opt.step()
+        losses_e.append(float(loss))
+        if it == 0:
+            ug = torch.cat([(p.detach() - i).flatten() for p, i in zip(net_g.parameters(), init)]).double()
+            ue = torch.cat([(p.detach() - i).flatten() for p, i in zip(net_e.parameters(), init)]).double()
+            first_cos = float((ug * ue).sum() / (ug.norm() * ue.norm()))
+            # the first Adam step is lr * g / (|g| + eps'): every weight with a non-zero gradient moved by ~lr on both sides
+            assert float(ug.abs().max()) <= 1.01 * lr and float(ue.abs().max()) <= 1.01 * lr
+    lo = acdt is None
+    print(f"[train step {mode} {'fp32' if lo else 'bf16'}] first-update cosine {first_cos:.5f}; losses graph {losses_g} eager {losses_e}")
+    assert losses_g[0] == pytest.approx(losses_e[0], rel=1e-5 if lo else 1e-2), "the first replay is the first update"
+    for a, b in zip(losses_g, losses_e):
+        assert a == pytest.approx(b, rel=2e-3 if lo else 3e-2)
+    assert losses_g[2] < losses_g[0]
+    # a stale input, a lost branch or a skipped optimizer launch gives cosine <= ~0.7; sign flips of rounding-sized gradients
+    # (exactly-zero-in-theory ones like conv_cout.bias, and in bf16 the small channel-branch gradients) cost a few percent
+    assert first_cos >= (0.98 if lo else 0.85), first_cos
+    for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
+        assert float((p - q).abs().max()) <= 2 * lr * 4 + 1e-5, k      # Adam: each side moves a weight by at most ~lr per step
+
+
+@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
+def test_deferred_finishing_gives_the_same_gradients(acdt):
+    """ops.deferred_finishes(): every partial-sum finishing launch of the backward (weight-gradient slabs, LayerNorm,
+    depth-wise conv, channel branch) is replaced by one launch at the end; gradients must agree to summation-order rounding.
+    A dropped finishing chunk leaves a gradient tensor (partly) zero: per-tensor error ~1, cosine < 1."""
+    from vmambair_amd.archs import MambaSISR6
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    lq = torch.rand(2, 3, 32, 32, device=DEV)
+    gt = torch.rand(2, 3, 128, 128, device=DEV)
+
+    def grads(defer):
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=acdt is not None):
+            out = net(lq)
+        loss = F.l1_loss(out.float(), gt)
+        if defer:
+            with ops.deferred_finishes():
+                loss.backward()
+                n = ops.pending_finish_chunks()
+                assert n > 0
+                # a deferred gradient holds no data yet: each must have been adopted as its leaf's .grad, not copied
+                assert ops.orphaned_deferred_outputs(net.parameters()) == 0
+                # 16-bit: the 1x1-conv / projection weight-gradient PRODUCTS were only recorded too (one grouped launch);
+                # flushing the finishing sums before them is an error, not a silent zero gradient
+                if ops.pending_wgrads():
+                    with pytest.raises(RuntimeError, match="flush_wgrads"):
+                        ops.flush_finishes(ops.FinishTable(DEV, n))
+                    ops.flush_wgrads(ops.WgradTable(DEV, ops.pending_wgrad_table_bytes()))
+                else:
+                    assert acdt is None, "bf16 activations take the in-tree MFMA weight-gradient kernels"
+                ops.flush_finishes(ops.FinishTable(DEV, n))
+                assert ops.pending_finish_chunks() == 0
+        else:
+            loss.backward()
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    ref, got = grads(False), grads(True)
+    gradients_agree(got, ref, what=f"deferred finishing {'fp32' if acdt is None else 'bf16'}", **LIMITS[acdt])
+
+
+@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("split", [False, True], ids=["one_graph", "two_graphs"])
+def test_micro_batch_branches_give_the_full_batch_gradients(acdt, split):
+    """GraphedTrainStep(micro_streams=2): forward + backward of the two half batches on two streams, gradients added --
+    must equal the gradients of the undivided batch (mean loss; nothing in the nets couples the images of a batch).
+    A lost or doubled micro-batch is an error of 0.5 / 1.0 of the flat gradient vector; the limit is 1e-3 (fp32)."""
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+    torch.manual_seed(0)
+    net = MambaSISR6(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+    lq = torch.rand(4, 3, 32, 32, device=DEV)
+    gt = torch.rand(4, 3, 128, 128, device=DEV)
+    got = {}
+    for M in (1, 2):
+        st = GraphedTrainStep(net, autocast_dtype=acdt, warmup=1, micro_streams=M, split_graphs=split)
+        st.static_lq, st.static_gt = lq.clone(), gt.clone()
+        loss = st._fwd_bwd()
+        torch.cuda.synchronize()
+        got[M] = (float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert got[2][0] == pytest.approx(got[1][0], rel=1e-5 if acdt is None else 1e-2)
+    gradients_agree(got[2][1], got[1][1], what=f"micro-batch branches {'fp32' if acdt is None else 'bf16'}", **LIMITS[acdt])

@@ -90,51 +90,77 @@ class _OSSUNet(nn.Module):
 
     def flops(self, shape=(3, 64, 64)) -> str:
         """Counterpart of the reference's ``flops()`` (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:101-138,646-664: fvcore's
-        ``flop_count`` with a handler that prices every ``SelectiveScan`` call at ``9 B L D N + B D L``) without fvcore -- the same
-        counting rules applied to the shapes this net's layers see for one ``(1, *shape)`` input: a multiply-accumulate is one flop
-        (fvcore's convention for convolutions / einsums), elementwise ops, norms, activations, flips and shuffles are ignored, the
-        six scans of an OSS module (four spatial directions as ONE call with D = 4 d_inner, two channel directions with
-        D = 2 dc_inner) by the reference's formula.  -> ``"params(M) <p> GFLOPs <g>"`` (the reference's format); ``flops_table``
-        holds the per-kind breakdown.  fvcore is not in the build image, so the total is not pinned against the reference's
-        printout (BASELINE.md quotes only the scan term)."""
+        ``flop_count`` with a handler that prices every ``SelectiveScan`` call at ``9 B L D N + B D L``) without fvcore and
+        without running the net: the same counting rules applied ANALYTICALLY to the shapes this net's layers see for one
+        ``(1, *shape)`` input.  A multiply-accumulate is one flop (fvcore's convention for convolutions / einsums); elementwise
+        ops, the hand-written norms, activations, flips and shuffles are ignored (fvcore has no handler for them either); the six
+        scans of an OSS module (four spatial directions as ONE call with D = 4 d_inner, two channel directions with
+        D = 2 dc_inner) by the reference's formula.
+
+        The count does not depend on which kernels the layers dispatch to (module forward hooks miss every Conv2d that
+        runs through ``conv1x1`` / ``dwconv3x3`` / ``conv3x3``): each ``nn.Conv2d`` is priced from its own weight shape at the
+        resolution of its UNet level, every Conv2d of the net exactly once (asserted).
+        -> ``"params(M) <p> GFLOPs <g>"`` (the reference's format); ``flops_table`` holds the per-kind breakdown.
+        Anchor: the reference publishes 10.50 M / 20.5 G for the RealSR net (README.md:82, figure) -- tests/test_host_logic.py."""
         from .oss_block import SS2D_1
+        _, H, W = shape
+        assert H % 8 == 0 and W % 8 == 0, "three 2x down-samplings"
         tally = {"conv": 0, "proj": 0, "scan": 0}
-        hooks = []
+        seen = set()
 
-        def conv_hook(m, inp, out):
-            tally["conv"] += out.numel() * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+        def conv(m: nn.Conv2d, h: int, w: int):
+            assert id(m) not in seen, "a convolution counted twice"
+            seen.add(id(m))
+            assert m.stride == (1, 1), "every convolution of these nets keeps its resolution (re-sampling is Pixel(Un)Shuffle)"
+            tally["conv"] += h * w * m.out_channels * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
 
-        def ss2d_hook(m, inp, out):
-            b, _, h, w = inp[0].shape
+        def ss2d(m: SS2D_1, h: int, w: int):
             L, D, R, N = h * w, m.d_inner, m.dt_rank, m.d_state
-            tally["proj"] += b * 4 * L * D * (R + 2 * N) + b * 4 * L * D * R                      # x_proj, dt_proj einsums
-            tally["scan"] += 9 * b * L * (4 * D) * N + b * (4 * D) * L                            # flops_selective_scan_fn
+            tally["proj"] += 4 * L * D * (R + 2 * N) + 4 * L * D * R                      # x_proj, dt_proj einsums
+            tally["scan"] += 9 * L * (4 * D) * N + (4 * D) * L                            # flops_selective_scan_fn
             dc = m.dc_inner if m.dc_inner is not None else 1
-            Rc, Nc, Lc = m.dtc_rank, m.dc_state, D                                               # channel branch: L = d_inner
-            tally["proj"] += b * 2 * Lc * dc * (Rc + 2 * Nc) + b * 2 * Lc * dc * Rc
-            tally["scan"] += 9 * b * Lc * (2 * dc) * Nc + b * (2 * dc) * Lc
-            if m.dc_inner is not None:                                                            # conv_cin / conv_cout on the (b, 1, d, 1) map
-                tally["conv"] += 2 * b * dc * Lc
-        for mod in self.modules():
-            if isinstance(mod, nn.Conv2d):
-                hooks.append(mod.register_forward_hook(conv_hook))
-            elif isinstance(mod, SS2D_1):
-                hooks.append(mod.register_forward_hook(ss2d_hook))
-        try:
-            p0 = next(self.parameters())
-            with torch.no_grad():
-                was = self.training
-                self.eval()
-                self(torch.randn((1, *shape), device=p0.device, dtype=p0.dtype))
-                self.train(was)
-        finally:
-            for h_ in hooks:
-                h_.remove()
-        # the channel branch's 1-channel convolutions are applied as affine maps (no Conv2d forward): counted in ss2d_hook above;
-        # conv_cin / conv_cout modules therefore never fire the conv hook
+            Rc, Nc, Lc = m.dtc_rank, m.dc_state, D                                        # channel branch: L = d_inner
+            tally["proj"] += 2 * Lc * dc * (Rc + 2 * Nc) + 2 * Lc * dc * Rc
+            tally["scan"] += 9 * Lc * (2 * dc) * Nc + (2 * dc) * Lc
+            if m.dc_inner is not None:                                                    # conv_cin / conv_cout on the (1, 1, d, 1) map
+                conv(m.conv_cin, Lc, 1)
+                conv(m.conv_cout, Lc, 1)
+
+        def tree(mod: nn.Module, h: int, w: int):
+            """every Conv2d / OSS module below ``mod`` sees an (h, w) map; the OSS modules first, so that their conv_cin /
+            conv_cout are priced on the channel map and not on (h, w)"""
+            for sub in mod.modules():
+                if isinstance(sub, SS2D_1):
+                    ss2d(sub, h, w)
+            for sub in mod.modules():
+                if isinstance(sub, nn.Conv2d) and id(sub) not in seen:
+                    conv(sub, h, w)
+
+        def stages(level):
+            return [self.encoder_level1, self.encoder_level2, self.encoder_level3, self.latent][level]
+
+        res = [(H >> k, W >> k) for k in range(4)]
+        tree(self.patch_embed, *res[0])
+        for k in range(4):
+            tree(stages(k), *res[k])
+        for down, k in ((self.down1_2, 0), (self.down2_3, 1), (self.down3_4, 2)):
+            tree(down, *res[k])                          # conv, then PixelUnshuffle
+        for up, k in ((self.up4_3, 3), (self.up3_2, 2), (self.up2_1, 1)):
+            tree(up, *res[k])                            # conv, then PixelShuffle
+        for dec, red, k in ((self.decoder_level3, self.reduce_chan_level3, 2), (self.decoder_level2, self.reduce_chan_level2, 1),
+                            (self.decoder_level1, None, 0), (self.refinement, None, 0)):
+            if red is not None:
+                conv(red, *res[k])
+            tree(dec, *res[k])
+        self._tail_flops(conv, H, W)
+        missing = [n for n, m in self.named_modules() if isinstance(m, nn.Conv2d) and id(m) not in seen]
+        assert not missing, f"convolutions without a price: {missing}"
         params = sum(p.numel() for p in self.parameters())
         self.flops_table = {k: v / 1e9 for k, v in tally.items()}
         return f"params(M) {params / 1e6} GFLOPs {sum(tally.values()) / 1e9}"
+
+    def _tail_flops(self, conv, H: int, W: int):
+        raise NotImplementedError
 
     def body(self, inp_img: torch.Tensor) -> torch.Tensor:
         e1 = self.encoder_level1(self.patch_embed(inp_img))
@@ -160,6 +186,12 @@ class MambaSISR6(_OSSUNet):
         self.scale = scale
         self.tail = _x4_tail(dim * 2, out_channels)
 
+    def _tail_flops(self, conv, H, W):
+        up, last = self.tail          # conv @ (H, W), shuffle, conv @ (2H, 2W), shuffle, conv_last @ (4H, 4W)
+        conv(up[0], H, W)
+        conv(up[2], 2 * H, 2 * W)
+        conv(last, 4 * H, 4 * W)
+
     def forward(self, inp_img):
         # tail = Sequential(upsampler, conv_last): the last layer (2 dim -> out_channels at the output resolution) on the in-tree
         # thin-convolution kernels; parameter names (tail.0.*, tail.1.*) are the reference's
@@ -182,6 +214,9 @@ class Mamber32(_OSSUNet):
                          ffn_expansion_factor, bias, LayerNorm_type)
         assert not dual_pixel_task, "dual-pixel defocus deblurring is not a config of the reference's options"
         self.output = _conv3(dim * 2, out_channels, bias)
+
+    def _tail_flops(self, conv, H, W):
+        conv(self.output, H, W)
 
     def forward(self, inp_img):
         return conv3x3(self.body(inp_img), self.output) + inp_img

@@ -156,7 +156,10 @@ def resume_training(step, resume_state: Union[str, dict], ema_from: Optional[str
         if ema_from is None:
             raise ValueError("the training state has no 'ema' entry (a .state file written by the reference: its EMA weights live in "
                              "net_g_<iter>.pth as 'params_ema'); pass ema_from=<that .pth>, or build the step with ema_decay=0")
-        blob = read_state(ema_from, "params_ema")
+        raw = torch.load(ema_from, map_location="cpu", weights_only=True)
+        if "params_ema" not in raw:   # read_state would fall back to 'params' (load_network's rule): not for the EMA weights
+            raise KeyError(f"{ema_from} has no 'params_ema' entry: the EMA weights would be seeded from the raw weights")
+        blob = _strip_module(raw["params_ema"])
         names = [n for n, p in bare_model(step.net).named_parameters() if p.requires_grad]
         missing = [n for n in names if n not in blob]
         if missing:

@@ -10,6 +10,7 @@ pass of each shape is captured once and replayed for every tile of that shape --
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, Iterator, List, Optional, Tuple
 
@@ -30,14 +31,6 @@ def tile_plan(height: int, width: int, tile: int, pad: int) -> Iterator[Tuple[in
             yield y0, y1, x0, x1, py0, py1, px0, px1
 
 
-class _NullCtx:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
-
-
 class TiledSR:
     """``out = TiledSR(net, scale)(img)``: ``img`` (B, C, H, W) -> (B, C, H*scale, W*scale), tile by tile.
 
@@ -56,6 +49,7 @@ class TiledSR:
         # (round 4) with ``batch_tiles``: the groups of DIFFERENT padded shapes (corner / edge / interior: four at 512 x 512) are
         # independent forwards, each too small to fill 256 CUs at batch 4 -- replay their graphs side by side, one HIP stream per
         # shape, and join before the result is read.  Same graphs, same kernels, same results; only the launch order overlaps.
+        # The FIRST call captures every shape on the main stream, one after the other: the overlap starts with the second image.
         self.concurrent_shapes = bool(concurrent_shapes)
         self._streams: Dict[Tuple[int, ...], torch.cuda.Stream] = {}
         self._graphs: Dict[Tuple[int, int, int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor, torch.Tensor]] = {}
@@ -110,26 +104,28 @@ class TiledSR:
                 if side:
                     shape_key = (tiles[0][5] - tiles[0][4], tiles[0][7] - tiles[0][6])
                     if (self.batch_tiles, C, *shape_key) in self._graphs:   # (first call: captured on the main stream, sequentially)
-                        st = self._streams.setdefault(shape_key, torch.cuda.Stream(device=img.device))
+                        st = self._streams.get(shape_key)
+                        if st is None:
+                            st = self._streams[shape_key] = torch.cuda.Stream(device=img.device)
                         if out is None:   # the first group's output fixes dtype / channels: allocate before any side stream writes
                             o0 = self._graphs[(self.batch_tiles, C, *shape_key)][2]
                             out = o0.new_zeros((1, o0.shape[1], H * s, W * s))
                         st.wait_stream(main)
                         used.append(st)
-                ctx = torch.cuda.stream(st) if st is not None else _NullCtx()
+                ctx = torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
                 with ctx:
-                  for k in range(0, len(tiles), self.batch_tiles):
-                      grp = tiles[k:k + self.batch_tiles]
-                      chops = [img[:, :, py0:py1, px0:px1] for (_, _, _, _, py0, py1, px0, px1) in grp]
-                      if graphed and len(grp) < self.batch_tiles:       # one graph per shape: pad the group with repeats
-                          chops = chops + [chops[-1]] * (self.batch_tiles - len(grp))
-                      o = self._run_tile(torch.cat(chops, 0).contiguous())
-                      self.tiles_run += len(grp) - 1
-                      if out is None:
-                          out = o.new_zeros((1, o.shape[1], H * s, W * s))
-                      for n, (y0, y1, x0, x1, py0, py1, px0, px1) in enumerate(grp):
-                          oy, ox = (y0 - py0) * s, (x0 - px0) * s
-                          out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[n:n + 1, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
+                    for k in range(0, len(tiles), self.batch_tiles):
+                        grp = tiles[k:k + self.batch_tiles]
+                        chops = [img[:, :, py0:py1, px0:px1] for (_, _, _, _, py0, py1, px0, px1) in grp]
+                        if graphed and len(grp) < self.batch_tiles:       # one graph per shape: pad the group with repeats
+                            chops = chops + [chops[-1]] * (self.batch_tiles - len(grp))
+                        o = self._run_tile(torch.cat(chops, 0).contiguous())
+                        self.tiles_run += len(grp) - 1
+                        if out is None:
+                            out = o.new_zeros((1, o.shape[1], H * s, W * s))
+                        for n, (y0, y1, x0, x1, py0, py1, px0, px1) in enumerate(grp):
+                            oy, ox = (y0 - py0) * s, (x0 - px0) * s
+                            out[:, :, y0 * s:y1 * s, x0 * s:x1 * s] = o[n:n + 1, :, oy:oy + (y1 - y0) * s, ox:ox + (x1 - x0) * s]
             for st in used:   # join: whoever reads `out` next runs after every shape's stream
                 main.wait_stream(st)
             return out
