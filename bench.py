@@ -482,6 +482,9 @@ def main():
     from vmambair_amd import _capi
     from vmambair_amd.archs import build_network
     lib = _capi.load()
+    if os.environ.get("VMAMBAIR_SCAN_SEGMENTS"):   # A-B timing: "fwd,bwd" time segments per row (-1 heuristic, 1 off, n)
+        fs, bs = (int(v) for v in os.environ["VMAMBAIR_SCAN_SEGMENTS"].split(","))
+        lib.oss_scan_set_segments(fs, bs)
 
     torch.manual_seed(0)
     derain = args.config == "deraining"

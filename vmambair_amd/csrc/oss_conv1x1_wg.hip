@@ -74,11 +74,22 @@ template <typename T, int KS, bool WT, int PT, bool RES, bool PF, bool LN>
 __global__ void __launch_bounds__(256)
 oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ y,
                       int M, int P, int64_t xsb, int64_t xsk, const T *__restrict__ res, WgLnArgs<T> ln) {
-    constexpr int K = 16 * KS, PITCH = PT + 8, NCT = PT / 32;   // LDS row pitch in elements: 16-byte aligned rows, banks spread
+    // LDS row pitches in elements (16-byte aligned rows).  (round 5) Two pitches: profiles/r04_pmc_lds_conflicts_per_kernel.txt had
+    // 44-47 % of this kernel's LDS cycles as bank-conflict cycles.  (a) The activation tile: a 16-lane group of ds_read_b64_tr_b16
+    // touches 4 rows x 32 bytes; with rows PT + 8 elements (272 bytes at PT = 128) apart, adjacent rows overlap by 16 bytes of
+    // bank space -- PT + 16 (288 bytes: 32 more than a bank sweep) lays the four pieces side by side.  (b) The output staging
+    // tile keeps PT + 8, and the 16-bit form writes 4 bytes per lane instead of 2 (below).
+    constexpr int K = 16 * KS, NCT = PT / 32;
+#ifdef OSS_EXP_WG_OLD_PITCH   // (OSS_EXP_*: A-B timing builds only, tools/build_experiment.sh)
+    constexpr int PX = PT + 8;
+#else
+    constexpr int PX = PT + 16;
+#endif
+    constexpr int PITCH = PT + 8;   // output staging tile
     using OT = typename std::conditional<RES, float, T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
-    T *xs = reinterpret_cast<T *>(wg_smem);                    // [K][PITCH]
-    OT *os = reinterpret_cast<OT *>(xs + K * PITCH);           // [4 waves][32][PITCH]
+    T *xs = reinterpret_cast<T *>(wg_smem);                    // [K][PX]
+    OT *os = reinterpret_cast<OT *>(xs + K * PX);              // [4 waves][32][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, p0 = blockIdx.x * PT;
     const T *xb = x + b * xsb + p0;
@@ -120,7 +131,7 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
     }
     // 1. the activation tile, 16 bytes per lane: lane -> (channel, 8-pixel chunk), a row's chunks on consecutive lanes
     constexpr int CPR = PT / 8;   // chunks per row
-    copy_tile_to_lds<T, K, PT, PITCH>(xb, xsk, xs, tid);
+    copy_tile_to_lds<T, K, PT, PX>(xb, xsk, xs, tid);
     if constexpr (LN) {
         if (tid < K) { lnw_s[tid] = lnw_r; lnb_s[tid] = lnb_r; }
     }
@@ -136,7 +147,7 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
         for (int i = 0; i < CPT; ++i) {
             const int c = part + i * NPART;
             if (c < K) {
-                const u32x2 q = *reinterpret_cast<const u32x2 *>(xs + c * PITCH + px);
+                const u32x2 q = *reinterpret_cast<const u32x2 *>(xs + c * PX + px);
                 unpack2<T>(q.x, v[i][0], v[i][1]); unpack2<T>(q.y, v[i][2], v[i][3]);
             } else {
                 v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
@@ -192,20 +203,20 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
                 float o[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[u] = (v[i][u] - mu_c[u]) * rstd[u] * wc + bc;   // BiasFree: mu_c = 0, bc = 0 (x * rstd * w)
-                *reinterpret_cast<u32x2 *>(xs + c * PITCH + px) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+                *reinterpret_cast<u32x2 *>(xs + c * PX + px) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
             }
         }
         __syncthreads();   // (also: red[] has been read by everyone before the output staging reuses it)
         T *nb = ln.n + (size_t)b * K * P + p0;
         for (int idx = tid; zi == 0 && idx < K * CPR; idx += 256) {
             const int c = idx / CPR, pc = idx - c * CPR;
-            *reinterpret_cast<u32x4 *>(nb + (size_t)c * P + 8 * pc) = *reinterpret_cast<const u32x4 *>(xs + c * PITCH + 8 * pc);
+            *reinterpret_cast<u32x4 *>(nb + (size_t)c * P + 8 * pc) = *reinterpret_cast<const u32x4 *>(xs + c * PX + 8 * pc);
         }
     }
     const int i16 = lane & 15, g = lane >> 4;
     // transpose-read address of this lane inside a [4][16] block: row i16 / 4, pixels 4 (i16 % 4) .. + 3; the lane then HOLDS
     // pixel i16 of the block.  Blocks of the 16-lane groups: pixels 16 (g & 1) + .. of the column tile, channels 8 (g >> 1) + ..
-    const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * PITCH + 16 * (g & 1) + 4 * (i16 & 3);
+    const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * PX + 16 * (g & 1) + 4 * (i16 & 3);
     OT *ow = os + wave * 32 * PITCH;
     for (int mt = wave * nz + zi; mt < mt_total; mt += 4 * nz) {
         const int m0 = mt * 32;
@@ -221,22 +232,51 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
             const s16x8 af = m0 + col < M ? cvt8<T>(cur.lo[ks], cur.hi[ks]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const T *bp = xs + ks * 16 * PITCH + ct * 32 + tr_off;
+                const T *bp = xs + ks * 16 * PX + ct * 32 + tr_off;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp + 4 * PITCH));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(bp + 4 * PX));
                 const s16x8 bf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 acc[ct] = Mfma<T>::run(af, bf, acc[ct]);
             }
         }
         // 4. results (+ bias) -> the wave's LDS tile [row][pixel] -> 16-byte stores (+ the residual, rounded once)
+#ifdef OSS_EXP_WG_OLD_EPI
+        constexpr bool kPairEpi = false;
+#else
+        constexpr bool kPairEpi = !RES;
+#endif
+        if constexpr (!kPairEpi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-            const float bv = __int_as_float(__builtin_amdgcn_ds_bpermute(row << 2, __float_as_int(cur.bl)));
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const float bv = __int_as_float(__builtin_amdgcn_ds_bpermute(row << 2, __float_as_int(cur.bl)));
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                if constexpr (RES) ow[row * PITCH + ct * 32 + col] = acc[ct][r] + bv;
-                else               ow[row * PITCH + ct * 32 + col] = from_f32<T>(acc[ct][r] + bv);
+                for (int ct = 0; ct < NCT; ++ct) {
+                    if constexpr (RES) ow[row * PITCH + ct * 32 + col] = acc[ct][r] + bv;
+                    else               ow[row * PITCH + ct * 32 + col] = from_f32<T>(acc[ct][r] + bv);
+                }
+            }
+        } else {
+            // (round 5) 16-bit results: one 4-byte write per lane and register PAIR instead of two 2-byte writes (two lanes per bank
+            // word each).  Registers r and r + 4 hold rows A and A + 8 of the same pixel column; neighbouring lanes swap one value
+            // (DPP quad_perm [1,0,3,2]) so that the even lane owns pixels (col, col + 1) of row A and the odd lane pixels
+            // (col - 1, col) of row A + 8.  Rows are 68 words apart: even lanes cover words w .. w+15, odd lanes w+32 .. w+47 (8 rows
+            // = 32 words mod 64), the upper half wave (rows + 4 = 16 words mod 64) the other two quarters -- 64 lanes, 64 banks.
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = (rr & 3) + 8 * (rr >> 2);          // 0..3, 8..11: paired with r + 4
+                const int rowA = (r & 3) + 8 * (r >> 2) + 4 * kg, rowB = rowA + 8;
+                const float bvA = __int_as_float(__builtin_amdgcn_ds_bpermute(rowA << 2, __float_as_int(cur.bl)));
+                const float bvB = __int_as_float(__builtin_amdgcn_ds_bpermute(rowB << 2, __float_as_int(cur.bl)));
+                T *dst = ow + (odd ? rowB : rowA) * PITCH + (col & ~1);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const float va = acc[ct][r] + bvA, vb = acc[ct][r + 4] + bvB;
+                    const float give = odd ? va : vb;
+                    const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xB1, 0xf, 0xf, false));
+                    *reinterpret_cast<uint32_t *>(dst + ct * 32) = odd ? pack2<T>(recv, vb) : pack2<T>(va, recv);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -263,7 +303,12 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
     }
 }
 
-static size_t wg_lds_bytes(int K, int pt, bool res) { return ((size_t)K * 2 + 4 * 32 * (res ? 4 : 2)) * (pt + 8) + 2 * (size_t)K * sizeof(float); }   // + the LayerNorm weight / bias image
+#ifdef OSS_EXP_WG_OLD_PITCH
+constexpr int kWgXPad = 8;
+#else
+constexpr int kWgXPad = 16;
+#endif
+static size_t wg_lds_bytes(int K, int pt, bool res) { return (size_t)K * 2 * (pt + kWgXPad) + (size_t)4 * 32 * (res ? 4 : 2) * (pt + 8) + 2 * (size_t)K * sizeof(float); }   // + the LayerNorm weight / bias image
 // pixels per workgroup (64 | 128) and the row-tile split (gridDim.z): 0 = by shape, else forced (A-B timing).  Measured
 // (tools/conv_wg_test.py, and inside the SR and Deraining steps): K = 96 / 192 want 128 pixels when that still gives a
 // workgroup per CU, K <= 48 wants 64; a launch with fewer workgroups than CUs (Deraining levels 1.. at batch 4) loses to the

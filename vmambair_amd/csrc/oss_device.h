@@ -200,6 +200,20 @@ __device__ __forceinline__ int tile_off(int n, int p, int i) {
     return n * (LPR * I) + (i >> 2) * (LPR * 4) + p * 4 + (i & 3);
 }
 
+// (round 5) the same image with the I/4 quad planes kTilePlanePad<I> floats further apart.  Reads are unchanged (lane p's quad k
+// sits at k * plane + 4 p: consecutive lanes, consecutive 16 bytes).  The STAGING writes were the conflict: thread k of
+// stage_bc_tiles owns 4-position group k of a state row = (pos k / (I/4), quad k % (I/4)), so consecutive threads wrote whole
+// planes apart -- LPR * 16 bytes, a multiple of the 256-byte bank sweep: I/4 threads on the same banks, i.e. (I = 16) a four-way
+// conflict on every ds_write_b128 of the tile refill.  profiles/r04_pmc_sq_scan.txt: SQ_LDS_BANK_CONFLICT = 25 % of
+// SQ_LDS_IDX_ACTIVE for oss_scan_fwd_kernel<bf16,64,16,12> -- the writes are 1/13 of the tile bytes moved and cost 4x.
+// With 256 / I floats of padding per plane, 16 consecutive threads cover 16 distinct 16-byte bank slots.
+template <int I> constexpr int kTilePlanePad = 256 / I;
+template <int LPR, int I> constexpr int kTileRowPad = LPR * I + (I / 4) * kTilePlanePad<I>;   // floats per state row
+template <int LPR, int I>
+__device__ __forceinline__ int tile_off_pad(int n, int p, int i) {
+    return n * kTileRowPad<LPR, I> + (i >> 2) * (LPR * 4 + kTilePlanePad<I>) + p * 4 + (i & 3);
+}
+
 // I items of one lane at scan positions tl .. tl+I-1 of a row of length L.  Forward rows read
 // memory tl+i; time-reversed rows read memory L-1-(tl+i) (one contiguous block, mirrored in
 // registers).  Positions >= L read as 0.
@@ -346,7 +360,7 @@ __device__ __forceinline__ void dt_rows_apply(const DtRows<T, I> &d, int R, bool
 // Stage nb state rows x TC scan positions of one (batch, group) of B and C into the LDS tiles as
 // fp32 (tile_off image).  `rev`: scan position s reads memory L-1-s.  WITH_C = false stages B only (the local pass of
 // the time-segmented forward never touches C).
-template <typename T, int LPR, int I, int NT, bool WITH_C = true>
+template <typename T, int LPR, int I, int NT, bool WITH_C = true, bool PAD = false>
 __device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB, const T *gC, int64_t strideB,
                                                int64_t strideC, int nb, int t0, int L, bool rev, int tid) {
     constexpr int TC = LPR * I;
@@ -391,7 +405,7 @@ __device__ __forceinline__ void stage_bc_tiles(float *sB, float *sC, const T *gB
         if (rev) { vb = f32x4{b4[3], b4[2], b4[1], b4[0]}; vc = f32x4{c4[3], c4[2], c4[1], c4[0]}; }
         else     { vb = f32x4{b4[0], b4[1], b4[2], b4[3]}; vc = f32x4{c4[0], c4[1], c4[2], c4[3]}; }
         const int pos = (4 * k) / I, i0 = (4 * k) % I;
-        const int off = tile_off<LPR, I>(n, pos, i0);
+        const int off = PAD ? tile_off_pad<LPR, I>(n, pos, i0) : tile_off<LPR, I>(n, pos, i0);
         *reinterpret_cast<f32x4 *>(sB + off) = vb;
         if constexpr (WITH_C) *reinterpret_cast<f32x4 *>(sC + off) = vc;
     }

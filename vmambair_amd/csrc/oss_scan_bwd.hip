@@ -440,7 +440,7 @@ static thread_local LaunchTimer *g_finish_timer = nullptr;   // set by scan_bwd_
 // workspace carving shared by the launchers; -> OSS_OK or OSS_ERR_WORKSPACE.  n_seg > 1 (time-segmented launch): one
 // weight-gradient partial per (batch, segment, row) and, behind them, the reverse-carry pairs (*carry).
 static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, float *&wdD, float *&wdb, int n_seg = 1,
-                    float **carry = nullptr) {
+                    float **carry = nullptr, int n_cseg = 0) {
     const oss_scan_fwd_params &f = p.f;
     const int rows_per_group = f.dim / f.n_groups;
     const int tiles = (rows_per_group + rows_per_wg - 1) / rows_per_wg;
@@ -448,7 +448,7 @@ static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, fl
     const size_t n_bc = ws_bc_floats(f.batch, f.n_groups, tiles, f.dstate, f.seqlen, rp);
     const size_t wb = (size_t)f.batch * n_seg;
     const size_t n_w = wb * f.dim * (f.dstate + 2 + (rp ? kMaxDtRank : 0));
-    const size_t n_carry = n_seg > 1 ? scan_carry_bytes(f.batch, f.dim, f.dstate, n_seg) / sizeof(float) : 0;
+    const size_t n_carry = n_seg > 1 ? scan_carry_bytes(f.batch, f.dim, f.dstate, std::max(n_seg, n_cseg)) / sizeof(float) : 0;
     const size_t need = sizeof(float) * (n_bc + n_w + n_carry);
     if (!p.workspace || p.workspace_bytes < need) return OSS_ERR_WORKSPACE;
     ws.bc = reinterpret_cast<float *>(p.workspace);
@@ -551,9 +551,20 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.3);
     int cps = n_chunks;
     if (n_seg > 1) { cps = (n_chunks + n_seg - 1) / n_seg; n_seg = (n_chunks + cps - 1) / cps; }
+    // carry segments per main segment (BwdSeg): the largest divisor of cps that keeps the carry pass within ~one workgroup per CU
+    int csub = 1;
+    if (n_seg > 1) {
+        static const int forced = [] { const char *e = std::getenv("VMAMBAIR_SCAN_CARRY_SPLIT"); return e ? std::atoi(e) : 0; }();   // A-B timing
+        for (int c = 2; c <= cps; ++c) {
+            if (cps % c) continue;
+            if ((n_chunks + cps / c - 1) / (cps / c) > kMaxSegments) break;   // one carry slot per carry segment (workspace query)
+            if (forced > 0 ? c <= forced : (long)wgs * (n_seg - 1) * c <= 512) csub = c;
+        }
+    }
+    const int ccps = cps / csub, n_cseg = n_seg > 1 ? (n_chunks + ccps - 1) / ccps : 0;
     BwdWs ws;
     float *wdD, *wdb, *carry = nullptr;
-    int rc = carve_ws(p, WAVES, ws, wdD, wdb, n_seg, &carry);
+    int rc = carve_ws(p, WAVES, ws, wdD, wdb, n_seg, &carry, n_cseg);
     if (rc != OSS_OK && n_seg > 1) {   // a caller that sized the workspace for the unsegmented form
         n_seg = 1; cps = n_chunks;
         rc = carve_ws(p, WAVES, ws, wdD, wdb);
@@ -568,7 +579,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     g_last_bwd_lane_states.store(hs ? 1 : 0);
     if constexpr (!FD) {
         if (n_seg > 1) {
-            const BwdSeg sg{carry, n_seg, cps};
+            const BwdSeg sg{carry, n_seg, cps, csub, ccps, n_cseg};
             // the carry pass is per ROW (nothing is summed over rows), so its row tile is free: 4-row workgroups (three times the
             // workgroups, several per CU) measured SLOWER than the main kernel's tile -- u:(4,192,16384) 0.355 against 0.340 ms for
             // the whole call -- because every workgroup stages the group's C rows again
@@ -577,7 +588,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             auto kc = oss_scan_bwd_carry_kernel<T, CW>;
             if (timer) { timer->segmented(); timer->begin(stream); }
             if (g_finish_timer) g_finish_timer->segmented();
-            hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_seg - 1))), dim3(CW * 64), sizeof(float) * 2 * kNB * TC,
+            hipLaunchKernelGGL(kc, dim3((unsigned)(f.batch * f.n_groups * ctiles * (n_cseg - csub))), dim3(CW * 64), sizeof(float) * 2 * kNB * TC,
                                stream, p, sg, ctiles);
             static LdsGate gate_s, gate_sh;
             bool launched = false;
@@ -603,7 +614,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             if (hs) {
                 static LdsGate gate_h;
                 rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, false, true>, smem, gate_h, wgs, WAVES * 64, p, ws,
-                                 stream, timer, BwdSeg{nullptr, 1, n_chunks});
+                                 stream, timer, BwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
                 if (rc != OSS_OK) return rc;
                 return launch_finish<T>(p, ws, wdD, wdb, stream);
             }
@@ -611,7 +622,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     }
     static LdsGate gate;
     rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false, false>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
-                     BwdSeg{nullptr, 1, n_chunks});
+                     BwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
     if (rc != OSS_OK) return rc;
     return launch_finish<T>(p, ws, wdD, wdb, stream);
 }

@@ -134,8 +134,13 @@ constexpr int kSlabA = 2 * kSlabK;     // floats per (row, dB | dC) array
 // oss_scan_bwd_carry_kernel (below) leaves in sg.carry.  Per-(batch, row) partials of dA / dD / dbias get one slot per
 // segment (summed by the finishing kernel in segment order).
 struct BwdSeg {
-    float *carry;   // [batch][dim][n_seg][dstate][2]: (prod of a_{t+1} over the segment, dh at its first step from a zero carry)
+    float *carry;   // [batch][dim][n_cseg][dstate][2]: (prod of a_{t+1} over the carry segment, dh at its first step from a zero carry)
     int n_seg, cps; // segments per row, 512-step chunks per segment
+    // (round 5) the carry pass has its own, finer segmentation: csub carry segments of ccps = cps / csub chunks per main segment,
+    // n_cseg of them per row.  A 2-segment launch at u:(4,384,4096) ran its carry pass on 128 workgroups x 4 chunks (half the
+    // CUs idle, 33 us next to the main kernel's 101); with csub = 2 it is 256 workgroups x 2 chunks, and the main kernel folds
+    // two pairs instead of one.  The C rows are staged per chunk, so finer TIME segments re-stage nothing (finer ROW tiles did).
+    int csub, ccps, n_cseg;
 };
 // HS: the forward pass left the state entering every 8-step block in f.hs (include/vmambair_oss.h: lane states).  A lane's
 // 8 steps then start from a LOADED state: the local forward recurrence, the product of a over the lane and one of the two lane
@@ -285,9 +290,9 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     if constexpr (SEG) {
         // dh entering from the later segments: fold their pairs, last segment first
         if (lane < N) {
-            const float2 *cr = reinterpret_cast<const float2 *>(sg.carry) + (((size_t)b * f.dim + d) * n_seg) * N + lane;
+            const float2 *cr = reinterpret_cast<const float2 *>(sg.carry) + (((size_t)b * f.dim + d) * sg.n_cseg) * N + lane;
             float dh = 0.f;
-            for (int j = n_seg - 1; j > seg; --j) {
+            for (int j = sg.n_cseg - 1; j >= (seg + 1) * sg.csub; --j) {   // the carry segments behind this segment's last step
                 const float2 pr = cr[(size_t)j * N];
                 dh = __builtin_fmaf(pr.x, dh, pr.y);
             }
@@ -765,7 +770,8 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
     const int rows_per_group = f.dim / G;
     int bid = blockIdx.x;
     const int tile = bid % tiles_per_group; bid /= tiles_per_group;
-    const int seg = 1 + bid % (sg.n_seg - 1); bid /= (sg.n_seg - 1);   // segment 0 has no predecessor to hand a carry to
+    const int n_cs = sg.n_cseg - sg.csub;   // the carry segments of main segment 0 have no predecessor to hand a carry to
+    const int seg = sg.csub + bid % n_cs; bid /= n_cs;
     const int g = bid % G;
     const int b = bid / G;
     const int row_in_group = tile * ROWS + wave;
@@ -784,7 +790,7 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
         A2v = (f.a_log_form ? -__expf(av) : av) * kLog2e;
     }
     const int n_chunks = (L + TC - 1) / TC;
-    const int c_begin = seg * sg.cps, c_end = min(n_chunks, c_begin + sg.cps);
+    const int c_begin = seg * sg.ccps, c_end = min(n_chunks, c_begin + sg.ccps);
     float dln_c = 0.f;
     {
         const int t1 = c_end * TC;
@@ -897,7 +903,7 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
         dln_c = lane_get(dl[0], 0);
     }
     if (row_valid && lane < N) {
-        float2 *cr = reinterpret_cast<float2 *>(sg.carry) + (((size_t)b * f.dim + d) * sg.n_seg + seg) * N + lane;
+        float2 *cr = reinterpret_cast<float2 *>(sg.carry) + (((size_t)b * f.dim + d) * sg.n_cseg + seg) * N + lane;
         *cr = make_float2(Pv, dhcv);
     }
 }

@@ -35,8 +35,11 @@ namespace oss {
 // Same arithmetic per step as the unsegmented kernel; the state entering a segment is associated differently
 // (segment-local partial states folded instead of one running chain), i.e. equal up to fp32 round-off.
 struct FwdSeg {
-    float *carry;   // [batch][dim][n_seg][dstate][2] floats
+    float *carry;   // [batch][dim][n_cseg][dstate][2] floats
     int n_seg, cps; // segments per row, chunks (of TC steps) per segment
+    // (round 5) the local pass has its own, finer segmentation (as the backward's carry pass, oss_scan_bwd_v2.h: BwdSeg): csub local
+    // segments of ccps = cps / csub chunks per segment, n_cseg slots per row; the real pass folds seg * csub pairs
+    int csub, ccps, n_cseg;
 };
 template <typename T, int LPR, int I, int WAVES, bool FD = false, int SEG = 0>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -49,9 +52,16 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     static_assert(I % 4 == 0, "");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sB = smem;                 // [kNB][TC]
-    float *sC = smem + kNB * TC;      // [kNB][TC]
-    float *carH = smem + 2 * kNB * TC;               // [dstate][ROWS]   h entering the chunk
+#ifdef OSS_EXP_FWD_NO_TILE_PAD   // (OSS_EXP_*: A-B timing builds only, tools/build_experiment.sh)
+    constexpr bool kPad = false;
+#else
+    constexpr bool kPad = true;       // bank-conflict-free staging writes (oss_device.h: tile_off_pad)
+#endif
+    constexpr int TR = kPad ? kTileRowPad<LPR, I> : TC;   // floats per state row of a tile
+    constexpr int PL = kPad ? LPR * 4 + kTilePlanePad<I> : LPR * 4;   // floats between the quads of a lane
+    float *sB = smem;                 // [kNB][TR]
+    float *sC = smem + kNB * TR;      // [kNB][TR]
+    float *carH = smem + 2 * kNB * TR;               // [dstate][ROWS]   h entering the chunk
     float *carP = carH + (size_t)p.dstate * ROWS;    // [dstate][ROWS]   prod of a since t = 0
     float *sA2 = carP + (size_t)p.dstate * ROWS;     // [dstate][ROWS]   A * log2(e)
 
@@ -69,7 +79,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     // (as the backward does, oss_scan_bwd_v2.h; round 3 measured FETCH = 2.5 x the input bytes for this kernel at
     // u:(8,384,4096): tile = id % 8 dealt a group's eight tiles to the eight XCDs).  Speed only: nothing depends on placement.
     int bid = blockIdx.x, tile;
-    const int ns = SEG == 0 ? 1 : (SEG == 1 ? sg.n_seg - 1 : sg.n_seg);   // the last segment has no successor: no local pass
+    const int ns = SEG == 0 ? 1 : (SEG == 1 ? (sg.n_seg - 1) * sg.csub : sg.n_seg);   // the last segment has no successor: no local pass
 #ifdef OSS_EXP_FWD_NO_XCD   // (OSS_EXP_*: A-B timing builds only, tools/build_experiment.sh)
     constexpr bool kXcdOrder = false;
 #else
@@ -114,8 +124,8 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
         const int dd = g * rows_per_group + (rg < rows_per_group ? rg : 0);
         float h0 = 0.f, P0 = 1.f;
         if constexpr (SEG == 2) {   // fold the local pairs of the earlier segments, in time order
-            const float2 *cr = reinterpret_cast<const float2 *>(sg.carry) + (((size_t)b * p.dim + dd) * sg.n_seg) * N + n;
-            for (int j = 0; j < seg; ++j) {
+            const float2 *cr = reinterpret_cast<const float2 *>(sg.carry) + (((size_t)b * p.dim + dd) * sg.n_cseg) * N + n;
+            for (int j = 0; j < seg * sg.csub; ++j) {
                 const float2 pr = cr[(size_t)j * N];
                 h0 = __builtin_fmaf(pr.x, h0, pr.y);
                 P0 *= pr.x;
@@ -128,8 +138,9 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     }
 
     const int n_chunks = (L + TC - 1) / TC;
-    const int c_begin = SEG != 0 ? seg * sg.cps : 0;
-    const int c_end = SEG != 0 ? min(n_chunks, c_begin + sg.cps) : n_chunks;
+    const int seg_chunks = SEG == 1 ? sg.ccps : sg.cps;   // SEG = 1: `seg` counts local (fine) segments
+    const int c_begin = SEG != 0 ? seg * seg_chunks : 0;
+    const int c_end = SEG != 0 ? min(n_chunks, c_begin + seg_chunks) : n_chunks;
     for (int c = c_begin; c < c_end; ++c) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;  // first time step of this lane
@@ -175,7 +186,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
         for (int n0 = 0; n0 < N; n0 += kNB) {
             const int nb = min(kNB, N - n0);
             __syncthreads();  // everyone is done with the previous tile (and the carry init)
-            stage_bc_tiles<T, LPR, I, NT, SEG != 1>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
+            stage_bc_tiles<T, LPR, I, NT, SEG != 1, kPad>(sB, sC, gB + (int64_t)n0 * p.B_dstate_stride,
                                           gC + (int64_t)n0 * p.C_dstate_stride, p.B_dstate_stride,
                                           p.C_dstate_stride, nb, t0, L, rev, tid);
             __syncthreads();
@@ -186,10 +197,10 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
                 const float Pc = carP[n * ROWS + wrow];
                 float a[I], bb[I];
                 float h = 0.f;
-                const float *tb = sB + tile_off<LPR, I>(nn, pos, 0);
+                const float *tb = sB + nn * TR + pos * 4;
 #pragma unroll
                 for (int k = 0; k < I / 4; ++k) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(tb + k * (LPR * 4));
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(tb + k * PL);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int i = 4 * k + j;
@@ -210,12 +221,12 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
                         float2 st = make_float2(Pfull, hfull);
                         *reinterpret_cast<float2 *>(x_row + (size_t)xc * 2 * N + 2 * n) = st;
                     }
-                    const float *tc = sC + tile_off<LPR, I>(nn, pos, 0);
+                    const float *tc = sC + nn * TR + pos * 4;
                     h = hin;
                     float h_mid = 0.f;   // I = 16: the state after this lane's 8th step
 #pragma unroll
                     for (int k = 0; k < I / 4; ++k) {
-                        const f32x4 cv = *reinterpret_cast<const f32x4 *>(tc + k * (LPR * 4));
+                        const f32x4 cv = *reinterpret_cast<const f32x4 *>(tc + k * PL);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int i = 4 * k + j;
@@ -251,7 +262,7 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
             const int rg = tile * ROWS + r;
             if (rg < rows_per_group) {
                 const int dd = g * rows_per_group + rg;
-                float2 *cr = reinterpret_cast<float2 *>(sg.carry) + (((size_t)b * p.dim + dd) * sg.n_seg + seg) * N + n;
+                float2 *cr = reinterpret_cast<float2 *>(sg.carry) + (((size_t)b * p.dim + dd) * sg.n_cseg + seg) * N + n;
                 *cr = make_float2(carP[idx], carH[idx]);
             }
         }
@@ -270,7 +281,12 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
     constexpr int TC = LPR * I;
     const int rows_per_group = p.dim / p.n_groups;
     const int tiles = (rows_per_group + ROWS - 1) / ROWS;
-    const size_t smem = sizeof(float) * (2 * (size_t)kNB * TC + 3 * (size_t)p.dstate * ROWS);
+#ifdef OSS_EXP_FWD_NO_TILE_PAD
+    constexpr int TR = TC;
+#else
+    constexpr int TR = kTileRowPad<LPR, I>;
+#endif
+    const size_t smem = sizeof(float) * (2 * (size_t)kNB * TR + 3 * (size_t)p.dstate * ROWS);
     if constexpr (!(LPR == 64 && I == 4 && WAVES == 4)) {
         // large dstate: tiles + per-row carries no longer fit 160 KiB -> the small-shape variant (4 rows, 256-step chunks)
         if (smem > kMaxLdsBytes) return launch_fwd<T, 64, 4, 4, FD>(p, seg_req, stream);
@@ -278,7 +294,8 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
     const unsigned wgs = (unsigned)(p.batch * p.n_groups * tiles);
     const int n_chunks = (p.seqlen + TC - 1) / TC;
     int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.55);
-    if (n_seg > 1 && (!p.workspace || p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, n_seg))) n_seg = 1;
+    // (the carry slots are per LOCAL segment, at most one per chunk: sized for that)
+    if (n_seg > 1 && (!p.workspace || p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, std::min(n_chunks, kMaxSegments)))) n_seg = 1;
     g_last_fwd_segments.store(1);
     if constexpr (!FD) {
         if (n_seg > 1) {
@@ -286,13 +303,22 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
             sg.carry = reinterpret_cast<float *>(p.workspace);
             sg.cps = (n_chunks + n_seg - 1) / n_seg;
             sg.n_seg = (n_chunks + sg.cps - 1) / sg.cps;
+            sg.csub = 1;
+            static const int forced = [] { const char *e = std::getenv("VMAMBAIR_SCAN_CARRY_SPLIT"); return e ? std::atoi(e) : 0; }();   // A-B timing
+            for (int c = 2; c <= sg.cps; ++c) {
+                if (sg.cps % c) continue;
+                if ((n_chunks + sg.cps / c - 1) / (sg.cps / c) > kMaxSegments) break;   // one carry slot per local segment
+                if (forced > 0 ? c <= forced : (long)wgs * (sg.n_seg - 1) * c <= 512) sg.csub = c;
+            }
+            sg.ccps = sg.cps / sg.csub;
+            sg.n_cseg = (n_chunks + sg.ccps - 1) / sg.ccps;
             g_last_fwd_segments.store(sg.n_seg);
             auto k1 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 1>;
             auto k2 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 2>;
             static LdsGate gate1, gate2;
             if (const int e = gate1.ensure(reinterpret_cast<const void *>(k1), smem)) return e;
             if (const int e = gate2.ensure(reinterpret_cast<const void *>(k2), smem)) return e;
-            hipLaunchKernelGGL(k1, dim3(wgs * (unsigned)(sg.n_seg - 1)), dim3(WAVES * 64), smem, stream, p, sg);
+            hipLaunchKernelGGL(k1, dim3(wgs * (unsigned)((sg.n_seg - 1) * sg.csub)), dim3(WAVES * 64), smem, stream, p, sg);
             hipLaunchKernelGGL(k2, dim3(wgs * (unsigned)sg.n_seg), dim3(WAVES * 64), smem, stream, p, sg);
             return (int)hipGetLastError();
         }
@@ -300,7 +326,7 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
     auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD, 0>;
     static LdsGate gate;
     if (const int e = gate.ensure(reinterpret_cast<const void *>(kern), smem)) return e;
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(WAVES * 64), smem, stream, p, FwdSeg{nullptr, 1, n_chunks});
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(WAVES * 64), smem, stream, p, FwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
     return (int)hipGetLastError();
 }
 
