@@ -201,13 +201,15 @@ __device__ __forceinline__ int tile_off(int n, int p, int i) {
 }
 
 // (round 5) the same image with the I/4 quad planes kTilePlanePad<I> floats further apart.  Reads are unchanged (lane p's quad k
-// sits at k * plane + 4 p: consecutive lanes, consecutive 16 bytes).  The STAGING writes were the conflict: thread k of
-// stage_bc_tiles owns 4-position group k of a state row = (pos k / (I/4), quad k % (I/4)), so consecutive threads wrote whole
-// planes apart -- LPR * 16 bytes, a multiple of the 256-byte bank sweep: I/4 threads on the same banks, i.e. (I = 16) a four-way
-// conflict on every ds_write_b128 of the tile refill.  profiles/r04_pmc_sq_scan.txt: SQ_LDS_BANK_CONFLICT = 25 % of
-// SQ_LDS_IDX_ACTIVE for oss_scan_fwd_kernel<bf16,64,16,12> -- the writes are 1/13 of the tile bytes moved and cost 4x.
-// With 256 / I floats of padding per plane, 16 consecutive threads cover 16 distinct 16-byte bank slots.
-template <int I> constexpr int kTilePlanePad = 256 / I;
+// sits at k * plane + 4 p: consecutive lanes, consecutive 16 bytes -- what the four lane groups of ds_read_b128 want).  The
+// STAGING writes were the conflict: thread k of stage_bc_tiles owns 4-position group k of a state row = (pos k / (I/4), quad
+// k % (I/4)), so consecutive threads wrote whole planes apart.  ds_write_b128 is serviced in contiguous 8-lane groups over 32
+// banks (128 bytes: MI355X_MICROARCH.md, LDS); planes LPR * 16 bytes apart are a multiple of that sweep, so the I/4 threads of
+// one position shared their banks: a four-way conflict (I = 16) on every write of the tile refill.
+// profiles/r04_pmc_sq_scan.txt: SQ_LDS_BANK_CONFLICT = 25 % of SQ_LDS_IDX_ACTIVE for oss_scan_fwd_kernel<bf16,64,16,12>.
+// With 128 / I floats of padding per plane a group's 8 threads -- 8 / (I/4) positions x I/4 quads -- cover the 8 slots of the
+// sweep once (16 floats were measured first: 25 % -> 10 %, quads 0 / 2 still on one slot).
+template <int I> constexpr int kTilePlanePad = 128 / I;
 template <int LPR, int I> constexpr int kTileRowPad = LPR * I + (I / 4) * kTilePlanePad<I>;   // floats per state row
 template <int LPR, int I>
 __device__ __forceinline__ int tile_off_pad(int n, int p, int i) {
