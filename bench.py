@@ -230,11 +230,13 @@ def bench_srgan_split64(args):
         "roofline": None, "cpu_baseline": None}), flush=True)
 
 
-def pmc_lookup(lib, kkey):
+def pmc_lookup(lib, kkey, shape=None):
     """HBM bytes per launch of kernel ``kkey`` from the PMC record under profiles/ (separate rocprofv3 --pmc passes,
     tools/pmc_traffic.sh + tools/pmc_record.py) -- only when the record was measured on THIS build of the scan kernels
     (``oss_scan_build_id()``); a record of another build is reported as stale, never silently.
-    Time-segmented calls are two launches (the profiler bucket times both): the local / carry pass is added to the main one."""
+    Time-segmented calls are two launches (the profiler bucket times both): the local / carry pass is added to the main one.
+    ``shape``: "u:(B,D,L)" of the call the line is about -- the record holds one entry per measured shape (`<key> @ <shape>`);
+    with a shape given, an entry measured at ANOTHER shape is not used (round 4's batch-4 line quoted the Deraining record)."""
     prof_dir = os.path.join(ROOT, "profiles")
     build = lib.oss_scan_build_id().decode()
     extra = []
@@ -250,10 +252,17 @@ def pmc_lookup(lib, kkey):
             rec = json.load(open(os.path.join(prof_dir, f)))
             if kkey not in rec:
                 continue
+            if shape is not None:
+                if f"{kkey} @ {shape}" not in rec:
+                    return None, f"no PMC record of this kernel at {shape} in profiles/{f}", None
+                suffix = f" @ {shape}"
+                kkey_s, extra = kkey + suffix, [k + suffix for k in extra]
+            else:
+                kkey_s = kkey
             if rec.get("_build_id") != build:
                 return None, (f"stale: profiles/{f} was measured on scan-kernel build {rec.get('_build_id', '(unrecorded)')}, "
                               f"this library is {build}"), None
-            e = rec[kkey]
+            e = rec[kkey_s]
             total = int(e["fetch_bytes"] + e["write_bytes"]) + sum(int(rec[k]["fetch_bytes"] + rec[k]["write_bytes"]) for k in extra if k in rec)
             note = f"FETCH_SIZE (x2, gfx950) + WRITE_SIZE per dispatch, separate rocprofv3 --pmc passes, build {build} [profiles/{f}]"
             if extra:
@@ -618,7 +627,9 @@ def main():
             kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}" + (" segmented" if dom["segmented"] else "")
             fdom = fin.get((dom["variant"], dom["io"], dom["segmented"])) if dom["kernel"] == "oss_scan_bwd_kernel" else None
             with_fin_ms = dom["total_ms"] + (fdom["total_ms"] if fdom else 0.0)
-            traffic, traffic_note, valu_busy = pmc_lookup(lib, kkey)
+            # the dominant call of the workload: SS2D_1 of the widest full-resolution level, D = d_inner rows per direction
+            call_shape = f"u:({B},48,16384)" if derain else f"u:({B},96,4096)"
+            traffic, traffic_note, valu_busy = pmc_lookup(lib, kkey, call_shape)
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": kkey,
@@ -626,6 +637,10 @@ def main():
                     # issue rate, not HBM -- share of the kernel with a SIMD's VALU issuing, from the SQ counters
                     # (profiles/r01_pmc_sq_scan.txt, tools/pmc_sq.sh); DESIGN.md section 5
                     "valu_busy": valu_busy,
+                    #  not a counter read in THIS run: the SQ record of this build id under profiles/, or null
+                    "valu_busy_source": (None if valu_busy is None else
+                                         "looked up in the SQ counter record of this scan build id under profiles/ (the file `traffic_note` "
+                                         "names), not measured in this run"),
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
                     # time segments per row of the LAST scan call (1 = one workgroup walks the whole row, as the reference does)

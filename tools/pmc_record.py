@@ -102,6 +102,9 @@ def main():
             e["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
         e["shape"] = note
         rec[k] = e
+        # (round 5) the same kernel is measured at several shapes (headline, batch 4, Deraining level 0, RealSR tile): every
+        # shape keeps its own entry, `<key> @ u:(B,D,L)`; the bare key is the LAST shape recorded (what rounds 2-4 read)
+        rec[k + " @ " + note.split()[0]] = dict(e)
     for k, v in prev.items():   # entries of the shapes recorded before
         if not k.startswith("_") and k not in rec:
             rec[k] = v

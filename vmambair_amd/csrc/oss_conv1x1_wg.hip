@@ -340,6 +340,7 @@ static void wg_shape(int B, int M, int K, int P, int &pt, int &nz) {
     if (nz < 1) nz = 1;
 }
 
+static constexpr bool wg_ks_built(int ks) { return ks == 1 || ks == 2 || ks == 3 || ks == 4 || ks == 6 || ks == 8 || ks == 12; }
 // 1 when the workgroup-level kernel takes the shape
 int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,
                   const void *res) {
@@ -349,6 +350,9 @@ int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, c
     if (res) return 0;
     if (io != OSS_BF16 && io != OSS_F16) return 0;
     if (K % 16 != 0 || K < 16 || K > 192 || P % 128 != 0 || M < 1) return 0;
+    // built for the widths a power-of-two-times-{1,3} base width gives (K = 16, 32, 48, 64, 96, 128, 192: dim 16 / 32 / 48 / 64 and
+    // their doublings); K = 80, 112, 144, 160, 176 stay on the wave-level kernels (round 5: 80 instantiations nobody launched)
+    if (!wg_ks_built(K / 16)) return 0;
     if (xsb % 8 != 0 || xsk % 8 != 0) return 0;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(res)) & 15u)
         return 0;
@@ -378,13 +382,8 @@ static int wg_launch(const T *x, const float *w, const float *bias, T *y, int B,
         case 2: OSS_WG(2); break;
         case 3: OSS_WG(3); break;
         case 4: OSS_WG(4); break;
-        case 5: OSS_WG(5); break;
         case 6: OSS_WG(6); break;
-        case 7: OSS_WG(7); break;
         case 8: OSS_WG(8); break;
-        case 9: OSS_WG(9); break;
-        case 10: OSS_WG(10); break;
-        case 11: OSS_WG(11); break;
         case 12: OSS_WG(12); break;
         default: return OSS_ERR_SHAPE;
     }
