@@ -174,6 +174,12 @@ int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
  * oss_scan_last_segments: what the last call used (1 = unsegmented). */
 void oss_scan_set_segments(int fwd_segments, int bwd_segments);
 int oss_scan_last_segments(int which /* 0 fwd, 1 bwd */);
+/* (round 5) A time-segmented call runs a cheap first launch -- the forward's segment-local pass, the backward's reverse-carry
+ * pass -- whose per-segment (product, state) pairs the main launch folds.  That first launch has its own, FINER segmentation:
+ * `split` pieces per main segment (a divisor of the segment's chunk count; the largest one <= split is taken), so that it fills
+ * the CUs the main launch's segment count was chosen for.  0 = heuristic (default: up to 512 workgroups), 1 = as coarse as
+ * the main launch (rounds 2-4).  Results differ from split = 1 only in how the carries are associated (fp32 round-off). */
+void oss_scan_set_carry_split(int split);
 /* 1 when the last oss_scan_bwd call ran the kernels that load the forward pass's lane states (f.hs), else 0 */
 int oss_scan_last_lane_states(void);
 

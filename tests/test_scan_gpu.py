@@ -682,6 +682,52 @@ def test_time_segmented_scans_match_oracle(itype, seqlen, segs):
     _with_segments(segs, segs, run)
 
 
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("segs,split", [(2, 1), (2, 2), (2, 4), (3, 3), (4, 2), (2, 0), (64, 4)])
+@pytest.mark.parametrize("seqlen", [4096, 3700, 6 * 512 + 5])
+def test_carry_pass_segmentation_finer_than_the_main_launch(itype, segs, split, seqlen):
+    """(round 5) oss_scan_set_carry_split: the forward's local pass and the backward's reverse-carry pass run on `split` pieces per
+    main segment (the largest divisor of the segment's chunk count <= split), the main launch folds one pair per piece.  Lengths:
+    8 full chunks, a ragged last chunk, a last segment shorter than the others (7 chunks).  split 1 = rounds 2-4, 0 = heuristic;
+    64 segments = one chunk per segment, nothing left to split.  All outputs and the seven gradients against the oracle."""
+    def run(lib):
+        lib.oss_scan_set_carry_split(split)
+        try:
+            check_fwd_bwd(make_inputs(2, 24, 16, 2, seqlen, itype, seed=5), True, itype, fwd_variant=0, bwd_variant=13)   # 512-step chunks both ways
+            want = min(segs, (seqlen + 511) // 512)
+            assert lib.oss_scan_last_segments(0) == want and lib.oss_scan_last_segments(1) == want
+            check_fwd_bwd(make_inputs(1, 26, 16, 2, seqlen, itype, seed=6), True, itype, fwd_variant=6, bwd_variant=10)   # 1024 / 512 steps, ragged row tile
+        finally:
+            lib.oss_scan_set_carry_split(0)
+    _with_segments(segs, segs, run)
+
+
+def test_carry_split_changes_association_only():
+    """the same call with split 1 and split 4: equal to fp32 round-off (the pairs are folded in the same order, grouped
+    differently), bit-identical reruns at either setting"""
+    lib = _capi.load()
+    ins = to_dev(make_inputs(2, 48, 16, 4, 4096, torch.float32, seed=9))
+    u, dl, A, B, C, D, b, g = ins
+
+    def call(split):
+        lib.oss_scan_set_carry_split(split)
+        out, x = vmambair_amd.selective_scan_fwd(u, dl, A, B, C, D, b, True, 1)
+        grads = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1)
+        torch.cuda.synchronize()
+        return [out] + [t for t in grads if t is not None]
+    lib.oss_scan_set_segments(2, 2)
+    lib.oss_scan_set_variant(0, 13)
+    try:
+        a1, a1b, a4, a4b = call(1), call(1), call(4), call(4)
+    finally:
+        lib.oss_scan_set_segments(-1, -1)
+        lib.oss_scan_set_variant(-1, -1)
+        lib.oss_scan_set_carry_split(0)
+    for x1, x1b, x4, x4b in zip(a1, a1b, a4, a4b):
+        assert torch.equal(x1, x1b) and torch.equal(x4, x4b)
+        assert_close(x4, x1, 2e-5, 2e-5 * max(1.0, float(x1.abs().max())), "split 4 vs split 1")
+
+
 @pytest.mark.parametrize("fv,bv", [(0, 10), (3, 11), (6, 12), (4, 13), (1, 13), (2, 10)])
 def test_time_segments_on_every_kernel_variant(fv, bv):
     """forward variants differ in chunk length (256 / 512 / 1024) and rows per wave; backward: the four round-2 row-tile sizes.

@@ -73,7 +73,7 @@ SUM_CHUNK_BYTES = 40   # sizeof(oss_sum_chunk)
 
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fwd_workspace_bytes", "oss_scan_lane_state_floats", "oss_scan_bwd_workspace_bytes",
-           "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments",
+           "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments", "oss_scan_set_carry_split",
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd", "oss_dwconv3x3_flat2_ok", "oss_dwconv3x3_silu_flat2_fwd",
            "oss_dwconv3x3_silu_flat2_bwd",
@@ -123,6 +123,8 @@ def load():
     lib.oss_scan_lane_state_floats.argtypes = [C.c_int] * 4
     lib.oss_scan_set_segments.restype = None
     lib.oss_scan_set_segments.argtypes = [C.c_int, C.c_int]
+    lib.oss_scan_set_carry_split.restype = None
+    lib.oss_scan_set_carry_split.argtypes = [C.c_int]
     lib.oss_scan_last_segments.restype = C.c_int
     lib.oss_scan_last_segments.argtypes = [C.c_int]
     lib.oss_scan_bwd.restype = C.c_int

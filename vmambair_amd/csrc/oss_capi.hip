@@ -36,6 +36,19 @@ int scan_pick_segments(long wgs, int n_chunks, int seg_req, double ovh) {
     return best;
 }
 
+static std::atomic<int> g_carry_split{0};
+int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks) {
+    if (n_seg <= 1) return 1;
+    const int forced = g_carry_split.load();
+    int csub = 1;
+    for (int c = 2; c <= cps; ++c) {
+        if (cps % c) continue;
+        if ((n_chunks + cps / c - 1) / (cps / c) > kMaxSegments) break;   // one carry slot per piece (the workspace queries)
+        if (forced > 0 ? c <= forced : wgs * (n_seg - 1) * c <= 512) csub = c;
+    }
+    return csub;
+}
+
 // ---- variant heuristics -----------------------------------------------------------------------
 // The forward/backward kernels are VALU-bound, so the cheapest variant in instructions per
 // (element, state) wins as long as the launch still fills 256 CUs x 4 SIMDs with >= 2 waves.
@@ -752,6 +765,7 @@ void oss_scan_set_segments(int fwd_segments, int bwd_segments) {
     g_force_bwd_seg.store(bwd_segments);
 }
 int oss_scan_last_segments(int which) { return which == 0 ? g_last_fwd_segments.load() : g_last_bwd_segments.load(); }
+void oss_scan_set_carry_split(int split) { g_carry_split.store(split < 0 ? 0 : split); }
 int oss_scan_last_lane_states(void) { return g_last_bwd_lane_states.load(); }
 int oss_scan_features(void) { return (kBuildFusedDt ? OSS_FEATURE_FUSED_DT : 0) | (kBuildLaneStates ? OSS_FEATURE_LANE_STATES : 0); }
 

@@ -551,16 +551,8 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.3);
     int cps = n_chunks;
     if (n_seg > 1) { cps = (n_chunks + n_seg - 1) / n_seg; n_seg = (n_chunks + cps - 1) / cps; }
-    // carry segments per main segment (BwdSeg): the largest divisor of cps that keeps the carry pass within ~one workgroup per CU
-    int csub = 1;
-    if (n_seg > 1) {
-        static const int forced = [] { const char *e = std::getenv("VMAMBAIR_SCAN_CARRY_SPLIT"); return e ? std::atoi(e) : 0; }();   // A-B timing
-        for (int c = 2; c <= cps; ++c) {
-            if (cps % c) continue;
-            if ((n_chunks + cps / c - 1) / (cps / c) > kMaxSegments) break;   // one carry slot per carry segment (workspace query)
-            if (forced > 0 ? c <= forced : (long)wgs * (n_seg - 1) * c <= 512) csub = c;
-        }
-    }
+    // carry segments per main segment (BwdSeg; oss_host.h: scan_carry_split)
+    const int csub = scan_carry_split((long)wgs, n_seg, cps, n_chunks);
     const int ccps = cps / csub, n_cseg = n_seg > 1 ? (n_chunks + ccps - 1) / ccps : 0;
     BwdWs ws;
     float *wdD, *wdb, *carry = nullptr;

@@ -303,13 +303,7 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
             sg.carry = reinterpret_cast<float *>(p.workspace);
             sg.cps = (n_chunks + n_seg - 1) / n_seg;
             sg.n_seg = (n_chunks + sg.cps - 1) / sg.cps;
-            sg.csub = 1;
-            static const int forced = [] { const char *e = std::getenv("VMAMBAIR_SCAN_CARRY_SPLIT"); return e ? std::atoi(e) : 0; }();   // A-B timing
-            for (int c = 2; c <= sg.cps; ++c) {
-                if (sg.cps % c) continue;
-                if ((n_chunks + sg.cps / c - 1) / (sg.cps / c) > kMaxSegments) break;   // one carry slot per local segment
-                if (forced > 0 ? c <= forced : (long)wgs * (sg.n_seg - 1) * c <= 512) sg.csub = c;
-            }
+            sg.csub = scan_carry_split((long)wgs, sg.n_seg, sg.cps, n_chunks);
             sg.ccps = sg.cps / sg.csub;
             sg.n_cseg = (n_chunks + sg.ccps - 1) / sg.ccps;
             g_last_fwd_segments.store(sg.n_seg);
