@@ -94,8 +94,10 @@ int scan_fwd_pick_variant(int batch, int dim, int seqlen, int dstate, int n_grou
     // level 0 at batch 4: 64): the widest workgroup, cut into time segments by scan_pick_segments until the CUs are covered
     // (u:(1,384,25600) f16 0.129 ms in 9 segments against 0.354 ms for one 8-row workgroup per tile; u:(4,192,16384) bf16
     // 0.139 in 4 segments against 0.222 -- profiles/r03_segment_sweep.txt)
-    // (u:(1,768,6400) f16: 0.070 ms in 4 segments against 0.093; at 128 such workgroups -- u:(8,192,4096) -- variant 3 stays ahead)
-    if (seqlen >= 4096 && rows_per_group % 12 == 0 && (long)batch * n_groups * (rows_per_group / 12) < 128) return 6;
+    // (u:(1,768,6400) f16: 0.070 ms in 4 segments against 0.093.  At exactly 128 such workgroups -- u:(8,192,4096), u:(4,384,4096) --
+    // variant 3 stayed ahead until round 5; with the local pass cut finer than the main launch (oss_scan_set_carry_split) two
+    // segments of the 12-row form win there too: u:(4,384,4096) bf16 0.059 against 0.064 ms, profiles/r05_sweep_batch4_scan_variants_and_segments.txt)
+    if (seqlen >= 4096 && rows_per_group % 12 == 0 && (long)batch * n_groups * (rows_per_group / 12) <= 128) return 6;
     // <= one 8-row workgroup per CU and a long sequence: 16 items per lane (half the chunk hand-overs; u:(8,192,4096)
     // bf16 0.065 ms against 0.077, profiles/r01_sweep_v4_bwd_variants.txt)
     if (seqlen >= 1024 && (long)batch * n_groups * ((rows_per_group + 7) / 8) <= 256) return 3;
