@@ -566,7 +566,8 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     // lane states saved by the forward pass (f.hs): the kernels that load them instead of re-running the forward recurrence
     const bool hs = kBuildLaneStates && !FD && f.hs != nullptr;
     // two tile buffers, two slab buffers (+ dt weights | + two buffers of this wave's lane states)
-    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * ((kV2SlabQ && !FD) ? kSlabA : TC) +
+    const bool slab_q = kV2SlabQ && !FD && !(hs && WAVES > 8);   // oss_scan_bwd2_kernel: SQ
+    const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * (slab_q ? kSlabA : TC) +
                                          (FD ? WAVES * kMaxDtRank : 0) + (hs ? 2 * (size_t)WAVES * NBB * 64 : 0));
     g_last_bwd_lane_states.store(hs ? 1 : 0);
     if constexpr (!FD) {

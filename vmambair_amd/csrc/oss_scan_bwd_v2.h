@@ -168,7 +168,11 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sT = smem;                          // [2 buffers][B | C][NBB][TC]  tile_off layout
-    constexpr bool SQ = kV2SlabQ && !FD;       // the fused-delta form also parks its ddelta rows in the slab, in time order
+    // the fused-delta form also parks its ddelta rows in the slab, in time order.  (r5) So does the lane-state form of the 12-wave
+    // workgroup: 32 KB of tiles + 110.6 KB of SlabQ slabs + 24.6 KB of lane states is 167 KB, over the 160 KB of a workgroup -- since
+    // round 4's SlabQ image every `hs` call of variant 10 returned OSS_ERR_SHAPE (an opt-in build feature whose tests skip on the
+    // shipped library: nobody saw it).  The time-order slab (98.3 KB) fits.
+    constexpr bool SQ = kV2SlabQ && !FD && !(HS && WAVES > 8);
     constexpr int SA = SQ ? kSlabA : TC;       // floats per (row, dB | dC) array of the slab
     float *slab = smem + 2 * 2 * NBB * TC;     // [2][ROWS][2][SA]  per-row dB / dC terms of one state; two buffers
     float *sW = slab + 2 * ROWS * 2 * SA;      // FD: [ROWS][kMaxDtRank] dt weights of the workgroup's rows (zero-padded)
