@@ -68,6 +68,13 @@ def collection_tier(item):
     return 1
 
 
+def pytest_runtest_setup(item):
+    """``VMAMBAIR_INJECT_SELFCHECK_FAILURE=1``: every ``selfcheck`` test fails in its set-up.  Used once per round to show what a
+    broken side test costs under ``pytest -x``: nothing but the self-comparisons (profiles/r05_pytest_gpu_injected_selfcheck_failure.txt)."""
+    if os.environ.get("VMAMBAIR_INJECT_SELFCHECK_FAILURE") and item.get_closest_marker("selfcheck") is not None:
+        pytest.fail("injected failure of a selfcheck test (VMAMBAIR_INJECT_SELFCHECK_FAILURE)")
+
+
 def pytest_collection_modifyitems(session, config, items):
     def key(pair):
         i, item = pair
