@@ -194,10 +194,11 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     // it eight times (speed only -- nothing depends on where a workgroup runs).
     int bid = blockIdx.x, tile, bg;
     const int n_seg = SEG ? sg.n_seg : 1;
-    if ((f.batch * G * n_seg) % 8 == 0) {
-        const int xcd = bid & 7, s_ = bid >> 3;
-        bg = (s_ / tiles_per_group) * 8 + xcd;
-        tile = s_ % tiles_per_group;
+    const int total = f.batch * G * n_seg * tiles_per_group;   // (round 5: any workgroup count that divides by 8, see oss_scan_fwd.hip)
+    if (total % 8 == 0) {
+        const int i = (bid & 7) * (total >> 3) + (bid >> 3);
+        bg = i / tiles_per_group;
+        tile = i % tiles_per_group;
     } else {
         tile = bid % tiles_per_group;
         bg = bid / tiles_per_group;

@@ -85,10 +85,15 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
 #else
     constexpr bool kXcdOrder = true;
 #endif
-    if (kXcdOrder && (p.batch * p.n_groups * ns) % 8 == 0) {
-        const int xcd = bid & 7, s_ = bid >> 3;
-        tile = s_ % tiles_per_group;
-        bid = (s_ / tiles_per_group) * 8 + xcd;
+    // (round 5) Generalised from "the number of sets divides by 8" to "the number of WORKGROUPS divides by 8": XCD x (ids with residue x)
+    // takes the x-th eighth of the (set, tile) pairs in set-major order, so it works on whole sets except at the two ends of its
+    // run.  u:(1,384,25600) in 9 segments is 36 sets x 8 tiles: the old rule did not apply and every XCD fetched every set's B / C
+    // (FETCH 87 MB for 36 MB of inputs, profiles/r05_pmc_FETCH_SIZE_realsr.txt).
+    const int total = p.batch * p.n_groups * ns * tiles_per_group;
+    if (kXcdOrder && total % 8 == 0) {
+        const int i = (bid & 7) * (total >> 3) + (bid >> 3);
+        tile = i % tiles_per_group;
+        bid = i / tiles_per_group;
     } else {
         tile = bid % tiles_per_group; bid /= tiles_per_group;
     }
