@@ -683,12 +683,13 @@ def test_time_segmented_scans_match_oracle(itype, seqlen, segs):
 
 
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-@pytest.mark.parametrize("segs,split", [(2, 1), (2, 2), (2, 4), (3, 3), (4, 2), (2, 0), (64, 4)])
-@pytest.mark.parametrize("seqlen", [4096, 3700, 6 * 512 + 5])
+@pytest.mark.parametrize("segs,split", [(2, 1), (2, 2), (2, 3), (2, 4), (3, 2), (3, 3), (4, 2), (2, 0), (64, 4)])
+@pytest.mark.parametrize("seqlen", [4096, 3700, 6 * 512 + 5, 5120, 6600])
 def test_carry_pass_segmentation_finer_than_the_main_launch(itype, segs, split, seqlen):
     """(round 5) oss_scan_set_carry_split: the forward's local pass and the backward's reverse-carry pass run on `split` pieces per
-    main segment (the largest divisor of the segment's chunk count <= split), the main launch folds one pair per piece.  Lengths:
-    8 full chunks, a ragged last chunk, a last segment shorter than the others (7 chunks).  split 1 = rounds 2-4, 0 = heuristic;
+    main segment (pieces of ceil(chunks / split) chunks, the last one shorter), the main launch folds one pair per piece.  Lengths:
+    8 full chunks, a ragged last chunk, a last segment shorter than the others (7 chunks), 10 chunks (two segments of 5: pieces 3 + 2
+    or 2 + 2 + 1), 13 chunks (segments of 7 and 6: the short one leaves its last piece EMPTY).  split 1 = rounds 2-4, 0 = heuristic;
     64 segments = one chunk per segment, nothing left to split.  All outputs and the seven gradients against the oracle."""
     def run(lib):
         lib.oss_scan_set_carry_split(split)

@@ -3,7 +3,7 @@
 # roofline.traffic reads (keyed by oss_scan_build_id()).  OUT=<json>  [SHAPES="B,D,L dtype tag;..."]
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out; OUT=${OUT:-$O/r05_pmc_traffic.json}; rm -f $OUT
-IFS=';' read -ra LIST <<< "${SHAPES:-8,96,4096 bf16 headline;4,96,4096 bf16 batch4;4,48,16384 bf16 derain0;1,96,25600 f16 realsr}"
+IFS=';' read -ra LIST <<< "${SHAPES:-8,96,4096 bf16 headline;4,96,4096 bf16 batch4;4,48,16384 bf16 derain0;1,96,25600 f16 realsr;1,96,73984 f16 realsr256}"
 for cfg in "${LIST[@]}"; do set -- $cfg
   SHAPE=$1 DTYPE=$2 REPS=4 bash tools/pmc_traffic.sh > $O/pmc_traffic_$3.log 2>&1
   cp $O/pmc_FETCH_SIZE.txt $O/r05_pmc_FETCH_SIZE_$3.txt; cp $O/pmc_WRITE_SIZE.txt $O/r05_pmc_WRITE_SIZE_$3.txt

@@ -40,11 +40,12 @@ static std::atomic<int> g_carry_split{0};
 int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks) {
     if (n_seg <= 1) return 1;
     const int forced = g_carry_split.load();
+    const int max_slots = std::min(n_chunks, kMaxSegments);   // what the workspace queries size the carry area for
     int csub = 1;
     for (int c = 2; c <= cps; ++c) {
-        if (cps % c) continue;
-        if ((n_chunks + cps / c - 1) / (cps / c) > kMaxSegments) break;   // one carry slot per piece (the workspace queries)
-        if (forced > 0 ? c <= forced : wgs * (n_seg - 1) * c <= 512) csub = c;
+        const int ccps = (cps + c - 1) / c, pieces = (cps + ccps - 1) / ccps;   // pieces of ccps chunks, the last one shorter
+        if (n_seg * pieces > max_slots) break;
+        if (forced > 0 ? pieces <= forced : wgs * (n_seg - 1) * pieces <= 512) csub = pieces;
     }
     return csub;
 }

@@ -55,8 +55,9 @@ inline size_t scan_carry_bytes(int batch, int dim, int dstate, int n_seg) {
     return sizeof(float) * 2 * (size_t)batch * dim * dstate * n_seg;
 }
 extern std::atomic<int> g_last_fwd_segments, g_last_bwd_segments, g_last_bwd_lane_states;
-// pieces of the first (local / carry) launch per main segment: the largest divisor c of cps with c <= forced (forced > 0), or with
-// wgs * (n_seg - 1) * c <= 512 (heuristic), that keeps one carry slot per piece within kMaxSegments (oss_scan_set_carry_split)
+// pieces of the first (local / carry) launch per main segment: the largest piece count c <= forced (forced > 0), or with
+// wgs * (n_seg - 1) * c <= 512 (heuristic), whose n_seg * c carry slots fit what the workspace queries allow.  A main segment
+// of cps chunks is cut into c pieces of ceil(cps / c) chunks, the last one shorter (oss_scan_set_carry_split)
 int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks);
 template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream);
 // one timer brackets the MAIN backward kernel, a second one the finishing kernel (oss_prof_* buckets 1 and 2)

@@ -553,7 +553,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     if (n_seg > 1) { cps = (n_chunks + n_seg - 1) / n_seg; n_seg = (n_chunks + cps - 1) / cps; }
     // carry segments per main segment (BwdSeg; oss_host.h: scan_carry_split)
     const int csub = scan_carry_split((long)wgs, n_seg, cps, n_chunks);
-    const int ccps = cps / csub, n_cseg = n_seg > 1 ? (n_chunks + ccps - 1) / ccps : 0;
+    const int ccps = (cps + csub - 1) / csub, n_cseg = n_seg > 1 ? n_seg * csub : 0;
     BwdWs ws;
     float *wdD, *wdb, *carry = nullptr;
     int rc = carve_ws(p, WAVES, ws, wdD, wdb, n_seg, &carry, n_cseg);

@@ -136,8 +136,8 @@ constexpr int kSlabA = 2 * kSlabK;     // floats per (row, dB | dC) array
 struct BwdSeg {
     float *carry;   // [batch][dim][n_cseg][dstate][2]: (prod of a_{t+1} over the carry segment, dh at its first step from a zero carry)
     int n_seg, cps; // segments per row, 512-step chunks per segment
-    // (round 5) the carry pass has its own, finer segmentation: csub carry segments of ccps = cps / csub chunks per main segment,
-    // n_cseg of them per row.  A 2-segment launch at u:(4,384,4096) ran its carry pass on 128 workgroups x 4 chunks (half the
+    // (round 5) the carry pass has its own, finer segmentation: csub carry pieces of ccps = ceil(cps / csub) chunks per main segment
+    // (the last one shorter), n_cseg = n_seg * csub slots per row.  A 2-segment launch at u:(4,384,4096) ran its carry pass on 128 workgroups x 4 chunks (half the
     // CUs idle, 33 us next to the main kernel's 101); with csub = 2 it is 256 workgroups x 2 chunks, and the main kernel folds
     // two pairs instead of one.  The C rows are staged per chunk, so finer TIME segments re-stage nothing (finer ROW tiles did).
     int csub, ccps, n_cseg;
@@ -795,7 +795,10 @@ oss_scan_bwd_carry_kernel(const oss_scan_bwd_params p, const BwdSeg sg, int tile
         A2v = (f.a_log_form ? -__expf(av) : av) * kLog2e;
     }
     const int n_chunks = (L + TC - 1) / TC;
-    const int c_begin = seg * sg.ccps, c_end = min(n_chunks, c_begin + sg.ccps);
+    // carry piece `seg` = piece j of main segment s: chunks s cps + j ccps .., clipped to the main segment and to the sequence (a short
+    // last main segment may leave its last pieces empty: they keep the identity pair (1, 0))
+    const int ms_ = seg / sg.csub, mj_ = seg - ms_ * sg.csub;
+    const int c_begin = ms_ * sg.cps + mj_ * sg.ccps, c_end = min(min(c_begin + sg.ccps, (ms_ + 1) * sg.cps), n_chunks);
     float dln_c = 0.f;
     {
         const int t1 = c_end * TC;

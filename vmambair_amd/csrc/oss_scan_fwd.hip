@@ -38,7 +38,8 @@ struct FwdSeg {
     float *carry;   // [batch][dim][n_cseg][dstate][2] floats
     int n_seg, cps; // segments per row, chunks (of TC steps) per segment
     // (round 5) the local pass has its own, finer segmentation (as the backward's carry pass, oss_scan_bwd_v2.h: BwdSeg): csub local
-    // segments of ccps = cps / csub chunks per segment, n_cseg slots per row; the real pass folds seg * csub pairs
+    // pieces of ccps = ceil(cps / csub) chunks per segment (the last one shorter), n_cseg = n_seg * csub slots per row; the real pass
+    // folds seg * csub pairs
     int csub, ccps, n_cseg;
 };
 template <typename T, int LPR, int I, int WAVES, bool FD = false, int SEG = 0>
@@ -143,9 +144,17 @@ oss_scan_fwd_kernel(const oss_scan_fwd_params p, const FwdSeg sg) {
     }
 
     const int n_chunks = (L + TC - 1) / TC;
-    const int seg_chunks = SEG == 1 ? sg.ccps : sg.cps;   // SEG = 1: `seg` counts local (fine) segments
-    const int c_begin = SEG != 0 ? seg * seg_chunks : 0;
-    const int c_end = SEG != 0 ? min(n_chunks, c_begin + seg_chunks) : n_chunks;
+    // SEG = 1: `seg` counts local pieces, csub per main segment: piece j of main segment s = chunks s cps + j ccps .. (the last piece of
+    // a segment is shorter when ccps does not divide cps)
+    int c_begin = 0, c_end = n_chunks;
+    if constexpr (SEG == 1) {
+        const int s_ = seg / sg.csub, j_ = seg - s_ * sg.csub;
+        c_begin = s_ * sg.cps + j_ * sg.ccps;
+        c_end = min(min(c_begin + sg.ccps, (s_ + 1) * sg.cps), n_chunks);
+    } else if constexpr (SEG == 2) {
+        c_begin = seg * sg.cps;
+        c_end = min(n_chunks, c_begin + sg.cps);
+    }
     for (int c = c_begin; c < c_end; ++c) {
         const int t0 = c * TC;
         const int tl = t0 + pos * I;  // first time step of this lane
@@ -309,8 +318,8 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
             sg.cps = (n_chunks + n_seg - 1) / n_seg;
             sg.n_seg = (n_chunks + sg.cps - 1) / sg.cps;
             sg.csub = scan_carry_split((long)wgs, sg.n_seg, sg.cps, n_chunks);
-            sg.ccps = sg.cps / sg.csub;
-            sg.n_cseg = (n_chunks + sg.ccps - 1) / sg.ccps;
+            sg.ccps = (sg.cps + sg.csub - 1) / sg.csub;
+            sg.n_cseg = sg.n_seg * sg.csub;
             g_last_fwd_segments.store(sg.n_seg);
             auto k1 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 1>;
             auto k2 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 2>;
