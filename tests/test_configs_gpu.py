@@ -199,6 +199,32 @@ def test_mamber32_block_at_128x128_matches_cpu_twin():
         assert_close(p.grad, want[k], 5e-3, 2e-3 * max(1.0, float(want[k].abs().max())), f"grad {k}")
 
 
+def test_realsr_block_at_the_272x272_tile_matches_cpu_twin():
+    """(round 5) configs[4] with tile 256 + halo 16: one RealSR OSS block (dim 48, rank-R channel scan) on a 272 x 272 tile -- L = 73 984,
+    the forward scan in two time segments with its local pass in pieces, depth-wise kernels at W / 8 = 34 lane groups -- inference
+    forward in fp32 and under fp16 autocast against the CPU oracle twins"""
+    from conftest import install_oracle_cpu_kernel
+    from vmambair_amd import _capi
+    install_oracle_cpu_kernel()
+    torch.manual_seed(6)
+    m = MamberBlock(48, variant="realsr").eval()
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith(("body.weight", "body.bias", "Ds", "Dsc")):
+                p_.add_(0.1 * torch.randn_like(p_))
+        x = torch.randn(1, 48, 272, 272)
+        want = m(x)
+        m.to(DEV)
+        got = m(x.to(DEV))
+        assert int(_capi.load().oss_scan_last_segments(0)) > 1, "the spatial scan of a batch-1 tile is cut into time segments"
+        assert_close(got, want, 1e-3, 1e-3 * float(want.abs().max()), "fp32 block output at L = 73984")
+        with torch.autocast("cuda", dtype=torch.float16):
+            got16 = m(x.to(DEV))
+        e = rel_l2(got16, want)
+        print(f"[realsr tile 272] fp16 autocast rel-L2 {e:.2e} (limit {LIMITS[torch.float16][0]:.0e})")
+        assert e <= LIMITS[torch.float16][0], e
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # configs[1]: the whole dim-48 net, bf16 autocast against fp32 on the same HIP kernels and against the CPU twins
 # ------------------------------------------------------------------------------------------------------------------

@@ -27,7 +27,9 @@ def ref(x, w, b, dy):
                                    # last workgroup) next to widths they must leave to the 4-pixel kernels (24, 12, 4)
                                    (2, 16, 32, 32), (3, 8, 8, 8), (1, 4, 6, 128), (1, 2, 5, 512), (2, 5, 37, 16),
                                    # (round 4) rows that straddle waves: W / 8 = 20, 18, 40, 5
-                                   (1, 6, 24, 160), (2, 3, 13, 144), (1, 2, 9, 320), (2, 4, 11, 40)])
+                                   (1, 6, 24, 160), (2, 3, 13, 144), (1, 2, 9, 320), (2, 4, 11, 40),
+                                   # (round 5) the RealSR bench's 256 + 16 + 16 tiles and their first down-sampling: W / 8 = 34, 17
+                                   (1, 3, 10, 272), (1, 2, 9, 136)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_dwconv_matches_torch(dtype, shape, has_bias):
     torch.manual_seed(0)
@@ -96,7 +98,8 @@ def test_dwconv_with_fused_silu(shape, dt):
 # (round 4) widths whose W / 8 lane groups do not tile a wave -- 24 (3 groups), 160 (20: the RealSR tiles), 144 (18: their edge
 # tiles), 192 / 320 (the Deraining tree's progressive patches) -- take the EDGE instantiations: rows straddle waves
 FUSED_SHAPES = [(2, 12, 64, 64), (1, 6, 32, 32), (3, 4, 16, 16), (2, 8, 8, 8), (1, 2, 128, 128), (2, 4, 5, 512), (2, 6, 37, 16),
-                (1, 254, 16, 64), (1, 4, 16, 24), (1, 6, 160, 160), (2, 4, 144, 160), (1, 4, 9, 144), (1, 2, 48, 192), (1, 2, 7, 320)]
+                (1, 254, 16, 64), (1, 4, 16, 24), (1, 6, 160, 160), (2, 4, 144, 160), (1, 4, 9, 144), (1, 2, 48, 192), (1, 2, 7, 320),
+                (1, 2, 16, 272), (1, 2, 8, 136)]
 
 
 @pytest.mark.parametrize("shape", FUSED_SHAPES)
