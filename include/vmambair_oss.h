@@ -97,7 +97,7 @@ typedef struct {
      * (cus/selective_scan_fwd_kernel.cuh:101-102).  Ignored by oss_scan_bwd (which has its own workspace). */
     void *workspace;
     size_t workspace_bytes;
-    /* Optional lane states (round 3; OPT-IN BUILD FEATURE since round 4 -- oss_scan_features() & OSS_FEATURE_LANE_STATES; a
+    /* Optional lane states (round 3; oss_scan_features() & OSS_FEATURE_LANE_STATES -- in every library since round 6; a
      * library built without it ignores the field): oss_scan_lane_state_floats() floats, layout [batch][dim][dstate][L8] with
      * L8 = round_up(ceil(seqlen / 8), 64): entry k of a (batch, row, state) line is the state h ENTERING scan steps 8k .. 8k+7
      * (h after step 8k - 1; 0 for k = 0).  oss_scan_fwd writes them when hs != NULL (a by-product of its second pass);
@@ -106,6 +106,16 @@ typedef struct {
      * from `x`, as the reference's backward does (cus/selective_scan_bwd_kernel.cuh:184-186).  The torch layers carry the
      * buffer as a third tensor next to (out, x): selective_scan_fwd(..., want_hs) -> [out, x, hs], selective_scan_bwd(..., hs). */
     float *hs;
+    /* Per-call launch tuning (round 6; ABI 7).  0 everywhere = the library's heuristics, which is what every product caller
+     * passes (memset the struct).  These fields are the thread- and stream-safe way to force a launch shape; the process-global
+     * setters further down (oss_scan_set_variant / _segments / _carry_split) exist for the test-suite and A-B timing scripts only
+     * and are overridden by a non-zero field.
+     *   tune_variant     : v + 1 forces kernel variant v of THIS call's direction (oss_scan_fwd: forward variants 0..7; in
+     *                      oss_scan_bwd_params.f the field is ignored -- the backward's own tune_variant is used)
+     *   tune_segments    : 1 = never cut the call in time, n > 1 = n time segments per row (clamped to the chunk count)
+     *   tune_carry_split : n >= 1 = pieces per main segment of the local / reverse-carry pass (see oss_scan_set_carry_split);
+     *                      oss_scan_bwd reads it from f.tune_carry_split */
+    int tune_variant, tune_segments, tune_carry_split, reserved2_;
 } oss_scan_fwd_params;
 
 /* Mirrors SSMParamsBwd (selective_scan.h:68-90). */
@@ -139,6 +149,9 @@ typedef struct {
     void *ddt;
     float *ddt_weight;
     int64_t ddt_batch_stride, ddt_group_stride, ddt_rank_stride;
+    /* per-call launch tuning of the backward (see oss_scan_fwd_params.tune_*): v + 1 forces backward variant v (1, 10..13);
+     * 1 = never segment, n > 1 = n time segments.  0 = heuristic. */
+    int tune_variant, tune_segments;
 } oss_scan_bwd_params;
 
 /* Time steps between two saved states in `x` (the reference's is 2048,
@@ -162,7 +175,11 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
  * (shorter sequences take the small-shape kernels, which read delta). */
 int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstate, int seqlen);
 
-/* Kernel-variant override for tuning / A-B benches: -1 = heuristic (default).  Forward variants 0..7, backward variants 0..13
+/* ---- PROCESS-GLOBAL tuning overrides: test-suite / A-B timing scripts ONLY ------------------------------------------------
+ * The three setters below mutate process-wide state that every later call from every thread and stream reads; they are not a
+ * product interface.  An integrator who needs a particular launch shape sets the per-call fields
+ * oss_scan_fwd_params.tune_* / oss_scan_bwd_params.tune_* instead, which win over these.
+ * Kernel-variant override: -1 = heuristic (default).  Forward variants 0..7, backward variants 0..13
  * (tables in oss_scan_fwd.hip / oss_scan_bwd.hip; 8 and 9 = two states per pass in packed fp32, oss_scan_bwd_pair.h; 10..13 =
  * the round-2 kernel, oss_scan_bwd_v2.h).  An
  * unknown number falls back to the small-shape variant. */
@@ -175,10 +192,14 @@ int oss_scan_last_variant(int which /* 0 fwd, 1 bwd */);
 void oss_scan_set_segments(int fwd_segments, int bwd_segments);
 int oss_scan_last_segments(int which /* 0 fwd, 1 bwd */);
 /* (round 5) A time-segmented call runs a cheap first launch -- the forward's segment-local pass, the backward's reverse-carry
- * pass -- whose per-segment (product, state) pairs the main launch folds.  That first launch has its own, FINER segmentation:
- * `split` pieces per main segment (a divisor of the segment's chunk count; the largest one <= split is taken), so that it fills
- * the CUs the main launch's segment count was chosen for.  0 = heuristic (default: up to 512 workgroups), 1 = as coarse as
- * the main launch (rounds 2-4).  Results differ from split = 1 only in how the carries are associated (fp32 round-off). */
+ * pass -- whose per-segment (product, state) pairs the main launch folds.  That first launch has its own, FINER segmentation: each main
+ * segment's cps chunks are cut into pieces of ceil(cps / split) chunks (ANY split: the last piece is shorter or empty and an empty
+ * piece keeps the identity pair), one workgroup and one pair slot per piece, so that it fills the CUs the main launch's segment
+ * count was chosen for.  0 = heuristic (default: up to 512 workgroups), 1 = as coarse as the main launch (rounds 2-4).  Results
+ * differ from split = 1 only in how the carries are associated (fp32 round-off).  The pair slots live in the caller's workspace:
+ * size it with oss_scan_fwd_workspace_bytes / oss_scan_bwd_workspace_bytes (they cover min(chunks, 64) slots per row and state);
+ * a workspace that holds the main segments' slots but not the finer pieces' makes the launch fall back to split = 1, and one
+ * that does not even hold those to the unsegmented launch. */
 void oss_scan_set_carry_split(int split);
 /* 1 when the last oss_scan_bwd call ran the kernels that load the forward pass's lane states (f.hs), else 0 */
 int oss_scan_last_lane_states(void);
@@ -550,9 +571,12 @@ int oss_conv3x3_thin_wgrad(oss_dtype io, const void *x, const void *dy, float *d
                            int cout, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride,
                            int64_t dy_channel_stride, oss_stream_t stream);
 
-/* Opt-in build features of the loaded library (vmambair_amd/_build.py: VMAMBAIR_BUILD_FEATURES=fused_dt,lane_states).  Both are
- * measured losers kept in the tree for the record; the shipped library has neither: dt_weight != NULL
- * is then rejected with OSS_ERR_SHAPE, oss_scan_fused_dt_ok() and oss_scan_lane_state_floats() answer 0, `hs` is ignored. */
+/* Runtime-selected scan forms the loaded library contains.  Since round 6 every build has both (rounds 4-5 kept them behind
+ * build flags): the fused-delta form of SURVEY.md 8f row 1 (chosen per call by oss_scan_fwd_params.dt_weight != NULL) and the
+ * lane states (chosen per call by oss_scan_fwd_params.hs != NULL).  Both are parity-green against the oracle and measured
+ * slower inside the training step, so the host layers leave them off unless asked.  A build that
+ * compiled one out (-DOSS_WITHOUT_FUSED_DT / -DOSS_WITHOUT_LANE_STATES) rejects dt_weight with OSS_ERR_SHAPE, answers 0 from
+ * oss_scan_fused_dt_ok() / oss_scan_lane_state_floats() and ignores `hs`. */
 #define OSS_FEATURE_FUSED_DT 1
 #define OSS_FEATURE_LANE_STATES 2
 int oss_scan_features(void);
@@ -563,7 +587,7 @@ int oss_scan_features(void);
  * (which: 0 = oss_scan_fwd_params, 1 = oss_scan_bwd_params, 2 = oss_chan_params; 0 for anything else).  Every binding layer
  * in this tree (vmambair_amd/_capi.py, csrc_host/oss_torch_host.cpp through vmambair_amd/_host.py) compares both with its
  * own compile-time values when it loads and refuses to run on a mismatch. */
-#define OSS_ABI_VERSION 6
+#define OSS_ABI_VERSION 7
 int oss_abi_version(void);
 size_t oss_abi_struct_bytes(int which);
 

@@ -48,10 +48,9 @@ def to_dev(ts):
 
 
 def _need_feature(bit, name):
-    """opt-in build features (include/vmambair_oss.h: oss_scan_features): their tests run on a library built with
-    VMAMBAIR_BUILD_FEATURES=<name> and skip on the shipped one (VERDICT r3 next #7)"""
-    if not _capi.has_feature(bit):
-        pytest.skip(f"libvmambair_oss.so was built without the opt-in feature '{name}'")
+    """the fused-delta / lane-state scan forms are part of every library since round 6 (csrc/oss_host.h): a library without them
+    is a broken build, not a reason to skip"""
+    assert _capi.has_feature(bit), f"libvmambair_oss.so lacks the scan form '{name}' (oss_scan_features() = {_capi.load().oss_scan_features()})"
 
 
 def check_fwd_bwd(cpu_inputs, softplus, itype, fwd_variant=-1, bwd_variant=-1, tight=True):
@@ -729,6 +728,44 @@ def test_carry_split_changes_association_only():
         assert_close(x4, x1, 2e-5, 2e-5 * max(1.0, float(x1.abs().max())), "split 4 vs split 1")
 
 
+@pytest.mark.parametrize("boundary", ["c++", "ctypes"])
+def test_per_call_tuning_fields_select_the_launch_shape_without_global_state(boundary):
+    """(round 6) ``oss_scan_fwd_params.tune_*`` / ``oss_scan_bwd_params.tune_*``: variant, time segments and the
+    carry split of ONE call, with the process-global setters left at their defaults -- bit-identical to the same launch shape
+    forced through the test-only setters, on both host boundaries; and a per-call field wins over a contradicting global."""
+    from vmambair_amd import _host
+    lib = _capi.load()
+    u, dl, A, B, C, D, b, g = to_dev(make_inputs(2, 48, 16, 4, 4096, torch.float32, seed=21))
+
+    def call(tune_f=None, tune_b=None):
+        out, x = vmambair_amd.selective_scan_fwd(u, dl, A, B, C, D, b, True, 1, tune=tune_f)
+        shape_f = (lib.oss_scan_last_variant(0), lib.oss_scan_last_segments(0))
+        grads = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=tune_b)
+        shape_b = (lib.oss_scan_last_variant(1), lib.oss_scan_last_segments(1))
+        torch.cuda.synchronize()
+        return [out] + [t for t in grads if t is not None], shape_f, shape_b
+
+    _host.use(boundary)
+    try:
+        per_call, sf, sb = call((0, 2, 4), (13, 2, 4))
+        assert sf == (0, 2) and sb == (13, 2)
+        heur, hf, hb = call()                                    # nothing sticks: the next call is back on the heuristics
+        lib.oss_scan_set_segments(2, 2); lib.oss_scan_set_variant(0, 13); lib.oss_scan_set_carry_split(4)
+        via_globals, gf, gb = call()
+        assert gf == sf and gb == sb
+        # a per-call field wins over the global: 1 = never segment, variant 4 / 1
+        _, wf, wb = call((4, 1, None), (1, 1, None))
+        assert wf == (4, 1) and wb == (1, 1)
+    finally:
+        lib.oss_scan_set_segments(-1, -1); lib.oss_scan_set_variant(-1, -1); lib.oss_scan_set_carry_split(0)
+        _host.use(None)
+    assert hf != sf or hb != sb, "the heuristic picked the forced shape: the test shows nothing"
+    for a, c in zip(per_call, via_globals):
+        assert torch.equal(a, c)
+    for a, c in zip(per_call, heur):
+        assert_close(a, c, 2e-5, 2e-5 * max(1.0, float(c.abs().max())), "forced launch shape vs heuristic")
+
+
 @pytest.mark.parametrize("fv,bv", [(0, 10), (3, 11), (6, 12), (4, 13), (1, 13), (2, 10)])
 def test_time_segments_on_every_kernel_variant(fv, bv):
     """forward variants differ in chunk length (256 / 512 / 1024) and rows per wave; backward: the four round-2 row-tile sizes.
@@ -994,16 +1031,11 @@ def test_lane_states_fall_back_where_they_do_not_apply():
         vmambair_amd.selective_scan_bwd(u, delta, A, B, C, D, bias, dout, x, True, 1, hs=hs[:-64])
 
 
-def test_shipped_library_rejects_the_opt_in_forms_loudly():
-    """a library built without the opt-in features must refuse dt_weight / want_hs -- never a silent fall-back"""
+def test_shipped_library_has_both_runtime_selected_scan_forms():
+    """(round 6) delta-inside-the-scan and the lane states are compiled into the shipped library and chosen per
+    call (dt_weight / hs): the driver's run exercises them instead of skipping 110 tests"""
     lib = _capi.load()
-    u, delta, A, B, C, D, bias, dout = to_dev(make_inputs(1, 8, 16, 2, 700, torch.bfloat16))
-    if not _capi.has_feature(_capi.FEATURE_LANE_STATES):
-        assert lib.oss_scan_lane_state_floats(1, 8, 700, 16) == 0
-        with pytest.raises(RuntimeError, match="lane_states"):
-            vmambair_amd.selective_scan_fwd(u, delta, A, B, C, D, bias, True, 1, want_hs=True)
-    if not _capi.has_feature(_capi.FEATURE_FUSED_DT):
-        assert lib.oss_scan_fused_dt_ok(_capi.OSS_BF16, 8, 96, 38, 6, 16, 4096) == 0
-        W = torch.randn(8, 3, device=DEV)
-        with pytest.raises(RuntimeError, match="fused_dt"):
-            vmambair_amd.selective_scan_fwd(u, delta[:, :6].contiguous(), A, B, C, D, bias, True, 1, dt_weight=W)
+    assert lib.oss_scan_features() == (_capi.FEATURE_FUSED_DT | _capi.FEATURE_LANE_STATES)
+    assert lib.oss_scan_lane_state_floats(1, 8, 700, 16) > 0
+    assert lib.oss_scan_fused_dt_ok(_capi.OSS_BF16, 8, 96, 38, 6, 16, 4096) == 1
+    assert lib.oss_scan_fused_dt_ok(_capi.OSS_BF16, 8, 384, 56, 24, 16, 4096) == 0      # dt_rank > 8 stays on the materialised delta

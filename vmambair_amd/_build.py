@@ -21,16 +21,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 #: the files the scan kernels are compiled from: their hash is the library's oss_scan_build_id()
 SCAN_FILES = ("oss_scan_fwd.hip", "oss_scan_bwd.hip", "oss_scan_bwd_v2.h", "oss_device.h")
 
-#: opt-in instantiations (csrc/oss_host.h: kBuildFusedDt / kBuildLaneStates): VMAMBAIR_BUILD_FEATURES=fused_dt,lane_states
-FEATURE_FLAGS = {"fused_dt": "-DOSS_WITH_FUSED_DT=1", "lane_states": "-DOSS_WITH_LANE_STATES=1"}
-
-
 def feature_flags():
-    names = [n for n in os.environ.get("VMAMBAIR_BUILD_FEATURES", "").replace(" ", "").split(",") if n]
-    unknown = [n for n in names if n not in FEATURE_FLAGS]
-    if unknown:
-        raise ValueError(f"VMAMBAIR_BUILD_FEATURES: unknown feature(s) {unknown}; known: {sorted(FEATURE_FLAGS)}")
-    return [FEATURE_FLAGS[n] for n in sorted(set(names))]
+    """(rounds 4-5: VMAMBAIR_BUILD_FEATURES compiled the fused-delta / lane-state scan forms in; since round 6 every library has
+    them -- csrc/oss_host.h: kBuildFusedDt / kBuildLaneStates -- and there is ONE build)"""
+    return []
 
 
 def scan_build_id() -> str:

@@ -11,7 +11,7 @@ import os
 from . import _build
 
 OSS_F32, OSS_F16, OSS_BF16 = 0, 1, 2
-FEATURE_FUSED_DT, FEATURE_LANE_STATES = 1, 2   # oss_scan_features(): opt-in build features (VMAMBAIR_BUILD_FEATURES)
+FEATURE_FUSED_DT, FEATURE_LANE_STATES = 1, 2   # oss_scan_features(): runtime-selected scan forms (in every library since round 6)
 
 ERRORS = {
     -1: "OSS_ERR_NULL: a required pointer is NULL",
@@ -37,6 +37,8 @@ class ScanFwdParams(C.Structure):
         ("dt_weight", C.c_void_p), ("dt_rank", C.c_int), ("reserved1_", C.c_int),
         ("dt_group_stride", C.c_int64), ("dt_rank_stride", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("hs", C.c_void_p),
+        # per-call launch tuning (ABI 7): 0 = heuristic; variant + 1 / segments / carry pieces (include/vmambair_oss.h)
+        ("tune_variant", C.c_int), ("tune_segments", C.c_int), ("tune_carry_split", C.c_int), ("reserved2_", C.c_int),
     ]
 
 
@@ -53,6 +55,7 @@ class ScanBwdParams(C.Structure):
         ("dBC_group_stride", C.c_int64),
         ("ddt", C.c_void_p), ("ddt_weight", C.c_void_p),
         ("ddt_batch_stride", C.c_int64), ("ddt_group_stride", C.c_int64), ("ddt_rank_stride", C.c_int64),
+        ("tune_variant", C.c_int), ("tune_segments", C.c_int),
     ]
 
 
@@ -88,7 +91,7 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_conv3x3_thin_wgrad", "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version", "oss_scan_features", "oss_abi_version", "oss_abi_struct_bytes"]
 
 #: include/vmambair_oss.h: OSS_ABI_VERSION this binding was written against
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -291,8 +294,8 @@ def has_feature(bit: int) -> bool:
 def require_feature(bit: int, what: str) -> None:
     if not has_feature(bit):
         name = {FEATURE_FUSED_DT: "fused_dt", FEATURE_LANE_STATES: "lane_states"}[bit]
-        raise RuntimeError(f"{what}: {lib_path()} was built without the opt-in feature '{name}' "
-                           f"(rebuild with VMAMBAIR_BUILD_FEATURES={name}; DESIGN.md 4.3 / section 9 say why it is off)")
+        raise RuntimeError(f"{what}: {lib_path()} was built without the scan form '{name}' "
+                           f"(-DOSS_WITHOUT_... in csrc/oss_host.h; the shipped build has both)")
 
 
 def check(rc: int, what: str) -> None:

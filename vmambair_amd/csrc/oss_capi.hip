@@ -37,9 +37,9 @@ int scan_pick_segments(long wgs, int n_chunks, int seg_req, double ovh) {
 }
 
 static std::atomic<int> g_carry_split{0};
-int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks) {
+int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks, int per_call) {
     if (n_seg <= 1) return 1;
-    const int forced = g_carry_split.load();
+    const int forced = per_call > 0 ? per_call : g_carry_split.load();   // the call's own field wins over the test-only global
     const int max_slots = std::min(n_chunks, kMaxSegments);   // what the workspace queries size the carry area for
     int csub = 1;
     for (int c = 2; c <= cps; ++c) {
@@ -224,11 +224,12 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
     if (!p->out || !p->x) return OSS_ERR_NULL;
     if (p->batch == 0 || p->seqlen == 0) return OSS_OK;
     const int eb = io == OSS_F32 ? 4 : 2;
-    int v = g_force_fwd.load();
+    // per-call fields (oss_scan_fwd_params.tune_*) win over the process-global test overrides; 0 / -1 = heuristic
+    int v = p->tune_variant > 0 ? p->tune_variant - 1 : g_force_fwd.load();
     if (v < 0) v = scan_fwd_pick_variant(p->batch, p->dim, p->seqlen, p->dstate, p->n_groups, eb);
     g_last_fwd.store(v);
     g_last_fwd_segments.store(1);
-    const int sr = g_force_fwd_seg.load();
+    const int sr = p->tune_segments > 0 ? p->tune_segments : g_force_fwd_seg.load();
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfTimer prof(0, v, (int)io, fwd_alg_bytes(*p, eb), fwd_own_bytes(*p, eb));
     prof.begin(s);
@@ -243,8 +244,8 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
     return rc;
 }
 
-static int bwd_variant_for(int batch, int dim, int seqlen, int dstate, int n_groups) {
-    int v = g_force_bwd.load();
+static int bwd_variant_for(int batch, int dim, int seqlen, int dstate, int n_groups, int per_call = 0) {
+    int v = per_call > 0 ? per_call - 1 : g_force_bwd.load();
     if (v < 0) v = scan_bwd_pick_variant(batch, dim, seqlen, dstate, n_groups);
     return v;
 }
@@ -286,13 +287,13 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
     if (f.batch == 0 || f.seqlen == 0) return OSS_OK;
     if (!f.x && oss_scan_num_chunks(f.seqlen) > 1) return OSS_ERR_NULL;  // selective_scan.cpp:310
     if (p->dout_row_mod < 0 || (p->dout_row_mod > 0 && f.dim % p->dout_row_mod != 0)) return OSS_ERR_SHAPE;
-    const int v = bwd_variant_for(f.batch, f.dim, f.seqlen, f.dstate, f.n_groups);
+    const int v = bwd_variant_for(f.batch, f.dim, f.seqlen, f.dstate, f.n_groups, p->tune_variant);
     g_last_bwd.store(v);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int eb = io == OSS_F32 ? 4 : 2;
     ProfTimer prof(1, v, (int)io, bwd_alg_bytes(f, eb), bwd_own_bytes(*p, eb));
     ProfTimer fprof(2, v, (int)io, 0.0);   // the finishing kernel of the same call
-    const int sr = g_force_bwd_seg.load();
+    const int sr = p->tune_segments > 0 ? p->tune_segments : g_force_bwd_seg.load();
     g_last_bwd_lane_states.store(0);
     switch (io) {
         case OSS_F32: return scan_bwd_dispatch<float>(*p, v, sr, s, &prof, &fprof);

@@ -31,20 +31,20 @@ struct LdsGate {
     }
 };
 
-// Opt-in instantiations: two measured losers stay in the tree behind build flags instead of in the shipped
-// library -- delta computed inside the scans (`FD`, DESIGN.md 4.3: 177.0 against 205.9 images/s) and lane states saved by the
-// forward pass for the backward (`HS`, DESIGN.md section 9: backward -1 %, forward +7 %).  vmambair_amd/_build.py passes
-// -DOSS_WITH_FUSED_DT / -DOSS_WITH_LANE_STATES when VMAMBAIR_BUILD_FEATURES names them; oss_scan_features() reports what
-// the loaded library has, oss_scan_fused_dt_ok() / oss_scan_lane_state_floats() answer 0 without the feature.
-#ifdef OSS_WITH_FUSED_DT
-constexpr bool kBuildFusedDt = true;
-#else
+// Runtime-selected scan forms that rounds 4-5 kept behind build flags and round 6 ships in every library (an
+// opt-in build that no driver run compiles rots unseen): delta computed inside the scans (`FD`; DESIGN.md 4.3:
+// parity-green against the oracle, measured slower, chosen per call by oss_scan_fwd_params.dt_weight) and lane states saved by the
+// forward pass for the backward (`HS`, DESIGN.md section 9: chosen per call by oss_scan_fwd_params.hs).  oss_scan_features()
+// reports both bits; the constants stay so that a size-constrained build can still drop the instantiations.
+#ifdef OSS_WITHOUT_FUSED_DT
 constexpr bool kBuildFusedDt = false;
-#endif
-#ifdef OSS_WITH_LANE_STATES
-constexpr bool kBuildLaneStates = true;
 #else
+constexpr bool kBuildFusedDt = true;
+#endif
+#ifdef OSS_WITHOUT_LANE_STATES
 constexpr bool kBuildLaneStates = false;
+#else
+constexpr bool kBuildLaneStates = true;
 #endif
 
 // Time-segmented launches (oss_scan_fwd.hip: FwdSeg, oss_scan_bwd_v2.h: BwdSeg).  seg_req: -1 = heuristic, 0 / 1 = never,
@@ -58,7 +58,7 @@ extern std::atomic<int> g_last_fwd_segments, g_last_bwd_segments, g_last_bwd_lan
 // pieces of the first (local / carry) launch per main segment: the largest piece count c <= forced (forced > 0), or with
 // wgs * (n_seg - 1) * c <= 512 (heuristic), whose n_seg * c carry slots fit what the workspace queries allow.  A main segment
 // of cps chunks is cut into c pieces of ceil(cps / c) chunks, the last one shorter (oss_scan_set_carry_split)
-int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks);
+int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks, int per_call = 0);
 template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream);
 // one timer brackets the MAIN backward kernel, a second one the finishing kernel (oss_prof_* buckets 1 and 2)
 struct LaunchTimer {

@@ -552,11 +552,15 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     int cps = n_chunks;
     if (n_seg > 1) { cps = (n_chunks + n_seg - 1) / n_seg; n_seg = (n_chunks + cps - 1) / cps; }
     // carry segments per main segment (BwdSeg; oss_host.h: scan_carry_split)
-    const int csub = scan_carry_split((long)wgs, n_seg, cps, n_chunks);
-    const int ccps = (cps + csub - 1) / csub, n_cseg = n_seg > 1 ? n_seg * csub : 0;
+    int csub = scan_carry_split((long)wgs, n_seg, cps, n_chunks, f.tune_carry_split);
+    int ccps = (cps + csub - 1) / csub, n_cseg = n_seg > 1 ? n_seg * csub : 0;
     BwdWs ws;
     float *wdD, *wdb, *carry = nullptr;
     int rc = carve_ws(p, WAVES, ws, wdD, wdb, n_seg, &carry, n_cseg);
+    if (rc != OSS_OK && n_seg > 1 && csub > 1) {   // room for the main segments' carry pairs but not the finer pieces' 
+        csub = 1; ccps = cps; n_cseg = n_seg;
+        rc = carve_ws(p, WAVES, ws, wdD, wdb, n_seg, &carry, n_cseg);
+    }
     if (rc != OSS_OK && n_seg > 1) {   // a caller that sized the workspace for the unsegmented form
         n_seg = 1; cps = n_chunks;
         rc = carve_ws(p, WAVES, ws, wdD, wdb);

@@ -308,8 +308,9 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
     const unsigned wgs = (unsigned)(p.batch * p.n_groups * tiles);
     const int n_chunks = (p.seqlen + TC - 1) / TC;
     int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.55);
-    // (the carry slots are per LOCAL segment, at most one per chunk: sized for that)
-    if (n_seg > 1 && (!p.workspace || p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, std::min(n_chunks, kMaxSegments)))) n_seg = 1;
+    // the carry slots are per LOCAL-pass piece.  A caller's workspace that holds the main segments' slots but not the finer
+    // pieces' keeps the segments and drops the finer split; only one that does not hold even those goes unsegmented
+    if (n_seg > 1 && !p.workspace) n_seg = 1;
     g_last_fwd_segments.store(1);
     if constexpr (!FD) {
         if (n_seg > 1) {
@@ -317,9 +318,12 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
             sg.carry = reinterpret_cast<float *>(p.workspace);
             sg.cps = (n_chunks + n_seg - 1) / n_seg;
             sg.n_seg = (n_chunks + sg.cps - 1) / sg.cps;
-            sg.csub = scan_carry_split((long)wgs, sg.n_seg, sg.cps, n_chunks);
+            sg.csub = scan_carry_split((long)wgs, sg.n_seg, sg.cps, n_chunks, p.tune_carry_split);
+            if (p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, sg.n_seg * sg.csub)) sg.csub = 1;
             sg.ccps = (sg.cps + sg.csub - 1) / sg.csub;
             sg.n_cseg = sg.n_seg * sg.csub;
+            if (p.workspace_bytes < scan_carry_bytes(p.batch, p.dim, p.dstate, sg.n_cseg)) sg.n_seg = 1;
+          if (sg.n_seg > 1) {
             g_last_fwd_segments.store(sg.n_seg);
             auto k1 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 1>;
             auto k2 = oss_scan_fwd_kernel<T, LPR, I, WAVES, false, 2>;
@@ -329,6 +333,7 @@ static int launch_fwd(const oss_scan_fwd_params &p, int seg_req, hipStream_t str
             hipLaunchKernelGGL(k1, dim3(wgs * (unsigned)((sg.n_seg - 1) * sg.csub)), dim3(WAVES * 64), smem, stream, p, sg);
             hipLaunchKernelGGL(k2, dim3(wgs * (unsigned)sg.n_seg), dim3(WAVES * 64), smem, stream, p, sg);
             return (int)hipGetLastError();
+          }
         }
     }
     auto kern = oss_scan_fwd_kernel<T, LPR, I, WAVES, FD, 0>;

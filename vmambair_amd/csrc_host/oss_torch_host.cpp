@@ -156,7 +156,8 @@ void fill_fwd(oss_scan_fwd_params &P, const Tensor &u, const Tensor &delta, cons
 // want_hs: also return the lane states (include/vmambair_oss.h: hs) as a third tensor, for scan_bwd's `hs` argument
 std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor &A, const Tensor &B, const Tensor &C,
                              const OptTensor &D, const OptTensor &delta_bias, bool delta_softplus, int64_t rev_group_start,
-                             int64_t u_row_mod, bool a_log_form, const OptTensor &dt_weight, bool want_hs) {
+                             int64_t u_row_mod, bool a_log_form, const OptTensor &dt_weight, bool want_hs, int64_t tune_variant,
+                             int64_t tune_segments, int64_t tune_carry_split) {
     const Dims d = common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight);
     const at::hip::OptionalHIPGuardMasqueradingAsCUDA guard(u.device());
     const int n_chunks = oss_scan_num_chunks((int)d.seqlen);
@@ -171,7 +172,7 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
     Tensor x = at::empty({d.batch, d.dim, (int64_t)n_chunks, 2 * d.dstate}, u.options().dtype(at::kFloat));
     OptTensor hs;
     TORCH_CHECK(!want_hs || (oss_scan_features() & OSS_FEATURE_LANE_STATES),
-                "want_hs: libvmambair_oss.so was built without the opt-in feature 'lane_states' (VMAMBAIR_BUILD_FEATURES)");
+                "want_hs: libvmambair_oss.so was built without the lane-state scan form (-DOSS_WITHOUT_LANE_STATES)");
     if (want_hs)
         hs = at::empty({(int64_t)oss_scan_lane_state_floats((int)d.batch, (int)d.dim, (int)d.seqlen, (int)d.dstate)},
                        u.options().dtype(at::kFloat));
@@ -181,6 +182,8 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
     }
     oss_scan_fwd_params P;
     fill_fwd(P, u, delta, A, B, C, D, delta_bias, &out, x, d, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight, hs);
+    // per-call launch tuning (0 = heuristic; include/vmambair_oss.h: oss_scan_fwd_params.tune_*)
+    P.tune_variant = (int)tune_variant; P.tune_segments = (int)tune_segments; P.tune_carry_split = (int)tune_carry_split;
     Tensor ws;   // scratch of the time-segmented launch (under-filled grids); a few hundred KB
     const size_t ws_bytes = oss_scan_fwd_workspace_bytes((int)d.batch, (int)d.dim, (int)d.seqlen, (int)d.dstate, (int)d.n_groups);
     if (ws_bytes) {
@@ -201,7 +204,8 @@ std::vector<Tensor> scan_fwd(const Tensor &u, const Tensor &delta, const Tensor 
 std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor &A, const Tensor &B, const Tensor &C,
                              const OptTensor &D, const OptTensor &delta_bias, const Tensor &dout, const OptTensor &x,
                              bool delta_softplus, int64_t rev_group_start, int64_t u_row_mod, int64_t dout_row_mod, bool a_log_form,
-                             const OptTensor &dbc_into, const OptTensor &dt_weight, const OptTensor &hs) {
+                             const OptTensor &dbc_into, const OptTensor &dt_weight, const OptTensor &hs, int64_t tune_variant,
+                             int64_t tune_segments, int64_t tune_carry_split) {
     const Dims d = common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight);
     TORCH_CHECK(dout.scalar_type() == u.scalar_type() && dout.is_cuda(), "dout must be a CUDA/HIP tensor of u's dtype");
     TORCH_CHECK(dout.dim() == 3 && dout.size(0) == d.batch && dout.size(1) == (dout_row_mod ? dout_row_mod : d.dim) &&
@@ -280,6 +284,7 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
     P.workspace = ws.data_ptr(); P.workspace_bytes = (size_t)ws.numel() * 4;
     P.dout_row_mod = (int)dout_row_mod;
     P.dBC_group_stride = into ? dbc_into->stride(1) : 0;
+    P.tune_variant = (int)tune_variant; P.tune_segments = (int)tune_segments; P.f.tune_carry_split = (int)tune_carry_split;
     hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     abi_check_once();
     check_rc(oss_scan_bwd(&P, io_of(u), reinterpret_cast<oss_stream_t>(stream)), "oss_scan_bwd");
@@ -298,10 +303,11 @@ extern "C" size_t vmambair_host_struct_bytes(int which) {
 
 TORCH_LIBRARY(vmambair_host, m) {
     m.def("scan_fwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, bool delta_softplus, "
-          "int rev_group_start, int u_row_mod, bool a_log_form, Tensor? dt_weight, bool want_hs) -> Tensor[]");
+          "int rev_group_start, int u_row_mod, bool a_log_form, Tensor? dt_weight, bool want_hs, int tune_variant=0, "
+          "int tune_segments=0, int tune_carry_split=0) -> Tensor[]");
     m.def("scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, Tensor dout, Tensor? x, "
           "bool delta_softplus, int rev_group_start, int u_row_mod, int dout_row_mod, bool a_log_form, Tensor(a!)? dbc_into, "
-          "Tensor? dt_weight, Tensor? hs) -> Tensor[]");
+          "Tensor? dt_weight, Tensor? hs, int tune_variant=0, int tune_segments=0, int tune_carry_split=0) -> Tensor[]");
 }
 
 TORCH_LIBRARY_IMPL(vmambair_host, CUDA, m) {

@@ -102,15 +102,25 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
     P.hs = _ptr(hs) if (hs is not None and hs.numel()) else None
 
 
+def _tune_fields(tune):
+    """``(variant, segments, carry_split)`` with None = heuristic -> the C struct's encoding (0 = heuristic, variant + 1)"""
+    if tune is None:
+        return 0, 0, 0
+    v, s, c = (tuple(tune) + (None, None, None))[:3]
+    return (0 if v is None or v < 0 else int(v) + 1), (0 if s is None or s < 0 else max(1, int(s))), (0 if c is None or c <= 0 else int(c))
+
+
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                        D: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor], delta_softplus: bool,
                        nrows: int = 1, rev_group_start: Optional[int] = None, u_row_mod: int = 0,
                        a_log_form: bool = False, dt_weight: Optional[torch.Tensor] = None,
-                       want_hs: bool = False) -> List[torch.Tensor]:
+                       want_hs: bool = False, tune: Optional[tuple] = None) -> List[torch.Tensor]:
     """``selective_scan_cuda_core.fwd`` (cus/selective_scan.cpp:157-239) -> ``[out, x]``.
     ``rev_group_start`` / ``u_row_mod``: omni-scan direction handling; ``dt_weight``: ``delta`` is the rank-R factor and the
     kernels evaluate delta themselves -- see include/vmambair_oss.h.  ``want_hs``: -> ``[out, x, hs]`` with the lane states
-    (the state entering every 8-step block) for ``selective_scan_bwd(..., hs=hs)``."""
+    (the state entering every 8-step block) for ``selective_scan_bwd(..., hs=hs)``.  ``tune``: per-call launch shape
+    ``(variant or None, segments or None, carry_split or None)`` -> ``oss_scan_fwd_params.tune_*`` (None = heuristic)."""
+    tv, ts, tc = _tune_fields(tune)
     if want_hs:
         _capi.require_feature(_capi.FEATURE_LANE_STATES, "selective_scan_fwd(want_hs=True)")
     if dt_weight is not None:
@@ -119,7 +129,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     if host is not None and u.is_cuda:   # compiled boundary (csrc_host/oss_torch_host.cpp): same checks, same C ABI
         return list(host.scan_fwd(u, delta, A, B, C, D, delta_bias, bool(delta_softplus),
                                   -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), bool(a_log_form), dt_weight,
-                                  bool(want_hs)))
+                                  bool(want_hs), tv, ts, tc))
     dims = _common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight)
     batch, dim, seqlen, dstate, _ = dims
     lib = _capi.load()
@@ -137,6 +147,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
         return [out, x] + ([hs] if want_hs else [])
     P = _capi.ScanFwdParams()
     _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus, rev_group_start, u_row_mod, a_log_form, dt_weight, hs)
+    P.tune_variant, P.tune_segments, P.tune_carry_split = tv, ts, tc
     # scratch for the time-segmented launch (under-filled grids: batch-1 tiles, few-row levels); a few hundred KB
     ws_bytes = int(lib.oss_scan_fwd_workspace_bytes(batch, dim, seqlen, dstate, dims[4]))
     if ws_bytes:
@@ -155,17 +166,18 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
                        dout_row_mod: int = 0, a_log_form: bool = False,
                        dbc_into: Optional[torch.Tensor] = None,
                        dt_weight: Optional[torch.Tensor] = None,
-                       hs: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+                       hs: Optional[torch.Tensor] = None, tune: Optional[tuple] = None) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``.
     With ``dt_weight`` (delta computed inside the scan; needs ``dbc_into``): ``ddelta`` is ``None``, the gradient of the rank
     factor lands in the first R rows of ``dbc_into`` and an eighth entry, the (dim, R) gradient of ``dt_weight``, is returned."""
+    tv, ts, tc = _tune_fields(tune)
     host = _host.ops()
     if host is not None and u.is_cuda:   # compiled boundary: [du, ddelta, dA, dB, dC, dD, dbias, ddt_weight], empty = absent
         r = host.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, bool(delta_softplus),
                           -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), int(dout_row_mod), bool(a_log_form),
-                          dbc_into, dt_weight, hs)
+                          dbc_into, dt_weight, hs, tv, ts, tc)
         du, ddelta, dA, dB, dC, dD, dbias, ddtw = r
         if dbc_into is not None:   # written in place (a mutated argument is not returned): the views are made here
             rows, N = dbc_into.shape[2], A.shape[1]
@@ -228,6 +240,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     P.dout_row_mod = int(dout_row_mod)
     P.dBC_group_stride = 0 if dbc_into is None else dbc_into.stride(1)
+    P.tune_variant, P.tune_segments, P.f.tune_carry_split = tv, ts, tc
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
