@@ -34,13 +34,19 @@ def _pin_vendor_state():
     """Every box starts as the driver's does (VERDICT r4 #1c): no vendor solver search, deterministic vendor algorithms, and
     an empty per-session MIOpen user database so that a find-db left behind by an earlier bench run on the same box cannot
     change which 3x3-convolution solver the tests see."""
+    import atexit
+    import shutil
     import tempfile
     torch.backends.cudnn.benchmark = False
+    # kept session-wide on purpose (ADVICE r5 asked to scope it to the selfcheck tests): the G8 whole-net fixtures compare with the
+    # reference at 5e-4 through the vendor's 3x3 convolutions of the skeleton, and the driver's box must see the solver every
+    # builder box saw.  bench.py and the product run with the vendor's own selection (and its solver search, --miopen-find).
     torch.backends.cudnn.deterministic = True
     if "MIOPEN_USER_DB_PATH" not in os.environ:
         d = tempfile.mkdtemp(prefix="miopen-tests-")
         os.environ["MIOPEN_USER_DB_PATH"] = d
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", d)
+        atexit.register(shutil.rmtree, d, ignore_errors=True)   # the per-session database does not outlive the session
 
 
 # ---- collection order ---------------------------------------------------------------------------------------------------

@@ -20,9 +20,13 @@ from vmambair_amd import ops
 pytestmark = [pytest.mark.gpu, pytest.mark.selfcheck]
 DEV = "cuda:0"
 
-# flat-vector / per-tensor limits.  fp32: summation order only (measured 1e-6 .. 1e-5 of the largest gradient; a structural
-# error is >= 0.3).  bf16 autocast: every activation is rounded to 8 bits of mantissa at different points on the two sides.
-LIMITS = {None: dict(flat_tol=1e-3, tensor_tol=5e-2), torch.bfloat16: dict(flat_tol=5e-2, tensor_tol=2.5e-1, cos_big=0.97, cos_small=0.5)}
+# flat-vector / per-tensor limits (near the measured noise, not thousands of times above it).  fp32: summation order
+# only -- measured flat 4.5e-7, worst tensor 4.2e-6 on three boxes (profiles/r05_pytest_gpu_final.txt); limits 1e-4 / 1e-3 leave
+# ~200x for another box's vendor 3x3-convolution solver and still catch a gradient tensor off by 0.1 % or a dropped finishing
+# chunk (an O(1) error of one tensor).  bf16 autocast: every activation is rounded to 8 bits of mantissa at different points on the
+# two sides -- measured flat 3.9e-3, worst tensor 5.4e-2; limits 2e-2 / 2e-1 (5x / 4x).
+LIMITS = {None: dict(flat_tol=1e-4, tensor_tol=1e-3, cos_big=0.9999, cos_small=0.9),
+          torch.bfloat16: dict(flat_tol=2e-2, tensor_tol=2e-1, cos_big=0.98, cos_small=0.6)}
 
 
 @pytest.mark.parametrize("mode", ["one_graph", "two_graphs", "two_branches"])
@@ -79,9 +83,20 @@ def test_graphed_train_step_matches_eager(mode, acdt):
     assert losses_g[2] < losses_g[0]
     # a stale input, a lost branch or a skipped optimizer launch gives cosine <= ~0.7; sign flips of rounding-sized gradients
     # (exactly-zero-in-theory ones like conv_cout.bias, and in bf16 the small channel-branch gradients) cost a few percent
-    assert first_cos >= (0.98 if lo else 0.85), first_cos
+    assert first_cos >= (0.995 if lo else 0.85), first_cos
+    tot = bad = 0
     for (k, p), q in zip(net_g.named_parameters(), net_e.parameters()):
-        assert float((p - q).abs().max()) <= 2 * lr * 4 + 1e-5, k      # Adam: each side moves a weight by at most ~lr per step
+        d = (p - q).abs()
+        assert float(d.max()) <= 2 * lr * 4 + 1e-5, k      # Adam: each side moves a weight by at most ~lr per step
+        tot += d.numel()
+        bad += int((d > lr + 1e-3 * q.abs()).sum())
+    print(f"[train step {mode} {'fp32' if lo else 'bf16'}] {bad} of {tot} weights differ by more than one Adam step after 3 steps")
+    if lo:
+        #  per-element bound for fp32: the two sides add the weight-gradient partials in different fixed orders, so only a
+        # gradient that is ~0 may flip its sign and move its weight by lr the other way -- a handful of elements, not 1 %.  A gradient
+        # tensor scaled wrongly by a few percent leaves the SIGN pattern alone but shows up in the three-step loss and in
+        # gradients_agree of the two tests below; a partly dropped finishing chunk zeroes a block of elements and shows up here.
+        assert bad <= 0.01 * tot, f"{bad} of {tot} weights differ by more than one Adam step"
 
 
 @pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])

@@ -59,7 +59,6 @@ WGRAD_KEEP_BUDGET = int(float(os.environ.get("VMAMBAIR_WGRAD_KEEP_MB", "8192")) 
 _WGRAD_OPERANDS: Optional[list] = None
 _WGRAD_STORAGES: Optional[set] = None
 _WGRAD_HELD = 0            # bytes of distinct storages held for recorded products since the last grouped launch
-_WGRAD_SEEN = 0            # the library's count of recorded products at the last ``_keep_operands`` call
 _WGRAD_FLUSHER = None
 WGRAD_STATS = {"held_bytes_max": 0, "budget_flushes": 0}   # since the last ``deferred_finishes`` entry (bench.py, tests)
 
@@ -71,12 +70,11 @@ def deferred_finishes(wgrads: Optional[bool] = None, wgrad_flusher=None):
     still open) before any weight gradient is read.  ``wgrad_flusher``: a callable that runs ``flush_wgrads`` on a table of the
     caller's; it is called in the middle of the backward whenever the operands held for recorded products pass
     ``WGRAD_KEEP_BUDGET`` (without one the budget is not enforced)."""
-    global _DEFER_KEEP, _DEFER_OUTS, _WGRAD_OPERANDS, _WGRAD_STORAGES, _WGRAD_HELD, _WGRAD_FLUSHER, _WGRAD_SEEN
+    global _DEFER_KEEP, _DEFER_OUTS, _WGRAD_OPERANDS, _WGRAD_STORAGES, _WGRAD_HELD, _WGRAD_FLUSHER
     lib = _capi.load()
     assert _DEFER_KEEP is None, "deferred_finishes() does not nest"
     _DEFER_KEEP, _DEFER_OUTS = [], []
     _WGRAD_OPERANDS, _WGRAD_STORAGES, _WGRAD_HELD, _WGRAD_FLUSHER = [], set(), 0, wgrad_flusher
-    _WGRAD_SEEN = int(lib.oss_deferred_wgrads())
     WGRAD_STATS.update(held_bytes_max=0, budget_flushes=0)
     lib.oss_set_defer_finish(1)
     lib.oss_set_defer_wgrad(1 if (DEFER_WGRADS if wgrads is None else wgrads) else 0)
@@ -88,19 +86,26 @@ def deferred_finishes(wgrads: Optional[bool] = None, wgrad_flusher=None):
         _DEFER_KEEP = _DEFER_OUTS = _WGRAD_OPERANDS = _WGRAD_STORAGES = _WGRAD_FLUSHER = None
 
 
-def _keep_operands(*tensors) -> None:
+def _recorded_before() -> int:
+    """the library's count of recorded weight-gradient products, read IMMEDIATELY BEFORE a recording entry point is called; hand
+    the value to ``_keep_operands`` right after the call.  (the decision "did THIS call record its product" is local to
+    the call -- it no longer depends on a Python-side counter staying in step with the library's across unrelated calls, direct
+    ``oss_flush_wgrads`` / ``oss_set_defer_wgrad`` calls or other threads' bookkeeping.)"""
+    if _WGRAD_OPERANDS is None:
+        return 0
+    return int(_capi.load().oss_deferred_wgrads())
+
+
+def _keep_operands(before: int, *tensors) -> None:
     """operands of a RECORDED (not yet launched) weight-gradient product: alive until ``flush_wgrads`` has queued the launch.
-    Called right after the library's weight-gradient entry point; holds nothing when that call launched its product at once
-    (fp32 I/O, the tile modes, recording switched off) -- the library's count of recorded products did not grow then (ADVICE r4:
-    the fp32 step pinned its operands until the 8 GiB budget and reported budget flushes that flushed nothing)."""
-    global _WGRAD_HELD, _WGRAD_SEEN
+    ``before`` = ``_recorded_before()`` taken right before the library's weight-gradient entry point; holds nothing when that
+    call launched its product at once (fp32 I/O, the tile modes, recording switched off) -- the library's count did not grow then
+    (the fp32 step pinned its operands until the 8 GiB budget and reported budget flushes that flushed nothing)."""
+    global _WGRAD_HELD
     if _WGRAD_OPERANDS is None:
         return
-    n = int(_capi.load().oss_deferred_wgrads())
-    if n <= _WGRAD_SEEN:
-        _WGRAD_SEEN = n
+    if int(_capi.load().oss_deferred_wgrads()) <= before:
         return
-    _WGRAD_SEEN = n
     for t in tensors:
         if t is None:
             continue
@@ -116,8 +121,7 @@ def _keep_operands(*tensors) -> None:
 
 
 def _release_operands() -> None:
-    global _WGRAD_HELD, _WGRAD_SEEN
-    _WGRAD_SEEN = 0           # flush_wgrads emptied the library's record
+    global _WGRAD_HELD
     if _WGRAD_OPERANDS is not None:
         _WGRAD_OPERANDS.clear()
         _WGRAD_STORAGES.clear()

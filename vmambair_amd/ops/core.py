@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from .. import _capi
-from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_operands, _keep_views, _planes, _ptr)  # noqa: F401
+from ._common import (_DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_operands, _keep_views, _recorded_before, _planes, _ptr)  # noqa: F401
 from . import scan as _scan
 from .scan import merge4, selective_scan_bwd, selective_scan_fwd
 
@@ -146,11 +146,12 @@ def proj_wgrad(x2: torch.Tensor, xdbl: torch.Tensor, dxdbl: torch.Tensor, ddts: 
             dwx = torch.empty((4, Cc, D), dtype=torch.float32, device=dev)
             dwdt = torch.empty((4, D, R), dtype=torch.float32, device=dev) if ddts is not None else None
             part = torch.empty((max(1, lib.oss_proj_wgrad_partial_floats(B, D, Cc, R, L)),), dtype=torch.float32, device=dev)
+            rec0 = _recorded_before()
             _capi.check(lib.oss_proj_wgrad(_DT[x2.dtype], x2.data_ptr(), xdbl.data_ptr(), dxdbl.data_ptr(), _ptr(ddts),
                                            dwx.data_ptr(), _ptr(dwdt), part.data_ptr(), B, D, Cc, R, L,
                                            torch.cuda.current_stream().cuda_stream), "oss_proj_wgrad")
             _keep(part, dwx, dwdt)
-            _keep_operands(x2, xdbl, dxdbl, ddts)
+            _keep_operands(rec0, x2, xdbl, dxdbl, ddts)
     return [dwx, dwdt]
 
 

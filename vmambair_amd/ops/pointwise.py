@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from .. import _capi
-from ._common import (_keep_operands,
+from ._common import (_keep_operands, _recorded_before,
                       _DT, _LIB, _check, _f32c, _fork_for_wgrad, _keep, _keep_views, _planes, _ptr)  # noqa: F401
 
 
@@ -65,11 +65,12 @@ def conv1x1_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, has_bia
             # 100 launches of a vendor reduction per fp32 step)
             db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if has_bias else None
             part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), dtype=torch.float32, device=x.device)
+            rec0 = _recorded_before()
             _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
                                               Cout, Cin, P, dy.stride(0), dy.stride(1), x.stride(0), x.stride(1),
                                               torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
             _keep(part, dw, db)
-            _keep_operands(dy, x)
+            _keep_operands(rec0, dy, x)
         if f32 and CONV1X1_F32_WGRAD_ONLY:
             dx = torch.nn.functional.conv_transpose2d(dy, weight.detach().float())
         else:
@@ -232,11 +233,12 @@ def ln_conv1x1_bwd(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: Optional[t
             dw = torch.empty((Cout, Cin), **f)
             db = torch.empty((Cout,), **f) if has_bias else None
             part = torch.empty(int(lib.oss_conv1x1_wgrad_partial_floats(B, Cout, Cin, P)), **f)
+            rec0 = _recorded_before()
             _capi.check(lib.oss_conv1x1_wgrad(_DT[x.dtype], dyp.data_ptr(), n.data_ptr(), dw.data_ptr(), _ptr(db), part.data_ptr(), B,
                                               Cout, Cin, P, dyp.stride(0), dyp.stride(1), n.stride(0), n.stride(1),
                                               torch.cuda.current_stream().cuda_stream), "oss_conv1x1_wgrad")
             _keep(part, dw, db)
-            _keep_operands(dyp, n)
+            _keep_operands(rec0, dyp, n)
         dlw = torch.empty((Cin,), **f)
         dlb = torch.empty((Cin,), **f) if ln_bias is not None else None
         lpart = torch.empty(int(lib.oss_conv1x1_dgrad_ln_bwd_partial_floats(B, Cin, P)), **f)
