@@ -113,7 +113,8 @@ def make_eager(model, net, ema, derain, acdt):
 
 def bench_realsr_tiled(args):
     """BASELINE.json configs[4]: RealSR inference 512x512 -> 2048x2048, tiled (RealESRGANer rule: tile 128 + halo 16), fp16, one
-    hipGraph per padded-tile shape.  One "step" = one image.  Single GPU.  pre_pad 0: the 3-level UNet needs every window to
+    hipGraph per padded-tile shape.  One "step" = one image.  Single GPU.  Also timed: tile 256 + halo 16 and the reference's
+    default tile = 0 (untiled), each with its own scan roofline.  pre_pad 0: the 3-level UNet needs every window to
     be a multiple of 8 pixels (PixelUnshuffle), and 512 + the script's default pre-pad of 10 leaves a 10-pixel last column
     of cells -- the reference net raises on it just the same."""
     if not torch.cuda.is_available():
@@ -131,18 +132,23 @@ def bench_realsr_tiled(args):
     # (round 5) tile 256: the reference's tile size is a free argument (RealSR/VmambaIR/utils.py:33, default 0 = the whole image in one
     # forward); 512 x 512 in tiles of 256 + halo 16 is FOUR tiles of ONE padded shape (272 x 272) = one stacked forward per image
     # instead of four (13 % halo pixels instead of 41 %), and closer to the untiled result the reference computes by default
+    # (round 6) the reference's DEFAULT is tile = 0 (RealSR/VmambaIR/utils.py:32): the whole 512 x 512 image in ONE forward, L = 262 144
+    # per scan row -- two more legs; and the headline VALUE stays on the baseline tiling of BASELINE.json configs[4] / rounds 2-4
+    # (tile 128 + halo 16) so that it is comparable round over round; the other tilings are labelled lines of their own
     for name, graph, bt, conc, tile in (("eager", False, 1, False, 128), ("graph", True, 1, False, 128), ("graph_4_tiles_stacked", True, 4, False, 128),
                                         ("graph_4_tiles_stacked_shapes_side_by_side", True, 4, True, 128),
-                                        ("tile256_eager", False, 1, False, 256), ("tile256_graph_4_tiles_stacked", True, 4, False, 256)):
+                                        ("tile256_eager", False, 1, False, 256), ("tile256_graph_4_tiles_stacked", True, 4, False, 256),
+                                        ("untiled_eager", False, 1, False, 0), ("untiled_graph", True, 1, False, 0)):
         drv = RealSREnhancer(net, 4, tile=tile, tile_pad=16, pre_pad=0, half=True, use_graph=graph, batch_tiles=bt, concurrent_shapes=conc)
+        runs = (lambda d=drv: d.tiled.tiles_run) if tile else (lambda d=drv: d.whole.calls)
         out = drv.enhance_tensor(img)   # capture / warm-up
         for _ in range(max(0, args.warmup - 1)):
             drv.enhance_tensor(img)
         torch.cuda.synchronize()
-        n0 = drv.tiled.tiles_run
+        n0 = runs()
         if graph:
             lib.oss_prof_reset()
-        mark = graph and (bt == 1 or tile == 256)   # kernel-trace markers (tools/prof_summary.py reads the LAST marked leg: tile 256)
+        mark = graph and (bt == 1 or tile == 256)   # kernel-trace markers (tools/prof_summary.py reads the LAST marked leg)
         if mark:
             lib.oss_prof_marker(1, torch.cuda.current_stream().cuda_stream)
         t0 = time.perf_counter()
@@ -152,47 +158,68 @@ def bench_realsr_tiled(args):
         dt = (time.perf_counter() - t0) / args.steps
         if mark:
             lib.oss_prof_marker(2, torch.cuda.current_stream().cuda_stream)
-        tiles = (drv.tiled.tiles_run - n0) // args.steps
+        tiles = (runs() - n0) // args.steps
         assert tuple(out.shape) == (1, 3, 2048, 2048) and torch.isfinite(out.float()).all()
         if not graph:
-            ref = out.float().clone()   # the eager run of the same tiling (the two tilings are different approximations of the image)
+            ref = out.float().clone()   # the eager run of the same tiling (the tilings are different approximations of the image)
         res[name] = {"s_per_image": round(dt, 4), "images_per_s": round(1.0 / dt, 3), "tiles_per_s": round(tiles / dt, 2),
-                     "tiles_per_image": tiles, "graphs": drv.tiled.n_graphs, "tiles_per_forward": bt, "shapes_side_by_side": conc,
-                     "tile": tile, "tile_pad": 16, "max_abs_diff_vs_eager": float((out.float() - ref).abs().max())}
-    # roofline of the dominant scan kernel: the same tiles once more, eager, with the library's events on
-    # (the tiling of the fastest leg: 272 x 272 tiles, one at a time -> u:(1,384,73984) calls, the shape of the PMC record)
-    drv = RealSREnhancer(net, 4, tile=256, tile_pad=16, pre_pad=0, half=True, use_graph=False)
-    lib.oss_prof_reset()
-    lib.oss_prof_enable(1)
-    drv.enhance_tensor(img)
-    torch.cuda.synchronize()
-    lib.oss_prof_enable(0)
-    recs = collect_prof(lib)
-    roof = None
-    if recs:
+                     "tiles_per_image": tiles, "graphs": drv.tiled.n_graphs if tile else drv.whole.n_graphs, "tiles_per_forward": bt,
+                     "shapes_side_by_side": conc, "tile": tile, "tile_pad": 16 if tile else 0,
+                     "max_abs_diff_vs_eager": float((out.float() - ref).abs().max())}
+        del drv
+        torch.cuda.empty_cache()
+
+    def scan_roofline(tile, shape):
+        """roofline of the dominant scan kernel of one tiling: the same tiles once more, eager, one at a time, with the library's events on"""
+        drv = RealSREnhancer(net, 4, tile=tile, tile_pad=16, pre_pad=0, half=True, use_graph=False)
+        lib.oss_prof_reset()
+        lib.oss_prof_enable(1)
+        drv.enhance_tensor(img)
+        torch.cuda.synchronize()
+        lib.oss_prof_enable(0)
+        recs = collect_prof(lib)
+        if not recs:
+            return None
         dom = max(recs, key=lambda r: r["total_ms"])
         ach = dom["alg_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
         kkey = f"{dom['kernel']} variant {dom['variant']} io {dom['io']}" + (" segmented" if dom["segmented"] else "")
-        traffic, traffic_note, _ = pmc_lookup(lib, kkey, "u:(1,96,73984)")
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                "traffic": traffic, "traffic_note": traffic_note, "kernel": kkey,
+        traffic, traffic_note, _ = pmc_lookup(lib, kkey, shape)
+        per = round(dom["alg_bytes"] / dom["launches"])
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "traffic": traffic, "traffic_note": traffic_note, "traffic_over_algorithmic": None if not traffic else round(traffic / per, 2),
+                "kernel": kkey, "call_shape": shape + " x 4 directions f16, omni form", "tile": tile,
                 "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "launches": dom["launches"],
-                "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"]),
+                "alg_bytes_per_launch": per,
                 "segments": {"fwd_last_call": int(lib.oss_scan_last_segments(0))},
                 "all_scan_kernels": [{"kernel": r["kernel"], "variant": r["variant"], "segmented": r["segmented"], "io": r["io"],
                                       "launches": r["launches"], "avg_ms": round(r["total_ms"] / r["launches"], 4),
                                       "alg_GBps": round(r["alg_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in recs],
                 "scan_ms_per_image": round(sum(r["total_ms"] for r in recs), 3),
-                "measured": "HIP events around every scan launch of one eager pass over the same tiles"}
-    g = max(res.values(), key=lambda r: r["images_per_s"])
+                "measured": "HIP events around every scan launch of one eager pass over the same tiles, one tile at a time"}
+
+    # padded tile of the baseline tiling: 128 + 2 x 16 = 160 x 160 interior tiles; tile 256: 272 x 272; untiled: 512 x 512
+    roof = scan_roofline(128, "u:(1,96,25600)")
+    roof256 = scan_roofline(256, "u:(1,96,73984)")
+    roof0 = scan_roofline(0, "u:(1,96,262144)")
+    base = {k: v for k, v in res.items() if v["tile"] == 128}
+    g = max(base.values(), key=lambda r: r["images_per_s"])
+    best256 = max((v for v in res.values() if v["tile"] == 256), key=lambda r: r["images_per_s"])
+    best0 = max((v for v in res.values() if v["tile"] == 0), key=lambda r: r["images_per_s"])
+    other = {"tile_256_plus_halo_16": {"images_per_s": best256["images_per_s"], "s_per_image": best256["s_per_image"],
+                                       "note": "four tiles of ONE padded shape (272 x 272) = one stacked forward per image; a different approximation "
+                                               "of the image than tile 128 (the channel branch pools per tile)", "roofline": roof256},
+             "untiled_tile_0_reference_default": {"images_per_s": best0["images_per_s"], "s_per_image": best0["s_per_image"],
+                                                   "note": "RealESRGANer's default tile = 0 (utils.py:32): the whole image in one forward, L = 262144",
+                                                   "roofline": roof0}}
     print(json.dumps({
         "metric": "images/sec, x4 real-world SR inference 512x512 -> 2048x2048, tiled, fp16", "value": g["images_per_s"],
         "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(g["s_per_image"] * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[4]: MambaRealSR11 [6,2,2,1]+6 dim48, fp16 autocast (scan arithmetic f32), "
-                               f"no_grad, 512x512 LQ, RealESRGANer rule tile {g['tile']} + halo 16, pre_pad 0 (the fastest leg; every leg is in this block)",
+                               "no_grad, 512x512 LQ, RealESRGANer rule tile 128 + halo 16, pre_pad 0 (`value` = the fastest leg of THIS tiling, "
+                               "the one rounds 2-4 and BASELINE.md quote; tile 256 and the untiled default are in `other_tilings`)",
                    "tiles_per_image": g["tiles_per_image"], "tiles_per_s": g["tiles_per_s"], "hipgraphs": g["graphs"],
-                   "tiles_per_forward": g["tiles_per_forward"], **res},
+                   "tiles_per_forward": g["tiles_per_forward"], "other_tilings": other, **res},
         "roofline": roof, "cpu_baseline": None}), flush=True)
 
 
@@ -369,7 +396,15 @@ def secondary_workloads():
     import subprocess
     me = os.path.abspath(__file__)
     out = {}
-    for name, extra in (("deraining", ["--config", "deraining", "--steps", "5", "--warmup", "2"]),
+    # (round 6, VERDICT r5 next #3a / #6) also: the headline net at the REFERENCE's own precision (it never autocasts, SURVEY.md
+    # App. C) and two later stages of the Deraining tree's progressive schedule (patch 256 x batch 2, patch 384 x batch 1:
+    # Deraining_mamber33.yml:27-30) with their time-segmented scan rooflines.  No vendor solver search on the added legs (start-up).
+    for name, extra in (("fp32", ["--config", "sr", "--dtype", "fp32", "--steps", "5", "--warmup", "2", "--miopen-find", "0"]),
+                        ("deraining", ["--config", "deraining", "--steps", "5", "--warmup", "2"]),
+                        ("deraining_256", ["--config", "deraining", "--patch", "256", "--batch-per-gpu", "2", "--steps", "3", "--warmup", "1",
+                                           "--miopen-find", "0"]),
+                        ("deraining_384", ["--config", "deraining", "--patch", "384", "--batch-per-gpu", "1", "--steps", "3", "--warmup", "1",
+                                           "--miopen-find", "0"]),
                         ("realsr_tiled", ["--config", "realsr-tiled", "--steps", "2", "--warmup", "1"])):
         t0 = time.time()
         try:
@@ -386,6 +421,7 @@ def secondary_workloads():
             if name == "realsr_tiled":
                 out[name]["tiles_per_s"] = j["config"].get("tiles_per_s")
                 out[name]["tiles_per_forward"] = j["config"].get("tiles_per_forward")
+                out[name]["other_tilings"] = j["config"].get("other_tilings")
         except Exception as e:   # noqa: BLE001
             out[name] = {"error": str(e)[:200]}
     return out
@@ -426,6 +462,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="default 8 (sr) / 4 (deraining)")
+    ap.add_argument("--patch", type=int, default=128,
+                    help="--config deraining: patch size of the progressive schedule (Deraining_mamber33.yml:27-30: gt_sizes "
+                         "[128,160,192,256,320,384] with mini_batch_sizes [8,5,3,2,1,1] per GPU); default 128 = BASELINE.json configs[3]")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed GLOBAL batch split over the ranks (BASELINE.json configs[2]: 32 -> 32/16/8/4 per GPU); scaling = strong")
     ap.add_argument("--config", choices=["sr", "deraining", "realsr-tiled", "srgan-split64"], default="sr")
@@ -514,8 +553,8 @@ def main():
             raise SystemExit(f"--global-batch: {e}")
     g = torch.Generator(device=dev).manual_seed(1000 + rank)  # per-rank shard of the synthetic batch
     if derain:
-        lq = torch.rand(B, 3, 128, 128, device=dev, generator=g)
-        gt = torch.rand(B, 3, 128, 128, device=dev, generator=g)
+        lq = torch.rand(B, 3, args.patch, args.patch, device=dev, generator=g)
+        gt = torch.rand(B, 3, args.patch, args.patch, device=dev, generator=g)
     else:
         lq = torch.rand(B, 3, 64, 64, device=dev, generator=g)
         gt = torch.rand(B, 3, 256, 256, device=dev, generator=g)
@@ -633,7 +672,7 @@ def main():
             fdom = fin.get((dom["variant"], dom["io"], dom["segmented"])) if dom["kernel"] == "oss_scan_bwd_kernel" else None
             with_fin_ms = dom["total_ms"] + (fdom["total_ms"] if fdom else 0.0)
             # the dominant call of the workload: SS2D_1 of the widest full-resolution level, D = d_inner rows per direction
-            call_shape = f"u:({B},48,16384)" if derain else f"u:({B},96,4096)"
+            call_shape = f"u:({B},48,{args.patch * args.patch})" if derain else f"u:({B},96,4096)"
             traffic, traffic_note, valu_busy = pmc_lookup(lib, kkey, call_shape)
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -698,14 +737,15 @@ def main():
 
         images = world * B * args.steps
         line = {
-            "metric": ("images/sec, deraining 128x128 training step (fwd+bwd+clip+AdamW), Mamber32 [3,5,7,9]+2" if derain else
+            "metric": (f"images/sec, deraining {args.patch}x{args.patch} training step (fwd+bwd+clip+AdamW), Mamber32 [3,5,7,9]+2" if derain else
                        "images/sec, x4 SR 64->256 training step (fwd+bwd+Adam+EMA), full VmambaIR UNet"),
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[3]: Deraining 128x128 patches, Mamber32 dim48 [3,5,7,9]+2, {args.dtype} "
-                                    f"autocast (scan arithmetic f32), batch {B} per GPU" if derain else
+            "config": {"workload": ((("BASELINE.json configs[3]: Deraining 128x128 patches" if args.patch == 128 else
+                                      f"Deraining progressive schedule stage (Deraining_mamber33.yml:27-30): {args.patch}x{args.patch} patches") +
+                                     f", Mamber32 dim48 [3,5,7,9]+2, {args.dtype} autocast (scan arithmetic f32), batch {B} per GPU") if derain else
                                     (f"BASELINE.json configs[2]: x4 SR 64x64 LQ, global batch {args.global_batch} over {world} GPU(s), "
                                      if args.global_batch else "BASELINE.json configs[1]: x4 SR 64x64 LQ, ") +
                                     f"MambaSISR6 dim48 [15,1,1,1]+15, {args.dtype} autocast (scan arithmetic f32), batch {B} per GPU"),

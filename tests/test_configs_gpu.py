@@ -117,11 +117,14 @@ def test_block_16bit_autocast_within_stated_tolerance(tag, dt, record_property):
 # ------------------------------------------------------------------------------------------------------------------
 # configs[3]: sequence lengths of the Deraining workload
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,itype", [(16384, torch.float32), (16384, torch.bfloat16), (147456, torch.float32)],
-                         ids=["L16384-f32", "L16384-bf16", "L147456-f32"])
+@pytest.mark.parametrize("L,itype", [(16384, torch.float32), (16384, torch.bfloat16), (147456, torch.float32), (65536, torch.bfloat16),
+                                     (262144, torch.float16)],
+                         ids=["L16384-f32", "L16384-bf16", "L147456-f32", "L65536-bf16", "L262144-f16"])
 def test_scan_at_deraining_lengths(L, itype):
-    """u (1, 192, L), B/C (1, 4, 16, L): encoder level 1 of Mamber32 at 128x128 and at the 384x384 patches the
-    progressive schedule ends on; every output and gradient against the oracle (the reference test's tolerances)"""
+    """u (1, 192, L), B/C (1, 4, 16, L): encoder level 1 of Mamber32 at 128x128, at the 256x256 stage and at the 384x384 patches the
+    progressive schedule ends on (Deraining_mamber33.yml:27-30); (round 6) L = 262 144 in fp16: the scan rows of the RealSR net on an
+    UNTILED 512 x 512 image, the reference's default tile = 0 (RealSR/VmambaIR/utils.py:32).  Every output and gradient against the
+    oracle (the reference test's tolerances)"""
     from test_scan_gpu import check_fwd_bwd, make_inputs
     check_fwd_bwd(make_inputs(1, 192, 16, 4, L, itype, seed=3, delta_scale=0.5), True, itype)
 
@@ -169,9 +172,11 @@ def test_scan_long_sequence_properties():
     assert int(_capi.load().oss_scan_bwd_workspace_bytes(Bsz, KD, L, N, G)) < (2 << 30)
 
 
-def test_mamber32_block_at_128x128_matches_cpu_twin():
-    """one Deraining OSS block (dim 48, additive channel gate) on a 128x128 patch, forward + all gradients, HIP vs the
-    CPU oracle twins of every op (oracle/cpu_twins.py)"""
+@pytest.mark.parametrize("hw", [128, 384])
+def test_mamber32_block_at_128x128_matches_cpu_twin(hw):
+    """one Deraining OSS block (dim 48, additive channel gate) on a 128x128 patch -- and (round 6) on the 384x384 patch the
+    progressive schedule ends on (L = 147 456: time-segmented scans both ways, the depth-wise kernels' separate forms) --
+    forward + all gradients, HIP vs the CPU oracle twins of every op (oracle/cpu_twins.py)"""
     from conftest import install_oracle_cpu_kernel
     install_oracle_cpu_kernel()
     torch.manual_seed(4)
@@ -180,8 +185,8 @@ def test_mamber32_block_at_128x128_matches_cpu_twin():
         for n_, p_ in m.named_parameters():
             if n_.endswith(("body.weight", "body.bias", "Ds", "Dsc")):
                 p_.add_(0.1 * torch.randn_like(p_))
-    x = torch.randn(1, 48, 128, 128)
-    dy = torch.randn(1, 48, 128, 128)
+    x = torch.randn(1, 48, hw, hw)
+    dy = torch.randn(1, 48, hw, hw)
     xc = x.clone().requires_grad_()
     yc = m(xc)
     yc.backward(dy)
@@ -191,7 +196,7 @@ def test_mamber32_block_at_128x128_matches_cpu_twin():
     xg = x.to(DEV).requires_grad_()
     yg = m(xg)
     yg.backward(dy.to(DEV))
-    assert_close(yg, yc, 1e-3, 1e-3 * float(yc.abs().max()), "block output at L = 16384")
+    assert_close(yg, yc, 1e-3, 1e-3 * float(yc.abs().max()), f"block output at L = {hw * hw}")
     assert_close(xg.grad, xc.grad, 3e-3, 3e-3 * float(xc.grad.abs().max()), "input grad")
     for k, p in m.named_parameters():
         if k.endswith("conv_cout.bias"):
@@ -199,10 +204,12 @@ def test_mamber32_block_at_128x128_matches_cpu_twin():
         assert_close(p.grad, want[k], 5e-3, 2e-3 * max(1.0, float(want[k].abs().max())), f"grad {k}")
 
 
-def test_realsr_block_at_the_272x272_tile_matches_cpu_twin():
+@pytest.mark.parametrize("hw", [272, 512])
+def test_realsr_block_at_the_272x272_tile_matches_cpu_twin(hw):
     """(round 5) configs[4] with tile 256 + halo 16: one RealSR OSS block (dim 48, rank-R channel scan) on a 272 x 272 tile -- L = 73 984,
     the forward scan in two time segments with its local pass in pieces, depth-wise kernels at W / 8 = 34 lane groups -- inference
-    forward in fp32 and under fp16 autocast against the CPU oracle twins"""
+    forward in fp32 and under fp16 autocast against the CPU oracle twins; (round 6) 512 x 512: the reference's default tile = 0
+    (RealSR/VmambaIR/utils.py:32) gives the first level of the net the WHOLE image, L = 262 144"""
     from conftest import install_oracle_cpu_kernel
     install_oracle_cpu_kernel()
     torch.manual_seed(6)
@@ -211,15 +218,15 @@ def test_realsr_block_at_the_272x272_tile_matches_cpu_twin():
         for n_, p_ in m.named_parameters():
             if n_.endswith(("body.weight", "body.bias", "Ds", "Dsc")):
                 p_.add_(0.1 * torch.randn_like(p_))
-        x = torch.randn(1, 48, 272, 272)
+        x = torch.randn(1, 48, hw, hw)
         want = m(x)
         m.to(DEV)
         got = m(x.to(DEV))
-        assert_close(got, want, 1e-3, 1e-3 * float(want.abs().max()), "fp32 block output at L = 73984")
+        assert_close(got, want, 1e-3, 1e-3 * float(want.abs().max()), f"fp32 block output at L = {hw * hw}")
         with torch.autocast("cuda", dtype=torch.float16):
             got16 = m(x.to(DEV))
         e = rel_l2(got16, want)
-        print(f"[realsr tile 272] fp16 autocast rel-L2 {e:.2e} (limit {LIMITS[torch.float16][0]:.0e})")
+        print(f"[realsr tile {hw}] fp16 autocast rel-L2 {e:.2e} (limit {LIMITS[torch.float16][0]:.0e})")
         assert e <= LIMITS[torch.float16][0], e
 
 

@@ -151,8 +151,12 @@ def test_fused_conv_silu_writes_into_a_half_buffer_and_reruns_bit_exact():
     assert torch.equal(buf[:, :C], dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-@pytest.mark.parametrize("shape", FUSED_SHAPES)
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+# float planes: only the shapes whose TWO (H + 2) x W float planes fit a workgroup's LDS (the separate kernels take the others)
+_GATE_CASES = [pytest.param(sh, dt, id=f"{name}-{'x'.join(map(str, sh))}") for dt, name in ((torch.bfloat16, "bf16"), (torch.float16, "f16"), (torch.float32, "f32"))
+               for sh in FUSED_SHAPES if not (dt == torch.float32 and (sh[2] + 2) * sh[3] * 4 * 2 > 159 * 1024)]
+
+
+@pytest.mark.parametrize("shape,dt", _GATE_CASES)
 @pytest.mark.parametrize("has_bias", [False, True])
 def test_fused_conv_gelu_gate(shape, dt, has_bias):
     """x1, x2 = dwconv(t).chunk(2); gelu(x1) * x2 (FeedForward.forward, MambaSISR6_arch.py:213-217) as one node: against plain
@@ -160,8 +164,6 @@ def test_fused_conv_gelu_gate(shape, dt, has_bias):
     torch.manual_seed(13)
     B, C2, H, W = shape
     Hd = C2 // 2
-    if dt == torch.float32 and (H + 2) * W * 4 * 2 > 159 * 1024:
-        pytest.skip("two float planes of this size do not fit the LDS of a workgroup: the separate kernels take it")
     assert ops.dwconv.fused_ok(torch.empty(shape, dtype=dt, device=DEV), 2)
     t = torch.randn(shape).to(dt)
     w, b = torch.randn(C2, 1, 3, 3) * 0.3, (torch.randn(C2) * 0.1 if has_bias else None)

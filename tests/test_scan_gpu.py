@@ -358,13 +358,15 @@ def test_full_size_properties(itype):
 # ------------------------------------------------------------------------------------------------
 # omni form: mirrored directions and shared u rows inside the kernels
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seqlen", [64, 100, 513, 1024, 2085])
+# forced backward variants: the shortest ragged and the longest length only (the grid is built, not pruned by skips)
+_OMNI_CASES = [pytest.param(seqlen, bv, id=f"{name}-{seqlen}") for bv, name in ((-1, "auto"), (10, "v2_12"), (11, "v2_8"))
+               for seqlen in ((64, 100, 513, 1024, 2085) if bv < 0 else (100, 2085))]
+
+
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("rows", [8, 48])
-@pytest.mark.parametrize("bv", [-1, 10, 11], ids=["auto", "v2_12", "v2_8"])
+@pytest.mark.parametrize("seqlen,bv", _OMNI_CASES)
 def test_omni_scan_matches_materialised_directions(seqlen, itype, rows, bv):
-    if bv >= 0 and seqlen not in (100, 2085):
-        pytest.skip("forced backward variants: shortest ragged and longest lengths only")
     lib = _capi.load()
     lib.oss_scan_set_variant(-1, bv)
     try:
@@ -664,13 +666,15 @@ def _with_segments(fs, bs, fn):
         lib.oss_scan_set_variant(-1, -1)
 
 
-@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+# 16-bit types: 2, 3 and the maximum segment count; float also 5
+_SEG_CASES = [pytest.param(it, sg, id=f"{name}-{sg}") for it, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16"), (torch.float16, "f16"))
+              for sg in ((2, 3, 5, 64) if it == torch.float32 else (2, 3, 64))]
+
+
 @pytest.mark.parametrize("seqlen", [1024, 2048 + 37, 4096 + 3, 5000])
-@pytest.mark.parametrize("segs", [2, 3, 5, 64])
+@pytest.mark.parametrize("itype,segs", _SEG_CASES)
 def test_time_segmented_scans_match_oracle(itype, seqlen, segs):
     """every segment count (64 = one chunk per segment) at full, ragged and non-multiple-of-4 lengths, all seven gradients"""
-    if itype != torch.float32 and segs == 5:
-        pytest.skip("16-bit types: 2, 3 and max segments")
 
     def run(lib):
         # forward variant 0 / backward variant 13: 512-step chunks both ways, so that every length here has >= 2 chunks
@@ -950,16 +954,20 @@ def _fwd_bwd_with_lane_states(cpu_inputs, softplus, fv=-1, bv=-1, segs=(-1, -1),
     return out, x, hs, g_hs, g_re, used
 
 
-@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
-@pytest.mark.parametrize("seqlen", [300, 1024, 2085, 4096 + 3])
-@pytest.mark.parametrize("fv,bv", [(-1, -1), (0, 10), (3, 11), (6, 12), (1, 10), (2, 11), (4, 13)])
+# heuristic variants: every type and length; forced variants: f32 / bf16 at the ragged lengths
+_HS_CASES = [pytest.param(it, L, fv, bv, id=f"{name}-{L}-f{fv}b{bv}")
+             for fv, bv in ((-1, -1), (0, 10), (3, 11), (6, 12), (1, 10), (2, 11), (4, 13))
+             for it, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16"), (torch.float16, "f16"))
+             for L in (300, 1024, 2085, 4096 + 3)
+             if (fv, bv) == (-1, -1) or (it != torch.float16 and L != 1024)]
+
+
+@pytest.mark.parametrize("itype,seqlen,fv,bv", _HS_CASES)
 def test_backward_from_saved_lane_states_matches_oracle(itype, seqlen, fv, bv):
     """every forward variant writes the lane states (chunk lengths 256 / 512 / 1024, 4 / 8 / 16 steps per lane, several rows per
     wave), every round-2 backward variant reads them: all seven gradients against the oracle at the reference's tolerances, and
     against the recomputing kernels to fp32 round-off"""
     _need_feature(_capi.FEATURE_LANE_STATES, "lane_states")
-    if (fv, bv) != (-1, -1) and (itype == torch.float16 or seqlen == 1024):
-        pytest.skip("forced variants: f32 / bf16 at the ragged lengths")
     cpu = make_inputs(2, 26, 16, 2, seqlen, itype)
     out, x, hs, g_hs, g_re, used = _fwd_bwd_with_lane_states(cpu, True, fv, bv)
     u, delta, A, B, C, D, bias, dout = cpu

@@ -377,7 +377,8 @@ struct FinishArgs {
 // last z-slab runs the weight-gradient sums (grid-stride).  V = 4: every lane adds four consecutive time steps with 16-byte
 // loads of the partial rows (a wave's 4-byte loads move 256 bytes per instruction -- the V = 1 form spent its time issuing
 // loads, 0.033 ms for 134 MB at u:(8,384,4096)); needs L % 4 == 0 and 8-byte aligned outputs, else V = 1.
-template <typename T, int V>
+// PB: the partial rows are bf16 (oss_scan_bwd_v2.h: kPartialsBf16 -- the round-2 kernels at bf16 I/O), same element layout
+template <typename T, int V, bool PB = false>
 __global__ void __launch_bounds__(256)
 oss_scan_bwd_finish(const FinishArgs a) {
     const size_t n_bg = (size_t)a.batch * a.G;
@@ -392,7 +393,8 @@ oss_scan_bwd_finish(const FinishArgs a) {
     if (t >= a.L) return;
     const size_t row = blockIdx.y, bg = blockIdx.z;
     const size_t pt = (2 * (size_t)a.N + a.RP) * a.L;   // partial floats per (b, g, tile)
-    const float *base = a.ws_bc + bg * a.tiles * pt + row * a.L + t;
+    using PT = typename std::conditional<PB, bf16_t, float>::type;
+    const PT *base = reinterpret_cast<const PT *>(a.ws_bc) + bg * a.tiles * pt + row * a.L + t;
     T *dst;
     if (row < (size_t)a.N) dst = reinterpret_cast<T *>(a.dB) + bg * a.out_group_stride + row * a.L + t;
     else if (row < 2 * (size_t)a.N) dst = reinterpret_cast<T *>(a.dC) + bg * a.out_group_stride + (row - a.N) * a.L + t;
@@ -404,10 +406,23 @@ oss_scan_bwd_finish(const FinishArgs a) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < a.tiles; k0 += 8) {   // eight 16-byte loads in flight, added in tile order
             f32x4 v8[8];
+            if constexpr (PB) {
+                u32x2 r8[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int kk = min(k0 + k, a.tiles - 1);   // clamped address, masked below: the loads stay one group
-                v8[k] = *reinterpret_cast<const f32x4 *>(base + (size_t)kk * pt);
+                for (int k = 0; k < 8; ++k) r8[k] = *reinterpret_cast<const u32x2 *>(base + (size_t)min(k0 + k, a.tiles - 1) * pt);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float q0, q1, q2, q3;
+                    unpack2<bf16_t>(r8[k].x, q0, q1);
+                    unpack2<bf16_t>(r8[k].y, q2, q3);
+                    v8[k] = f32x4{q0, q1, q2, q3};
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int kk = min(k0 + k, a.tiles - 1);   // clamped address, masked below: the loads stay one group
+                    v8[k] = *reinterpret_cast<const f32x4 *>(base + (size_t)kk * pt);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -423,7 +438,7 @@ oss_scan_bwd_finish(const FinishArgs a) {
         for (int k0 = 0; k0 < a.tiles; k0 += 8) {   // eight loads in flight, added in tile order (same sum as a rolled loop)
             float v8[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v8[k] = (k0 + k < a.tiles) ? base[(size_t)(k0 + k) * pt] : 0.f;
+            for (int k = 0; k < 8; ++k) v8[k] = (k0 + k < a.tiles) ? to_f32(base[(size_t)(k0 + k) * pt]) : 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v8[k];
         }
@@ -465,7 +480,7 @@ static int carve_ws(const oss_scan_bwd_params &p, int rows_per_wg, BwdWs &ws, fl
     return OSS_OK;
 }
 
-template <typename T>
+template <typename T, bool PB = false>
 static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *wdD, float *wdb, hipStream_t stream, int n_seg = 1) {
     const oss_scan_fwd_params &f = p.f;
     FinishArgs a;
@@ -490,8 +505,8 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
     const int V = vec ? 4 : 1;
     const dim3 grid((unsigned)((f.seqlen + 256 * V - 1) / (256 * V)), (unsigned)(2 * f.dstate + a.R), (unsigned)(f.batch * f.n_groups + 1));
     if (g_finish_timer) g_finish_timer->begin(stream);
-    if (vec) hipLaunchKernelGGL((oss_scan_bwd_finish<T, 4>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((oss_scan_bwd_finish<T, 1>), grid, dim3(256), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((oss_scan_bwd_finish<T, 4, PB>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((oss_scan_bwd_finish<T, 1, PB>), grid, dim3(256), 0, stream, a);
     if (g_finish_timer) g_finish_timer->end(stream);
     return (int)hipGetLastError();
 }
@@ -605,7 +620,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
             if (timer) timer->end(stream);
             rc = (int)hipGetLastError();
             if (rc != OSS_OK) return rc;
-            return launch_finish<T>(p, ws, wdD, wdb, stream, n_seg);
+            return launch_finish<T, kPartialsBf16<T, false>>(p, ws, wdD, wdb, stream, n_seg);
         }
         if constexpr (kBuildLaneStates) {
             if (hs) {
@@ -613,7 +628,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
                 rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, false, true>, smem, gate_h, wgs, WAVES * 64, p, ws,
                                  stream, timer, BwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
                 if (rc != OSS_OK) return rc;
-                return launch_finish<T>(p, ws, wdD, wdb, stream);
+                return launch_finish<T, kPartialsBf16<T, false>>(p, ws, wdD, wdb, stream);
             }
         }
     }
@@ -621,7 +636,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false, false>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
                      BwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
     if (rc != OSS_OK) return rc;
-    return launch_finish<T>(p, ws, wdD, wdb, stream);
+    return launch_finish<T, kPartialsBf16<T, FD>>(p, ws, wdD, wdb, stream);
 }
 
 // variant table (numbers kept from rounds 1-3; 0 and 2..9 -- the other round-1 row tiles and the packed two-states-per-pass

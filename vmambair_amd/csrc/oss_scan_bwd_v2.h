@@ -118,6 +118,19 @@ constexpr bool kV2EdgeLanes = false;
 #else
 constexpr bool kV2EdgeLanes = true;
 #endif
+// round 6: the workgroup's dB / dC row-tile partials -- written here, re-read by oss_scan_bwd_finish -- were
+// 268 of the call's 417 MB of HBM traffic at u:(8,384,4096) bf16 (algorithmic: 142).  With bf16 I/O the final dB / dC are rounded
+// to bf16 anyway, so the partials (each already the fp32 sum of the tile's <= 12 rows) go out as bf16: half the partial bytes both
+// ways.  What changes numerically: <= 8 tile partials are rounded to 8 bits of mantissa BEFORE their fp32 sum is rounded once more
+// -- an extra relative error of at most 2^-9 per partial on a result that carries 2^-9 itself; the reference's tolerance for
+// bf16 gradients is rtol 3e-2 / atol 5e-2 (test_selective_scan.py:400,490-502).  fp16 I/O keeps fp32 partials (10 bits of
+// mantissa to protect, a 65504 range to overflow), so does fp32 I/O and the fused-delta form.  OSS_EXP_V2_F32_PARTIALS: A-B.
+#ifdef OSS_EXP_V2_F32_PARTIALS
+constexpr bool kV2Bf16Partials = false;
+#else
+constexpr bool kV2Bf16Partials = true;
+#endif
+template <typename T, bool FD> constexpr bool kPartialsBf16 = kV2Bf16Partials && !FD && std::is_same<T, bf16_t>::value;
 // SlabQ: one row's dB (or dC) terms of one state, 512 scan positions = 64 lanes x 2 quads.  The round-2 image was time order
 // (lane p wrote its quads at floats 8p and 8p + 4: a 32-byte lane stride, so a 16-lane phase of a ds_write_b128 covered only
 // half of the 64 banks, two-way conflicts on every slab write -- SQ_LDS_BANK_CONFLICT 31 % of the LDS cycles,
@@ -228,8 +241,10 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     const float bias = f.delta_bias ? f.delta_bias[d] : 0.f;
     const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
     const float *x_row = f.x ? f.x + ((size_t)b * f.dim + d) * n_xchunks * 2 * N : nullptr;
-    float *ws_bc = ws.bc + ((size_t)(b * G + g) * tiles_per_group + tile) * (2 * N + ws.rp) * L;
-    const bool ws_vec = (L % 4) == 0;   // 16-byte stores of the partial rows
+    constexpr bool PB = kPartialsBf16<T, FD>;                 // partial rows as bf16 (same element layout, half the bytes)
+    using PT = typename std::conditional<PB, bf16_t, float>::type;
+    PT *ws_bc = reinterpret_cast<PT *>(ws.bc) + ((size_t)(b * G + g) * tiles_per_group + tile) * (2 * N + ws.rp) * L;
+    const bool ws_vec = (L % 4) == 0;   // 16-byte (bf16 partials: 8-byte) stores of the partial rows
 
     // ---- tile staging, split in two: global -> registers (issue), registers -> LDS (commit)
     constexpr uintptr_t amask = (sizeof(T) == 4) ? 15u : 7u;
@@ -420,7 +435,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
         // lane-dependent parts of the slab-sum addresses: a half wave = 32 groups of 4 scan positions x one half of the rows
         const int sl = SPLIT ? (lane & 31) : lane;
         const float *sum_src = slab + (SQ ? (sl & 1) * kSlabK + 4 * (sl >> 1) : 4 * sl) + (SPLIT ? (lane >> 5) * (HR * 2 * SA) : 0);
-        float *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * sl) : (t0 + 4 * sl));
+        PT *sum_dst = ws_bc + (rev ? (L - 4 - t0 - 4 * sl) : (t0 + 4 * sl));
 
         // everything of one state (B/C tiles already in registers); leaves its dB / dC terms in the slab buffer `par`
         auto state_pass = [&](int n, float (&bt)[I], float (&ct)[I], float hin_saved) {
@@ -533,15 +548,23 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
                             acc[k] = __int_as_float(sw[0]) + __int_as_float(sw[1]);
                         }
                     }
-                    float *dst = sum_dst + (size_t)(arr ? prow1 : prow0) * L + (rev ? -off : off);
+                    PT *dst = sum_dst + (size_t)(arr ? prow1 : prow0) * L + (rev ? -off : off);
                     if (!SPLIT || lane < 32) {
                         if (chunk_full && ws_vec) {
-                            *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
+                            if constexpr (PB) {
+                                *reinterpret_cast<u32x2 *>(dst) = rev ? u32x2{pack2<bf16_t>(acc.w, acc.z), pack2<bf16_t>(acc.y, acc.x)}
+                                                                      : u32x2{pack2<bf16_t>(acc.x, acc.y), pack2<bf16_t>(acc.z, acc.w)};
+                            } else {
+                                *reinterpret_cast<f32x4 *>(dst) = rev ? f32x4{acc.w, acc.z, acc.y, acc.x} : acc;
+                            }
                         } else {
                             const int t = t0 + off + 4 * sl;   // scan position of acc.x; mirrored groups store at L-1-t
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (t + j < L) dst[rev ? (3 - j) : j] = acc[j];
+                                if (t + j < L) {
+                                    if constexpr (PB) dst[rev ? (3 - j) : j] = from_f32<bf16_t>(acc[j]);
+                                    else dst[rev ? (3 - j) : j] = acc[j];
+                                }
                         }
                     }
                 }
