@@ -321,6 +321,101 @@ def collect_prof(lib):
     return recs
 
 
+def family_counts(lib, passes):
+    """algorithmic bytes / entry-point calls per kernel family since ``oss_prof_family_enable(1)`` (include/vmambair_oss.h), per pass"""
+    out = []
+    for f in range(int(lib.oss_prof_family_count())):
+        name, pat, by, calls = C.c_char_p(), C.c_char_p(), C.c_double(), C.c_longlong()
+        if lib.oss_prof_family(f, C.byref(name), C.byref(pat), C.byref(by), C.byref(calls)) != 0:
+            continue
+        out.append({"family": name.value.decode(), "patterns": pat.value.decode().split("|"), "alg_bytes_per_step": by.value / passes,
+                    "entry_calls_per_step": calls.value / passes})
+    return out
+
+
+def steady_state_kernel_trace(argv, timeout=300):
+    """``rocprofv3 --kernel-trace`` of THIS script (a subprocess replaying the same captured step) -> per kernel name
+    (launches per step, ms per step, avg us) inside the marker-bracketed timed region; None + reason when the tracer is not
+    there or fails.  The rows are what tools/prof_summary.py prints as the STEADY STATE table of profiles/*rocprof*.txt."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="bench-trace-", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__), *argv, "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-secondary", "--skip-roofline", "--no-non-scan"]
+        r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=timeout)
+        dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None, f"rocprofv3 rc {r.returncode}, {len(dbs)} result databases: {(r.stderr or '')[-160:]}"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        mb = cur.execute("select max(end) from kernels where name like '%oss_prof_marker_begin%'").fetchone()[0]
+        me = cur.execute("select min(start) from kernels where name like '%oss_prof_marker_end%' and start > ?", (mb or 0,)).fetchone()[0]
+        if not (mb and me):
+            return None, "marker kernels not found in the trace"
+        rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels where start>=? and end<=? "
+                                "group by name order by 3 desc", (mb, me)))
+        steps = sum(r_[1] for r_ in rows if "oss_adam_tick_kernel" in r_[0]) or 3
+        return {"steps": steps, "wall_ms_per_step": (me - mb) / 1e6 / steps,
+                "kernels": [{"name": n, "launches_per_step": c / steps, "ms_per_step": ms / steps, "avg_us": us} for n, c, ms, us in rows]}, None
+    except Exception as e:   # noqa: BLE001  the headline must survive a broken tracer
+        return None, f"{type(e).__name__}: {str(e)[:160]}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def non_scan_roofline(fams, trace):
+    """the part of the step that is NOT a scan kernel under a roofline too: per kernel family, algorithmic
+    bytes per step (the library's entry-point accounting, counted while the step was captured) over the family's kernel time per
+    step in the steady-state trace; plus the ten largest non-scan kernels by time."""
+    def short(n):
+        n = n.replace("void oss::", "").replace("oss::", "")
+        return n if len(n) <= 110 else n[:107] + "..."
+    ks = trace["kernels"]
+    fam_of = {}
+    for k in ks:
+        nm = k["name"]
+        if "oss_scan_" in nm:
+            fam_of[nm] = "scan"
+            continue
+        fam_of[nm] = next((f["family"] for f in fams if any(pt and pt in nm for pt in f["patterns"])), "other (vendor 3x3 convolutions / transposes, aten)")
+    out = []
+    for f in fams + [{"family": "other (vendor 3x3 convolutions / transposes, aten)", "alg_bytes_per_step": None, "entry_calls_per_step": None}]:
+        mine = [k for k in ks if fam_of[k["name"]] == f["family"]]
+        if not mine:
+            continue
+        ms = sum(k["ms_per_step"] for k in mine)
+        n = sum(k["launches_per_step"] for k in mine)
+        by = f["alg_bytes_per_step"]
+        gbps = None if not by else by / (ms * 1e-3) / 1e9
+        out.append({"family": f["family"], "launches_per_step": round(n, 1), "ms_per_step": round(ms, 4), "avg_us": round(1e3 * ms / max(n, 1e-9), 2),
+                    "alg_MB_per_step": None if by is None else round(by / 1e6, 1), "alg_GBps": None if gbps is None else round(gbps, 1),
+                    "frac_of_hbm_peak": None if gbps is None else round(gbps / HBM_PEAK_GBPS, 4)})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    scan = [k for k in ks if fam_of[k["name"]] == "scan"]
+    rest = [k for k in ks if fam_of[k["name"]] != "scan" and "oss_prof_marker" not in k["name"]]
+    fam_gbps = {r["family"]: r["alg_GBps"] for r in out}
+    return {"launches_per_step": round(sum(k["launches_per_step"] for k in ks)), "kernel_ms_per_step": round(sum(k["ms_per_step"] for k in ks), 3),
+            "wall_ms_per_step_under_the_tracer": round(trace["wall_ms_per_step"], 3),
+            "scan": {"launches_per_step": round(sum(k["launches_per_step"] for k in scan), 1), "ms_per_step": round(sum(k["ms_per_step"] for k in scan), 3)},
+            "non_scan": {"launches_per_step": round(sum(k["launches_per_step"] for k in rest), 1), "ms_per_step": round(sum(k["ms_per_step"] for k in rest), 3),
+                         "alg_MB_per_step": round(sum(r["alg_MB_per_step"] or 0 for r in out), 1)},
+            "families": out,
+            "top_kernels": [{"kernel": short(k["name"]), "family": fam_of[k["name"]], "launches_per_step": round(k["launches_per_step"], 1),
+                             "avg_us": round(k["avg_us"], 2), "ms_per_step": round(k["ms_per_step"], 4),
+                             "family_alg_GBps": fam_gbps.get(fam_of[k["name"]])} for k in rest[:10]],
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "measured": "kernel time: rocprofv3 --kernel-trace of this script replaying the same captured step (3 steps between the marker "
+                        "kernels, no vendor solver search in that run); bytes: algorithmic (each operand once, scratch partials excluded), "
+                        "counted by the library's entry points while THIS run captured its step"}
+
+
+
 def cpu_config1(cores):
     """BASELINE.json configs[0] / SURVEY.md 8d "Config 1": ``MamberBlock(dim=48)`` (x2 SR, 48x48 LQ, d_state 16, ONE OSS block),
     ``torch.manual_seed(0); x = randn(2,48,48,48)``, fp32, forward and forward+backward, median of 3, on the host cores.
@@ -486,6 +581,8 @@ def main():
                          "its heuristic's pick: 228.1 -> 232.0 images/s, 37 s more start-up (profiles/r04_multirank_flow_check_and_"
                          "miopen_find.txt).  Default: 1 for the 16-bit training workloads, 0 for --dtype fp32 (3 minutes of search for "
                          "+0.3 %) and for the inference configs; VMAMBAIR_MIOPEN_FIND overrides the default")
+    ap.add_argument("--no-non-scan", action="store_true",
+                    help="skip `roofline.non_scan` (a second, kernel-traced run of this script: rocprofv3 --kernel-trace, about 40 s)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--rendezvous-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true",
@@ -594,7 +691,10 @@ def main():
                                 split_graphs=os.environ.get("VMAMBAIR_BENCH_SPLIT", "0") == "1",   # A-B: the two-graph form of N > 1 on one rank
                                 overlap_wgrads=os.environ.get("VMAMBAIR_OVERLAP_WGRADS", "0") == "1", **opt_kw)
         log("capturing the training step")
+        lib.oss_prof_family_enable(1)     # algorithmic bytes per non-scan kernel family, per pass (warm-up passes + the captured one)
         step.capture(lq, gt)
+        lib.oss_prof_family_enable(0)
+        fam_counts = family_counts(lib, step.warmup + 1)
         log("captured")
     else:
         ema = [p.detach().clone() for p in net.parameters()]
@@ -718,6 +818,13 @@ def main():
         if roof is not None:
             roof["copy_kernel_GBps"] = round(copy_gbps, 1)
         del src, dst
+        if roof is not None and args.graph and world == 1 and not args.no_non_scan and not args.skip_roofline:
+            log("non-scan roofline: kernel trace of the same step (rocprofv3 subprocess)")
+            torch.cuda.empty_cache()
+            targv = ["--config", args.config, "--dtype", args.dtype, "--batch-per-gpu", str(B), "--patch", str(args.patch), "--miopen-find", "0",
+                     "--micro-streams", str(args.micro_streams)]
+            trace, why = steady_state_kernel_trace(targv)
+            roof["non_scan"] = non_scan_roofline(fam_counts, trace) if trace else {"error": why}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -152,6 +152,11 @@ typedef struct {
     /* per-call launch tuning of the backward (see oss_scan_fwd_params.tune_*): v + 1 forces backward variant v (1, 10..13);
      * 1 = never segment, n > 1 = n time segments.  0 = heuristic. */
     int tune_variant, tune_segments;
+    /* row-tile partials of dB / dC (scratch between the main and the finishing kernel): 0 = the library's rule -- bf16 partials at
+     * bf16 I/O when at most 8 row tiles are summed (half the scratch traffic; adds at most tiles x 2^-9 x max|partial| to a result
+     * that is rounded to bf16 anyway), fp32 otherwise; 1 = always fp32 partials (the reference's fp32 accumulation,
+     * cus/selective_scan_bwd_kernel.cuh:208-221, to the letter) */
+    int tune_partials, reserved3_;
 } oss_scan_bwd_params;
 
 /* Time steps between two saved states in `x` (the reference's is 2048,
@@ -570,6 +575,16 @@ size_t oss_conv3x3_thin_wgrad_partial_floats(int batch, int cin, int cout);
 int oss_conv3x3_thin_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partial, int batch, int cin,
                            int cout, int height, int width, int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride,
                            int64_t dy_channel_stride, oss_stream_t stream);
+
+/* Algorithmic bytes of the block's NON-scan launches, by kernel family (round 6; bench.py `roofline.non_scan`).  While counting
+ * is on, every entry point of this header that launches a kernel adds the bytes its launch must move at minimum (each operand
+ * read once, each result written once, fp32 master weights included, scratch partials not) to its family's counter -- host-side
+ * bookkeeping only, so it also works while a hipGraph is being captured.  oss_prof_family_enable(1) clears the counters.
+ * oss_prof_family: name, the '|'-separated substrings of the family's kernel names (for matching a kernel trace), bytes and
+ * entry-point calls since counting was switched on.  The scan kernels have their own event profiler above (oss_prof_collect2). */
+void oss_prof_family_enable(int on);
+int oss_prof_family_count(void);
+int oss_prof_family(int family, const char **name, const char **kernel_patterns, double *algorithmic_bytes, long long *calls);
 
 /* Runtime-selected scan forms the loaded library contains.  Since round 6 every build has both (rounds 4-5 kept them behind
  * build flags): the fused-delta form of SURVEY.md 8f row 1 (chosen per call by oss_scan_fwd_params.dt_weight != NULL) and the

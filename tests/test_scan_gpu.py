@@ -732,6 +732,30 @@ def test_carry_split_changes_association_only():
         assert_close(x4, x1, 2e-5, 2e-5 * max(1.0, float(x1.abs().max())), "split 4 vs split 1")
 
 
+@pytest.mark.parametrize("rows,bf16_partials", [(96, True), (48, True), (108, False)])
+def test_bf16_row_tile_partials_rule_and_bound(rows, bf16_partials):
+    """(round 6) at bf16 I/O the round-2 backward writes its dB / dC row-tile partials as bf16 when at most 8 tiles are summed
+    (oss_scan_bwd_v2.h: kMaxBf16PartialTiles; 96 rows per group = 8 twelve-row tiles is the headline's call) and as fp32 beyond;
+    ``tune=(..., fp32_partials=True)`` (oss_scan_bwd_params.tune_partials = 1) forces fp32.  Everything that is not a sum over
+    row tiles is bit-identical between the two; dB / dC differ by at most tiles x 2^-9 x the largest partial -- bounded here by
+    the largest |dB| of the fp32 run times the tile count -- and both sit inside the reference's bf16 tolerance of the oracle
+    (test_reference_grid and the 16-bit cases above run on the default rule)."""
+    G, N, L, Bsz = 2, 16, 1536, 2
+    u, dl, A, B, C, D, b, g = to_dev(make_inputs(Bsz, G * rows, N, G, L, torch.bfloat16, seed=31))
+    out, x = vmambair_amd.selective_scan_fwd(u, dl, A, B, C, D, b, True, 1)
+    auto = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=(10, 1, None))
+    f32p = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=(10, 1, None, True))
+    names = ["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"]
+    for n, a, f in zip(names, auto, f32p):
+        if n in ("dB", "dC") and bf16_partials:
+            tiles = (rows + 11) // 12
+            bound = tiles * 2.0 ** -8 * float(f.float().abs().max())
+            d = float((a.float() - f.float()).abs().max())
+            assert 0 < d <= bound, (n, d, bound)          # > 0: the bf16 form really ran
+        else:
+            assert torch.equal(a, f), n
+
+
 @pytest.mark.parametrize("boundary", ["c++", "ctypes"])
 def test_per_call_tuning_fields_select_the_launch_shape_without_global_state(boundary):
     """(round 6) ``oss_scan_fwd_params.tune_*`` / ``oss_scan_bwd_params.tune_*``: variant, time segments and the

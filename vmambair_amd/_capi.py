@@ -55,7 +55,7 @@ class ScanBwdParams(C.Structure):
         ("dBC_group_stride", C.c_int64),
         ("ddt", C.c_void_p), ("ddt_weight", C.c_void_p),
         ("ddt_batch_stride", C.c_int64), ("ddt_group_stride", C.c_int64), ("ddt_rank_stride", C.c_int64),
-        ("tune_variant", C.c_int), ("tune_segments", C.c_int),
+        ("tune_variant", C.c_int), ("tune_segments", C.c_int), ("tune_partials", C.c_int), ("reserved3_", C.c_int),
     ]
 
 
@@ -78,7 +78,7 @@ SUM_CHUNK_BYTES = 40   # sizeof(oss_sum_chunk)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fwd_workspace_bytes", "oss_scan_lane_state_floats", "oss_scan_bwd_workspace_bytes",
            "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments", "oss_scan_set_carry_split",
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
-           "oss_prof_collect", "oss_prof_collect2", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd", "oss_dwconv3x3_flat2_ok", "oss_dwconv3x3_silu_flat2_fwd",
+           "oss_prof_collect", "oss_prof_collect2", "oss_prof_family_enable", "oss_prof_family_count", "oss_prof_family", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd", "oss_dwconv3x3_flat2_ok", "oss_dwconv3x3_silu_flat2_fwd",
            "oss_dwconv3x3_silu_flat2_bwd",
            "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_fwd_pool", "oss_ln_nchw_fwd_pool_tiles", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_conv1x1_dgrad_ln_bwd_ok",
@@ -144,6 +144,11 @@ def load():
     lib.oss_prof_collect.restype = C.c_int
     lib.oss_prof_collect.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                      C.POINTER(C.c_double)]
+    lib.oss_prof_family_enable.argtypes = [C.c_int]
+    lib.oss_prof_family_enable.restype = None
+    lib.oss_prof_family_count.restype = C.c_int
+    lib.oss_prof_family.restype = C.c_int
+    lib.oss_prof_family.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     lib.oss_prof_collect2.restype = C.c_int
     lib.oss_prof_collect2.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -172,6 +172,41 @@ struct ProfTimer : LaunchTimer {  // begin/end bracket exactly one kernel launch
     }
 };
 
+
+// ---- algorithmic bytes per kernel FAMILY of the block's non-scan launches (round 6: bench.py `roofline.non_scan`) ------------
+// Every entry point below adds the bytes its launch must move at minimum -- each operand read once, each result written once,
+// fp32 master weights included, scratch partials NOT included -- to its family's counter while counting is on.  bench.py reads
+// the counters after ONE eager training step and divides by the family's kernel time from a kernel trace of the same step.
+enum Fam { FAM_CONV1X1 = 0, FAM_WGRAD, FAM_DWCONV, FAM_PROJ, FAM_LN, FAM_CHAN, FAM_MERGE, FAM_GATE, FAM_CONV3X3, FAM_FINISH, FAM_OPTIM, FAM_N };
+static const char *const kFamName[FAM_N] = {"conv1x1 forward / input gradient (+ fused LayerNorm)", "1x1 / projection weight gradients",
+                                            "depth-wise 3x3 (+ silu / gelu gate / flattenings)", "x_proj / dt_proj forward + input gradient",
+                                            "LayerNorm (+ silu gate, pooled sums)", "channel branch (+ rowsum / row_affine)",
+                                            "cross-scan / cross-merge / merge4", "gelu gate (unfused)", "thin 3x3 convolutions",
+                                            "deferred partial-sum finishing", "Adam(W) + EMA"};
+// substrings of the kernel names a family launches (matched by bench.py against the kernel trace)
+static const char *const kFamKernels[FAM_N] = {"oss_conv1x1_pair_kernel|oss_conv1x1_pairk_kernel|oss_conv1x1_pairw_kernel|oss_conv1x1_wg_kernel|"
+                                               "oss_conv1x1_dgrad_lnbwd_kernel|oss_conv1x1_f32_kernel",
+                                               "oss_conv1x1_wgrad|oss_rows_f32_wgrad|oss_proj_wgrad",
+                                               "oss_dwconv3x3|oss_dwgate",
+                                               "oss_proj_fwd|oss_proj_dgrad|oss_dt_fwd|oss_dt_dgrad|oss_proj_valu",
+                                               "oss_ln_nchw",
+                                               "oss_chan_|oss_rowsum|oss_row_affine",
+                                               "oss_merge4|oss_cross_scan2|oss_cross_merge2",
+                                               "oss_gelu_gate",
+                                               "oss_conv3x3_",
+                                               "oss_sum_partials",
+                                               "oss_adam"};
+static std::atomic<int> g_fam_on{0};
+static double g_fam_bytes[FAM_N];
+static long long g_fam_calls[FAM_N];
+static inline int esz(oss_dtype io) { return io == OSS_F32 ? 4 : 2; }
+static inline void fam_count(int fam, double bytes) {
+    if (!g_fam_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_fam_bytes[fam] += bytes;
+    g_fam_calls[fam] += 1;
+}
+
 // bytes a launch must move at minimum
 static double fwd_alg_bytes(const oss_scan_fwd_params &p, int s) {
     const double BKL = (double)p.batch * p.dim * p.seqlen, BGNL = (double)p.batch * p.n_groups * p.dstate * p.seqlen;
@@ -306,6 +341,7 @@ int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream
 int oss_dwconv3x3_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, void *pre_silu, int batch,
                       int channels, int height, int width, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip,
                       oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * (pre_silu ? 3.0 : 2.0) + 40.0 * channels);
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3(io, x, weight, bias, y, batch, channels, height, width, xsb, xsc, ysb, ysc, flip,
@@ -318,6 +354,7 @@ int oss_dwconv3x3_fused_ok(oss_dtype io, int height, int width, int channels_per
 
 int oss_dwconv3x3_silu_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int channels,
                            int height, int width, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * 2.0 + 40.0 * channels);
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3(io, x, weight, bias, y, batch, channels, height, width, xsb, xsc, ysb, ysc, 0,
@@ -327,6 +364,7 @@ int oss_dwconv3x3_silu_fwd(oss_dtype io, const void *x, const float *weight, con
 int oss_dwconv3x3_silu_bwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *dy, void *dx,
                            float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
                            int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * 3.0 + 80.0 * channels);
     if (!x || !weight || !dy || !dx || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_bwd_fused(io, 0, x, weight, bias, dy, dx, dweight, dbias, partials, batch, channels, height, width, xsb, xsc,
@@ -337,6 +375,7 @@ int oss_dwconv3x3_flat2_ok(oss_dtype io, int height, int width) { return dwconv3
 
 int oss_dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *x2, int batch, int channels,
                                  int height, int width, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * 3.0 + 40.0 * channels);
     if (!x || !weight || !x2) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_silu_flat2_fwd(io, x, weight, bias, x2, batch, channels, height, width, xsb, xsc, reinterpret_cast<hipStream_t>(stream));
@@ -345,6 +384,7 @@ int oss_dwconv3x3_silu_flat2_fwd(oss_dtype io, const void *x, const float *weigh
 int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *g2, void *dx,
                                  float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
                                  int64_t xsb, int64_t xsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * 4.0 + 80.0 * channels);
     if (!x || !weight || !g2 || !dx || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_silu_flat2_bwd(io, x, weight, bias, g2, dx, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, dsb,
@@ -353,6 +393,7 @@ int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weigh
 
 int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
                    int height, int width, int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * hidden * height * width * esz(io) * 3.0 + 80.0 * hidden);
     if (!t || !weight || !out) return OSS_ERR_NULL;
     if (batch <= 0 || hidden <= 0 || height <= 0 || width <= 0 || hidden > 32767 || batch > 65535) return OSS_ERR_SHAPE;
     return dwgate_fwd(io, t, weight, bias, out, batch, hidden, height, width, tsb, tsc, osb, osc, reinterpret_cast<hipStream_t>(stream));
@@ -361,6 +402,7 @@ int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float
 int oss_dwgate_bwd(oss_dtype io, const void *t, const float *weight, const float *bias, const void *dout, void *dt,
                    float *dweight, float *dbias, float *partials, int batch, int hidden, int height, int width, int64_t tsb,
                    int64_t tsc, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * hidden * height * width * esz(io) * 5.0 + 160.0 * hidden);
     if (!t || !weight || !dout || !dt || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || hidden <= 0 || height <= 0 || width <= 0 || hidden > 32767 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_bwd_fused(io, 1, t, weight, bias, dout, dt, dweight, dbias, partials, batch, 2 * hidden, height, width, tsb,
@@ -370,6 +412,7 @@ int oss_dwgate_bwd(oss_dtype io, const void *t, const float *weight, const float
 int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partials,
                         const void *pre_silu, void *dpre, int batch, int channels, int height, int width, int64_t xsb,
                         int64_t xsc, int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * (pre_silu ? 4.0 : 2.0));
     if (!x || !dy || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_wgrad(io, x, dy, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, gsb, gsc,
@@ -378,6 +421,7 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
 
 int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, const void *residual, void *y,
                     int batch, int cout, int cin, int pixels, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    fam_count(FAM_CONV1X1, (double)batch * pixels * esz(io) * ((double)cin + cout + (residual ? cout : 0)) + 4.0 * cin * cout);
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535 || cout > 32 * 65535) return OSS_ERR_SHAPE;
     return conv1x1(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, cin, 1, reinterpret_cast<hipStream_t>(stream),
@@ -386,6 +430,7 @@ int oss_conv1x1_fwd(oss_dtype io, const void *x, const float *weight, const floa
 
 int oss_conv1x1_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cout, int cin, int pixels,
                       int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    fam_count(FAM_CONV1X1, (double)batch * pixels * esz(io) * ((double)cin + cout) + 4.0 * cin * cout);
     if (!dy || !weight || !dx) return OSS_ERR_NULL;
     if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     // dx[ci] = sum_co W[co][ci] dy[co]: the same GEMM with the weights read transposed
@@ -399,6 +444,7 @@ size_t oss_conv1x1_wgrad_partial_floats(int batch, int cout, int cin, int pixels
 
 int oss_conv1x1_wgrad(oss_dtype io, const void *dy, const void *x, float *dweight, float *dbias, float *partials, int batch,
                       int cout, int cin, int pixels, int64_t gsb, int64_t gsc, int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    fam_count(FAM_WGRAD, (double)batch * pixels * esz(io) * ((double)cin + cout) + 4.0 * cin * cout);
     if (!dy || !x || !dweight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || cout <= 0 || cin <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return conv1x1_wgrad(io, dy, x, dweight, partials, batch, cout, cin, pixels, gsb, gsc, xsb, xsc,
@@ -415,6 +461,7 @@ size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen)
 
 int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const float *dt_projs_weight, void *xdbl, void *dts,
                  int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
+    fam_count(FAM_PROJ, (double)batch * seqlen * esz(io) * (2.0 * D + 4.0 * C + (dts ? 4.0 * R + 4.0 * D : 0.0)) + 16.0 * C * D + 16.0 * D * R);
     if (!x2 || !x_proj_weight || !dt_projs_weight || !xdbl) return OSS_ERR_NULL;   // dts == NULL: fused-delta form
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
     return proj_fwd(io, x2, x_proj_weight, dt_projs_weight, xdbl, dts, batch, D, C, R, seqlen, reinterpret_cast<hipStream_t>(stream));
@@ -422,6 +469,7 @@ int oss_proj_fwd(oss_dtype io, const void *x2, const float *x_proj_weight, const
 
 int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, const float *x_proj_weight,
                    const float *dt_projs_weight, void *dx2, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
+    fam_count(FAM_PROJ, (double)batch * seqlen * esz(io) * ((ddts ? 4.0 * D + 4.0 * R : 0.0) + 4.0 * C + (du ? 4.0 * D : 0.0) + 2.0 * D) + 16.0 * C * D);
     if (!dxdbl || !x_proj_weight || !dt_projs_weight || !dx2) return OSS_ERR_NULL;   // ddts == NULL: fused-delta form
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
     return proj_dgrad(io, ddts, dxdbl, du, x_proj_weight, dt_projs_weight, dx2, batch, D, C, R, seqlen,
@@ -434,6 +482,7 @@ int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstat
 }
 int oss_conv1x1_wg(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cout, int cin,
                    int pixels, int64_t xsb, int64_t xsc, int transposed_weight, oss_stream_t stream) {
+    fam_count(FAM_CONV1X1, (double)batch * pixels * esz(io) * ((double)cin + cout) + 4.0 * cin * cout);
     if (!x || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return conv1x1_wg(io, x, weight, bias, y, batch, cout, cin, pixels, xsb, xsc, transposed_weight, reinterpret_cast<hipStream_t>(stream));
@@ -449,6 +498,7 @@ int oss_ln_conv1x1_ok(oss_dtype io, int cout, int cin, int pixels) {
 int oss_ln_conv1x1_fwd(oss_dtype io, const void *x, const float *ln_weight, const float *ln_bias, float eps, void *n, float *mean,
                        float *rstd, const float *weight, const float *bias, void *y, int batch, int cout, int cin, int pixels,
                        int64_t xsb, int64_t xsc, oss_stream_t stream) {
+    fam_count(FAM_CONV1X1, (double)batch * pixels * (esz(io) * (2.0 * cin + cout) + 8.0) + 4.0 * cin * cout);
     if (!x || !ln_weight || !n || !mean || !rstd || !weight || !y) return OSS_ERR_NULL;
     if (batch <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return ln_conv1x1_wg(io, x, ln_weight, ln_bias, eps, n, mean, rstd, weight, bias, y, batch, cout, cin, pixels, xsb, xsc,
@@ -465,6 +515,7 @@ size_t oss_conv1x1_dgrad_ln_bwd_partial_floats(int batch, int cin, int pixels) {
 int oss_conv1x1_dgrad_ln_bwd(oss_dtype io, const void *dy, const float *weight, const void *x, const float *ln_weight, int ln_has_bias,
                              const float *mean, const float *rstd, const void *skip_grad, void *dx, float *dln_weight, float *dln_bias,
                              float *partials, int batch, int cout, int cin, int pixels, int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    fam_count(FAM_CONV1X1, (double)batch * pixels * (esz(io) * ((double)cout + 2.0 * cin + (skip_grad ? cin : 0)) + 8.0) + 4.0 * cin * cout);
     if (!dy || !weight || !x || !ln_weight || !mean || !rstd || !dx || !dln_weight || !partials) return OSS_ERR_NULL;
     if (batch <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return conv1x1_dgrad_lnbwd(io, dy, weight, x, ln_weight, ln_has_bias, mean, rstd, skip_grad, dx, dln_weight, dln_bias, partials, batch,
@@ -477,6 +528,7 @@ void oss_conv1x1_wgrad_set_span(int mult) { conv1x1_wgrad_set_span(mult); }
 
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream) {
+    fam_count(FAM_WGRAD, (double)batch * seqlen * esz(io) * (2.0 * D + 8.0 * C + (ddts ? 4.0 * D : 0.0)));
     if (!x2 || !xdbl || !dxdbl || !dx_proj_weight || !partials) return OSS_ERR_NULL;
     if (ddts && !ddt_projs_weight) return OSS_ERR_NULL;   // ddts == NULL: the scan backward produced ddt_projs_weight itself
     if (batch <= 0 || D <= 0 || seqlen <= 0 || R <= 0 || C <= R) return OSS_ERR_SHAPE;
@@ -504,6 +556,7 @@ int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *d
 
 int oss_cross_scan2(oss_dtype in_type, oss_dtype out_type, const void *x, void *x2, int batch, int D, int height, int width,
                     int64_t x_batch_stride, int64_t x_channel_stride, oss_stream_t stream) {
+    fam_count(FAM_MERGE, (double)batch * D * height * width * (esz(in_type) + 2.0 * esz(out_type)));
     if (!x || !x2) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0) return OSS_ERR_SHAPE;
     return cross_scan2(in_type, out_type, x, x2, batch, D, height, width, x_batch_stride, x_channel_stride,
@@ -511,12 +564,14 @@ int oss_cross_scan2(oss_dtype in_type, oss_dtype out_type, const void *x, void *
 }
 
 int oss_cross_merge2(oss_dtype io, const void *g2, void *dx, int batch, int D, int height, int width, oss_stream_t stream) {
+    fam_count(FAM_MERGE, (double)batch * D * height * width * esz(io) * 3.0);
     if (!g2 || !dx) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0) return OSS_ERR_SHAPE;
     return cross_merge2(io, g2, dx, batch, D, height, width, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oss_chan_fwd(const oss_chan_params *p, oss_stream_t stream) {
+    fam_count(FAM_CHAN, p ? 4.0 * p->B * ((double)p->L * (2.0 * p->Cc + 2.0 * p->dc * 18.0 + 3.0) + (p->pool_part ? (double)p->n_part * p->L : p->L)) : 0.0);
     if (!p) return OSS_ERR_NULL;
     return chan_fwd(*p, reinterpret_cast<hipStream_t>(stream));
 }
@@ -525,12 +580,14 @@ size_t oss_chan_grad_floats(int L, int dc, int Rc, int Cc) { return chan_grad_fl
 size_t oss_chan_bwd_scratch_floats(int B, int L, int dc, int Rc, int Cc) { return chan_bwd_scratch_floats(B, L, dc, Rc, Cc); }
 
 int oss_chan_bwd(const oss_chan_params *p, const float *gc, float *dpooled, float *grads, float *scratch, oss_stream_t stream) {
+    fam_count(FAM_CHAN, p ? 4.0 * p->B * ((double)p->L * (2.0 * p->Cc + 2.0 * p->dc * 18.0 + 5.0)) : 0.0);
     if (!p) return OSS_ERR_NULL;
     return chan_bwd(*p, gc, dpooled, grads, scratch, reinterpret_cast<hipStream_t>(stream));
 }
 
 int oss_rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int batch, int channels, int pixels, int64_t asb,
                int64_t asc, int64_t bsb, int64_t bsc, float alpha, oss_stream_t stream) {
+    fam_count(FAM_CHAN, (double)batch * channels * pixels * esz(io) * (bmul ? 2.0 : 1.0));
     if (!a || !out) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0) return OSS_ERR_SHAPE;
     return rowsum(io, a, bmul, out, batch, channels, pixels, asb, asc, bsb, bsc, alpha, reinterpret_cast<hipStream_t>(stream));
@@ -538,6 +595,7 @@ int oss_rowsum(oss_dtype io, const void *a, const void *bmul, float *out, int ba
 
 int oss_row_affine(oss_dtype io, const void *x, const float *mul, const float *add, void *y, int batch, int channels, int pixels,
                    int64_t xsb, int64_t xsc, float alpha, oss_stream_t stream) {
+    fam_count(FAM_CHAN, (double)batch * channels * pixels * esz(io) * 2.0);
     if (!x || !y) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0) return OSS_ERR_SHAPE;
     return row_affine(io, x, mul, add, y, batch, channels, pixels, xsb, xsc, alpha, reinterpret_cast<hipStream_t>(stream));
@@ -545,6 +603,7 @@ int oss_row_affine(oss_dtype io, const void *x, const float *mul, const float *a
 
 int oss_gelu_gate_fwd(oss_dtype io, const void *h, void *out, int batch, size_t half_elems, int64_t h_batch_stride,
                       oss_stream_t stream) {
+    fam_count(FAM_GATE, (double)batch * half_elems * esz(io) * 3.0);
     if (!h || !out) return OSS_ERR_NULL;
     if (batch <= 0 || half_elems == 0) return OSS_ERR_SHAPE;
     return gelu_gate_fwd(io, h, out, batch, half_elems, h_batch_stride, reinterpret_cast<hipStream_t>(stream));
@@ -552,6 +611,7 @@ int oss_gelu_gate_fwd(oss_dtype io, const void *h, void *out, int batch, size_t 
 
 int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, int batch, size_t half_elems,
                       int64_t h_batch_stride, int64_t dout_batch_stride, oss_stream_t stream) {
+    fam_count(FAM_GATE, (double)batch * half_elems * esz(io) * 5.0);
     if (!h || !dout || !dh) return OSS_ERR_NULL;
     if (batch <= 0 || half_elems == 0) return OSS_ERR_SHAPE;
     return gelu_gate_bwd(io, h, dout, dh, batch, half_elems, h_batch_stride, dout_batch_stride, reinterpret_cast<hipStream_t>(stream));
@@ -560,11 +620,13 @@ int oss_gelu_gate_bwd(oss_dtype io, const void *h, const void *dout, void *dh, i
 int oss_conv3x3_thin_ok(oss_dtype io, int cin, int cout, int height, int width) { return conv3x3_thin_ok(io, cin, cout, height, width); }
 int oss_conv3x3_thin_fwd(oss_dtype io, const void *x, const float *weight, const float *bias, void *y, int batch, int cin, int cout,
                          int height, int width, int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, oss_stream_t stream) {
+    fam_count(FAM_CONV3X3, (double)batch * height * width * esz(io) * ((double)cin + cout));
     if (!x || !weight || !y) return OSS_ERR_NULL;
     return conv3x3_thin_fwd(io, x, weight, bias, y, batch, cin, cout, height, width, xsb, xsc, ysb, ysc, reinterpret_cast<hipStream_t>(stream));
 }
 int oss_conv3x3_thin_dgrad(oss_dtype io, const void *dy, const float *weight, void *dx, int batch, int cin, int cout, int height,
                            int width, int64_t gsb, int64_t gsc, int64_t dsb, int64_t dsc, oss_stream_t stream) {
+    fam_count(FAM_CONV3X3, (double)batch * height * width * esz(io) * ((double)cin + cout));
     if (!dy || !weight || !dx) return OSS_ERR_NULL;
     return conv3x3_thin_dgrad(io, dy, weight, dx, batch, cin, cout, height, width, gsb, gsc, dsb, dsc, reinterpret_cast<hipStream_t>(stream));
 }
@@ -573,6 +635,7 @@ size_t oss_conv3x3_thin_wgrad_partial_floats(int batch, int cin, int cout) {
 }
 int oss_conv3x3_thin_wgrad(oss_dtype io, const void *x, const void *dy, float *dweight, float *dbias, float *partial, int batch, int cin,
                            int cout, int height, int width, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc, oss_stream_t stream) {
+    fam_count(FAM_CONV3X3, (double)batch * height * width * esz(io) * ((double)cin + cout));
     if (!x || !dy || !dweight || !partial) return OSS_ERR_NULL;
     return conv3x3_thin_wgrad(io, x, dy, dweight, dbias, partial, batch, cin, cout, height, width, xsb, xsc, gsb, gsc,
                               reinterpret_cast<hipStream_t>(stream));
@@ -641,6 +704,11 @@ int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chu
     if (!host_table || !device_table) return OSS_ERR_NULL;
     if (n > capacity_chunks) return OSS_ERR_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_fam_on.load(std::memory_order_relaxed)) {
+        double by = 0.0;
+        for (const oss_sum_chunk &c : g_defer_chunks) by += 4.0 * c.n * (c.K + 1.0);
+        fam_count(FAM_FINISH, by);
+    }
     std::memcpy(host_table, g_defer_chunks.data(), n * sizeof(oss_sum_chunk));
     hipError_t e = hipMemcpyAsync(device_table, host_table, n * sizeof(oss_sum_chunk), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
@@ -650,6 +718,7 @@ int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chu
 
 int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
                       float ema_decay, oss_stream_t stream) {
+    fam_count(FAM_OPTIM, 36.0 * n_chunks * 2048.0);
     if (!chunks || !state) return OSS_ERR_NULL;
     if (n_chunks <= 0) return OSS_ERR_SHAPE;
     return adam_ema_step(chunks, n_chunks, state, lr, beta1, beta2, eps, ema_decay, reinterpret_cast<hipStream_t>(stream));
@@ -657,6 +726,7 @@ int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, 
 
 int oss_adamw_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,
                        float weight_decay, float ema_decay, const float *grad_scale, oss_stream_t stream) {
+    fam_count(FAM_OPTIM, 36.0 * n_chunks * 2048.0);
     if (!chunks || !state) return OSS_ERR_NULL;
     if (n_chunks <= 0 || weight_decay < 0.f) return OSS_ERR_SHAPE;
     return adam_ema_step(chunks, n_chunks, state, lr, beta1, beta2, eps, ema_decay, reinterpret_cast<hipStream_t>(stream),
@@ -664,6 +734,7 @@ int oss_adamw_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state,
 }
 
 int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int height, int width, oss_stream_t stream) {
+    fam_count(FAM_MERGE, (double)batch * D * height * width * (4.0 * esz(io) + 4.0));
     if (!out || !y) return OSS_ERR_NULL;
     if (batch <= 0 || D <= 0 || height <= 0 || width <= 0 || (long)batch * D > 65535) return OSS_ERR_SHAPE;
     return merge4(io, out, y, batch, D, height, width, reinterpret_cast<hipStream_t>(stream));
@@ -672,6 +743,7 @@ int oss_merge4(oss_dtype io, const void *out, float *y, int batch, int D, int he
 int oss_ln_nchw_fwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate,
                     void *y, float *mean, float *rstd, int batch, int channels, int pixels, int64_t xsb, int64_t xsc,
                     int64_t gsb, int64_t gsc, float eps, oss_stream_t stream) {
+    fam_count(FAM_LN, (double)batch * channels * pixels * (esz(xt) + esz(yt) * (gate ? 2.0 : 1.0)) + 8.0 * batch * pixels);
     if (!x || !weight || !y || !mean || !rstd) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535) return OSS_ERR_SHAPE;
     return ln_nchw_fwd(xt, yt, x, weight, bias, gate, y, mean, rstd, batch, channels, pixels, xsb, xsc, gsb, gsc, eps,
@@ -686,6 +758,7 @@ int oss_ln_nchw_fwd_pool_tiles(int channels, int pixels, int64_t xsb, int64_t xs
 int oss_ln_nchw_fwd_pool(oss_dtype xt, oss_dtype yt, const void *x, const float *weight, const float *bias, const void *gate, void *y,
                          float *mean, float *rstd, float *pool_part, int batch, int channels, int pixels, int64_t xsb, int64_t xsc,
                          int64_t gsb, int64_t gsc, float eps, oss_stream_t stream) {
+    fam_count(FAM_LN, (double)batch * channels * pixels * (esz(xt) + esz(yt) * (gate ? 2.0 : 1.0)) + 8.0 * batch * pixels);
     if (!x || !weight || !y || !mean || !rstd || !pool_part) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
     return ln_nchw_fwd(xt, yt, x, weight, bias, gate, y, mean, rstd, batch, channels, pixels, xsb, xsc, gsb, gsc, eps,
@@ -696,6 +769,7 @@ int oss_ln_nchw_bwd(oss_dtype xt, oss_dtype yt, const void *x, const float *weig
                     const void *dy, const float *mean, const float *rstd, void *dx, void *dgate, float *dweight,
                     float *dbias, float *partials, const void *skip_grad, int batch, int channels, int pixels, int64_t xsb,
                     int64_t xsc, int64_t gsb, int64_t gsc, int64_t dgate_batch_stride, oss_stream_t stream) {
+    fam_count(FAM_LN, (double)batch * channels * pixels * (2.0 * esz(xt) + esz(yt) * (1.0 + (gate ? 2.0 : 0.0) + (skip_grad ? 1.0 : 0.0))) + 8.0 * batch * pixels);
     if (!x || !weight || !dy || !mean || !rstd || !dx || !dweight || !partials) return OSS_ERR_NULL;
     if (gate && !dgate) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
@@ -709,6 +783,7 @@ int oss_ln_nchw_bwd_affine(oss_dtype xt, oss_dtype yt, const void *x, const floa
                            void *dgate, float *dweight, float *dbias, float *partials, const void *skip_grad, int batch,
                            int channels, int pixels, int64_t xsb, int64_t xsc, int64_t gsb, int64_t gsc,
                            int64_t dgate_batch_stride, oss_stream_t stream) {
+    fam_count(FAM_LN, (double)batch * channels * pixels * (2.0 * esz(xt) + esz(yt) * (1.0 + (gate ? 2.0 : 0.0) + (skip_grad ? 1.0 : 0.0))) + 8.0 * batch * pixels);
     if (!x || !weight || !dy || !mean || !rstd || !dx || !dweight || !partials || !dy_add) return OSS_ERR_NULL;
     if (gate && !dgate) return OSS_ERR_NULL;
     if (batch <= 0 || channels <= 0 || pixels <= 0 || batch > 65535 || channels > 4096) return OSS_ERR_SHAPE;
@@ -723,6 +798,22 @@ size_t oss_ln_nchw_bwd_partial_floats(int batch, int channels, int pixels) {
 }
 
 void oss_prof_enable(int on) { g_prof_on.store(on ? 1 : 0); }
+
+void oss_prof_family_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on) for (int f = 0; f < FAM_N; ++f) { g_fam_bytes[f] = 0.0; g_fam_calls[f] = 0; }
+    g_fam_on.store(on ? 1 : 0);
+}
+int oss_prof_family_count(void) { return FAM_N; }
+int oss_prof_family(int family, const char **name, const char **kernel_patterns, double *algorithmic_bytes, long long *calls) {
+    if (family < 0 || family >= FAM_N) return OSS_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (name) *name = kFamName[family];
+    if (kernel_patterns) *kernel_patterns = kFamKernels[family];
+    if (algorithmic_bytes) *algorithmic_bytes = g_fam_bytes[family];
+    if (calls) *calls = g_fam_calls[family];
+    return OSS_OK;
+}
 
 void oss_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -549,7 +549,7 @@ static int launch_bwd(const oss_scan_bwd_params &p, hipStream_t stream, LaunchTi
 constexpr int kCarryWaves = OSS_CARRY_WAVES;
 
 // round-2 kernel (oss_scan_bwd_v2.h): lane-resident per-state scalars, register-prefetched tiles, one barrier per state
-template <typename T, int WAVES, int NBB, int MINW, bool FD = false>
+template <typename T, int WAVES, int NBB, int MINW, bool FD = false, bool PB = false>
 static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t stream, LaunchTimer *timer) {
     if constexpr (!FD) {
         if (p.f.dt_weight) {
@@ -561,6 +561,12 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     const oss_scan_fwd_params &f = p.f;
     const int rows_per_group = f.dim / f.n_groups;
     const int tiles = (rows_per_group + WAVES - 1) / WAVES;
+    if constexpr (!PB && kPartialsBf16Ok<T, FD>) {
+        // bf16 row-tile partials (oss_scan_bwd_v2.h: kV2Bf16Partials): few tiles, no lane states, not switched off for this call
+        const bool lane_states = kBuildLaneStates && f.hs != nullptr;
+        if (tiles <= kMaxBf16PartialTiles && !lane_states && p.tune_partials != 1)
+            return launch_bwd2<T, WAVES, NBB, MINW, false, true>(p, seg_req, stream, timer);
+    }
     const unsigned wgs = (unsigned)(f.batch * f.n_groups * tiles);
     const int n_chunks = (f.seqlen + TC - 1) / TC;
     int n_seg = FD ? 1 : scan_pick_segments(wgs, n_chunks, seg_req, 0.3);
@@ -583,7 +589,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     if (rc != OSS_OK) return rc;
     g_last_bwd_segments.store(n_seg);
     // lane states saved by the forward pass (f.hs): the kernels that load them instead of re-running the forward recurrence
-    const bool hs = kBuildLaneStates && !FD && f.hs != nullptr;
+    const bool hs = kBuildLaneStates && !FD && !PB && f.hs != nullptr;
     // two tile buffers, two slab buffers (+ dt weights | + two buffers of this wave's lane states)
     const bool slab_q = kV2SlabQ && !FD && !(hs && WAVES > 8);   // oss_scan_bwd2_kernel: SQ
     const size_t smem = sizeof(float) * (4 * (size_t)NBB * TC + 4 * (size_t)WAVES * (slab_q ? kSlabA : TC) +
@@ -604,7 +610,7 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
                                stream, p, sg, ctiles);
             static LdsGate gate_s, gate_sh;
             bool launched = false;
-            if constexpr (kBuildLaneStates) {
+            if constexpr (kBuildLaneStates && !PB) {
                 if (hs) {
                     auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, true>;
                     if (const int e = gate_sh.ensure(reinterpret_cast<const void *>(km), smem)) return e;
@@ -613,30 +619,30 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
                 }
             }
             if (!launched) {
-                auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, false>;
+                auto km = oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, true, false, PB>;
                 if (const int e = gate_s.ensure(reinterpret_cast<const void *>(km), smem)) return e;
                 hipLaunchKernelGGL(km, dim3(wgs * (unsigned)n_seg), dim3(WAVES * 64), smem, stream, p, ws, sg);
             }
             if (timer) timer->end(stream);
             rc = (int)hipGetLastError();
             if (rc != OSS_OK) return rc;
-            return launch_finish<T, kPartialsBf16<T, false>>(p, ws, wdD, wdb, stream, n_seg);
+            return launch_finish<T, PB>(p, ws, wdD, wdb, stream, n_seg);
         }
-        if constexpr (kBuildLaneStates) {
+        if constexpr (kBuildLaneStates && !PB) {
             if (hs) {
                 static LdsGate gate_h;
                 rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, false, false, true>, smem, gate_h, wgs, WAVES * 64, p, ws,
                                  stream, timer, BwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
                 if (rc != OSS_OK) return rc;
-                return launch_finish<T, kPartialsBf16<T, false>>(p, ws, wdD, wdb, stream);
+                return launch_finish<T, false>(p, ws, wdD, wdb, stream);
             }
         }
     }
     static LdsGate gate;
-    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false, false>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
+    rc = launch_main(oss_scan_bwd2_kernel<T, WAVES, NBB, MINW, FD, false, false, PB>, smem, gate, wgs, WAVES * 64, p, ws, stream, timer,
                      BwdSeg{nullptr, 1, n_chunks, 1, n_chunks, 1});
     if (rc != OSS_OK) return rc;
-    return launch_finish<T, kPartialsBf16<T, FD>>(p, ws, wdD, wdb, stream);
+    return launch_finish<T, PB>(p, ws, wdD, wdb, stream);
 }
 
 // variant table (numbers kept from rounds 1-3; 0 and 2..9 -- the other round-1 row tiles and the packed two-states-per-pass

@@ -130,7 +130,12 @@ constexpr bool kV2Bf16Partials = false;
 #else
 constexpr bool kV2Bf16Partials = true;
 #endif
-template <typename T, bool FD> constexpr bool kPartialsBf16 = kV2Bf16Partials && !FD && std::is_same<T, bf16_t>::value;
+// ... and only where at most kMaxBf16PartialTiles partials are summed: the added error is bounded by tiles x 2^-9 x max|partial|
+// (random signs: sqrt(tiles / 3) x 2^-9), the size of what rounding the kernel's bf16 INPUTS already puts into a sum over the
+// group's rows; with 32 - 64 tiles (the reference's test grid: 768 rows per group) one element in 1e5 left the reference's atol.
+// oss_scan_bwd_params.tune_partials = 1 forces fp32 partials for a call.
+constexpr int kMaxBf16PartialTiles = 8;
+template <typename T, bool FD> constexpr bool kPartialsBf16Ok = kV2Bf16Partials && !FD && std::is_same<T, bf16_t>::value;
 // SlabQ: one row's dB (or dC) terms of one state, 512 scan positions = 64 lanes x 2 quads.  The round-2 image was time order
 // (lane p wrote its quads at floats 8p and 8p + 4: a 32-byte lane stride, so a 16-lane phase of a ds_write_b128 covered only
 // half of the 64 banks, two-way conflicts on every slab write -- SQ_LDS_BANK_CONFLICT 31 % of the LDS cycles,
@@ -159,9 +164,10 @@ struct BwdSeg {
 // 8 steps then start from a LOADED state: the local forward recurrence, the product of a over the lane and one of the two lane
 // scans per state drop out of the state pass (28 of its 165 vector instructions); the loads go global -> LDS directly
 // (global_load_lds_dword: no registers) one staging batch ahead, into a wave-private region next to the B / C tiles.
-template <typename T, int WAVES, int NBB, int MINW, bool FD, bool SEG = false, bool HS = false>
+template <typename T, int WAVES, int NBB, int MINW, bool FD, bool SEG = false, bool HS = false, bool PB = false>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
 oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg sg) {
+    static_assert(!PB || (kPartialsBf16Ok<T, FD> && !HS), "bf16 partial rows: bf16 I/O, not the fused-delta / lane-state forms");
     static_assert(!(FD && SEG), "the fused-delta form is not segmented");
     static_assert(!(FD && HS), "the fused-delta form recomputes the forward states");
     constexpr int LPR = 64, I = 8;
@@ -241,7 +247,7 @@ oss_scan_bwd2_kernel(const oss_scan_bwd_params p, const BwdWs ws, const BwdSeg s
     const float bias = f.delta_bias ? f.delta_bias[d] : 0.f;
     const int n_xchunks = (L + kScanChunk - 1) / kScanChunk;
     const float *x_row = f.x ? f.x + ((size_t)b * f.dim + d) * n_xchunks * 2 * N : nullptr;
-    constexpr bool PB = kPartialsBf16<T, FD>;                 // partial rows as bf16 (same element layout, half the bytes)
+    // PB: partial rows as bf16 (same element layout, half the bytes)
     using PT = typename std::conditional<PB, bf16_t, float>::type;
     PT *ws_bc = reinterpret_cast<PT *>(ws.bc) + ((size_t)(b * G + g) * tiles_per_group + tile) * (2 * N + ws.rp) * L;
     const bool ws_vec = (L % 4) == 0;   // 16-byte (bf16 partials: 8-byte) stores of the partial rows

@@ -103,11 +103,13 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
 
 
 def _tune_fields(tune):
-    """``(variant, segments, carry_split)`` with None = heuristic -> the C struct's encoding (0 = heuristic, variant + 1)"""
+    """``(variant, segments, carry_split[, fp32_partials])`` with None = heuristic -> the C struct's encoding (0 = heuristic,
+    variant + 1; fp32_partials True -> oss_scan_bwd_params.tune_partials = 1, backward only)"""
     if tune is None:
-        return 0, 0, 0
-    v, s, c = (tuple(tune) + (None, None, None))[:3]
-    return (0 if v is None or v < 0 else int(v) + 1), (0 if s is None or s < 0 else max(1, int(s))), (0 if c is None or c <= 0 else int(c))
+        return 0, 0, 0, 0
+    v, s, c, f = (tuple(tune) + (None, None, None, None))[:4]
+    return ((0 if v is None or v < 0 else int(v) + 1), (0 if s is None or s < 0 else max(1, int(s))), (0 if c is None or c <= 0 else int(c)),
+            (1 if f else 0))
 
 
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
@@ -120,7 +122,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     kernels evaluate delta themselves -- see include/vmambair_oss.h.  ``want_hs``: -> ``[out, x, hs]`` with the lane states
     (the state entering every 8-step block) for ``selective_scan_bwd(..., hs=hs)``.  ``tune``: per-call launch shape
     ``(variant or None, segments or None, carry_split or None)`` -> ``oss_scan_fwd_params.tune_*`` (None = heuristic)."""
-    tv, ts, tc = _tune_fields(tune)
+    tv, ts, tc, _ = _tune_fields(tune)
     if want_hs:
         _capi.require_feature(_capi.FEATURE_LANE_STATES, "selective_scan_fwd(want_hs=True)")
     if dt_weight is not None:
@@ -172,12 +174,12 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``.
     With ``dt_weight`` (delta computed inside the scan; needs ``dbc_into``): ``ddelta`` is ``None``, the gradient of the rank
     factor lands in the first R rows of ``dbc_into`` and an eighth entry, the (dim, R) gradient of ``dt_weight``, is returned."""
-    tv, ts, tc = _tune_fields(tune)
+    tv, ts, tc, tp = _tune_fields(tune)
     host = _host.ops()
     if host is not None and u.is_cuda:   # compiled boundary: [du, ddelta, dA, dB, dC, dD, dbias, ddt_weight], empty = absent
         r = host.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, bool(delta_softplus),
                           -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), int(dout_row_mod), bool(a_log_form),
-                          dbc_into, dt_weight, hs, tv, ts, tc)
+                          dbc_into, dt_weight, hs, tv, ts, tc, tp)
         du, ddelta, dA, dB, dC, dD, dbias, ddtw = r
         if dbc_into is not None:   # written in place (a mutated argument is not returned): the views are made here
             rows, N = dbc_into.shape[2], A.shape[1]
@@ -240,7 +242,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     P.workspace, P.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     P.dout_row_mod = int(dout_row_mod)
     P.dBC_group_stride = 0 if dbc_into is None else dbc_into.stride(1)
-    P.tune_variant, P.tune_segments, P.f.tune_carry_split = tv, ts, tc
+    P.tune_variant, P.tune_segments, P.f.tune_carry_split, P.tune_partials = tv, ts, tc, tp
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
