@@ -152,11 +152,24 @@ typedef struct {
     /* per-call launch tuning of the backward (see oss_scan_fwd_params.tune_*): v + 1 forces backward variant v (1, 10..13);
      * 1 = never segment, n > 1 = n time segments.  0 = heuristic. */
     int tune_variant, tune_segments;
-    /* row-tile partials of dB / dC (scratch between the main and the finishing kernel): 0 = the library's rule -- bf16 partials at
-     * bf16 I/O when at most 8 row tiles are summed (half the scratch traffic; adds at most tiles x 2^-9 x max|partial| to a result
-     * that is rounded to bf16 anyway), fp32 otherwise; 1 = always fp32 partials (the reference's fp32 accumulation,
-     * cus/selective_scan_bwd_kernel.cuh:208-221, to the letter) */
+    /* row-tile partials of dB / dC (scratch between the main and the finishing kernel): 0 / 1 = fp32 (default: the reference's fp32
+     * accumulation, cus/selective_scan_bwd_kernel.cuh:208-221, to the letter); 2 = bf16 partials at bf16 I/O (round-2 kernels, not the
+     * fused-delta / lane-state forms; ignored elsewhere): half the scratch traffic, but every tile's partial is rounded to 8 bits of
+     * mantissa before the tiles are summed -- an absolute error of 2^-9 x |partial| that can leave the reference's bf16 tolerance
+     * when the tiles cancel.  An opt-in for callers who accept that (measured +1.7 % on the headline step). */
     int tune_partials, reserved3_;
+    /* (round 6) The dt-factor gradient in the backward's finishing launch.  With finish_dt_weight != NULL (and f.dt_weight == NULL:
+     * delta materialised, ddelta written as usual) the finishing kernel -- which already adds the row-tile partials of dB / dC --
+     * also evaluates the adjoint of the archs' `dts = einsum("b k r l, k d r -> b k d l", dts, dt_projs_weight)`
+     * (SRGAN/VmambaIR/archs/MambaSISR6_arch.py:411):
+     *     ddt[b, g, r, t] = sum over the rows d of group g of finish_dt_weight[d * finish_dt_rank + r] * ddelta[b, d, t]
+     * into `ddt` (element strides ddt_batch_stride / ddt_group_stride / ddt_rank_stride; normally the first rows of the gradient
+     * of x_dbl that dBC_group_stride already points dB / dC into), in extra workgroups of the SAME launch: the two are independent
+     * and memory-bound, so the block's backward has one launch less (oss_dt_dgrad_kernel of oss_proj_dgrad, which is then called
+     * with ddts == NULL).  oss_scan_bwd_finish_dt_ok() says whether a shape qualifies (rank <= 8, seqlen % 4 == 0; 8 / 16-byte
+     * aligned ddelta / ddt rows). */
+    const float *finish_dt_weight;  /* (dim, finish_dt_rank) float contiguous, or NULL */
+    int finish_dt_rank, reserved4_;
 } oss_scan_bwd_params;
 
 /* Time steps between two saved states in `x` (the reference's is 2048,
@@ -174,6 +187,9 @@ int oss_scan_fwd(const oss_scan_fwd_params *p, oss_dtype io, oss_stream_t stream
 /* (the workspace size covers the fused-delta form with dt_rank <= 8 as well) */
 size_t oss_scan_bwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, int n_groups);
 int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream);
+
+/* 1 when oss_scan_bwd_params.finish_dt_weight may be used at this length / rank (see the struct) */
+int oss_scan_bwd_finish_dt_ok(int seqlen, int dt_rank);
 
 /* 1 when the fused-delta form (oss_scan_fwd_params.dt_weight) covers this SS2D_1 shape: 16-bit I/O on the matrix-core
  * projection kernels (which may then be called with dts / ddts == NULL), dt_rank <= 8, dstate <= 64, seqlen >= 512
@@ -355,6 +371,10 @@ size_t oss_proj_wgrad_partial_floats(int batch, int D, int C, int R, int seqlen)
 /* 16-bit I/O runs oss_proj_fwd / _dgrad on the matrix cores (MFMA); float I/O, or force_vector_alu != 0
  * (tests, A-B timing), on the vector-ALU kernels.  Same results up to the summation order. */
 void oss_proj_set_path(int force_vector_alu);
+/* 1 when oss_proj_fwd may be called with dts == NULL / oss_proj_dgrad with ddts == NULL at this shape (the matrix-core projection
+ * kernels: 16-bit I/O, even seqlen, D <= 768, 2 C <= 256, R <= 32, and the vector-ALU path not forced) -- i.e. when the dt rows of
+ * the gradient of x_dbl may come from somewhere else (oss_scan_bwd_params.finish_dt_weight, the fused-delta form) */
+int oss_proj_rows_optional_ok(oss_dtype io, int batch, int D, int C, int R, int seqlen);
 int oss_proj_wgrad(oss_dtype io, const void *x2, const void *xdbl, const void *dxdbl, const void *ddts, float *dx_proj_weight,
                    float *ddt_projs_weight, float *partials, int batch, int D, int C, int R, int seqlen, oss_stream_t stream);
 

@@ -732,23 +732,51 @@ def test_carry_split_changes_association_only():
         assert_close(x4, x1, 2e-5, 2e-5 * max(1.0, float(x1.abs().max())), "split 4 vs split 1")
 
 
-@pytest.mark.parametrize("rows,bf16_partials", [(96, True), (48, True), (108, False)])
-def test_bf16_row_tile_partials_rule_and_bound(rows, bf16_partials):
-    """(round 6) at bf16 I/O the round-2 backward writes its dB / dC row-tile partials as bf16 when at most 8 tiles are summed
-    (oss_scan_bwd_v2.h: kMaxBf16PartialTiles; 96 rows per group = 8 twelve-row tiles is the headline's call) and as fp32 beyond;
-    ``tune=(..., fp32_partials=True)`` (oss_scan_bwd_params.tune_partials = 1) forces fp32.  Everything that is not a sum over
-    row tiles is bit-identical between the two; dB / dC differ by at most tiles x 2^-9 x the largest partial -- bounded here by
-    the largest |dB| of the fp32 run times the tile count -- and both sit inside the reference's bf16 tolerance of the oracle
-    (test_reference_grid and the 16-bit cases above run on the default rule)."""
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("L,rows,R,bv,segs", [(1024, 48, 3, -1, -1), (4096, 96, 6, -1, -1), (2052, 13, 8, 13, 3), (700, 24, 5, 1, -1), (516, 12, 1, 11, -1)])
+def test_dt_factor_gradient_in_the_finishing_launch(itype, L, rows, R, bv, segs):
+    """(round 6) ``finish_dt_weight`` (include/vmambair_oss.h: oss_scan_bwd_params): the backward's finishing launch also evaluates
+    the adjoint of the archs' dt_proj einsum (MambaSISR6_arch.py:411), ddt[b, k, r, t] = sum_d W[k, d, r] ddelta[b, k, d, t], into the
+    first R rows of the x_dbl gradient.  Checked against that sum evaluated in float64 from the SAME call's ddelta (the scan's own
+    outputs are checked against the oracle elsewhere and must not change: bit-identical with and without the extra workgroups);
+    round-1 and round-2 kernels, a time-segmented launch, ragged row tiles, every I/O type, rank 1 .. 8."""
+    K, N, Bsz = 4, 16, 2
+    Cc = R + 2 * N
+    cpu = make_inputs(Bsz, K * rows, N, K, L, itype, seed=23)
+    u, dl, A, B, C, D, b, g = to_dev(cpu)
+    W = (torch.randn(K * rows, R, generator=torch.Generator().manual_seed(3)) * 0.5).to(DEV)
+    out, x = vmambair_amd.selective_scan_fwd(u, dl, A, B, C, D, b, True, 1)
+    tune = (bv if bv >= 0 else None, segs if segs > 0 else None, None)
+    into_a = torch.zeros(Bsz, K, Cc, L, dtype=itype, device=DEV)
+    into_b = torch.full((Bsz, K, Cc, L), 7.0, dtype=itype, device=DEV)
+    plain = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, dbc_into=into_a, tune=tune)
+    with_dt = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, dbc_into=into_b, tune=tune, finish_dt_weight=W)
+    for n, p_, q_ in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], plain, with_dt):
+        assert torch.equal(p_, q_), n
+    assert torch.equal(into_a[:, :, R:], into_b[:, :, R:]) and float(into_a[:, :, :R].abs().max()) == 0.0
+    want = torch.einsum("bkdl,kdr->bkrl", with_dt[1].double().view(Bsz, K, rows, L), W.double().view(K, rows, R))
+    got = into_b[:, :, :R].double()
+    lo = itype == torch.float32
+    scale = float(want.abs().max())
+    assert_close(got, want, 1e-5 if lo else 8e-3, (1e-5 if lo else 4e-3) * scale, "dt rows of the x_dbl gradient")
+
+
+@pytest.mark.parametrize("rows", [96, 48, 108])
+def test_opt_in_bf16_row_tile_partials_change_only_the_row_tile_sums(rows):
+    """(round 6) ``tune=(..., "bf16")`` (oss_scan_bwd_params.tune_partials = 2): at bf16 I/O the round-2 backward writes its dB / dC
+    row-tile partials as bf16 (half the scratch traffic; DESIGN.md 4.2 says why it is NOT the default: one element of the
+    reference's grid left the bf16 tolerance).  Everything that is not a sum over row tiles is bit-identical to the default;
+    dB / dC differ by at most tiles x 2^-9 x the largest partial -- bounded here by the largest |dB| of the default run times the
+    tile count.  The default is checked against the oracle everywhere else in this file."""
     G, N, L, Bsz = 2, 16, 1536, 2
     u, dl, A, B, C, D, b, g = to_dev(make_inputs(Bsz, G * rows, N, G, L, torch.bfloat16, seed=31))
     out, x = vmambair_amd.selective_scan_fwd(u, dl, A, B, C, D, b, True, 1)
-    auto = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=(10, 1, None))
-    f32p = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=(10, 1, None, True))
+    f32p = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=(10, 1, None))
+    bf16p = vmambair_amd.selective_scan_bwd(u, dl, A, B, C, D, b, g, x, True, 1, tune=(10, 1, None, "bf16"))
     names = ["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"]
-    for n, a, f in zip(names, auto, f32p):
-        if n in ("dB", "dC") and bf16_partials:
-            tiles = (rows + 11) // 12
+    tiles = (rows + 11) // 12
+    for n, a, f in zip(names, bf16p, f32p):
+        if n in ("dB", "dC"):
             bound = tiles * 2.0 ** -8 * float(f.float().abs().max())
             d = float((a.float() - f.float()).abs().max())
             assert 0 < d <= bound, (n, d, bound)          # > 0: the bf16 form really ran

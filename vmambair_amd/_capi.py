@@ -56,6 +56,7 @@ class ScanBwdParams(C.Structure):
         ("ddt", C.c_void_p), ("ddt_weight", C.c_void_p),
         ("ddt_batch_stride", C.c_int64), ("ddt_group_stride", C.c_int64), ("ddt_rank_stride", C.c_int64),
         ("tune_variant", C.c_int), ("tune_segments", C.c_int), ("tune_partials", C.c_int), ("reserved3_", C.c_int),
+        ("finish_dt_weight", C.c_void_p), ("finish_dt_rank", C.c_int), ("reserved4_", C.c_int),
     ]
 
 
@@ -76,14 +77,14 @@ SUM_CHUNK_BYTES = 40   # sizeof(oss_sum_chunk)
 
 #: every symbol include/vmambair_oss.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fwd_workspace_bytes", "oss_scan_lane_state_floats", "oss_scan_bwd_workspace_bytes",
-           "oss_scan_bwd", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments", "oss_scan_set_carry_split",
+           "oss_scan_bwd", "oss_scan_bwd_finish_dt_ok", "oss_scan_fused_dt_ok", "oss_scan_set_variant", "oss_scan_last_variant", "oss_scan_set_segments", "oss_scan_set_carry_split",
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_prof_collect2", "oss_prof_family_enable", "oss_prof_family_count", "oss_prof_family", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd", "oss_dwconv3x3_flat2_ok", "oss_dwconv3x3_silu_flat2_fwd",
            "oss_dwconv3x3_silu_flat2_bwd",
            "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_fwd_pool", "oss_ln_nchw_fwd_pool_tiles", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_conv1x1_dgrad_ln_bwd_ok",
            "oss_conv1x1_dgrad_ln_bwd_partial_floats", "oss_conv1x1_dgrad_ln_bwd", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
-           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_chan_fwd", "oss_chan_grad_floats",
+           "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_proj_rows_optional_ok", "oss_chan_fwd", "oss_chan_grad_floats",
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
            "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
            "oss_flush_finishes", "oss_set_defer_wgrad", "oss_deferred_wgrads", "oss_deferred_wgrad_table_bytes", "oss_flush_wgrads",
@@ -132,6 +133,10 @@ def load():
     lib.oss_scan_last_segments.argtypes = [C.c_int]
     lib.oss_scan_bwd.restype = C.c_int
     lib.oss_scan_bwd.argtypes = [C.POINTER(ScanBwdParams), C.c_int, C.c_void_p]
+    lib.oss_proj_rows_optional_ok.restype = C.c_int
+    lib.oss_proj_rows_optional_ok.argtypes = [C.c_int] * 6
+    lib.oss_scan_bwd_finish_dt_ok.restype = C.c_int
+    lib.oss_scan_bwd_finish_dt_ok.argtypes = [C.c_int, C.c_int]
     lib.oss_scan_fused_dt_ok.restype = C.c_int
     lib.oss_scan_fused_dt_ok.argtypes = [C.c_int] * 7
     lib.oss_scan_set_variant.restype = None

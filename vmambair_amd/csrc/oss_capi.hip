@@ -311,6 +311,8 @@ size_t oss_scan_fwd_workspace_bytes(int batch, int dim, int seqlen, int dstate, 
     return segs > 1 ? scan_carry_bytes(batch, dim, dstate, segs) : 0;
 }
 
+int oss_scan_bwd_finish_dt_ok(int seqlen, int dt_rank) { return scan_finish_dt_ok(seqlen, dt_rank) ? 1 : 0; }
+
 int oss_scan_bwd(const oss_scan_bwd_params *p, oss_dtype io, oss_stream_t stream) {
     if (!p) return OSS_ERR_NULL;
     int rc = check_fwd(&p->f);
@@ -477,6 +479,9 @@ int oss_proj_dgrad(oss_dtype io, const void *ddts, void *dxdbl, const void *du, 
 }
 
 void oss_proj_set_path(int force_vector_alu) { proj_force_valu(force_vector_alu); }
+int oss_proj_rows_optional_ok(oss_dtype io, int batch, int D, int C, int R, int seqlen) {
+    return proj_mfma_ok(io, batch, D, C, R, seqlen) ? 1 : 0;
+}
 int oss_scan_fused_dt_ok(oss_dtype io, int batch, int D, int C, int R, int dstate, int seqlen) {
     return kBuildFusedDt && proj_mfma_ok(io, batch, D, C, R, seqlen) && R >= 1 && R <= kMaxDtRank && dstate <= 64 && seqlen >= 512;
 }

@@ -59,6 +59,8 @@ extern std::atomic<int> g_last_fwd_segments, g_last_bwd_segments, g_last_bwd_lan
 // wgs * (n_seg - 1) * c <= 512 (heuristic), whose n_seg * c carry slots fit what the workspace queries allow.  A main segment
 // of cps chunks is cut into c pieces of ceil(cps / c) chunks, the last one shorter (oss_scan_set_carry_split)
 int scan_carry_split(long wgs, int n_seg, int cps, int n_chunks, int per_call = 0);
+// the dt-factor gradient inside the backward's finishing launch (oss_scan_bwd_params.finish_dt_weight): whole 8 / 16-byte quads
+inline bool scan_finish_dt_ok(int seqlen, int rank) { return seqlen > 0 && seqlen % 4 == 0 && rank >= 1 && rank <= 8; }
 template <typename T> int scan_fwd_dispatch(const oss_scan_fwd_params &p, int variant, int seg_req, hipStream_t stream);
 // one timer brackets the MAIN backward kernel, a second one the finishing kernel (oss_prof_* buckets 1 and 2)
 struct LaunchTimer {

@@ -372,16 +372,89 @@ struct FinishArgs {
     int64_t A_d_stride;
     size_t out_group_stride;    // (batch, group) block stride of dB and of dC
     int64_t dz_batch_stride, dz_group_stride, dz_rank_stride;
+    // (round 6) the dt-factor gradient in the same launch (oss_scan_bwd_params.finish_dt_weight): extra z-slabs of the grid run
+    //   dZ[b, g, r, t] = sum over the rows d of group g of dtw[d, r] * ddelta[b, d, t]
+    // -- what oss_dt_dgrad_kernel (oss_proj.hip) did as the NEXT launch of the block's backward -- next to the partial-row sums
+    const void *ddelta;
+    int64_t dd_batch_stride, dd_d_stride;
+    const float *dtw;
+    int dtR;                    // 0 = off
+    unsigned dt_blocks;         // B * G * ceil(L / 1024)
 };
 // grid = (ceil(L / (256 V)), 2 N + R output rows, batch * G + 1): no index arithmetic beyond one multiply-add per pointer; the
 // last z-slab runs the weight-gradient sums (grid-stride).  V = 4: every lane adds four consecutive time steps with 16-byte
 // loads of the partial rows (a wave's 4-byte loads move 256 bytes per instruction -- the V = 1 form spent its time issuing
 // loads, 0.033 ms for 134 MB at u:(8,384,4096)); needs L % 4 == 0 and 8-byte aligned outputs, else V = 1.
+// the dt-factor gradient of one (batch, group, 1024-step slice): a wave owns 256 steps (lane = 4 consecutive ones, 8-byte loads
+// for the 16-bit types) and walks ALL rows of the group itself -- no cross-wave sum, no LDS; sixteen rows in flight per pass.
+// A row's dt_rank weights ride in the lanes (lane r = w[r]; v_readlane), as in oss_dt_dgrad_kernel.  Needs L % 4 == 0.
+template <typename T>
+__device__ __forceinline__ void finish_dt_body(const FinishArgs &a, unsigned blk) {
+    constexpr int DU = 16, RM = 8;
+    const unsigned per = (unsigned)((a.L + 1023) / 1024);
+    const unsigned bg = blk / per, sl = blk - bg * per;
+    const unsigned b = bg / (unsigned)a.G, g = bg - b * (unsigned)a.G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t t = (size_t)sl * 1024 + (size_t)(wave * 64 + lane) * 4;
+    const bool ok = t < a.L;
+    const size_t tc = ok ? t : 0;
+    const int rows = a.dim / a.G, R = a.dtR;
+    const T *src = reinterpret_cast<const T *>(a.ddelta) + (size_t)b * a.dd_batch_stride + (size_t)g * rows * a.dd_d_stride + tc;
+    const float *wg = a.dtw + (size_t)g * rows * R;
+    float acc[RM][4];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[r][i] = 0.f;
+    const int rl = min(lane, R - 1);
+    for (int d0 = 0; d0 < rows; d0 += DU) {
+        float gq[DU][4], wl[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {   // clamped rows, masked through a zero weight: the loads stay one group
+            const int d = min(d0 + u, rows - 1);
+            const T *q = src + (size_t)d * a.dd_d_stride;
+            if constexpr (sizeof(T) == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(q);
+                gq[u][0] = v.x; gq[u][1] = v.y; gq[u][2] = v.z; gq[u][3] = v.w;
+            } else {
+                const u32x2 v = *reinterpret_cast<const u32x2 *>(q);
+                unpack2<T>(v.x, gq[u][0], gq[u][1]);
+                unpack2<T>(v.y, gq[u][2], gq[u][3]);
+            }
+            wl[u] = (lane < R && d0 + u < rows) ? wg[(size_t)d * R + rl] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u)
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl[u]), r));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[r][i] = __builtin_fmaf(wv, gq[u][i], acc[r][i]);
+            }
+    }
+    if (!ok) return;
+    T *dst = reinterpret_cast<T *>(a.dZ) + (size_t)b * a.dz_batch_stride + (size_t)g * a.dz_group_stride + t;
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+        if (r < R) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<f32x4 *>(dst + (size_t)r * a.dz_rank_stride) = f32x4{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            } else {
+                *reinterpret_cast<u32x2 *>(dst + (size_t)r * a.dz_rank_stride) = u32x2{pack2<T>(acc[r][0], acc[r][1]), pack2<T>(acc[r][2], acc[r][3])};
+            }
+        }
+}
+
 // PB: the partial rows are bf16 (oss_scan_bwd_v2.h: kPartialsBf16 -- the round-2 kernels at bf16 I/O), same element layout
 template <typename T, int V, bool PB = false>
 __global__ void __launch_bounds__(256)
 oss_scan_bwd_finish(const FinishArgs a) {
     const size_t n_bg = (size_t)a.batch * a.G;
+    if (blockIdx.z > n_bg) {   // z-slabs behind the weight-gradient slab: the dt-factor gradient, one 1024-step slice per workgroup
+        const unsigned blk = (unsigned)((blockIdx.z - n_bg - 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (blk < a.dt_blocks) finish_dt_body<T>(a, blk);
+        return;
+    }
     if (blockIdx.z >= n_bg) {
         const int total_w = a.dim * a.N + a.dim + a.dim * a.R;
         const int stride = (int)(gridDim.x * gridDim.y) * 256;
@@ -496,6 +569,20 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
     a.A_log = f.a_log_form ? f.A : nullptr; a.A_d_stride = f.A_d_stride;
     a.out_group_stride = p.dBC_group_stride > 0 ? (size_t)p.dBC_group_stride : (size_t)f.dstate * f.seqlen;
     a.dz_batch_stride = p.ddt_batch_stride; a.dz_group_stride = p.ddt_group_stride; a.dz_rank_stride = p.ddt_rank_stride;
+    // the dt-factor gradient in this launch (finish_dt_weight; never together with the fused-delta form, which has its own rows)
+    a.ddelta = p.ddelta; a.dd_batch_stride = p.ddelta_batch_stride; a.dd_d_stride = p.ddelta_d_stride;
+    a.dtw = nullptr; a.dtR = 0; a.dt_blocks = 0;
+    const bool want_dt = p.finish_dt_weight != nullptr;
+    if (want_dt) {
+        if (f.dt_weight || !p.ddt || !p.ddelta || !scan_finish_dt_ok(f.seqlen, p.finish_dt_rank)) return OSS_ERR_SHAPE;
+        const auto al8 = [](const void *q, size_t m) { return (reinterpret_cast<uintptr_t>(q) & (m - 1)) == 0; };
+        const size_t va = sizeof(T) == 4 ? 16 : 8;
+        if (!al8(p.ddelta, va) || !al8(p.ddt, va) || p.ddelta_batch_stride % 4 || p.ddelta_d_stride % 4 || p.ddt_batch_stride % 4 ||
+            p.ddt_group_stride % 4 || p.ddt_rank_stride % 4)
+            return OSS_ERR_SHAPE;
+        a.dtw = p.finish_dt_weight; a.dtR = p.finish_dt_rank; a.dZ = p.ddt;
+        a.dt_blocks = (unsigned)((size_t)f.batch * f.n_groups * ((f.seqlen + 1023) / 1024));
+    }
     if ((size_t)f.batch * f.n_groups + 1 > 65535 || 2 * f.dstate + a.R > 65535) return OSS_ERR_SHAPE;
     // four time steps per lane when every partial row and every output row starts 16 / 8-byte aligned
     const auto al = [](const void *q, size_t m) { return (reinterpret_cast<uintptr_t>(q) & (m - 1)) == 0; };
@@ -503,7 +590,10 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
     bool vec = f.seqlen % 4 == 0 && a.out_group_stride % 4 == 0 && al(ws.bc, 16) && al(p.dB, oa) && al(p.dC, oa);
     if (a.R) vec = vec && al(p.ddt, oa) && a.dz_batch_stride % 4 == 0 && a.dz_group_stride % 4 == 0 && a.dz_rank_stride % 4 == 0;
     const int V = vec ? 4 : 1;
-    const dim3 grid((unsigned)((f.seqlen + 256 * V - 1) / (256 * V)), (unsigned)(2 * f.dstate + a.R), (unsigned)(f.batch * f.n_groups + 1));
+    const unsigned gx = (unsigned)((f.seqlen + 256 * V - 1) / (256 * V)), gy = (unsigned)(2 * f.dstate + a.R);
+    const unsigned dt_slabs = a.dt_blocks ? (a.dt_blocks + gx * gy - 1) / (gx * gy) : 0;
+    if ((size_t)f.batch * f.n_groups + 1 + dt_slabs > 65535) return OSS_ERR_SHAPE;
+    const dim3 grid(gx, gy, (unsigned)(f.batch * f.n_groups + 1) + dt_slabs);
     if (g_finish_timer) g_finish_timer->begin(stream);
     if (vec) hipLaunchKernelGGL((oss_scan_bwd_finish<T, 4, PB>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((oss_scan_bwd_finish<T, 1, PB>), grid, dim3(256), 0, stream, a);
@@ -562,9 +652,9 @@ static int launch_bwd2(const oss_scan_bwd_params &p, int seg_req, hipStream_t st
     const int rows_per_group = f.dim / f.n_groups;
     const int tiles = (rows_per_group + WAVES - 1) / WAVES;
     if constexpr (!PB && kPartialsBf16Ok<T, FD>) {
-        // bf16 row-tile partials (oss_scan_bwd_v2.h: kV2Bf16Partials): few tiles, no lane states, not switched off for this call
+        // bf16 row-tile partials (oss_scan_bwd_v2.h: kV2Bf16Partials): only when THIS call asks for them (tune_partials == 2)
         const bool lane_states = kBuildLaneStates && f.hs != nullptr;
-        if (tiles <= kMaxBf16PartialTiles && !lane_states && p.tune_partials != 1)
+        if (p.tune_partials == 2 && !lane_states)
             return launch_bwd2<T, WAVES, NBB, MINW, false, true>(p, seg_req, stream, timer);
     }
     const unsigned wgs = (unsigned)(f.batch * f.n_groups * tiles);

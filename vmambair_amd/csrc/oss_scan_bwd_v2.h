@@ -118,23 +118,20 @@ constexpr bool kV2EdgeLanes = false;
 #else
 constexpr bool kV2EdgeLanes = true;
 #endif
-// round 6: the workgroup's dB / dC row-tile partials -- written here, re-read by oss_scan_bwd_finish -- were
-// 268 of the call's 417 MB of HBM traffic at u:(8,384,4096) bf16 (algorithmic: 142).  With bf16 I/O the final dB / dC are rounded
-// to bf16 anyway, so the partials (each already the fp32 sum of the tile's <= 12 rows) go out as bf16: half the partial bytes both
-// ways.  What changes numerically: <= 8 tile partials are rounded to 8 bits of mantissa BEFORE their fp32 sum is rounded once more
-// -- an extra relative error of at most 2^-9 per partial on a result that carries 2^-9 itself; the reference's tolerance for
-// bf16 gradients is rtol 3e-2 / atol 5e-2 (test_selective_scan.py:400,490-502).  fp16 I/O keeps fp32 partials (10 bits of
-// mantissa to protect, a 65504 range to overflow), so does fp32 I/O and the fused-delta form.  OSS_EXP_V2_F32_PARTIALS: A-B.
+// round 6: the workgroup's dB / dC row-tile partials -- written here, re-read by oss_scan_bwd_finish -- are
+// 268 of the call's 417 MB of HBM traffic at u:(8,384,4096) bf16 (algorithmic: 142).  OPT-IN per call (oss_scan_bwd_params.
+// tune_partials = 2, bf16 I/O only): the partials (each already the fp32 sum of the tile's <= 12 rows) go out as bf16 -- half the
+// partial bytes both ways, traffic 2.9 x -> 2.0 x algorithmic, finishing kernel 18 -> 10 us, headline step +1.7 %
+// (profiles/r06_ab_bf16_partials.txt).  NOT the default, because it is not free numerically: every partial is rounded to 8 bits of
+// mantissa BEFORE the tiles are summed, an absolute error of 2^-9 x |partial| that survives when the tiles cancel -- at the
+// reference's own test grid (randn inputs, |dB| up to 83) one element in 131 072 left the reference's bf16 tolerance (atol 5e-2,
+// test_selective_scan.py:400,490-502) with only TWO tiles.  The default keeps the reference's fp32 accumulation
+// (cus/selective_scan_bwd_kernel.cuh:208-221) to the letter.  OSS_EXP_V2_F32_PARTIALS compiles the bf16 form out.
 #ifdef OSS_EXP_V2_F32_PARTIALS
 constexpr bool kV2Bf16Partials = false;
 #else
 constexpr bool kV2Bf16Partials = true;
 #endif
-// ... and only where at most kMaxBf16PartialTiles partials are summed: the added error is bounded by tiles x 2^-9 x max|partial|
-// (random signs: sqrt(tiles / 3) x 2^-9), the size of what rounding the kernel's bf16 INPUTS already puts into a sum over the
-// group's rows; with 32 - 64 tiles (the reference's test grid: 768 rows per group) one element in 1e5 left the reference's atol.
-// oss_scan_bwd_params.tune_partials = 1 forces fp32 partials for a call.
-constexpr int kMaxBf16PartialTiles = 8;
 template <typename T, bool FD> constexpr bool kPartialsBf16Ok = kV2Bf16Partials && !FD && std::is_same<T, bf16_t>::value;
 // SlabQ: one row's dB (or dC) terms of one state, 512 scan positions = 64 lanes x 2 quads.  The round-2 image was time order
 // (lane p wrote its quads at floats 8p and 8p + 4: a 32-byte lane stride, so a 16-lane phase of a ds_write_b128 covered only

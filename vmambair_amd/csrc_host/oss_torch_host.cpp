@@ -205,7 +205,7 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
                              const OptTensor &D, const OptTensor &delta_bias, const Tensor &dout, const OptTensor &x,
                              bool delta_softplus, int64_t rev_group_start, int64_t u_row_mod, int64_t dout_row_mod, bool a_log_form,
                              const OptTensor &dbc_into, const OptTensor &dt_weight, const OptTensor &hs, int64_t tune_variant,
-                             int64_t tune_segments, int64_t tune_carry_split, int64_t tune_partials) {
+                             int64_t tune_segments, int64_t tune_carry_split, int64_t tune_partials, const OptTensor &finish_dt_weight) {
     const Dims d = common_checks(u, delta, A, B, C, D, delta_bias, u_row_mod, dt_weight);
     TORCH_CHECK(dout.scalar_type() == u.scalar_type() && dout.is_cuda(), "dout must be a CUDA/HIP tensor of u's dtype");
     TORCH_CHECK(dout.dim() == 3 && dout.size(0) == d.batch && dout.size(1) == (dout_row_mod ? dout_row_mod : d.dim) &&
@@ -286,6 +286,17 @@ std::vector<Tensor> scan_bwd(const Tensor &u, const Tensor &delta, const Tensor 
     P.dBC_group_stride = into ? dbc_into->stride(1) : 0;
     P.tune_variant = (int)tune_variant; P.tune_segments = (int)tune_segments; P.f.tune_carry_split = (int)tune_carry_split;
     P.tune_partials = (int)tune_partials;
+    if (finish_dt_weight.has_value() && finish_dt_weight->defined()) {   // the dt-factor gradient in the finishing launch
+        const Tensor &w = *finish_dt_weight;
+        TORCH_CHECK(!fused && into, "finish_dt_weight needs dbc_into and the materialised-delta form");
+        TORCH_CHECK(w.scalar_type() == at::kFloat && w.is_cuda() && w.is_contiguous() && w.dim() == 2 && w.size(0) == d.dim,
+                    "finish_dt_weight must be a contiguous (dim, R) float32 tensor");
+        TORCH_CHECK(oss_scan_bwd_finish_dt_ok((int)d.seqlen, (int)w.size(1)), "finish_dt_weight: rank <= 8 and seqlen % 4 == 0");
+        P.finish_dt_weight = w.data_ptr<float>();
+        P.finish_dt_rank = (int)w.size(1);
+        P.ddt = dbc_into->data_ptr();
+        P.ddt_batch_stride = dbc_into->stride(0); P.ddt_group_stride = dbc_into->stride(1); P.ddt_rank_stride = dbc_into->stride(2);
+    }
     hipStream_t stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     abi_check_once();
     check_rc(oss_scan_bwd(&P, io_of(u), reinterpret_cast<oss_stream_t>(stream)), "oss_scan_bwd");
@@ -308,7 +319,7 @@ TORCH_LIBRARY(vmambair_host, m) {
           "int tune_segments=0, int tune_carry_split=0) -> Tensor[]");
     m.def("scan_bwd(Tensor u, Tensor delta, Tensor A, Tensor B, Tensor C, Tensor? D, Tensor? delta_bias, Tensor dout, Tensor? x, "
           "bool delta_softplus, int rev_group_start, int u_row_mod, int dout_row_mod, bool a_log_form, Tensor(a!)? dbc_into, "
-          "Tensor? dt_weight, Tensor? hs, int tune_variant=0, int tune_segments=0, int tune_carry_split=0, int tune_partials=0) -> Tensor[]");
+          "Tensor? dt_weight, Tensor? hs, int tune_variant=0, int tune_segments=0, int tune_carry_split=0, int tune_partials=0, Tensor? finish_dt_weight=None) -> Tensor[]");
 }
 
 TORCH_LIBRARY_IMPL(vmambair_host, CUDA, m) {

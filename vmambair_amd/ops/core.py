@@ -31,6 +31,14 @@ def core_supported(D: int, R: int, N: int) -> bool:
 #: it moves into them are not; the two kernels it retires (oss_dt_fwd / oss_dt_dgrad, 13 us each) run at the HBM roof.
 FUSED_DT = os.environ.get("VMAMBAIR_FUSED_DT", "0") == "1"
 
+#: ``VMAMBAIR_SCAN_BF16_PARTIALS=1``: the spatial scans' backward writes its dB / dC row-tile partials as bf16 (opt-in, A-B timing:
+#: include/vmambair_oss.h: oss_scan_bwd_params.tune_partials; not parity-safe at the reference's bf16 atol)
+BF16_PARTIALS = os.environ.get("VMAMBAIR_SCAN_BF16_PARTIALS", "0") == "1"
+
+#: ``VMAMBAIR_FINISH_DT=0``: the adjoint of dt_proj stays a launch of its own (oss_dt_dgrad_kernel inside oss_proj_dgrad) instead of
+#: extra workgroups of the scan backward's finishing launch (include/vmambair_oss.h: oss_scan_bwd_params.finish_dt_weight) -- A-B timing
+FINISH_DT = os.environ.get("VMAMBAIR_FINISH_DT", "1") == "1"
+
 
 def fused_dt_supported(dtype: torch.dtype, B: int, D: int, Cc: int, R: int, N: int, L: int) -> bool:
     """delta computed inside the scan kernels: 16-bit I/O, dt_rank <= 8, L >= 512 (include/vmambair_oss.h)"""
@@ -201,13 +209,19 @@ def ss2d_core_bwd(dy: torch.Tensor, x2: torch.Tensor, xdbl: torch.Tensor, dts: t
     g2 = cross_scan2(dy, x2.dtype)
     dxdbl = torch.empty((B, 4, Cc, L), dtype=x2.dtype, device=x2.device)
     fused = dts.numel() == 0 and x2.numel() > 0   # the forward ran the fused-delta form
+    # (round 6) the dt rows of dxdbl from the scan backward's finishing launch instead of a launch of their own (oss_dt_dgrad)
+    fin_dt = FINISH_DT and not fused and x2.numel() > 0 and bool(_capi.load().oss_scan_bwd_finish_dt_ok(L, R)) and \
+        bool(_capi.load().oss_proj_rows_optional_ok(_DT[x2.dtype], B, D, Cc, R, L))
     res = selective_scan_bwd(
         x2.view(B, 2 * D, L), xdbl if fused else dts, A_logs.detach().float(), xdbl[:, :, R:R + N], xdbl[:, :, R + N:],
         Ds.detach().float(), dt_bias.detach().float().reshape(-1), g2.view(B, 2 * D, L), states, True, 1, 2, 2 * D, 2 * D, True,
         dbc_into=dxdbl, dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fused else None,
-        hs=lane_states if (lane_states is not None and lane_states.numel()) else None)
+        hs=lane_states if (lane_states is not None and lane_states.numel()) else None,
+        finish_dt_weight=dt_projs_weight.detach().float().reshape(4 * D, R) if fin_dt else None,
+        tune=(None, None, None, "bf16") if BF16_PARTIALS else None)
     du, ddts, dA, _, _, dD, dbias = res[:7]
-    dx2 = proj_dgrad(ddts, dxdbl, du, x_proj_weight, dt_projs_weight)   # fused: every row of dxdbl is already in place
+    # fused / fin_dt: every row of dxdbl is already in place
+    dx2 = proj_dgrad(None if fin_dt else ddts, dxdbl, du, x_proj_weight, dt_projs_weight)
     dx = cross_merge2(dx2, H, W) if merge else dx2   # merge = False: the caller's depth-wise-conv backward reads both flattenings
     dwx, dwdt = proj_wgrad(x2, xdbl, dxdbl, ddts, R)
     if fused:

@@ -103,13 +103,13 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
 
 
 def _tune_fields(tune):
-    """``(variant, segments, carry_split[, fp32_partials])`` with None = heuristic -> the C struct's encoding (0 = heuristic,
-    variant + 1; fp32_partials True -> oss_scan_bwd_params.tune_partials = 1, backward only)"""
+    """``(variant, segments, carry_split[, partials])`` with None = heuristic -> the C struct's encoding (0 = heuristic,
+    variant + 1; partials "bf16" -> oss_scan_bwd_params.tune_partials = 2, backward only: bf16 row-tile partials, opt-in)"""
     if tune is None:
         return 0, 0, 0, 0
     v, s, c, f = (tuple(tune) + (None, None, None, None))[:4]
     return ((0 if v is None or v < 0 else int(v) + 1), (0 if s is None or s < 0 else max(1, int(s))), (0 if c is None or c <= 0 else int(c)),
-            (1 if f else 0))
+            (2 if f == "bf16" else 0))
 
 
 def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
@@ -168,18 +168,22 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
                        dout_row_mod: int = 0, a_log_form: bool = False,
                        dbc_into: Optional[torch.Tensor] = None,
                        dt_weight: Optional[torch.Tensor] = None,
-                       hs: Optional[torch.Tensor] = None, tune: Optional[tuple] = None) -> List[Optional[torch.Tensor]]:
+                       hs: Optional[torch.Tensor] = None, tune: Optional[tuple] = None,
+                       finish_dt_weight: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """``selective_scan_cuda_core.bwd`` (cus/selective_scan.cpp:241-349) ->
     ``[du, ddelta, dA, dB, dC, dD, ddelta_bias]`` (the last two ``None`` when absent).  In the omni
     form ``du`` has ``dim`` rows (one per direction); the caller adds the rows that share ``u``.
     With ``dt_weight`` (delta computed inside the scan; needs ``dbc_into``): ``ddelta`` is ``None``, the gradient of the rank
-    factor lands in the first R rows of ``dbc_into`` and an eighth entry, the (dim, R) gradient of ``dt_weight``, is returned."""
+    factor lands in the first R rows of ``dbc_into`` and an eighth entry, the (dim, R) gradient of ``dt_weight``, is returned.
+    ``finish_dt_weight`` (dim, R) fp32 (needs ``dbc_into``, not together with ``dt_weight``): ``ddelta`` is returned as usual AND the
+    finishing launch fills the first R rows of ``dbc_into`` with ``dt_projs_weight^T . ddelta`` -- the dt rows of the gradient of
+    x_dbl, which ``oss_proj_dgrad`` is then not asked for (include/vmambair_oss.h: oss_scan_bwd_params.finish_dt_weight)."""
     tv, ts, tc, tp = _tune_fields(tune)
     host = _host.ops()
     if host is not None and u.is_cuda:   # compiled boundary: [du, ddelta, dA, dB, dC, dD, dbias, ddt_weight], empty = absent
         r = host.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, bool(delta_softplus),
                           -1 if rev_group_start is None else int(rev_group_start), int(u_row_mod), int(dout_row_mod), bool(a_log_form),
-                          dbc_into, dt_weight, hs, tv, ts, tc, tp)
+                          dbc_into, dt_weight, hs, tv, ts, tc, tp, finish_dt_weight)
         du, ddelta, dA, dB, dC, dD, dbias, ddtw = r
         if dbc_into is not None:   # written in place (a mutated argument is not returned): the views are made here
             rows, N = dbc_into.shape[2], A.shape[1]
@@ -243,6 +247,14 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     P.dout_row_mod = int(dout_row_mod)
     P.dBC_group_stride = 0 if dbc_into is None else dbc_into.stride(1)
     P.tune_variant, P.tune_segments, P.f.tune_carry_split, P.tune_partials = tv, ts, tc, tp
+    if finish_dt_weight is not None:
+        _check(not fused and dbc_into is not None, "finish_dt_weight needs dbc_into and the materialised-delta form")
+        _check(finish_dt_weight.dtype == torch.float32 and finish_dt_weight.is_cuda and finish_dt_weight.is_contiguous() and
+               finish_dt_weight.dim() == 2 and finish_dt_weight.shape[0] == dim, "finish_dt_weight must be a contiguous (dim, R) float32 tensor")
+        _check(bool(lib.oss_scan_bwd_finish_dt_ok(seqlen, finish_dt_weight.shape[1])), "finish_dt_weight: rank <= 8 and seqlen % 4 == 0")
+        P.finish_dt_weight, P.finish_dt_rank = finish_dt_weight.data_ptr(), finish_dt_weight.shape[1]
+        P.ddt = dbc_into.data_ptr()
+        P.ddt_batch_stride, P.ddt_group_stride, P.ddt_rank_stride = dbc_into.stride(0), dbc_into.stride(1), dbc_into.stride(2)
     with torch.cuda.device(u.device):
         stream = torch.cuda.current_stream().cuda_stream
         _capi.check(lib.oss_scan_bwd(P, _DT[u.dtype], stream), "oss_scan_bwd")
