@@ -379,23 +379,27 @@ struct FinishArgs {
     int64_t dd_batch_stride, dd_d_stride;
     const float *dtw;
     int dtR;                    // 0 = off
-    unsigned dt_blocks;         // B * G * ceil(L / 1024)
+    unsigned dt_blocks;         // B * G * ceil(L / 256)
 };
 // grid = (ceil(L / (256 V)), 2 N + R output rows, batch * G + 1): no index arithmetic beyond one multiply-add per pointer; the
 // last z-slab runs the weight-gradient sums (grid-stride).  V = 4: every lane adds four consecutive time steps with 16-byte
 // loads of the partial rows (a wave's 4-byte loads move 256 bytes per instruction -- the V = 1 form spent its time issuing
 // loads, 0.033 ms for 134 MB at u:(8,384,4096)); needs L % 4 == 0 and 8-byte aligned outputs, else V = 1.
-// the dt-factor gradient of one (batch, group, 1024-step slice): a wave owns 256 steps (lane = 4 consecutive ones, 8-byte loads
-// for the 16-bit types) and walks ALL rows of the group itself -- no cross-wave sum, no LDS; sixteen rows in flight per pass.
-// A row's dt_rank weights ride in the lanes (lane r = w[r]; v_readlane), as in oss_dt_dgrad_kernel.  Needs L % 4 == 0.
+// the dt-factor gradient of one (batch, group, 256-step slice): lane = 4 consecutive steps (8-byte loads for the 16-bit types), the
+// block's four waves split the group's rows (wave w: rows w, w + 4, ...; twelve in flight per pass) and are added through LDS in
+// wave order (32 KB).  A row's dt_rank weights ride in the lanes (lane r = w[r]; v_readlane), as in oss_dt_dgrad_kernel.
+// (First version: one wave walked all rows of its 256 steps -- 96 dependent loads on 512 waves made these workgroups the long pole
+// of the launch, 40 us against 24 + 12 for the two separate launches.)  Needs L % 4 == 0.
+constexpr int kFinishDtSteps = 256;
 template <typename T>
 __device__ __forceinline__ void finish_dt_body(const FinishArgs &a, unsigned blk) {
-    constexpr int DU = 16, RM = 8;
-    const unsigned per = (unsigned)((a.L + 1023) / 1024);
+    constexpr int DU = 12, RM = 8, NW = 4;
+    __shared__ float red[NW * RM * kFinishDtSteps];
+    const unsigned per = (unsigned)((a.L + kFinishDtSteps - 1) / kFinishDtSteps);
     const unsigned bg = blk / per, sl = blk - bg * per;
     const unsigned b = bg / (unsigned)a.G, g = bg - b * (unsigned)a.G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t t = (size_t)sl * 1024 + (size_t)(wave * 64 + lane) * 4;
+    const size_t t = (size_t)sl * kFinishDtSteps + (size_t)lane * 4;
     const bool ok = t < a.L;
     const size_t tc = ok ? t : 0;
     const int rows = a.dim / a.G, R = a.dtR;
@@ -407,11 +411,11 @@ __device__ __forceinline__ void finish_dt_body(const FinishArgs &a, unsigned blk
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[r][i] = 0.f;
     const int rl = min(lane, R - 1);
-    for (int d0 = 0; d0 < rows; d0 += DU) {
+    for (int d0 = wave; d0 < rows; d0 += DU * NW) {
         float gq[DU][4], wl[DU];
 #pragma unroll
         for (int u = 0; u < DU; ++u) {   // clamped rows, masked through a zero weight: the loads stay one group
-            const int d = min(d0 + u, rows - 1);
+            const int dd = d0 + u * NW, d = min(dd, rows - 1);
             const T *q = src + (size_t)d * a.dd_d_stride;
             if constexpr (sizeof(T) == 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(q);
@@ -421,7 +425,7 @@ __device__ __forceinline__ void finish_dt_body(const FinishArgs &a, unsigned blk
                 unpack2<T>(v.x, gq[u][0], gq[u][1]);
                 unpack2<T>(v.y, gq[u][2], gq[u][3]);
             }
-            wl[u] = (lane < R && d0 + u < rows) ? wg[(size_t)d * R + rl] : 0.f;
+            wl[u] = (lane < R && dd < rows) ? wg[(size_t)d * R + rl] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < DU; ++u)
@@ -432,17 +436,26 @@ __device__ __forceinline__ void finish_dt_body(const FinishArgs &a, unsigned blk
                 for (int i = 0; i < 4; ++i) acc[r][i] = __builtin_fmaf(wv, gq[u][i], acc[r][i]);
             }
     }
-    if (!ok) return;
-    T *dst = reinterpret_cast<T *>(a.dZ) + (size_t)b * a.dz_batch_stride + (size_t)g * a.dz_group_stride + t;
 #pragma unroll
     for (int r = 0; r < RM; ++r)
-        if (r < R) {
+        *reinterpret_cast<f32x4 *>(red + (wave * RM + r) * kFinishDtSteps + lane * 4) = f32x4{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+    __syncthreads();
+    T *dst = reinterpret_cast<T *>(a.dZ) + (size_t)b * a.dz_batch_stride + (size_t)g * a.dz_group_stride + t;
+    for (int r = wave; r < R; r += NW) {
+        f32x4 sum = *reinterpret_cast<const f32x4 *>(red + r * kFinishDtSteps + lane * 4);
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(red + (w2 * RM + r) * kFinishDtSteps + lane * 4);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        if (ok) {
             if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<f32x4 *>(dst + (size_t)r * a.dz_rank_stride) = f32x4{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+                *reinterpret_cast<f32x4 *>(dst + (size_t)r * a.dz_rank_stride) = sum;
             } else {
-                *reinterpret_cast<u32x2 *>(dst + (size_t)r * a.dz_rank_stride) = u32x2{pack2<T>(acc[r][0], acc[r][1]), pack2<T>(acc[r][2], acc[r][3])};
+                *reinterpret_cast<u32x2 *>(dst + (size_t)r * a.dz_rank_stride) = u32x2{pack2<T>(sum.x, sum.y), pack2<T>(sum.z, sum.w)};
             }
         }
+    }
 }
 
 // PB: the partial rows are bf16 (oss_scan_bwd_v2.h: kPartialsBf16 -- the round-2 kernels at bf16 I/O), same element layout
@@ -450,12 +463,17 @@ template <typename T, int V, bool PB = false>
 __global__ void __launch_bounds__(256)
 oss_scan_bwd_finish(const FinishArgs a) {
     const size_t n_bg = (size_t)a.batch * a.G;
-    if (blockIdx.z > n_bg) {   // z-slabs behind the weight-gradient slab: the dt-factor gradient, one 1024-step slice per workgroup
-        const unsigned blk = (unsigned)((blockIdx.z - n_bg - 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // z-slabs [0, dt_slabs): the dt-factor gradient, one 256-step slice per workgroup -- FIRST, so that these (longer) workgroups
+    // start with the launch and the partial-row sums fill in around them; then batch * G slabs of partial-row sums; the last
+    // slab reduces the weight-gradient partials
+    const unsigned dt_slabs = a.dt_blocks ? (a.dt_blocks + gridDim.x * gridDim.y - 1) / (gridDim.x * gridDim.y) : 0;
+    if (blockIdx.z < dt_slabs) {
+        const unsigned blk = (unsigned)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (blk < a.dt_blocks) finish_dt_body<T>(a, blk);
         return;
     }
-    if (blockIdx.z >= n_bg) {
+    const size_t bz = blockIdx.z - dt_slabs;
+    if (bz >= n_bg) {
         const int total_w = a.dim * a.N + a.dim + a.dim * a.R;
         const int stride = (int)(gridDim.x * gridDim.y) * 256;
         for (int i = (int)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x; i < total_w; i += stride)
@@ -464,7 +482,7 @@ oss_scan_bwd_finish(const FinishArgs a) {
     }
     const size_t t = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
     if (t >= a.L) return;
-    const size_t row = blockIdx.y, bg = blockIdx.z;
+    const size_t row = blockIdx.y, bg = bz;
     const size_t pt = (2 * (size_t)a.N + a.RP) * a.L;   // partial floats per (b, g, tile)
     using PT = typename std::conditional<PB, bf16_t, float>::type;
     const PT *base = reinterpret_cast<const PT *>(a.ws_bc) + bg * a.tiles * pt + row * a.L + t;
@@ -581,7 +599,7 @@ static int launch_finish(const oss_scan_bwd_params &p, const BwdWs &ws, float *w
             p.ddt_group_stride % 4 || p.ddt_rank_stride % 4)
             return OSS_ERR_SHAPE;
         a.dtw = p.finish_dt_weight; a.dtR = p.finish_dt_rank; a.dZ = p.ddt;
-        a.dt_blocks = (unsigned)((size_t)f.batch * f.n_groups * ((f.seqlen + 1023) / 1024));
+        a.dt_blocks = (unsigned)((size_t)f.batch * f.n_groups * ((f.seqlen + kFinishDtSteps - 1) / kFinishDtSteps));
     }
     if ((size_t)f.batch * f.n_groups + 1 > 65535 || 2 * f.dstate + a.R > 65535) return OSS_ERR_SHAPE;
     // four time steps per lane when every partial row and every output row starts 16 / 8-byte aligned
