@@ -538,6 +538,44 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_preflight(dev, nbytes, world, timeout_s=120.0):
+    """The first RCCL collective of the process, before anything is captured: an all-reduce of the size of the gradient exchange
+    (one warm call creates the communicators, a second one is timed), run in a watchdog thread so that a hang becomes a reason
+    instead of a dead job.  -> (ok, reason or None, ms or None)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            t = torch.ones(max(1, nbytes // 4), dtype=torch.float32, device=dev)
+            dist.all_reduce(t)
+            torch.cuda.current_stream().synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(t)
+            e1.record()
+            e1.synchronize()
+            box["ms"] = e0.elapsed_time(e1)
+            box["sum"] = float(t[0].item())
+        except Exception as e:   # noqa: BLE001
+            box["err"] = f"{type(e).__name__}: {str(e)[:200]}"
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return False, f"the {nbytes >> 20} MB RCCL all-reduce did not return within {timeout_s:.0f} s", None
+    if "err" in box:
+        return False, box["err"], None
+    if abs(box["sum"] - float(world) ** 2) > 1e-3:   # ones -> world after the first call -> world^2 after the second
+        return False, f"RCCL all-reduce returned {box['sum']} instead of {float(world) ** 2}", None
+    return True, None, box["ms"]
+
+
+def host_barrier():
+    """a barrier over the CPU backend (gloo): works whatever state RCCL is in"""
+    dist.all_reduce(torch.zeros(1))
+
+
 def rendezvous_only(world, rank):
     """``--rendezvous-only`` (tests/test_ddp_gloo.py): the launcher path without a GPU -- the ranks meet over gloo, agree on
     the world size with one all-reduce, rank 0 prints a line.  Everything up to the first device call of a real run."""
@@ -622,12 +660,25 @@ def main():
                          "on this node (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl = {"ok": None, "fallback": None, "preflight_ms": None}
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_gpu:
             dist.init_process_group("gloo")
+            rccl.update(ok=False, fallback="--share-gpu: gloo by request")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # CPU tensors over gloo, device tensors over RCCL: the host side (agreement between ranks, the timing reduction, barriers in
+            # the fall-back) never depends on the state of RCCL
+            dist.init_process_group("cpu:gloo,cuda:nccl")
+            ok, why, ms = rccl_preflight(dev, 48 << 20, world)
+            flag = torch.tensor([1.0 if ok else 0.0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank takes the same path
+            agreed = bool(flag.item() >= 1.0)
+            rccl.update(ok=agreed, preflight_ms=None if ms is None else round(ms, 3),
+                        fallback=None if agreed else ("RCCL preflight failed" + (f" on this rank: {why}" if why else " on another rank") +
+                                                      "; gradients are exchanged through pinned host memory over gloo"))
+            log(f"RCCL preflight: {'ok, %.3f ms for 48 MB' % ms if agreed and ms is not None else rccl['fallback']}")
+    via_host = world > 1 and not rccl["ok"]
 
     from vmambair_amd import _capi
     from vmambair_amd.archs import build_network
@@ -661,7 +712,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            host_barrier()
         torch.cuda.synchronize()
 
     if world > 1 and args.miopen_find:
@@ -678,21 +729,52 @@ def main():
         for first in (True, False):
             if (rank == 0) == first:
                 prewarm()
-            dist.barrier()
+            host_barrier()
         log("vendor solver search done (rank 0 first)")
 
+    bucket_note = None
     if args.graph:
-        # whole step replayed as a hipGraph; N > 1: one flat-gradient all-reduce between two graphs
+        # whole step replayed as a hipGraph; N > 1: the flat-gradient all-reduce (in buckets) between the backward and optimizer graphs
         from vmambair_amd.train_graph import GraphedTrainStep
         if world > 1:  # same initial weights on every rank (DDP's constructor broadcast)
             for p_ in net.parameters():
-                dist.broadcast(p_.data, 0)
-        step = GraphedTrainStep(net, autocast_dtype=acdt, micro_streams=args.micro_streams,
-                                split_graphs=os.environ.get("VMAMBAIR_BENCH_SPLIT", "0") == "1",   # A-B: the two-graph form of N > 1 on one rank
-                                overlap_wgrads=os.environ.get("VMAMBAIR_OVERLAP_WGRADS", "0") == "1", **opt_kw)
+                if via_host:
+                    c_ = p_.data.cpu()
+                    dist.broadcast(c_, 0)
+                    p_.data.copy_(c_)
+                else:
+                    dist.broadcast(p_.data, 0)
+        # N > 1: the gradient exchange in 3 reverse-order buckets, each all-reduced on a side stream while the next one is flushed
+        # (train_graph.py: grad_buckets); VMAMBAIR_GRAD_BUCKETS=1 = ONE all-reduce between two graphs (rounds 3-5); also settable on one
+        # rank (A-B of what the bucketed flow costs without anything to overlap)
+        buckets = int(os.environ.get("VMAMBAIR_GRAD_BUCKETS", "3" if world > 1 else "1"))
+        if args.micro_streams > 1 or os.environ.get("VMAMBAIR_OVERLAP_WGRADS", "0") == "1":
+            buckets = 1
+
+        def make_step(nb):
+            return GraphedTrainStep(net, autocast_dtype=acdt, micro_streams=args.micro_streams,
+                                    split_graphs=os.environ.get("VMAMBAIR_BENCH_SPLIT", "0") == "1",   # A-B: the two-graph form of N > 1 on one rank
+                                    overlap_wgrads=os.environ.get("VMAMBAIR_OVERLAP_WGRADS", "0") == "1", grad_buckets=nb,
+                                    allreduce_via_host=via_host, **opt_kw)
         log("capturing the training step")
         lib.oss_prof_family_enable(1)     # algorithmic bytes per non-scan kernel family, per pass (warm-up passes + the captured one)
-        step.capture(lq, gt)
+        try:
+            step = make_step(buckets)
+            step.capture(lq, gt)
+        except Exception as e:   # noqa: BLE001
+            if buckets <= 1:
+                raise
+            # the bucketed flow has never met a real multi-GPU box before the driver's run: fall back to the single exchange
+            bucket_note = f"bucketed capture failed ({type(e).__name__}: {str(e)[:160]}); ONE all-reduce between two graphs instead"
+            log(bucket_note)
+            lib.oss_set_defer_wgrad(0)
+            lib.oss_set_defer_finish(0)
+            from vmambair_amd.ops import _common as _oc
+            _oc._DEFER_KEEP = _oc._DEFER_OUTS = _oc._WGRAD_OPERANDS = _oc._WGRAD_STORAGES = _oc._WGRAD_FLUSHER = None
+            torch.cuda.synchronize()
+            lib.oss_prof_family_enable(1)
+            step = make_step(1)
+            step.capture(lq, gt)
         lib.oss_prof_family_enable(0)
         fam_counts = family_counts(lib, step.warmup + 1)
         log("captured")
@@ -754,7 +836,7 @@ def main():
         prof_steps = min(3, args.steps)
     else:
         prof_steps = args.steps
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], dtype=torch.float64)   # a CPU tensor: over gloo, whatever state RCCL is in
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -866,7 +948,13 @@ def main():
                        **({"smoke_only": "--share-gpu: ranks share GPUs and talk over gloo -- flow check of the multi-rank path, not a measurement"}
                           if args.share_gpu else {}),
                        "allreduce_ms_per_step": None if allreduce_ms is None else round(allreduce_ms, 3),
-                       "allreduce_overlapped": False,
+                       # bucketed: every bucket but the last is exchanged on a side stream while the main stream flushes the next
+                       # bucket's weight gradients (train_graph.py); False = ONE all-reduce between two graphs
+                       "allreduce_overlapped": bool(args.graph and getattr(step, "nbuckets", 1) > 1 and world > 1),
+                       "allreduce_buckets": getattr(step, "nbuckets", 1) if args.graph else None,
+                       "rccl_preflight_ms_48MB": rccl["preflight_ms"],
+                       **({"fallback": "; ".join(x for x in (rccl["fallback"], bucket_note) if x)}
+                          if (world > 1 and (rccl["fallback"] or bucket_note)) else {}),
                        "allreduce_bytes": 4 * sum(p.numel() for p in net.parameters()) if world > 1 else 0,
                        "peak_memory_GB": peak_mem_gb,
                        "deferred_weight_gradients": None if not wgrad_stats else {
@@ -877,7 +965,9 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        host_barrier()
+        if via_host and not args.share_gpu:
+            os._exit(0)   # RCCL is in an unknown state (a preflight thread may still sit in it): leave without its teardown
         dist.destroy_process_group()
 
 

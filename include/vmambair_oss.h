@@ -449,6 +449,10 @@ typedef struct {
 void oss_set_defer_finish(int on);
 size_t oss_deferred_chunks(void);
 int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chunks, oss_stream_t stream);
+/* (round 6) only the FIRST max_chunks registered chunks (registration order = the order of the backward); 0 = all.  The rest stays
+ * registered.  With oss_flush_wgrads_n: the gradients of the layers whose backward ran first can be finished -- and handed to the
+ * data-parallel all-reduce -- while the remaining groups are still being flushed (vmambair_amd/train_graph.py: grad_buckets). */
+int oss_flush_finishes_n(void *host_table, void *device_table, size_t capacity_chunks, size_t max_chunks, oss_stream_t stream);
 
 /* Deferred weight gradients.  After oss_set_defer_wgrad(1), oss_conv1x1_wgrad and the x_proj / dt_proj products of oss_proj_wgrad
  * (16-bit I/O) do not launch: each call records its problem (operands, partial buffer and outputs must stay alive and unread)
@@ -465,6 +469,8 @@ void oss_set_defer_wgrad(int on);
 size_t oss_deferred_wgrads(void);
 size_t oss_deferred_wgrad_table_bytes(void);
 int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes, oss_stream_t stream);
+/* only the FIRST max_products recorded products (recording order = the order of the backward: last layers first); 0 = all */
+int oss_flush_wgrads_n(void *host_table, void *device_table, size_t capacity_bytes, size_t max_products, oss_stream_t stream);
 
 /* Adam + EMA of the training step (MambaSISR_model.py:120-147: torch.optim.Adam without amsgrad / weight decay,
  * then ema = decay * ema + (1 - decay) * param) as one elementwise launch over a chunk table in device memory:

@@ -63,6 +63,25 @@ def _worker(rank, world, port, tmp):
         for (k, p3) in net3.named_parameters():
             assert p3.grad.untyped_storage().data_ptr() == base, k
             assert torch.allclose(p3.grad, grads[k], rtol=1e-5, atol=1e-7), k
+    # (round 6) the bucketed exchange of the captured step (train_graph.py: grad_buckets): the flat buffer laid out in REVERSE
+    # parameter order (the order in which a backward hands gradients over), three buckets, each packed and all-reduced on its own
+    # -- any interleaving of pack_bucket / allreduce_bucket over the buckets gives the gradient mean
+    net4 = MamberBlock(16, variant="srgan")
+    net4.load_state_dict(ref_state)
+    net4(x_all[idx]).square().mean().backward()
+    ps4 = list(net4.parameters())
+    fb = ddp.FlatGrads(ps4, order=list(range(len(ps4)))[::-1], n_buckets=3)
+    assert fb.n_buckets == 3 and sorted(i for m in fb.bucket_members for i in m) == list(range(len(ps4)))
+    assert fb.bucket_ranges[0][0] == 0 and fb.bucket_ranges[-1][1] == fb.flat.numel()
+    assert all(a[1] == b[0] for a, b in zip(fb.bucket_ranges, fb.bucket_ranges[1:]))
+    for k in range(fb.n_buckets):
+        fb.pack_bucket(k)
+        fb.allreduce_bucket(k)
+    for (k, p4) in net4.named_parameters():
+        assert p4.grad.untyped_storage().data_ptr() == fb.flat.untyped_storage().data_ptr(), k
+        assert torch.allclose(p4.grad, grads[k], rtol=1e-5, atol=1e-7), k
+    # the last parameter's gradient (first to be handed over by a backward) sits at the front of the buffer: bucket 0
+    assert ps4[-1].grad.data_ptr() == fb.flat.data_ptr()
     if rank == 0:
         torch.save({"grads": grads, "state": ref_state, "x": x_all, "loss": red["l_pix"]}, os.path.join(tmp, "r0.pt"))
     # both ranks hold the same averaged gradient
@@ -126,11 +145,15 @@ def _deraining_worker(rank, world, port, tmp):
         for p in params:
             p.grad = None
         torch.nn.functional.l1_loss(net(blob["x"][sl]), blob["y"][sl]).backward()
-        if fg is None:
-            fg = ddp.FlatGrads(params)
-        fg.pack()
-        local_norm = float(fg.flat.norm())
-        fg.allreduce_mean()
+        if fg is None:   # (round 6) the bucketed order of the captured step: reverse parameter order, three buckets
+            fg = ddp.FlatGrads(params, order=list(range(len(params)))[::-1], n_buckets=3)
+        local_sq = 0.0
+        for k in range(fg.n_buckets):          # bucket k is packed, then exchanged (on a side stream in train_graph.py) ...
+            fg.pack_bucket(k)
+            local_sq += float(fg.flat[slice(*fg.bucket_ranges[k])].square().sum())   # this rank's own gradient, before the exchange
+            fg.allreduce_bucket(k)
+        local_norm = local_sq ** 0.5
+        # ... and the clip runs only after EVERY bucket came back: on the averaged gradient of the whole net
         norms.append((local_norm, float(torch.nn.utils.clip_grad_norm_(params, 0.01))))   # on the AVERAGED gradient
         opt.step()
     flat = torch.cat([p.detach().reshape(-1) for p in params])

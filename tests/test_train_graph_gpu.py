@@ -369,3 +369,43 @@ def test_train_loop_drives_the_schedule_and_saves_states(tmp_path):
     assert [round(lr / 2e-4, 3) for _, lr, _ in seen] == [1.0, 1.0, 1.0, 0.5, 0.5, 0.25]   # milestones at last_epoch 3 and 5
     assert sorted(p.name for p in tmp_path.iterdir()) == ["2.state", "4.state", "6.state"]
     assert all(torch.isfinite(torch.tensor(l)) for _, _, l in seen)
+
+
+@pytest.mark.parametrize("acdt", [None, torch.bfloat16], ids=["fp32", "bf16"])
+def test_bucketed_gradient_flush_is_bit_identical_to_the_single_flush(acdt):
+    """(round 6) ``grad_buckets=3``: the backward graph stops before the grouped weight-gradient launch; three small graphs each flush
+    the products / finishing sums of one reverse-order bucket and pack it (between them the multi-GPU step issues that bucket's
+    all-reduce on a side stream).  Same kernels on the same operands as the single flush of the two-graph step, so three training
+    steps must leave bit-identical weights, EMA and losses; the buckets cover every parameter once, in hand-over order, and their
+    cuts are monotone."""
+    from vmambair_amd.archs import MambaSISR6
+    from vmambair_amd.train_graph import GraphedTrainStep
+
+    def make():
+        torch.manual_seed(0)
+        return MambaSISR6(dim=16, num_blocks=[1, 1, 1, 1], num_refinement_blocks=1).to(DEV)
+
+    torch.manual_seed(3)
+    lq = torch.rand(2, 3, 32, 32, device=DEV)
+    gt = torch.rand(2, 3, 128, 128, device=DEV)
+    res = []
+    for buckets in (1, 3):
+        net = make()
+        st = GraphedTrainStep(net, autocast_dtype=acdt, warmup=2, split_graphs=True, grad_buckets=buckets)
+        losses = [float(st(lq, gt)) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, [p.detach().clone() for p in net.parameters()], [e.clone() for e in st.ema], st))
+    (l1, w1, e1, _), (l3, w3, e3, st3) = res
+    assert l1 == l3, (l1, l3)
+    for a, b in zip(w1, w3):
+        assert torch.equal(a, b)
+    for a, b in zip(e1, e3):
+        assert torch.equal(a, b)
+    fl = st3._flat
+    assert fl.n_buckets == 3 and len(st3.graph_flush) == 3
+    assert sorted(i for m in fl.bucket_members for i in m) == list(range(len(st3.params)))
+    assert all(a[0] <= b[0] and a[1] <= b[1] for a, b in zip(st3._cuts, st3._cuts[1:])), st3._cuts
+    # 16-bit: the weight-gradient products are recorded (grouped launch); fp32 launches them at once and only the finishing sums wait
+    assert st3._cuts[0][0 if acdt is not None else 1] > 0, "the first bucket holds nothing recorded: nothing would overlap"
+    sizes = [b - a for a, b in fl.bucket_ranges]
+    assert min(sizes) > 0.15 * sum(sizes), sizes

@@ -87,7 +87,7 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_proj_rows_optional_ok", "oss_chan_fwd", "oss_chan_grad_floats",
            "oss_chan_bwd_scratch_floats", "oss_chan_bwd", "oss_rowsum", "oss_row_affine", "oss_gelu_gate_fwd",
            "oss_gelu_gate_bwd", "oss_adam_ema_step", "oss_adamw_ema_step", "oss_set_defer_finish", "oss_deferred_chunks",
-           "oss_flush_finishes", "oss_set_defer_wgrad", "oss_deferred_wgrads", "oss_deferred_wgrad_table_bytes", "oss_flush_wgrads",
+           "oss_flush_finishes", "oss_flush_finishes_n", "oss_flush_wgrads_n", "oss_set_defer_wgrad", "oss_deferred_wgrads", "oss_deferred_wgrad_table_bytes", "oss_flush_wgrads",
            "oss_conv3x3_thin_ok", "oss_conv3x3_thin_fwd", "oss_conv3x3_thin_dgrad", "oss_conv3x3_thin_wgrad_partial_floats",
            "oss_conv3x3_thin_wgrad", "oss_hbm_copy", "oss_prof_marker", "oss_scan_build_id", "oss_version", "oss_scan_features", "oss_abi_version", "oss_abi_struct_bytes"]
 
@@ -256,6 +256,10 @@ def load():
     lib.oss_set_defer_finish.restype = None
     lib.oss_set_defer_finish.argtypes = [C.c_int]
     lib.oss_deferred_chunks.restype = C.c_size_t
+    lib.oss_flush_finishes_n.restype = C.c_int
+    lib.oss_flush_finishes_n.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.oss_flush_wgrads_n.restype = C.c_int
+    lib.oss_flush_wgrads_n.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
     lib.oss_flush_finishes.restype = C.c_int
     lib.oss_flush_finishes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.oss_set_defer_wgrad.restype = None

@@ -663,16 +663,20 @@ size_t oss_deferred_wgrad_table_bytes(void) {
     // descriptors (padded to 256 bytes) + one 16-bit problem index per workgroup
     return ((g_wgrad_descs.size() + 255) & ~(size_t)255) + 2 * blocks;
 }
-int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes, oss_stream_t stream) {
+// max_products: flush only the FIRST that many recorded products (recording order = the backward's order, last layers first) and
+// keep the rest recorded -- the bucketed gradient exchange (train_graph.py) finishes the gradients of the layers whose backward
+// ran first, hands them to the all-reduce and flushes the next group while that runs.  0 = all.
+int oss_flush_wgrads_n(void *host_table, void *device_table, size_t capacity_bytes, size_t max_products, oss_stream_t stream) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
-    const size_t n = g_wgrad_blocks.size();
+    const size_t n_all = g_wgrad_blocks.size();
+    const size_t n = max_products > 0 ? std::min(n_all, max_products) : n_all;
     if (n == 0) return 0;
     if (!host_table || !device_table) return OSS_ERR_NULL;
     if (n > 65535) return OSS_ERR_SHAPE;
     const size_t db = wgrad_desc_bytes();
-    const size_t desc_bytes = (g_wgrad_descs.size() + 255) & ~(size_t)255;
+    const size_t desc_bytes = (n * db + 255) & ~(size_t)255;
     size_t total = 0;
-    for (unsigned b : g_wgrad_blocks) total += b;
+    for (size_t i = 0; i < n; ++i) total += g_wgrad_blocks[i];
     if (desc_bytes + 2 * total > capacity_bytes) return OSS_ERR_WORKSPACE;
     if (total > 0x7fffffffu) return OSS_ERR_SHAPE;
     const int io = wgrad_desc_io(g_wgrad_descs.data());
@@ -684,13 +688,16 @@ int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes
         for (unsigned k = 0; k < g_wgrad_blocks[i]; ++k) map[first + k] = (uint16_t)i;
         first += g_wgrad_blocks[i];
     }
-    std::memcpy(host_table, g_wgrad_descs.data(), g_wgrad_descs.size());
+    std::memcpy(host_table, g_wgrad_descs.data(), n * db);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const hipError_t e = hipMemcpyAsync(device_table, host_table, desc_bytes + 2 * total, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
-    g_wgrad_descs.clear();
-    g_wgrad_blocks.clear();
+    g_wgrad_descs.erase(g_wgrad_descs.begin(), g_wgrad_descs.begin() + n * db);
+    g_wgrad_blocks.erase(g_wgrad_blocks.begin(), g_wgrad_blocks.begin() + n);
     return wgrad_grouped_launch(io, device_table, reinterpret_cast<unsigned char *>(device_table) + desc_bytes, (unsigned)total, s);
+}
+int oss_flush_wgrads(void *host_table, void *device_table, size_t capacity_bytes, oss_stream_t stream) {
+    return oss_flush_wgrads_n(host_table, device_table, capacity_bytes, 0, stream);
 }
 
 void oss_set_defer_finish(int on) {
@@ -702,23 +709,28 @@ size_t oss_deferred_chunks(void) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
     return g_defer_chunks.size();
 }
-int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chunks, oss_stream_t stream) {
+// max_chunks: only the FIRST that many registered chunks (registration order = the backward's order); 0 = all
+int oss_flush_finishes_n(void *host_table, void *device_table, size_t capacity_chunks, size_t max_chunks, oss_stream_t stream) {
     std::lock_guard<std::mutex> lk(g_defer_mu);
-    const size_t n = g_defer_chunks.size();
+    const size_t n_all = g_defer_chunks.size();
+    const size_t n = max_chunks > 0 ? std::min(n_all, max_chunks) : n_all;
     if (n == 0) return 0;
     if (!host_table || !device_table) return OSS_ERR_NULL;
     if (n > capacity_chunks) return OSS_ERR_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (g_fam_on.load(std::memory_order_relaxed)) {
         double by = 0.0;
-        for (const oss_sum_chunk &c : g_defer_chunks) by += 4.0 * c.n * (c.K + 1.0);
+        for (size_t i = 0; i < n; ++i) by += 4.0 * g_defer_chunks[i].n * (g_defer_chunks[i].K + 1.0);
         fam_count(FAM_FINISH, by);
     }
     std::memcpy(host_table, g_defer_chunks.data(), n * sizeof(oss_sum_chunk));
     hipError_t e = hipMemcpyAsync(device_table, host_table, n * sizeof(oss_sum_chunk), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
-    g_defer_chunks.clear();
+    g_defer_chunks.erase(g_defer_chunks.begin(), g_defer_chunks.begin() + n);
     return sum_partials_multi(reinterpret_cast<const oss_sum_chunk *>(device_table), (int)n, s);
+}
+int oss_flush_finishes(void *host_table, void *device_table, size_t capacity_chunks, oss_stream_t stream) {
+    return oss_flush_finishes_n(host_table, device_table, capacity_chunks, 0, stream);
 }
 
 int oss_adam_ema_step(const oss_adam_chunk *chunks, int n_chunks, float *state, float lr, float beta1, float beta2, float eps,

@@ -96,14 +96,46 @@ class FlatGrads:
     train_graph.py): ``pack`` copies the freshly produced gradients into it with one multi-tensor copy and
     re-points ``p.grad`` at views of the buffer, so that the data-parallel exchange is a single all-reduce of
     ``flat`` with no per-step loop over the ~1450 tensors and nothing to unpack afterwards (the optimizer reads
-    the views).  Built from the first set of gradients it sees; shapes must not change afterwards."""
+    the views).  Built from the first set of gradients it sees; shapes must not change afterwards.
 
-    def __init__(self, params):
+    (round 6) ``order`` / ``n_buckets``: the buffer is laid out in ``order`` (indices into ``params``: the order in which the
+    backward finishes the gradients, last layers first) and cut into ``n_buckets`` contiguous slices of about equal size --
+    DDP's reverse-order buckets (Deraining/basicsr/models/base_model.py:76-82 wraps the net in DistributedDataParallel, whose
+    reducer all-reduces a bucket as soon as its gradients exist).  ``pack_bucket(k)`` / ``allreduce_bucket(k)`` work on one slice,
+    so bucket k's exchange can run on a side stream while the step finishes the gradients of bucket k + 1.
+    ``via_host``: stage every exchange through pinned host memory and the CPU backend (gloo) -- the fall-back of bench.py when
+    the RCCL preflight fails, and what ``--share-gpu`` uses; a flow that always works, never the fast path."""
+
+    def __init__(self, params, order=None, n_buckets: int = 1, via_host: bool = False):
         self.params = list(params)
         grads = [p.grad for p in self.params]
         assert all(g is not None and g.dtype == torch.float32 for g in grads), "FlatGrads needs an fp32 grad per parameter"
+        n = len(grads)
+        order = list(range(n)) if order is None else list(order)
+        assert sorted(order) == list(range(n)), "order must be a permutation of the parameter indices"
+        self.order = order
         self.flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
-        self.views = [v.view_as(g) for v, g in zip(self.flat.split([g.numel() for g in grads]), grads)]
+        pieces = self.flat.split([grads[i].numel() for i in order])
+        self.views = [None] * n
+        for piece, i in zip(pieces, order):
+            self.views[i] = piece.view_as(grads[i])
+        # bucket boundaries: cut after the parameter at which the running size passes k / n_buckets of the total
+        n_buckets = max(1, min(int(n_buckets), n))
+        total, run, k = self.flat.numel(), 0, 1
+        self.bucket_members, cur, self.bucket_ranges, start = [], [], [], 0
+        for i in order:
+            cur.append(i)
+            run += grads[i].numel()
+            if k < n_buckets and run >= k * total / n_buckets:
+                self.bucket_members.append(cur)
+                self.bucket_ranges.append((start, run))
+                cur, start, k = [], run, k + 1
+        if cur or not self.bucket_members:
+            self.bucket_members.append(cur)
+            self.bucket_ranges.append((start, total))
+        self.n_buckets = len(self.bucket_members)
+        self.via_host = bool(via_host)
+        self._host = None
 
     def pack(self) -> None:
         with torch.no_grad():
@@ -111,20 +143,43 @@ class FlatGrads:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
+    def pack_bucket(self, k: int) -> None:
+        idx = self.bucket_members[k]
+        with torch.no_grad():
+            torch._foreach_copy_([self.views[i] for i in idx], [self.params[i].grad for i in idx])
+        for i in idx:
+            self.params[i].grad = self.views[i]
+
+    def _exchange(self, t: torch.Tensor) -> None:
+        world = dist.get_world_size()
+        staged = t.is_cuda and (self.via_host or dist.get_backend() == "gloo")
+        if staged:
+            # host staging (gloo has no device path worth using: fed from a stream with a whole training step still queued it ran at
+            # 10-23 s per step on the MI355X box; fenced and staged through pinned memory it is 11 ms).  A flow check / fall-back.
+            if self._host is None or self._host.numel() < self.flat.numel():
+                self._host = torch.empty(self.flat.numel(), dtype=torch.float32).pin_memory()
+            h = self._host[:t.numel()]
+            torch.cuda.current_stream().synchronize()
+            h.copy_(t)
+            dist.all_reduce(h)
+            h.div_(world)
+            t.copy_(h, non_blocking=False)
+            return
+        dist.all_reduce(t)
+        t.div_(world)
+
     def allreduce_mean(self) -> None:
         """mean over ranks, in place (a no-op without an initialised process group / with one rank)"""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        gloo_on_gpu = self.flat.is_cuda and dist.get_backend() == "gloo"
-        if gloo_on_gpu:
-            # gloo stages device tensors through the host.  Fed from a stream with a whole training step still queued it ran at
-            # 10-23 s per step on the MI355X box (two ranks sharing the GPU, `bench.py --share-gpu`), fenced at 11 ms: gloo is a
-            # flow check here, never the product's collective (RCCL enqueues on the stream), so fence it.
-            torch.cuda.synchronize()
-        dist.all_reduce(self.flat)
-        if gloo_on_gpu:
-            torch.cuda.synchronize()
-        self.flat.div_(dist.get_world_size())
+        self._exchange(self.flat)
+
+    def allreduce_bucket(self, k: int) -> None:
+        """mean over ranks of bucket ``k`` only (on the CURRENT stream: the caller picks the side stream)"""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        a, b = self.bucket_ranges[k]
+        self._exchange(self.flat[a:b])
 
 
 def allreduce_grads_flat(params) -> None:

@@ -186,29 +186,33 @@ def pending_wgrads() -> int:
     return int(_capi.load().oss_deferred_wgrads())
 
 
-def flush_wgrads(table: WgradTable) -> None:
+def flush_wgrads(table: WgradTable, count: int = 0) -> None:
     """run every recorded weight-gradient product as ONE grouped launch on the current stream (before ``flush_finishes``:
-    the finishing sums read the partials this launch writes)"""
+    the finishing sums read the partials this launch writes).  ``count`` > 0: only the FIRST that many recorded products (the
+    backward's order: last layers first) -- the bucketed gradient exchange of train_graph.py; the rest stays recorded."""
     lib = _capi.load()
     capturing = torch.cuda.is_current_stream_capturing()
     if table.copied is not None and not capturing:
         table.copied.synchronize()   # the previous copy out of the pinned table has executed (cf. flush_finishes)
     with torch.cuda.device(table.dev.device):
-        _capi.check(lib.oss_flush_wgrads(table.host.data_ptr(), table.dev.data_ptr(), table.capacity,
-                                         torch.cuda.current_stream().cuda_stream), "oss_flush_wgrads")
+        _capi.check(lib.oss_flush_wgrads_n(table.host.data_ptr(), table.dev.data_ptr(), table.capacity, max(0, int(count)),
+                                           torch.cuda.current_stream().cuda_stream), "oss_flush_wgrads")
         if not capturing:
             table.copied = torch.cuda.Event()
             table.copied.record()
-    _release_operands()   # the launch that reads them is queued on this stream: stream order protects the memory
+    if int(lib.oss_deferred_wgrads()) == 0:
+        _release_operands()   # the launch that reads them is queued on this stream: stream order protects the memory
 
 
 def pending_finish_chunks() -> int:
     return int(_capi.load().oss_deferred_chunks())
 
 
-def flush_finishes(table: FinishTable) -> None:
+def flush_finishes(table: FinishTable, count: int = 0) -> None:
+    """``count`` > 0: only the FIRST that many registered chunks (with ``flush_wgrads(count=...)`` of the products registered up to the
+    same moment of the backward: a chunk that sums a product's partials is registered when the product is recorded)"""
     lib = _capi.load()
-    if int(lib.oss_deferred_wgrads()):
+    if int(lib.oss_deferred_wgrads()) and count <= 0:
         raise RuntimeError("weight-gradient products are still recorded: call flush_wgrads before flush_finishes "
                            "(the finishing sums read the partials the grouped launch writes)")
     capturing = torch.cuda.is_current_stream_capturing()
@@ -217,12 +221,12 @@ def flush_finishes(table: FinishTable) -> None:
         # of the previous flush must have executed first (inside a capture the call runs once, at capture time)
         table.copied.synchronize()
     with torch.cuda.device(table.dev.device):
-        _capi.check(lib.oss_flush_finishes(table.host.data_ptr(), table.dev.data_ptr(), table.capacity,
-                                           torch.cuda.current_stream().cuda_stream), "oss_flush_finishes")
+        _capi.check(lib.oss_flush_finishes_n(table.host.data_ptr(), table.dev.data_ptr(), table.capacity, max(0, int(count)),
+                                             torch.cuda.current_stream().cuda_stream), "oss_flush_finishes")
         if not capturing:
             table.copied = torch.cuda.Event()
             table.copied.record()
-    if _DEFER_KEEP is not None:
+    if _DEFER_KEEP is not None and int(lib.oss_deferred_chunks()) == 0:
         _DEFER_KEEP.clear()
         _DEFER_OUTS.clear()
 

@@ -24,6 +24,15 @@ that buffer is all-reduced with a single RCCL call (48.1 MB for MambaSISR6 -- xG
 ~0.1-0.6 ms) and divided in place; a second graph applies Adam + EMA reading the views.
 No DDP hooks inside a capture, no per-bucket calls, no per-step host loop over the gradient tensors.
 
+(round 6) ``grad_buckets = K > 1`` overlaps that exchange with the end of the backward, the way the reference's
+DistributedDataParallel reducer does with its reverse-order buckets (Deraining/basicsr/models/base_model.py:76-82): the weight
+gradients of the step are only RECORDED during the backward and run as grouped launches at its end (ops/_common.py), so the
+overlap window is that end -- the first graph stops after the backward, K small graphs each flush the recorded products and
+finishing sums of ONE bucket (backward order: last layers first; the cut points are the library's record counts at the moment
+the bucket's last gradient was handed to autograd, found on the first warm-up pass) and pack it into its slice of the flat
+buffer, and between their replays bucket k's all-reduce is issued on a side stream while the main stream flushes bucket k + 1.
+The collectives stay OUTSIDE the graphs.  Same kernels on the same operands as K = 1, so the gradients are bit-identical.
+
 Deferred finishing (``defer_finishes``), the adoption contract that goes with it and the optional
 micro-batch branches (``micro_streams``) are described at their code below and in ops.py.
 """
@@ -45,7 +54,8 @@ class GraphedTrainStep:
                  loss_fn: Callable = torch.nn.functional.l1_loss, warmup: int = 3, shadow_weights: bool = True,
                  fused_optimizer: bool = True, split_graphs: bool = False, overlap_wgrads: bool = False,
                  defer_finishes: bool = True, micro_streams: int = 1, weight_decay: float = 0.0,
-                 clip_grad_norm: Optional[float] = None, multi_shape: bool = False):
+                 clip_grad_norm: Optional[float] = None, multi_shape: bool = False, grad_buckets: int = 1,
+                 allreduce_via_host: bool = False):
         """``weight_decay`` / ``clip_grad_norm`` / ``ema_decay=0``: the Deraining step (AdamW + clip_grad_norm_(0.01), no
         EMA: Deraining/basicsr/models/image_restoration_model.py:121-167).  ``multi_shape``: keep one forward+backward
         graph per (lq, gt) shape -- the progressive patch schedule of that tree changes the patch size and the batch
@@ -59,7 +69,10 @@ class GraphedTrainStep:
         # two graphs (forward+backward | optimizer) with the gradient all-reduce between them: always for world > 1;
         # ``split_graphs`` forces the same structure on one GPU (tests)
         self.multi_shape = multi_shape
-        self.split = self.world > 1 or split_graphs or multi_shape
+        # grad_buckets > 1: the gradient exchange in buckets overlapped with the flushes at the end of the backward (module docstring)
+        self.nbuckets = max(1, int(grad_buckets))
+        self.allreduce_via_host = bool(allreduce_via_host)
+        self.split = self.world > 1 or split_graphs or multi_shape or self.nbuckets > 1
         # split mode: the first graph ends by packing every gradient into ONE persistent fp32 buffer (a multi-tensor copy,
         # captured) and re-points ``p.grad`` at views of it, so that the only work between the two graphs is a single
         # all-reduce of that buffer -- no per-step host loop over the ~1450 gradient tensors, no unpack
@@ -135,6 +148,16 @@ class GraphedTrainStep:
         self.ftables = [None] * self.nmicro
         self.wtables = [None] * self.nmicro
         self.wgrad_stats = None   # of the last deferred backward: bytes held for recorded products, grouped launches (ops/_common.py)
+        if self.nbuckets > 1:
+            assert self.nmicro == 1 and not overlap_wgrads and defer_finishes, "grad_buckets needs the deferred single-branch step"
+            assert not multi_shape, "grad_buckets: the bucket cuts are record counts of ONE input shape (use grad_buckets=1 with multi_shape)"
+            self.warmup = max(self.warmup, 2)   # pass 1 finds the bucket cuts, pass 2 sizes the per-bucket tables
+        self._cuts = None            # per bucket: (recorded products, registered chunks) when its last gradient was handed over
+        self._defer_ctx = None       # the deferred_finishes() context kept open between the backward graph and the flush graphs
+        self._flushed = (0, 0)
+        self.btables = None          # per bucket (WgradTable, FinishTable)
+        self.graph_flush = []
+        self.ar_stream = torch.cuda.Stream(device=self.device) if self.nbuckets > 1 else None
         self.graph_fb: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None
         self.static_lq = self.static_gt = self.static_loss = None
@@ -144,8 +167,121 @@ class GraphedTrainStep:
         self.allreduce_ms = None   # set by time_allreduce(): events around the flat all-reduce (bench.py)
 
     # ---- pieces ------------------------------------------------------------------------------
+    def _backward_open(self, loss, leaves):
+        """bucketed mode: the backward with every weight-gradient product and finishing sum only RECORDED; the deferred context
+        stays open (``_flush_bucket`` closes it after the last bucket).  On the very first pass it also finds the bucket cuts: a
+        post-accumulate hook on every leaf notes the order in which autograd hands the gradients over and the library's record
+        counts at that moment."""
+        assert self._defer_ctx is None, "the previous step's buckets were not all flushed"
+        marks, handles = [], []
+        if self._cuts is None:
+            from . import _capi
+            lib = _capi.load()
+            owner = {id(p): i for i, p in enumerate(self.params)}
+            for name, (m, sh) in self.shadow.items():
+                owner[id(sh)] = owner[id(m)]
+            for t in leaves:
+                handles.append(t.register_post_accumulate_grad_hook(
+                    lambda t_, i=owner[id(t)]: marks.append((i, int(lib.oss_deferred_wgrads()), int(lib.oss_deferred_chunks())))))
+        self._defer_ctx = _ops.deferred_finishes(wgrad_flusher=None)   # no budget flushes: they would shift the cut counts
+        self._defer_ctx.__enter__()
+        self._flushed = (0, 0)
+        try:
+            loss.backward()
+        except BaseException:
+            self._defer_ctx.__exit__(None, None, None)
+            self._defer_ctx = None
+            raise
+        finally:
+            for h in handles:
+                h.remove()
+        if self._cuts is None:
+            self._probe = marks
+
+    def _make_buckets(self):
+        """from the first pass's marks: parameter order = order of the hand-over, K buckets of about equal size, the cut of a bucket
+        = the record counts at its last member's hand-over (monotone: later buckets include everything recorded before)"""
+        from .ddp import FlatGrads
+        seen, order, at = set(), [], {}
+        for i, nw, nc in self._probe:
+            if i not in seen:
+                seen.add(i)
+                order.append(i)
+            at[i] = (nw, nc)
+        order += [i for i in range(len(self.params)) if i not in seen]   # (a parameter that never got a gradient: none in these nets)
+        self._flat = FlatGrads(self.params, order=order, n_buckets=self.nbuckets, via_host=self.allreduce_via_host)
+        self.nbuckets = self._flat.n_buckets
+        cuts, hi = [], (0, 0)
+        for members in self._flat.bucket_members:
+            for i in members:
+                if i in at:
+                    hi = (max(hi[0], at[i][0]), max(hi[1], at[i][1]))
+            cuts.append(hi)
+        self._cuts = cuts
+        self._probe = None
+        shadow_of = {id(m): sh for m, sh in self.shadow.values()}
+        mg_of = {id(m): g for m, g in zip(self._masters, self._master_grads)}
+        self._bucket_shadows = [[(self.params[i], shadow_of[id(self.params[i])], mg_of[id(self.params[i])]) for i in members
+                                 if id(self.params[i]) in shadow_of] for members in self._flat.bucket_members]
+
+    def _flush_bucket(self, k: int):
+        """finish the gradients of bucket ``k`` (grouped weight-gradient launch + finishing sums of everything recorded up to its
+        cut), convert its shadow gradients, pack it into its slice of the flat buffer.  The last bucket takes whatever is left
+        and closes the deferred context."""
+        last = k == self.nbuckets - 1
+        nw = 0 if last else max(0, self._cuts[k][0] - self._flushed[0])
+        nc = 0 if last else max(0, self._cuts[k][1] - self._flushed[1])
+        if self.btables is None:
+            self.btables = [[None, None] for _ in range(self.nbuckets)]
+        wt, ft = self.btables[k]
+        if last or nw > 0:
+            if _ops.pending_wgrads():
+                need = _ops.pending_wgrad_table_bytes()
+                if wt is None or wt.capacity < need:
+                    assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient tables must exist before the capture"
+                    wt = self.btables[k][0] = _ops.WgradTable(self.device, need)
+                _ops.flush_wgrads(wt, count=nw)
+        if last or nc > 0:
+            n = _ops.pending_finish_chunks()
+            if n:
+                if ft is None or ft.capacity < n:
+                    assert not torch.cuda.is_current_stream_capturing(), "the finish tables must exist before the capture"
+                    ft = self.btables[k][1] = _ops.FinishTable(self.device, n)
+                _ops.flush_finishes(ft, count=nc)
+        if not last:
+            self._flushed = (self._cuts[k][0], self._cuts[k][1])
+        trip = self._bucket_shadows[k]
+        if trip:
+            with torch.no_grad():
+                torch._foreach_copy_([g for _, _, g in trip], [sh.grad for _, sh, _ in trip])
+            for m, _, g in trip:
+                m.grad = g
+        self._flat.pack_bucket(k)
+        if last:
+            self._defer_ctx.__exit__(None, None, None)
+            self._defer_ctx = None
+
+    def _allreduce_bucket(self, k: int):
+        """bucket k's exchange on the side stream, behind everything the main stream has queued so far (its flush graph)"""
+        if self.world == 1:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.ar_stream):
+            self.ar_stream.wait_event(ev)
+            if self.allreduce_ms is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._flat.allreduce_bucket(k)
+                e1.record()
+                self._ar_events.append((e0, e1))
+            else:
+                self._flat.allreduce_bucket(k)
+
     def _backward(self, loss, leaves, slot: int = 0):
         """backward of one (micro-)batch on the current stream; ``leaves``: the tensors whose .grad it fills"""
+        if self.nbuckets > 1:
+            return self._backward_open(loss, leaves)
         if not self.defer:
             with _ops.wgrad_side_stream(self.wside):
                 loss.backward()
@@ -202,6 +338,8 @@ class GraphedTrainStep:
                 out = self.net(self.static_lq)
         loss = self.loss_fn(out.float(), self.static_gt)
         self._backward(loss, list(self.params) + self._shadows)
+        if self.nbuckets > 1:
+            return loss.detach()   # gradients are finished, converted and packed bucket by bucket (_flush_bucket)
         if self.wside is not None:
             torch.cuda.current_stream().wait_stream(self.wside)   # join before anything reads a weight gradient
         if self._shadows:
@@ -259,6 +397,26 @@ class GraphedTrainStep:
         if self.split:
             self._pack_grads()
         return total
+
+    def _first_bucket_pass(self):
+        """the very first warm-up pass of the bucketed mode: everything flushed at once (as the unbucketed step does), then the
+        flat buffer is built in hand-over order and cut into buckets"""
+        wt = _ops.WgradTable(self.device, _ops.pending_wgrad_table_bytes()) if _ops.pending_wgrads() else None
+        if wt is not None:
+            _ops.flush_wgrads(wt)
+        n = _ops.pending_finish_chunks()
+        if n:
+            _ops.flush_finishes(_ops.FinishTable(self.device, n))
+        self._defer_ctx.__exit__(None, None, None)
+        self._defer_ctx = None
+        if self._shadows:
+            with torch.no_grad():
+                torch._foreach_copy_(self._master_grads, [s_.grad for s_ in self._shadows])
+            for m, g in zip(self._masters, self._master_grads):
+                m.grad = g
+        self._make_buckets()
+        self._flat.pack()
+        self._allreduce()
 
     def _pack_grads(self):
         if self._flat is None:
@@ -368,13 +526,15 @@ class GraphedTrainStep:
 
     def _stash(self):
         if self._active is not None:
-            self._shapes[self._active] = (self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables, self.wtables)
+            self._shapes[self._active] = (self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables, self.wtables,
+                                          self.graph_flush, self.btables)
 
     def _activate(self, key):
         if key == self._active:
             return
         self._stash()
-        self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables, self.wtables = self._shapes[key]
+        (self.static_lq, self.static_gt, self.static_loss, self.graph_fb, self.ftables, self.wtables, self.graph_flush,
+         self.btables) = self._shapes[key]
         self._active = key
 
     @property
@@ -392,6 +552,7 @@ class GraphedTrainStep:
                                    "to keep one graph per shape (progressive patch schedule)")
             self._stash()
             self.graph_fb, self.ftables, self.wtables = None, [None] * self.nmicro, [None] * self.nmicro
+            self.graph_flush, self.btables = [], None
         self._active = key
         self.static_lq = lq.clone()
         self.static_gt = gt.clone()
@@ -401,7 +562,16 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):  # warm-up outside capture: lazy inits, MIOpen find, LDS attributes
             for _ in range(self.warmup):
                 self._fwd_bwd()
-                self._allreduce()
+                if self.nbuckets > 1:
+                    if self._cuts is None:       # first pass of all: one flush of everything, then the buckets are defined
+                        self._first_bucket_pass()
+                    else:
+                        for k in range(self.nbuckets):
+                            self._flush_bucket(k)
+                            self._allreduce_bucket(k)
+                        torch.cuda.current_stream().wait_stream(self.ar_stream)
+                else:
+                    self._allreduce()
                 self._opt_ema()
                 torch.cuda.synchronize()   # the pointer tables of step k must not be rewritten while step k - 1 runs
         torch.cuda.current_stream().wait_stream(side)
@@ -413,6 +583,13 @@ class GraphedTrainStep:
             self.static_loss = self._fwd_bwd()
             if not self.split:
                 self._opt_ema()
+        self.graph_flush = []
+        if self.nbuckets > 1:   # one small graph per bucket, same memory pool (they read what the backward graph left recorded)
+            for k in range(self.nbuckets):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=self.graph_fb.pool()):
+                    self._flush_bucket(k)
+                self.graph_flush.append(gk)
         if self.split and self.graph_opt is None:   # one optimizer graph for every shape: it reads the flat gradient views
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt):
@@ -443,7 +620,14 @@ class GraphedTrainStep:
             self.iteration += 1
             return self.static_loss
         self.graph_fb.replay()
-        if self.split:
+        if self.nbuckets > 1:
+            for k, gk in enumerate(self.graph_flush):
+                gk.replay()
+                self._allreduce_bucket(k)     # side stream: runs while the main stream flushes the next bucket
+            if self.world > 1:
+                torch.cuda.current_stream().wait_stream(self.ar_stream)
+            self.graph_opt.replay()
+        elif self.split:
             if self.allreduce_ms is not None and self.world > 1:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -463,4 +647,4 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b in self._ar_events]
         self._ar_events = []
-        return sum(ms) / len(ms)
+        return sum(ms) / (len(ms) / self.nbuckets)   # per step: the buckets of a step are separate collectives
