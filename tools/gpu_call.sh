@@ -3,7 +3,7 @@
 #   LEGS="smoke pytest bench prof:<tag>:<bench args>"  -- each leg under its own timeout, logs under gpurun_out/<TAG>_*
 # TAG names the call (default r5).  PYTEST_ARGS / BENCH_ARGS add to the legs' command lines.
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out; TAG=${TAG:-r5}
+O=gpurun_out; TAG=${TAG:-r6}
 prof() {  # prof <tag> <bench args...>: rocprofv3 kernel trace of bench.py, steady-state table cut by the marker kernels
   local t=$1; shift
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/prof_$t" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" "$@" --no-cpu-baseline --no-secondary --skip-roofline > "$GRAFT_REPO_ROOT/$O/${TAG}_prof_bench_$t.txt" 2> "$GRAFT_REPO_ROOT/$O/${TAG}_prof_bench_$t.err" ); echo "rc=$?"

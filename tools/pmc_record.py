@@ -21,19 +21,21 @@ FWD = {(64, 8, 8): 0, (32, 16, 8): 1, (16, 16, 4): 2, (64, 16, 8): 3, (64, 4, 4)
 
 def key_of(name):
     """kernel name of the trace -> the key bench.py builds from the library's profiler buckets"""
-    m = re.search(r"oss_scan_bwd2_kernel<([^,]+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?(?:, (\w+))?>", name)
+    m = re.search(r"oss_scan_bwd2_kernel<([^,]+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?(?:, (\w+))?(?:, (\w+))?>", name)
     if m:
         seg = " segmented" if m.group(6) == "true" else ""
         if m.group(7) == "true":   # the instantiation that loads the forward pass's lane states: not the product's default
             seg += " lane states"
+        if m.group(8) == "true":   # (round 6) the opt-in form that writes its row-tile partials as bf16 (tune_partials = 2)
+            seg += " bf16 partials"
         return f"oss_scan_bwd_kernel variant {BWD2[int(m.group(2))]} io {IO[m.group(1)]}{seg}"
     m = re.search(r"oss_scan_fwd_kernel<([^,]+), (\d+), (\d+), (\d+), (\w+)(?:, (\d+))?>", name)
     if m:
         seg = {None: "", "0": "", "1": " local pass", "2": " segmented"}[m.group(6)]
         return f"oss_scan_fwd_kernel variant {FWD[(int(m.group(2)), int(m.group(3)), int(m.group(4)))]} io {IO[m.group(1)]}{seg}"
-    m = re.search(r"oss_scan_bwd_finish<([^,>]+)", name)
+    m = re.search(r"oss_scan_bwd_finish<([^,>]+)(?:, (\d+))?(?:, (\w+))?>", name)
     if m:
-        return f"oss_scan_bwd_finish io {IO[m.group(1)]}"
+        return f"oss_scan_bwd_finish io {IO[m.group(1)]}" + (" bf16 partials" if m.group(3) == "true" else "")
     m = re.search(r"oss_scan_bwd_carry_kernel<([^,]+), (\d+)>", name)
     if m:
         return f"oss_scan_bwd_carry_kernel rows {m.group(2)} io {IO[m.group(1)]}"

@@ -22,8 +22,11 @@ Cm = torch.randn(B, 4, N, L, device=dev).to(dt)
 Dv = torch.ones(4 * D, device=dev)
 bias = torch.randn(4 * D, device=dev) * 0.1
 g2 = torch.randn(B, 2 * D, L, device=dev).to(dt)
+# PARTIALS=bf16: the opt-in bf16 row-tile partials of the backward (oss_scan_bwd_params.tune_partials = 2) -- A-B of their traffic
+tune = (None, None, None, "bf16") if os.environ.get("PARTIALS", "") == "bf16" else None
+FWD_ONLY = os.environ.get("FWD_ONLY", "0") == "1"      # inference shapes (RealSR tiles, the untiled image): no backward
 for _ in range(int(os.environ.get("REPS", "6"))):
     out, st = ops.selective_scan_fwd(x2, delta, A_log, Bm, Cm, Dv, bias, True, 1, 2, 2 * D, True)
-    res = ops.selective_scan_bwd(x2, delta, A_log, Bm, Cm, Dv, bias, g2, st, True, 1, 2, 2 * D, 2 * D, True)
+    res = [out] if FWD_ONLY else ops.selective_scan_bwd(x2, delta, A_log, Bm, Cm, Dv, bias, g2, st, True, 1, 2, 2 * D, 2 * D, True, tune=tune)
 torch.cuda.synchronize()
 print("done", float(out.float().abs().mean()), float(res[0].float().abs().mean()))
