@@ -60,9 +60,6 @@ _WGRAD_OPERANDS: Optional[list] = None
 _WGRAD_STORAGES: Optional[set] = None
 _WGRAD_HELD = 0            # bytes of distinct storages held for recorded products since the last grouped launch
 _WGRAD_FLUSHER = None
-#: (round 6) > 0: ``_keep_operands`` also calls the flusher whenever that many products are recorded -- train_graph.py's early grouped
-#: launches on a side stream (the bandwidth-bound weight-gradient launch next to the latency-bound chain of the backward)
-WGRAD_FLUSH_EVERY = 0
 WGRAD_STATS = {"held_bytes_max": 0, "budget_flushes": 0}   # since the last ``deferred_finishes`` entry (bench.py, tests)
 
 
@@ -121,8 +118,6 @@ def _keep_operands(before: int, *tensors) -> None:
     if WGRAD_KEEP_BUDGET and _WGRAD_FLUSHER is not None and _WGRAD_HELD > WGRAD_KEEP_BUDGET:
         WGRAD_STATS["budget_flushes"] += 1
         _WGRAD_FLUSHER()   # -> flush_wgrads(table): queues the grouped launch and releases the operands
-    elif WGRAD_FLUSH_EVERY > 0 and _WGRAD_FLUSHER is not None and int(_capi.load().oss_deferred_wgrads()) >= WGRAD_FLUSH_EVERY:
-        _WGRAD_FLUSHER()
 
 
 def _release_operands() -> None:
@@ -191,12 +186,10 @@ def pending_wgrads() -> int:
     return int(_capi.load().oss_deferred_wgrads())
 
 
-def flush_wgrads(table: WgradTable, count: int = 0, release: bool = True) -> None:
+def flush_wgrads(table: WgradTable, count: int = 0) -> None:
     """run every recorded weight-gradient product as ONE grouped launch on the current stream (before ``flush_finishes``:
     the finishing sums read the partials this launch writes).  ``count`` > 0: only the FIRST that many recorded products (the
-    backward's order: last layers first) -- the bucketed gradient exchange of train_graph.py; the rest stays recorded.
-    ``release=False``: the launch goes to ANOTHER stream than the one that produced the operands (train_graph.py's early side-stream
-    flushes): keep the operands alive until the caller has joined the streams (a later ``flush_wgrads`` with release=True drops them)."""
+    backward's order: last layers first) -- the bucketed gradient exchange of train_graph.py; the rest stays recorded."""
     lib = _capi.load()
     capturing = torch.cuda.is_current_stream_capturing()
     if table.copied is not None and not capturing:
@@ -207,7 +200,7 @@ def flush_wgrads(table: WgradTable, count: int = 0, release: bool = True) -> Non
         if not capturing:
             table.copied = torch.cuda.Event()
             table.copied.record()
-    if release and int(lib.oss_deferred_wgrads()) == 0:
+    if int(lib.oss_deferred_wgrads()) == 0:
         _release_operands()   # the launch that reads them is queued on this stream: stream order protects the memory
 
 

@@ -152,10 +152,6 @@ class GraphedTrainStep:
             assert self.nmicro == 1 and not overlap_wgrads and defer_finishes, "grad_buckets needs the deferred single-branch step"
             assert not multi_shape, "grad_buckets: the bucket cuts are record counts of ONE input shape (use grad_buckets=1 with multi_shape)"
             self.warmup = max(self.warmup, 2)   # pass 1 finds the bucket cuts, pass 2 sizes the per-bucket tables
-        # early weight-gradient launches on a side stream (see _backward); 0 = one grouped launch at the end of the backward
-        self.side_flushes = max(0, int(os.environ.get("VMAMBAIR_WGRAD_SIDE_FLUSHES", "0")))
-        self.wflush_side = torch.cuda.Stream(device=self.device) if (self.side_flushes > 0 and self.nbuckets == 1 and not overlap_wgrads) else None
-        self._n_products = 0
         self._cuts = None            # per bucket: (recorded products, registered chunks) when its last gradient was handed over
         self._defer_ctx = None       # the deferred_finishes() context kept open between the backward graph and the flush graphs
         self._flushed = (0, 0)
@@ -293,13 +289,8 @@ class GraphedTrainStep:
         tables = self.wtables[slot] if self.wtables[slot] is not None else []
         self.wtables[slot] = tables
         used = [0]
-        # (round 6) early grouped launches on a side stream: the bandwidth-bound weight-gradient launch runs NEXT TO the latency-bound
-        # chain of the backward instead of after it (VMAMBAIR_WGRAD_SIDE_FLUSHES=n: n early launches + the final one; one fork each,
-        # ONE join before the finishing sums).  The product count per early launch comes from the first (eager) pass.
-        side = self.wflush_side if (self.wflush_side is not None and self._n_products and self.nmicro == 1) else None
-        forked = [False]
 
-        def flush_wgrads_now(final=False):
+        def flush_wgrads_now():
             # one pinned table per grouped launch of a backward: a captured copy node reads its host buffer at REPLAY time,
             # so two launches of one graph must not share one
             nb = _ops.pending_wgrad_table_bytes()
@@ -309,40 +300,20 @@ class GraphedTrainStep:
             if tables[k] is None or tables[k].capacity < nb:
                 assert not torch.cuda.is_current_stream_capturing(), "the weight-gradient tables must exist before the capture"
                 tables[k] = _ops.WgradTable(self.device, nb)
-            if side is not None and not final:
-                side.wait_stream(torch.cuda.current_stream())        # fork: everything recorded so far has been produced
-                with torch.cuda.stream(side):
-                    _ops.flush_wgrads(tables[k], release=False)      # operands stay alive until the join below
-                forked[0] = True
-            else:
-                if forked[0]:
-                    torch.cuda.current_stream().wait_stream(side)    # join: before the last launch and the finishing sums
-                    forked[0] = False
-                _ops.flush_wgrads(tables[k])
+            _ops.flush_wgrads(tables[k])
             used[0] = k + 1
 
-        from .ops import _common as _oc
-        _oc.WGRAD_FLUSH_EVERY = -(-self._n_products // (self.side_flushes + 1)) if side is not None else 0
         with _ops.deferred_finishes(wgrad_flusher=flush_wgrads_now if self.wside is None else None):
             with _ops.wgrad_side_stream(self.wside):
-                try:
-                    loss.backward()
-                finally:
-                    _oc.WGRAD_FLUSH_EVERY = 0
+                loss.backward()
             if self.wside is not None:
                 torch.cuda.current_stream().wait_stream(self.wside)
             if not torch.cuda.is_current_stream_capturing():   # eager warm-up steps: every deferred gradient was adopted
                 lost = _ops.orphaned_deferred_outputs(leaves)
                 if lost:
                     raise RuntimeError(f"{lost} deferred weight gradients were copied before the flush (see ops.py CONTRACT)")
-            if self._n_products == 0 and not torch.cuda.is_current_stream_capturing():
-                self._n_products = _ops.pending_wgrads() + 0   # first eager pass (nothing flushed early): products per backward
             if _ops.pending_wgrads():   # the recorded weight-gradient products, as ONE grouped launch (ops/_common.py) --
-                flush_wgrads_now(final=True)   # or the last of a few (budget flushes; early side-stream launches)
-            elif forked[0]:
-                torch.cuda.current_stream().wait_stream(side)
-                forked[0] = False
-                _oc._release_operands()
+                flush_wgrads_now()      # or the last of a few, when the operands held passed WGRAD_KEEP_BUDGET on the way
             self.wgrad_stats = dict(_ops.WGRAD_STATS, grouped_launches=used[0])
             n = _ops.pending_finish_chunks()
             if self.ftables[slot] is None or self.ftables[slot].capacity < n:   # first (eager, warm-up) step: sizes the table
