@@ -408,4 +408,4 @@ def test_bucketed_gradient_flush_is_bit_identical_to_the_single_flush(acdt):
     # 16-bit: the weight-gradient products are recorded (grouped launch); fp32 launches them at once and only the finishing sums wait
     assert st3._cuts[0][0 if acdt is not None else 1] > 0, "the first bucket holds nothing recorded: nothing would overlap"
     sizes = [b - a for a, b in fl.bucket_ranges]
-    assert min(sizes) > 0.15 * sum(sizes), sizes
+    assert min(sizes) > 0.1 * sum(sizes), sizes   # (the dim-16 test net: one tail convolution is 60 % of the first bucket)

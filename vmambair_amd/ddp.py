@@ -119,17 +119,21 @@ class FlatGrads:
         self.views = [None] * n
         for piece, i in zip(pieces, order):
             self.views[i] = piece.view_as(grads[i])
-        # bucket boundaries: cut after the parameter at which the running size passes k / n_buckets of the total
+        # bucket boundaries: cut after the parameter at which the running size passes the bucket's share; the share is re-computed from
+        # what is LEFT after every cut (one large tensor -- the x4 tail's 3x3 convolutions sit at the front of the order -- must not
+        # leave the following bucket with a sliver)
         n_buckets = max(1, min(int(n_buckets), n))
         total, run, k = self.flat.numel(), 0, 1
         self.bucket_members, cur, self.bucket_ranges, start = [], [], [], 0
+        goal = total / n_buckets
         for i in order:
             cur.append(i)
             run += grads[i].numel()
-            if k < n_buckets and run >= k * total / n_buckets:
+            if k < n_buckets and run >= goal:
                 self.bucket_members.append(cur)
                 self.bucket_ranges.append((start, run))
                 cur, start, k = [], run, k + 1
+                goal = run + (total - run) / (n_buckets - k + 1)
         if cur or not self.bucket_members:
             self.bucket_members.append(cur)
             self.bucket_ranges.append((start, total))
