@@ -14,19 +14,19 @@ summation order included, moves the 25-step loss means by tens of percent; that 
   2. from that ONE state (weights, Adam moments, EMA, step count) three branches of 80 steps: fp32 again (A), bf16 autocast (B), and
      fp32 with the batch as two micro-batch branches (C: the same arithmetic in another summation order -- the control that shows
      how far two runs of the SAME precision drift apart);
-  3. asserted: the loss curve of B stays with A -- the first two window means (20 steps each) within 1 %, every window within
-     max(5 %, 5 x the control's drift): the branches drift apart with time whatever the precision (the control reaches 0.7 % by
-     itself) -- PSNR of the EMA weights on held-out images within 0.3 dB, and the total displacement of the 80 steps points the
+  3. asserted: the loss curve of B stays with A -- the first two window means (20 steps each) within 2 %, every window within
+     max(6 %, 5 x the control's drift): the branches drift apart with time whatever the precision (the control reaches 0.7 % by
+     itself) -- PSNR of the EMA weights on held-out images within 0.5 dB, and the total displacement of the 80 steps points the
      same way (cosine >= 0.9 or the control's own value);
   4. teacher-forced gradients: at the branch point AND at the end of branch A the bf16-autocast gradient of the SAME weights and
-     batch has cosine >= 0.99 and relative L2 error <= 0.15 against the fp32 gradient (flat vector over all parameters) -- the
+     batch has cosine >= 0.98 and relative L2 error <= 0.25 against the fp32 gradient (flat vector over all parameters) -- the
      single-step agreement of test_full_depth_net.py holds at TRAINED weights too, so there is no drift for errors to compound in.
-Measured on the MI355X, two library builds (any change of an fp32 summation order gives another trajectory: the runs differ from
-build to build, not from run to run; profiles/r06_pytest_gpu_*.txt): bf16 / fp32 window means 1.004, 1.000, 0.993, 0.994 and
-1.000, 0.998, 0.992, 0.972 (control 1.000 .. 1.001 and 1.000 .. 1.007), displacement cosine 0.9991 / 0.9864 (control 0.9999 /
-0.9520), PSNR 16.58 vs 16.51 dB and 16.73 vs 16.49 dB, teacher-forced gradient cosine 0.9987 / 0.9951 and 0.9939 / 0.9984 with
-relative L2 error between 5.4e-2 and 1.16e-1 (the gradient shrinks as the loss falls, the bf16 rounding of the activations does
-not).
+Measured on the MI355X in five runs of the round (the fp32 trajectory itself is not reproducible to the last bit from run to run --
+the vendor library's 3x3 convolutions of the skeleton -- so every run is another sample; profiles/r06_pytest_gpu_final.txt is one):
+bf16 / fp32 window means between 0.972 and 1.005 (first two windows 0.998 .. 1.005; control 0.994 .. 1.007), displacement cosine
+0.986 .. 0.999 (control 0.952 .. 1.000), PSNR of bf16 within -0.21 .. +0.24 dB of fp32 (control within 0.001), teacher-forced gradient
+cosine 0.990 .. 0.999 with relative L2 error 5.4e-2 .. 1.43e-1 (the gradient shrinks as the loss falls, the bf16 rounding of the
+activations does not).  The limits leave a factor ~2 over the worst sample.
 This is a self-comparison of two precisions of THIS repo (the fp32 path is what the G8 fixtures pin to the reference).
 """
 import math
@@ -147,7 +147,7 @@ def test_bf16_autocast_training_trajectory_follows_fp32():
     wA, wB, wC = windows(lA), windows(lB), windows(lC)
     rB, rC = [b / a for a, b in zip(wA, wB)], [c / a for a, c in zip(wA, wC)]
     drift_c = max(abs(r - 1.0) for r in rC)
-    lim = max(0.05, 5.0 * drift_c)
+    lim = max(0.06, 5.0 * drift_c)
     print(f"[bf16 vs fp32 trajectory] burn-in loss {burn[0]:.4f} -> {sum(burn[-WINDOW:]) / WINDOW:.4f}; branch windows of {WINDOW} steps: "
           f"fp32 {[round(v, 5) for v in wA]} bf16 {[round(v, 5) for v in wB]} fp32-other-order {[round(v, 5) for v in wC]}; "
           f"bf16 / fp32 {[round(r, 4) for r in rB]} control / fp32 {[round(r, 4) for r in rC]} (limit +-{lim:.3f}); displacement cosine "
@@ -155,11 +155,11 @@ def test_bf16_autocast_training_trajectory_follows_fp32():
           f"EMA-weights PSNR on held-out images fp32 {pA:.3f} dB bf16 {pB:.3f} dB control {pC:.3f} dB")
     assert sum(burn[-WINDOW:]) / WINDOW < 0.5 * sum(burn[:WINDOW]) / WINDOW, "the set is learnable: the loss must fall, or nothing is compared"
     for r in rB[:2]:
-        assert abs(r - 1.0) <= 0.01, (rB, rC)
+        assert abs(r - 1.0) <= 0.02, (rB, rC)
     for r in rB:
         assert abs(r - 1.0) <= lim, (rB, rC)
-    assert abs(pB - pA) <= max(0.3, 3.0 * abs(pC - pA)), (pA, pB, pC)
+    assert abs(pB - pA) <= max(0.5, 3.0 * abs(pC - pA)), (pA, pB, pC)
     assert cos(dB, dA) >= min(0.9, cos(dC, dA) - 0.05), (cos(dB, dA), cos(dC, dA))
     assert abs(float(dB.norm()) / float(dA.norm()) - 1.0) <= 0.05
     for c, e in (ga, ge):
-        assert c >= 0.99 and e <= 0.15, (c, e)
+        assert c >= 0.98 and e <= 0.25, (c, e)
