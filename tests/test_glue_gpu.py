@@ -494,3 +494,42 @@ def test_conv1x1_fp32_route_and_fallbacks(monkeypatch):
     assert not ops.conv1x1(odd, conv).grad_fn.__class__.__name__.startswith("Conv1x1Fn")
     monkeypatch.setattr(ops.pointwise, "CONV1X1_F32", False)
     assert not ops.conv1x1(x, conv).grad_fn.__class__.__name__.startswith("Conv1x1Fn")
+
+
+def test_family_byte_counters_follow_the_entry_points():
+    """(round 6) ``oss_prof_family*`` (include/vmambair_oss.h): the algorithmic-bytes accounting behind bench.py's
+    ``roofline.non_scan`` -- counting on: a 1x1 convolution and a LayerNorm add their formula's bytes to their own family and to no
+    other; counting off: nothing moves; switching it on again clears the counters."""
+    import ctypes as C
+    from vmambair_amd import _capi
+    lib = _capi.load()
+
+    def read():
+        out = {}
+        for f in range(int(lib.oss_prof_family_count())):
+            name, pat, by, calls = C.c_char_p(), C.c_char_p(), C.c_double(), C.c_longlong()
+            assert lib.oss_prof_family(f, C.byref(name), C.byref(pat), C.byref(by), C.byref(calls)) == 0
+            out[name.value.decode()] = (by.value, calls.value, pat.value.decode())
+        return out
+    B, Cin, Cout, H, W = 2, 96, 192, 32, 32
+    x = torch.randn(B, Cin, H, W, device=DEV).to(torch.bfloat16)
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=True).to(DEV)
+    wln, bln = torch.ones(Cin, device=DEV), torch.zeros(Cin, device=DEV)
+    lib.oss_prof_family_enable(1)
+    ops.conv1x1(x, conv)
+    ops.layer_norm_nchw(x, wln, bln, None, None, False, None)
+    lib.oss_prof_family_enable(0)
+    ops.conv1x1(x, conv)                       # not counted
+    torch.cuda.synchronize()
+    got = read()
+    conv_fam = next(k for k in got if k.startswith("conv1x1"))
+    ln_fam = next(k for k in got if k.startswith("LayerNorm"))
+    P = H * W
+    assert got[conv_fam][1] == 1 and got[conv_fam][0] == B * P * 2 * (Cin + Cout) + 4 * Cin * Cout
+    assert got[ln_fam][1] == 1 and got[ln_fam][0] == B * Cin * P * (2 + 2) + 8 * B * P
+    assert all(v[1] == 0 for k, v in got.items() if k not in (conv_fam, ln_fam)), got
+    assert "oss_conv1x1_wg_kernel" in got[conv_fam][2] and "oss_ln_nchw" in got[ln_fam][2]
+    assert lib.oss_prof_family(99, None, None, None, None) != 0
+    lib.oss_prof_family_enable(1)
+    lib.oss_prof_family_enable(0)
+    assert all(v[1] == 0 for v in read().values())

@@ -496,3 +496,46 @@ def test_conv_core_node_is_gpu_only_and_shape_gated():
     # 16-bit and float I/O, H % 8 == 0, W / 8 a power of two <= 32
     assert lib.oss_dwconv3x3_flat2_ok(2, 64, 64) == 1 and lib.oss_dwconv3x3_flat2_ok(0, 128, 128) == 1
     assert lib.oss_dwconv3x3_flat2_ok(2, 60, 64) == 0 and lib.oss_dwconv3x3_flat2_ok(1, 160, 160) == 0 and lib.oss_dwconv3x3_flat2_ok(2, 8, 512) == 0
+
+
+def test_bench_non_scan_roofline_table_from_counts_and_a_trace():
+    """bench.py ``non_scan_roofline``: the family table of ``roofline.non_scan`` from (a) the library's byte counts per family and
+    (b) a kernel trace -- kernels are assigned by the family's name patterns, scan kernels and the marker kernels are left out of
+    the non-scan totals, unknown kernels land in "other", rates are bytes / time"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fams = [{"family": "conv1x1 forward", "patterns": ["oss_conv1x1_wg_kernel", "oss_conv1x1_pair_kernel"], "alg_bytes_per_step": 8e9, "entry_calls_per_step": 400},
+            {"family": "LayerNorm", "patterns": ["oss_ln_nchw"], "alg_bytes_per_step": 3e9, "entry_calls_per_step": 150},
+            {"family": "unused", "patterns": ["oss_never"], "alg_bytes_per_step": 0.0, "entry_calls_per_step": 0}]
+    trace = {"steps": 3, "wall_ms_per_step": 30.0, "kernels": [
+        {"name": "void oss::oss_scan_bwd2_kernel<oss::bf16_t, 12, 4, 3, false, false, false, false>(...)", "launches_per_step": 32, "ms_per_step": 7.0, "avg_us": 218.75},
+        {"name": "void oss::oss_conv1x1_wg_kernel<oss::bf16_t, 6, false, 128>(...)", "launches_per_step": 60, "ms_per_step": 1.0, "avg_us": 16.7},
+        {"name": "void oss::oss_conv1x1_pair_kernel<oss::bf16_t, 6>(...)", "launches_per_step": 40, "ms_per_step": 1.0, "avg_us": 25.0},
+        {"name": "void oss::oss_ln_nchw_fwd_kernel<float>(...)", "launches_per_step": 50, "ms_per_step": 0.5, "avg_us": 10.0},
+        {"name": "igemm_fwd_gtcx35_nhwc_bf16", "launches_per_step": 2, "ms_per_step": 0.25, "avg_us": 125.0},
+        {"name": "oss::oss_prof_marker_begin()", "launches_per_step": 1 / 3, "ms_per_step": 0.001, "avg_us": 3.0}]}
+    r = bench.non_scan_roofline(fams, trace)
+    by = {f["family"]: f for f in r["families"]}
+    assert set(by) == {"conv1x1 forward", "LayerNorm", "other (vendor 3x3 convolutions / transposes, aten)"}
+    assert by["conv1x1 forward"]["launches_per_step"] == 100 and by["conv1x1 forward"]["ms_per_step"] == 2.0
+    assert by["conv1x1 forward"]["alg_GBps"] == 4000.0 and by["conv1x1 forward"]["frac_of_hbm_peak"] == 0.5
+    assert by["LayerNorm"]["alg_GBps"] == 6000.0
+    assert by["other (vendor 3x3 convolutions / transposes, aten)"]["alg_GBps"] is None
+    assert r["scan"]["launches_per_step"] == 32 and r["scan"]["dominant_kernel_in_graph"]["avg_launch_ms"] == 0.2188
+    assert r["non_scan"]["launches_per_step"] == 152 and abs(r["non_scan"]["ms_per_step"] - 2.75) < 1e-9
+    assert [k["family"] for k in r["top_kernels"]][:2] == ["conv1x1 forward", "conv1x1 forward"]
+    assert all("marker" not in k["kernel"] for k in r["top_kernels"])
+
+
+def test_scan_tune_tuple_maps_to_the_struct_encoding():
+    """``selective_scan_fwd / _bwd(tune=...)`` -> oss_scan_*_params.tune_* (0 = heuristic, variant + 1; "bf16" -> tune_partials 2)"""
+    from vmambair_amd.ops.scan import _tune_fields
+    assert _tune_fields(None) == (0, 0, 0, 0)
+    assert _tune_fields((0, 2, 4)) == (1, 2, 4, 0)
+    assert _tune_fields((13, 1, None, "bf16")) == (14, 1, 0, 2)
+    assert _tune_fields((None, None, None)) == (0, 0, 0, 0)
+    assert _tune_fields((-1, -1, 0, None)) == (0, 0, 0, 0)
