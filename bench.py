@@ -712,7 +712,9 @@ def main():
     rccl = {"ok": None, "fallback": None, "preflight_ms": None}
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.share_gpu:
+        # VMAMBAIR_SHARE_GPU_RCCL=1 (test of the fall-back on a 1-GPU box): the ranks share a GPU but take the RCCL path -- RCCL refuses
+        # two ranks on one device, so the preflight fails and the host-staged exchange takes over
+        if args.share_gpu and os.environ.get("VMAMBAIR_SHARE_GPU_RCCL", "0") != "1":
             dist.init_process_group("gloo")
             rccl.update(ok=False, fallback="--share-gpu: gloo by request")
         else:
@@ -1017,7 +1019,9 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         host_barrier()
-        if via_host and not args.share_gpu:
+        if via_host and rccl["ok"] is False and "by request" not in (rccl["fallback"] or ""):
+            sys.stdout.flush()
+            sys.stderr.flush()
             os._exit(0)   # RCCL is in an unknown state (a preflight thread may still sit in it): leave without its teardown
         dist.destroy_process_group()
 
