@@ -533,3 +533,50 @@ def test_family_byte_counters_follow_the_entry_points():
     lib.oss_prof_family_enable(1)
     lib.oss_prof_family_enable(0)
     assert all(v[1] == 0 for v in read().values())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,has_bias,with_res", [
+    (2, 255, 96, 32, 32, False, True),     # project_out of a dim-96 block: odd K, two chunks, skip connection
+    (2, 96, 510, 32, 32, False, False),    # project_in of the same block: its INPUT GRADIENT is the K = 510 contraction (4 chunks)
+    (1, 510, 128, 16, 16, True, False),    # four row tiles, bias, forward at K = 510
+    (2, 200, 48, 16, 16, True, True),      # K just above the single-tile kernel's limit, ragged last chunk, M = 48
+    (1, 512, 96, 16, 8, False, False),     # K = 512 exactly
+    (1, 193, 33, 16, 16, True, False),     # odd everything
+])
+def test_conv1x1_wide_contraction_workgroup_kernel(dt, B, Cin, Cout, H, W, has_bias, with_res):
+    """(round 6) oss_conv1x1_wgk.hip: 192 < K <= 512 input channels through a K-chunked workgroup-level kernel (activation and
+    weight chunks staged in LDS, transpose-reads, zero-filled tails) -- forward (+ bias, + skip connection) and input gradient
+    against float64 convolutions of the SAME rounded operands, and against the wave-level kernels they replace"""
+    from vmambair_amd import _capi
+    lib = _capi.load()
+    torch.manual_seed(Cin + Cout)
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=has_bias).to(DEV)
+    x = torch.randn(B, Cin, H, W, device=DEV).to(dt)
+    res = torch.randn(B, Cout, H, W, device=DEV).to(dt) if with_res else None
+    gy = torch.randn(B, Cout, H, W, device=DEV).to(dt)
+
+    def run():
+        xi = x.clone().requires_grad_()
+        y = ops.conv1x1(xi, conv, res)
+        y.backward(gy)
+        return y.detach(), xi.grad.detach()
+    outs = {}
+    try:
+        for on in (1, 0):
+            lib.oss_conv1x1_set_wgk(on)
+            outs[on] = run()
+    finally:
+        lib.oss_conv1x1_set_wgk(1)
+    # the weights are narrowed to the I/O type inside the kernels: the reference uses the same rounded operands, in float64
+    wq = conv.weight.detach().to(dt).double()
+    yref = F.conv2d(x.double(), wq, conv.bias.detach().double() if has_bias else None)
+    if with_res:
+        yref = yref + res.double()
+    dxref = F.conv_transpose2d(gy.double(), wq)
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    for name, got, want in (("y", outs[1][0], yref), ("dx", outs[1][1], dxref)):
+        assert_close(got.double(), want, 2 * eps, 2 * eps * float(want.abs().max()), f"wide-K kernel {name}")
+    # same products, fp32 accumulation: the two kernel families differ by summation order only
+    for a, b_, name in ((outs[1][0], outs[0][0], "y"), (outs[1][1], outs[0][1], "dx")):
+        assert_close(a.float(), b_.float(), 2 * eps, 2 * eps * float(b_.float().abs().max()), f"wide-K vs wave-level {name}")

@@ -1001,6 +1001,10 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
         const bool wt = (ws_m == 1 && ws_k == M), plain = (ws_k == 1 && ws_m == K);
         if ((wt || plain) && conv_wg_on() && conv1x1_wg_ok(io, M, K, P, xsb, xsk, x, y, w, res))
             return conv1x1_wg(io, x, w, bias, y, B, M, K, P, xsb, xsk, wt ? 1 : 0, s, res);
+        // (round 6) wide contractions (192 < K <= 512, M <= 128: project_out, project_in's input gradient): the K-chunked
+        // workgroup-level kernel of oss_conv1x1_wgk.hip
+        if ((wt || plain) && conv_wg_on() && conv1x1_wgk_ok(io, M, K, P, xsb, xsk, x, y, w, res, wt ? 1 : 0))
+            return conv1x1_wgk(io, x, w, bias, y, B, M, K, P, xsb, xsk, wt ? 1 : 0, s, res);
     }
     switch (io) {
         case OSS_BF16:
