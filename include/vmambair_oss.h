@@ -335,11 +335,6 @@ int oss_conv1x1_dgrad_ln_bwd(oss_dtype io, const void *dy, const float *weight, 
 /* A-B switches of the dispatch inside oss_conv1x1_fwd / _dgrad: on = 0 never takes the workgroup-level kernel (env
  * VMAMBAIR_CONV1X1_WG=0); pixels = 64 | 128 forces its tile width, 0 = by grid size */
 void oss_conv1x1_set_wg(int on, int pixels);
-/* (round 6) 1 (default; env VMAMBAIR_CONV1X1_WGK=0 turns it off): 16-bit 1x1 convolutions with a wide contraction (192 < K <= 512 input
- * channels, <= 128 output rows, pixels % 128 == 0 -- the EFFN's project_out and the input gradient of project_in,
- * SRGAN/VmambaIR/archs/MambaSISR6_arch.py:201-218) take the K-chunked workgroup-level kernel of oss_conv1x1_wgk.hip instead of the
- * wave-level kernels.  Test / A-B switch, process-global like oss_conv1x1_set_wg. */
-void oss_conv1x1_set_wgk(int on);
 void oss_conv1x1_wgrad_set_tile(int mode);
 /* pixels per partial product of the GROUPED weight-gradient launch (oss_flush_wgrads), in units of 512: default 4 (env
  * VMAMBAIR_WGRAD_SPAN); 1 reproduces the one-problem launches bit for bit, larger values write fewer partial vectors */

@@ -123,7 +123,11 @@ def test_fused_scan_merge_node_equals_separate_ops():
                                             (1, 96, 510, 64, 64), (1, 48, 192, 32, 48), (1, 96, 97, 24, 24),
                                             # round 3: the workgroup-level kernel (K % 16 == 0, H W % 128 == 0) with ragged row tiles,
                                             # one / two / twelve k-steps, fewer row tiles than waves
-                                            (1, 96, 97, 16, 16), (2, 32, 40, 16, 8), (1, 16, 8, 8, 16), (1, 192, 33, 16, 8), (2, 64, 255, 16, 16)])
+                                            (1, 96, 97, 16, 16), (2, 32, 40, 16, 8), (1, 16, 8, 8, 16), (1, 192, 33, 16, 8), (2, 64, 255, 16, 16),
+                                            # round 6: unaligned weight rows (K % 4 != 0) with an odd number of rows in the ragged last row tile --
+                                            # the tile's block of rows * K floats ends in a PARTIAL quad (the staging stored it unshifted: the last
+                                            # 1 - 3 weights of the matrix's last row were wrong; tools/conv_wave_check.py)
+                                            (1, 193, 33, 16, 16), (1, 255, 31, 8, 8), (1, 127, 97, 8, 16), (1, 510, 65, 8, 8), (1, 201, 33, 8, 8)])
 @pytest.mark.parametrize("has_bias", [True, False])
 def test_conv1x1_mfma(dt, B, Cin, Cout, H, W, has_bias):
     """MFMA 1x1 convolution (fwd, input grad, weight grad) against F.conv2d in fp32 on the same
@@ -533,50 +537,3 @@ def test_family_byte_counters_follow_the_entry_points():
     lib.oss_prof_family_enable(1)
     lib.oss_prof_family_enable(0)
     assert all(v[1] == 0 for v in read().values())
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("B,Cin,Cout,H,W,has_bias,with_res", [
-    (2, 255, 96, 32, 32, False, True),     # project_out of a dim-96 block: odd K, two chunks, skip connection
-    (2, 96, 510, 32, 32, False, False),    # project_in of the same block: its INPUT GRADIENT is the K = 510 contraction (4 chunks)
-    (1, 510, 128, 16, 16, True, False),    # four row tiles, bias, forward at K = 510
-    (2, 200, 48, 16, 16, True, True),      # K just above the single-tile kernel's limit, ragged last chunk, M = 48
-    (1, 512, 96, 16, 8, False, False),     # K = 512 exactly
-    (1, 193, 33, 16, 16, True, False),     # odd everything
-])
-def test_conv1x1_wide_contraction_workgroup_kernel(dt, B, Cin, Cout, H, W, has_bias, with_res):
-    """(round 6) oss_conv1x1_wgk.hip: 192 < K <= 512 input channels through a K-chunked workgroup-level kernel (activation and
-    weight chunks staged in LDS, transpose-reads, zero-filled tails) -- forward (+ bias, + skip connection) and input gradient
-    against float64 convolutions of the SAME rounded operands, and against the wave-level kernels they replace"""
-    from vmambair_amd import _capi
-    lib = _capi.load()
-    torch.manual_seed(Cin + Cout)
-    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=has_bias).to(DEV)
-    x = torch.randn(B, Cin, H, W, device=DEV).to(dt)
-    res = torch.randn(B, Cout, H, W, device=DEV).to(dt) if with_res else None
-    gy = torch.randn(B, Cout, H, W, device=DEV).to(dt)
-
-    def run():
-        xi = x.clone().requires_grad_()
-        y = ops.conv1x1(xi, conv, res)
-        y.backward(gy)
-        return y.detach(), xi.grad.detach()
-    outs = {}
-    try:
-        for on in (1, 0):
-            lib.oss_conv1x1_set_wgk(on)
-            outs[on] = run()
-    finally:
-        lib.oss_conv1x1_set_wgk(1)
-    # the weights are narrowed to the I/O type inside the kernels: the reference uses the same rounded operands, in float64
-    wq = conv.weight.detach().to(dt).double()
-    yref = F.conv2d(x.double(), wq, conv.bias.detach().double() if has_bias else None)
-    if with_res:
-        yref = yref + res.double()
-    dxref = F.conv_transpose2d(gy.double(), wq)
-    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
-    for name, got, want in (("y", outs[1][0], yref), ("dx", outs[1][1], dxref)):
-        assert_close(got.double(), want, 2 * eps, 2 * eps * float(want.abs().max()), f"wide-K kernel {name}")
-    # same products, fp32 accumulation: the two kernel families differ by summation order only
-    for a, b_, name in ((outs[1][0], outs[0][0], "y"), (outs[1][1], outs[0][1], "dx")):
-        assert_close(a.float(), b_.float(), 2 * eps, 2 * eps * float(b_.float().abs().max()), f"wide-K vs wave-level {name}")

@@ -528,7 +528,6 @@ int oss_conv1x1_dgrad_ln_bwd(oss_dtype io, const void *dy, const float *weight, 
 }
 
 void oss_conv1x1_set_wg(int on, int pixels) { conv1x1_set_wg(on); conv1x1_wg_set_pixels(pixels); }
-void oss_conv1x1_set_wgk(int on) { conv1x1_set_wgk(on); }
 void oss_conv1x1_wgrad_set_tile(int mode) { conv1x1_wgrad_set_tile(mode); }
 void oss_conv1x1_wgrad_set_span(int mult) { conv1x1_wgrad_set_span(mult); }
 

@@ -513,7 +513,11 @@ oss_conv1x1_pairw_kernel(const T *__restrict__ x, const float *__restrict__ w, c
             }
         }
     } else {   // ---- the tile's weights -> LDS
-        const int total = 32 * K, lim = min(M - m0, 32) * K - 4;
+        // the tile's rows are ONE contiguous block of `have` floats, copied in quads.  When `have` is not a multiple of 4 (odd K with
+        // an odd number of rows in a ragged last tile: K = 193, M = 33) the last quad starts past `lim` and is read `d` elements
+        // EARLIER (clamped address): its values then sit `d` slots further up in the register.  (Round 6: until then they were
+        // stored unshifted and the last 1 - 3 weights of the matrix's last row were wrong -- found by tools/conv_wave_check.py.)
+        const int have = min(M - m0, 32) * K, total = 32 * K, lim = max(have - 4, 0);
         const float *base = w + (size_t)m0 * K;
         f32x4 q[NI];
 #pragma unroll
@@ -522,11 +526,17 @@ oss_conv1x1_pairw_kernel(const T *__restrict__ x, const float *__restrict__ w, c
         const int sr = 1024 / K, sk = 1024 - sr * K;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (4 * (i * 256 + tid) < total) {
+            const int off = 4 * (i * 256 + tid);
+            if (off < total) {
+                const int d = max(off - lim, 0);          // 0 except for the block's last, partial quad (1 .. 3)
+                float v4[4] = {q[i][0], q[i][1], q[i][2], q[i][3]};
+                if (d == 1) { v4[0] = v4[1]; v4[1] = v4[2]; v4[2] = v4[3]; }
+                else if (d == 2) { v4[0] = v4[2]; v4[1] = v4[3]; }
+                else if (d >= 3) { v4[0] = v4[3]; }
                 int rr = r, kk = k;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (rr < 32) wl[rr * RS + kk] = from_f32<T>(q[i][e]);
+                    if (rr < 32 && off + e < have) wl[rr * RS + kk] = from_f32<T>(v4[e]);
                     if (++kk == K) { kk = 0; ++rr; }
                 }
             }
@@ -1001,10 +1011,6 @@ int conv1x1(oss_dtype io, const void *x, const float *w, const float *bias, void
         const bool wt = (ws_m == 1 && ws_k == M), plain = (ws_k == 1 && ws_m == K);
         if ((wt || plain) && conv_wg_on() && conv1x1_wg_ok(io, M, K, P, xsb, xsk, x, y, w, res))
             return conv1x1_wg(io, x, w, bias, y, B, M, K, P, xsb, xsk, wt ? 1 : 0, s, res);
-        // (round 6) wide contractions (192 < K <= 512, M <= 128: project_out, project_in's input gradient): the K-chunked
-        // workgroup-level kernel of oss_conv1x1_wgk.hip
-        if ((wt || plain) && conv_wg_on() && conv1x1_wgk_ok(io, M, K, P, xsb, xsk, x, y, w, res, wt ? 1 : 0))
-            return conv1x1_wgk(io, x, w, bias, y, B, M, K, P, xsb, xsk, wt ? 1 : 0, s, res);
     }
     switch (io) {
         case OSS_BF16:

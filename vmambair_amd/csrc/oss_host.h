@@ -135,12 +135,6 @@ int conv1x1_dgrad_lnbwd(oss_dtype io, const void *dy, const float *w, const void
                         const float *rstd, const void *skip, void *dx, float *dlw, float *dlb, float *part, int B, int M, int K, int P,
                         int64_t xsb, int64_t xsk, hipStream_t s);
 void conv1x1_set_wg(int on);
-// K-chunked workgroup-level 1x1 convolution for 192 < K <= 512, M <= 128 (oss_conv1x1_wgk.hip)
-int conv1x1_wgk_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,
-                   const void *res, int wt);
-int conv1x1_wgk(oss_dtype io, const void *x, const float *w, const float *bias, void *y, int B, int M, int K, int P, int64_t xsb,
-                int64_t xsk, int wt, hipStream_t s, const void *res);
-void conv1x1_set_wgk(int on);
 void conv1x1_wg_set_pixels(int pt);
 int conv1x1_wg_ok(oss_dtype io, int M, int K, int P, int64_t xsb, int64_t xsk, const void *x, const void *y, const float *w,
                   const void *res = nullptr);
