@@ -10,8 +10,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vmambair_amd import _capi, ops  # noqa: E402
 
 lib = _capi.load()
-if hasattr(lib, "oss_conv1x1_set_wgk"):
-    lib.oss_conv1x1_set_wgk(0)
 dev = "cuda:0"
 for dt in (torch.bfloat16,):
     for K in (127, 129, 191, 193, 200, 201, 255, 257, 300, 510):
