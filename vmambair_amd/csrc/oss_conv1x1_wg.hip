@@ -108,6 +108,18 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k0 = ks * 16 + kg * 8;
+#ifdef OSS_EXP_WG_HALF_W   // TIMING ONLY (wrong results): half of the weight bytes -- what 16-bit master copies would cost to load
+            if constexpr (!WT) {
+                r.lo[ks] = *reinterpret_cast<const f32x4 *>(w + (size_t)mrow * K + k0);
+                r.hi[ks] = r.lo[ks];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r.lo[ks][e] = w[(size_t)(k0 + e) * M + mrow];
+                    r.hi[ks][e] = r.lo[ks][e];
+                }
+            }
+#else
             if constexpr (!WT) {
                 r.lo[ks] = *reinterpret_cast<const f32x4 *>(w + (size_t)mrow * K + k0);
                 r.hi[ks] = *reinterpret_cast<const f32x4 *>(w + (size_t)mrow * K + k0 + 4);
@@ -118,6 +130,7 @@ oss_conv1x1_wg_kernel(const T *__restrict__ x, const float *__restrict__ w, cons
                     r.hi[ks][e] = w[(size_t)(k0 + 4 + e) * M + mrow];
                 }
             }
+#endif
         }
         r.bl = bias ? bias[mrow] : 0.f;
     };
