@@ -124,6 +124,13 @@ def bench_realsr_tiled(args):
     from vmambair_amd.archs import build_network
     from vmambair_amd.infer import RealSREnhancer
     lib = _capi.load()
+    # A-B timing only (test-suite setters): VMAMBAIR_SCAN_SEGMENTS="fwd,bwd" time segments per row, VMAMBAIR_SCAN_VARIANT="fwd,bwd" kernel variants
+    if os.environ.get("VMAMBAIR_SCAN_SEGMENTS"):
+        fs, bs = (int(v) for v in os.environ["VMAMBAIR_SCAN_SEGMENTS"].split(","))
+        lib.oss_scan_set_segments(fs, bs)
+    if os.environ.get("VMAMBAIR_SCAN_VARIANT"):
+        fv, bv = (int(v) for v in os.environ["VMAMBAIR_SCAN_VARIANT"].split(","))
+        lib.oss_scan_set_variant(fv, bv)
     torch.manual_seed(0)
     net = build_network(NET_REALSR).to(dev)
     img = torch.rand(1, 3, 512, 512, device=dev)
