@@ -203,7 +203,10 @@ def test_realsr_enhancer_fp16_on_gpu_matches_cpu_twin():
         again = drv4c.enhance_tensor(img)
         torch.cuda.synchronize()
         assert torch.equal(again, first)
-    assert torch.equal(first, got4) and len(drv4c.tiled._streams) == drv4c.tiled.n_graphs > 1
+    # (round 6) side by side the scans are never cut into time segments (infer.TiledSR: scan_tuning): where the sequential form's
+    # heuristic segments a call, the two agree to fp32 round-off of the scan's carries instead of bit for bit
+    assert_close(first, got4, 2e-3, 2e-3, "shape groups side by side against one after the other")
+    assert len(drv4c.tiled._streams) == drv4c.tiled.n_graphs > 1
 
 
 def test_tiles_stacked_on_the_batch_axis_give_the_same_image():

@@ -88,6 +88,16 @@ class TiledSR:
         return len(self._graphs)
 
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        if self.concurrent_shapes and self.batch_tiles > 1 and img.shape[0] == 1 and img.is_cuda:
+            # (round 6) the shape groups run side by side on their own streams and fill the GPU TOGETHER: a scan that cuts itself into
+            # time segments because ITS OWN call leaves CUs idle only adds its local pass (512 x 512 in tiles of 128 + 16: 20.2 ->
+            # 21.5 images/s with the segments off, profiles/r06_ab_realsr_segments.txt).  Per-call tune fields, baked into the graphs.
+            from .ops.scan import scan_tuning
+            with scan_tuning(fwd=(None, 1, None)):
+                return self._call(img)
+        return self._call(img)
+
+    def _call(self, img: torch.Tensor) -> torch.Tensor:
         B, C, H, W = img.shape
         s = self.scale
         out = None

@@ -102,6 +102,28 @@ def _fill_fwd(P, u, delta, A, B, C, D, delta_bias, out, x, dims, delta_softplus,
     P.hs = _ptr(hs) if (hs is not None and hs.numel()) else None
 
 
+import contextlib
+import threading
+
+_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def scan_tuning(fwd: Optional[tuple] = None, bwd: Optional[tuple] = None):
+    """Per-thread DEFAULT launch shape of the scan calls issued inside the context by code that does not pass ``tune=`` itself (the
+    block / net modules): ``fwd`` / ``bwd`` = ``(variant, segments, carry_split[, partials])`` as ``selective_scan_fwd / _bwd(tune=)``
+    take them.  It ends up in the per-call fields of the params structs (include/vmambair_oss.h: tune_*), never in the library's
+    process-global setters -- so it is safe next to other threads and streams, and a hipGraph captured inside keeps the shape.
+    Used by infer.TiledSR(concurrent_shapes=True): four forwards side by side already fill the GPU, so their scans must not be cut
+    into time segments (the heuristic only sees ONE call's workgroup count)."""
+    old = (getattr(_TLS, "fwd", None), getattr(_TLS, "bwd", None))
+    _TLS.fwd, _TLS.bwd = fwd, bwd
+    try:
+        yield
+    finally:
+        _TLS.fwd, _TLS.bwd = old
+
+
 def _tune_fields(tune):
     """``(variant, segments, carry_split[, partials])`` with None = heuristic -> the C struct's encoding (0 = heuristic,
     variant + 1; partials "bf16" -> oss_scan_bwd_params.tune_partials = 2, backward only: bf16 row-tile partials, opt-in)"""
@@ -122,7 +144,7 @@ def selective_scan_fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     kernels evaluate delta themselves -- see include/vmambair_oss.h.  ``want_hs``: -> ``[out, x, hs]`` with the lane states
     (the state entering every 8-step block) for ``selective_scan_bwd(..., hs=hs)``.  ``tune``: per-call launch shape
     ``(variant or None, segments or None, carry_split or None)`` -> ``oss_scan_fwd_params.tune_*`` (None = heuristic)."""
-    tv, ts, tc, _ = _tune_fields(tune)
+    tv, ts, tc, _ = _tune_fields(tune if tune is not None else getattr(_TLS, "fwd", None))
     if want_hs:
         _capi.require_feature(_capi.FEATURE_LANE_STATES, "selective_scan_fwd(want_hs=True)")
     if dt_weight is not None:
@@ -178,7 +200,7 @@ def selective_scan_bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B:
     ``finish_dt_weight`` (dim, R) fp32 (needs ``dbc_into``, not together with ``dt_weight``): ``ddelta`` is returned as usual AND the
     finishing launch fills the first R rows of ``dbc_into`` with ``dt_projs_weight^T . ddelta`` -- the dt rows of the gradient of
     x_dbl, which ``oss_proj_dgrad`` is then not asked for (include/vmambair_oss.h: oss_scan_bwd_params.finish_dt_weight)."""
-    tv, ts, tc, tp = _tune_fields(tune)
+    tv, ts, tc, tp = _tune_fields(tune if tune is not None else getattr(_TLS, "bwd", None))
     host = _host.ops()
     if host is not None and u.is_cuda:   # compiled boundary: [du, ddelta, dA, dB, dC, dD, dbias, ddt_weight], empty = absent
         r = host.scan_bwd(u, delta, A, B, C, D, delta_bias, dout, x, bool(delta_softplus),
