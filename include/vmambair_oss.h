@@ -254,6 +254,8 @@ int oss_dwconv3x3_wgrad(oss_dtype io, const void *x, const void *dy, float *dwei
  *                           weight gradient reads anyway, dy * silu' stays in LDS between the two passes of ONE launch
  *   oss_dwgate_fwd:         out (batch, hidden, H, W) = gelu(x1) * x2 with x1, x2 = the two channel halves of
  *                           conv(t) + bias, t (batch, 2 hidden, H, W)         (FeedForward.forward, MambaSISR6_arch.py:213-217)
+ *                           The forward streams (nothing LDS-resident) and takes every plane oss_dwgate_fwd_ok accepts: width a multiple
+ *                           of 8 and <= 512, any height -- the inference path of planes the backward's form cannot hold
  *   oss_dwgate_bwd:         dt, dweight (2 hidden, 9), dbias of it from t and dout, one launch
  * partials: batch * channels * 10 floats of scratch (channels = 2 hidden for the gate); dbias may be NULL.  The gradients that
  * reach the convolution are rounded to the io type before both uses, as the separate kernels hand them over. */
@@ -265,6 +267,7 @@ int oss_dwconv3x3_silu_bwd(oss_dtype io, const void *x, const float *weight, con
                            float *dweight, float *dbias, float *partials, int batch, int channels, int height, int width,
                            int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride, int64_t dy_channel_stride,
                            int64_t dx_batch_stride, int64_t dx_channel_stride, oss_stream_t stream);
+int oss_dwgate_fwd_ok(oss_dtype io, int height, int width);
 int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
                    int height, int width, int64_t t_batch_stride, int64_t t_channel_stride, int64_t out_batch_stride,
                    int64_t out_channel_stride, oss_stream_t stream);

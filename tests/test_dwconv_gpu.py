@@ -215,6 +215,38 @@ def test_shapes_the_fused_forms_leave_to_the_separate_kernels():
     assert bool(ops.dwconv.fused_ok(torch.empty((1, 2, 256, 256), dtype=torch.bfloat16, device=DEV), 1))   # 129 KiB: one plane still fits
 
 
+@pytest.mark.parametrize("shape,dt", [((1, 6, 272, 272), torch.float16), ((1, 4, 512, 512), torch.float16), ((2, 6, 136, 144), torch.bfloat16),
+                                      ((1, 2, 300, 200), torch.float32), ((1, 4, 272, 136), torch.float16)],
+                         ids=["tile256-f16", "untiled512-f16", "bf16-136x144", "f32-300x200", "f16-272x136"])
+@pytest.mark.parametrize("has_bias", [False, True])
+def test_gate_streams_in_inference_on_planes_beyond_the_lds(shape, dt, has_bias):
+    """round 6: without a backward to prepare, ``dwconv3x3_gelu_gate`` takes the one-launch streaming forward (``oss_dwgate_fwd``) on every
+    plane ``oss_dwgate_fwd_ok`` accepts -- the RealSR tiles of 272 x 272 and the untiled 512 x 512 plane, whose two planes do not fit the
+    backward's LDS-resident form (they ran dwconv -> gelu_gate: 7 plane passes instead of 3).  Against plain PyTorch fp32 and against
+    the two separate kernels; with gradients enabled the same call still builds the two separate nodes"""
+    torch.manual_seed(17)
+    B, C2, H, W = shape
+    conv = torch.nn.Conv2d(C2, C2, 3, padding=1, groups=C2, bias=has_bias).to(DEV)
+    t = torch.randn(shape, device=DEV).to(dt)
+    assert ops.dwconv.gate_fwd_ok(t)
+    big = not ops.dwconv.fused_ok(t, 2)
+    with torch.no_grad():
+        out = ops.dwconv3x3_gelu_gate(t, conv)
+        sep = ops.gelu_gate(ops.dwconv3x3(t, conv))
+        one = ops.dwconv.dwgate_fwd(t, conv.weight, conv.bias)
+    assert torch.equal(out, one), "the inference call is the one-launch form (the separate kernels round the convolution in between)"
+    x1, x2 = F.conv2d(t.float(), conv.weight, conv.bias, padding=1, groups=C2).chunk(2, dim=1)
+    want = F.gelu(x1) * x2
+    rt = {torch.bfloat16: 1e-2, torch.float16: 2e-3, torch.float32: 1e-4}[dt]
+    assert_close(out, want, rt, 2 * rt, "out")
+    assert_close(out, sep.float(), rt, 2 * rt, "out vs separate")
+    if big:
+        tg = t.clone().requires_grad_()
+        assert ops.dwconv3x3_gelu_gate(tg, conv).grad_fn.__class__.__name__.startswith("GeluGateFn")
+    assert not ops.dwconv.gate_fwd_ok(torch.empty((1, 2, 16, 20), dtype=torch.float16, device=DEV))
+    assert not ops.dwconv.gate_fwd_ok(torch.empty((1, 2, 16, 520), dtype=torch.float16, device=DEV))
+
+
 # (round 4) SS2D_1's convolution together with cross_scan_2d's two forward flattenings (MambaSISR6_arch.py:399-404, 486)
 FLAT2_SHAPES = [(2, 96, 64, 64), (1, 192, 32, 32), (2, 384, 16, 16), (1, 768, 8, 8), (1, 48, 128, 128), (1, 6, 24, 64), (2, 5, 8, 256),
                 (1, 3, 40, 8)]

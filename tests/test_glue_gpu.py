@@ -451,6 +451,35 @@ def test_channel_branch_from_the_pooled_sums_matches_the_pooling_pass():
     assert_close(a[0], bb[0].float(), 1e-2, 1e-2, "out")
 
 
+@pytest.mark.parametrize("variant,d,H,W", [("realsr", 48, 256, 256), ("realsr", 96, 128, 192), ("srgan", 96, 272, 272), ("realsr", 384, 64, 64)],
+                         ids=["realsr-512tiles", "realsr-192tiles", "srgan-578tiles", "L768-more-channels-than-threads"])
+def test_channel_branch_pools_many_tiles(variant, d, H, W):
+    """round 6: the pooled descriptor from MANY per-workgroup sums (an untiled RealSR plane leaves 1024 per channel): up to 8 threads per
+    channel add contiguous runs of the tiles, then the runs in order -- against the pooling pass and a float64 sum of the tiles"""
+    from vmambair_amd import oss_block
+    torch.manual_seed(33)
+    m = oss_block.SS2D_1(d_model=d, ssm_ratio=2, variant=variant).to(DEV)
+    D = m.d_inner
+    y = torch.randn(1, D, H, W, device=DEV)
+    z = torch.randn(1, D, H, W, device=DEV).to(torch.float16)
+    y2, _, _, pool = torch.ops.vmambair.ln_nchw_fwd(y, m.out_norm.body.weight, m.out_norm.body.bias, z, 1, True)
+    if pool.numel() == 0:   # more channels than this LayerNorm form pools: the tile sums by hand (any split of the pixels is a valid input)
+        pool = y2.float().reshape(1, D, -1, 128).sum(-1).permute(0, 2, 1).contiguous()
+    assert pool.shape[1] >= 32 and (pool.shape[1] >= 128 or D > 512)
+    lift = m.dc_inner is not None
+    if True:
+        args = ((m.conv_cin.weight, m.conv_cin.bias) if lift else (None, None)) + (m.xc_proj_weight, m.dtc_projs_weight, m.dtc_projs_bias, m.Ac_logs, m.Dsc) + \
+            ((m.conv_cout.weight, m.conv_cout.bias) if lift else (None, None)) + (m.channel_norm.body.weight, m.channel_norm.body.bias, True)
+    args = tuple(a.detach() if isinstance(a, torch.Tensor) else a for a in args)
+    a = torch.ops.vmambair.chan_gate_fwd(y2, *args, pool)
+    bb = torch.ops.vmambair.chan_gate_fwd(y2, *args, None)
+    want = pool.double().sum(1) / (H * W)
+    assert_close(a[2], want.float(), 1e-5, 1e-6, "pooled vs float64 sum of the tiles")
+    assert_close(a[2], bb[2], 1e-4, 2e-6, "pooled")
+    assert_close(a[1], bb[1], 1e-3, 1e-4, "c")
+    assert_close(a[0], bb[0].float(), 1e-2, 1e-2, "out")
+
+
 # ---- round 4: fp32 I/O on v_mfma_f32_32x32x2_f32 (csrc/oss_conv1x1_f32.hip) -- the reference's own precision -------------------
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 96, 384, 64, 64), (1, 48, 96, 16, 24), (2, 127, 48, 8, 8), (1, 96, 254, 12, 10),
                                             (3, 5, 7, 2, 6), (1, 255, 96, 16, 16), (2, 384, 384, 8, 8), (1, 96, 510, 32, 32),

@@ -393,6 +393,8 @@ int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weigh
                                     dsc, reinterpret_cast<hipStream_t>(stream));
 }
 
+int oss_dwgate_fwd_ok(oss_dtype io, int height, int width) { return dwgate_fwd_ok(io, height, width); }
+
 int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
                    int height, int width, int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, oss_stream_t stream) {
     fam_count(FAM_DWCONV, (double)batch * hidden * height * width * esz(io) * 3.0 + 80.0 * hidden);

@@ -74,21 +74,40 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *ycs = ybuf + 2 * dc * L;  // [L]
     float *red = ycs + L;            // [kChRed]
     float *ypart = red + kChRed;     // [4][2 dc][L]: the state groups' partial sums of y
-    for (int l = tid; l < L; l += NT) {
-        float pl;
-        if (p.pool_part) {   // (uniform) the pooled descriptor from the LayerNorm forward's per-workgroup output sums, in order
+    if (p.pool_part) {   // (uniform) the pooled descriptor from the LayerNorm forward's per-workgroup output sums
+        // NS threads per channel, each adding a contiguous run of the tiles in order, then the NS runs in order (a fixed order: reruns are
+        // bit-identical).  One thread per channel walking all tiles -- 96 of the 512 threads busy, 8 loads in flight each -- was 128
+        // dependent rounds at the 1024 tiles of an untiled 512 x 512 RealSR plane: most of that launch's 61 us (round 6)
+        const int ns = max(1, min(8, NT / L)), per = (p.n_part + ns - 1) / ns;
+        float *run = ypart;   // [ns][L] of its [4][2 dc][L]: free until the scans
+        for (int idx = tid; idx < ns * L; idx += NT) {
+            const int sub = idx / L, l = idx - sub * L;
+            const int k0 = sub * per, k1 = min(p.n_part, k0 + per);
             const float *pp = p.pool_part + (size_t)b * p.n_part * L + l;
             float sum = 0.f;
-            int k = 0;
-            for (; k + 8 <= p.n_part; k += 8) {
-                float v[8];
+            int k = k0;
+            for (; k + 16 <= k1; k += 16) {
+                float v[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)(k + q) * L];
+                for (int q = 0; q < 16; ++q) v[q] = pp[(size_t)(k + q) * L];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) sum += v[q];
+                for (int q = 0; q < 16; ++q) sum += v[q];
             }
-            for (; k < p.n_part; ++k) sum += pp[(size_t)k * L];
-            pl = sum * p.pool_scale;
+            for (; k < k1; ++k) sum += pp[(size_t)k * L];
+            run[idx] = sum;
+        }
+        __syncthreads();
+        for (int l = tid; l < L; l += NT) {
+            float sum = run[l];
+            for (int sub = 1; sub < ns; ++sub) sum += run[sub * L + l];
+            ycs[l] = sum * p.pool_scale;
+        }
+        __syncthreads();   // ycs holds the pooled values
+    }
+    for (int l = tid; l < L; l += NT) {
+        float pl;
+        if (p.pool_part) {
+            pl = ycs[l];
             const_cast<float *>(p.pooled)[(size_t)b * L + l] = pl;   // kept for the backward
         } else {
             pl = p.pooled[(size_t)b * L + l];

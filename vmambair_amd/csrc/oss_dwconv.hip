@@ -732,9 +732,16 @@ static int dwgate_fwd_launch(const void *t, const float *w, const float *bias, v
     return (int)hipGetLastError();
 }
 
+// the forward alone streams (three rows per lane group, nothing in LDS): any plane of rows of W / 8 <= 64 lane groups -- the inference
+// path of planes too large for the backward's LDS-resident form (RealSR at 272 x 272 tiles and untiled 512 x 512)
+int dwgate_fwd_ok(oss_dtype io, int H, int W) {
+    if (io != OSS_F16 && io != OSS_BF16 && io != OSS_F32) return 0;
+    return (H > 0 && W > 0 && W % 8 == 0 && W <= 512) ? 1 : 0;
+}
+
 int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
                int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s) {
-    if (!dwconv3x3_fused_ok(io, H, W, 2)) return OSS_ERR_SHAPE;
+    if (!dwgate_fwd_ok(io, H, W)) return OSS_ERR_SHAPE;
     if (io == OSS_F32) return dwgate_fwd_launch<float>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s);
     return io == OSS_F16 ? dwgate_fwd_launch<f16_t>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s)
                          : dwgate_fwd_launch<bf16_t>(t, w, bias, out, B, Hd, H, W, tsb, tsc, osb, osc, s);

@@ -80,6 +80,7 @@ int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, vo
               int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre = nullptr, int act = 0);
 // the convolution fused with what follows it (oss_dwconv.hip): mode 0 = silu (SS2D_1), 1 = gelu gate of the EFFN
 int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch);
+int dwgate_fwd_ok(oss_dtype io, int H, int W);
 int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
                int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s);
 int dwconv3x3_bwd_fused(oss_dtype io, int mode, const void *x, const float *w, const float *bias, const void *dy, void *dx,

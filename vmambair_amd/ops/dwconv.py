@@ -29,6 +29,13 @@ def fused_ok(x: torch.Tensor, planes: int) -> bool:
     return bool(_capi.load().oss_dwconv3x3_fused_ok(_DT[x.dtype], x.shape[2], x.shape[3], planes))
 
 
+def gate_fwd_ok(t: torch.Tensor) -> bool:
+    """does the streaming forward of the gate (``dwgate_fwd``) take this tensor?  No LDS bound: forward-only uses"""
+    if not (DW_FUSED and t.is_cuda and t.dim() == 4 and t.dtype in _DT and t.numel()):
+        return False
+    return bool(_capi.load().oss_dwgate_fwd_ok(_DT[t.dtype], t.shape[2], t.shape[3]))
+
+
 def _aligned(*ts: torch.Tensor) -> bool:
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 for t in ts)
 
@@ -310,5 +317,9 @@ def dwconv3x3_gelu_gate(t: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
     """the EFFN between its two 1x1 convolutions: fused when the shape allows, else the two separate nodes"""
     if fused_ok(t, 2):
         return DWGateFn.apply(t, conv.weight, conv.bias)
+    if not (torch.is_grad_enabled() and (t.requires_grad or conv.weight.requires_grad)) and gate_fwd_ok(t):
+        # inference on planes the backward's LDS-resident form cannot hold (RealSR tiles of 272 x 272, the untiled 512 x 512):
+        # the forward streams, so the convolution still is never stored
+        return torch.ops.vmambair.dwgate_fwd(t, conv.weight, conv.bias)
     from .ffn import gelu_gate
     return gelu_gate(dwconv3x3(t, conv))
