@@ -268,6 +268,23 @@ int oss_dwconv3x3_silu_bwd(oss_dtype io, const void *x, const float *weight, con
                            int64_t x_batch_stride, int64_t x_channel_stride, int64_t dy_batch_stride, int64_t dy_channel_stride,
                            int64_t dx_batch_stride, int64_t dx_channel_stride, oss_stream_t stream);
 int oss_dwgate_fwd_ok(oss_dtype io, int height, int width);
+
+/* The whole second half of an OSS block, forward only (inference), as ONE launch:
+ *   out = x + project_out( gelu(x1) * x2 ),  x1, x2 = dwconv3x3( project_in( norm2(x) ) ).chunk(2)
+ * (FeedForward.forward, SRGAN/VmambaIR/archs/MambaSISR6_arch.py:201-218; the block's `x = x + self.ffn(self.norm2(x))`, :513-516;
+ * LayerNorm :144-195 -- norm_bias NULL = the BiasFree form.)  The 2 hidden-channel and hidden-channel intermediates never reach memory;
+ * they are rounded to the io type where the launch-per-layer chain (oss_conv1x1_fwd with norm, oss_dwgate_fwd, oss_conv1x1_fwd with
+ * residual) stores them, so the two forms agree to the rounding of the last accumulation.  No biases on the three convolutions (no
+ * reference config has them: `bias: False` in every options file).
+ *   x, out: (batch, channels, H, W) of the io type (OSS_F16 / OSS_BF16), rows contiguous, 16-byte aligned, strides multiples of 8
+ *   w_in:   (2 hidden, channels) of the io type -- project_in.weight rounded once by the caller (in inference a constant)
+ *   w_dw:   (2 hidden, 9) float -- dwconv.weight
+ *   w_out:  (channels, hidden rounded up to a multiple of 16) of the io type, the padding columns zero -- project_out.weight
+ * oss_effn_fwd_ok: channels in {32, 48, 64, 96}, width a multiple of 8; anything else (and every training call) stays on the chain. */
+int oss_effn_fwd_ok(oss_dtype io, int channels, int hidden, int height, int width);
+int oss_effn_fwd(oss_dtype io, const void *x, const float *norm_weight, const float *norm_bias, const void *w_in, const float *w_dw,
+                 const void *w_out, void *out, int batch, int channels, int hidden, int height, int width, int64_t x_batch_stride,
+                 int64_t x_channel_stride, int64_t out_batch_stride, int64_t out_channel_stride, float eps, oss_stream_t stream);
 int oss_dwgate_fwd(oss_dtype io, const void *t, const float *weight, const float *bias, void *out, int batch, int hidden,
                    int height, int width, int64_t t_batch_stride, int64_t t_channel_stride, int64_t out_batch_stride,
                    int64_t out_channel_stride, oss_stream_t stream);

@@ -1,0 +1,116 @@
+"""The second half of an OSS block as ONE forward launch (csrc/oss_effn.hip, inference only):
+``x + project_out(gelu(x1) * x2)``, ``x1, x2 = dwconv(project_in(norm2(x))).chunk(2, 1)``
+(SRGAN/VmambaIR/archs/MambaSISR6_arch.py:201-218 FeedForward, :513-516 the block, :144-195 LayerNorm) against plain PyTorch fp32 of
+the same ops and against the launch-per-layer chain of this repo (LayerNorm inside project_in, dwconv + gate, project_out + skip)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+from vmambair_amd import ops, oss_block
+from vmambair_amd.ops import ffn as ffn_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def reference(x, norm, ff):
+    """fp32 PyTorch on the values the kernel reads (x and the two 1x1 weights as rounded to the I/O type)"""
+    dt = x.dtype
+    xf = x.float()
+    mu = xf.mean(1, keepdim=True)
+    var = xf.var(1, keepdim=True, unbiased=False)
+    w = norm.body.weight.float().view(1, -1, 1, 1)
+    if norm.with_bias:
+        n = (xf - mu) / torch.sqrt(var + 1e-5) * w + norm.body.bias.float().view(1, -1, 1, 1)
+    else:
+        n = xf / torch.sqrt(var + 1e-5) * w
+    n = n.to(dt).float()                                              # the chain stores norm2(x) in the I/O type
+    t = F.conv2d(n, ff.project_in.weight.to(dt).float()).to(dt).float()
+    t = F.conv2d(t, ff.dwconv.weight.float(), None, padding=1, groups=t.shape[1])
+    x1, x2 = t.chunk(2, dim=1)
+    g = (F.gelu(x1) * x2).to(dt).float()
+    return xf + F.conv2d(g, ff.project_out.weight.to(dt).float())
+
+
+_CASES = [  # (B, D, H, W, LayerNorm type)
+    (1, 48, 64, 64, "WithBias"),      # RealSR level 1 (encoder), hidden 127
+    (2, 96, 40, 48, "WithBias"),      # dim 96, hidden 255: 16 chunks, the last one ragged
+    (1, 96, 20, 24, "WithBias"),      # H not a multiple of the 8-row tile, W a multiple of 8 only
+    (1, 32, 8, 8, "BiasFree"),        # one tile, half of it outside the image; the un-centred LayerNorm form
+    (1, 64, 17, 40, "WithBias"),
+    (3, 48, 9, 16, "BiasFree"),
+    (1, 96, 136, 144, "WithBias"),    # a RealSR corner tile (tile 128 + halo 16: 144 wide) at level 1
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("B,D,H,W,ln", _CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}x{c[3]}-{c[4]}" for c in _CASES])
+def test_fused_effn_forward_against_pytorch_fp32_and_the_chain(B, D, H, W, ln, dt):
+    torch.manual_seed(5)
+    norm = oss_block.LayerNorm(D, ln).to(DEV)
+    ff = oss_block.FeedForward(D, 2.66, False).to(DEV)
+    with torch.no_grad():
+        norm.body.weight.uniform_(0.5, 1.5)
+        if norm.with_bias:
+            norm.body.bias.normal_(0, 0.3)
+        ff.dwconv.weight.mul_(2.0)
+    x = (torch.randn(B, D, H, W, device=DEV) * 1.5 + 0.2).to(dt)
+    hidden = ff.project_out.in_channels
+    assert ffn_ops.effn_fwd_ok(x, hidden)
+    with torch.no_grad():
+        want = reference(x, norm, ff)
+        got = ff(x, pre_norm=norm)
+        w_in, w_out = ops.effn_round_weights(ff.project_in.weight, ff.project_out.weight, dt)
+        direct = torch.ops.vmambair.effn_fwd(x, norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight, w_out, hidden)
+        ffn_ops.EFFN_FUSED = False
+        try:
+            chain = ff(x, pre_norm=norm)
+        finally:
+            ffn_ops.EFFN_FUSED = True
+    assert torch.equal(got, direct), "FeedForward.forward without a backward to prepare IS the one-launch form"
+    assert got.dtype == dt and got.shape == x.shape
+    # one rounding of the result to the I/O type (+ the differences of two roundings of intermediates that fall on the other side)
+    rt = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
+    scale = float(want.abs().max())
+    assert_close(got, want, rt, rt * scale * 0.5, "fused vs PyTorch fp32")
+    assert_close(got, chain.float(), rt, rt * scale * 0.5, "fused vs the launch-per-layer chain")
+    # and the chain is as close to the reference as the fused form is (the tolerance is not hiding a bias of the new kernel)
+    e_f = float((got.float() - want).abs().mean()), float((chain.float() - want).abs().mean())
+    assert e_f[0] <= 1.5 * e_f[1] + 1e-6, f"mean |error| fused {e_f[0]:.3e} vs chain {e_f[1]:.3e}"
+
+
+def test_fused_effn_leaves_training_and_unsupported_streams_to_the_chain():
+    """with gradients enabled the module builds the autograd chain; fp32 streams, widths that are not a multiple of 8 and channel counts
+    without an instantiation are not taken (effn_fwd_ok) and the raw op refuses them loudly"""
+    torch.manual_seed(6)
+    norm = oss_block.LayerNorm(48, "WithBias").to(DEV)
+    ff = oss_block.FeedForward(48, 2.66, False).to(DEV)
+    x = torch.randn(1, 48, 16, 16, device=DEV).to(torch.bfloat16)
+    out = ff(x.clone().requires_grad_(), pre_norm=norm)
+    assert out.grad_fn is not None
+    assert not ffn_ops.effn_fwd_ok(x.float(), 127)
+    assert not ffn_ops.effn_fwd_ok(torch.empty(1, 48, 16, 20, device=DEV, dtype=torch.float16), 127)
+    assert not ffn_ops.effn_fwd_ok(torch.empty(1, 192, 16, 16, device=DEV, dtype=torch.float16), 510)
+    assert not ffn_ops.effn_fwd_ok(torch.empty(1, 48, 16, 16, device=DEV, dtype=torch.float16)[:, :, :, ::2], 127)
+    w_in, w_out = ops.effn_round_weights(ff.project_in.weight, ff.project_out.weight, torch.float16)
+    with pytest.raises(RuntimeError):
+        torch.ops.vmambair.effn_fwd(x.float(), norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight, w_out, 127)
+    with pytest.raises(RuntimeError):   # weights of the wrong type
+        torch.ops.vmambair.effn_fwd(x, norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight, w_out, 127)
+
+
+def test_rounded_weights_follow_the_parameters():
+    """the module keeps the rounded copies per weight version: an in-place update (an optimizer step, load_state_dict) refreshes them"""
+    torch.manual_seed(7)
+    norm = oss_block.LayerNorm(48, "WithBias").to(DEV)
+    ff = oss_block.FeedForward(48, 2.66, False).to(DEV)
+    x = torch.randn(1, 48, 16, 16, device=DEV).to(torch.float16)
+    with torch.no_grad():
+        a = ff(x, pre_norm=norm)
+        first = ff._rounded(torch.float16)
+        assert ff._rounded(torch.float16)[0] is first[0]
+        ff.project_out.weight.mul_(2.0)
+        b = ff(x, pre_norm=norm)
+    assert ff._rounded(torch.float16)[0] is not first[0]
+    assert_close((b.float() - x.float()), 2.0 * (a.float() - x.float()), 5e-3, 5e-3 * float(a.abs().max()), "doubled project_out")

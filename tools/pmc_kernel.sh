@@ -1,22 +1,19 @@
 #!/bin/bash
-# SQ / TCP / TCC counters of one script's kernels (default tools/wgrad_one.py), 8 SQ counters per pass; --pmc only ever with
-# --kernel-trace.  KERNELS = grep pattern for the summary.  Output: gpurun_out/pmc_kernel.txt
-# SCRIPT / ARGS: the python command; SETS: "a b;c d" overrides the counter sets (one pass each); OUT: output file name
+# SQ counters of ONE kernel family of any python command: CMD="python tools/effn_one.py" KERNEL=oss_effn bash tools/pmc_kernel.sh
+# (8 counters per pass: the SQ block has 8 slots on gfx950; --pmc only ever next to --kernel-trace).  Output: gpurun_out/pmc_kernel.txt
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-SCRIPT=${SCRIPT:-tools/wgrad_one.py}
-KERNELS=${KERNELS:-oss_conv1x1}
-OUT=${OUT:-gpurun_out/pmc_kernel.txt}
-SETS=${SETS:-"SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAVES;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_MISC;TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum;TA_TA_BUSY_sum TA_BUSY_avr TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"}
+OUT=gpurun_out/${OUT:-pmc_kernel.txt}
 : > $OUT
 pass=0
-IFS=';' read -ra SETLIST <<< "$SETS"
-for set in "${SETLIST[@]}"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT"; do
   pass=$((pass + 1))
   rm -rf /tmp/pmc_k$pass
-  ( cd /tmp && timeout ${PASS_TIMEOUT:-300} rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_k$pass -- python "$GRAFT_REPO_ROOT/$SCRIPT" $ARGS > "$GRAFT_REPO_ROOT/gpurun_out/pmc_k$pass.log" 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_k$pass -- ${CMD:-python $GRAFT_REPO_ROOT/tools/effn_one.py} > "$GRAFT_REPO_ROOT/gpurun_out/pmc_k$pass.log" 2>&1 )
   echo "pass $pass rc=$?"
-  for c in $set; do python tools/pmc_summary.py /tmp/pmc_k$pass $c /tmp/pmc_k_one.txt > /dev/null; grep -E "^#|$KERNELS" /tmp/pmc_k_one.txt | cut -c1-150 >> $OUT; done
+  for c in $set; do python tools/pmc_summary.py /tmp/pmc_k$pass $c /tmp/pmc_k_one.txt > /dev/null 2>&1; grep -E "${KERNEL:-oss_effn}" /tmp/pmc_k_one.txt | cut -c1-120 | sed "s/^/$c /" >> $OUT; done
 done
-cat $OUT | head -120
+cat $OUT | cut -c1-150

@@ -187,7 +187,7 @@ static const char *const kFamName[FAM_N] = {"conv1x1 forward / input gradient (+
 static const char *const kFamKernels[FAM_N] = {"oss_conv1x1_pair_kernel|oss_conv1x1_pairk_kernel|oss_conv1x1_pairw_kernel|oss_conv1x1_wg_kernel|"
                                                "oss_conv1x1_dgrad_lnbwd_kernel|oss_conv1x1_f32_kernel",
                                                "oss_conv1x1_wgrad|oss_rows_f32_wgrad|oss_proj_wgrad",
-                                               "oss_dwconv3x3|oss_dwgate",
+                                               "oss_dwconv3x3|oss_dwgate|oss_effn",
                                                "oss_proj_fwd|oss_proj_dgrad|oss_dt_fwd|oss_dt_dgrad|oss_proj_valu",
                                                "oss_ln_nchw",
                                                "oss_chan_|oss_rowsum|oss_row_affine",
@@ -391,6 +391,18 @@ int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weigh
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || channels > 65535 || batch > 65535) return OSS_ERR_SHAPE;
     return dwconv3x3_silu_flat2_bwd(io, x, weight, bias, g2, dx, dweight, dbias, partials, batch, channels, height, width, xsb, xsc, dsb,
                                     dsc, reinterpret_cast<hipStream_t>(stream));
+}
+
+int oss_effn_fwd_ok(oss_dtype io, int channels, int hidden, int height, int width) { return effn_fwd_ok(io, channels, hidden, height, width); }
+
+int oss_effn_fwd(oss_dtype io, const void *x, const float *norm_weight, const float *norm_bias, const void *w_in, const float *w_dw,
+                 const void *w_out, void *out, int batch, int channels, int hidden, int height, int width, int64_t xsb, int64_t xsc,
+                 int64_t osb, int64_t osc, float eps, oss_stream_t stream) {
+    fam_count(FAM_DWCONV, (double)batch * channels * height * width * esz(io) * 3.0 + (double)hidden * (3.0 * channels * esz(io) + 72.0));
+    if (!x || !norm_weight || !w_in || !w_dw || !w_out || !out) return OSS_ERR_NULL;
+    if (batch <= 0 || channels <= 0 || hidden <= 0 || height <= 0 || width <= 0) return OSS_ERR_SHAPE;
+    return effn_fwd(io, x, norm_weight, norm_bias, w_in, w_dw, w_out, out, batch, channels, hidden, height, width, xsb, xsc, osb, osc, eps,
+                    reinterpret_cast<hipStream_t>(stream));
 }
 
 int oss_dwgate_fwd_ok(oss_dtype io, int height, int width) { return dwgate_fwd_ok(io, height, width); }

@@ -243,23 +243,7 @@ template <typename T> __device__ __forceinline__ float raw_item_f32(uint32_t r) 
     else return to_f32(T{(uint16_t)r});
 }
 
-// Phi(a) and phi(a) of the exact (erf) gelu from ONE exponential: erf(|z|) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),
-// t = 1 / (1 + p |z|)  (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- fp32 round-off level, four orders of magnitude under the
-// rounding of the 16-bit tensors these kernels read and write), and with z = a / sqrt(2) the exponential is the one of
-// phi(a) = exp(-a^2 / 2) / sqrt(2 pi).  The library erff costs ~35 instructions behind a divergent branch; this is 12.
-__device__ __forceinline__ void gelu_parts(float a, float &cdf, float &pdf) {
-    const float e = exp2_hw(-0.5f * a * a * kLog2e);
-    const float z = fabsf(a) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
-    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    poly = __builtin_fmaf(poly, t, 1.421413741f);
-    poly = __builtin_fmaf(poly, t, -0.284496736f);
-    poly = __builtin_fmaf(poly, t, 0.254829592f);
-    const float half_tail = 0.5f * poly * t * e;          // (1 - erf|z|) / 2
-    cdf = a >= 0.f ? 1.f - half_tail : half_tail;
-    pdf = 0.3989422804014327f * e;
-}
-
+// (gelu_parts: oss_stencil.h -- shared with the fused EFFN forward, oss_effn.hip)
 template <typename T>
 __device__ __forceinline__ void conv_rows(const float (&v)[3][10], const float *__restrict__ k, float bv, float (&acc)[8]) {
 #pragma unroll

@@ -80,6 +80,10 @@ int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, vo
               int64_t xsb, int64_t xsc, int64_t ysb, int64_t ysc, int flip, hipStream_t s, void *pre = nullptr, int act = 0);
 // the convolution fused with what follows it (oss_dwconv.hip): mode 0 = silu (SS2D_1), 1 = gelu gate of the EFFN
 int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch);
+int effn_fwd_ok(oss_dtype io, int D, int hidden, int H, int W);
+int effn_fwd(oss_dtype io, const void *x, const float *ln_w, const float *ln_b, const void *w_in, const float *w_dw, const void *w_out,
+             void *out, int B, int D, int hidden, int H, int W, int64_t xsb, int64_t xsc, int64_t osb, int64_t osc, float eps,
+             hipStream_t s);
 int dwgate_fwd_ok(oss_dtype io, int H, int W);
 int dwgate_fwd(oss_dtype io, const void *t, const float *w, const float *bias, void *out, int B, int Hd, int H, int W,
                int64_t tsb, int64_t tsc, int64_t osb, int64_t osc, hipStream_t s);

@@ -30,6 +30,6 @@ from .dwconv import (DWConv3x3Fn, DWGateFn, dwconv3x3, dwconv3x3_bwd, dwconv3x3_
                      dwconv3x3_silu_bwd, dwconv3x3_silu_flat2_bwd, dwconv3x3_silu_flat2_fwd, dwconv3x3_silu_fwd, dwgate_bwd, dwgate_fwd, flat2_ok)
 from .conv3x3 import ThinConv3x3Fn, conv3x3_thin_bwd, conv3x3_thin_fwd  # noqa: F401
 from .conv3x3 import conv3x3 as conv3x3_layer  # noqa: F401
-from .ffn import GeluGateFn, gelu_gate, gelu_gate_bwd, gelu_gate_fwd  # noqa: F401
+from .ffn import GeluGateFn, effn_fwd, effn_fwd_ok, effn_round_weights, gelu_gate, gelu_gate_bwd, gelu_gate_fwd  # noqa: F401
 from .layernorm import _CODE_DT, _DT_CODE, LayerNormNCHWFn, layer_norm_nchw, ln_nchw_bwd, ln_nchw_fwd  # noqa: F401
 from .scan import merge4, selective_scan_bwd, selective_scan_fwd  # noqa: F401

@@ -1,4 +1,5 @@
-"""Gate of the EFFN: gelu(x1) * x2 on the two channel halves of one tensor (MambaSISR6_arch.py:213-217).
+"""Gate of the EFFN: gelu(x1) * x2 on the two channel halves of one tensor (MambaSISR6_arch.py:213-217); and (round 6) the whole
+second half of an OSS block as one forward launch for inference (``effn_fwd``, csrc/oss_effn.hip).
 """
 from __future__ import annotations
 
@@ -67,3 +68,51 @@ class GeluGateFn(torch.autograd.Function):
 
 def gelu_gate(h: torch.Tensor) -> torch.Tensor:
     return GeluGateFn.apply(h)
+
+
+#: ``VMAMBAIR_EFFN_FUSED=0``: inference keeps the launch-per-layer chain (A-B timing)
+EFFN_FUSED = os.environ.get("VMAMBAIR_EFFN_FUSED", "1") == "1"
+
+
+def effn_fwd_ok(x: torch.Tensor, hidden: int) -> bool:
+    """does the one-launch forward of ``x + project_out(gate(dwconv(project_in(norm2(x)))))`` take this stream?"""
+    if not (EFFN_FUSED and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and x.numel()):
+        return False
+    if not (x.stride(3) == 1 and x.stride(2) == x.size(3) and x.stride(0) % 8 == 0 and x.stride(1) % 8 == 0 and x.data_ptr() % 16 == 0):
+        return False
+    return bool(_capi.load().oss_effn_fwd_ok(_DT[x.dtype], x.shape[1], hidden, x.shape[2], x.shape[3]))
+
+
+def effn_round_weights(project_in: torch.Tensor, project_out: torch.Tensor, dtype: torch.dtype):
+    """the two 1x1 weights as the kernel reads them: rounded to the I/O type (what the chain's kernels do at every use), project_out's
+    rows padded with zeros to a multiple of 16 columns -> (w_in (2 h, D), w_out (D, HP))"""
+    h2, D = project_in.shape[0], project_in.shape[1]
+    h = h2 // 2
+    hp = (h + 15) // 16 * 16
+    w_in = project_in.detach().reshape(h2, D).to(dtype).contiguous()
+    w_out = torch.zeros((D, hp), dtype=dtype, device=project_out.device)
+    w_out[:, :h] = project_out.detach().reshape(D, h).to(dtype)
+    return w_in, w_out
+
+
+def effn_fwd(x: torch.Tensor, ln_w: torch.Tensor, ln_b: Optional[torch.Tensor], w_in: torch.Tensor, w_dw: torch.Tensor,
+             w_out: torch.Tensor, hidden: int) -> torch.Tensor:
+    """``x + project_out(gelu(x1) * x2)`` with ``x1, x2 = dwconv(project_in(LayerNorm(x))).chunk(2, 1)`` (MambaSISR6_arch.py:201-218,
+    513-516) in ONE launch, forward only.  ``w_in`` / ``w_out``: ``effn_round_weights``; ``w_dw``: dwconv.weight (2 h, 1, 3, 3)"""
+    B, D, H, W = x.shape
+    _check(effn_fwd_ok(x, hidden), "effn_fwd: the fused forward does not take this tensor (effn_fwd_ok)")
+    hp = (hidden + 15) // 16 * 16
+    _check(tuple(w_in.shape) == (2 * hidden, D) and tuple(w_out.shape) == (D, hp) and w_in.dtype == x.dtype and w_out.dtype == x.dtype
+           and w_in.is_contiguous() and w_out.is_contiguous() and w_dw.numel() == 2 * hidden * 9,
+           "effn_fwd: weights must come from effn_round_weights (w_in (2 h, D), w_out (D, h padded to 16) of x's dtype)")
+    lw, lb, dw = _f32c(ln_w), (None if ln_b is None else _f32c(ln_b)), _f32c(w_dw.detach().reshape(2 * hidden, 9))
+    out = torch.empty((B, D, H, W), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.load().oss_effn_fwd(_DT[x.dtype], x.data_ptr(), lw.data_ptr(), _ptr(lb), w_in.data_ptr(), dw.data_ptr(),
+                                              w_out.data_ptr(), out.data_ptr(), B, D, hidden, H, W, x.stride(0), x.stride(1),
+                                              out.stride(0), out.stride(1), 1e-5, torch.cuda.current_stream().cuda_stream), "oss_effn_fwd")
+    return out
+
+
+_LIB.define("effn_fwd(Tensor x, Tensor ln_w, Tensor? ln_b, Tensor w_in, Tensor w_dw, Tensor w_out, int hidden) -> Tensor")
+_LIB.impl("effn_fwd", effn_fwd, "CUDA")
