@@ -277,9 +277,11 @@ int oss_dwgate_fwd_ok(oss_dtype io, int height, int width);
  * residual) stores them, so the two forms agree to the rounding of the last accumulation.  No biases on the three convolutions (no
  * reference config has them: `bias: False` in every options file).
  *   x, out: (batch, channels, H, W) of the io type (OSS_F16 / OSS_BF16), rows contiguous, 16-byte aligned, strides multiples of 8
- *   w_in:   (2 hidden, channels) of the io type -- project_in.weight rounded once by the caller (in inference a constant)
- *   w_dw:   (2 hidden, 9) float -- dwconv.weight
- *   w_out:  (channels, hidden rounded up to a multiple of 16) of the io type, the padding columns zero -- project_out.weight
+ * With HP = hidden rounded up to a multiple of 16 and every padding row / column ZERO (the kernel's loop has no masks):
+ *   w_in:   (2 HP, channels) of the io type -- project_in.weight rounded once by the caller (in inference a constant): rows
+ *           0 .. hidden - 1 = its first half (x1), rows HP .. HP + hidden - 1 = its second half (x2)
+ *   w_dw:   (2 HP, 9) float -- dwconv.weight in the same row order
+ *   w_out:  (channels, HP) of the io type -- project_out.weight
  * oss_effn_fwd_ok: channels in {32, 48, 64, 96}, width a multiple of 8; anything else (and every training call) stays on the chain. */
 int oss_effn_fwd_ok(oss_dtype io, int channels, int hidden, int height, int width);
 int oss_effn_fwd(oss_dtype io, const void *x, const float *norm_weight, const float *norm_bias, const void *w_in, const float *w_dw,

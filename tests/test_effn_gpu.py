@@ -61,8 +61,8 @@ def test_fused_effn_forward_against_pytorch_fp32_and_the_chain(B, D, H, W, ln, d
     with torch.no_grad():
         want = reference(x, norm, ff)
         got = ff(x, pre_norm=norm)
-        w_in, w_out = ops.effn_round_weights(ff.project_in.weight, ff.project_out.weight, dt)
-        direct = torch.ops.vmambair.effn_fwd(x, norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight, w_out, hidden)
+        w_in, w_dw, w_out = ops.effn_round_weights(ff.project_in.weight, ff.dwconv.weight, ff.project_out.weight, dt)
+        direct = torch.ops.vmambair.effn_fwd(x, norm.body.weight, norm.body.bias, w_in, w_dw, w_out, hidden)
         ffn_ops.EFFN_FUSED = False
         try:
             chain = ff(x, pre_norm=norm)
@@ -93,11 +93,15 @@ def test_fused_effn_leaves_training_and_unsupported_streams_to_the_chain():
     assert not ffn_ops.effn_fwd_ok(torch.empty(1, 48, 16, 20, device=DEV, dtype=torch.float16), 127)
     assert not ffn_ops.effn_fwd_ok(torch.empty(1, 192, 16, 16, device=DEV, dtype=torch.float16), 510)
     assert not ffn_ops.effn_fwd_ok(torch.empty(1, 48, 16, 16, device=DEV, dtype=torch.float16)[:, :, :, ::2], 127)
-    w_in, w_out = ops.effn_round_weights(ff.project_in.weight, ff.project_out.weight, torch.float16)
+    w_in, w_dw, w_out = ops.effn_round_weights(ff.project_in.weight, ff.dwconv.weight, ff.project_out.weight, torch.float16)
+    assert w_in.shape == (256, 48) and w_dw.shape == (256, 9) and w_out.shape == (48, 128)
+    assert float(w_in[127:128].abs().sum()) == 0 and float(w_in[255:].abs().sum()) == 0 and float(w_out[:, 127:].abs().sum()) == 0
     with pytest.raises(RuntimeError):
-        torch.ops.vmambair.effn_fwd(x.float(), norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight, w_out, 127)
+        torch.ops.vmambair.effn_fwd(x.float(), norm.body.weight, norm.body.bias, w_in, w_dw, w_out, 127)
     with pytest.raises(RuntimeError):   # weights of the wrong type
-        torch.ops.vmambair.effn_fwd(x, norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight, w_out, 127)
+        torch.ops.vmambair.effn_fwd(x, norm.body.weight, norm.body.bias, w_in, w_dw, w_out, 127)
+    with pytest.raises(RuntimeError):   # the unpadded depth-wise weight
+        torch.ops.vmambair.effn_fwd(x.half(), norm.body.weight, norm.body.bias, w_in, ff.dwconv.weight.reshape(254, 9), w_out, 127)
 
 
 def test_rounded_weights_follow_the_parameters():

@@ -20,9 +20,11 @@
 // The halo costs GEMM 1 (TH + 2)(TW + 8) / (TH TW) = 1.9 x the MFMAs of the plain product -- on a pipe that is a quarter busy; the
 // depth-wise taps and the gate (the VALU work that bounds the kernel) are computed for output pixels only.
 // 16-bit weights: the caller hands W_in and W_out already rounded to the I/O type (what the chain's kernels do per fragment with
-// v_cvt_pk at every use; in inference the weights are constants and the rounding is done once), W_out rows padded with zeros to a
-// multiple of 16 columns.
+// v_cvt_pk at every use; in inference the weights are constants and the rounding is done once) and padded with zeros to HP = h rounded
+// up to 16: W_in and the depth-wise taps as [x1 half: HP rows | x2 half: HP rows], W_out rows as HP columns -- the loop has no masks.
+#include <cstdlib>
 #include <initializer_list>
+#include <type_traits>
 #include "oss_device.h"
 #include "oss_host.h"
 #include "oss_mfma.h"
@@ -36,8 +38,8 @@ struct EffnArgs {
     const void *x;           // (B, D, H, W), strides xsb / xsc, rows contiguous
     void *out;               // same layout, strides osb / osc
     const float *ln_w, *ln_b;   // norm2 (ln_b NULL: BiasFree)
-    const void *w_in;        // (2 h, D) I/O type
-    const float *w_dw;       // (2 h, 9)
+    const void *w_in;        // (2 HP, D) I/O type: rows 0 .. h - 1 = the x1 half, HP .. HP + h - 1 = the x2 half, the rest zero
+    const float *w_dw;       // (2 HP, 9), same row order
     const void *w_out;       // (D, HP) I/O type, HP = h rounded up to 16, zero padded
     int h, HP, H, W;
     int64_t xsb, xsc, osb, osc;
@@ -51,36 +53,48 @@ struct EffnGeo {
     static constexpr int SP = TW + 8;              // stored columns of a halo row: image columns w0 - 4 .. w0 + TW + 3
     static constexpr int HR = TH + 2;
     static constexpr int NQ = HR * SP;             // stored halo pixels (flat index q = hr * SP + sc)
-    static constexpr int N1T = (NQ + 31) / 32;     // GEMM 1 column tiles
-    static constexpr int XP = ((N1T * 32 + 127) / 128) * 128 + 32;   // xs row pitch: 64 bytes past a 256-byte bank sweep (oss_conv1x1_wg.hip)
-    static constexpr int TP = N1T * 32 + 8;        // ts row pitch
+    // a WAVE owns RW = TH / 4 output rows end to end: its halo is RW + 2 stored rows = WQ stored pixels starting at q = wave * RW * SP
+    static constexpr int RW = TH / 4;
+    static constexpr int WQ = (RW + 2) * SP;
+    static constexpr int N1W = WQ / 32;            // GEMM 1 column tiles of a wave (the waves' halos overlap: 4 N1W tiles against NQ / 32)
+    // xs: rows of XP = 256 pixel slots, row c rotated by 32 (c & 3) slots: ds_read_b64_tr_b16 is serviced in 32-lane halves over 64
+    // banks, a half = two 16-lane groups x four channel rows x 32 bytes -- with the rotation the eight pieces lie at bank bytes
+    // 0,64,128,192 | 32,96,160,224 (the rule of oss_conv1x1_wg.hip, whose pitch of 32 slots past a bank sweep does not fit here)
+    static constexpr int XP = 256;
+    static_assert(NQ <= XP, "a row's stored pixels fit its slots");
+    // ts: wave-private [32 channels][TP]; 8-byte writes (16-lane groups = 16 channels, banks (a / 4) mod 32): rows 50 words apart put
+    // the 16 pieces on 32 different banks; the 8-byte reads of step 2 are two deep at every pitch (tools: brute force in DESIGN.md)
+    static constexpr int TP = WQ + 4;
     static constexpr int N2 = TH * TW;             // output pixels
     static constexpr int N2T = N2 / 32;
-    static constexpr int GP = ((N2 + 127) / 128) * 128 + 32;         // gs row pitch
+    static constexpr int GP = 32;                  // gs row pitch (wave-private [16][32]: rows 64 bytes apart = the transpose-read's bank rule)
     static constexpr int OP = N2 + 4;              // output staging pitch (floats)
     static constexpr int MT2 = (D + 31) / 32;
     static constexpr size_t xs_bytes = (size_t)D * XP * sizeof(T);
-    static constexpr size_t ts_bytes = (size_t)32 * TP * sizeof(T);
-    static constexpr size_t gs_bytes = (size_t)16 * GP * sizeof(T);
-    static constexpr size_t ln_bytes = (size_t)2 * D * sizeof(float);
-    static constexpr size_t lds_bytes = xs_bytes + ts_bytes + gs_bytes + ln_bytes;
-    static_assert(N2T == 4, "a wave owns one 32-pixel column tile of GEMM 2");
-    static_assert(16 * TH * (TW / 8) == 256, "one (pair, row, 8-pixel piece) per thread and chunk");
-    static_assert((size_t)D * OP * sizeof(float) <= xs_bytes, "the output staging tile reuses the activation image");
-    static_assert((size_t)4 * NQ * sizeof(float) <= ts_bytes, "the LayerNorm partial sums reuse the t tile");
+    static constexpr size_t ts_bytes = (size_t)4 * 32 * TP * sizeof(T);
+    static constexpr size_t gs_bytes = (size_t)4 * 16 * GP * sizeof(T);
+    static constexpr size_t lds_bytes = xs_bytes + ts_bytes + gs_bytes;
+    static_assert((size_t)2 * D * sizeof(float) <= gs_bytes, "the LayerNorm weight / bias image lies in the gate tiles until the main loop");
+    static_assert(N2T == 4 && RW * TW == 32, "a wave owns one 32-pixel column tile of GEMM 2 = its own output rows");
+    static_assert(WQ % 32 == 0, "a wave's halo pixels are whole MFMA column tiles");
+    static_assert(16 * RW * (TW / 8) == 64, "one (pair, row, 8-pixel piece) per lane and chunk");
+    static_assert((size_t)D * OP * sizeof(float) <= xs_bytes + ts_bytes, "the output staging tile reuses the activation image and the t tiles");
+    static_assert((size_t)4 * NQ * sizeof(float) <= ts_bytes, "the LayerNorm partial sums reuse the t tiles");
     static_assert(NQ % 4 == 0 && NQ / 4 <= 64, "LayerNorm: quads of pixels x 4 channel parts on 256 threads");
 };
 
+// (the narrow forms fit three workgroups per CU in LDS: registers for three waves per SIMD)
 template <typename T, int KS, int TH, int TW>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (KS > 3 || std::is_same<T, bf16_t>::value) ? 2 : 3)   // (bf16 unpacking: 26 registers more)
 oss_effn_fwd_kernel(EffnArgs a) {
     using G = EffnGeo<T, KS, TH, TW>;
-    constexpr int D = G::D, SP = G::SP, HR = G::HR, NQ = G::NQ, N1T = G::N1T, XP = G::XP, TP = G::TP, GP = G::GP, OP = G::OP, MT2 = G::MT2;
+    constexpr int D = G::D, SP = G::SP, HR = G::HR, NQ = G::NQ, N1W = G::N1W, RW = G::RW, XP = G::XP, TP = G::TP, GP = G::GP, OP = G::OP, MT2 = G::MT2;
     extern __shared__ __attribute__((aligned(16))) unsigned char effn_smem[];
     T *xs = reinterpret_cast<T *>(effn_smem);                                   // [D][XP]
-    T *ts = reinterpret_cast<T *>(effn_smem + G::xs_bytes);                     // [32][TP]: rows 0..15 = x1 of the chunk's pairs, 16..31 = x2
-    T *gs = reinterpret_cast<T *>(effn_smem + G::xs_bytes + G::ts_bytes);       // [16][GP]
-    float *lnw_s = reinterpret_cast<float *>(effn_smem + G::xs_bytes + G::ts_bytes + G::gs_bytes), *lnb_s = lnw_s + D;
+    T *ts_all = reinterpret_cast<T *>(effn_smem + G::xs_bytes);                 // [4 waves][32][TP]: rows 0..15 = x1 of the chunk's pairs, 16..31 = x2
+    T *gs_all = reinterpret_cast<T *>(effn_smem + G::xs_bytes + G::ts_bytes);   // [4 waves][16][GP]
+    float *lnw_s = reinterpret_cast<float *>(gs_all), *lnb_s = lnw_s + D;        // (prologue only)
+    auto xoff = [](int c, int q) { return c * XP + ((q + 32 * (c & 3)) & (XP - 1)); };   // element (channel c, stored pixel q) of xs
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y, ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
     const int h0 = ty * TH, w0 = tx * TW, H = a.H, W = a.W, h = a.h;
@@ -91,26 +105,27 @@ oss_effn_fwd_kernel(EffnArgs a) {
     // weight fragments: W_in's (GEMM 1, used at the top of a chunk) are requested during the previous chunk's step 2; the depth-wise
     // taps and W_out's fragments (steps 2 and 3) at the top of their own chunk, behind GEMM 1.  (All three one chunk ahead in two
     // register sets: 108 VGPRs, and the D = 96 bf16 instantiation spilled.)
-    u32x4 a1[KS], a2[MT2];
-    float k1[9], k2[9];
-    const int pr = tid >> 4, orow = (tid & 15) / (TW / 8), seg = (tid & 15) % (TW / 8);   // this thread's piece in step 2
+    u32x4 a1[KS];
+    struct Rest { u32x4 a2[MT2]; float k1[9], k2[9]; };
+    const int pr = lane >> 2, orow = (lane & 3) / (TW / 8), seg = (lane & 3) % (TW / 8);   // this lane's piece in step 2 (orow: of the wave's RW rows)
     auto issue_a1 = [&](int c0) {
-        const int cr = c0 + (col & 15);
-        const int ch = min(col < 16 ? cr : h + cr, 2 * h - 1);
+        const int ch = c0 + (col & 15) + (col < 16 ? 0 : a.HP);   // (zero rows behind each half: no masks in the loop)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a1[ks] = *reinterpret_cast<const u32x4 *>(w_in + (size_t)ch * D + ks * 16 + kg * 8);
     };
-    auto issue_rest = [&](int c0) {
+    auto issue_rest = [&](int c0, Rest &f) {
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
             const int dm = min(mt * 32 + col, D - 1);
-            a2[mt] = *reinterpret_cast<const u32x4 *>(w_out + (size_t)dm * a.HP + c0 + kg * 8);
+            f.a2[mt] = *reinterpret_cast<const u32x4 *>(w_out + (size_t)dm * a.HP + c0 + kg * 8);
         }
-        const int cp = min(c0 + pr, h - 1);
+        const int cp = c0 + pr;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) { k1[i] = a.w_dw[(size_t)cp * 9 + i]; k2[i] = a.w_dw[(size_t)(h + cp) * 9 + i]; }
+        for (int i = 0; i < 9; ++i) { f.k1[i] = a.w_dw[(size_t)cp * 9 + i]; f.k2[i] = a.w_dw[(size_t)(a.HP + cp) * 9 + i]; }
     };
+    Rest cur;
     issue_a1(0);
+    issue_rest(0, cur);
     if (tid < D) { lnw_s[tid] = a.ln_w[tid]; lnb_s[tid] = a.ln_b ? a.ln_b[tid] : 0.f; }
 
     // 0a. the halo tile of x: 8-byte pieces (4 pixels), (channel, halo row, piece) on consecutive threads
@@ -137,7 +152,7 @@ oss_effn_fwd_kernel(EffnArgs a) {
                     const int idx = tid + (i0 + i) * 256;
                     if (TOTAL % 256 == 0 || idx < TOTAL) {
                         const int d = idx / (HR * PPR), r = idx - d * (HR * PPR), hr = r / PPR, pc = r - hr * PPR;
-                        *reinterpret_cast<u32x2 *>(xs + d * XP + hr * SP + 4 * pc) = q[i];
+                        *reinterpret_cast<u32x2 *>(xs + xoff(d, hr * SP + 4 * pc)) = q[i];
                     }
                 }
             }
@@ -148,7 +163,7 @@ oss_effn_fwd_kernel(EffnArgs a) {
     {
         constexpr int QPT = NQ / 4, NPART = 4, CPT = D / NPART;
         static_assert(D % NPART == 0, "channels per part");
-        float *red = reinterpret_cast<float *>(ts);   // [NPART][NQ]
+        float *red = reinterpret_cast<float *>(ts_all);   // [NPART][NQ]
         const bool act = tid < QPT * NPART;
         const int quad = act ? tid % QPT : 0, part = act ? tid / QPT : 0, px = 4 * quad;
         const int hr = px / SP, sc = px - hr * SP, ih = h0 - 1 + hr, iw = w0 - 4 + sc;
@@ -156,7 +171,7 @@ oss_effn_fwd_kernel(EffnArgs a) {
         // (the pixel's values are read from LDS again in each of the three passes: 24 x 4 of them held in registers over the passes
         // pushed the D = 96 instantiation into scratch memory)
         auto ld4 = [&](int i, float (&v)[4]) {
-            const u32x2 q = *reinterpret_cast<const u32x2 *>(xs + (part + i * NPART) * XP + px);
+            const u32x2 q = *reinterpret_cast<const u32x2 *>(xs + xoff(part + i * NPART, px));
             unpack2<T>(q.x, v[0], v[1]); unpack2<T>(q.y, v[2], v[3]);
         };
         float sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -209,16 +224,26 @@ oss_effn_fwd_kernel(EffnArgs a) {
                 ld4(i, v);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) o[u] = (v[u] - mu_c[u]) * rstd[u] * wc + bc;   // outside the image: rstd = bc = 0 -> 0
-                *reinterpret_cast<u32x2 *>(xs + c * XP + px) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
+                *reinterpret_cast<u32x2 *>(xs + xoff(c, px)) = u32x2{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3])};
             }
         }
-        __syncthreads();   // (also: red[] = ts has been read by everyone)
+        __syncthreads();   // (also: red[] = the t tiles has been read by everyone)
     }
 
+    // From here to the epilogue the waves do not meet: wave w computes t on ITS halo (stored rows RW w .. RW w + RW + 1 = column tiles
+    // of GEMM 1 starting at pixel q0), convolves and gates ITS RW output rows, and multiplies them into ITS 32 output pixels.  The
+    // neighbouring waves' halos overlap by two stored rows (GEMM 1 does 4 N1W column tiles instead of NQ / 32 -- MFMAs on a pipe
+    // that is a tenth busy) and in exchange the two workgroup barriers per chunk of the first version are gone: with two waves per
+    // SIMD, every barrier left the SIMD idle whenever both of its waves were waiting (profiles/r06_pmc_sq_effn_v1_barriers.txt:
+    // VALU busy 27 % of the wave cycles, 36 % waiting, 27 % neither).  LDS operations of one wave execute in order.
+    T *ts = ts_all + wave * 32 * TP, *gs = gs_all + wave * 16 * GP;
+    const int q0 = wave * RW * SP;
     const int i16 = lane & 15, g = lane >> 4;
-    const int tr1 = (8 * (g >> 1) + (i16 >> 2)) * XP + 16 * (g & 1) + 4 * (i16 & 3);
-    const int tr2 = (8 * (g >> 1) + (i16 >> 2)) * GP + 16 * (g & 1) + 4 * (i16 & 3) + 32 * wave;
-    constexpr int NPW = (N1T + 3) / 4;   // GEMM 1 column tiles per wave
+    const int tr1_row = (8 * (g >> 1) + (i16 >> 2)) * XP;
+    int tr1_px[N1W];   // the lane's four pixels of column tile j, rotated like its channel row (rows r and r + 4 k share r & 3)
+#pragma unroll
+    for (int j = 0; j < N1W; ++j) tr1_px[j] = (q0 + 32 * j + 16 * (g & 1) + 4 * (i16 & 3) + 32 * (i16 >> 2)) & (XP - 1);
+    const int tr2 = (8 * (g >> 1) + (i16 >> 2)) * GP + 16 * (g & 1) + 4 * (i16 & 3);
     f32x16 acc2[MT2];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)
@@ -226,57 +251,80 @@ oss_effn_fwd_kernel(EffnArgs a) {
         for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
 
     for (int c0 = 0; c0 < h; c0 += 16) {
-        issue_rest(c0);
-        // 1. t[32 rows][halo pixels] = W_in rows of the chunk x the normalised tile
+        const bool more = c0 + 16 < h;
+        // 1. t[32 rows][the wave's halo pixels] = W_in rows of the chunk x the normalised tile
         {
-            const bool rv = c0 + (col & 15) < h;
-            s16x8 af[KS];
+            // pixels are the ROWS of this product (activations = operand A) and the chunk's 32 channels its columns: a lane then holds four
+            // consecutive pixels of ONE channel per register quad and t goes to LDS as 8-byte pieces (as [channel][pixel] rows with
+            // 2-byte writes the stores alone were 190 LDS cycles per wave and chunk, two lanes per bank word)
+            s16x8 wf[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) af[ks] = rv ? __builtin_bit_cast(s16x8, a1[ks]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(s16x8, a1[ks]);
+            // the wave's N1W column tiles side by side (N1W accumulators): one tile after the other on ONE accumulator was a chain of
+            // dependent MFMAs, each behind the LDS latency of its own two transpose-reads (lgkmcnt(1) before every MFMA in the ISA)
+            f32x16 acc[N1W];
 #pragma unroll
-            for (int jj = 0; jj < NPW; ++jj) {
-                const int j = wave + 4 * jj;
-                if (j < N1T) {   // (wave-uniform)
-                    f32x16 acc;
+            for (int j = 0; j < N1W; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            auto rd = [&](int ks, int j) -> s16x8 {
+                const T *bp = xs + ks * 16 * XP + tr1_row + tr1_px[j];
+                const s16x4e lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4e *)(bp));
+                const s16x4e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4e *)(bp + 4 * XP));
+                return s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            };
+            s16x8 xf[N1W];
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        const T *bp = xs + ks * 16 * XP + 32 * j + tr1;
-                        const s16x4e lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4e *)(bp));
-                        const s16x4e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4e *)(bp + 4 * XP));
-                        const s16x8 bf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        acc = Mfma<T>::run(af[ks], bf, acc);
-                    }
+            for (int j = 0; j < N1W; ++j) xf[j] = rd(0, j);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        ts[row * TP + 32 * j + col] = from_f32<T>(acc[r]);
-                    }
+            for (int ks = 0; ks < KS; ++ks) {
+                s16x8 xn[N1W];
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int j = 0; j < N1W; ++j) xn[j] = rd(ks + 1, j);
+                }
+#pragma unroll
+                for (int j = 0; j < N1W; ++j) acc[j] = Mfma<T>::run(xf[j], wf[ks], acc[j]);
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int j = 0; j < N1W; ++j) xf[j] = xn[j];
                 }
             }
+#pragma unroll
+            for (int j = 0; j < N1W; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)   // rows (= pixels) 8 rg + 4 kg .. + 3 of the tile, column (= channel) col
+                    *reinterpret_cast<u32x2 *>(ts + col * TP + 32 * j + 8 * rg + 4 * kg) =
+                        u32x2{pack2<T>(acc[j][4 * rg], acc[j][4 * rg + 1]), pack2<T>(acc[j][4 * rg + 2], acc[j][4 * rg + 3])};
         }
-        __syncthreads();
-        if (c0 + 16 < h) issue_a1(c0 + 16);
-        // 2. depth-wise 3x3 of both planes of the thread's pair on its 8-pixel row piece, then the gate
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (more) issue_a1(c0 + 16);
+        // 2. depth-wise 3x3 of both planes of the lane's pair on its 8-pixel row piece, then the gate
         {
+            // every LDS read of the piece first (both planes, three rows, four 8-byte pieces each), then the arithmetic
+            u32x2 raw[2][3][4];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int dr = 0; dr < 3; ++dr) {
+                    const T *tp = ts + (pl * 16 + pr) * TP + (orow + dr) * SP + 8 * seg;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) raw[pl][dr][i] = *reinterpret_cast<const u32x2 *>(tp + 4 * i);
+                }
             float x12[2][8];
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                const T *tp = ts + (pl * 16 + pr) * TP;
-                const float *k = pl ? k2 : k1;
+                const float *k = pl ? cur.k2 : cur.k1;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x12[pl][j] = 0.f;
 #pragma unroll
                 for (int dr = 0; dr < 3; ++dr) {
-                    const int q = (orow + dr) * SP + 4 + 8 * seg;
-                    const u32x2 qa = *reinterpret_cast<const u32x2 *>(tp + q - 4), qb = *reinterpret_cast<const u32x2 *>(tp + q),
-                                qc = *reinterpret_cast<const u32x2 *>(tp + q + 4), qd = *reinterpret_cast<const u32x2 *>(tp + q + 8);
                     float v[10], dump;
-                    unpack2<T>(qa.y, dump, v[0]);
-                    unpack2<T>(qb.x, v[1], v[2]); unpack2<T>(qb.y, v[3], v[4]);
-                    unpack2<T>(qc.x, v[5], v[6]); unpack2<T>(qc.y, v[7], v[8]);
-                    unpack2<T>(qd.x, v[9], dump);
+                    unpack2<T>(raw[pl][dr][0].y, dump, v[0]);
+                    unpack2<T>(raw[pl][dr][1].x, v[1], v[2]); unpack2<T>(raw[pl][dr][1].y, v[3], v[4]);
+                    unpack2<T>(raw[pl][dr][2].x, v[5], v[6]); unpack2<T>(raw[pl][dr][2].y, v[7], v[8]);
+                    unpack2<T>(raw[pl][dr][3].x, v[9], dump);
                     const float k0 = k[dr * 3], k1 = k[dr * 3 + 1], k2 = k[dr * 3 + 2];
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
@@ -293,7 +341,8 @@ oss_effn_fwd_kernel(EffnArgs a) {
             *reinterpret_cast<u32x4 *>(gs + pr * GP + orow * TW + 8 * seg) =
                 u32x4{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // 3. out[D rows][the wave's 32 pixels] += W_out[:, chunk] x gate
         {
             const T *bp = gs + tr2;
@@ -302,12 +351,15 @@ oss_effn_fwd_kernel(EffnArgs a) {
             const s16x8 bf = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt) {
-                const s16x8 af = mt * 32 + col < D ? __builtin_bit_cast(s16x8, a2[mt]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                const s16x8 af = (D % 32 == 0 || mt * 32 + col < D) ? __builtin_bit_cast(s16x8, cur.a2[mt]) : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 acc2[mt] = Mfma<T>::run(af, bf, acc2[mt]);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the next chunk's step 1 / 2 overwrite ts / gs
+        if (more) issue_rest(c0 + 16, cur);   // (a second register set for them, requested a chunk ahead: no gain, A-B in DESIGN.md)
     }
-    __syncthreads();   // everyone is done with xs (GEMM 1 of the last chunk) before it becomes the output staging tile
+    __syncthreads();   // everyone is done with xs and the t tiles before they become the output staging tile
     // 4. fp32 sums -> LDS -> + x -> one rounding -> 16-byte stores along the image rows
     float *os = reinterpret_cast<float *>(effn_smem);   // [D][OP]
 #pragma unroll

@@ -83,32 +83,38 @@ def effn_fwd_ok(x: torch.Tensor, hidden: int) -> bool:
     return bool(_capi.load().oss_effn_fwd_ok(_DT[x.dtype], x.shape[1], hidden, x.shape[2], x.shape[3]))
 
 
-def effn_round_weights(project_in: torch.Tensor, project_out: torch.Tensor, dtype: torch.dtype):
-    """the two 1x1 weights as the kernel reads them: rounded to the I/O type (what the chain's kernels do at every use), project_out's
-    rows padded with zeros to a multiple of 16 columns -> (w_in (2 h, D), w_out (D, HP))"""
+def effn_round_weights(project_in: torch.Tensor, dwconv: torch.Tensor, project_out: torch.Tensor, dtype: torch.dtype):
+    """the EFFN's weights as the kernel reads them -> (w_in (2 HP, D), w_dw (2 HP, 9) fp32, w_out (D, HP)), HP = h rounded up to 16:
+    the two 1x1 weights rounded to the I/O type (what the chain's kernels do at every use), both halves of project_in / dwconv
+    (x1 rows | x2 rows) and project_out's columns padded with zeros"""
     h2, D = project_in.shape[0], project_in.shape[1]
     h = h2 // 2
     hp = (h + 15) // 16 * 16
-    w_in = project_in.detach().reshape(h2, D).to(dtype).contiguous()
-    w_out = torch.zeros((D, hp), dtype=dtype, device=project_out.device)
+    dev = project_in.device
+    w_in = torch.zeros((2, hp, D), dtype=dtype, device=dev)
+    w_in[:, :h] = project_in.detach().reshape(2, h, D).to(dtype)
+    w_dw = torch.zeros((2, hp, 9), dtype=torch.float32, device=dev)
+    w_dw[:, :h] = dwconv.detach().reshape(2, h, 9).float()
+    w_out = torch.zeros((D, hp), dtype=dtype, device=dev)
     w_out[:, :h] = project_out.detach().reshape(D, h).to(dtype)
-    return w_in, w_out
+    return w_in.reshape(2 * hp, D), w_dw.reshape(2 * hp, 9), w_out
 
 
 def effn_fwd(x: torch.Tensor, ln_w: torch.Tensor, ln_b: Optional[torch.Tensor], w_in: torch.Tensor, w_dw: torch.Tensor,
              w_out: torch.Tensor, hidden: int) -> torch.Tensor:
     """``x + project_out(gelu(x1) * x2)`` with ``x1, x2 = dwconv(project_in(LayerNorm(x))).chunk(2, 1)`` (MambaSISR6_arch.py:201-218,
-    513-516) in ONE launch, forward only.  ``w_in`` / ``w_out``: ``effn_round_weights``; ``w_dw``: dwconv.weight (2 h, 1, 3, 3)"""
+    513-516) in ONE launch, forward only.  ``w_in`` / ``w_dw`` / ``w_out``: ``effn_round_weights``"""
     B, D, H, W = x.shape
     _check(effn_fwd_ok(x, hidden), "effn_fwd: the fused forward does not take this tensor (effn_fwd_ok)")
     hp = (hidden + 15) // 16 * 16
-    _check(tuple(w_in.shape) == (2 * hidden, D) and tuple(w_out.shape) == (D, hp) and w_in.dtype == x.dtype and w_out.dtype == x.dtype
-           and w_in.is_contiguous() and w_out.is_contiguous() and w_dw.numel() == 2 * hidden * 9,
-           "effn_fwd: weights must come from effn_round_weights (w_in (2 h, D), w_out (D, h padded to 16) of x's dtype)")
-    lw, lb, dw = _f32c(ln_w), (None if ln_b is None else _f32c(ln_b)), _f32c(w_dw.detach().reshape(2 * hidden, 9))
+    _check(tuple(w_in.shape) == (2 * hp, D) and tuple(w_out.shape) == (D, hp) and tuple(w_dw.shape) == (2 * hp, 9)
+           and w_in.dtype == x.dtype and w_out.dtype == x.dtype and w_dw.dtype == torch.float32
+           and w_in.is_contiguous() and w_out.is_contiguous() and w_dw.is_contiguous(),
+           "effn_fwd: weights must come from effn_round_weights (w_in (2 HP, D) and w_out (D, HP) of x's dtype, w_dw (2 HP, 9) float)")
+    lw, lb = _f32c(ln_w), (None if ln_b is None else _f32c(ln_b))
     out = torch.empty((B, D, H, W), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        _capi.check(_capi.load().oss_effn_fwd(_DT[x.dtype], x.data_ptr(), lw.data_ptr(), _ptr(lb), w_in.data_ptr(), dw.data_ptr(),
+        _capi.check(_capi.load().oss_effn_fwd(_DT[x.dtype], x.data_ptr(), lw.data_ptr(), _ptr(lb), w_in.data_ptr(), w_dw.data_ptr(),
                                               w_out.data_ptr(), out.data_ptr(), B, D, hidden, H, W, x.stride(0), x.stride(1),
                                               out.stride(0), out.stride(1), 1e-5, torch.cuda.current_stream().cuda_stream), "oss_effn_fwd")
     return out

@@ -91,12 +91,12 @@ class FeedForward(nn.Module):
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
 
     def _rounded(self, dtype: torch.dtype):
-        """the two 1x1 weights rounded to the I/O type once per weight version (inference: constants) -- ops.ffn.effn_round_weights"""
-        wi, wo = self.project_in.weight, self.project_out.weight
-        key = (dtype, wi._version, wo._version, wi.data_ptr(), wo.data_ptr())
+        """the weights as the one-launch forward reads them, once per weight version (inference: constants) -- ops.ffn.effn_round_weights"""
+        wi, wd, wo = self.project_in.weight, self.dwconv.weight, self.project_out.weight
+        key = (dtype, wi._version, wd._version, wo._version, wi.data_ptr(), wd.data_ptr(), wo.data_ptr())
         hit = getattr(self, "_rounded_cache", None)
         if hit is None or hit[0] != key:
-            hit = (key, effn_round_weights(wi, wo, dtype))
+            hit = (key, effn_round_weights(wi, wd, wo, dtype))
             self._rounded_cache = hit
         return hit[1]
 
@@ -108,9 +108,8 @@ class FeedForward(nn.Module):
                 and effn_fwd_ok(x, self.project_out.in_channels):
             # inference: norm2 -> project_in -> dwconv -> gate -> project_out -> + x as ONE launch (csrc/oss_effn.hip); the 2h- and
             # h-channel intermediates never reach memory
-            w_in, w_out = self._rounded(x.dtype)
-            return torch.ops.vmambair.effn_fwd(x, pre_norm.body.weight, pre_norm.body.bias, w_in, self.dwconv.weight, w_out,
-                                               self.project_out.in_channels)
+            w_in, w_dw, w_out = self._rounded(x.dtype)
+            return torch.ops.vmambair.effn_fwd(x, pre_norm.body.weight, pre_norm.body.bias, w_in, w_dw, w_out, self.project_out.in_channels)
         if pre_norm is not None:
             t, residual = _norm_then_conv(x, pre_norm, self.project_in)
         else:
