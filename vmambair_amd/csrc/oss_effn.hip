@@ -34,6 +34,17 @@ namespace oss {
 
 typedef short s16x4e __attribute__((ext_vector_type(4)));
 
+// two fp32 -> one word of two I/O elements, one instruction for both types (oss_device.h's generic pack2 is two v_cvt_f16_f32 and an
+// OR for fp16: 48 of this kernel's ~550 VALU instructions per chunk)
+template <typename T> __device__ __forceinline__ uint32_t pk2(float lo, float hi) { return pack2<T>(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pk2<f16_t>(float lo, float hi) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 h = __builtin_convertvector(f32x2{lo, hi}, f16x2);   // v_cvt_pk_f16_f32 (gfx950), round to nearest even
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+
 struct EffnArgs {
     const void *x;           // (B, D, H, W), strides xsb / xsc, rows contiguous
     void *out;               // same layout, strides osb / osc
@@ -295,7 +306,7 @@ oss_effn_fwd_kernel(EffnArgs a) {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)   // rows (= pixels) 8 rg + 4 kg .. + 3 of the tile, column (= channel) col
                     *reinterpret_cast<u32x2 *>(ts + col * TP + 32 * j + 8 * rg + 4 * kg) =
-                        u32x2{pack2<T>(acc[j][4 * rg], acc[j][4 * rg + 1]), pack2<T>(acc[j][4 * rg + 2], acc[j][4 * rg + 3])};
+                        u32x2{pk2<T>(acc[j][4 * rg], acc[j][4 * rg + 1]), pk2<T>(acc[j][4 * rg + 2], acc[j][4 * rg + 3])};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -339,7 +350,7 @@ oss_effn_fwd_kernel(EffnArgs a) {
                 o[j] = x12[0][j] * cdf * x12[1][j];
             }
             *reinterpret_cast<u32x4 *>(gs + pr * GP + orow * TW + 8 * seg) =
-                u32x4{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
+                u32x4{pk2<T>(o[0], o[1]), pk2<T>(o[2], o[3]), pk2<T>(o[4], o[5]), pk2<T>(o[6], o[7])};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -383,8 +394,8 @@ oss_effn_fwd_kernel(EffnArgs a) {
                 float r8[8];
                 unpack2<T>(rq.x, r8[0], r8[1]); unpack2<T>(rq.y, r8[2], r8[3]); unpack2<T>(rq.z, r8[4], r8[5]); unpack2<T>(rq.w, r8[6], r8[7]);
                 *reinterpret_cast<u32x4 *>(ob + dm * a.osc + (int64_t)ih * W + iw) =
-                    u32x4{pack2<T>(v0.x + r8[0], v0.y + r8[1]), pack2<T>(v0.z + r8[2], v0.w + r8[3]),
-                          pack2<T>(v1.x + r8[4], v1.y + r8[5]), pack2<T>(v1.z + r8[6], v1.w + r8[7])};
+                    u32x4{pk2<T>(v0.x + r8[0], v0.y + r8[1]), pk2<T>(v0.z + r8[2], v0.w + r8[3]),
+                          pk2<T>(v1.x + r8[4], v1.y + r8[5]), pk2<T>(v1.z + r8[6], v1.w + r8[7])};
             }
         }
     }
