@@ -131,6 +131,9 @@ def bench_realsr_tiled(args):
     if os.environ.get("VMAMBAIR_SCAN_VARIANT"):
         fv, bv = (int(v) for v in os.environ["VMAMBAIR_SCAN_VARIANT"].split(","))
         lib.oss_scan_set_variant(fv, bv)
+    # profiling only: VMAMBAIR_REALSR_LEGS="eager,graph_4_tiles_stacked_shapes_side_by_side" times just these legs (an eager leg of the
+    # tiling first: the graph legs are compared with it) and prints them alone -- the kernel trace then ends on the leg wanted
+    only_legs = [v for v in os.environ.get("VMAMBAIR_REALSR_LEGS", "").split(",") if v]
     torch.manual_seed(0)
     net = build_network(NET_REALSR).to(dev)
     img = torch.rand(1, 3, 512, 512, device=dev)
@@ -146,6 +149,8 @@ def bench_realsr_tiled(args):
                                         ("graph_4_tiles_stacked_shapes_side_by_side", True, 4, True, 128),
                                         ("tile256_eager", False, 1, False, 256), ("tile256_graph_4_tiles_stacked", True, 4, False, 256),
                                         ("untiled_eager", False, 1, False, 0), ("untiled_graph", True, 1, False, 0)):
+        if only_legs and name not in only_legs:
+            continue
         drv = RealSREnhancer(net, 4, tile=tile, tile_pad=16, pre_pad=0, half=True, use_graph=graph, batch_tiles=bt, concurrent_shapes=conc)
         runs = (lambda d=drv: d.tiled.tiles_run) if tile else (lambda d=drv: d.whole.calls)
         out = drv.enhance_tensor(img)   # capture / warm-up
@@ -155,7 +160,7 @@ def bench_realsr_tiled(args):
         n0 = runs()
         if graph:
             lib.oss_prof_reset()
-        mark = graph and (bt == 1 or tile == 256)   # kernel-trace markers (tools/prof_summary.py reads the LAST marked leg)
+        mark = graph and (bt == 1 or tile == 256 or bool(only_legs))   # kernel-trace markers (tools/prof_summary.py reads the LAST marked leg)
         if mark:
             lib.oss_prof_marker(1, torch.cuda.current_stream().cuda_stream)
         t0 = time.perf_counter()
@@ -175,6 +180,10 @@ def bench_realsr_tiled(args):
                      "max_abs_diff_vs_eager": float((out.float() - ref).abs().max())}
         del drv
         torch.cuda.empty_cache()
+
+    if only_legs:
+        print(json.dumps({"legs": res}), flush=True)
+        return
 
     def scan_roofline(tile, shape):
         """roofline of the dominant scan kernel of one tiling: the same tiles once more, eager, one at a time, with the library's events on"""
