@@ -284,6 +284,11 @@ int oss_dwgate_fwd_ok(oss_dtype io, int height, int width);
  *   w_out:  (channels, HP) of the io type -- project_out.weight
  * oss_effn_fwd_ok: channels in {32, 48, 64, 96}, width a multiple of 8; anything else (and every training call) stays on the chain. */
 int oss_effn_fwd_ok(oss_dtype io, int channels, int hidden, int height, int width);
+/* w_in / w_dw / w_out of oss_effn_fwd from the module's float parameters (project_in.weight (2 hidden, channels), dwconv.weight
+ * (2 hidden, 9), project_out.weight (channels, hidden)) in ONE launch: an inference graph captures it in front of the forward and
+ * so never replays stale copies after the parameters changed in place. */
+int oss_effn_round_weights(oss_dtype io, const float *project_in, const float *dwconv, const float *project_out, void *w_in, float *w_dw,
+                           void *w_out, int channels, int hidden, oss_stream_t stream);
 int oss_effn_fwd(oss_dtype io, const void *x, const float *norm_weight, const float *norm_bias, const void *w_in, const float *w_dw,
                  const void *w_out, void *out, int batch, int channels, int hidden, int height, int width, int64_t x_batch_stride,
                  int64_t x_channel_stride, int64_t out_batch_stride, int64_t out_channel_stride, float eps, oss_stream_t stream);

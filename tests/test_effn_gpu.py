@@ -118,3 +118,52 @@ def test_rounded_weights_follow_the_parameters():
         b = ff(x, pre_norm=norm)
     assert ff._rounded(torch.float16)[0] is not first[0]
     assert_close((b.float() - x.float()), 2.0 * (a.float() - x.float()), 5e-3, 5e-3 * float(a.abs().max()), "doubled project_out")
+
+
+def test_round_weights_kernel_matches_the_torch_construction():
+    """oss_effn_round_weights (one launch) against slicing / padding / casting with torch ops"""
+    torch.manual_seed(8)
+    for D, dt in ((48, torch.float16), (96, torch.bfloat16), (32, torch.float16)):
+        ff = oss_block.FeedForward(D, 2.66, False).to(DEV)
+        h = ff.project_out.in_channels
+        hp = (h + 15) // 16 * 16
+        w_in, w_dw, w_out = ops.effn_round_weights(ff.project_in.weight, ff.dwconv.weight, ff.project_out.weight, dt)
+        want_in = torch.zeros(2, hp, D, device=DEV, dtype=dt)
+        want_in[:, :h] = ff.project_in.weight.detach().reshape(2, h, D).to(dt)
+        want_dw = torch.zeros(2, hp, 9, device=DEV)
+        want_dw[:, :h] = ff.dwconv.weight.detach().reshape(2, h, 9)
+        want_out = torch.zeros(D, hp, device=DEV, dtype=dt)
+        want_out[:, :h] = ff.project_out.weight.detach().reshape(D, h).to(dt)
+        assert torch.equal(w_in, want_in.reshape(2 * hp, D)) and torch.equal(w_dw, want_dw.reshape(2 * hp, 9)) and torch.equal(w_out, want_out)
+
+
+def test_a_captured_inference_graph_follows_in_place_weight_updates():
+    """the rounded weight copies are cached per weight version in eager mode; inside a graph capture the rounding launch is captured
+    with the forward, so a replay after an in-place update of the parameters (load_state_dict, an optimizer step between two
+    validations) computes with the NEW weights -- as every other kernel of the net does, reading the fp32 parameters directly"""
+    torch.manual_seed(9)
+    norm = oss_block.LayerNorm(48, "WithBias").to(DEV)
+    ff = oss_block.FeedForward(48, 2.66, False).to(DEV)
+    x = torch.randn(2, 48, 24, 32, device=DEV).to(torch.float16)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ff(x, pre_norm=norm)   # warm-up: fills the eager cache
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = ff(x, pre_norm=norm)
+        g.replay()
+        torch.cuda.synchronize()
+        first = out.clone()
+        assert torch.equal(first, ff(x, pre_norm=norm))
+        ff.project_in.weight.mul_(1.5)
+        ff.dwconv.weight.add_(0.05)
+        ff.project_out.weight.mul_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        fresh = ff(x, pre_norm=norm)
+    assert not torch.equal(out, first)
+    assert torch.equal(out, fresh), "the replay used the parameters as they are now"

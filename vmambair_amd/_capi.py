@@ -81,7 +81,7 @@ SYMBOLS = ["oss_scan_chunk", "oss_scan_num_chunks", "oss_scan_fwd", "oss_scan_fw
            "oss_scan_last_segments", "oss_scan_last_lane_states", "oss_prof_enable", "oss_prof_reset",
            "oss_prof_collect", "oss_prof_collect2", "oss_prof_family_enable", "oss_prof_family_count", "oss_prof_family", "oss_dwconv3x3_fwd", "oss_dwconv3x3_wgrad", "oss_dwconv3x3_fused_ok", "oss_dwconv3x3_silu_fwd", "oss_dwconv3x3_silu_bwd", "oss_dwconv3x3_flat2_ok", "oss_dwconv3x3_silu_flat2_fwd",
            "oss_dwconv3x3_silu_flat2_bwd",
-           "oss_dwgate_fwd_ok", "oss_effn_fwd_ok", "oss_effn_fwd", "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_fwd_pool", "oss_ln_nchw_fwd_pool_tiles", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
+           "oss_dwgate_fwd_ok", "oss_effn_fwd_ok", "oss_effn_round_weights", "oss_effn_fwd", "oss_dwgate_fwd", "oss_dwgate_bwd", "oss_ln_nchw_fwd", "oss_ln_nchw_fwd_pool", "oss_ln_nchw_fwd_pool_tiles", "oss_ln_nchw_bwd", "oss_ln_nchw_bwd_affine", "oss_ln_nchw_bwd_partial_floats", "oss_merge4", "oss_conv1x1_fwd", "oss_conv1x1_dgrad",
            "oss_conv1x1_wgrad_partial_floats", "oss_conv1x1_wgrad", "oss_conv1x1_wgrad_set_tile", "oss_conv1x1_wgrad_set_span", "oss_conv1x1_wg", "oss_conv1x1_set_wg", "oss_ln_conv1x1_ok", "oss_ln_conv1x1_fwd", "oss_conv1x1_dgrad_ln_bwd_ok",
            "oss_conv1x1_dgrad_ln_bwd_partial_floats", "oss_conv1x1_dgrad_ln_bwd", "oss_cross_scan2", "oss_cross_merge2", "oss_proj_fwd",
            "oss_proj_dgrad", "oss_proj_wgrad_partial_floats", "oss_proj_wgrad", "oss_proj_set_path", "oss_proj_rows_optional_ok", "oss_chan_fwd", "oss_chan_grad_floats",
@@ -168,6 +168,8 @@ def load():
     lib.oss_dwgate_fwd_ok.argtypes = [C.c_int] * 3
     lib.oss_effn_fwd_ok.restype = C.c_int
     lib.oss_effn_fwd_ok.argtypes = [C.c_int] * 5
+    lib.oss_effn_round_weights.restype = C.c_int
+    lib.oss_effn_round_weights.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 2 + [C.c_void_p]
     lib.oss_effn_fwd.restype = C.c_int
     lib.oss_effn_fwd.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_int64] * 4 + [C.c_float, C.c_void_p]
     for fn in (lib.oss_dwconv3x3_silu_fwd, lib.oss_dwgate_fwd):

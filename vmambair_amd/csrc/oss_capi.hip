@@ -395,6 +395,12 @@ int oss_dwconv3x3_silu_flat2_bwd(oss_dtype io, const void *x, const float *weigh
 
 int oss_effn_fwd_ok(oss_dtype io, int channels, int hidden, int height, int width) { return effn_fwd_ok(io, channels, hidden, height, width); }
 
+int oss_effn_round_weights(oss_dtype io, const float *project_in, const float *dwconv, const float *project_out, void *w_in, float *w_dw,
+                           void *w_out, int channels, int hidden, oss_stream_t stream) {
+    if (!project_in || !dwconv || !project_out || !w_in || !w_dw || !w_out) return OSS_ERR_NULL;
+    return effn_round_weights(io, project_in, dwconv, project_out, w_in, w_dw, w_out, channels, hidden, reinterpret_cast<hipStream_t>(stream));
+}
+
 int oss_effn_fwd(oss_dtype io, const void *x, const float *norm_weight, const float *norm_bias, const void *w_in, const float *w_dw,
                  const void *w_out, void *out, int batch, int channels, int hidden, int height, int width, int64_t xsb, int64_t xsc,
                  int64_t osb, int64_t osc, float eps, oss_stream_t stream) {

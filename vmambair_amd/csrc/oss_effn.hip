@@ -401,7 +401,45 @@ oss_effn_fwd_kernel(EffnArgs a) {
     }
 }
 
+// The weights as the kernel above reads them, from the module's fp32 parameters, ONE launch (so that a captured inference graph can
+// redo it on every replay and never serves stale copies): w_in (2 HP, D) and w_out (D, HP) rounded to the I/O type, w_dw (2 HP, 9)
+// float, both halves' padding rows and w_out's padding columns zero.
+template <typename T>
+__global__ void __launch_bounds__(256)
+oss_effn_round_weights_kernel(const float *__restrict__ pin /*(2 h, D)*/, const float *__restrict__ pdw /*(2 h, 9)*/,
+                              const float *__restrict__ pout /*(D, h)*/, T *__restrict__ w_in, float *__restrict__ w_dw,
+                              T *__restrict__ w_out, int D, int h, int HP) {
+    const int n1 = 2 * HP * D, n2 = 2 * HP * 9, n3 = D * HP;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n1) {
+        const int r = i / D, c = i - r * D, half = r / HP, rr = r - half * HP;
+        w_in[i] = from_f32<T>(rr < h ? pin[(size_t)(half * h + rr) * D + c] : 0.f);
+    } else if (i < n1 + n2) {
+        const int k = i - n1, r = k / 9, t = k - r * 9, half = r / HP, rr = r - half * HP;
+        w_dw[k] = rr < h ? pdw[(size_t)(half * h + rr) * 9 + t] : 0.f;
+    } else if (i < n1 + n2 + n3) {
+        const int k = i - n1 - n2, r = k / HP, c = k - r * HP;
+        w_out[k] = from_f32<T>(c < h ? pout[(size_t)r * h + c] : 0.f);
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+int effn_round_weights(oss_dtype io, const float *pin, const float *pdw, const float *pout, void *w_in, float *w_dw, void *w_out, int D,
+                       int hidden, hipStream_t s) {
+    if (io != OSS_F16 && io != OSS_BF16) return OSS_ERR_SHAPE;
+    if (D < 1 || hidden < 1 || hidden > 16384 || D > 4096) return OSS_ERR_SHAPE;
+    const int HP = (hidden + 15) / 16 * 16;
+    const long total = 2L * HP * D + 2L * HP * 9 + (long)D * HP;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (io == OSS_F16)
+        hipLaunchKernelGGL(oss_effn_round_weights_kernel<f16_t>, grid, dim3(256), 0, s, pin, pdw, pout, reinterpret_cast<f16_t *>(w_in), w_dw,
+                           reinterpret_cast<f16_t *>(w_out), D, hidden, HP);
+    else
+        hipLaunchKernelGGL(oss_effn_round_weights_kernel<bf16_t>, grid, dim3(256), 0, s, pin, pdw, pout, reinterpret_cast<bf16_t *>(w_in), w_dw,
+                           reinterpret_cast<bf16_t *>(w_out), D, hidden, HP);
+    return (int)hipGetLastError();
+}
+
 static constexpr bool effn_ks_built(int ks) { return ks == 2 || ks == 3 || ks == 4 || ks == 6; }
 
 int effn_fwd_ok(oss_dtype io, int D, int hidden, int H, int W) {

@@ -81,6 +81,8 @@ int dwconv3x3(oss_dtype io, const void *x, const float *w, const float *bias, vo
 // the convolution fused with what follows it (oss_dwconv.hip): mode 0 = silu (SS2D_1), 1 = gelu gate of the EFFN
 int dwconv3x3_fused_ok(oss_dtype io, int H, int W, int nch);
 int effn_fwd_ok(oss_dtype io, int D, int hidden, int H, int W);
+int effn_round_weights(oss_dtype io, const float *pin, const float *pdw, const float *pout, void *w_in, float *w_dw, void *w_out, int D,
+                       int hidden, hipStream_t s);
 int effn_fwd(oss_dtype io, const void *x, const float *ln_w, const float *ln_b, const void *w_in, const float *w_dw, const void *w_out,
              void *out, int B, int D, int hidden, int H, int W, int64_t xsb, int64_t xsc, int64_t osb, int64_t osc, float eps,
              hipStream_t s);

@@ -91,13 +91,17 @@ def effn_round_weights(project_in: torch.Tensor, dwconv: torch.Tensor, project_o
     h = h2 // 2
     hp = (h + 15) // 16 * 16
     dev = project_in.device
-    w_in = torch.zeros((2, hp, D), dtype=dtype, device=dev)
-    w_in[:, :h] = project_in.detach().reshape(2, h, D).to(dtype)
-    w_dw = torch.zeros((2, hp, 9), dtype=torch.float32, device=dev)
-    w_dw[:, :h] = dwconv.detach().reshape(2, h, 9).float()
-    w_out = torch.zeros((D, hp), dtype=dtype, device=dev)
-    w_out[:, :h] = project_out.detach().reshape(D, h).to(dtype)
-    return w_in.reshape(2 * hp, D), w_dw.reshape(2 * hp, 9), w_out
+    _check(project_in.is_cuda and dtype in (torch.float16, torch.bfloat16) and project_out.shape[0] == D and project_out.shape[1] == h
+           and dwconv.shape[0] == h2, "effn_round_weights: project_in (2 h, D, 1, 1), dwconv (2 h, 1, 3, 3), project_out (D, h, 1, 1) on the GPU")
+    pin, pdw, pout = _f32c(project_in.reshape(h2, D)), _f32c(dwconv.reshape(h2, 9)), _f32c(project_out.reshape(D, h))
+    w_in = torch.empty((2 * hp, D), dtype=dtype, device=dev)
+    w_dw = torch.empty((2 * hp, 9), dtype=torch.float32, device=dev)
+    w_out = torch.empty((D, hp), dtype=dtype, device=dev)
+    with torch.cuda.device(dev):   # one launch (captured with the forward by an inference graph: no stale copies after an in-place update)
+        _capi.check(_capi.load().oss_effn_round_weights(_DT[dtype], pin.data_ptr(), pdw.data_ptr(), pout.data_ptr(), w_in.data_ptr(),
+                                                        w_dw.data_ptr(), w_out.data_ptr(), D, h, torch.cuda.current_stream().cuda_stream),
+                    "oss_effn_round_weights")
+    return w_in, w_dw, w_out
 
 
 def effn_fwd(x: torch.Tensor, ln_w: torch.Tensor, ln_b: Optional[torch.Tensor], w_in: torch.Tensor, w_dw: torch.Tensor,

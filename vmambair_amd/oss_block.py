@@ -93,6 +93,10 @@ class FeedForward(nn.Module):
     def _rounded(self, dtype: torch.dtype):
         """the weights as the one-launch forward reads them, once per weight version (inference: constants) -- ops.ffn.effn_round_weights"""
         wi, wd, wo = self.project_in.weight, self.dwconv.weight, self.project_out.weight
+        if wi.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a graph capture the one-launch rounding is captured too and replayed with the forward: a graph must not bake in
+            # copies that an in-place weight update (load_state_dict, an optimizer step between validations) would leave stale
+            return effn_round_weights(wi, wd, wo, dtype)
         key = (dtype, wi._version, wd._version, wo._version, wi.data_ptr(), wd.data_ptr(), wo.data_ptr())
         hit = getattr(self, "_rounded_cache", None)
         if hit is None or hit[0] != key:
