@@ -74,10 +74,12 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     float *ycs = ybuf + 2 * dc * L;  // [L]
     float *red = ycs + L;            // [kChRed]
     float *ypart = red + kChRed;     // [4][2 dc][L]: the state groups' partial sums of y
-    if (p.pool_part) {   // (uniform) the pooled descriptor from the LayerNorm forward's per-workgroup output sums
-        // NS threads per channel, each adding a contiguous run of the tiles in order, then the NS runs in order (a fixed order: reruns are
-        // bit-identical).  One thread per channel walking all tiles -- 96 of the 512 threads busy, 8 loads in flight each -- was 128
-        // dependent rounds at the 1024 tiles of an untiled 512 x 512 RealSR plane: most of that launch's 61 us (round 6)
+    // the pooled descriptor from the LayerNorm forward's per-workgroup output sums.  Few tiles (the training patches: 8 ... 32): one thread
+    // per channel adds them in order.  Many tiles (an untiled 512 x 512 RealSR plane leaves 1024): that was 96 of the 512 threads busy with
+    // 8 loads in flight each, 128 dependent rounds = most of a 61 us launch -- then NS threads per channel add contiguous runs of the
+    // tiles, and the NS runs are added in order (a fixed order either way: reruns are bit-identical).  (round 6)
+    const bool pool_runs = p.pool_part && p.n_part >= 64;   // (uniform)
+    if (pool_runs) {
         const int ns = max(1, min(8, NT / L)), per = (p.n_part + ns - 1) / ns;
         float *run = ypart;   // [ns][L] of its [4][2 dc][L]: free until the scans
         for (int idx = tid; idx < ns * L; idx += NT) {
@@ -106,8 +108,22 @@ oss_chan_fwd_kernel(oss_chan_params p) {
     }
     for (int l = tid; l < L; l += NT) {
         float pl;
-        if (p.pool_part) {
+        if (pool_runs) {
             pl = ycs[l];
+            const_cast<float *>(p.pooled)[(size_t)b * L + l] = pl;   // kept for the backward
+        } else if (p.pool_part) {
+            const float *pp = p.pool_part + (size_t)b * p.n_part * L + l;
+            float sum = 0.f;
+            int k = 0;
+            for (; k + 8 <= p.n_part; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = pp[(size_t)(k + q) * L];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += v[q];
+            }
+            for (; k < p.n_part; ++k) sum += pp[(size_t)k * L];
+            pl = sum * p.pool_scale;
             const_cast<float *>(p.pooled)[(size_t)b * L + l] = pl;   // kept for the backward
         } else {
             pl = p.pooled[(size_t)b * L + l];
