@@ -167,3 +167,15 @@ def test_a_captured_inference_graph_follows_in_place_weight_updates():
         fresh = ff(x, pre_norm=norm)
     assert not torch.equal(out, first)
     assert torch.equal(out, fresh), "the replay used the parameters as they are now"
+
+
+def test_fused_effn_under_inference_mode_with_inference_parameters():
+    """a module built under ``torch.inference_mode()`` has parameters without a version counter: the rounded copies are then made per call"""
+    torch.manual_seed(10)
+    with torch.inference_mode():
+        norm = oss_block.LayerNorm(48, "WithBias").to(DEV)
+        ff = oss_block.FeedForward(48, 2.66, False).to(DEV)
+        x = torch.randn(1, 48, 16, 24, device=DEV).to(torch.float16)
+        got = ff(x, pre_norm=norm)
+        want = reference(x, norm, ff)
+    assert_close(got, want, 2e-3, 1e-3 * float(want.abs().max()), "inference mode")

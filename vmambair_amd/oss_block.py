@@ -97,6 +97,8 @@ class FeedForward(nn.Module):
             # inside a graph capture the one-launch rounding is captured too and replayed with the forward: a graph must not bake in
             # copies that an in-place weight update (load_state_dict, an optimizer step between validations) would leave stale
             return effn_round_weights(wi, wd, wo, dtype)
+        if wi.is_inference() or wd.is_inference() or wo.is_inference():
+            return effn_round_weights(wi, wd, wo, dtype)   # (inference tensors carry no version counter: nothing to key a cache on)
         key = (dtype, wi._version, wd._version, wo._version, wi.data_ptr(), wd.data_ptr(), wo.data_ptr())
         hit = getattr(self, "_rounded_cache", None)
         if hit is None or hit[0] != key:
