@@ -192,7 +192,11 @@ __device__ __forceinline__ s16x8 load_wfrag(const float *__restrict__ w, int mro
     if constexpr (!WT && WVEC) {
         const bool kok = k0 + 8 <= K;
         const float *wp = w + mc * K + (kok ? k0 : 0);
+#ifdef OSS_EXP_HALF_W   // TIMING ONLY (wrong results): half of the weight bytes -- what 16-bit weight copies would cost to load
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = w0;
+#else
         const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#endif
         const s16x8 f = cvt8<T>(w0, w1);
         return (mok && kok) ? f : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
     } else {
@@ -202,7 +206,12 @@ __device__ __forceinline__ s16x8 load_wfrag(const float *__restrict__ w, int mro
             const int k = k0 + e;
             const bool kok = k < K;
             const int kc = kok ? k : K - 1;
+#ifdef OSS_EXP_HALF_W
+            const int kh = kc & ~1;
+            const float w1 = WT ? w[kh * M + mc] : w[mc * K + kh];
+#else
             const float w1 = WT ? w[kc * M + mc] : w[mc * K + kc];
+#endif
             wv[e] = (mok && kok) ? w1 : 0.f;
         }
         return cvt8<T>(f32x4{wv[0], wv[1], wv[2], wv[3]}, f32x4{wv[4], wv[5], wv[6], wv[7]});
@@ -503,7 +512,11 @@ oss_conv1x1_pairw_kernel(const T *__restrict__ x, const float *__restrict__ w, c
         const int mcl = min(m0 + m4, M - 4);                   // (M % 4 == 0: a chunk is inside the matrix or wholly outside)
         f32x4 q[NI];
 #pragma unroll
+#ifdef OSS_EXP_HALF_W
+        for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4 *>(w + (size_t)min(kr + 32 * (i & ~1), K - 1) * M + mcl);
+#else
         for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4 *>(w + (size_t)min(kr + 32 * i, K - 1) * M + mcl);
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int k = kr + 32 * i;
@@ -521,7 +534,11 @@ oss_conv1x1_pairw_kernel(const T *__restrict__ x, const float *__restrict__ w, c
         const float *base = w + (size_t)m0 * K;
         f32x4 q[NI];
 #pragma unroll
+#ifdef OSS_EXP_HALF_W
+        for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4 *>(base + min(4 * ((i & ~1) * 256 + tid), lim));
+#else
         for (int i = 0; i < NI; ++i) q[i] = *reinterpret_cast<const f32x4 *>(base + min(4 * (i * 256 + tid), lim));
+#endif
         int r = (4 * tid) / K, k = (4 * tid) - r * K;
         const int sr = 1024 / K, sk = 1024 - sr * K;
 #pragma unroll
