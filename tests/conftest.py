@@ -25,6 +25,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tier(n): explicit collection tier of a test or module (0 reference / oracle comparisons ... 2 equivalences "
+                                       "of two HIP paths); wins over the name / file rules below (ADVICE r5: tiers by marker, not by substring)")
     config.addinivalue_line("markers", "selfcheck: compares two configurations of this repo with each other (train-step / knob "
                                        "guards), not with the oracle or the reference's vectors; always collected LAST")
     _pin_vendor_state()
@@ -65,6 +67,9 @@ _FIRST = ("test_golden_vectors", "test_reference_grid", "test_oracle_fwd_matches
 def collection_tier(item):
     if item.get_closest_marker("selfcheck") is not None:
         return 3
+    explicit = item.get_closest_marker("tier")
+    if explicit is not None and explicit.args:
+        return int(explicit.args[0])
     fname = os.path.basename(str(item.fspath))
     name = item.originalname if getattr(item, "originalname", None) else item.name
     if any(t in name for t in _TIER2_NAMES) and not any(t in name for t in ("bit_exact", "oracle", "cpu_twin")):

@@ -10,7 +10,7 @@ from conftest import assert_close
 from vmambair_amd import ops, oss_block
 from vmambair_amd.ops import ffn as ffn_ops
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.tier(1)]   # one op against plain PyTorch fp32 (and against the chain of this repo)
 DEV = "cuda:0"
 
 
