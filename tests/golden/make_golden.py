@@ -21,6 +21,7 @@ Fixture families:
   g3_block_*.npz    OSS block (SS2D_1 / MamberBlock variants): state_dict, input, output, grads
   g4_net_*.npz      whole small UNet forward
   g3_block_*_d96 / _d384 / _cfg1 / realsr_fp16   (round 2) production widths, BASELINE config 1, fp16-exact RealSR block
+  g9_effn_*.npz     (round 6) x + ffn(norm2(x)) of the reference's MamberBlock: norm2 / ffn state dict, input, output
   g5_psnr.npz, g5_ckpt_*.pth, g5_net_psnr.npz    (round 2) the reference's calculate_psnr / tensor2img / save_network
   g6_tiles_*.npz    (round 2) RealESRGANer.pre_process/tile_process/post_process and MambaSISRModel2.test run on
                     position-coded images with a recording stand-in for the network
@@ -338,6 +339,33 @@ def make_g3c1():
 
 
 # --------------------------------------------------------------------------------------------
+# round 6: G9 -- the EFFN half of a block, x + ffn(norm2(x)), from the reference's own modules (pins csrc/oss_effn.hip, the
+# one-launch inference forward: widths it takes -- 32 / 48 / 64 / 96 channels, image widths that are multiples of 8)
+# --------------------------------------------------------------------------------------------
+def make_g9():
+    cases = (("SRGAN", "srgan_d96", 96, (1, 96, 12, 24), "WithBias"), ("SRGAN", "srgan_d48", 48, (1, 48, 9, 16), "WithBias"),
+             ("RealSR", "realsr_d48", 48, (1, 48, 16, 8), "WithBias"), ("mamber32", "mamber32_d96", 96, (1, 96, 8, 32), "WithBias"),
+             ("SRGAN", "srgan_d64_biasfree", 64, (1, 64, 12, 16), "BiasFree"), ("SRGAN", "srgan_d32", 32, (3, 32, 7, 8), "WithBias"))
+    archs = {}
+    for seed, (tree, tag, dim, shape, ln) in enumerate(cases):
+        arch = archs.get(tree) or archs.setdefault(tree, load_arch(tree))
+        torch.manual_seed(90 + seed)
+        m = arch.MamberBlock(dim=dim, num_heads=1, ffn_expansion_factor=2.66, bias=False, LayerNorm_type=ln)
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                if n_.startswith("norm2.") and n_.endswith(("body.weight", "body.bias")):
+                    p_.data = p_.data.clone() + 0.2 * torch.randn(p_.shape)
+                p_.data = _h(p_.data)
+            x = _h(torch.randn(*shape) * 1.5 + 0.2)
+            y = x + m.ffn(m.norm2(x))
+        arrays = {"x": x.half(), "y": y, "dim": np.array(dim), "ln": np.array(ln), "tree": np.array(tree)}
+        for k, v in m.state_dict().items():
+            if k.startswith(("norm2.", "ffn.")):
+                arrays["sd." + k] = v.half()
+        save(f"g9_effn_{tag}.npz", **arrays)
+
+
+# --------------------------------------------------------------------------------------------
 # round 2: G5 -- checkpoint format and PSNR (f4)
 # --------------------------------------------------------------------------------------------
 def _extract(path, names, ns, cls=None):
@@ -572,7 +600,7 @@ def make_g8(tag="full", num_blocks=(15, 1, 1, 1), refine=15, hw=64, seed=0):
 
 if __name__ == "__main__":
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g3w", "g3c1", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g3w", "g3c1", "g5", "g6", "g7", "g9"]
     if "g8" in which:       # not in the default list: ~75 min
         make_g8()
     if "g8small" in which:
@@ -587,6 +615,6 @@ if __name__ == "__main__":
         make_g3()
     if "g4" in which:
         make_g4()
-    for k, fn in (("g3w", make_g3w), ("g3c1", make_g3c1), ("g5", make_g5), ("g6", make_g6), ("g7", make_g7)):
+    for k, fn in (("g3w", make_g3w), ("g3c1", make_g3c1), ("g5", make_g5), ("g6", make_g6), ("g7", make_g7), ("g9", make_g9)):
         if k in which:
             fn()

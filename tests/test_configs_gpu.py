@@ -114,6 +114,37 @@ def test_block_16bit_autocast_within_stated_tolerance(tag, dt, record_property):
     assert ey <= ly and edx <= ldx and worst <= lg, (ey, edx, worst, wk)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=lambda v: str(v).replace("torch.", ""))
+def test_cfg1_block_inference_forward_within_the_16bit_tolerance_of_the_reference(dt, monkeypatch):
+    """(round 6) BASELINE.json configs[0] -- the reference's own CPU-runnable case: ONE OSS block, (2, 48, 48, 48) -- forward only under
+    ``no_grad`` on a 16-bit stream (as the blocks see it inside the nets under autocast).  This is the path that takes the inference-only
+    forms: the EFFN half as ONE launch (csrc/oss_effn.hip), the streaming gate, the pooled sums.  Held to the stated 16-bit output
+    tolerance against the reference's fp32 output (fp16: the fixture input is fp16-exact; bf16: + the rounding of the input itself, so
+    twice the limit) and to the launch-per-layer chain on the same input at twice the limit.  (The other G3 fixtures are 10 / 12
+    pixels wide: the one-launch form needs rows of a multiple of 8 pixels -- its own fixtures are G9, tests/test_effn_gpu.py.)"""
+    from vmambair_amd import oss_block
+    from vmambair_amd.ops import ffn as ffn_ops
+    z, m = _load("cfg1")
+    x = z["x"].float().to(DEV).to(dt)
+    s = int(z["io_stride"])
+    took = []
+    real_ok = oss_block.effn_fwd_ok
+    monkeypatch.setattr(oss_block, "effn_fwd_ok", lambda t, h: (took.append(real_ok(t, h)) or took[-1]))
+    with torch.no_grad(), torch.autocast("cuda", dtype=dt):
+        y = m(x)
+        ffn_ops.EFFN_FUSED = False
+        try:
+            y_chain = m(x)
+        finally:
+            ffn_ops.EFFN_FUSED = True
+    assert took and took[0], "the one-launch EFFN forward takes d = 48 on a 16-bit stream"
+    ey = rel_l2(y[..., ::s, ::s], z["y"])
+    ec = rel_l2(y, y_chain)
+    print(f"[inference] cfg1 {dt}: rel-L2 vs the reference {ey:.2e}, vs the chain {ec:.2e}")
+    assert ey <= LIMITS[dt][0] * (2 if dt == torch.bfloat16 else 1), ey
+    assert ec <= 2 * LIMITS[dt][0], ec
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # configs[3]: sequence lengths of the Deraining workload
 # ------------------------------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_close
+from conftest import assert_close, golden_files, load_golden
 from vmambair_amd import ops, oss_block
 from vmambair_amd.ops import ffn as ffn_ops
 
@@ -179,3 +179,38 @@ def test_fused_effn_under_inference_mode_with_inference_parameters():
         got = ff(x, pre_norm=norm)
         want = reference(x, norm, ff)
     assert_close(got, want, 2e-3, 1e-3 * float(want.abs().max()), "inference mode")
+
+
+def _g9(name, device):
+    """the reference's ``norm2`` + ``ffn`` of one G9 fixture as this repo's modules (state dict loaded strictly), input, reference output"""
+    z = load_golden(name)
+    dim, ln = int(z["dim"]), str(z["ln"])
+    norm = oss_block.LayerNorm(dim, ln)
+    ff = oss_block.FeedForward(dim, 2.66, False)
+    norm.load_state_dict({k[len("sd.norm2."):]: v.float() for k, v in z.items() if k.startswith("sd.norm2.")}, strict=True)
+    ff.load_state_dict({k[len("sd.ffn."):]: v.float() for k, v in z.items() if k.startswith("sd.ffn.")}, strict=True)
+    return norm.to(device), ff.to(device), z["x"].float(), z["y"].float()
+
+
+@pytest.mark.tier(0)
+@pytest.mark.parametrize("name", golden_files("g9_effn_"))
+def test_fused_effn_forward_against_the_reference_golden_vectors(name):
+    """G9 (tests/golden/make_golden.py: ``x + ffn(norm2(x))`` of the reference's own MamberBlock, SRGAN / RealSR / mamber32 trees, fp16-exact
+    weights and input, fp32 arithmetic): the one-launch forward on the fp16 input must land within one fp16 rounding of the result plus
+    the roundings of the three intermediates the chain also rounds -- relative L2 <= 1e-3 (the stated fp16 output tolerance of the block
+    fixtures, tests/test_configs_gpu.py), and elementwise 3e-3 of the output scale"""
+    norm, ff, x, want = _g9(name, DEV)
+    xh = x.to(DEV).half()
+    assert ffn_ops.effn_fwd_ok(xh, ff.project_out.in_channels)
+    with torch.no_grad():
+        got = ff(xh, pre_norm=norm)
+        ffn_ops.EFFN_FUSED = False
+        try:
+            chain = ff(xh, pre_norm=norm)
+        finally:
+            ffn_ops.EFFN_FUSED = True
+    rel = float((got.float().cpu() - want).norm() / want.norm())
+    relc = float((chain.float().cpu() - want).norm() / want.norm())
+    print(f"[g9] {name}: rel-L2 vs the reference: one launch {rel:.2e}, chain {relc:.2e}")
+    assert rel <= 1e-3, rel
+    assert_close(got, want, 3e-3, 3e-3 * float(want.abs().max()), "fused EFFN vs the reference's output")

@@ -86,3 +86,21 @@ def test_oracle_16bit_rounds_outputs_to_input_dtype():
     out, _ = oss_oracle.scan_fwd(ub, db_, A, Bb, Cb, D, bias, sp)
     assert out.dtype == torch.bfloat16
     assert_close(out, z["out"], 3e-2, 5e-2, "bf16 out")  # test_selective_scan.py:399-400
+
+
+@pytest.mark.parametrize("name", golden_files("g9_effn_"))
+def test_effn_half_of_the_block_matches_reference(name, oracle_cpu_kernel):
+    """G9 (round 6): ``x + ffn(norm2(x))`` of the reference's own MamberBlock (SRGAN / RealSR / mamber32 trees, WithBias and BiasFree
+    LayerNorm) against the host-side mirror of this repo on the CPU twins, fp32: the fixture the one-launch GPU forward
+    (csrc/oss_effn.hip) is held to in tests/test_effn_gpu.py is first shown to be what LayerNorm + FeedForward of this repo compute"""
+    from vmambair_amd import oss_block
+    z = load_golden(name)
+    dim, ln = int(z["dim"]), str(z["ln"])
+    norm = oss_block.LayerNorm(dim, ln)
+    ff = oss_block.FeedForward(dim, 2.66, False)
+    norm.load_state_dict({k[len("sd.norm2."):]: v.float() for k, v in z.items() if k.startswith("sd.norm2.")}, strict=True)
+    ff.load_state_dict({k[len("sd.ffn."):]: v.float() for k, v in z.items() if k.startswith("sd.ffn.")}, strict=True)
+    x = z["x"].float()
+    with torch.no_grad():
+        y = ff(x, pre_norm=norm)
+    assert_close(y, z["y"], 1e-5, 1e-5 * float(z["y"].abs().max()), "x + ffn(norm2(x))")
